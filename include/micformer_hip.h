@@ -1,0 +1,170 @@
+/*
+ * micformer_hip.h -- C-ABI of libmicformer_hip.so: hand-written HIP (gfx950 / CDNA4) kernels for the
+ * MicFormer training hot path (fxxJuses/MICFormer, MicFormer/models/MICFormer_self.py = "MS.py",
+ * MicFormer/models/STN.py, MicFormer/loss/dice.py, MicFormer/train_mmwhs_noPad.py = "train.py").
+ *
+ * The reference has NO native / FFI layer (it is pure PyTorch); the boundary
+ * this library sits behind is the nn.Module surface of MS.py.  Each entry point below replaces the
+ * ATen op sequence of the cited reference lines and is what a ctypes binding inside those modules
+ * calls.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers + sizes, no torch types; every pointer is DEVICE memory owned by the caller
+ *     (PyTorch caching allocator), 16-byte aligned; kernels never allocate, free or synchronise, so
+ *     every call is hipGraph-capturable; the stream is explicit (last argument).
+ *   - activations are fp32, channels-last: (B, D, H, W, C) contiguous, C innermost ("tokens x C").
+ *   - weights/biases are in the reference's state_dict layout (nn.Linear [N,K], Conv3d [N,C,k,k,k],
+ *     ConvTranspose3d [C,N,k,k,k]); weight/bias gradients are ACCUMULATED (atomicAdd) into the
+ *     destination, which the caller zero-fills (or which already holds .grad).
+ *   - return 0 (MICF_OK) or a negative MICF_E* code; nothing throws across the ABI; re-entrant.
+ */
+#ifndef MICFORMER_HIP_H
+#define MICFORMER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* micf_stream_t; /* hipStream_t */
+
+#define MICF_OK 0
+#define MICF_EINVAL (-1)       /* bad argument (null pointer, non-positive size, misaligned) */
+#define MICF_EUNSUPPORTED (-2) /* shape outside what the kernels implement (e.g. window > 8 tokens) */
+#define MICF_ELAUNCH (-3)      /* HIP reported a launch error */
+
+#define MICF_ABI_VERSION 1
+
+int micf_abi_version(void);
+const char* micf_strerror(int code);
+
+/* ---- LayerNorm over the last dim, eps inside rsqrt (nn.LayerNorm: MS.py:308,321,461,468,540,569,987,988).
+ * Row r of the input is [x1[r, 0:c1] | x2[r, 0:C-c1]] (x2 may be NULL with c1 == C); the two-source form
+ * replaces torch.cat([moving, fixed], -1) + norm2 (MS.py:1033-1034).  mean/rstd [rows] are saved for backward. */
+int micf_layernorm_fwd(const float* x1, const float* x2, int c1, const float* gamma, const float* beta, float* y,
+                       float* mean, float* rstd, int64_t rows, int C, float eps, micf_stream_t stream);
+/* dx = LN'(dy) + add, where add [rows,C] is optional (NULL = 0; it may alias dx1 when c1 == C) -- this fuses the
+ * residual-branch gradient sum of a block (d(shortcut) + d(norm(x))); dgamma/dbeta are accumulated. */
+int micf_layernorm_bwd(const float* dy, const float* x1, const float* x2, int c1, const float* mean,
+                       const float* rstd, const float* gamma, float* dx1, float* dx2, float* dgamma, float* dbeta,
+                       int64_t rows, int C, const float* add, micf_stream_t stream);
+
+/* ---- nn.Linear + fused epilogue (q/kv/proj MS.py:188-201,246-259; Mlp MS.py:28-34; concat_back_dim MS.py:1027-1030).
+ *   lin = [a1 | a2] @ W^T + bias        a1 [M,k1], a2 [M,K-k1] (NULL when k1 == K), W [N,K]
+ *   if pre_act != NULL: pre_act = lin   (saved for GELU backward)
+ *   act: 0 none, 1 exact-erf GELU
+ *   y = resid ? resid + s[row / rows_per_sample] * act(lin) : act(lin)    (s = DropPath scale per sample, NULL = 1)
+ * The residual form fuses `shortcut + drop_path(x)` (MS.py:419,424,517,522). */
+int micf_linear_fwd(const float* a1, const float* a2, int k1, const float* w, const float* bias, const float* resid,
+                    const float* dp_scale, int64_t rows_per_sample, float* y, float* pre_act, int64_t M, int N, int K,
+                    int act, micf_stream_t stream);
+/* d[a1|a2] (=|+=) (s * dy) @ W, optionally multiplied element-wise by GELU'(pre_act[M,K]) (fc2 -> fc1 seam). */
+int micf_linear_bwd_data(const float* dy, const float* dp_scale, int64_t rows_per_sample, const float* w,
+                         const float* pre_act, float* da1, float* da2, int k1, int accumulate, int64_t M, int N, int K,
+                         micf_stream_t stream);
+/* dW += (s*dy)^T @ A, dbias += colsum(s*dy);  A = [a1|a2], or GELU(a1) when a_gelu != 0 (a1 = saved pre-activation). */
+int micf_linear_bwd_weight(const float* dy, const float* dp_scale, int64_t rows_per_sample, const float* a1,
+                           const float* a2, int k1, int a_gelu, float* dw, float* dbias, int64_t M, int N, int K,
+                           micf_stream_t stream);
+
+/* ---- (Cross)WindowAttention3D core on channels-last token grids, windows by index math (never materialised):
+ * softmax((q*scale) k^T) v per head and per non-overlapping (wd,wh,ww) window (MS.py:193-200, 251-258;
+ * window_partition/reverse MS.py:37-50,117-132).  q [T,ldq], k/v [T,ldkv] (k = kv, v = kv + C), o [T,ldo].
+ * D,H,W must be multiples of the window (the host pads, MS.py:345-350); window tokens <= 8. */
+int micf_window_attn_fwd(const float* q, int ldq, const float* k, const float* v, int ldkv, float* o, int ldo, int B,
+                         int D, int H, int W, int C, int heads, int wd, int wh, int ww, float scale,
+                         micf_stream_t stream);
+int micf_window_attn_bwd(const float* q, int ldq, const float* k, const float* v, int ldkv, const float* d_o, int ldo,
+                         float* dq, int lddq, float* dk, float* dv, int lddkv, int B, int D, int H, int W, int C,
+                         int heads, int wd, int wh, int ww, float scale, micf_stream_t stream);
+
+/* ---- 3x3x3, stride 1, zero-pad 1 convolution as implicit GEMM over channels-last sources.
+ * Input channels are [x1 (c1) | x2 (c2)] (x2 may be NULL): conv_offset.0 on cat[LN(x), xa] (MS.py:314,354-356)
+ * and Head.out_conv (MS.py:1046,1053).  w [N, c1+c2, 3,3,3].  y_layout 0: channels-last [T,N]; 1: NCDHW. */
+int micf_conv3_fwd(const float* x1, int c1, const float* x2, int c2, const float* w, const float* bias, float* y,
+                   int y_layout, int B, int D, int H, int W, int N, micf_stream_t stream);
+int micf_conv3_bwd_data(const float* dy, int dy_layout, const float* w, float* dx1, int c1, int acc1, float* dx2,
+                        int c2, int acc2, int B, int D, int H, int W, int N, micf_stream_t stream);
+int micf_conv3_bwd_weight(const float* dy, int dy_layout, const float* x1, int c1, const float* x2, int c2, float* dw,
+                          float* dbias, int B, int D, int H, int W, int N, micf_stream_t stream);
+
+/* ---- deformable re-sampling of the key/value modality (MS.py:313-318 tail, 326-337, 360-384; STN.py:9-32):
+ *   off = W1 @ GELU(LN16(h))           h [T,16] = conv_offset.0 output, W1 [3,16] (no bias)
+ *   flow = off + ref,  ref = ((i+.5)/Hk*2-1, (j+.5)/Wk*2-1, (k+.5)/Dk*2-1)   (divisors permuted as in MS.py:333-335)
+ *   coord_ax = ((2*((idx+flow)/(S-1) - .5) + 1) * S - 1) / 2                   (STN.py:24 + grid_sample align_corners=False)
+ *   xs = trilinear gather of xa at coord, zero padding; non-finite coords (S == 1) give 0.
+ * flow [T,3] is saved for backward. */
+int micf_offset_sample_fwd(const float* h, const float* ln_g, const float* ln_b, const float* w1, const float* xa,
+                           float* flow, float* xs, int B, int D, int H, int W, int C, float eps, micf_stream_t stream);
+/* dxa += (atomic scatter), dh [T,16] written, dln_g/dln_b/dw1 accumulated. */
+int micf_offset_sample_bwd(const float* dxs, const float* h, const float* ln_g, const float* ln_b, const float* w1,
+                           const float* xa, const float* flow, float* dxa, float* dh, float* dln_g, float* dln_b,
+                           float* dw1, int B, int D, int H, int W, int C, float eps, micf_stream_t stream);
+
+/* Standalone SpatialTransformer.forward (STN.py:9-32) on channels-last src [B,D,H,W,C] with a given flow [T,3]
+ * (voxel displacement, z,y,x): out [T,C].  Backward: dsrc += (atomic scatter, caller zero-fills), dflow [T,3] written. */
+int micf_stn_fwd(const float* src, const float* flow, float* out, int B, int D, int H, int W, int C,
+                 micf_stream_t stream);
+int micf_stn_bwd(const float* dout, const float* src, const float* flow, float* dsrc, float* dflow, int B, int D,
+                 int H, int W, int C, micf_stream_t stream);
+
+/* ---- stride == kernel convolutions = per-patch GEMMs with index math.
+ * patch_embed: Conv3d(1->E, k=s=p) on modality `mod` of vol [B,nmod,D,H,W], right-padded with zeros to a multiple
+ * of p (PatchEmbed3D.forward MS.py:860-878); y [B,D',H',W',E] channels-last. */
+int micf_patch_embed_fwd(const float* vol, int nmod, int mod, const float* w, const float* bias, float* y, int B,
+                         int D, int H, int W, int E, int p, micf_stream_t stream);
+int micf_patch_embed_bwd_weight(const float* dy, const float* vol, int nmod, int mod, float* dw, float* dbias, int B,
+                                int D, int H, int W, int E, int p, micf_stream_t stream);
+/* conv_down: Conv3d(C->N, k=s=2) on channels-last x [B,D,H,W,C], odd dims zero-padded (PatchMerging MS.py:548-557). */
+int micf_conv_down_fwd(const float* x, const float* w, const float* bias, float* y, int B, int D, int H, int W, int C,
+                       int N, micf_stream_t stream);
+int micf_conv_down_bwd_data(const float* dy, const float* w, float* dx, int B, int D, int H, int W, int C, int N,
+                            micf_stream_t stream);
+int micf_conv_down_bwd_weight(const float* dy, const float* x, float* dw, float* dbias, int B, int D, int H, int W,
+                              int C, int N, micf_stream_t stream);
+/* conv_up: ConvTranspose3d(C->N, k=s in {2,4}) on channels-last x [B,D,H,W,C] -> y [B,kD,kH,kW,N] channels-last
+ * (PatchExpand MS.py:575-577; reverse_patch_embedding MS.py:990,1037). */
+int micf_conv_up_fwd(const float* x, const float* w, const float* bias, float* y, int B, int D, int H, int W, int C,
+                     int N, int k, micf_stream_t stream);
+int micf_conv_up_bwd_data(const float* dy, const float* w, float* dx, int B, int D, int H, int W, int C, int N, int k,
+                          micf_stream_t stream);
+int micf_conv_up_bwd_weight(const float* dy, const float* x, float* dw, float* dbias, int B, int D, int H, int W,
+                            int C, int N, int k, micf_stream_t stream);
+
+/* ---- zero-pad / crop of channels-last volumes (F.pad to window multiples MS.py:349-350,483; crop MS.py:399-400,497-498) */
+int micf_pad3d(const float* src, float* dst, int B, int D, int H, int W, int Dp, int Hp, int Wp, int C,
+               micf_stream_t stream);
+int micf_crop3d(const float* src, float* dst, int B, int D, int H, int W, int Dp, int Hp, int Wp, int C,
+                int accumulate, micf_stream_t stream);
+/* F.interpolate(mode='trilinear', align_corners=True) on channels-last volumes (MS.py:1018-1025) and its adjoint. */
+int micf_resize_trilinear_fwd(const float* src, float* dst, int B, int D, int H, int W, int Do, int Ho, int Wo, int C,
+                              micf_stream_t stream);
+int micf_resize_trilinear_bwd(const float* ddst, float* dsrc, int B, int D, int H, int W, int Do, int Ho, int Wo,
+                              int C, micf_stream_t stream);
+
+/* ---- MDiceLoss (dice.py:130-166): sigmoid-Dice (squared denominator, smooth 1, batch-joint sums) + per-channel
+ * BCE on the sigmoid output, (0.7*sum dice + 0.3*sum bce)/K.  logits/target [B,K,V] (NCDHW).
+ * sums [K*4] doubles {sum p t, sum p^2, sum t^2, sum bce} is scratch that the call zero-fills; loss [1]. */
+int micf_dice_bce_fwd(const float* logits, const float* target, double* sums, float* loss, int B, int K, int64_t V,
+                      micf_stream_t stream);
+int micf_dice_bce_bwd(const float* logits, const float* target, const double* sums, const float* grad_out,
+                      float* dlogits, int B, int K, int64_t V, micf_stream_t stream);
+/* meandice of argmax masks (train.py:392-407, :305): classes 1..K-1, smooth 1e-6, batch-joint.
+ * counts [3*K] int64 scratch (zero-filled by the call); label is the integer class map [B,V] (uint8); out [1] double. */
+int micf_argmax_meandice(const float* logits, const uint8_t* label, uint8_t* mask_out, int64_t* counts, double* out,
+                         int B, int K, int64_t V, micf_stream_t stream);
+
+/* ---- torch.optim.Adam(lr, betas, eps, weight_decay=0) over a flat fp32 buffer + CosineAnnealingLR stepped per
+ * iteration (train.py:114,148,206-207).  state = {int64 step; double lr} on the device so a captured graph advances:
+ * micf_adam_tick increments step and recomputes lr = eta_min + (base-eta_min)*(1+cos(pi*(step-1)/t_max))/2,
+ * micf_adam_step applies the update with bias corrections for `step`. */
+int micf_adam_tick(void* state, double base_lr, double eta_min, int64_t t_max, micf_stream_t stream);
+int micf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const void* state, float beta1,
+                   float beta2, float eps, micf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MICFORMER_HIP_H */

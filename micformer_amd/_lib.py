@@ -1,0 +1,106 @@
+"""ctypes binding of libmicformer_hip.so (the C-ABI declared in include/micformer_hip.h).
+
+There is NO fallback: if the library is missing or a symbol cannot be resolved the import raises, and every op
+raises on non-CUDA tensors -- the product path is the HIP path or nothing.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmicformer_hip.so")
+
+_P, _I, _L, _F, _D = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double
+_T = {"p": _P, "i": _I, "l": _L, "f": _F, "d": _D}
+
+# name -> argument signature (p pointer, i int, l int64, f float, d double); every function returns int
+# except micf_strerror.  Mirrors include/micformer_hip.h one to one (tests/test_abi.py checks the header).
+SIGNATURES = {
+    "micf_layernorm_fwd": "ppippppplifp",
+    "micf_layernorm_bwd": "pppippppppplipp",
+    "micf_linear_fwd": "ppipppplppliiip",
+    "micf_linear_bwd_data": "pplppppiiliip",
+    "micf_linear_bwd_weight": "pplppiippliip",
+    "micf_window_attn_fwd": "pippipiiiiiiiiiifp",
+    "micf_window_attn_bwd": "pippipipippiiiiiiiiiifp",
+    "micf_conv3_fwd": "pipipppiiiiiip",
+    "micf_conv3_bwd_data": "pippiipiiiiiiip",
+    "micf_conv3_bwd_weight": "pipipippiiiiip",
+    "micf_offset_sample_fwd": "pppppppiiiiifp",
+    "micf_offset_sample_bwd": "ppppppppppppiiiiifp",
+    "micf_stn_fwd": "pppiiiiip",
+    "micf_stn_bwd": "pppppiiiiip",
+    "micf_patch_embed_fwd": "piipppiiiiiip",
+    "micf_patch_embed_bwd_weight": "ppiippiiiiiip",
+    "micf_conv_down_fwd": "ppppiiiiiip",
+    "micf_conv_down_bwd_data": "pppiiiiiip",
+    "micf_conv_down_bwd_weight": "ppppiiiiiip",
+    "micf_conv_up_fwd": "ppppiiiiiiip",
+    "micf_conv_up_bwd_data": "pppiiiiiiip",
+    "micf_conv_up_bwd_weight": "ppppiiiiiiip",
+    "micf_pad3d": "ppiiiiiiiip",
+    "micf_crop3d": "ppiiiiiiiiip",
+    "micf_resize_trilinear_fwd": "ppiiiiiiiip",
+    "micf_resize_trilinear_bwd": "ppiiiiiiiip",
+    "micf_dice_bce_fwd": "ppppiilp",
+    "micf_dice_bce_bwd": "pppppiilp",
+    "micf_argmax_meandice": "pppppiilp",
+    "micf_adam_tick": "pddlp",
+    "micf_adam_step": "pppplpfffp",
+}
+
+
+class MicfError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -m micformer_amd.build` (hipcc, gfx950). "
+            "micformer_amd has no CPU / PyTorch fallback path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, sig in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing: fail loudly
+        fn.argtypes = [_T[c] for c in sig]
+        fn.restype = _I
+    lib.micf_strerror.argtypes = [_I]
+    lib.micf_strerror.restype = ctypes.c_char_p
+    lib.micf_abi_version.argtypes = []
+    lib.micf_abi_version.restype = _I
+    if lib.micf_abi_version() != 1:
+        raise ImportError("libmicformer_hip.so ABI version mismatch")
+    return lib
+
+
+lib = _load()
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32 (or given dtype) CUDA tensor; None -> NULL."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise MicfError("micformer_amd ops need CUDA (ROCm) tensors: there is no CPU path")
+    if not t.is_contiguous():
+        raise MicfError("micformer_amd ops need contiguous tensors")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    rc = getattr(lib, name)(*args, stream())
+    if rc != 0:
+        raise MicfError(f"{name} failed: {lib.micf_strerror(rc).decode()} (code {rc})")
+
+
+def f32(t):
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        raise MicfError(f"expected float32 tensor, got {t.dtype}")
+    return ptr(t)

@@ -1,0 +1,103 @@
+// misc.hip -- ABI bookkeeping + the layout helpers of the block wrappers: zero-pad / crop to window multiples
+// (F.pad MS.py:349-350, 483; crop MS.py:399-400, 497-498) and the trilinear align_corners=True resize of the decoder's
+// odd-size branch (F.interpolate MS.py:1018-1025) with its adjoint.
+#include "common.h"
+
+namespace micf {
+
+__global__ void __launch_bounds__(256) pad3d_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int D, int H,
+                                                    int W, int Dp, int Hp, int Wp, int C, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int64_t t = i / C; const int c = (int)(i - t * C);
+    const int w = (int)(t % Wp); t /= Wp; const int h = (int)(t % Hp); t /= Hp; const int d = (int)(t % Dp); const int b = (int)(t / Dp);
+    dst[i] = (d < D && h < H && w < W) ? src[((((int64_t)b * D + d) * H + h) * W + w) * C + c] : 0.f;
+  }
+}
+__global__ void __launch_bounds__(256) crop3d_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int D, int H,
+                                                     int W, int Dp, int Hp, int Wp, int C, int accumulate, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int64_t t = i / C; const int c = (int)(i - t * C);
+    const int w = (int)(t % W); t /= W; const int h = (int)(t % H); t /= H; const int d = (int)(t % D); const int b = (int)(t / D);
+    const float v = src[((((int64_t)b * Dp + d) * Hp + h) * Wp + w) * C + c];
+    dst[i] = accumulate ? dst[i] + v : v;
+  }
+}
+
+// align_corners=True: src = dst * (S_in - 1) / (S_out - 1)   (0 when S_out == 1)
+__device__ __forceinline__ void ac_coord(int o, int Sin, int Sout, int& i0, int& i1, float& f) {
+  const float scale = Sout > 1 ? (float)(Sin - 1) / (float)(Sout - 1) : 0.f;
+  const float s = scale * (float)o;
+  i0 = (int)s; if (i0 > Sin - 1) i0 = Sin - 1;
+  i1 = i0 + (i0 < Sin - 1 ? 1 : 0);
+  f = s - (float)i0;
+}
+template <bool BWD>
+__global__ void __launch_bounds__(256) resize_kernel(const float* __restrict__ a, float* __restrict__ o, int B, int D, int H, int W,
+                                                     int Do, int Ho, int Wo, int C, int64_t total) {
+  // FWD: a = src [B,D,H,W,C], o = dst [B,Do,Ho,Wo,C];   BWD: a = d(dst), o = d(src) (atomic scatter, pre-zeroed)
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int64_t t = i / C; const int c = (int)(i - t * C);
+    const int w = (int)(t % Wo); t /= Wo; const int h = (int)(t % Ho); t /= Ho; const int d = (int)(t % Do); const int b = (int)(t / Do);
+    int d0, d1, h0, h1, w0, w1; float fd, fh, fw;
+    ac_coord(d, D, Do, d0, d1, fd); ac_coord(h, H, Ho, h0, h1, fh); ac_coord(w, W, Wo, w0, w1, fw);
+    float acc = 0.f;
+    const float gv = BWD ? a[i] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int dd = (q & 4) ? d1 : d0, hh = (q & 2) ? h1 : h0, ww = (q & 1) ? w1 : w0;
+      const float wt = ((q & 4) ? fd : 1.f - fd) * ((q & 2) ? fh : 1.f - fh) * ((q & 1) ? fw : 1.f - fw);
+      const int64_t s = ((((int64_t)b * D + dd) * H + hh) * W + ww) * C + c;
+      if (BWD) atomicAdd(o + s, wt * gv); else acc += wt * a[s];
+    }
+    if (!BWD) o[i] = acc;
+  }
+}
+
+}  // namespace micf
+using namespace micf;
+
+extern "C" int micf_abi_version(void) { return MICF_ABI_VERSION; }
+
+extern "C" const char* micf_strerror(int code) {
+  switch (code) {
+    case MICF_OK: return "ok";
+    case MICF_EINVAL: return "invalid argument (null pointer, bad size or misaligned buffer)";
+    case MICF_EUNSUPPORTED: return "shape not supported by the HIP kernels";
+    case MICF_ELAUNCH: return "HIP kernel launch failed";
+    default: return "unknown micf error code";
+  }
+}
+
+static int grid_for(int64_t total) { int64_t b = (total + 255) / 256; return (int)(b > 16384 ? 16384 : (b < 1 ? 1 : b)); }
+
+extern "C" int micf_pad3d(const float* src, float* dst, int B, int D, int H, int W, int Dp, int Hp, int Wp, int C,
+                          micf_stream_t stream) {
+  if (!src || !dst || B <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || Dp < D || Hp < H || Wp < W) return MICF_EINVAL;
+  const int64_t total = (int64_t)B * Dp * Hp * Wp * C;
+  hipLaunchKernelGGL(pad3d_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst, B, D, H, W, Dp, Hp, Wp, C, total);
+  MICF_RETURN_LAUNCH();
+}
+extern "C" int micf_crop3d(const float* src, float* dst, int B, int D, int H, int W, int Dp, int Hp, int Wp, int C, int accumulate,
+                           micf_stream_t stream) {
+  if (!src || !dst || B <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || Dp < D || Hp < H || Wp < W) return MICF_EINVAL;
+  const int64_t total = (int64_t)B * D * H * W * C;
+  hipLaunchKernelGGL(crop3d_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst, B, D, H, W, Dp, Hp, Wp, C,
+                     accumulate, total);
+  MICF_RETURN_LAUNCH();
+}
+extern "C" int micf_resize_trilinear_fwd(const float* src, float* dst, int B, int D, int H, int W, int Do, int Ho, int Wo, int C,
+                                         micf_stream_t stream) {
+  if (!src || !dst || B <= 0 || D <= 0 || H <= 0 || W <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0 || C <= 0) return MICF_EINVAL;
+  const int64_t total = (int64_t)B * Do * Ho * Wo * C;
+  hipLaunchKernelGGL(resize_kernel<false>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst, B, D, H, W, Do, Ho, Wo, C, total);
+  MICF_RETURN_LAUNCH();
+}
+extern "C" int micf_resize_trilinear_bwd(const float* ddst, float* dsrc, int B, int D, int H, int W, int Do, int Ho, int Wo, int C,
+                                         micf_stream_t stream) {
+  if (!ddst || !dsrc || B <= 0 || D <= 0 || H <= 0 || W <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0 || C <= 0) return MICF_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(dsrc, 0, sizeof(float) * (size_t)B * D * H * W * C, s) != hipSuccess) return MICF_ELAUNCH;
+  const int64_t total = (int64_t)B * Do * Ho * Wo * C;
+  hipLaunchKernelGGL(resize_kernel<true>, dim3(grid_for(total)), dim3(256), 0, s, ddst, dsrc, B, D, H, W, Do, Ho, Wo, C, total);
+  MICF_RETURN_LAUNCH();
+}

@@ -1,0 +1,291 @@
+// offset_sample.hip -- the deformable re-sampling tail of CrossTransformerBlock3D.forward_part1, fused per token:
+//   LayerNormProxy(16) -> GELU -> Conv3d(16->3, k1, no bias)          (MS.py:263-273, 315-317)
+//   + _get_ref_points (divisors permuted exactly as MS.py:333-335)       (MS.py:326-337, 360-364)
+//   + SpatialTransformer: idx + flow -> 2*(new/(S-1) - .5) -> grid_sample(trilinear, zeros, align_corners=False)
+//                                                                         (STN.py:9-32, MS.py:379)
+// One 64-lane wave per token: the 16-wide offset head is computed redundantly in each 16-lane group, then the lanes
+// stride over the C channels of the 8 tap rows (each a contiguous channels-last token row: coalesced).
+// Backward scatters d(xa) with atomics (taps of neighbouring tokens collide), reduces d(flow) across the wave, and
+// runs the 16-wide head backwards, accumulating the tiny parameter gradients per wave before one atomic flush.
+#include "common.h"
+
+namespace micf {
+
+constexpr int kHid = 16;
+constexpr int kTokPerWave = 8;
+
+__device__ __forceinline__ float sum16(float v) {   // all-reduce inside each 16-lane group
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+struct Taps {
+  float cz, cy, cx;        // continuous source index per axis
+  float z0, y0, x0;        // floor
+  bool finite;
+};
+
+__device__ __forceinline__ float src_coord(int idx, float flow, int S) {
+  const float nw = (float)idx + flow;                       // STN.py:20
+  const float n = 2.f * (nw / (float)(S - 1) - 0.5f);       // STN.py:24   (S == 1: division by zero, kept)
+  return ((n + 1.f) * (float)S - 1.f) / 2.f;                // grid_sample un-normalise, align_corners=False
+}
+
+__device__ __forceinline__ Taps make_taps(int d, int h, int w, const float* flow, int D, int H, int W) {
+  Taps t;
+  t.cz = src_coord(d, flow[0], D);
+  t.cy = src_coord(h, flow[1], H);
+  t.cx = src_coord(w, flow[2], W);
+  t.finite = isfinite(t.cz) && isfinite(t.cy) && isfinite(t.cx);
+  t.z0 = floorf(t.cz); t.y0 = floorf(t.cy); t.x0 = floorf(t.cx);
+  return t;
+}
+
+// corner (dz,dy,dx): validity + linear token offset inside the sample + weight parts
+__device__ __forceinline__ bool corner(const Taps& t, int dz, int dy, int dx, int D, int H, int W, int& lin) {
+  const float z = t.z0 + dz, y = t.y0 + dy, x = t.x0 + dx;
+  if (!(z >= 0.f && z <= (float)(D - 1) && y >= 0.f && y <= (float)(H - 1) && x >= 0.f && x <= (float)(W - 1))) return false;
+  lin = ((int)z * H + (int)y) * W + (int)x;
+  return true;
+}
+
+// 16-wide head: every lane k = lane & 15 holds channel k; returns off[3] (same in all lanes), fills per-lane pieces
+__device__ __forceinline__ void head_fwd(const float* hrow, const float* ln_g, const float* ln_b, const float* w1, float eps,
+                                         int k, float& xh, float& rs, float& ln, float& gl, float off[3]) {
+  const float hv = hrow[k];
+  const float mu = sum16(hv) * (1.f / kHid);
+  const float dv = hv - mu;
+  rs = 1.0f / sqrtf(sum16(dv * dv) * (1.f / kHid) + eps);
+  xh = dv * rs;
+  ln = xh * ln_g[k] + ln_b[k];
+  gl = gelu_f(ln);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) off[a] = sum16(w1[a * kHid + k] * gl);
+}
+
+__global__ void __launch_bounds__(256) offset_sample_fwd_kernel(const float* __restrict__ h, const float* __restrict__ ln_g,
+                                                                const float* __restrict__ ln_b, const float* __restrict__ w1,
+                                                                const float* __restrict__ xa, float* __restrict__ flow_out,
+                                                                float* __restrict__ xs, Geo g, int C, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, k = lane & 15;
+  const int64_t T = g.tokens();
+  for (int it = 0; it < kTokPerWave; ++it) {
+    const int64_t t = ((int64_t)blockIdx.x * 4 + wave) * kTokPerWave + it;
+    if (t >= T) return;
+    float xh, rs, ln, gl, off[3];
+    head_fwd(h + t * kHid, ln_g, ln_b, w1, eps, k, xh, rs, ln, gl, off);
+    int b, d, hh, w; g.decode((int)t, b, d, hh, w);
+    float fl[3];
+    fl[0] = off[0] + (((float)d + 0.5f) / (float)g.H * 2.f - 1.f);      // MS.py:335  ref[...,0] /= H_key
+    fl[1] = off[1] + (((float)hh + 0.5f) / (float)g.W * 2.f - 1.f);     // MS.py:334  ref[...,1] /= W_key
+    fl[2] = off[2] + (((float)w + 0.5f) / (float)g.D * 2.f - 1.f);      // MS.py:333  ref[...,2] /= D_key
+    if (lane < 3) flow_out[t * 3 + lane] = fl[lane];
+    const Taps tp = make_taps(d, hh, w, fl, g.D, g.H, g.W);
+    const float* base = xa + (int64_t)b * g.D * g.H * g.W * C;
+    int lin[8]; float wgt[8]; bool ok[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int dz = q >> 2, dy = (q >> 1) & 1, dx = q & 1;
+      ok[q] = tp.finite && corner(tp, dz, dy, dx, g.D, g.H, g.W, lin[q]);
+      const float wx = dx ? tp.cx - tp.x0 : (tp.x0 + 1.f) - tp.cx;
+      const float wy = dy ? tp.cy - tp.y0 : (tp.y0 + 1.f) - tp.cy;
+      const float wz = dz ? tp.cz - tp.z0 : (tp.z0 + 1.f) - tp.cz;
+      wgt[q] = wx * wy * wz;
+    }
+    for (int c = lane; c < C; c += 64) {
+      float acc = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (ok[q]) acc += base[(int64_t)lin[q] * C + c] * wgt[q];
+      xs[t * C + c] = acc;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) offset_sample_bwd_kernel(
+    const float* __restrict__ dxs, const float* __restrict__ h, const float* __restrict__ ln_g, const float* __restrict__ ln_b,
+    const float* __restrict__ w1, const float* __restrict__ xa, const float* __restrict__ flow, float* __restrict__ dxa,
+    float* __restrict__ dh, float* __restrict__ dln_g, float* __restrict__ dln_b, float* __restrict__ dw1, Geo g, int C, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, k = lane & 15;
+  const int64_t T = g.tokens();
+  float acc_w[3] = {0.f, 0.f, 0.f}, acc_g = 0.f, acc_b = 0.f;       // per-lane (channel k) partials, lanes 0..15 flush
+  for (int it = 0; it < kTokPerWave; ++it) {
+    const int64_t t = ((int64_t)blockIdx.x * 4 + wave) * kTokPerWave + it;
+    if (t >= T) break;
+    float xh, rs, ln, gl, off[3];
+    head_fwd(h + t * kHid, ln_g, ln_b, w1, eps, k, xh, rs, ln, gl, off);
+    int b, d, hh, w; g.decode((int)t, b, d, hh, w);
+    const float fl[3] = {flow[t * 3 + 0], flow[t * 3 + 1], flow[t * 3 + 2]};
+    const Taps tp = make_taps(d, hh, w, fl, g.D, g.H, g.W);
+    const int64_t boff = (int64_t)b * g.D * g.H * g.W * C;
+    int lin[8]; bool ok[8]; float wx[8], wy[8], wz[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int dz = q >> 2, dy = (q >> 1) & 1, dx = q & 1;
+      ok[q] = tp.finite && corner(tp, dz, dy, dx, g.D, g.H, g.W, lin[q]);
+      wx[q] = dx ? tp.cx - tp.x0 : (tp.x0 + 1.f) - tp.cx;
+      wy[q] = dy ? tp.cy - tp.y0 : (tp.y0 + 1.f) - tp.cy;
+      wz[q] = dz ? tp.cz - tp.z0 : (tp.z0 + 1.f) - tp.cz;
+    }
+    float gz = 0.f, gy = 0.f, gx = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      const float go = dxs[t * C + c];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        if (!ok[q]) continue;
+        const int dz = q >> 2, dy = (q >> 1) & 1, dx = q & 1;
+        const int64_t a = boff + (int64_t)lin[q] * C + c;
+        atomicAdd(dxa + a, wx[q] * wy[q] * wz[q] * go);
+        const float val = xa[a] * go;
+        gx += (dx ? val : -val) * wy[q] * wz[q];
+        gy += (dy ? val : -val) * wx[q] * wz[q];
+        gz += (dz ? val : -val) * wx[q] * wy[q];
+      }
+    }
+    gz = wave_sum(gz); gy = wave_sum(gy); gx = wave_sum(gx);
+    // grid_sample: d/dn = d/dcoord * S/2 ; STN.py:24: d/dnew = 2 * d/dn / (S-1)      (S == 1 -> 0/0 = NaN, as the reference)
+    float go3[3];
+    go3[0] = (2.f * ((float)g.D / 2.f * gz)) / (float)(g.D - 1);
+    go3[1] = (2.f * ((float)g.H / 2.f * gy)) / (float)(g.H - 1);
+    go3[2] = (2.f * ((float)g.W / 2.f * gx)) / (float)(g.W - 1);
+    // 16-wide head backward (lane k)
+    float dgl = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { acc_w[a] += go3[a] * gl; dgl += w1[a * kHid + k] * go3[a]; }
+    const float dln = dgl * gelu_grad_f(ln);
+    acc_g += dln * xh;
+    acc_b += dln;
+    const float gd = ln_g[k] * dln;
+    const float ma = sum16(gd) * (1.f / kHid);
+    const float mb = sum16(gd * xh) * (1.f / kHid);
+    if (lane < kHid) dh[t * kHid + k] = rs * (gd - ma - xh * mb);
+  }
+  if (lane < kHid) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) atomicAdd(dw1 + a * kHid + k, acc_w[a]);
+    atomicAdd(dln_g + k, acc_g);
+    atomicAdd(dln_b + k, acc_b);
+  }
+}
+
+
+// ---- standalone SpatialTransformer (STN.py:9-32) on channels-last src with a GIVEN flow [T,3] (voxel units, z,y,x)
+__global__ void __launch_bounds__(256) stn_fwd_kernel(const float* __restrict__ src, const float* __restrict__ flow,
+                                                      float* __restrict__ out, Geo g, int C) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t t = (int64_t)blockIdx.x * 4 + wave;
+  if (t >= g.tokens()) return;
+  int b, d, hh, w; g.decode((int)t, b, d, hh, w);
+  const float fl[3] = {flow[t * 3 + 0], flow[t * 3 + 1], flow[t * 3 + 2]};
+  const Taps tp = make_taps(d, hh, w, fl, g.D, g.H, g.W);
+  const float* base = src + (int64_t)b * g.D * g.H * g.W * C;
+  int lin[8]; float wgt[8]; bool ok[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int dz = q >> 2, dy = (q >> 1) & 1, dx = q & 1;
+    ok[q] = tp.finite && corner(tp, dz, dy, dx, g.D, g.H, g.W, lin[q]);
+    const float wx = dx ? tp.cx - tp.x0 : (tp.x0 + 1.f) - tp.cx;
+    const float wy = dy ? tp.cy - tp.y0 : (tp.y0 + 1.f) - tp.cy;
+    const float wz = dz ? tp.cz - tp.z0 : (tp.z0 + 1.f) - tp.cz;
+    wgt[q] = wx * wy * wz;
+  }
+  for (int c = lane; c < C; c += 64) {
+    float acc = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (ok[q]) acc += base[(int64_t)lin[q] * C + c] * wgt[q];
+    out[t * C + c] = acc;
+  }
+}
+
+__global__ void __launch_bounds__(256) stn_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ src,
+                                                      const float* __restrict__ flow, float* __restrict__ dsrc,
+                                                      float* __restrict__ dflow, Geo g, int C) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t t = (int64_t)blockIdx.x * 4 + wave;
+  if (t >= g.tokens()) return;
+  int b, d, hh, w; g.decode((int)t, b, d, hh, w);
+  const float fl[3] = {flow[t * 3 + 0], flow[t * 3 + 1], flow[t * 3 + 2]};
+  const Taps tp = make_taps(d, hh, w, fl, g.D, g.H, g.W);
+  const int64_t boff = (int64_t)b * g.D * g.H * g.W * C;
+  int lin[8]; bool ok[8]; float wx[8], wy[8], wz[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int dz = q >> 2, dy = (q >> 1) & 1, dx = q & 1;
+    ok[q] = tp.finite && corner(tp, dz, dy, dx, g.D, g.H, g.W, lin[q]);
+    wx[q] = dx ? tp.cx - tp.x0 : (tp.x0 + 1.f) - tp.cx;
+    wy[q] = dy ? tp.cy - tp.y0 : (tp.y0 + 1.f) - tp.cy;
+    wz[q] = dz ? tp.cz - tp.z0 : (tp.z0 + 1.f) - tp.cz;
+  }
+  float gz = 0.f, gy = 0.f, gx = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float go = dout[t * C + c];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      if (!ok[q]) continue;
+      const int dz = q >> 2, dy = (q >> 1) & 1, dx = q & 1;
+      const int64_t a = boff + (int64_t)lin[q] * C + c;
+      if (dsrc) atomicAdd(dsrc + a, wx[q] * wy[q] * wz[q] * go);
+      const float val = src[a] * go;
+      gx += (dx ? val : -val) * wy[q] * wz[q];
+      gy += (dy ? val : -val) * wx[q] * wz[q];
+      gz += (dz ? val : -val) * wx[q] * wy[q];
+    }
+  }
+  gz = wave_sum(gz); gy = wave_sum(gy); gx = wave_sum(gx);
+  if (dflow && lane == 0) {
+    dflow[t * 3 + 0] = (2.f * ((float)g.D / 2.f * gz)) / (float)(g.D - 1);
+    dflow[t * 3 + 1] = (2.f * ((float)g.H / 2.f * gy)) / (float)(g.H - 1);
+    dflow[t * 3 + 2] = (2.f * ((float)g.W / 2.f * gx)) / (float)(g.W - 1);
+  }
+}
+
+}  // namespace micf
+using namespace micf;
+
+extern "C" int micf_offset_sample_fwd(const float* h, const float* ln_g, const float* ln_b, const float* w1,
+                                      const float* xa, float* flow, float* xs, int B, int D, int H, int W, int C,
+                                      float eps, micf_stream_t stream) {
+  if (!h || !ln_g || !ln_b || !w1 || !xa || !flow || !xs || B <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0) return MICF_EINVAL;
+  const Geo g{B, D, H, W};
+  if (g.tokens() >= (1LL << 31)) return MICF_EUNSUPPORTED;
+  const int blocks = ceil_div(g.tokens(), 4 * kTokPerWave);
+  hipLaunchKernelGGL(offset_sample_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, h, ln_g, ln_b, w1, xa, flow,
+                     xs, g, C, eps);
+  MICF_RETURN_LAUNCH();
+}
+
+extern "C" int micf_offset_sample_bwd(const float* dxs, const float* h, const float* ln_g, const float* ln_b,
+                                      const float* w1, const float* xa, const float* flow, float* dxa, float* dh,
+                                      float* dln_g, float* dln_b, float* dw1, int B, int D, int H, int W, int C, float eps,
+                                      micf_stream_t stream) {
+  if (!dxs || !h || !ln_g || !ln_b || !w1 || !xa || !flow || !dxa || !dh || !dln_g || !dln_b || !dw1 || B <= 0 || D <= 0 ||
+      H <= 0 || W <= 0 || C <= 0)
+    return MICF_EINVAL;
+  const Geo g{B, D, H, W};
+  if (g.tokens() >= (1LL << 31)) return MICF_EUNSUPPORTED;
+  const int blocks = ceil_div(g.tokens(), 4 * kTokPerWave);
+  hipLaunchKernelGGL(offset_sample_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dxs, h, ln_g, ln_b, w1, xa,
+                     flow, dxa, dh, dln_g, dln_b, dw1, g, C, eps);
+  MICF_RETURN_LAUNCH();
+}
+
+extern "C" int micf_stn_fwd(const float* src, const float* flow, float* out, int B, int D, int H, int W, int C,
+                            micf_stream_t stream) {
+  if (!src || !flow || !out || B <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0) return MICF_EINVAL;
+  const Geo g{B, D, H, W};
+  if (g.tokens() >= (1LL << 31)) return MICF_EUNSUPPORTED;
+  hipLaunchKernelGGL(stn_fwd_kernel, dim3(ceil_div(g.tokens(), 4)), dim3(256), 0, (hipStream_t)stream, src, flow, out, g, C);
+  MICF_RETURN_LAUNCH();
+}
+
+extern "C" int micf_stn_bwd(const float* dout, const float* src, const float* flow, float* dsrc, float* dflow, int B, int D,
+                            int H, int W, int C, micf_stream_t stream) {
+  if (!dout || !src || !flow || (!dsrc && !dflow) || B <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0) return MICF_EINVAL;
+  const Geo g{B, D, H, W};
+  if (g.tokens() >= (1LL << 31)) return MICF_EUNSUPPORTED;
+  hipLaunchKernelGGL(stn_bwd_kernel, dim3(ceil_div(g.tokens(), 4)), dim3(256), 0, (hipStream_t)stream, dout, src, flow, dsrc,
+                     dflow, g, C);
+  MICF_RETURN_LAUNCH();
+}

@@ -1,0 +1,133 @@
+"""Training-step engine for the MicFormer hot path on MI355X.
+
+One step == the reference's loop body (train_mmwhs_noPad.py:183-207):
+    optimizer.zero_grad(); segs = model(x); loss = MDiceLoss(segs, labels); loss.backward();
+    Adam(lr=1e-4, wd=0).step(); CosineAnnealingLR.step()
+with MI355X-first plumbing around the HIP kernels:
+  * all parameters live in ONE flat fp32 HBM buffer (and their gradients / Adam moments in three more), so zero_grad
+    is one memset, Adam is one fused streaming kernel and the data-parallel gradient exchange is one RCCL all-reduce
+    over xGMI; `state_dict()` keys/shapes are untouched (the nn.Parameters become views);
+  * the LR schedule and Adam's step counter live on the device (micf_adam_tick), so the whole step -- forward,
+    loss, backward, Adam -- can be captured once into a HIP graph and replayed without host work;
+  * data parallelism: one process per GPU, whole CT+MR pairs sharded across ranks, per-rank loss (the Dice sums are
+    per-rank batches -- the accepted DDP semantics), gradient all-reduce(sum)/world, rank-identical weights.
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .loss.dice import MDiceLoss
+
+
+class TrainEngine:
+    def __init__(self, model, base_lr=1e-4, t_max=150, eta_min=0.0, betas=(0.9, 0.999), eps=1e-8, criterion=None,
+                 use_graph=False, process_group=None, grad_bucket_bytes=64 << 20):
+        self.model = model
+        self.criterion = criterion if criterion is not None else MDiceLoss()
+        self.base_lr, self.t_max, self.eta_min = base_lr, t_max, eta_min
+        self.betas, self.eps = betas, eps
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (process_group is not None or dist.is_initialized()) else 1
+        if self.world > 1 and process_group is None:
+            self.pg = dist.group.WORLD
+        self.bucket_elems = max(int(grad_bucket_bytes) // 4, 1)
+        self._flatten()
+        if self.world > 1:
+            dist.broadcast(self.flat_p, src=0, group=self.pg)      # rank-identical initial weights
+        self.use_graph = use_graph
+        self._graph = None
+        self._static = None
+        self.steps_done = 0
+
+    # ------------------------------------------------------------------ flat parameter / gradient storage
+    def _flatten(self):
+        params = [p for p in self.model.parameters()]
+        dev = params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("TrainEngine needs the model on a CUDA (ROCm) device")
+        sizes = [p.numel() for p in params]
+        # 4-element (16 B) alignment of every tensor so kernels can use 16-byte accesses on parameter views
+        offs, total = [], 0
+        for n in sizes:
+            offs.append(total)
+            total += (n + 3) // 4 * 4
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, o, n in zip(params, offs, sizes):
+                self.flat_p[o:o + n].copy_(p.reshape(-1))
+                p.data = self.flat_p[o:o + n].view(p.shape)
+                p.grad = self.flat_g[o:o + n].view(p.shape)
+        self.params, self.offsets, self.sizes = params, offs, sizes
+        self.adam_state = ops.adam_state(dev)
+
+    # ------------------------------------------------------------------ one optimisation step
+    def _fwd_bwd(self, x, target):
+        self.flat_g.zero_()                                         # optimizer.zero_grad()        train.py:183
+        logits = self.model(x)                                      #                              train.py:185
+        loss = self.criterion(logits, target)                       #                              train.py:187
+        loss.backward()                                             #                              train.py:200
+        return loss.detach()
+
+    def _update(self):
+        if self.world > 1:
+            self._allreduce_grads()
+        ops.adam_tick(self.adam_state, self.base_lr, self.eta_min, self.t_max)   # scheduler (per iteration) train.py:206-207
+        ops.adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.adam_state,
+                      self.betas[0], self.betas[1], self.eps)       # optimizer.step()             train.py:201
+
+    def _step_impl(self, x, target):
+        loss = self._fwd_bwd(x, target)
+        self._update()
+        return loss
+
+    def _allreduce_grads(self):
+        """Gradient all-reduce(sum)/world over RCCL/xGMI in a few large buckets of the flat buffer."""
+        n = self.flat_g.numel()
+        works = []
+        for s in range(0, n, self.bucket_elems):
+            works.append(dist.all_reduce(self.flat_g[s:s + self.bucket_elems], op=dist.ReduceOp.SUM, group=self.pg,
+                                         async_op=True))
+        for w in works:
+            w.wait()
+        self.flat_g.div_(self.world)
+
+    def step(self, x, target):
+        """Run one training step; returns the (device) loss of this rank's batch."""
+        if not self.use_graph:
+            loss = self._step_impl(x, target)
+        else:
+            if self._graph is None:
+                self._capture(x, target)
+            self._static[0].copy_(x, non_blocking=True)
+            self._static[1].copy_(target, non_blocking=True)
+            self._graph.replay()
+            if self.world > 1:
+                self._update()                                      # RCCL all-reduce + Adam stay outside the graph
+            loss = self._static[2]
+        self.steps_done += 1
+        return loss
+
+    def _capture(self, x, target):
+        """Warm up eagerly on a side stream (3 real steps), then capture ONE step into a HIP graph."""
+        sx, st = x.clone(), target.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                self._step_impl(sx, st)
+                self.steps_done += 1
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            # single GPU: the whole step; data parallel: forward+backward only (the collective is issued eagerly)
+            sl = self._step_impl(sx, st) if self.world == 1 else self._fwd_bwd(sx, st)
+        self._graph, self._static = g, (sx, st, sl)
+
+    # ------------------------------------------------------------------ helpers
+    def lr(self):
+        st = self.adam_state.cpu()
+        return float(st[1:2].view(torch.float64)[0])

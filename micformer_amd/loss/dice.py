@@ -1,0 +1,49 @@
+"""MDiceLoss / MDiceLoss_Val of the reference's MicFormer/loss/dice.py on fused HIP reductions.
+
+MDiceLoss.forward (dice.py:158-166): per class channel, sigmoid-Dice with squared denominator and smooth 1 (sums over
+batch AND space) plus BCE on the sigmoid output, (0.7*sum dice + 0.3*sum bce)/K -- one streaming pass forward, one
+element-wise pass backward.
+"""
+import torch
+import torch.nn as nn
+
+from .. import functional as Fn
+from .. import ops
+
+
+class MDiceLoss(nn.Module):
+    def __init__(self, do_sigmoid=True):
+        super().__init__()
+        if not do_sigmoid:
+            raise NotImplementedError("HIP MDiceLoss implements do_sigmoid=True (reference default)")
+        self.do_sigmoid = do_sigmoid
+        self.labels = ['backgroud', 'CT-A', 'CT-B', 'CT-C', 'CT-D', 'CT-E', 'CT-F', 'CT-G']
+
+    def forward(self, inputs, target):
+        return Fn.DiceBCEFn.apply(inputs.float(), target.float())
+
+    def metric(self, inputs, target):
+        """Thresholded-sigmoid per-class Dice per sample (dice.py:168-175, binary_dice metric_mode)."""
+        p = inputs > 0            # sigmoid(z) > 0.5
+        out = []
+        for j in range(target.size(0)):
+            row = []
+            for i in range(target.size(1)):
+                t = target[j, i]
+                if t.sum() == 0:
+                    row.append(torch.tensor(1. if p[j, i].sum() == 0 else 0., device=inputs.device))
+                else:
+                    row.append((2 * (p[j, i] * t).sum()) / ((p[j, i].sum() + t.sum()) * 1.0))
+            out.append(row)
+        return out
+
+
+class MDiceLoss_Val(MDiceLoss):
+    """Validation loss = the Dice part only (dice.py:216-221); computed from the same fused sums."""
+
+    def forward(self, inputs, target):
+        inputs, target = inputs.float().contiguous(), target.float().contiguous()
+        _, sums = ops.dice_bce_fwd(inputs, target)
+        s = sums.reshape(-1, 4)
+        dice = 1.0 - (2.0 * s[:, 0] + 1.0) / (s[:, 1] + s[:, 2] + 1.0)
+        return (dice.sum() / s.shape[0]).float()

@@ -1,0 +1,505 @@
+"""MI355X-native MicFormer: the nn.Module surface of the reference's ``MicFormer/models/MICFormer_self.py`` (MS.py)
+with every forward/backward executed by hand-written HIP kernels through the C-ABI of libmicformer_hip.so.
+
+Drop-in contract:
+  * same importable names, constructor signatures and ``state_dict`` keys/shapes as MS.py, so reference checkpoints
+    load with ``strict=True`` and ``train_mmwhs_noPad.py`` can ``from models.MICFormer_self import Head`` unchanged;
+  * ``Head(...)(x)`` takes float32 ``(B, 2, D, H, W)`` (ch0 = CT "moving", ch1 = MR "fixed") and returns logits
+    ``(B, num_classes, D', H', W')``, differentiable w.r.t. every parameter;
+  * ``torch.nn`` layers are used ONLY as parameter containers (their ATen forwards are never called); there is no
+    CPU / PyTorch fallback -- CPU tensors raise.
+
+Extra keyword-only constructor arguments (``depths``, ``num_heads``, ``drop_path_rate``) expose what the reference
+hard-codes, so BASELINE's "tiny" config can be built.
+"""
+from functools import reduce
+from operator import mul
+
+import torch
+import torch.nn as nn
+
+from .. import functional as Fn
+from .STN import Re_SpatialTransformer, SpatialTransformer
+
+__all__ = ["Head", "MicFormer", "BasicLayer", "BasicLayerUp", "CrossTransformerBlock3D", "TransformerBlock3D",
+           "CrossWindowAttention3D", "WindowAttention3D", "PatchEmbed3D", "PatchMerging", "PatchExpand", "Mlp",
+           "LayerNormProxy", "DropPath", "window_partition", "window_reverse", "get_window_size"]
+
+
+# ----------------------------------------------------------------------------- layout helpers (views only)
+def window_partition(x, window_size):
+    """(B, D, H, W, C) -> (B*nW, wd*wh*ww, C); same contract as MS.py:37-50.  Not used by the kernels (index math)."""
+    B, D, H, W, C = x.shape
+    wd, wh, ww = window_size
+    x = x.reshape(B, D // wd, wd, H // wh, wh, W // ww, ww, C)
+    return x.permute(0, 1, 3, 5, 2, 4, 6, 7).reshape(-1, reduce(mul, window_size), C)
+
+
+def window_reverse(windows, window_size, B, D, H, W):
+    """Inverse of window_partition; same contract as MS.py:117-132."""
+    wd, wh, ww = window_size
+    x = windows.reshape(B, D // wd, H // wh, W // ww, wd, wh, ww, -1)
+    return x.permute(0, 1, 4, 2, 5, 3, 6, 7).reshape(B, D, H, W, -1)
+
+
+def get_window_size(x_size, window_size, shift_size=None):
+    """MS.py:135-145: clamp each window dim to the volume dim when the volume is not larger."""
+    return Fn.effective_window(tuple(x_size), tuple(window_size))
+
+
+class DropPath(nn.Module):
+    """Stochastic depth per sample (timm.models.layers.DropPath semantics, scale_by_keep=True; MS.py:5,320,467).
+
+    The kernels take the per-sample scale (mask / keep_prob) as a [B] device vector and fuse it into the residual
+    epilogue, so this module only draws that vector.
+    """
+
+    def __init__(self, drop_prob=0.0, scale_by_keep=True):
+        super().__init__()
+        self.drop_prob = float(drop_prob)
+        self.scale_by_keep = scale_by_keep
+
+    def sample_scale(self, batch, device):
+        if self.drop_prob == 0.0 or not self.training:
+            return None
+        keep = 1.0 - self.drop_prob
+        s = torch.empty(batch, dtype=torch.float32, device=device).bernoulli_(keep)
+        if keep > 0.0 and self.scale_by_keep:
+            s.div_(keep)
+        return s
+
+    def forward(self, x):
+        s = self.sample_scale(x.shape[0], x.device)
+        return x if s is None else x * s.reshape((-1,) + (1,) * (x.dim() - 1))
+
+    def extra_repr(self):
+        return f"drop_prob={self.drop_prob:0.3f}"
+
+
+class _NoDrop(nn.Identity):
+    def sample_scale(self, batch, device):
+        return None
+
+
+def _drop_path(rate):
+    return DropPath(rate) if rate > 0.0 else _NoDrop()
+
+
+# ----------------------------------------------------------------------------- small modules
+class _MlpFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        from .. import ops
+        x = x.contiguous()
+        xf = x.reshape(-1, x.shape[-1])
+        g, h = ops.linear_fwd(xf, w1, b1, act=1, want_pre=True)
+        y = ops.linear_fwd(g, w2, b2)
+        ctx.save_for_backward(xf, h, w1, w2)
+        return y.reshape(x.shape[:-1] + (w2.shape[0],))
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .. import ops
+        xf, h, w1, w2 = ctx.saved_tensors
+        dy2 = dy.contiguous().reshape(-1, w2.shape[0])
+        dw1, dw2 = torch.zeros_like(w1), torch.zeros_like(w2)
+        db1 = torch.zeros(w1.shape[0], device=w1.device)
+        db2 = torch.zeros(w2.shape[0], device=w2.device)
+        ops.linear_bwd_weight(dy2, h, dw2, db2, a_gelu=True)
+        dh = ops.linear_bwd_data(dy2, w2, pre_act=h)
+        ops.linear_bwd_weight(dh, xf, dw1, db1)
+        dx = ops.linear_bwd_data(dh, w1)
+        return dx.reshape(dy.shape[:-1] + (w1.shape[1],)), dw1, db1, dw2, db2
+
+
+class Mlp(nn.Module):
+    """fc1 -> exact GELU -> fc2 (MS.py:16-34); dropout p must be 0 (it is everywhere in the reference)."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        if act_layer is not nn.GELU or drop != 0.:
+            raise NotImplementedError("HIP Mlp implements exact-erf GELU with dropout 0 (the reference's configuration)")
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.drop = nn.Dropout(drop)
+
+    def forward(self, x):
+        return _MlpFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
+
+
+class _WindowAttnFn(torch.autograd.Function):
+    """Attention over EXPLICIT windows (nW, N, C) x (nW, N, C): the standalone module contract of MS.py:179-203."""
+
+    @staticmethod
+    def forward(ctx, xq, xkv, heads, wq, bq, wkv, bkv, wp, bp):
+        from .. import ops
+        nW, N, C = xq.shape
+        if xkv.shape[1] != N or N > 8:
+            raise NotImplementedError("HIP window attention: query/key windows of equal size <= 8 tokens")
+        xqf, xkf = xq.contiguous().reshape(-1, C), xkv.contiguous().reshape(-1, C)
+        scale = (C // heads) ** -0.5
+        dims, ws = (nW, 1, 1, N), (1, 1, N)
+        q = ops.linear_fwd(xqf, wq, bq)
+        kv = ops.linear_fwd(xkf, wkv, bkv)
+        o = ops.window_attn_fwd(q, kv, dims, heads, ws, scale)
+        y = ops.linear_fwd(o, wp, bp)
+        ctx.save_for_backward(xqf, xkf, q, kv, o, wq, wkv, wp)
+        ctx.meta = (dims, ws, heads, scale, bq is not None, xq.shape)
+        return y.reshape(nW, N, C)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .. import ops
+        xqf, xkf, q, kv, o, wq, wkv, wp = ctx.saved_tensors
+        dims, ws, heads, scale, qkv_bias, shape = ctx.meta
+        C = wq.shape[0]
+        dyf = dy.contiguous().reshape(-1, C)
+        dwq, dwkv, dwp = torch.zeros_like(wq), torch.zeros_like(wkv), torch.zeros_like(wp)
+        dbq = torch.zeros(C, device=wq.device) if qkv_bias else None
+        dbkv = torch.zeros(2 * C, device=wq.device) if qkv_bias else None
+        dbp = torch.zeros(C, device=wq.device)
+        ops.linear_bwd_weight(dyf, o, dwp, dbp)
+        do = ops.linear_bwd_data(dyf, wp)
+        dq, dkv = ops.window_attn_bwd(q, kv, do, dims, heads, ws, scale)
+        ops.linear_bwd_weight(dq, xqf, dwq, dbq)
+        ops.linear_bwd_weight(dkv, xkf, dwkv, dbkv)
+        dxq = ops.linear_bwd_data(dq, wq)
+        dxk = ops.linear_bwd_data(dkv, wkv)
+        return dxq.reshape(shape), dxk.reshape(shape), None, dwq, dbq, dwkv, dbkv, dwp, dbp
+
+
+class _WindowAttentionBase(nn.Module):
+    def __init__(self, dim, window_size, num_heads, qkv_bias=False, qk_scale=None, attn_drop=0., proj_drop=0.):
+        super().__init__()
+        if attn_drop != 0. or proj_drop != 0.:
+            raise NotImplementedError("HIP window attention implements dropout 0 (the reference's configuration)")
+        if dim % num_heads != 0:
+            raise ValueError("dim must be a multiple of num_heads")
+        self.dim = dim
+        self.window_size = window_size
+        self.num_heads = num_heads
+        head_dim = dim // num_heads
+        if qk_scale is not None and abs(qk_scale - head_dim ** -0.5) > 1e-12:
+            raise NotImplementedError("qk_scale override is not implemented")
+        self.scale = head_dim ** -0.5
+        self.q = nn.Linear(dim, dim, bias=qkv_bias)
+        self.kv = nn.Linear(dim, dim * 2, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+        self.softmax = nn.Softmax(dim=-1)
+
+    def _run(self, x, xa):
+        return _WindowAttnFn.apply(x, xa, self.num_heads, self.q.weight, self.q.bias, self.kv.weight, self.kv.bias,
+                                   self.proj.weight, self.proj.bias)
+
+
+class CrossWindowAttention3D(_WindowAttentionBase):
+    """Q from x windows, K/V from xa windows (MS.py:148-203)."""
+
+    def forward(self, x, xa):
+        return self._run(x, xa)
+
+
+class WindowAttention3D(_WindowAttentionBase):
+    """Plain window MSA, no mask / bias table / shift (MS.py:206-261)."""
+
+    def forward(self, x):
+        return self._run(x, x)
+
+
+class LayerNormProxy(nn.Module):
+    """LayerNorm over the channel dim of a channels-first tensor (MS.py:263-273)."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.norm = nn.LayerNorm(dim)
+        self.dim = dim
+
+    def forward(self, x):
+        y = Fn.LayerNormFn.apply(x.permute(0, 2, 3, 4, 1), None, self.norm.weight, self.norm.bias, self.norm.eps)
+        return y.permute(0, 4, 1, 2, 3)
+
+
+def _block_params(block, keys):
+    sd = dict(block.named_parameters())
+    return [sd[k] for k in keys]
+
+
+class CrossTransformerBlock3D(nn.Module):
+    """x <- x + DropPath(CrossAttn(LN(x), deformably re-sampled RAW xa)); x <- x + DropPath(MLP(LN(x)))  (MS.py:277-426)."""
+
+    def __init__(self, dim, num_heads, window_size=(4, 4, 4), hidden_channels=16, kk=3, offset_range_factor=2,
+                 mlp_ratio=4., qkv_bias=True, qk_scale=None, drop=0., attn_drop=0., drop_path=0.,
+                 act_layer=nn.GELU, norm_layer=nn.LayerNorm, use_checkpoint=False):
+        super().__init__()
+        if hidden_channels != 16 or kk != 3 or offset_range_factor < 0 or not qkv_bias or norm_layer is not nn.LayerNorm:
+            raise NotImplementedError("HIP cross block implements the reference configuration: hidden 16, 3x3x3 offset "
+                                      "conv, offset_range_factor >= 0 (no tanh), qkv_bias=True, nn.LayerNorm")
+        self.dim = dim
+        self.num_heads = num_heads
+        self.window_size = tuple(window_size)
+        self.mlp_ratio = mlp_ratio
+        self.use_checkpoint = use_checkpoint
+        self.hidden_channels = hidden_channels
+        self.kk = kk
+        self.offset_range_factor = offset_range_factor
+        self.norm1 = norm_layer(dim)
+        self.cross_attn = CrossWindowAttention3D(dim, window_size=self.window_size, num_heads=num_heads,
+                                                 qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=drop)
+        self.conv_offset = nn.Sequential(
+            nn.Conv3d(dim * 2, hidden_channels, kk, 1, kk // 2),
+            LayerNormProxy(hidden_channels),
+            nn.GELU(),
+            nn.Conv3d(hidden_channels, 3, 1, 1, 0, bias=False))
+        self.drop_path = _drop_path(drop_path)
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+        self.stn = SpatialTransformer()
+
+    def forward(self, x, xa):
+        B = x.shape[0]
+        s1 = self.drop_path.sample_scale(B, x.device)
+        s2 = self.drop_path.sample_scale(B, x.device)
+        return Fn.CrossBlockFn.apply(x, xa, s1, s2, self.num_heads, self.window_size, self.norm1.eps,
+                                     *_block_params(self, Fn.CROSS_KEYS))
+
+
+class TransformerBlock3D(nn.Module):
+    """x <- x + DropPath(WindowMSA(LN(x))); x <- x + DropPath(MLP(LN(x)))  (MS.py:430-524).  No shift, no mask."""
+
+    def __init__(self, dim, num_heads, window_size=(4, 4, 4), hidden_channels=16, kk=3, offset_range_factor=2,
+                 mlp_ratio=4., qkv_bias=True, qk_scale=None, drop=0., attn_drop=0., drop_path=0.,
+                 act_layer=nn.GELU, norm_layer=nn.LayerNorm, use_checkpoint=False):
+        super().__init__()
+        if not qkv_bias or norm_layer is not nn.LayerNorm:
+            raise NotImplementedError("HIP self block implements qkv_bias=True with nn.LayerNorm (reference configuration)")
+        self.dim = dim
+        self.num_heads = num_heads
+        self.window_size = tuple(window_size)
+        self.mlp_ratio = mlp_ratio
+        self.use_checkpoint = use_checkpoint
+        self.hidden_channels = hidden_channels
+        self.kk = kk
+        self.offset_range_factor = offset_range_factor
+        self.norm1 = norm_layer(dim)
+        self.self_attn = WindowAttention3D(dim, window_size=self.window_size, num_heads=num_heads, qkv_bias=qkv_bias,
+                                           qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=drop)
+        self.drop_path = _drop_path(drop_path)
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+
+    def forward(self, x):
+        B = x.shape[0]
+        s1 = self.drop_path.sample_scale(B, x.device)
+        s2 = self.drop_path.sample_scale(B, x.device)
+        return Fn.SelfBlockFn.apply(x, s1, s2, self.num_heads, self.window_size, self.norm1.eps,
+                                    *_block_params(self, Fn.SELF_KEYS))
+
+
+class PatchMerging(nn.Module):
+    """Conv3d(C->2C, k=s=2) + LN on channels-last tokens (MS.py:527-561)."""
+
+    def __init__(self, dim, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.dim = dim
+        self.down_conv = nn.Conv3d(dim, 2 * dim, (2, 2, 2), stride=2, padding=0)
+        self.norm = norm_layer(2 * dim)
+
+    def forward(self, x):
+        y = Fn.ConvDownFn.apply(x, self.down_conv.weight, self.down_conv.bias)
+        return Fn.LayerNormFn.apply(y, None, self.norm.weight, self.norm.bias, self.norm.eps)
+
+
+class PatchExpand(nn.Module):
+    """ConvTranspose3d(C->C/2, k=s=2) + LN on channels-last tokens (MS.py:564-579)."""
+
+    def __init__(self, dim, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.dim = dim
+        self.up_conv = nn.ConvTranspose3d(dim, dim // 2, (2, 2, 2), stride=2, padding=0)
+        self.norm = norm_layer(dim // 2)
+
+    def forward(self, x):
+        y = Fn.ConvUpFn.apply(x, self.up_conv.weight, self.up_conv.bias, 2)
+        return Fn.LayerNormFn.apply(y, None, self.norm.weight, self.norm.bias, self.norm.eps)
+
+
+class BasicLayer(nn.Module):
+    """One stage: depth x {2 self blocks (one per modality), 2 cross blocks (both read the PRE-update pair)} + optional
+    resampling module passed as `downsample` (PatchMerging in the encoder, PatchExpand in the decoder)  (MS.py:582-707)."""
+
+    _resample_attr = "downsample"
+
+    def __init__(self, dim, depth, num_heads, window_size, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop=0.,
+                 attn_drop=0., drop_path=0., norm_layer=nn.LayerNorm, downsample=None, use_checkpoint=False):
+        super().__init__()
+        self.window_size = window_size
+        self.depth = depth
+        self.use_checkpoint = use_checkpoint
+
+        def rate(i):
+            return drop_path[i] if isinstance(drop_path, list) else drop_path
+
+        def mk(cls):
+            return nn.ModuleList([cls(dim=dim, num_heads=num_heads, window_size=window_size, mlp_ratio=mlp_ratio,
+                                      qkv_bias=qkv_bias, qk_scale=qk_scale, drop=drop, attn_drop=attn_drop,
+                                      drop_path=rate(i), norm_layer=norm_layer, use_checkpoint=use_checkpoint)
+                                  for i in range(depth)])
+
+        self.blocks1 = mk(CrossTransformerBlock3D)
+        self.blocks2 = mk(CrossTransformerBlock3D)
+        self.self_blocks1 = mk(TransformerBlock3D)
+        self.self_blocks2 = mk(TransformerBlock3D)
+        resample = downsample(dim=dim, norm_layer=norm_layer) if downsample is not None else None
+        setattr(self, self._resample_attr, resample)
+
+    def forward(self, x, xa):
+        for i in range(self.depth):
+            x, xa = self.self_blocks1[i](x), self.self_blocks2[i](xa)
+            x, xa = self.blocks1[i](x, xa), self.blocks2[i](xa, x)
+        resample = getattr(self, self._resample_attr)
+        if resample is not None:
+            return x, xa, resample(x), resample(xa)
+        return x, xa, x, xa
+
+
+class BasicLayerUp(BasicLayer):
+    """Same stage with the resampling module registered as `upsample` (MS.py:710-834; never instantiated by MicFormer)."""
+
+    _resample_attr = "upsample"
+
+    def __init__(self, dim, depth, num_heads, window_size, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop=0.,
+                 attn_drop=0., drop_path=0., norm_layer=nn.LayerNorm, upsample=None, use_checkpoint=False):
+        super().__init__(dim, depth, num_heads, window_size, mlp_ratio, qkv_bias, qk_scale, drop, attn_drop, drop_path,
+                         norm_layer, upsample, use_checkpoint)
+
+
+class PatchEmbed3D(nn.Module):
+    """Conv3d(in_chans=1 -> E, k=s=patch) with right zero-padding (MS.py:837-878).  Standalone forward keeps the
+    reference's channels-first output; MicFormer uses the channels-last kernel output directly."""
+
+    def __init__(self, patch_size=(4, 4, 4), in_chans=3, embed_dim=96, norm_layer=None):
+        super().__init__()
+        patch_size = tuple(patch_size)
+        if len(set(patch_size)) != 1:
+            raise NotImplementedError("HIP patch embed implements cubic patches")
+        if in_chans != 1:
+            raise NotImplementedError("HIP patch embed implements in_chans=1 (Head splits the modalities, MS.py:1050)")
+        self.patch_size = patch_size
+        self.in_chans = in_chans
+        self.embed_dim = embed_dim
+        self.proj = nn.Conv3d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+        self.norm = norm_layer(embed_dim) if norm_layer is not None else None
+
+    def tokens(self, vol, mod):
+        """vol (B, nmod, D, H, W), modality index -> (B, D', H', W', E) channels-last (+ optional norm)."""
+        y = Fn.PatchEmbedFn.apply(vol, mod, self.proj.weight, self.proj.bias, self.patch_size[0])
+        if self.norm is not None:
+            y = Fn.LayerNormFn.apply(y, None, self.norm.weight, self.norm.bias, self.norm.eps)
+        return y
+
+    def forward(self, x):
+        return self.tokens(x, 0).permute(0, 4, 1, 2, 3)
+
+
+class MicFormer(nn.Module):
+    """4 encoder stages + 4 decoder stages (all BasicLayer) with skip concat+Linear, shared patch embed / merging across
+    the two modalities, final LN over cat[moving, fixed] and ConvTranspose3d k4 s4  (MS.py:881-1039)."""
+
+    def __init__(self, pretrained=None, pretrained2d=False, patch_size=(4, 4, 4), in_chans=1, embed_dim=64,
+                 depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24], window_size=(7, 7, 7), mlp_ratio=4., qkv_bias=True,
+                 qk_scale=None, drop_rate=0., attn_drop_rate=0., drop_path_rate=0.2, norm_layer=nn.LayerNorm,
+                 patch_norm=False, frozen_stages=-1, use_checkpoint=False):
+        super().__init__()
+        if drop_rate != 0.:
+            raise NotImplementedError("drop_rate must be 0 (reference configuration)")
+        self.pretrained = pretrained
+        self.pretrained2d = pretrained2d
+        self.num_layers = len(depths)
+        self.embed_dim = embed_dim
+        self.patch_norm = patch_norm
+        self.frozen_stages = frozen_stages
+        self.window_size = tuple(window_size)
+        self.patch_size = tuple(patch_size)
+        self.depths = list(depths)
+
+        self.patch_embed = PatchEmbed3D(patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim,
+                                        norm_layer=norm_layer if patch_norm else None)
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        dpr = [v.item() for v in torch.linspace(0, drop_path_rate, sum(depths))]      # MS.py:941
+
+        def stage(i, resample):
+            return BasicLayer(dim=int(embed_dim * 2 ** i), depth=depths[i], num_heads=num_heads[i],
+                              window_size=self.window_size, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale,
+                              drop=drop_rate, attn_drop=attn_drop_rate,
+                              drop_path=dpr[sum(depths[:i]):sum(depths[:i + 1])], norm_layer=norm_layer,
+                              downsample=resample, use_checkpoint=use_checkpoint)
+
+        self.layers = nn.ModuleList(
+            [stage(i, PatchMerging if i < self.num_layers - 1 else None) for i in range(self.num_layers)])
+        self.up_layers = nn.ModuleList()
+        self.concat_back_dim = nn.ModuleList()
+        for i in reversed(range(self.num_layers)):
+            c = int(embed_dim * 2 ** i)
+            self.up_layers.append(stage(i, PatchExpand if i > 0 else None))
+            self.concat_back_dim.append(nn.Linear(2 * c, c))          # index 0 is never used in forward (MS.py:1015-1016)
+        self.num_features = int(embed_dim * 2 ** (self.num_layers - 1))
+        self.norm = norm_layer(self.num_features)
+        self.norm2 = norm_layer(self.embed_dim * 2)
+        self.reverse_patch_embedding = nn.ConvTranspose3d(2 * embed_dim, embed_dim // 2, self.patch_size,
+                                                          stride=self.patch_size[0])
+
+    def features(self, vol_m, mod_m, vol_f, mod_f):
+        """Channels-last (B, D', H', W', E/2) feature that feeds Head.out_conv."""
+        m = self.patch_embed.tokens(vol_m, mod_m)
+        f = self.patch_embed.tokens(vol_f, mod_f)
+        skips = []
+        for layer in self.layers:
+            m_out, f_out, m, f = layer(m, f)
+            skips.append((m_out, f_out))
+        ln = self.norm
+        m = Fn.LayerNormFn.apply(m, None, ln.weight, ln.bias, ln.eps)
+        f = Fn.LayerNormFn.apply(f, None, ln.weight, ln.bias, ln.eps)
+        last = self.num_layers - 1
+        for inx, up in enumerate(self.up_layers):
+            if inx > 0:
+                sm, sf = skips[last - inx]
+                if m.shape != sm.shape:                                # odd token grids (MS.py:1018-1025)
+                    m = Fn.ResizeTrilinearFn.apply(m, tuple(sm.shape[1:4]))
+                    f = Fn.ResizeTrilinearFn.apply(f, tuple(sf.shape[1:4]))
+                lin = self.concat_back_dim[inx]
+                m = Fn.LinearFn.apply(m, sm, lin.weight, lin.bias)
+                f = Fn.LinearFn.apply(f, sf, lin.weight, lin.bias)
+            _, _, m, f = up(m, f)
+        x = Fn.LayerNormFn.apply(m, f, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        rp = self.reverse_patch_embedding
+        return Fn.ConvUpFn.apply(x, rp.weight, rp.bias, self.patch_size[0])
+
+    def forward(self, moving, fixed):
+        """(B,1,D,H,W) x 2 -> (B, E/2, D', H', W'), as the reference (a channels-first VIEW of the kernel output)."""
+        return self.features(moving, 0, fixed, 0).permute(0, 4, 1, 2, 3)
+
+
+class Head(nn.Module):
+    """Segmentation network: MicFormer + Conv3d(E/2 -> num_classes, 3, padding=1)  (MS.py:1042-1055)."""
+
+    def __init__(self, n_channels=1, embed_dim=96, num_classes=14, window_size=(2, 2, 2), *, depths=(2, 2, 6, 2),
+                 num_heads=(3, 6, 12, 24), drop_path_rate=0.2):
+        super().__init__()
+        self.swin = MicFormer(window_size=window_size, in_chans=n_channels, embed_dim=embed_dim, depths=list(depths),
+                              num_heads=list(num_heads), drop_path_rate=drop_path_rate)
+        self.out_conv = nn.Conv3d(embed_dim // 2, num_classes, 3, padding=1)
+
+    def forward(self, x):
+        if x.dim() != 5 or x.shape[1] != 2:
+            raise ValueError("Head expects (B, 2, D, H, W): torch.split(x, 1, dim=1) must give (moving, fixed)")
+        if not x.is_cuda:
+            raise RuntimeError("micformer_amd.Head runs on the MI355X HIP kernels only (no CPU path): move the model "
+                               "and the input to cuda")
+        x = x.float().contiguous()
+        feat = self.swin.features(x, 0, x, 1)
+        return Fn.OutConvFn.apply(feat, self.out_conv.weight, self.out_conv.bias)

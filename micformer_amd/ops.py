@@ -1,0 +1,300 @@
+"""Tensor-level wrappers over the C-ABI (allocate outputs with torch, pass raw pointers + sizes + the current stream).
+
+PyTorch is used here only for device memory and streams.  Every function takes contiguous fp32 CUDA tensors;
+argument order follows include/micformer_hip.h.
+"""
+import torch
+
+from ._lib import call, f32, ptr
+
+_empty = torch.empty
+
+
+def _new(like, *shape, dtype=torch.float32):
+    return _empty(shape, dtype=dtype, device=like.device)
+
+
+# ----------------------------------------------------------------------------- LayerNorm
+def layernorm_fwd(x1, gamma, beta, eps, x2=None):
+    """x1 [rows, c1] (+ x2 [rows, c2]) -> y [rows, C], mean [rows], rstd [rows]."""
+    rows, c1 = x1.shape
+    C = c1 + (x2.shape[1] if x2 is not None else 0)
+    y = _new(x1, rows, C)
+    mean = _new(x1, rows)
+    rstd = _new(x1, rows)
+    call("micf_layernorm_fwd", f32(x1), f32(x2), c1, f32(gamma), f32(beta), f32(y), f32(mean), f32(rstd), rows, C,
+         float(eps))
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x1, mean, rstd, gamma, dgamma, dbeta, x2=None, add=None):
+    """Returns dx1 (and dx2); dgamma/dbeta are accumulated in place.  dx = LN'(dy) + add."""
+    rows, c1 = x1.shape
+    C = dy.shape[1]
+    dx1 = _new(x1, rows, c1)
+    dx2 = _new(x1, rows, C - c1) if x2 is not None else None
+    call("micf_layernorm_bwd", f32(dy), f32(x1), f32(x2), c1, f32(mean), f32(rstd), f32(gamma), f32(dx1), f32(dx2),
+         f32(dgamma), f32(dbeta), rows, C, f32(add))
+    return (dx1, dx2) if x2 is not None else dx1
+
+
+# ----------------------------------------------------------------------------- Linear
+def linear_fwd(a1, w, bias, a2=None, resid=None, dp_scale=None, rows_per_sample=0, act=0, want_pre=False):
+    M, k1 = a1.shape
+    N, K = w.shape
+    assert k1 + (a2.shape[1] if a2 is not None else 0) == K
+    y = _new(a1, M, N)
+    pre = _new(a1, M, N) if want_pre else None
+    call("micf_linear_fwd", f32(a1), f32(a2), k1, f32(w), f32(bias), f32(resid), f32(dp_scale), rows_per_sample,
+         f32(y), f32(pre), M, N, K, act)
+    return (y, pre) if want_pre else y
+
+
+def linear_bwd_data(dy, w, dp_scale=None, rows_per_sample=0, pre_act=None, k1=None, out=None, accumulate=False):
+    """d[a1|a2] = (s*dy) @ W (* GELU'(pre_act)).  Returns da1 or (da1, da2) when k1 < K."""
+    M, N = dy.shape
+    K = w.shape[1]
+    k1 = K if k1 is None else k1
+    if out is not None:
+        da1, da2 = out, None
+    else:
+        da1 = _new(dy, M, k1)
+        da2 = _new(dy, M, K - k1) if k1 < K else None
+    call("micf_linear_bwd_data", f32(dy), f32(dp_scale), rows_per_sample, f32(w), f32(pre_act), f32(da1), f32(da2), k1,
+         1 if accumulate else 0, M, N, K)
+    return (da1, da2) if da2 is not None else da1
+
+
+def linear_bwd_weight(dy, a1, dw, dbias, a2=None, dp_scale=None, rows_per_sample=0, a_gelu=False):
+    """dw += (s*dy)^T [a1|a2] (or GELU(a1)); dbias += colsum(s*dy).  dw/dbias are accumulated in place."""
+    M, N = dy.shape
+    k1 = a1.shape[1]
+    K = dw.shape[1]
+    call("micf_linear_bwd_weight", f32(dy), f32(dp_scale), rows_per_sample, f32(a1), f32(a2), k1, 1 if a_gelu else 0,
+         f32(dw), f32(dbias), M, N, K)
+
+
+# ----------------------------------------------------------------------------- window attention
+def window_attn_fwd(q, kv, dims, heads, ws, scale):
+    B, D, H, W = dims
+    T, C = q.shape
+    o = _new(q, T, C)
+    call("micf_window_attn_fwd", f32(q), C, f32(kv), kv.data_ptr() + 4 * C, 2 * C, f32(o), C, B, D, H, W, C, heads,
+         ws[0], ws[1], ws[2], float(scale))
+    return o
+
+
+def window_attn_bwd(q, kv, d_o, dims, heads, ws, scale):
+    B, D, H, W = dims
+    T, C = q.shape
+    dq = _new(q, T, C)
+    dkv = _new(q, T, 2 * C)
+    call("micf_window_attn_bwd", f32(q), C, f32(kv), kv.data_ptr() + 4 * C, 2 * C, f32(d_o), C, f32(dq), C, f32(dkv),
+         dkv.data_ptr() + 4 * C, 2 * C, B, D, H, W, C, heads, ws[0], ws[1], ws[2], float(scale))
+    return dq, dkv
+
+
+# ----------------------------------------------------------------------------- conv 3x3x3
+def conv3_fwd(x1, w, bias, dims, x2=None, ncdhw_out=False):
+    B, D, H, W = dims
+    c1 = x1.shape[-1]
+    c2 = x2.shape[-1] if x2 is not None else 0
+    N = w.shape[0]
+    y = _new(x1, B, N, D, H, W) if ncdhw_out else _new(x1, B * D * H * W, N)
+    call("micf_conv3_fwd", f32(x1), c1, f32(x2), c2, f32(w), f32(bias), f32(y), 1 if ncdhw_out else 0, B, D, H, W, N)
+    return y
+
+
+def conv3_bwd_data(dy, w, dims, c1, c2=0, ncdhw=False, dx1=None, dx2=None, acc1=False, acc2=False, want1=True, want2=True):
+    B, D, H, W = dims
+    N = w.shape[0]
+    T = B * D * H * W
+    if dx1 is None and want1:
+        dx1 = _new(dy, T, c1)
+    if dx2 is None and want2 and c2 > 0:
+        dx2 = _new(dy, T, c2)
+    call("micf_conv3_bwd_data", f32(dy), 1 if ncdhw else 0, f32(w), f32(dx1), c1, 1 if acc1 else 0, f32(dx2), c2,
+         1 if acc2 else 0, B, D, H, W, N)
+    return dx1, dx2
+
+
+def conv3_bwd_weight(dy, x1, dw, dbias, dims, x2=None, ncdhw=False):
+    B, D, H, W = dims
+    c1 = x1.shape[-1]
+    c2 = x2.shape[-1] if x2 is not None else 0
+    N = dw.shape[0]
+    call("micf_conv3_bwd_weight", f32(dy), 1 if ncdhw else 0, f32(x1), c1, f32(x2), c2, f32(dw), f32(dbias), B, D, H, W, N)
+
+
+# ----------------------------------------------------------------------------- offset head + deformable sampling
+def offset_sample_fwd(h, ln_g, ln_b, w1, xa, dims, eps):
+    B, D, H, W = dims
+    T, C = xa.shape
+    flow = _new(xa, T, 3)
+    xs = _new(xa, T, C)
+    call("micf_offset_sample_fwd", f32(h), f32(ln_g), f32(ln_b), f32(w1), f32(xa), f32(flow), f32(xs), B, D, H, W, C,
+         float(eps))
+    return flow, xs
+
+
+def offset_sample_bwd(dxs, h, ln_g, ln_b, w1, xa, flow, dxa, dln_g, dln_b, dw1, dims, eps):
+    """dxa (pre-zeroed or holding a partial sum) is accumulated; returns dh [T,16]."""
+    B, D, H, W = dims
+    T, C = xa.shape
+    dh = _new(xa, T, h.shape[1])
+    call("micf_offset_sample_bwd", f32(dxs), f32(h), f32(ln_g), f32(ln_b), f32(w1), f32(xa), f32(flow), f32(dxa), f32(dh),
+         f32(dln_g), f32(dln_b), f32(dw1), B, D, H, W, C, float(eps))
+    return dh
+
+
+def stn_fwd(src, flow, dims):
+    """src [T,C] channels-last, flow [T,3] -> out [T,C]."""
+    B, D, H, W = dims
+    out = torch.empty_like(src)
+    call("micf_stn_fwd", f32(src), f32(flow), f32(out), B, D, H, W, src.shape[1])
+    return out
+
+
+def stn_bwd(dout, src, flow, dims):
+    B, D, H, W = dims
+    dsrc = torch.zeros_like(src)
+    dflow = torch.empty_like(flow)
+    call("micf_stn_bwd", f32(dout), f32(src), f32(flow), f32(dsrc), f32(dflow), B, D, H, W, src.shape[1])
+    return dsrc, dflow
+
+
+# ----------------------------------------------------------------------------- stride == kernel convs
+def patch_embed_fwd(vol, mod, w, bias, p):
+    B, nmod, D, H, W = vol.shape
+    E = w.shape[0]
+    Dc, Hc, Wc = -(-D // p), -(-H // p), -(-W // p)
+    y = _new(vol, B, Dc, Hc, Wc, E)
+    call("micf_patch_embed_fwd", f32(vol), nmod, mod, f32(w), f32(bias), f32(y), B, D, H, W, E, p)
+    return y
+
+
+def patch_embed_bwd_weight(dy, vol, mod, dw, dbias, p):
+    B, nmod, D, H, W = vol.shape
+    E = dw.shape[0]
+    call("micf_patch_embed_bwd_weight", f32(dy), f32(vol), nmod, mod, f32(dw), f32(dbias), B, D, H, W, E, p)
+
+
+def conv_down_fwd(x, w, bias):
+    B, D, H, W, C = x.shape
+    N = w.shape[0]
+    y = _new(x, B, -(-D // 2), -(-H // 2), -(-W // 2), N)
+    call("micf_conv_down_fwd", f32(x), f32(w), f32(bias), f32(y), B, D, H, W, C, N)
+    return y
+
+
+def conv_down_bwd_data(dy, w, xshape):
+    B, D, H, W, C = xshape
+    N = w.shape[0]
+    dx = _new(dy, B, D, H, W, C)
+    call("micf_conv_down_bwd_data", f32(dy), f32(w), f32(dx), B, D, H, W, C, N)
+    return dx
+
+
+def conv_down_bwd_weight(dy, x, dw, dbias):
+    B, D, H, W, C = x.shape
+    N = dw.shape[0]
+    call("micf_conv_down_bwd_weight", f32(dy), f32(x), f32(dw), f32(dbias), B, D, H, W, C, N)
+
+
+def conv_up_fwd(x, w, bias, k):
+    B, D, H, W, C = x.shape
+    N = w.shape[1]
+    y = _new(x, B, D * k, H * k, W * k, N)
+    call("micf_conv_up_fwd", f32(x), f32(w), f32(bias), f32(y), B, D, H, W, C, N, k)
+    return y
+
+
+def conv_up_bwd_data(dy, w, xshape, k):
+    B, D, H, W, C = xshape
+    N = w.shape[1]
+    dx = _new(dy, B, D, H, W, C)
+    call("micf_conv_up_bwd_data", f32(dy), f32(w), f32(dx), B, D, H, W, C, N, k)
+    return dx
+
+
+def conv_up_bwd_weight(dy, x, dw, dbias, k):
+    B, D, H, W, C = x.shape
+    N = dw.shape[1]
+    call("micf_conv_up_bwd_weight", f32(dy), f32(x), f32(dw), f32(dbias), B, D, H, W, C, N, k)
+
+
+# ----------------------------------------------------------------------------- pad / crop / resize
+def pad3d(x, dims, pdims):
+    B, D, H, W = dims
+    Dp, Hp, Wp = pdims
+    C = x.shape[-1]
+    y = _new(x, B * Dp * Hp * Wp, C)
+    call("micf_pad3d", f32(x), f32(y), B, D, H, W, Dp, Hp, Wp, C)
+    return y
+
+
+def crop3d(xp, dims, pdims, out=None, accumulate=False):
+    B, D, H, W = dims
+    Dp, Hp, Wp = pdims
+    C = xp.shape[-1]
+    y = out if out is not None else _new(xp, B * D * H * W, C)
+    call("micf_crop3d", f32(xp), f32(y), B, D, H, W, Dp, Hp, Wp, C, 1 if accumulate else 0)
+    return y
+
+
+def resize_trilinear_fwd(x, size):
+    B, D, H, W, C = x.shape
+    y = _new(x, B, size[0], size[1], size[2], C)
+    call("micf_resize_trilinear_fwd", f32(x), f32(y), B, D, H, W, size[0], size[1], size[2], C)
+    return y
+
+
+def resize_trilinear_bwd(dy, xshape):
+    B, D, H, W, C = xshape
+    dx = _new(dy, B, D, H, W, C)
+    call("micf_resize_trilinear_bwd", f32(dy), f32(dx), B, D, H, W, dy.shape[1], dy.shape[2], dy.shape[3], C)
+    return dx
+
+
+# ----------------------------------------------------------------------------- loss / metrics / optimiser
+def dice_bce_fwd(logits, target):
+    B, K = logits.shape[:2]
+    V = logits[0, 0].numel()
+    sums = _new(logits, K * 4, dtype=torch.float64)
+    loss = _new(logits, 1)
+    call("micf_dice_bce_fwd", f32(logits), f32(target), ptr(sums), f32(loss), B, K, V)
+    return loss, sums
+
+
+def dice_bce_bwd(logits, target, sums, grad_out):
+    B, K = logits.shape[:2]
+    V = logits[0, 0].numel()
+    dz = torch.empty_like(logits)
+    call("micf_dice_bce_bwd", f32(logits), f32(target), ptr(sums), f32(grad_out), f32(dz), B, K, V)
+    return dz
+
+
+def argmax_meandice(logits, label=None, want_mask=True):
+    """logits [B,K,...] fp32; label uint8 class map [B,...] or None.  Returns (mask uint8, meandice 0-d double or None)."""
+    B, K = logits.shape[:2]
+    V = logits[0, 0].numel()
+    mask = torch.empty((B,) + tuple(logits.shape[2:]), dtype=torch.uint8, device=logits.device) if want_mask else None
+    counts = torch.empty(3 * K, dtype=torch.int64, device=logits.device) if label is not None else None
+    out = torch.empty(1, dtype=torch.float64, device=logits.device) if label is not None else None
+    if label is not None and label.dtype != torch.uint8:
+        raise TypeError("label map must be uint8")
+    call("micf_argmax_meandice", f32(logits), ptr(label), ptr(mask), ptr(counts), ptr(out), B, K, V)
+    return mask, out
+
+
+def adam_state(device):
+    """{int64 step; double lr} on the device, zero-initialised (16 bytes)."""
+    return torch.zeros(2, dtype=torch.int64, device=device)
+
+
+def adam_tick(state, base_lr, eta_min, t_max):
+    call("micf_adam_tick", ptr(state), float(base_lr), float(eta_min), int(t_max))
+
+
+def adam_step(p, g, m, v, state, beta1=0.9, beta2=0.999, eps=1e-8):
+    call("micf_adam_step", f32(p), f32(g), f32(m), f32(v), p.numel(), ptr(state), float(beta1), float(beta2), float(eps))

@@ -1,0 +1,289 @@
+"""GPU parity tests, module / model level: the HIP nn.Modules (called through the C-ABI) against
+(a) golden vectors produced by the REAL reference (tests/golden, closed-form weights, no RNG) and
+(b) the CPU oracle on seeded inputs.  fp32 tolerances: 1e-4 abs on logits, identical argmax where the reference's
+top-2 margin exceeds 1e-3, Dice within 1e-3 (north_star), gradients 2e-3 relative per tensor.
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import fill  # noqa: E402
+from oracle import micformer_ref as R  # noqa: E402
+from oracle.shapes import filled_params  # noqa: E402
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def M():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import micformer_amd.models.MICFormer_self as m
+    return m
+
+
+def load(name):
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(G, name)).items()}
+
+
+def close(got, want, atol=2e-5, rtol=1e-4, what=""):
+    got = got.detach().cpu().double()
+    want = want.detach().cpu().double()
+    assert got.shape == want.shape, f"{what}: shape {tuple(got.shape)} vs {tuple(want.shape)}"
+    scale = max(float(want.abs().max()), 1e-30)
+    err = float((got - want).abs().max())
+    assert math.isfinite(err), f"{what}: non-finite error"
+    assert err <= atol + rtol * scale, f"{what}: max abs err {err:.3e} (scale {scale:.3e})"
+
+
+def fill_module(mod):
+    with torch.no_grad():
+        for name, t in mod.state_dict().items():
+            t.copy_(fill.fill_tensor(name, t))
+    return mod
+
+
+def build_head(M, E, depths, train=False):
+    h = M.Head(embed_dim=E, num_classes=8, depths=depths)
+    fill_module(h)
+    h = h.cuda()
+    return h.train() if train else h.eval()
+
+
+# ----------------------------------------------------------------------------- blocks vs reference goldens (F1)
+@pytest.mark.parametrize("tag,dims", [("c24", (2, 4, 6, 4, 24, 3)), ("c48", (1, 6, 4, 8, 48, 3)), ("pad", (1, 5, 3, 4, 24, 3))])
+def test_blocks_against_reference(M, tag, dims):
+    B, D, H, W, C, heads = dims
+    g = load(f"f1_modules_{tag}.npz")
+    x = fill.lattice((B, D, H, W, C), f"F1.{tag}.x", 0.8, 0.211).cuda().requires_grad_(True)
+    xa = fill.lattice((B, D, H, W, C), f"F1.{tag}.xa", 0.7, 0.173).cuda().requires_grad_(True)
+    gy = fill.lattice((B, D, H, W, C), f"F1.{tag}.gy", 1.0, 0.291).cuda()
+    blk = fill_module(M.TransformerBlock3D(dim=C, num_heads=heads, window_size=(2, 2, 2), qkv_bias=True)).cuda().eval()
+    y = blk(x)
+    close(y, g["self_y"], what="self_y")
+    grads = torch.autograd.grad((y * gy).sum(), [x] + list(blk.parameters()))
+    close(grads[0], g["self_gx"], rtol=3e-4, what="self_gx")
+    for (n, _), gv in zip(blk.named_parameters(), grads[1:]):
+        close(gv, g["self_g." + n], rtol=5e-4, what="self_g." + n)
+    cb = fill_module(M.CrossTransformerBlock3D(dim=C, num_heads=heads, window_size=(2, 2, 2), qkv_bias=True)).cuda().eval()
+    y = cb(x, xa)
+    close(y, g["cross_y"], what="cross_y")
+    grads = torch.autograd.grad((y * gy).sum(), [x, xa] + list(cb.parameters()))
+    close(grads[0], g["cross_gx"], rtol=3e-4, what="cross_gx")
+    close(grads[1], g["cross_gxa"], rtol=3e-4, what="cross_gxa")
+    for (n, _), gv in zip(cb.named_parameters(), grads[2:]):
+        close(gv, g["cross_g." + n], rtol=5e-4, what="cross_g." + n)
+    if tag == "pad":
+        return
+    pm = fill_module(M.PatchMerging(C)).cuda()
+    y = pm(x)
+    close(y, g["merge_y"], what="merge_y")
+    gm = fill.lattice(tuple(y.shape), f"F1.{tag}.gm", 1.0, 0.31).cuda()
+    grads = torch.autograd.grad((y * gm).sum(), [x] + list(pm.parameters()))
+    close(grads[0], g["merge_gx"], rtol=3e-4, what="merge_gx")
+    for (n, _), gv in zip(pm.named_parameters(), grads[1:]):
+        close(gv, g["merge_g." + n], rtol=5e-4, what="merge_g." + n)
+    pe = fill_module(M.PatchExpand(C)).cuda()
+    y = pe(x)
+    close(y, g["expand_y"], what="expand_y")
+    ge = fill.lattice(tuple(y.shape), f"F1.{tag}.ge", 1.0, 0.33).cuda()
+    grads = torch.autograd.grad((y * ge).sum(), [x] + list(pe.parameters()))
+    close(grads[0], g["expand_gx"], rtol=3e-4, what="expand_gx")
+    for (n, _), gv in zip(pe.named_parameters(), grads[1:]):
+        close(gv, g["expand_g." + n], rtol=5e-4, what="expand_g." + n)
+
+
+def test_odd_dims_against_reference(M):
+    g = load("f1_odd.npz")
+    x = fill.lattice((1, 5, 3, 6, 24), "F1.odd.x", 0.8, 0.211).cuda()
+    pm = fill_module(M.PatchMerging(24)).cuda()
+    close(pm(x), g["merge_y"], what="odd merge")
+    vol = fill.lattice((2, 1, 9, 8, 10), "F1.odd.vol", 0.9, 0.113).cuda()
+    pe = fill_module(M.PatchEmbed3D(patch_size=(4, 4, 4), in_chans=1, embed_dim=24)).cuda()
+    y = pe(vol)
+    close(y, g["embed_y"], what="odd embed (channels-first API)")
+    gv = fill.lattice(tuple(g["embed_y"].shape), "F1.odd.gv", 1.0, 0.3).cuda()
+    gw, gb = torch.autograd.grad((y * gv).sum(), list(pe.parameters()))
+    close(gw, g["embed_gw"], rtol=3e-4, what="embed_gw")
+    close(gb, g["embed_gb"], rtol=3e-4, what="embed_gb")
+
+
+def test_drop_path_scales_match_oracle(M):
+    """Training-mode DropPath with INJECTED per-sample scales (the only stochastic element) against the oracle."""
+    from micformer_amd import functional as Fn
+    B, D, H, W, C, heads = 3, 4, 4, 2, 24, 3
+    x, xa = torch.randn(B, D, H, W, C, generator=torch.Generator().manual_seed(1)), torch.randn(B, D, H, W, C, generator=torch.Generator().manual_seed(2))
+    s1, s2 = torch.tensor([0.0, 1.25, 1.25]), torch.tensor([1.25, 0.0, 1.25])
+    from oracle.shapes import _block
+    for cross in (False, True):
+        shp = {}
+        _block(shp, "", C, cross)
+        P = {k: fill.fill_tensor(k, torch.empty(s)) for k, s in shp.items()}
+        keys = Fn.CROSS_KEYS if cross else Fn.SELF_KEYS
+        params = [P[k].cuda().requires_grad_(True) for k in keys]
+        xr, xar = x.clone().requires_grad_(True), xa.clone().requires_grad_(True)
+        Pr = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+        xc, xac = x.cuda().requires_grad_(True), xa.cuda().requires_grad_(True)
+        if cross:
+            want = R.cross_block(xr, xar, Pr, "", heads, (2, 2, 2), s1, s2)
+            got = Fn.CrossBlockFn.apply(xc, xac, s1.cuda(), s2.cuda(), heads, (2, 2, 2), 1e-5, *params)
+        else:
+            want = R.self_block(xr, Pr, "", heads, (2, 2, 2), s1, s2)
+            got = Fn.SelfBlockFn.apply(xc, s1.cuda(), s2.cuda(), heads, (2, 2, 2), 1e-5, *params)
+        close(got, want, what="droppath fwd")
+        gw = torch.autograd.grad(want.sum(), [xr] + [Pr[k] for k in keys])
+        gg = torch.autograd.grad(got.sum(), [xc] + params)
+        for a, b, n in zip(gg, gw, ["x"] + list(keys)):
+            close(a, b, rtol=5e-4, what="droppath grad " + n)
+
+
+# ----------------------------------------------------------------------------- whole model vs reference goldens
+def test_state_dict_is_the_reference_contract(M):
+    for tag in ("base", "tiny", "large"):
+        ref = json.load(open(os.path.join(G, f"state_dict_{tag}.json")))
+        h = M.Head(embed_dim=ref["embed_dim"], num_classes=8, depths=tuple(ref["depths"]))
+        assert [[k, list(v.shape)] for k, v in h.state_dict().items()] == ref["keys"]
+
+
+def test_tiny_32_config1_against_reference(M):
+    """BASELINE config 1 (tiny, one 32^3 pair): logits, argmax mask, loss, meandice vs the reference's CPU forward."""
+    from micformer_amd import MDiceLoss, ops
+    g = load("f3_tiny32.npz")
+    h = build_head(M, 24, (1, 1, 1, 1))
+    x = fill.make_volume(1, 32, 32, 32).cuda()
+    lab = fill.make_label_map(1, 32, 32, 32)
+    with torch.no_grad():
+        logits = h(x)
+    assert logits.shape == (1, 8, 32, 32, 32) and logits.is_contiguous()
+    close(logits[:, :, ::4, ::4, ::4], g["logits_stride"], atol=1e-4, what="tiny logits (strided, fp32 fixture)")
+    close(logits, g["logits"].float(), atol=2e-3, what="tiny logits (full, fp16 fixture)")
+    mask, md = ops.argmax_meandice(logits, lab.to(torch.uint8).cuda())
+    mism = (mask.cpu().long() != g["mask"].long()).float().mean().item()
+    assert mism <= 1e-4, f"argmax mismatch fraction {mism}"
+    tgt = fill.one_hot(lab).cuda()
+    close(MDiceLoss()(logits, tgt), g["loss"], atol=1e-5, what="tiny loss")
+    assert abs(float(md.item()) - float(g["meandice"])) <= 1e-3, "Dice vs reference > 1e-3"
+
+
+def test_tiny_32_backward_matches_reference_nan_pattern(M):
+    """The reference's backward through the S == 1 stage is non-finite (0 * inf in STN.py:24); parity includes that."""
+    from micformer_amd import MDiceLoss
+    ref = json.load(open(os.path.join(G, "f3_tiny32_gradnorms.json")))
+    h = build_head(M, 24, (1, 1, 1, 1))
+    x = fill.make_volume(1, 32, 32, 32).cuda()
+    tgt = fill.one_hot(fill.make_label_map(1, 32, 32, 32)).cuda()
+    MDiceLoss()(h(x), tgt).backward()
+    bad = []
+    for n, p in h.named_parameters():
+        r = ref[n]
+        if r == "none":
+            ok = p.grad is None
+        elif r == "nonfinite":
+            ok = p.grad is not None and not bool(torch.isfinite(p.grad).all())
+        else:
+            ok = p.grad is not None and abs(float(p.grad.double().norm()) - r) <= 2e-3 * r + 1e-9
+        if not ok:
+            bad.append(n)
+    assert not bad, f"{len(bad)} tensors differ from the reference, e.g. {bad[:5]}"
+
+
+def test_base_64_forward_backward_against_reference(M):
+    from micformer_amd import MDiceLoss, ops
+    g = load("f4_base64.npz")
+    ref_gn = json.load(open(os.path.join(G, "f4_base64_gradnorms.json")))
+    h = build_head(M, 48, (2, 2, 6, 2))
+    x = fill.make_volume(1, 64, 64, 64).cuda()
+    lab = fill.make_label_map(1, 64, 64, 64)
+    tgt = fill.one_hot(lab).cuda()
+    logits = h(x)
+    close(logits[:, :, ::4, ::4, ::4], g["logits_stride"], atol=1e-4, what="base64 logits")
+    loss = MDiceLoss()(logits, tgt)
+    close(loss, g["loss"], atol=1e-5, what="base64 loss")
+    mask, md = ops.argmax_meandice(logits.detach(), lab.to(torch.uint8).cuda())
+    bad = (mask.cpu().long() != g["mask"].long()) & (g["margin"].float() > 1e-3)
+    assert int(bad.sum()) == 0, "argmax differs where the reference's top-2 margin > 1e-3"
+    assert abs(float(md.item()) - float(g["meandice"])) <= 1e-3
+    loss.backward()
+    wrong = []
+    for n, p in h.named_parameters():
+        r = ref_gn[n]
+        if r == "none":
+            if p.grad is not None:
+                wrong.append((n, "grad present"))
+        else:
+            v = float(p.grad.double().norm())
+            if not abs(v - r) <= 2e-3 * r + 1e-10:
+                wrong.append((n, v, r))
+    assert not wrong, f"{len(wrong)} grad norms off, e.g. {wrong[:4]}"
+    sd = dict(h.named_parameters())
+    for key, n in (("g_out_conv_w", "out_conv.weight"), ("g_patch_embed_w", "swin.patch_embed.proj.weight"),
+                   ("g_l0_b1_q", "swin.layers.0.blocks1.0.cross_attn.q.weight"),
+                   ("g_l2_off3", "swin.layers.2.blocks2.3.conv_offset.3.weight"),
+                   ("g_up3_fc1_b", "swin.up_layers.3.self_blocks2.1.mlp.fc1.bias")):
+        close(sd[n].grad, g[key], atol=1e-9, rtol=3e-3, what=key)
+
+
+def test_noncubic_pad_and_odd_resize_against_reference(M):
+    from micformer_amd import MDiceLoss
+    h = build_head(M, 24, (1, 1, 1, 1))
+    g = load("f4b_noncubic.npz")
+    x = fill.make_volume(1, 40, 40, 32).cuda()
+    with torch.no_grad():
+        logits = h(x)
+    close(logits[:, :, ::2, ::2, ::2], g["logits_stride"], atol=1e-4, what="noncubic logits")
+    close(MDiceLoss()(logits, fill.one_hot(fill.make_label_map(1, 40, 40, 32)).cuda()), g["loss"], atol=1e-5, what="noncubic loss")
+    ref_gn = json.load(open(os.path.join(G, "f4b_noncubic_gradnorms.json")))
+    h.zero_grad()
+    MDiceLoss()(h(x), fill.one_hot(fill.make_label_map(1, 40, 40, 32)).cuda()).backward()
+    wrong = [(n, float(p.grad.double().norm()), ref_gn[n]) for n, p in h.named_parameters()
+             if ref_gn[n] != "none" and not abs(float(p.grad.double().norm()) - ref_gn[n]) <= 2e-3 * ref_gn[n] + 1e-10]
+    assert not wrong, f"{len(wrong)} grad norms off, e.g. {wrong[:4]}"
+    g = load("f4c_odd36.npz")
+    with torch.no_grad():
+        logits = h(fill.make_volume(1, 36, 36, 36).cuda())
+    close(logits[:, :, ::2, ::2, ::2], g["logits_stride"], atol=1e-4, what="odd36 logits")
+
+
+def test_two_train_steps_against_reference(M):
+    """zero_grad -> fwd -> MDiceLoss -> bwd -> Adam(1e-4) -> cosine LR (train.py:183-207), two iterations, vs torch.optim.Adam
+    on the reference model (fixture f5)."""
+    from micformer_amd.engine import TrainEngine
+    g = load("f5_adam.npz")
+    h = build_head(M, 48, (2, 2, 6, 2))          # eval(): DropPath off, as the goldens
+    eng = TrainEngine(h, base_lr=1e-4, t_max=150, use_graph=False)
+    x = fill.make_volume(1, 64, 64, 64).cuda()
+    t = fill.one_hot(fill.make_label_map(1, 64, 64, 64)).cuda()
+    names = [k[3:] for k in g if k.startswith("w1.")]
+    sub = lambda v: v.reshape(-1)[::17] if v.numel() > 20000 else v
+    eng.step(x, t)
+    sd = h.state_dict()
+    for n in names:
+        close(sub(sd[n]), g["w1." + n], atol=3e-7, rtol=0, what="w1." + n)
+    loss2 = eng.step(x, t)
+    close(loss2, g["loss2"], atol=2e-5, what="loss2")
+    sd = h.state_dict()
+    for n in names:
+        close(sub(sd[n]), g["w2." + n], atol=2e-6, rtol=0, what="w2." + n)
+
+
+def test_base_128_properties_full_size(M):
+    """BASELINE's full size (base, 128^3, batch 2): size-independent properties instead of an oracle run --
+    batch independence (sample b of a batch == the same sample alone) and determinism of the forward."""
+    h = build_head(M, 48, (2, 2, 6, 2))
+    x = torch.randn(2, 2, 128, 128, 128, generator=torch.Generator().manual_seed(1234)).cuda()
+    with torch.no_grad():
+        y2 = h(x)
+        y0 = h(x[:1].contiguous())
+        y1 = h(x[1:].contiguous())
+        y2b = h(x)
+    assert y2.shape == (2, 8, 128, 128, 128)
+    assert torch.isfinite(y2).all()
+    assert torch.equal(y2, y2b), "forward is not deterministic"
+    close(y2[:1], y0, atol=1e-5, what="batch independence, sample 0")
+    close(y2[1:], y1, atol=1e-5, what="batch independence, sample 1")

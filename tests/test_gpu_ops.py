@@ -1,0 +1,377 @@
+"""GPU parity tests, op level: every C-ABI entry point against the CPU oracle / a plain PyTorch fp32 reference of the
+same op, on seeded inputs, forward and backward.  Tolerance: fp32 kernels vs fp32 CPU -> 2e-5 abs + 1e-4 of the
+tensor's max (atomically accumulated weight gradients: 2e-4 of max).  Run on the GPU box: pytest -m gpu.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import fill  # noqa: E402
+from oracle import micformer_ref as R  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from micformer_amd import ops as o
+    return o
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape) * 7919)
+    return (torch.randn(*shape, generator=g) * scale).float()
+
+
+def dev(t):
+    return t.cuda().contiguous() if t is not None else None
+
+
+def close(got, want, atol=2e-5, rtol=1e-4, what=""):
+    got = got.detach().cpu().double()
+    want = want.detach().cpu().double()
+    assert got.shape == want.shape, f"{what}: shape {tuple(got.shape)} vs {tuple(want.shape)}"
+    scale = max(float(want.abs().max()), 1e-30)
+    err = float((got - want).abs().max())
+    assert math.isfinite(err), f"{what}: non-finite error"
+    assert err <= atol + rtol * scale, f"{what}: max abs err {err:.3e} (scale {scale:.3e})"
+
+
+# ----------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("rows,C,c1", [(37, 48, 48), (130, 24, 24), (65, 96, 48), (9, 384, 384), (5, 16, 16)])
+def test_layernorm(ops, rows, C, c1):
+    x = rnd(rows, C, seed=1) * 2 + 0.3
+    g, b = 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
+    dy, add = rnd(rows, C, seed=4), rnd(rows, C, seed=5)
+    xr = x.clone().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = R.layer_norm(xr, gr, br)
+    gx, gg, gb = torch.autograd.grad((y * dy).sum(), [xr, gr, br])
+    x1, x2 = (x, None) if c1 == C else (x[:, :c1].contiguous(), x[:, c1:].contiguous())
+    yy, mean, rstd = ops.layernorm_fwd(dev(x1), dev(g), dev(b), 1e-5, dev(x2))
+    close(yy, y, what="ln y")
+    close(mean, x.mean(1), what="ln mean")
+    dg, db = torch.zeros(C).cuda(), torch.zeros(C).cuda()
+    use_add = c1 == C
+    r = ops.layernorm_bwd(dev(dy), dev(x1), mean, rstd, dev(g), dg, db, dev(x2), add=dev(add) if use_add else None)
+    dx = r if c1 == C else torch.cat([r[0], r[1]], 1)
+    close(dx, gx + (add if use_add else 0), what="ln dx")
+    close(dg, gg, rtol=2e-4, what="ln dgamma")
+    close(db, gb, rtol=2e-4, what="ln dbeta")
+
+
+# ----------------------------------------------------------------------------- Linear
+@pytest.mark.parametrize("M,N,K,k1", [(200, 48, 48, 48), (513, 96, 48, 48), (70, 192, 48, 48), (64, 48, 192, 192),
+                                        (333, 24, 24, 24), (90, 96, 192, 96), (50, 3, 16, 16), (77, 10, 6, 6),
+                                        (1000, 384, 768, 384), (8, 1536, 384, 384)])
+def test_linear_fwd_bwd(ops, M, N, K, k1):
+    a, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2) / math.sqrt(K), 0.1 * rnd(N, seed=3)
+    resid, dy = rnd(M, N, seed=4), rnd(M, N, seed=5)
+    rps = max(M // 3, 1)
+    s = torch.tensor([0.0, 1.25, 1.25, 0.0, 1.25][: (M + rps - 1) // rps])
+    a1, a2 = (a, None) if k1 == K else (a[:, :k1].contiguous(), a[:, k1:].contiguous())
+    srow = s[torch.arange(M) // rps].unsqueeze(1)
+    # forward variants
+    close(ops.linear_fwd(dev(a1), dev(w), dev(b), dev(a2)), F.linear(a, w, b), what="plain")
+    y, pre = ops.linear_fwd(dev(a1), dev(w), dev(b), dev(a2), act=1, want_pre=True)
+    close(pre, F.linear(a, w, b), what="pre")
+    close(y, R.gelu(F.linear(a, w, b)), what="gelu")
+    y = ops.linear_fwd(dev(a1), dev(w), dev(b), dev(a2), resid=dev(resid), dp_scale=dev(s), rows_per_sample=rps)
+    close(y, resid + srow * F.linear(a, w, b), what="resid+droppath")
+    y = ops.linear_fwd(dev(a1), dev(w), None, dev(a2), resid=dev(resid))
+    close(y, resid + F.linear(a, w), what="resid nobias")
+    # backward: data
+    want = (srow * dy) @ w
+    r = ops.linear_bwd_data(dev(dy), dev(w), dp_scale=dev(s), rows_per_sample=rps, k1=k1)
+    got = r if k1 == K else torch.cat([r[0], r[1]], 1)
+    close(got, want, what="dA")
+    h = rnd(M, K, seed=6)
+    hr = h.clone().requires_grad_(True)
+    gh, = torch.autograd.grad((R.gelu(hr) * (dy @ w)).sum(), hr)
+    close(ops.linear_bwd_data(dev(dy), dev(w), pre_act=dev(h)), gh, what="dA * gelu'")
+    if k1 == K:
+        base = rnd(M, K, seed=7)
+        out = dev(base.clone())
+        ops.linear_bwd_data(dev(dy), dev(w), out=out, accumulate=True)
+        close(out, base + dy @ w, what="dA accumulate")
+    # backward: weight
+    dw, db = torch.zeros(N, K).cuda(), torch.zeros(N).cuda()
+    ops.linear_bwd_weight(dev(dy), dev(a1), dw, db, dev(a2), dp_scale=dev(s), rows_per_sample=rps)
+    close(dw, (srow * dy).t() @ a, rtol=2e-4, what="dW")
+    close(db, (srow * dy).sum(0), rtol=2e-4, what="db")
+    if k1 == K:
+        dw.zero_()
+        ops.linear_bwd_weight(dev(dy), dev(a), dw, None, a_gelu=True)
+        close(dw, dy.t() @ R.gelu(a), rtol=2e-4, what="dW gelu(A)")
+
+
+def test_linear_large_rows_split_reduction(ops):
+    M, N, K = 40000, 48, 192
+    a, dy = rnd(M, K, seed=11), rnd(M, N, seed=12)
+    dw, db = torch.zeros(N, K).cuda(), torch.zeros(N).cuda()
+    ops.linear_bwd_weight(dev(dy), dev(a), dw, db)
+    close(dw, (dy.double().t() @ a.double()).float(), rtol=3e-4, what="dW split")
+    close(db, dy.double().sum(0).float(), rtol=3e-4, what="db split")
+
+
+# ----------------------------------------------------------------------------- window attention
+def _attn_ref(q, kv, dims, heads, ws):
+    B, D, H, W = dims
+    C = q.shape[1]
+    hd = C // heads
+    qw = R._to_windows(q.reshape(B, D, H, W, C), ws)
+    kw = R._to_windows(kv[:, :C].reshape(B, D, H, W, C), ws)
+    vw = R._to_windows(kv[:, C:].reshape(B, D, H, W, C), ws)
+    nW, N, _ = qw.shape
+    sp = lambda t: t.reshape(nW, N, heads, hd).transpose(1, 2)
+    att = torch.softmax((sp(qw) * hd ** -0.5) @ sp(kw).transpose(-1, -2), -1)
+    o = (att @ sp(vw)).transpose(1, 2).reshape(nW, N, C)
+    return R._from_windows(o, ws, B, D, H, W).reshape(-1, C)
+
+
+@pytest.mark.parametrize("dims,C,heads,ws", [((2, 4, 6, 4), 48, 3, (2, 2, 2)), ((1, 2, 2, 2), 24, 3, (2, 2, 2)),
+                                              ((1, 1, 1, 1), 192, 24, (1, 1, 1)), ((2, 6, 4, 2), 96, 3, (2, 2, 2)),
+                                              ((1, 4, 2, 6), 48, 8, (2, 2, 2)), ((3, 1, 4, 4), 48, 3, (1, 2, 2))])
+def test_window_attention(ops, dims, C, heads, ws):
+    T = dims[0] * dims[1] * dims[2] * dims[3]
+    q = rnd(T, C, seed=1).requires_grad_(True)
+    kv = rnd(T, 2 * C, seed=2).requires_grad_(True)
+    do = rnd(T, C, seed=3)
+    o = _attn_ref(q, kv, dims, heads, ws)
+    gq, gkv = torch.autograd.grad((o * do).sum(), [q, kv])
+    scale = (C // heads) ** -0.5
+    oo = ops.window_attn_fwd(dev(q.detach()), dev(kv.detach()), dims, heads, ws, scale)
+    close(oo, o, what="attn o")
+    dq, dkv = ops.window_attn_bwd(dev(q.detach()), dev(kv.detach()), dev(do), dims, heads, ws, scale)
+    close(dq, gq, what="attn dq")
+    close(dkv, gkv, what="attn dkv")
+
+
+# ----------------------------------------------------------------------------- conv 3x3x3
+@pytest.mark.parametrize("dims,c1,c2,N,ncdhw", [((2, 4, 5, 6), 24, 24, 16, False), ((1, 6, 4, 4), 48, 48, 16, False),
+                                                ((2, 5, 4, 7), 12, 0, 8, True), ((1, 3, 3, 3), 24, 0, 8, True),
+                                                ((1, 2, 1, 3), 6, 6, 16, False)])
+def test_conv3(ops, dims, c1, c2, N, ncdhw):
+    B, D, H, W = dims
+    T = B * D * H * W
+    x1 = rnd(T, c1, seed=1)
+    x2 = rnd(T, c2, seed=2) if c2 else None
+    w = rnd(N, c1 + c2, 3, 3, 3, seed=3) / math.sqrt(27 * (c1 + c2))
+    b = 0.1 * rnd(N, seed=4)
+    xin = torch.cat([x1] + ([x2] if c2 else []), 1).reshape(B, D, H, W, c1 + c2).permute(0, 4, 1, 2, 3).contiguous().requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = F.conv3d(xin, wr, br, padding=1)                                  # (B,N,D,H,W)
+    dy = rnd(B, N, D, H, W, seed=5)
+    gx, gw, gb = torch.autograd.grad((y * dy).sum(), [xin, wr, br])
+    gx = gx.permute(0, 2, 3, 4, 1).reshape(T, c1 + c2)
+    yy = ops.conv3_fwd(dev(x1), dev(w), dev(b), dims, x2=dev(x2), ncdhw_out=ncdhw)
+    close(yy, y if ncdhw else y.permute(0, 2, 3, 4, 1).reshape(T, N), what="conv3 y")
+    dyl = dy if ncdhw else dy.permute(0, 2, 3, 4, 1).reshape(T, N).contiguous()
+    d1, d2 = ops.conv3_bwd_data(dev(dyl), dev(w), dims, c1, c2, ncdhw=ncdhw)
+    close(d1, gx[:, :c1], what="conv3 dx1")
+    if c2:
+        close(d2, gx[:, c1:], what="conv3 dx2")
+        base1, base2 = rnd(T, c1, seed=8), rnd(T, c2, seed=9)
+        o1, o2 = dev(base1.clone()), dev(base2.clone())
+        ops.conv3_bwd_data(dev(dyl), dev(w), dims, c1, c2, ncdhw=ncdhw, dx1=o1, dx2=o2, acc1=True, acc2=True)
+        close(o1, base1 + gx[:, :c1], what="conv3 dx1 acc")
+        close(o2, base2 + gx[:, c1:], what="conv3 dx2 acc")
+    dw, db = torch.zeros_like(w).cuda(), torch.zeros(N).cuda()
+    ops.conv3_bwd_weight(dev(dyl), dev(x1), dw, db, dims, x2=dev(x2), ncdhw=ncdhw)
+    close(dw, gw, rtol=2e-4, what="conv3 dw")
+    close(db, gb, rtol=2e-4, what="conv3 db")
+
+
+# ----------------------------------------------------------------------------- offset head + deformable sampling
+@pytest.mark.parametrize("dims,C", [((2, 4, 6, 4), 24), ((1, 5, 5, 5), 48), ((1, 2, 2, 2), 24), ((1, 1, 1, 1), 96),
+                                    ((1, 3, 5, 2), 96), ((1, 1, 4, 4), 24)])
+def test_offset_sample(ops, dims, C):
+    B, D, H, W = dims
+    T = B * D * H * W
+    h = rnd(T, 16, seed=1).requires_grad_(True)
+    xa = rnd(T, C, seed=2).requires_grad_(True)
+    lg = (1 + 0.1 * rnd(16, seed=3)).requires_grad_(True)
+    lb = (0.1 * rnd(16, seed=4)).requires_grad_(True)
+    w1 = (rnd(3, 16, seed=5) * 0.5).requires_grad_(True)
+    dxs = rnd(T, C, seed=6)
+    off = F.linear(R.gelu(R.layer_norm(h.reshape(B, D, H, W, 16), lg, lb)), w1)
+    flow = off + R.reference_points(D, H, W)
+    xs = R.trilinear_gather_zero(xa.reshape(B, D, H, W, C), R.sample_coords(flow)).reshape(T, C)
+    g = torch.autograd.grad((xs * dxs).sum(), [xa, h, lg, lb, w1])
+    fl, xx = ops.offset_sample_fwd(dev(h.detach()), dev(lg.detach()), dev(lb.detach()), dev(w1.detach()), dev(xa.detach()), dims, 1e-5)
+    close(fl, flow.reshape(T, 3), what="flow")
+    close(xx, xs, what="xs")
+    base = rnd(T, C, seed=7)
+    dxa = dev(base.clone())
+    dlg, dlb, dw1 = torch.zeros(16).cuda(), torch.zeros(16).cuda(), torch.zeros(3, 16).cuda()
+    dh = ops.offset_sample_bwd(dev(dxs), dev(h.detach()), dev(lg.detach()), dev(lb.detach()), dev(w1.detach()), dev(xa.detach()),
+                               fl, dxa, dlg, dlb, dw1, dims, 1e-5)
+    close(dxa, base + g[0], what="dxa")
+    for got, want, name in ((dh, g[1], "dh"), (dlg, g[2], "dln_g"), (dlb, g[3], "dln_b"), (dw1, g[4], "dw1")):
+        want = want.reshape(got.shape)
+        assert torch.equal(torch.isfinite(got.cpu()), torch.isfinite(want)), f"{name}: NaN pattern differs from the oracle"
+        fin = torch.isfinite(want)
+        close(torch.where(fin, got.cpu(), torch.zeros_like(want)), torch.where(fin, want, torch.zeros_like(want)), rtol=3e-4, what=name)
+
+
+def test_stn_module_against_reference_goldens():
+    """Standalone SpatialTransformer vs vectors produced by the reference's STN.py (tests/golden/f2_stn.npz)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import os
+    from micformer_amd.models.STN import SpatialTransformer
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "f2_stn.npz"))
+    stn = SpatialTransformer()
+    for tag, (D, H, W) in {"s1": (1, 1, 1), "s2": (2, 2, 2), "s3": (3, 3, 3), "s5": (5, 5, 5), "nc": (4, 6, 8),
+                           "nc2": (3, 5, 2), "flat": (1, 4, 4)}.items():
+        src = fill.lattice((2, 8, D, H, W), f"F2.{tag}.src", 1.0, 0.7).cuda().requires_grad_(True)
+        off = fill.lattice((2, D, H, W, 3), f"F2.{tag}.off", 1.3, 0.9)
+        ref = torch.from_numpy(g[tag + "_ref"])
+        pos = (off + ref).permute(0, 4, 1, 2, 3).contiguous().cuda().requires_grad_(True)
+        y = stn(src, pos)
+        close(y.permute(0, 2, 3, 4, 1), torch.from_numpy(g[tag + "_y"]), what=tag + " y")
+        gy = fill.lattice((2, 8, D, H, W), f"F2.{tag}.gy", 1.0, 0.41).cuda()
+        gs, gp = torch.autograd.grad((y * gy).sum(), [src, pos])
+        close(gs.permute(0, 2, 3, 4, 1), torch.from_numpy(g[tag + "_gsrc"]), what=tag + " gsrc")
+        want = torch.from_numpy(g[tag + "_gpos"])
+        got = gp.permute(0, 2, 3, 4, 1).cpu()
+        assert torch.equal(torch.isfinite(got), torch.isfinite(want)), tag + ": NaN pattern of d/dflow differs from the reference"
+        fin = torch.isfinite(want)
+        close(torch.where(fin, got, torch.zeros_like(got)), torch.where(fin, want, torch.zeros_like(want)), what=tag + " gpos")
+
+
+# ----------------------------------------------------------------------------- patch convs
+@pytest.mark.parametrize("shape,E", [((2, 2, 8, 8, 8), 24), ((1, 2, 9, 8, 10), 24), ((1, 2, 16, 12, 8), 48)])
+def test_patch_embed(ops, shape, E):
+    vol = rnd(*shape, seed=1)
+    P = {"proj.weight": (rnd(E, 1, 4, 4, 4, seed=2) / 8).requires_grad_(True), "proj.bias": (0.1 * rnd(E, seed=3)).requires_grad_(True)}
+    for mod in (0, 1):
+        y = R.patch_embed(vol[:, mod:mod + 1], P, "")
+        dy = rnd(*y.shape, seed=4)
+        gw, gb = torch.autograd.grad((y * dy).sum(), list(P.values()))
+        yy = ops.patch_embed_fwd(dev(vol), mod, dev(P["proj.weight"].detach()), dev(P["proj.bias"].detach()), 4)
+        close(yy, y, what="embed y")
+        dw, db = torch.zeros(E, 1, 4, 4, 4).cuda(), torch.zeros(E).cuda()
+        ops.patch_embed_bwd_weight(dev(dy), dev(vol), mod, dw, db, 4)
+        close(dw, gw, rtol=2e-4, what="embed dw")
+        close(db, gb, rtol=2e-4, what="embed db")
+
+
+@pytest.mark.parametrize("shape", [(2, 4, 6, 4, 24), (1, 5, 3, 6, 24), (1, 8, 8, 8, 48), (1, 2, 2, 2, 96)])
+def test_conv_down(ops, shape):
+    B, D, H, W, C = shape
+    x = rnd(*shape, seed=1).requires_grad_(True)
+    w = (rnd(2 * C, C, 2, 2, 2, seed=2) / math.sqrt(8 * C)).requires_grad_(True)
+    b = (0.1 * rnd(2 * C, seed=3)).requires_grad_(True)
+    xc = F.pad(x.permute(0, 4, 1, 2, 3), (0, W % 2, 0, H % 2, 0, D % 2))
+    y = F.conv3d(xc, w, b, stride=2).permute(0, 2, 3, 4, 1)
+    dy = rnd(*y.shape, seed=4)
+    gx, gw, gb = torch.autograd.grad((y * dy).sum(), [x, w, b])
+    close(ops.conv_down_fwd(dev(x.detach()), dev(w.detach()), dev(b.detach())), y, what="down y")
+    close(ops.conv_down_bwd_data(dev(dy), dev(w.detach()), shape), gx, what="down dx")
+    dw, db = torch.zeros_like(w).cuda(), torch.zeros(2 * C).cuda()
+    ops.conv_down_bwd_weight(dev(dy), dev(x.detach()), dw, db)
+    close(dw, gw, rtol=2e-4, what="down dw")
+    close(db, gb, rtol=2e-4, what="down db")
+
+
+@pytest.mark.parametrize("shape,N,k", [((2, 2, 3, 2, 48), 24, 2), ((1, 4, 4, 4, 96), 48, 2), ((1, 3, 2, 4, 48), 12, 4),
+                                        ((2, 2, 2, 2, 96), 24, 4)])
+def test_conv_up(ops, shape, N, k):
+    B, D, H, W, C = shape
+    x = rnd(*shape, seed=1).requires_grad_(True)
+    w = (rnd(C, N, k, k, k, seed=2) / math.sqrt(C)).requires_grad_(True)
+    b = (0.1 * rnd(N, seed=3)).requires_grad_(True)
+    y = F.conv_transpose3d(x.permute(0, 4, 1, 2, 3), w, b, stride=k).permute(0, 2, 3, 4, 1)
+    dy = rnd(*y.shape, seed=4)
+    gx, gw, gb = torch.autograd.grad((y * dy).sum(), [x, w, b])
+    close(ops.conv_up_fwd(dev(x.detach()), dev(w.detach()), dev(b.detach()), k), y, what="up y")
+    close(ops.conv_up_bwd_data(dev(dy), dev(w.detach()), shape, k), gx, what="up dx")
+    dw, db = torch.zeros_like(w).cuda(), torch.zeros(N).cuda()
+    ops.conv_up_bwd_weight(dev(dy), dev(x.detach()), dw, db, k)
+    close(dw, gw, rtol=2e-4, what="up dw")
+    close(db, gb, rtol=2e-4, what="up db")
+
+
+# ----------------------------------------------------------------------------- pad / crop / resize
+def test_pad_crop_resize(ops):
+    dims, pd, C = (2, 5, 3, 4), (6, 4, 4), 24
+    x = rnd(2 * 5 * 3 * 4, C, seed=1)
+    xp = ops.pad3d(dev(x), dims, pd)
+    want = F.pad(x.reshape(2, 5, 3, 4, C), (0, 0, 0, 0, 0, 1, 0, 1)).reshape(-1, C)
+    close(xp, want, atol=0, rtol=0, what="pad")
+    close(ops.crop3d(xp, dims, pd), x, atol=0, rtol=0, what="crop")
+    base = rnd(*x.shape, seed=2)
+    o = dev(base.clone())
+    ops.crop3d(xp, dims, pd, out=o, accumulate=True)
+    close(o, base + x, what="crop acc")
+    v = rnd(1, 3, 2, 5, 8, seed=3).requires_grad_(True)
+    size = (5, 3, 4)
+    y = F.interpolate(v.permute(0, 4, 1, 2, 3), size=size, mode="trilinear", align_corners=True).permute(0, 2, 3, 4, 1)
+    dy = rnd(*y.shape, seed=4)
+    gv, = torch.autograd.grad((y * dy).sum(), v)
+    close(ops.resize_trilinear_fwd(dev(v.detach()), size), y, what="resize")
+    close(ops.resize_trilinear_bwd(dev(dy), tuple(v.shape)), gv, what="resize bwd")
+
+
+# ----------------------------------------------------------------------------- loss / metrics / optimiser
+def test_dice_bce_against_reference_golden(ops):
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "f6_loss.npz"))
+    z = torch.from_numpy(g["z"])
+    t = fill.one_hot(torch.from_numpy(g["label"]).long())
+    loss, sums = ops.dice_bce_fwd(dev(z), dev(t))
+    close(loss.reshape(()), torch.from_numpy(g["loss"]), atol=2e-6, what="loss vs reference")
+    one = torch.ones(1).cuda()
+    dz = ops.dice_bce_bwd(dev(z), dev(t), sums, one)
+    close(dz, torch.from_numpy(g["gz"]), atol=1e-9, rtol=2e-4, what="dloss/dz vs reference")
+    from micformer_amd.loss.dice import MDiceLoss, MDiceLoss_Val
+    zz = dev(z).requires_grad_(True)
+    l = MDiceLoss()(zz, dev(t))
+    (2 * l).backward()
+    close(zz.grad, 2 * torch.from_numpy(g["gz"]), atol=1e-9, rtol=2e-4, what="module grad")
+    close(MDiceLoss_Val()(dev(z), dev(t)), torch.from_numpy(g["val_loss"]), atol=2e-6, what="val loss")
+
+
+def test_dice_bce_larger(ops):
+    z = rnd(2, 8, 12, 10, 14, seed=1) * 3
+    t = fill.one_hot(fill.make_label_map(2, 12, 10, 14))
+    zr = z.clone().requires_grad_(True)
+    l = R.mdice_loss(zr, t)
+    gz, = torch.autograd.grad(l, zr)
+    loss, sums = ops.dice_bce_fwd(dev(z), dev(t))
+    close(loss.reshape(()), l, atol=2e-6, what="loss")
+    close(ops.dice_bce_bwd(dev(z), dev(t), sums, torch.full((1,), 0.5).cuda()), 0.5 * gz, atol=1e-9, rtol=2e-4, what="dz")
+
+
+def test_argmax_meandice(ops):
+    z = rnd(2, 8, 6, 5, 7, seed=1)
+    z[0, 3, 0, 0, 0] = z[0, 5, 0, 0, 0] = 9.0          # tie: first index wins, as torch.argmax
+    lab = fill.make_label_map(2, 6, 5, 7)
+    mask, md = ops.argmax_meandice(dev(z), dev(lab.to(torch.uint8)))
+    want = R.argmax_mask(z)
+    assert torch.equal(mask.cpu().long(), want)
+    assert abs(float(md.item()) - float(R.meandice(want, lab, 8))) < 1e-12
+
+
+def test_adam_against_oracle(ops):
+    n = 1003
+    p, g1, g2 = rnd(n, seed=1), rnd(n, seed=2) * 1e-3, rnd(n, seed=3) * 1e-3
+    m, v = torch.zeros(n), torch.zeros(n)
+    pp, mm, vv = p.clone(), m.clone(), v.clone()
+    P, M, V = dev(p.clone()), dev(m.clone()), dev(v.clone())
+    st = ops.adam_state("cuda")
+    for step, g in ((1, g1), (2, g2), (3, g1)):
+        lr = R.cosine_lr(1e-4, step - 1, 150)
+        pp, mm, vv = R.adam_update(pp, g, mm, vv, step, lr)
+        ops.adam_tick(st, 1e-4, 0.0, 150)
+        ops.adam_step(P, dev(g), M, V, st)
+    assert int(st.cpu()[0]) == 3
+    close(P, pp, atol=1e-7, rtol=0, what="adam p")
+    close(M, mm, atol=1e-9, rtol=1e-5, what="adam m")
+    close(V, vv, atol=1e-12, rtol=1e-5, what="adam v")

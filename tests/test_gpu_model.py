@@ -241,9 +241,15 @@ def test_noncubic_pad_and_odd_resize_against_reference(M):
     ref_gn = json.load(open(os.path.join(G, "f4b_noncubic_gradnorms.json")))
     h.zero_grad()
     MDiceLoss()(h(x), fill.one_hot(fill.make_label_map(1, 40, 40, 32)).cuda()).backward()
+    # the (2,2,1) last stage has S == 1 along W: the reference's own gradients are NaN upstream of it; parity includes that
+    def same(v, r):
+        if r != r:
+            return v != v
+        return abs(v - r) <= 2e-3 * r + 1e-10
     wrong = [(n, float(p.grad.double().norm()), ref_gn[n]) for n, p in h.named_parameters()
-             if ref_gn[n] != "none" and not abs(float(p.grad.double().norm()) - ref_gn[n]) <= 2e-3 * ref_gn[n] + 1e-10]
+             if ref_gn[n] != "none" and not same(float(p.grad.double().norm()), ref_gn[n])]
     assert not wrong, f"{len(wrong)} grad norms off, e.g. {wrong[:4]}"
+    assert any(v == v for v in ref_gn.values() if v != "none"), "fixture should hold some finite gradients"
     g = load("f4c_odd36.npz")
     with torch.no_grad():
         logits = h(fill.make_volume(1, 36, 36, 36).cuda())

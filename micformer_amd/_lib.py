@@ -92,10 +92,44 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def call(name, *args):
-    rc = getattr(lib, name)(*args, stream())
+# Optional per-entry-point timing with HIP events on the launch stream (bench.py's roofline leg).
+# PROFILE = None (off) or a dict  name -> [events [(start, end)], bytes, flops]
+PROFILE = None
+
+
+def call(name, *args, cost=None):
+    """Launch one C-ABI entry point on torch's current stream.  cost = (algorithmic bytes, flops) for the profiler."""
+    if PROFILE is None:
+        rc = getattr(lib, name)(*args, stream())
+    else:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(lib, name)(*args, stream())
+        e1.record()
+        key = name if (cost is None or len(cost) < 3) else f"{name}|{cost[2]}"
+        rec = PROFILE.setdefault(key, [[], 0, 0])
+        rec[0].append((e0, e1))
+        if cost is not None:
+            rec[1] += cost[0]
+            rec[2] += cost[1]
     if rc != 0:
         raise MicfError(f"{name} failed: {lib.micf_strerror(rc).decode()} (code {rc})")
+
+
+def profile_start():
+    global PROFILE
+    PROFILE = {}
+
+
+def profile_stop():
+    """-> {name: dict(calls, ms, bytes, flops)}; synchronises."""
+    global PROFILE
+    prof, PROFILE = PROFILE, None
+    torch.cuda.synchronize()
+    out = {}
+    for name, (evs, nbytes, flops) in (prof or {}).items():
+        out[name] = dict(calls=len(evs), ms=sum(a.elapsed_time(b) for a, b in evs), bytes=nbytes, flops=flops)
+    return out
 
 
 def f32(t):

@@ -46,9 +46,10 @@ struct Conv3In {
 
 struct Conv3FwdP {   // T mapping: x = token, r = tap*Cin + c
   Conv3In in;
-  template <int BX, int SX>
-  __device__ __forceinline__ void load(float* S, int x0, int r0, int r_end, int tid) const {
-    fill_T<BX, SX>(S, x0, r0, tid, [&](int x, int r, float* v) {
+  template <int BX> using Stage = StageT<BX>;
+  template <int BX>
+  __device__ __forceinline__ void fetch(Stage<BX>& st, int x0, int r0, int r_end, int tid) const {
+    st.fetch(x0, r0, tid, [&](int x, int r, float* v) {
       if (x < in.X) in.load4(x, r, r_end, v); else v[0] = v[1] = v[2] = v[3] = 0.f;
     });
   }
@@ -56,9 +57,10 @@ struct Conv3FwdP {   // T mapping: x = token, r = tap*Cin + c
 
 struct Conv3WgtQ {   // D mapping: x = tap*Cin + c (4 consecutive c), r = token
   Conv3In in; int J;
-  template <int BX, int SX>
-  __device__ __forceinline__ void load(float* S, int x0, int r0, int r_end, int tid) const {
-    fill_D<BX, SX>(S, x0, r0, tid, [&](int x, int r, float* v) {
+  template <int BX> using Stage = StageD<BX>;
+  template <int BX>
+  __device__ __forceinline__ void fetch(Stage<BX>& st, int x0, int r0, int r_end, int tid) const {
+    st.fetch(x0, r0, tid, [&](int x, int r, float* v) {
       if (r < r_end) in.load4(r, x, J, v); else v[0] = v[1] = v[2] = v[3] = 0.f;
     });
   }
@@ -110,6 +112,13 @@ struct Conv3FwdEpi {
     else { const int64_t b = i / DHW, vox = i - b * DHW; y[(b * N + j) * DHW + vox] = v; }
   }
 };
+struct Conv3FwdSplitEpi {   // y pre-zeroed; split 0 adds the bias; channels-last only
+  const float* bias; float* y; int N;
+  __device__ __forceinline__ void operator()(int i, int j, float v) const {
+    if (bias && blockIdx.z == 0) v += bias[j];
+    atomicAdd(y + (int64_t)i * N + j, v);
+  }
+};
 struct Conv3DataEpi {
   float* d1; float* d2; int c1, c2, acc1, acc2;
   __device__ __forceinline__ void operator()(int i, int j, float v) const {
@@ -117,11 +126,11 @@ struct Conv3DataEpi {
     else if (d2) { float* p = d2 + (int64_t)i * c2 + (j - c1); *p = acc2 ? *p + v : v; }
   }
 };
-struct Conv3WgtEpi {
+struct Conv3WgtEpi {   // (i = tap*Cin + c, j = n) -> dw[n][c][tap]
   float* dw; int Cin;
   __device__ __forceinline__ void operator()(int i, int j, float v) const {
-    const int tap = j / Cin, c = j - tap * Cin;
-    atomicAdd(dw + ((int64_t)i * Cin + c) * 27 + tap, v);
+    const int tap = i / Cin, c = i - tap * Cin;
+    atomicAdd(dw + ((int64_t)j * Cin + c) * 27 + tap, v);
   }
 };
 
@@ -157,8 +166,14 @@ extern "C" int micf_conv3_fwd(const float* x1, int c1, const float* x2, int c2, 
   const int vec = (c1 % 4 == 0) && (c2 % 4 == 0) && aligned16(x1) && (!x2 || aligned16(x2));
   Conv3FwdP pa{Conv3In{x1, x2 ? x2 : x1, c1, c2 > 0 ? c2 : 1, Cin, g, (int)T, vec}};
   auto qa = make_elem<false>(Conv3WFwd{w, Cin}, N);
+  hipStream_t s = (hipStream_t)stream;
+  const int splits = (y_layout == 0) ? pick_splits(T, N, 27 * Cin) : 1;
+  if (splits > 1) {   // small token grids (8^3, 4^3 stages): split the 27*Cin reduction over workgroups
+    if (hipMemsetAsync(y, 0, sizeof(float) * (size_t)T * N, s) != hipSuccess) return MICF_ELAUNCH;
+    return launch_gemm(pa, qa, Conv3FwdSplitEpi{bias, y, N}, T, N, 27 * Cin, splits, s) == hipSuccess ? MICF_OK : MICF_ELAUNCH;
+  }
   Conv3FwdEpi epi{bias, y, y_layout, N, (int64_t)D * H * W};
-  return launch_gemm(pa, qa, epi, T, N, 27 * Cin, 1, (hipStream_t)stream) == hipSuccess ? MICF_OK : MICF_ELAUNCH;
+  return launch_gemm(pa, qa, epi, T, N, 27 * Cin, 1, s) == hipSuccess ? MICF_OK : MICF_ELAUNCH;
 }
 
 extern "C" int micf_conv3_bwd_data(const float* dy, int dy_layout, const float* w, float* dx1, int c1, int acc1,
@@ -182,11 +197,21 @@ extern "C" int micf_conv3_bwd_weight(const float* dy, int dy_layout, const float
   const int64_t T = g.tokens();
   const int64_t DHW = (int64_t)D * H * W;
   const int vec = (c1 % 4 == 0) && (c2 % 4 == 0) && aligned16(x1) && (!x2 || aligned16(x2));
-  auto pa = make_elem<false>(Conv3DyT{dy, dy_layout, N, DHW}, N);
-  Conv3WgtQ qa{Conv3In{x1, x2 ? x2 : x1, c1, c2 > 0 ? c2 : 1, Cin, g, (int)T, vec}, 27 * Cin};
+  // dW^T[tap*Cin + c, n] = sum_t in[nbr(t, tap), c] * dy[t, n]: the long 27*Cin axis is the tile's I side (full MFMA rows),
+  // the narrow N (16 / 8) is its J side; the reduction over tokens is split across workgroups (atomic epilogue).
+  Conv3WgtQ pa{Conv3In{x1, x2 ? x2 : x1, c1, c2 > 0 ? c2 : 1, Cin, g, (int)T, vec}, 27 * Cin};
   Conv3WgtEpi epi{dw, Cin};
   hipStream_t s = (hipStream_t)stream;
-  if (launch_gemm(pa, qa, epi, N, 27 * Cin, (int)T, pick_splits(N, 27 * Cin, T), s) != hipSuccess) return MICF_ELAUNCH;
+  const int splits = pick_splits(27 * Cin, N, T);
+  hipError_t e;
+  if (dy_layout == 0) {
+    RowsD qa{dy, dy, N, N, 1, N, nullptr, 1, 0, (N % 4 == 0) && aligned16(dy)};
+    e = launch_gemm(pa, qa, epi, 27 * Cin, N, (int)T, splits, s);
+  } else {
+    auto qa = make_elem<true>(Conv3DyT{dy, dy_layout, N, DHW}, N);
+    e = launch_gemm(pa, qa, epi, 27 * Cin, N, (int)T, splits, s);
+  }
+  if (e != hipSuccess) return MICF_ELAUNCH;
   if (dbias) {
     if (dy_layout == 0) return colsum_atomic(dy, nullptr, 1, dbias, T, N, s);
     int chunks = (int)((DHW + 65535) / 65536);

@@ -2,24 +2,33 @@
 //
 //   C[i, j] = sum_r P[i, r] * Q[r, j]        i < I, j < J, r in [r_begin, r_end)
 //
-// One 256-thread workgroup (4 waves of 64) computes a BI x BJ tile with v_mfma_f32_16x16x4_f32
-// (exact fp32: bitwise a k-ordered fmaf chain, 64 FLOP/clk/SIMD), staging 16-deep reduction slabs of
-// P and Q through LDS in r-major order (Ps[r][i], Qs[r][j]) so that every MFMA fragment read
-// (lane l -> i = l & 15, r = l >> 4) is a conflict-free ds_read_b32: the row stride is == 16 (mod 32) banks.
+// One 256-thread workgroup (4 waves of 64) computes a BI x BJ tile with v_mfma_f32_16x16x4_f32 (exact fp32: bitwise
+// a k-ordered fmaf chain, 64 FLOP/clk/SIMD).  32-deep reduction slabs of P and Q are staged through LDS in r-major
+// order (Ps[r][i], Qs[r][j]); the next slab is fetched from HBM into registers BEFORE the MFMAs of the current slab
+// and committed to the other LDS buffer after them (one barrier per slab), so HBM/L2 latency hides behind the
+// matrix pipe even when only one workgroup fits the problem (the small-token stages of MicFormer).
+//
+// LDS layout: row stride == 16 (mod 32) banks and the column rotated by 8*(r>>2), col' = (x + 8*(r>>2)) mod BX:
+//   * MFMA fragment reads (lane l -> x = l & 15, r = l >> 4) are conflict-free ds_read_b32;
+//   * the transposing stores of r-contiguous sources (thread = 4 consecutive r of one x) are <= 2-way (free);
+//   * float4 stores of x-contiguous sources stay 16-byte aligned.
+//
 // Operands are described by ACCESSOR functors (how element (x, r) is found in HBM: plain rows, two-source
-// concatenation, 3x3x3 halo gather, stride==kernel patch gather, ...) and results leave through an EPILOGUE
-// functor (bias / GELU / residual + DropPath scale / scatter / atomicAdd), so windowing, im2col and cat are
-// index arithmetic and are never materialised.
+// concatenation, 3x3x3 halo gather, stride==kernel patch gather, ...) and results leave through an EPILOGUE functor
+// (bias / GELU / residual + DropPath scale / scatter / atomicAdd), so windowing, im2col and cat are index arithmetic
+// and are never materialised.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <type_traits>
 
 namespace micf {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kThreads = 256;
-constexpr int kBR = 16;  // reduction depth staged per LDS slab
+constexpr int kBR = 32;  // reduction depth staged per LDS slab
 
 constexpr int lds_stride(int b) { return (b % 32 == 16) ? b : b + 16; }
 
@@ -32,34 +41,90 @@ struct Tile {
   static_assert(TI * 16 * WI == BI && TJ * 16 * WJ == BJ, "tile must split into 16x16 MFMA tiles");
 };
 
-// ------------------------------------------------------------------ LDS fill helpers
-// "T" mapping: the source is contiguous along r.  Thread handles 4 consecutive r of one x.
-//   f4(x, r, out[4]) must zero-fill anything out of range.
-template <int BX, int SX, class F4>
-__device__ __forceinline__ void fill_T(float* S, int x0, int r0, int tid, F4 f4) {
-#pragma unroll
-  for (int idx = tid; idx < BX * 4; idx += kThreads) {
-    const int x = idx >> 2, r4 = (idx & 3) * 4;
-    float v[4];
-    f4(x0 + x, r0 + r4, v);
-    S[(r4 + 0) * SX + x] = v[0];
-    S[(r4 + 1) * SX + x] = v[1];
-    S[(r4 + 2) * SX + x] = v[2];
-    S[(r4 + 3) * SX + x] = v[3];
-  }
+// rotated column of element (r, x) inside a slab of width BX
+template <int BX>
+__device__ __forceinline__ int swz(int r, int x) {
+  int c = x + 8 * (r >> 2);
+  if constexpr ((BX & (BX - 1)) == 0) return c & (BX - 1);
+  else return c % BX;
 }
-// "D" mapping: the source is contiguous along x.  Thread handles 4 consecutive x of one r.
-template <int BX, int SX, class F4>
-__device__ __forceinline__ void fill_D(float* S, int x0, int r0, int tid, F4 f4) {
-  constexpr int XV = BX / 4;
+
+// ------------------------------------------------------------------ staging: fetch (HBM -> registers), commit (-> LDS)
+// "T" mapping: the source is contiguous along r.  A thread handles 4 consecutive r of one x (float4 from HBM).
+template <int BX>
+struct StageT {
+  static constexpr int NIT = (BX * (kBR / 4) + kThreads - 1) / kThreads;
+  float v[NIT][4];
+  template <class F4>   // f4(x, r, out[4]) zero-fills anything out of range
+  __device__ __forceinline__ void fetch(int x0, int r0, int tid, F4 f4) {
 #pragma unroll
-  for (int idx = tid; idx < kBR * XV; idx += kThreads) {
-    const int r = idx / XV, x4 = (idx % XV) * 4;
-    float v[4];
-    f4(x0 + x4, r0 + r, v);
-    *reinterpret_cast<float4*>(&S[r * SX + x4]) = make_float4(v[0], v[1], v[2], v[3]);
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = tid + it * kThreads;
+      if (idx < BX * (kBR / 4)) f4(x0 + idx / (kBR / 4), r0 + (idx % (kBR / 4)) * 4, v[it]);
+    }
   }
-}
+  template <int SX>
+  __device__ __forceinline__ void commit(float* S, int tid) const {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = tid + it * kThreads;
+      if (idx < BX * (kBR / 4)) {
+        const int x = idx / (kBR / 4), r4 = (idx % (kBR / 4)) * 4;
+        const int c = swz<BX>(r4, x);                 // r4..r4+3 share r >> 2
+#pragma unroll
+        for (int e = 0; e < 4; ++e) S[(r4 + e) * SX + c] = v[it][e];
+      }
+    }
+  }
+};
+// "D" mapping: the source is contiguous along x.  A thread handles 4 consecutive x of one r (float4 both sides).
+template <int BX>
+struct StageD {
+  static constexpr int XV = BX / 4;
+  static constexpr int NIT = (kBR * XV + kThreads - 1) / kThreads;
+  float v[NIT][4];
+  template <class F4>
+  __device__ __forceinline__ void fetch(int x0, int r0, int tid, F4 f4) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = tid + it * kThreads;
+      if (idx < kBR * XV) f4(x0 + (idx % XV) * 4, r0 + idx / XV, v[it]);
+    }
+  }
+  template <int SX>
+  __device__ __forceinline__ void commit(float* S, int tid) const {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = tid + it * kThreads;
+      if (idx < kBR * XV) {
+        const int r = idx / XV, x4 = (idx % XV) * 4;
+        *reinterpret_cast<float4*>(&S[r * SX + swz<BX>(r, x4)]) = make_float4(v[it][0], v[it][1], v[it][2], v[it][3]);
+      }
+    }
+  }
+};
+// "E" mapping: per-element functor, threads walk x fastest (scalar both sides).
+template <int BX>
+struct StageE {
+  static constexpr int NIT = (BX * kBR + kThreads - 1) / kThreads;
+  float v[NIT];
+  template <class F1>   // f1(x, r) -> value (zero when out of range)
+  __device__ __forceinline__ void fetch(int x0, int r0, int tid, F1 f1) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = tid + it * kThreads;
+      if (idx < BX * kBR) v[it] = f1(x0 + idx % BX, r0 + idx / BX);
+    }
+  }
+  template <int SX>
+  __device__ __forceinline__ void commit(float* S, int tid) const {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = tid + it * kThreads;
+      if (idx < BX * kBR) { const int r = idx / BX, x = idx % BX; S[r * SX + swz<BX>(r, x)] = v[it]; }
+    }
+  }
+};
 
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {
@@ -79,9 +144,10 @@ struct RowsT {
   int64_t rps;
   int gelu;
   int vec;              // 1: ld1, ld2, k1 multiples of 4 and bases 16-B aligned -> float4 loads
-  template <int BX, int SX>
-  __device__ __forceinline__ void load(float* S, int x0, int r0, int r_end, int tid) const {
-    fill_T<BX, SX>(S, x0, r0, tid, [&](int x, int r, float* v) {
+  template <int BX> using Stage = StageT<BX>;
+  template <int BX>
+  __device__ __forceinline__ void fetch(Stage<BX>& st, int x0, int r0, int r_end, int tid) const {
+    st.fetch(x0, r0, tid, [&](int x, int r, float* v) {
       v[0] = v[1] = v[2] = v[3] = 0.f;
       if (x >= X || r >= r_end) return;
       if (vec && r + 3 < r_end) {
@@ -120,9 +186,10 @@ struct RowsD {
   int64_t rps;
   int gelu;
   int vec;
-  template <int BX, int SX>
-  __device__ __forceinline__ void load(float* S, int x0, int r0, int r_end, int tid) const {
-    fill_D<BX, SX>(S, x0, r0, tid, [&](int x, int r, float* v) {
+  template <int BX> using Stage = StageD<BX>;
+  template <int BX>
+  __device__ __forceinline__ void fetch(Stage<BX>& st, int x0, int r0, int r_end, int tid) const {
+    st.fetch(x0, r0, tid, [&](int x, int r, float* v) {
       v[0] = v[1] = v[2] = v[3] = 0.f;
       if (r >= r_end || x >= X) return;
       if (vec && x + 3 < X) {
@@ -156,19 +223,16 @@ template <class F, bool MAP_T>
 struct Elem {
   F f;
   int X;
-  template <int BX, int SX>
-  __device__ __forceinline__ void load(float* S, int x0, int r0, int r_end, int tid) const {
+  template <int BX> using Stage = typename std::conditional<MAP_T, StageT<BX>, StageE<BX>>::type;
+  template <int BX>
+  __device__ __forceinline__ void fetch(Stage<BX>& st, int x0, int r0, int r_end, int tid) const {
     if constexpr (MAP_T) {
-      fill_T<BX, SX>(S, x0, r0, tid, [&](int x, int r, float* v) {
+      st.fetch(x0, r0, tid, [&](int x, int r, float* v) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (x < X && r + e < r_end) ? f(x, r + e) : 0.f;
       });
     } else {
-#pragma unroll
-      for (int idx = tid; idx < BX * kBR; idx += kThreads) {
-        const int r = idx / BX, x = idx % BX;
-        S[r * SX + x] = (x0 + x < X && r0 + r < r_end) ? f(x0 + x, r0 + r) : 0.f;
-      }
+      st.fetch(x0, r0, tid, [&](int x, int r) { return (x < X && r < r_end) ? f(x, r) : 0.f; });
     }
   }
 };
@@ -176,10 +240,13 @@ template <bool MAP_T, class F>
 __host__ __device__ inline Elem<F, MAP_T> make_elem(F f, int X) { return Elem<F, MAP_T>{f, X}; }
 
 // ------------------------------------------------------------------ the kernel
+// colsum (optional): out[i] += sum_r P[i, r] over this block's reduction range (blocks with blockIdx.y == 0 only) --
+// the bias gradient of a weight-gradient GEMM comes for free from the P slab already sitting in LDS.
 template <class T, class PAcc, class QAcc, class Epi>
-__global__ void __launch_bounds__(kThreads) gemm_kernel(PAcc pa, QAcc qa, Epi epi, int I, int J, int R, int r_chunk) {
-  __shared__ __attribute__((aligned(16))) float Ps[kBR * T::SP];
-  __shared__ __attribute__((aligned(16))) float Qs[kBR * T::SQ];
+__global__ void __launch_bounds__(kThreads) gemm_kernel(PAcc pa, QAcc qa, Epi epi, int I, int J, int R, int r_chunk,
+                                                        float* colsum) {
+  __shared__ __attribute__((aligned(16))) float Ps[2][kBR * T::SP];
+  __shared__ __attribute__((aligned(16))) float Qs[2][kBR * T::SQ];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wi = wave / T::WJ, wj = wave % T::WJ;
   const int i0 = blockIdx.x * T::BI, j0 = blockIdx.y * T::BJ;
@@ -192,25 +259,50 @@ __global__ void __launch_bounds__(kThreads) gemm_kernel(PAcc pa, QAcc qa, Epi ep
 #pragma unroll
     for (int b = 0; b < T::TJ; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  typename PAcc::template Stage<T::BI> sp;
+  typename QAcc::template Stage<T::BJ> sq;
+  const bool do_colsum = (colsum != nullptr) && (blockIdx.y == 0) && (tid < T::BI);
+  float csum = 0.f;
+
   const int li = lane & 15, lr = lane >> 4;
+  pa.template fetch<T::BI>(sp, i0, r_begin, r_end, tid);
+  qa.template fetch<T::BJ>(sq, j0, r_begin, r_end, tid);
+  sp.template commit<T::SP>(Ps[0], tid);
+  sq.template commit<T::SQ>(Qs[0], tid);
+  __syncthreads();
+  int cur = 0;
   for (int r0 = r_begin; r0 < r_end; r0 += kBR) {
-    pa.template load<T::BI, T::SP>(Ps, i0, r0, r_end, tid);
-    qa.template load<T::BJ, T::SQ>(Qs, j0, r0, r_end, tid);
-    __syncthreads();
+    const bool more = r0 + kBR < r_end;
+    if (more) {                                   // prefetch the next slab into registers
+      pa.template fetch<T::BI>(sp, i0, r0 + kBR, r_end, tid);
+      qa.template fetch<T::BJ>(sq, j0, r0 + kBR, r_end, tid);
+    }
+    const float* P = Ps[cur];
+    const float* Q = Qs[cur];
 #pragma unroll
     for (int rr = 0; rr < kBR; rr += 4) {
       float a[T::TI], b[T::TJ];
+      const int r = rr + lr;
 #pragma unroll
-      for (int t = 0; t < T::TI; ++t) a[t] = Ps[(rr + lr) * T::SP + wi * (T::BI / T::WI) + t * 16 + li];
+      for (int t = 0; t < T::TI; ++t) a[t] = P[r * T::SP + swz<T::BI>(r, wi * (T::BI / T::WI) + t * 16 + li)];
 #pragma unroll
-      for (int t = 0; t < T::TJ; ++t) b[t] = Qs[(rr + lr) * T::SQ + wj * (T::BJ / T::WJ) + t * 16 + li];
+      for (int t = 0; t < T::TJ; ++t) b[t] = Q[r * T::SQ + swz<T::BJ>(r, wj * (T::BJ / T::WJ) + t * 16 + li)];
 #pragma unroll
       for (int ta = 0; ta < T::TI; ++ta)
 #pragma unroll
         for (int tb = 0; tb < T::TJ; ++tb)
           acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
     }
+    if (do_colsum) {
+#pragma unroll 8
+      for (int r = 0; r < kBR; ++r) csum += P[r * T::SP + swz<T::BI>(r, tid)];
+    }
+    if (more) {
+      sp.template commit<T::SP>(Ps[cur ^ 1], tid);
+      sq.template commit<T::SQ>(Qs[cur ^ 1], tid);
+    }
     __syncthreads();
+    cur ^= 1;
   }
   // C/D fragment: lane l, reg v -> row (l >> 4) * 4 + v, col l & 15
 #pragma unroll
@@ -223,42 +315,50 @@ __global__ void __launch_bounds__(kThreads) gemm_kernel(PAcc pa, QAcc qa, Epi ep
         const int j = j0 + wj * (T::BJ / T::WJ) + tb * 16 + li;
         if (i < I && j < J) epi(i, j, acc[ta][tb][v]);
       }
+  if (do_colsum && i0 + tid < I) atomicAdd(colsum + i0 + tid, csum);
 }
 
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
-// Launch with a tile picked from J (the narrow dimension on this path); splits > 1 only with an atomic epilogue.
+template <class T, class PAcc, class QAcc, class Epi>
+inline void launch_tile(PAcc pa, QAcc qa, Epi epi, int64_t I, int J, int R, int r_chunk, int splits, float* colsum,
+                        hipStream_t stream) {
+  dim3 g(ceil_div(I, T::BI), ceil_div(J, T::BJ), splits);
+  hipLaunchKernelGGL((gemm_kernel<T, PAcc, QAcc, Epi>), g, dim3(kThreads), 0, stream, pa, qa, epi, (int)I, J, R, r_chunk,
+                     colsum);
+}
+
+// Launch with a tile picked from the problem shape.  splits > 1 only with an accumulating (atomic) epilogue.
+// Small problems (the 8^3 / 4^3 token stages) take 32x32 tiles so that more of the 256 CUs get a workgroup.
 template <class PAcc, class QAcc, class Epi>
-inline hipError_t launch_gemm(PAcc pa, QAcc qa, Epi epi, int64_t I, int J, int R, int splits, hipStream_t stream) {
+inline hipError_t launch_gemm(PAcc pa, QAcc qa, Epi epi, int64_t I, int J, int R, int splits, hipStream_t stream,
+                              float* colsum = nullptr) {
   if (I <= 0 || J <= 0 || R <= 0) return hipSuccess;
   if (splits < 1) splits = 1;
   int r_chunk = ceil_div(ceil_div(R, splits), kBR) * kBR;
   splits = ceil_div(R, r_chunk);
   if (J <= 16) {
-    using T = Tile<64, 16, 4, 1>;
-    dim3 g(ceil_div(I, T::BI), ceil_div(J, T::BJ), splits);
-    hipLaunchKernelGGL((gemm_kernel<T, PAcc, QAcc, Epi>), g, dim3(kThreads), 0, stream, pa, qa, epi, (int)I, J, R, r_chunk);
-  } else if (J <= 32) {
-    using T = Tile<64, 32, 2, 2>;
-    dim3 g(ceil_div(I, T::BI), ceil_div(J, T::BJ), splits);
-    hipLaunchKernelGGL((gemm_kernel<T, PAcc, QAcc, Epi>), g, dim3(kThreads), 0, stream, pa, qa, epi, (int)I, J, R, r_chunk);
+    launch_tile<Tile<64, 16, 4, 1>>(pa, qa, epi, I, J, R, r_chunk, splits, colsum, stream);
+  } else if (J <= 32 || (int64_t)ceil_div(I, 64) * ceil_div(J, 64) * splits < 256) {
+    if (J <= 32 && (int64_t)ceil_div(I, 64) * splits >= 256)
+      launch_tile<Tile<64, 32, 2, 2>>(pa, qa, epi, I, J, R, r_chunk, splits, colsum, stream);
+    else
+      launch_tile<Tile<32, 32, 2, 2>>(pa, qa, epi, I, J, R, r_chunk, splits, colsum, stream);
   } else if (J % 64 != 0 && J % 48 == 0) {
-    using T = Tile<64, 48, 4, 1>;
-    dim3 g(ceil_div(I, T::BI), ceil_div(J, T::BJ), splits);
-    hipLaunchKernelGGL((gemm_kernel<T, PAcc, QAcc, Epi>), g, dim3(kThreads), 0, stream, pa, qa, epi, (int)I, J, R, r_chunk);
+    launch_tile<Tile<64, 48, 4, 1>>(pa, qa, epi, I, J, R, r_chunk, splits, colsum, stream);
   } else {
-    using T = Tile<64, 64, 2, 2>;
-    dim3 g(ceil_div(I, T::BI), ceil_div(J, T::BJ), splits);
-    hipLaunchKernelGGL((gemm_kernel<T, PAcc, QAcc, Epi>), g, dim3(kThreads), 0, stream, pa, qa, epi, (int)I, J, R, r_chunk);
+    launch_tile<Tile<64, 64, 2, 2>>(pa, qa, epi, I, J, R, r_chunk, splits, colsum, stream);
   }
   return hipGetLastError();
 }
 
-// How many reduction splits to use when R (rows) is huge and the output tile grid is tiny (weight gradients).
+// How many reduction splits to use when R is long and the output tile grid is small (weight gradients, small-grid
+// convolutions): aim for >= 512 workgroups while keeping >= 64 reduction rows per split.
 inline int pick_splits(int64_t I, int J, int64_t R) {
-  const int64_t tiles = (int64_t)ceil_div(I, 64) * ceil_div(J, 64);
-  int64_t want = (1024 + tiles - 1) / tiles;          // aim for ~1024 workgroups (4 per CU)
-  int64_t maxs = (R + 255) / 256;                      // at least 256 reduction rows per split
+  int64_t tiles = (int64_t)ceil_div(I, 64) * ceil_div(J, 64);
+  if (tiles < 256) tiles = (int64_t)ceil_div(I, 32) * ceil_div(J, 32);
+  int64_t want = (512 + tiles - 1) / tiles;
+  int64_t maxs = (R + 63) / 64;
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
   return (int)want;

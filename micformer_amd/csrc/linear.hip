@@ -99,7 +99,7 @@ extern "C" int micf_linear_bwd_weight(const float* dy, const float* dp_scale, in
   const int avec = (k1 % 4 == 0) && (k2 % 4 == 0) && aligned16(a1) && (!a2 || aligned16(a2));
   RowsD qa{a1, a2 ? a2 : a1, k1, k1, k2 > 0 ? k2 : 1, K, nullptr, 1, a_gelu, avec};
   AtomicEpi epi{dw, K};
-  if (launch_gemm(pa, qa, epi, N, K, (int)M, pick_splits(N, K, M), (hipStream_t)stream) != hipSuccess) return MICF_ELAUNCH;
-  if (dbias) return colsum_atomic(dy, dp_scale, rows_per_sample, dbias, M, N, (hipStream_t)stream);
+  // dbias = column sums of (s*dy): taken from the dy slab already staged in LDS by the same launch
+  if (launch_gemm(pa, qa, epi, N, K, (int)M, pick_splits(N, K, M), (hipStream_t)stream, dbias) != hipSuccess) return MICF_ELAUNCH;
   return MICF_OK;
 }

@@ -161,8 +161,7 @@ extern "C" int micf_patch_embed_bwd_weight(const float* dy, const float* vol, in
   // dW[e, tap] = sum_t dy[t, e] * patch[t, tap]
   RowsD pa{dy, dy, E, E, 1, E, nullptr, 1, 0, (E % 4 == 0) && aligned16(dy)};
   auto qa = make_elem<false>(EmbedVolT{EmbedVol{vol, nmod, mod, g, (int64_t)D * H * W}}, K);
-  if (launch_gemm(pa, qa, AtomicRowsEpi{dw, K}, E, K, (int)Tc, pick_splits(E, K, Tc), S_(stream)) != hipSuccess) return MICF_ELAUNCH;
-  if (dbias) return colsum_atomic(dy, nullptr, 1, dbias, Tc, E, S_(stream));
+  if (launch_gemm(pa, qa, AtomicRowsEpi{dw, K}, E, K, (int)Tc, pick_splits(E, K, Tc), S_(stream), dbias) != hipSuccess) return MICF_ELAUNCH;
   return MICF_OK;
 }
 
@@ -194,9 +193,8 @@ extern "C" int micf_conv_down_bwd_weight(const float* dy, const float* x, float*
   const int64_t Tc = (int64_t)B * g.Dc * g.Hc * g.Wc;
   RowsD pa{dy, dy, N, N, 1, N, nullptr, 1, 0, (N % 4 == 0) && aligned16(dy)};
   auto qa = make_elem<false>(DownInT{DownIn{x, C, g}}, 8 * C);
-  if (launch_gemm(pa, qa, DownWgtEpi{dw, C, 8}, N, 8 * C, (int)Tc, pick_splits(N, 8 * C, Tc), S_(stream)) != hipSuccess)
+  if (launch_gemm(pa, qa, DownWgtEpi{dw, C, 8}, N, 8 * C, (int)Tc, pick_splits(N, 8 * C, Tc), S_(stream), dbias) != hipSuccess)
     return MICF_ELAUNCH;
-  if (dbias) return colsum_atomic(dy, nullptr, 1, dbias, Tc, N, S_(stream));
   return MICF_OK;
 }
 

@@ -24,41 +24,77 @@ struct WinGeo {
 
 constexpr int kMaxWin = 8;
 
-// thread = (window, head, query i); pair-major inside the block so a pair's N threads are adjacent.
+// Thread = (window, in-window token i, head) with HEAD FASTEST, then the token: the 64-byte head slices of a token row and
+// the two w-adjacent tokens of a window are contiguous in HBM, so consecutive lanes read consecutive 16-byte pieces.
+// A workgroup owns wpb = 256 / (N * heads) whole windows.
+struct WinThread {
+  bool active; int win, i, head, local;   // local = (window-in-block * N + i) * heads + head
+};
+__device__ __forceinline__ WinThread win_thread(const WinGeo& g, int64_t nwin) {
+  WinThread t;
+  const int per = g.N * g.heads;
+  const int wpb = 256 / per;
+  const int wl = threadIdx.x / per, rem = threadIdx.x % per;
+  t.i = rem / g.heads; t.head = rem % g.heads; t.local = threadIdx.x;
+  const int64_t w = (int64_t)blockIdx.x * wpb + wl;
+  t.active = (wl < wpb) && (w < nwin);
+  t.win = t.active ? (int)w : 0;
+  return t;
+}
+
+template <int HD>
+__device__ __forceinline__ void load_row(float* dst, const float* src) {
+#pragma unroll
+  for (int d = 0; d < HD; d += 4) {
+    const float4 a = *reinterpret_cast<const float4*>(src + d);
+    dst[d] = a.x; dst[d + 1] = a.y; dst[d + 2] = a.z; dst[d + 3] = a.w;
+  }
+}
+
 template <int HD>   // HD > 0: compile-time head dim (multiple of 4, float4 loads); HD == 0: runtime, scalar loads
 __global__ void __launch_bounds__(256) wattn_fwd_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
                                                         const float* __restrict__ v, int ldkv, float* __restrict__ o,
-                                                        int ldo, WinGeo g, float scale, int64_t npairs) {
-  const int ppb = 256 / g.N;
-  const int p_local = threadIdx.x / g.N, i = threadIdx.x % g.N;
-  if (p_local >= ppb) return;
-  const int64_t pair = (int64_t)blockIdx.x * ppb + p_local;
-  if (pair >= npairs) return;
-  const int head = (int)(pair % g.heads);
-  const int win = (int)(pair / g.heads);
+                                                        int ldo, WinGeo g, float scale, int64_t nwin) {
+  const WinThread t = win_thread(g, nwin);
+  if (!t.active) return;
   const int hd = HD > 0 ? HD : g.hd;
-  const int hoff = head * hd;
-  const float* qp = q + (int64_t)g.token(win, i) * ldq + hoff;
+  const int hoff = t.head * hd;
+  int tok[kMaxWin];
+#pragma unroll
+  for (int j = 0; j < kMaxWin; ++j) tok[j] = (j < g.N) ? g.token(t.win, j) : 0;
+  const int ti = g.token(t.win, t.i);
   float s[kMaxWin];
   float mx = -INFINITY;
+  if constexpr (HD > 0) {
+    float qr[HD];
+    load_row<HD>(qr, q + (int64_t)ti * ldq + hoff);
 #pragma unroll
-  for (int j = 0; j < kMaxWin; ++j) {
-    s[j] = -INFINITY;
-    if (j < g.N) {
-      const float* kp = k + (int64_t)g.token(win, j) * ldkv + hoff;
-      float acc = 0.f;
-      if constexpr (HD > 0) {
+    for (int d = 0; d < HD; ++d) qr[d] *= scale;
 #pragma unroll
-        for (int d = 0; d < HD; d += 4) {
-          const float4 a = *reinterpret_cast<const float4*>(qp + d);
-          const float4 b = *reinterpret_cast<const float4*>(kp + d);
-          acc += (a.x * scale) * b.x + (a.y * scale) * b.y + (a.z * scale) * b.z + (a.w * scale) * b.w;
-        }
-      } else {
-        for (int d = 0; d < hd; ++d) acc += (qp[d] * scale) * kp[d];
+    for (int j = 0; j < kMaxWin; ++j) {
+      s[j] = -INFINITY;
+      if (j < g.N) {
+        float kr[HD];
+        load_row<HD>(kr, k + (int64_t)tok[j] * ldkv + hoff);
+        float acc = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) acc += qr[d] * kr[d];
+        s[j] = acc;
+        mx = fmaxf(mx, acc);
       }
-      s[j] = acc;
-      mx = fmaxf(mx, acc);
+    }
+  } else {
+    const float* qp = q + (int64_t)ti * ldq + hoff;
+#pragma unroll
+    for (int j = 0; j < kMaxWin; ++j) {
+      s[j] = -INFINITY;
+      if (j < g.N) {
+        const float* kp = k + (int64_t)tok[j] * ldkv + hoff;
+        float acc = 0.f;
+        for (int d = 0; d < hd; ++d) acc += (qp[d] * scale) * kp[d];
+        s[j] = acc;
+        mx = fmaxf(mx, acc);
+      }
     }
   }
   float den = 0.f;
@@ -68,66 +104,87 @@ __global__ void __launch_bounds__(256) wattn_fwd_kernel(const float* __restrict_
     den += s[j];
   }
   const float inv = 1.0f / den;
-  float* op = o + (int64_t)g.token(win, i) * ldo + hoff;
+  float* op = o + (int64_t)ti * ldo + hoff;
   if constexpr (HD > 0) {
+    float acc[HD];
 #pragma unroll
-    for (int d = 0; d < HD; d += 4) {
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int d = 0; d < HD; ++d) acc[d] = 0.f;
 #pragma unroll
-      for (int j = 0; j < kMaxWin; ++j) {
-        if (j < g.N) {
-          const float4 b = *reinterpret_cast<const float4*>(v + (int64_t)g.token(win, j) * ldkv + hoff + d);
-          const float p = s[j] * inv;
-          acc.x += p * b.x; acc.y += p * b.y; acc.z += p * b.z; acc.w += p * b.w;
-        }
+    for (int j = 0; j < kMaxWin; ++j) {
+      if (j < g.N) {
+        float vr[HD];
+        load_row<HD>(vr, v + (int64_t)tok[j] * ldkv + hoff);
+        const float p = s[j] * inv;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) acc[d] += p * vr[d];
       }
-      *reinterpret_cast<float4*>(op + d) = acc;
     }
+#pragma unroll
+    for (int d = 0; d < HD; d += 4) *reinterpret_cast<float4*>(op + d) = make_float4(acc[d], acc[d + 1], acc[d + 2], acc[d + 3]);
   } else {
     for (int d = 0; d < hd; ++d) {
       float acc = 0.f;
-      for (int j = 0; j < g.N; ++j) acc += s[j] * inv * v[(int64_t)g.token(win, j) * ldkv + hoff + d];
+      for (int j = 0; j < g.N; ++j) acc += s[j] * inv * v[(int64_t)tok[j] * ldkv + hoff + d];
       op[d] = acc;
     }
   }
 }
 
-// Backward.  Phase 1: thread (pair, i) recomputes row i of P, dP = do v^T, dS = P (dP - sum_j P dP) and writes
-// dq_i = scale * dS k; P and dS rows go to LDS.  Phase 2: thread (pair, j) forms dk_j = scale * dS[:, j]^T q and
-// dv_j = P[:, j]^T do.
+// Backward.  Phase 1: thread (window, i, head) recomputes row i of P, dP = do v^T, dS = P (dP - sum_j P dP) and writes
+// dq_i = scale * dS k; P and dS rows go to LDS.  Phase 2: the same thread, now as key/value row j = i, forms
+// dk_j = scale * dS[:, j]^T q and dv_j = P[:, j]^T do from the LDS rows of its window mates.
 template <int HD>
 __global__ void __launch_bounds__(256) wattn_bwd_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
                                                         const float* __restrict__ v, int ldkv,
                                                         const float* __restrict__ d_o, int ldo, float* __restrict__ dq,
                                                         int lddq, float* __restrict__ dk, float* __restrict__ dv,
-                                                        int lddkv, WinGeo g, float scale, int64_t npairs) {
+                                                        int lddkv, WinGeo g, float scale, int64_t nwin) {
   __shared__ float Pm[256][kMaxWin + 1];
   __shared__ float Sm[256][kMaxWin + 1];
-  const int ppb = 256 / g.N;
-  const int p_local = threadIdx.x / g.N, i = threadIdx.x % g.N;
-  const int64_t pair = (int64_t)blockIdx.x * ppb + p_local;
-  const bool active = (p_local < ppb) && (pair < npairs);
-  const int head = active ? (int)(pair % g.heads) : 0;
-  const int win = active ? (int)(pair / g.heads) : 0;
+  const WinThread t = win_thread(g, nwin);
   const int hd = HD > 0 ? HD : g.hd;
-  const int hoff = head * hd;
-  if (active) {
-    const int ti = g.token(win, i);
-    const float* qp = q + (int64_t)ti * ldq + hoff;
-    const float* dop = d_o + (int64_t)ti * ldo + hoff;
+  const int hoff = t.head * hd;
+  int tok[kMaxWin];
+#pragma unroll
+  for (int j = 0; j < kMaxWin; ++j) tok[j] = (t.active && j < g.N) ? g.token(t.win, j) : 0;
+  if (t.active) {
+    const int ti = g.token(t.win, t.i);
     float s[kMaxWin], dp[kMaxWin];
     float mx = -INFINITY;
+    if constexpr (HD > 0) {
+      float qr[HD], dor[HD];
+      load_row<HD>(qr, q + (int64_t)ti * ldq + hoff);
+      load_row<HD>(dor, d_o + (int64_t)ti * ldo + hoff);
 #pragma unroll
-    for (int j = 0; j < kMaxWin; ++j) {
-      s[j] = -INFINITY; dp[j] = 0.f;
-      if (j < g.N) {
-        const int tj = g.token(win, j);
-        const float* kp = k + (int64_t)tj * ldkv + hoff;
-        const float* vp = v + (int64_t)tj * ldkv + hoff;
-        float a = 0.f, b = 0.f;
-        for (int d = 0; d < hd; ++d) { a += (qp[d] * scale) * kp[d]; b += dop[d] * vp[d]; }
-        s[j] = a; dp[j] = b;
-        mx = fmaxf(mx, a);
+      for (int d = 0; d < HD; ++d) qr[d] *= scale;
+#pragma unroll
+      for (int j = 0; j < kMaxWin; ++j) {
+        s[j] = -INFINITY; dp[j] = 0.f;
+        if (j < g.N) {
+          float kr[HD], vr[HD];
+          load_row<HD>(kr, k + (int64_t)tok[j] * ldkv + hoff);
+          load_row<HD>(vr, v + (int64_t)tok[j] * ldkv + hoff);
+          float a = 0.f, b = 0.f;
+#pragma unroll
+          for (int d = 0; d < HD; ++d) { a += qr[d] * kr[d]; b += dor[d] * vr[d]; }
+          s[j] = a; dp[j] = b;
+          mx = fmaxf(mx, a);
+        }
+      }
+    } else {
+      const float* qp = q + (int64_t)ti * ldq + hoff;
+      const float* dop = d_o + (int64_t)ti * ldo + hoff;
+#pragma unroll
+      for (int j = 0; j < kMaxWin; ++j) {
+        s[j] = -INFINITY; dp[j] = 0.f;
+        if (j < g.N) {
+          const float* kp = k + (int64_t)tok[j] * ldkv + hoff;
+          const float* vp = v + (int64_t)tok[j] * ldkv + hoff;
+          float a = 0.f, b = 0.f;
+          for (int d = 0; d < hd; ++d) { a += (qp[d] * scale) * kp[d]; b += dop[d] * vp[d]; }
+          s[j] = a; dp[j] = b;
+          mx = fmaxf(mx, a);
+        }
       }
     }
     float den = 0.f;
@@ -140,35 +197,73 @@ __global__ void __launch_bounds__(256) wattn_bwd_kernel(const float* __restrict_
 #pragma unroll
     for (int j = 0; j < kMaxWin; ++j) {
       const float ds = s[j] * (dp[j] - dot);
-      Pm[threadIdx.x][j] = s[j];
-      Sm[threadIdx.x][j] = ds;
+      Pm[t.local][j] = s[j];
+      Sm[t.local][j] = ds;
       dp[j] = ds;
     }
     float* dqp = dq + (int64_t)ti * lddq + hoff;
-    for (int d = 0; d < hd; ++d) {
-      float acc = 0.f;
+    if constexpr (HD > 0) {
+      float acc[HD];
 #pragma unroll
-      for (int j = 0; j < kMaxWin; ++j)
-        if (j < g.N) acc += dp[j] * k[(int64_t)g.token(win, j) * ldkv + hoff + d];
-      dqp[d] = acc * scale;
+      for (int d = 0; d < HD; ++d) acc[d] = 0.f;
+#pragma unroll
+      for (int j = 0; j < kMaxWin; ++j) {
+        if (j < g.N) {
+          float kr[HD];
+          load_row<HD>(kr, k + (int64_t)tok[j] * ldkv + hoff);
+#pragma unroll
+          for (int d = 0; d < HD; ++d) acc[d] += dp[j] * kr[d];
+        }
+      }
+#pragma unroll
+      for (int d = 0; d < HD; d += 4)
+        *reinterpret_cast<float4*>(dqp + d) = make_float4(acc[d] * scale, acc[d + 1] * scale, acc[d + 2] * scale, acc[d + 3] * scale);
+    } else {
+      for (int d = 0; d < hd; ++d) {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < kMaxWin; ++j)
+          if (j < g.N) acc += dp[j] * k[(int64_t)tok[j] * ldkv + hoff + d];
+        dqp[d] = acc * scale;
+      }
     }
   }
   __syncthreads();
-  if (active) {
-    const int j = i;                       // this thread now owns key/value row j of its pair
-    const int tj = g.token(win, j);
-    const int base = p_local * g.N;
-    float* dkp = dk + (int64_t)tj * lddkv + hoff;
-    float* dvp = dv + (int64_t)tj * lddkv + hoff;
-    for (int d = 0; d < hd; ++d) {
-      float ak = 0.f, av = 0.f;
-      for (int ii = 0; ii < g.N; ++ii) {
-        const int t2 = g.token(win, ii);
-        ak += Sm[base + ii][j] * q[(int64_t)t2 * ldq + hoff + d];
-        av += Pm[base + ii][j] * d_o[(int64_t)t2 * ldo + hoff + d];
+  if (t.active) {
+    const int j = t.i;                      // this thread now owns key/value row j of its (window, head)
+    const int base = t.local - t.i * g.heads;          // LDS row of (window, i = 0, head); row of i = base + i*heads
+    float* dkp = dk + (int64_t)g.token(t.win, j) * lddkv + hoff;
+    float* dvp = dv + (int64_t)g.token(t.win, j) * lddkv + hoff;
+    if constexpr (HD > 0) {
+      float ak[HD], av[HD];
+#pragma unroll
+      for (int d = 0; d < HD; ++d) { ak[d] = 0.f; av[d] = 0.f; }
+#pragma unroll
+      for (int ii = 0; ii < kMaxWin; ++ii) {
+        if (ii < g.N) {
+          float qr[HD], dor[HD];
+          load_row<HD>(qr, q + (int64_t)tok[ii] * ldq + hoff);
+          load_row<HD>(dor, d_o + (int64_t)tok[ii] * ldo + hoff);
+          const float sd = Sm[base + ii * g.heads][j], pp = Pm[base + ii * g.heads][j];
+#pragma unroll
+          for (int d = 0; d < HD; ++d) { ak[d] += sd * qr[d]; av[d] += pp * dor[d]; }
+        }
       }
-      dkp[d] = ak * scale;
-      dvp[d] = av;
+#pragma unroll
+      for (int d = 0; d < HD; d += 4) {
+        *reinterpret_cast<float4*>(dkp + d) = make_float4(ak[d] * scale, ak[d + 1] * scale, ak[d + 2] * scale, ak[d + 3] * scale);
+        *reinterpret_cast<float4*>(dvp + d) = make_float4(av[d], av[d + 1], av[d + 2], av[d + 3]);
+      }
+    } else {
+      for (int d = 0; d < hd; ++d) {
+        float ak = 0.f, av = 0.f;
+        for (int ii = 0; ii < g.N; ++ii) {
+          ak += Sm[base + ii * g.heads][j] * q[(int64_t)tok[ii] * ldq + hoff + d];
+          av += Pm[base + ii * g.heads][j] * d_o[(int64_t)tok[ii] * ldo + hoff + d];
+        }
+        dkp[d] = ak * scale;
+        dvp[d] = av;
+      }
     }
   }
 }
@@ -177,7 +272,7 @@ static int make_geo(WinGeo& g, int B, int D, int H, int W, int C, int heads, int
   if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || heads <= 0 || wd <= 0 || wh <= 0 || ww <= 0) return MICF_EINVAL;
   if (C % heads != 0) return MICF_EINVAL;
   if (D % wd || H % wh || W % ww) return MICF_EINVAL;       // the host pads to window multiples first
-  if (wd * wh * ww > kMaxWin) return MICF_EUNSUPPORTED;
+  if (wd * wh * ww > kMaxWin || wd * wh * ww * heads > 256) return MICF_EUNSUPPORTED;
   g = WinGeo{B, D, H, W, wd, wh, ww, wd * wh * ww, heads, C / heads, D / wd, H / wh, W / ww};
   return MICF_OK;
 }
@@ -192,16 +287,15 @@ extern "C" int micf_window_attn_fwd(const float* q, int ldq, const float* k, con
   WinGeo g;
   int rc = make_geo(g, B, D, H, W, C, heads, wd, wh, ww);
   if (rc) return rc;
-  const int64_t npairs = (int64_t)B * g.nwd * g.nwh * g.nww * heads;
-  const int ppb = 256 / g.N;
-  const dim3 grid(ceil_div(npairs, ppb));
+  const int64_t nwin = (int64_t)B * g.nwd * g.nwh * g.nww;
+  const dim3 grid(ceil_div(nwin, 256 / (g.N * heads)));
   const bool vec = (g.hd % 4 == 0) && (ldq % 4 == 0) && (ldkv % 4 == 0) && (ldo % 4 == 0) && aligned16(q) &&
                    aligned16(k) && aligned16(v) && aligned16(o);
   hipStream_t s = (hipStream_t)stream;
-  if (vec && g.hd == 16) hipLaunchKernelGGL(wattn_fwd_kernel<16>, grid, dim3(256), 0, s, q, ldq, k, v, ldkv, o, ldo, g, scale, npairs);
-  else if (vec && g.hd == 8) hipLaunchKernelGGL(wattn_fwd_kernel<8>, grid, dim3(256), 0, s, q, ldq, k, v, ldkv, o, ldo, g, scale, npairs);
-  else if (vec && g.hd == 32) hipLaunchKernelGGL(wattn_fwd_kernel<32>, grid, dim3(256), 0, s, q, ldq, k, v, ldkv, o, ldo, g, scale, npairs);
-  else hipLaunchKernelGGL(wattn_fwd_kernel<0>, grid, dim3(256), 0, s, q, ldq, k, v, ldkv, o, ldo, g, scale, npairs);
+  if (vec && g.hd == 16) hipLaunchKernelGGL(wattn_fwd_kernel<16>, grid, dim3(256), 0, s, q, ldq, k, v, ldkv, o, ldo, g, scale, nwin);
+  else if (vec && g.hd == 8) hipLaunchKernelGGL(wattn_fwd_kernel<8>, grid, dim3(256), 0, s, q, ldq, k, v, ldkv, o, ldo, g, scale, nwin);
+  else if (vec && g.hd == 32) hipLaunchKernelGGL(wattn_fwd_kernel<32>, grid, dim3(256), 0, s, q, ldq, k, v, ldkv, o, ldo, g, scale, nwin);
+  else hipLaunchKernelGGL(wattn_fwd_kernel<0>, grid, dim3(256), 0, s, q, ldq, k, v, ldkv, o, ldo, g, scale, nwin);
   MICF_RETURN_LAUNCH();
 }
 
@@ -212,10 +306,17 @@ extern "C" int micf_window_attn_bwd(const float* q, int ldq, const float* k, con
   WinGeo g;
   int rc = make_geo(g, B, D, H, W, C, heads, wd, wh, ww);
   if (rc) return rc;
-  const int64_t npairs = (int64_t)B * g.nwd * g.nwh * g.nww * heads;
-  const int ppb = 256 / g.N;
-  const dim3 grid(ceil_div(npairs, ppb));
-  hipLaunchKernelGGL(wattn_bwd_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, q, ldq, k, v, ldkv, d_o, ldo, dq, lddq,
-                     dk, dv, lddkv, g, scale, npairs);
+  const int64_t nwin = (int64_t)B * g.nwd * g.nwh * g.nww;
+  const dim3 grid(ceil_div(nwin, 256 / (g.N * heads)));
+  const bool vec = (g.hd % 4 == 0) && (ldq % 4 == 0) && (ldkv % 4 == 0) && (ldo % 4 == 0) && (lddq % 4 == 0) &&
+                   (lddkv % 4 == 0) && aligned16(q) && aligned16(k) && aligned16(v) && aligned16(d_o) && aligned16(dq) &&
+                   aligned16(dk) && aligned16(dv);
+  hipStream_t s = (hipStream_t)stream;
+#define MICF_BWD(HD_) hipLaunchKernelGGL(wattn_bwd_kernel<HD_>, grid, dim3(256), 0, s, q, ldq, k, v, ldkv, d_o, ldo, dq, lddq, dk, dv, lddkv, g, scale, nwin)
+  if (vec && g.hd == 16) MICF_BWD(16);
+  else if (vec && g.hd == 8) MICF_BWD(8);
+  else if (vec && g.hd == 32) MICF_BWD(32);
+  else MICF_BWD(0);
+#undef MICF_BWD
   MICF_RETURN_LAUNCH();
 }

@@ -5,7 +5,21 @@ argument order follows include/micformer_hip.h.
 """
 import torch
 
+from . import _lib
 from ._lib import call, f32, ptr
+
+
+DETAIL = False   # profiler: key entries by shape as well as by entry point
+
+
+def _cost(flops, *tensors, tag=None):
+    """(algorithmic bytes, flops[, shape tag]) of one launch for bench.py's profiler: every listed tensor is moved once."""
+    if _lib.PROFILE is None:
+        return None
+    c = (sum(t.numel() * t.element_size() for t in tensors if t is not None), int(flops))
+    if DETAIL:
+        c = c + (tag if tag is not None else "x".join(str(t.shape[0]) + "." + str(t.shape[-1]) for t in tensors[:2] if t is not None),)
+    return c
 
 _empty = torch.empty
 
@@ -23,7 +37,8 @@ def layernorm_fwd(x1, gamma, beta, eps, x2=None):
     mean = _new(x1, rows)
     rstd = _new(x1, rows)
     call("micf_layernorm_fwd", f32(x1), f32(x2), c1, f32(gamma), f32(beta), f32(y), f32(mean), f32(rstd), rows, C,
-         float(eps))
+         float(eps),
+         cost=_cost(8 * rows * C, x1, x2, y))
     return y, mean, rstd
 
 
@@ -34,7 +49,8 @@ def layernorm_bwd(dy, x1, mean, rstd, gamma, dgamma, dbeta, x2=None, add=None):
     dx1 = _new(x1, rows, c1)
     dx2 = _new(x1, rows, C - c1) if x2 is not None else None
     call("micf_layernorm_bwd", f32(dy), f32(x1), f32(x2), c1, f32(mean), f32(rstd), f32(gamma), f32(dx1), f32(dx2),
-         f32(dgamma), f32(dbeta), rows, C, f32(add))
+         f32(dgamma), f32(dbeta), rows, C, f32(add),
+         cost=_cost(12 * rows * C, dy, x1, x2, dx1, dx2, add))
     return (dx1, dx2) if x2 is not None else dx1
 
 
@@ -46,7 +62,8 @@ def linear_fwd(a1, w, bias, a2=None, resid=None, dp_scale=None, rows_per_sample=
     y = _new(a1, M, N)
     pre = _new(a1, M, N) if want_pre else None
     call("micf_linear_fwd", f32(a1), f32(a2), k1, f32(w), f32(bias), f32(resid), f32(dp_scale), rows_per_sample,
-         f32(y), f32(pre), M, N, K, act)
+         f32(y), f32(pre), M, N, K, act,
+         cost=_cost(2 * M * N * K, a1, a2, w, resid, y, pre, tag=f'{M}x{N}x{K}'))
     return (y, pre) if want_pre else y
 
 
@@ -61,7 +78,8 @@ def linear_bwd_data(dy, w, dp_scale=None, rows_per_sample=0, pre_act=None, k1=No
         da1 = _new(dy, M, k1)
         da2 = _new(dy, M, K - k1) if k1 < K else None
     call("micf_linear_bwd_data", f32(dy), f32(dp_scale), rows_per_sample, f32(w), f32(pre_act), f32(da1), f32(da2), k1,
-         1 if accumulate else 0, M, N, K)
+         1 if accumulate else 0, M, N, K,
+         cost=_cost(2 * M * N * K, dy, w, pre_act, da1, da2, tag=f'{M}x{N}x{K}'))
     return (da1, da2) if da2 is not None else da1
 
 
@@ -71,7 +89,8 @@ def linear_bwd_weight(dy, a1, dw, dbias, a2=None, dp_scale=None, rows_per_sample
     k1 = a1.shape[1]
     K = dw.shape[1]
     call("micf_linear_bwd_weight", f32(dy), f32(dp_scale), rows_per_sample, f32(a1), f32(a2), k1, 1 if a_gelu else 0,
-         f32(dw), f32(dbias), M, N, K)
+         f32(dw), f32(dbias), M, N, K,
+         cost=_cost(2 * M * N * K, dy, a1, a2, dw, tag=f'{M}x{N}x{K}'))
 
 
 # ----------------------------------------------------------------------------- window attention
@@ -80,7 +99,8 @@ def window_attn_fwd(q, kv, dims, heads, ws, scale):
     T, C = q.shape
     o = _new(q, T, C)
     call("micf_window_attn_fwd", f32(q), C, f32(kv), kv.data_ptr() + 4 * C, 2 * C, f32(o), C, B, D, H, W, C, heads,
-         ws[0], ws[1], ws[2], float(scale))
+         ws[0], ws[1], ws[2], float(scale),
+         cost=_cost(4 * T * C * ws[0] * ws[1] * ws[2], q, kv, o))
     return o
 
 
@@ -90,7 +110,8 @@ def window_attn_bwd(q, kv, d_o, dims, heads, ws, scale):
     dq = _new(q, T, C)
     dkv = _new(q, T, 2 * C)
     call("micf_window_attn_bwd", f32(q), C, f32(kv), kv.data_ptr() + 4 * C, 2 * C, f32(d_o), C, f32(dq), C, f32(dkv),
-         dkv.data_ptr() + 4 * C, 2 * C, B, D, H, W, C, heads, ws[0], ws[1], ws[2], float(scale))
+         dkv.data_ptr() + 4 * C, 2 * C, B, D, H, W, C, heads, ws[0], ws[1], ws[2], float(scale),
+         cost=_cost(8 * T * C * ws[0] * ws[1] * ws[2], q, kv, d_o, dq, dkv))
     return dq, dkv
 
 
@@ -101,7 +122,8 @@ def conv3_fwd(x1, w, bias, dims, x2=None, ncdhw_out=False):
     c2 = x2.shape[-1] if x2 is not None else 0
     N = w.shape[0]
     y = _new(x1, B, N, D, H, W) if ncdhw_out else _new(x1, B * D * H * W, N)
-    call("micf_conv3_fwd", f32(x1), c1, f32(x2), c2, f32(w), f32(bias), f32(y), 1 if ncdhw_out else 0, B, D, H, W, N)
+    call("micf_conv3_fwd", f32(x1), c1, f32(x2), c2, f32(w), f32(bias), f32(y), 1 if ncdhw_out else 0, B, D, H, W, N,
+         cost=_cost(2 * B * D * H * W * 27 * (c1 + c2) * N, x1, x2, w, y))
     return y
 
 
@@ -114,7 +136,8 @@ def conv3_bwd_data(dy, w, dims, c1, c2=0, ncdhw=False, dx1=None, dx2=None, acc1=
     if dx2 is None and want2 and c2 > 0:
         dx2 = _new(dy, T, c2)
     call("micf_conv3_bwd_data", f32(dy), 1 if ncdhw else 0, f32(w), f32(dx1), c1, 1 if acc1 else 0, f32(dx2), c2,
-         1 if acc2 else 0, B, D, H, W, N)
+         1 if acc2 else 0, B, D, H, W, N,
+         cost=_cost(2 * T * 27 * (c1 + c2) * N, dy, w, dx1, dx2))
     return dx1, dx2
 
 
@@ -123,7 +146,8 @@ def conv3_bwd_weight(dy, x1, dw, dbias, dims, x2=None, ncdhw=False):
     c1 = x1.shape[-1]
     c2 = x2.shape[-1] if x2 is not None else 0
     N = dw.shape[0]
-    call("micf_conv3_bwd_weight", f32(dy), 1 if ncdhw else 0, f32(x1), c1, f32(x2), c2, f32(dw), f32(dbias), B, D, H, W, N)
+    call("micf_conv3_bwd_weight", f32(dy), 1 if ncdhw else 0, f32(x1), c1, f32(x2), c2, f32(dw), f32(dbias), B, D, H, W, N,
+         cost=_cost(2 * B * D * H * W * 27 * (c1 + c2) * N, dy, x1, x2, dw))
 
 
 # ----------------------------------------------------------------------------- offset head + deformable sampling
@@ -133,7 +157,8 @@ def offset_sample_fwd(h, ln_g, ln_b, w1, xa, dims, eps):
     flow = _new(xa, T, 3)
     xs = _new(xa, T, C)
     call("micf_offset_sample_fwd", f32(h), f32(ln_g), f32(ln_b), f32(w1), f32(xa), f32(flow), f32(xs), B, D, H, W, C,
-         float(eps))
+         float(eps),
+         cost=_cost(T * (16 * C + 400), h, xa, flow, xs))
     return flow, xs
 
 
@@ -143,7 +168,8 @@ def offset_sample_bwd(dxs, h, ln_g, ln_b, w1, xa, flow, dxa, dln_g, dln_b, dw1, 
     T, C = xa.shape
     dh = _new(xa, T, h.shape[1])
     call("micf_offset_sample_bwd", f32(dxs), f32(h), f32(ln_g), f32(ln_b), f32(w1), f32(xa), f32(flow), f32(dxa), f32(dh),
-         f32(dln_g), f32(dln_b), f32(dw1), B, D, H, W, C, float(eps))
+         f32(dln_g), f32(dln_b), f32(dw1), B, D, H, W, C, float(eps),
+         cost=_cost(T * (40 * C + 800), dxs, h, xa, flow, dxa, dxa, dh))
     return dh
 
 
@@ -169,21 +195,24 @@ def patch_embed_fwd(vol, mod, w, bias, p):
     E = w.shape[0]
     Dc, Hc, Wc = -(-D // p), -(-H // p), -(-W // p)
     y = _new(vol, B, Dc, Hc, Wc, E)
-    call("micf_patch_embed_fwd", f32(vol), nmod, mod, f32(w), f32(bias), f32(y), B, D, H, W, E, p)
+    call("micf_patch_embed_fwd", f32(vol), nmod, mod, f32(w), f32(bias), f32(y), B, D, H, W, E, p,
+         cost=_cost(2 * y.numel() * p ** 3, y, w) if _lib.PROFILE is not None else None)
     return y
 
 
 def patch_embed_bwd_weight(dy, vol, mod, dw, dbias, p):
     B, nmod, D, H, W = vol.shape
     E = dw.shape[0]
-    call("micf_patch_embed_bwd_weight", f32(dy), f32(vol), nmod, mod, f32(dw), f32(dbias), B, D, H, W, E, p)
+    call("micf_patch_embed_bwd_weight", f32(dy), f32(vol), nmod, mod, f32(dw), f32(dbias), B, D, H, W, E, p,
+         cost=_cost(2 * dy.numel() * p ** 3, dy, dw))
 
 
 def conv_down_fwd(x, w, bias):
     B, D, H, W, C = x.shape
     N = w.shape[0]
     y = _new(x, B, -(-D // 2), -(-H // 2), -(-W // 2), N)
-    call("micf_conv_down_fwd", f32(x), f32(w), f32(bias), f32(y), B, D, H, W, C, N)
+    call("micf_conv_down_fwd", f32(x), f32(w), f32(bias), f32(y), B, D, H, W, C, N,
+         cost=_cost(2 * y.numel() * 8 * C, x, w, y))
     return y
 
 
@@ -191,21 +220,24 @@ def conv_down_bwd_data(dy, w, xshape):
     B, D, H, W, C = xshape
     N = w.shape[0]
     dx = _new(dy, B, D, H, W, C)
-    call("micf_conv_down_bwd_data", f32(dy), f32(w), f32(dx), B, D, H, W, C, N)
+    call("micf_conv_down_bwd_data", f32(dy), f32(w), f32(dx), B, D, H, W, C, N,
+         cost=_cost(2 * dy.numel() * 8 * C, dy, w, dx))
     return dx
 
 
 def conv_down_bwd_weight(dy, x, dw, dbias):
     B, D, H, W, C = x.shape
     N = dw.shape[0]
-    call("micf_conv_down_bwd_weight", f32(dy), f32(x), f32(dw), f32(dbias), B, D, H, W, C, N)
+    call("micf_conv_down_bwd_weight", f32(dy), f32(x), f32(dw), f32(dbias), B, D, H, W, C, N,
+         cost=_cost(2 * dy.numel() * 8 * C, dy, x, dw))
 
 
 def conv_up_fwd(x, w, bias, k):
     B, D, H, W, C = x.shape
     N = w.shape[1]
     y = _new(x, B, D * k, H * k, W * k, N)
-    call("micf_conv_up_fwd", f32(x), f32(w), f32(bias), f32(y), B, D, H, W, C, N, k)
+    call("micf_conv_up_fwd", f32(x), f32(w), f32(bias), f32(y), B, D, H, W, C, N, k,
+         cost=_cost(2 * y.numel() * C, x, w, y))
     return y
 
 
@@ -213,14 +245,16 @@ def conv_up_bwd_data(dy, w, xshape, k):
     B, D, H, W, C = xshape
     N = w.shape[1]
     dx = _new(dy, B, D, H, W, C)
-    call("micf_conv_up_bwd_data", f32(dy), f32(w), f32(dx), B, D, H, W, C, N, k)
+    call("micf_conv_up_bwd_data", f32(dy), f32(w), f32(dx), B, D, H, W, C, N, k,
+         cost=_cost(2 * dy.numel() * C, dy, w, dx))
     return dx
 
 
 def conv_up_bwd_weight(dy, x, dw, dbias, k):
     B, D, H, W, C = x.shape
     N = dw.shape[1]
-    call("micf_conv_up_bwd_weight", f32(dy), f32(x), f32(dw), f32(dbias), B, D, H, W, C, N, k)
+    call("micf_conv_up_bwd_weight", f32(dy), f32(x), f32(dw), f32(dbias), B, D, H, W, C, N, k,
+         cost=_cost(2 * dy.numel() * C, dy, x, dw))
 
 
 # ----------------------------------------------------------------------------- pad / crop / resize
@@ -262,7 +296,8 @@ def dice_bce_fwd(logits, target):
     V = logits[0, 0].numel()
     sums = _new(logits, K * 4, dtype=torch.float64)
     loss = _new(logits, 1)
-    call("micf_dice_bce_fwd", f32(logits), f32(target), ptr(sums), f32(loss), B, K, V)
+    call("micf_dice_bce_fwd", f32(logits), f32(target), ptr(sums), f32(loss), B, K, V,
+         cost=_cost(30 * logits.numel(), logits, target))
     return loss, sums
 
 
@@ -270,7 +305,8 @@ def dice_bce_bwd(logits, target, sums, grad_out):
     B, K = logits.shape[:2]
     V = logits[0, 0].numel()
     dz = torch.empty_like(logits)
-    call("micf_dice_bce_bwd", f32(logits), f32(target), ptr(sums), f32(grad_out), f32(dz), B, K, V)
+    call("micf_dice_bce_bwd", f32(logits), f32(target), ptr(sums), f32(grad_out), f32(dz), B, K, V,
+         cost=_cost(30 * logits.numel(), logits, target, dz))
     return dz
 
 
@@ -297,4 +333,5 @@ def adam_tick(state, base_lr, eta_min, t_max):
 
 
 def adam_step(p, g, m, v, state, beta1=0.9, beta2=0.999, eps=1e-8):
-    call("micf_adam_step", f32(p), f32(g), f32(m), f32(v), p.numel(), ptr(state), float(beta1), float(beta2), float(eps))
+    call("micf_adam_step", f32(p), f32(g), f32(m), f32(v), p.numel(), ptr(state), float(beta1), float(beta2), float(eps),
+         cost=_cost(12 * p.numel(), p, p, g, m, m, v, v))

@@ -16,11 +16,15 @@ namespace micf {
 // token <-> (b, d, h, w) on a channels-last grid
 struct Geo {
   int B, D, H, W;
+  FastDiv fW, fH, fD;
+  Geo() {}
+  Geo(int B_, int D_, int H_, int W_) : B(B_), D(D_), H(H_), W(W_), fW((uint32_t)W_), fH((uint32_t)H_), fD((uint32_t)D_) {}
   __host__ __device__ int64_t tokens() const { return (int64_t)B * D * H * W; }
   __device__ __forceinline__ void decode(int t, int& b, int& d, int& h, int& w) const {
-    w = t % W; t /= W;
-    h = t % H; t /= H;
-    d = t % D; b = t / D;
+    uint32_t q, r;
+    fW.divmod((uint32_t)t, q, r); w = (int)r;
+    fH.divmod(q, q, r); h = (int)r;
+    fD.divmod(q, q, r); d = (int)r; b = (int)q;
   }
   __device__ __forceinline__ int token(int b, int d, int h, int w) const { return ((b * D + d) * H + h) * W + w; }
 };

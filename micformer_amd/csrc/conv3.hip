@@ -2,14 +2,18 @@
 // MFMA core: the halo gather, the concatenation of the two input modalities and the NCDHW <-> channels-last
 // conversion of the logits are accessor index math (no im2col, no torch.cat, no permute copies).
 // Replaces conv_offset[0] on cat[LN(x), xa] (MS.py:314, 354-356) and Head.out_conv (MS.py:1046, 1053).
+// Orientation (gemm_core.h): the tile's I side is whatever is contiguous in the OUTPUT -- the 16 hidden channels for the
+// channels-last offset conv, the voxels for the NCDHW logits, the input channels for d(input).
 #include "common.h"
 
 namespace micf {
 
-// P operand of the forward: (x = token, r = tap*Cin + c) -> input[nbr(token, tap), c], zero outside the volume.
-// sign = +1: nbr = token + (tap - 1)   (forward / weight gradient)
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float a, float b, float c, float d) { *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d); }
+
+// input [x1 (c1) | x2 (c2)] at the 27 neighbours of a token; zero outside the volume
 struct Conv3In {
-  const float* x1; const float* x2; int c1, c2, Cin; Geo g; int X; int vec;
+  const float* x1; const float* x2; int c1, c2, Cin; Geo g; int X; int vec; FastDiv fCin;
   __device__ __forceinline__ bool nbr(int t, int tap, int& tn) const {
     int b, d, h, w; g.decode(t, b, d, h, w);
     const int dd = d + tap / 9 - 1, hh = h + (tap / 3) % 3 - 1, ww = w + tap % 3 - 1;
@@ -20,31 +24,30 @@ struct Conv3In {
   __device__ __forceinline__ float at(int tn, int c) const {
     return c < c1 ? x1[(int64_t)tn * c1 + c] : x2[(int64_t)tn * c2 + (c - c1)];
   }
-  // 4 consecutive channels of one (token, tap); zero-filled when outside
+  // 4 consecutive channels of one (token, tap) at reduction index r = tap*Cin + c; zero-filled when outside
   __device__ __forceinline__ void load4(int t, int r, int r_lim, float* v) const {
     v[0] = v[1] = v[2] = v[3] = 0.f;
     if (vec) {
       if (r >= r_lim) return;
-      const int tap = r / Cin, c = r - tap * Cin;
+      uint32_t tap, c; fCin.divmod((uint32_t)r, tap, c);
       int tn;
-      if (!nbr(t, tap, tn)) return;
-      const float4 q = c < c1 ? *reinterpret_cast<const float4*>(x1 + (int64_t)tn * c1 + c)
-                              : *reinterpret_cast<const float4*>(x2 + (int64_t)tn * c2 + (c - c1));
+      if (!nbr(t, (int)tap, tn)) return;
+      const float4 q = (int)c < c1 ? ld4(x1 + (int64_t)tn * c1 + c) : ld4(x2 + (int64_t)tn * c2 + (c - c1));
       v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
     } else {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int rr = r + e;
         if (rr >= r_lim) continue;
-        const int tap = rr / Cin, c = rr - tap * Cin;
+        uint32_t tap, c; fCin.divmod((uint32_t)rr, tap, c);
         int tn;
-        if (nbr(t, tap, tn)) v[e] = at(tn, c);
+        if (nbr(t, (int)tap, tn)) v[e] = at(tn, (int)c);
       }
     }
   }
 };
 
-struct Conv3FwdP {   // T mapping: x = token, r = tap*Cin + c
+struct Conv3TokT {   // T mapping: x = token, r = tap*Cin + c
   Conv3In in;
   template <int BX> using Stage = StageT<BX>;
   template <int BX>
@@ -55,7 +58,7 @@ struct Conv3FwdP {   // T mapping: x = token, r = tap*Cin + c
   }
 };
 
-struct Conv3WgtQ {   // D mapping: x = tap*Cin + c (4 consecutive c), r = token
+struct Conv3ColD {   // D mapping: x = tap*Cin + c (4 consecutive c), r = token
   Conv3In in; int J;
   template <int BX> using Stage = StageD<BX>;
   template <int BX>
@@ -68,69 +71,97 @@ struct Conv3WgtQ {   // D mapping: x = tap*Cin + c (4 consecutive c), r = token
 
 // weights w[n][c][tap] seen as (x = n, r = tap*Cin + c)  [forward]   or   (x = c, r = tap*N + n)  [data gradient]
 struct Conv3WFwd {
-  const float* w; int Cin;
+  const float* w; int Cin; FastDiv fCin;
   __device__ __forceinline__ float operator()(int x, int r) const {
-    const int tap = r / Cin, c = r - tap * Cin;
+    uint32_t tap, c; fCin.divmod((uint32_t)r, tap, c);
     return w[((int64_t)x * Cin + c) * 27 + tap];
   }
 };
 struct Conv3WBwd {
-  const float* w; int Cin, N;
+  const float* w; int Cin; FastDiv fN;
   __device__ __forceinline__ float operator()(int x, int r) const {
-    const int tap = r / N, n = r - tap * N;
+    uint32_t tap, n; fN.divmod((uint32_t)r, tap, n);
     return w[((int64_t)n * Cin + x) * 27 + tap];
   }
 };
 
 // dy seen from the INPUT token: (x = token, r = tap*N + n) -> dy[token - (tap - 1), n]
 struct Conv3DyGather {
-  const float* dy; int layout, N; Geo g; int64_t DHW;
+  const float* dy; int layout, N; Geo g; int64_t DHW; FastDiv fN;
   __device__ __forceinline__ float operator()(int x, int r) const {
-    const int tap = r / N, n = r - tap * N;
+    uint32_t tap, n; fN.divmod((uint32_t)r, tap, n);
     int b, d, h, w; g.decode(x, b, d, h, w);
-    const int dd = d - (tap / 9 - 1), hh = h - ((tap / 3) % 3 - 1), ww = w - (tap % 3 - 1);
+    const int dd = d - ((int)tap / 9 - 1), hh = h - (((int)tap / 3) % 3 - 1), ww = w - ((int)tap % 3 - 1);
     if ((unsigned)dd >= (unsigned)g.D || (unsigned)hh >= (unsigned)g.H || (unsigned)ww >= (unsigned)g.W) return 0.f;
     const int64_t vox = ((int64_t)dd * g.H + hh) * g.W + ww;
     return layout == 0 ? dy[((int64_t)b * DHW + vox) * N + n] : dy[((int64_t)b * N + n) * DHW + vox];
   }
 };
-// dy as (x = n, r = token)
-struct Conv3DyT {
-  const float* dy; int layout, N; int64_t DHW;
+// NCDHW dy as (x = n, r = token)
+struct Conv3DyPlanes {
+  const float* dy; int N; int64_t DHW; FastDiv fDHW;
   __device__ __forceinline__ float operator()(int x, int r) const {
-    if (layout == 0) return dy[(int64_t)r * N + x];
-    const int64_t b = r / DHW, vox = r - b * DHW;
-    return dy[(b * N + x) * DHW + vox];
+    uint32_t b, vox; fDHW.divmod((uint32_t)r, b, vox);
+    return dy[((int64_t)b * N + x) * DHW + vox];
   }
 };
 
-struct Conv3FwdEpi {
-  const float* bias; float* y; int layout, N; int64_t DHW;
-  __device__ __forceinline__ void operator()(int i, int j, float v) const {
-    if (bias) v += bias[j];
-    if (layout == 0) y[(int64_t)i * N + j] = v;
-    else { const int64_t b = i / DHW, vox = i - b * DHW; y[(b * N + j) * DHW + vox] = v; }
+struct Conv3FwdClEpi {      // channels-last y[token j, n = i .. i+3]
+  const float* bias; float* y; int N, vec;
+  __device__ __forceinline__ void operator()(int i, int j, f32x4 v, int n) const {
+    float* p = y + (int64_t)j * N + i;
+    if (vec && n == 4) {
+      if (bias) { const float4 b = ld4(bias + i); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+      st4(p, v[0], v[1], v[2], v[3]);
+    } else {
+      MICF_FOR_N(n, e) p[e] = v[e] + (bias ? bias[i + e] : 0.f);
+    }
   }
 };
-struct Conv3FwdSplitEpi {   // y pre-zeroed; split 0 adds the bias; channels-last only
+struct Conv3FwdClSplitEpi {  // y pre-zeroed; reduction split 0 adds the bias
   const float* bias; float* y; int N;
-  __device__ __forceinline__ void operator()(int i, int j, float v) const {
-    if (bias && blockIdx.z == 0) v += bias[j];
-    atomicAdd(y + (int64_t)i * N + j, v);
+  __device__ __forceinline__ void operator()(int i, int j, f32x4 v, int n) const {
+    float* p = y + (int64_t)j * N + i;
+    MICF_FOR_N(n, e) atomicAdd(p + e, v[e] + ((bias && blockIdx.y == 0) ? bias[i + e] : 0.f));
   }
 };
-struct Conv3DataEpi {
-  float* d1; float* d2; int c1, c2, acc1, acc2;
-  __device__ __forceinline__ void operator()(int i, int j, float v) const {
-    if (j < c1) { if (d1) { float* p = d1 + (int64_t)i * c1 + j; *p = acc1 ? *p + v : v; } }
-    else if (d2) { float* p = d2 + (int64_t)i * c2 + (j - c1); *p = acc2 ? *p + v : v; }
+struct Conv3FwdPlanesEpi {   // NCDHW y[b, n = j, voxel i .. i+3]
+  const float* bias; float* y; int N; int64_t DHW; FastDiv fDHW; int vec;
+  __device__ __forceinline__ void operator()(int i, int j, f32x4 v, int n) const {
+    const float bb = bias ? bias[j] : 0.f;
+    uint32_t b, vox; fDHW.divmod((uint32_t)i, b, vox);
+    if (vec && n == 4) {           // DHW % 4 == 0: the 4 voxels stay inside one sample
+      st4(y + ((int64_t)b * N + j) * DHW + vox, v[0] + bb, v[1] + bb, v[2] + bb, v[3] + bb);
+    } else {
+      MICF_FOR_N(n, e) { fDHW.divmod((uint32_t)(i + e), b, vox); y[((int64_t)b * N + j) * DHW + vox] = v[e] + bb; }
+    }
+  }
+};
+struct Conv3DataEpi {        // dx[token j, c = i .. i+3] split over the two sources at c1
+  float* d1; float* d2; int c1, c2, acc1, acc2, vec;
+  __device__ __forceinline__ void operator()(int i, int j, f32x4 v, int n) const {
+    if (vec && n == 4) {
+      float* p; int acc;
+      if (i < c1) { if (!d1) return; p = d1 + (int64_t)j * c1 + i; acc = acc1; }
+      else { if (!d2) return; p = d2 + (int64_t)j * c2 + (i - c1); acc = acc2; }
+      if (acc) { const float4 o = ld4(p); v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
+      st4(p, v[0], v[1], v[2], v[3]);
+    } else {
+      MICF_FOR_N(n, e) {
+        const int c = i + e;
+        if (c < c1) { if (d1) { float* p = d1 + (int64_t)j * c1 + c; *p = acc1 ? *p + v[e] : v[e]; } }
+        else if (d2) { float* p = d2 + (int64_t)j * c2 + (c - c1); *p = acc2 ? *p + v[e] : v[e]; }
+      }
+    }
   }
 };
 struct Conv3WgtEpi {   // (i = tap*Cin + c, j = n) -> dw[n][c][tap]
-  float* dw; int Cin;
-  __device__ __forceinline__ void operator()(int i, int j, float v) const {
-    const int tap = i / Cin, c = i - tap * Cin;
-    atomicAdd(dw + ((int64_t)j * Cin + c) * 27 + tap, v);
+  float* dw; int Cin; FastDiv fCin;
+  __device__ __forceinline__ void operator()(int i, int j, f32x4 v, int n) const {
+    MICF_FOR_N(n, e) {
+      uint32_t tap, c; fCin.divmod((uint32_t)(i + e), tap, c);
+      atomicAdd(dw + ((int64_t)j * Cin + c) * 27 + tap, v[e]);
+    }
   }
 };
 
@@ -151,10 +182,16 @@ __global__ void __launch_bounds__(256) plane_sum_kernel(const float* __restrict_
 
 }  // namespace micf
 using namespace micf;
+#define RC(e) ((e) == hipSuccess ? MICF_OK : MICF_ELAUNCH)
 
 static bool conv3_args_ok(int B, int D, int H, int W, int N, int c1, int c2) {
   return B > 0 && D > 0 && H > 0 && W > 0 && N > 0 && c1 > 0 && c2 >= 0 && (int64_t)B * D * H * W < (1LL << 31) &&
          (int64_t)27 * (c1 + c2) * (int64_t)(N > c1 + c2 ? N : c1 + c2) < (1LL << 31);
+}
+
+static Conv3In make_in(const float* x1, int c1, const float* x2, int c2, const Geo& g) {
+  const int vec = (c1 % 4 == 0) && (c2 % 4 == 0) && aligned16(x1) && (!x2 || aligned16(x2));
+  return Conv3In{x1, x2 ? x2 : x1, c1, c2 > 0 ? c2 : 1, c1 + c2, g, (int)g.tokens(), vec, FastDiv((uint32_t)(c1 + c2))};
 }
 
 extern "C" int micf_conv3_fwd(const float* x1, int c1, const float* x2, int c2, const float* w, const float* bias,
@@ -163,17 +200,22 @@ extern "C" int micf_conv3_fwd(const float* x1, int c1, const float* x2, int c2, 
   const Geo g{B, D, H, W};
   const int Cin = c1 + c2;
   const int64_t T = g.tokens();
-  const int vec = (c1 % 4 == 0) && (c2 % 4 == 0) && aligned16(x1) && (!x2 || aligned16(x2));
-  Conv3FwdP pa{Conv3In{x1, x2 ? x2 : x1, c1, c2 > 0 ? c2 : 1, Cin, g, (int)T, vec}};
-  auto qa = make_elem<false>(Conv3WFwd{w, Cin}, N);
+  const int64_t DHW = (int64_t)D * H * W;
   hipStream_t s = (hipStream_t)stream;
-  const int splits = (y_layout == 0) ? pick_splits(T, N, 27 * Cin) : 1;
-  if (splits > 1) {   // small token grids (8^3, 4^3 stages): split the 27*Cin reduction over workgroups
-    if (hipMemsetAsync(y, 0, sizeof(float) * (size_t)T * N, s) != hipSuccess) return MICF_ELAUNCH;
-    return launch_gemm(pa, qa, Conv3FwdSplitEpi{bias, y, N}, T, N, 27 * Cin, splits, s) == hipSuccess ? MICF_OK : MICF_ELAUNCH;
+  Conv3TokT tok{make_in(x1, c1, x2, c2, g)};
+  auto wgt = make_elem<false>(Conv3WFwd{w, Cin, FastDiv((uint32_t)Cin)}, N);
+  if (y_layout == 0) {          // C[i = n, j = token]
+    const int splits = pick_splits(N, T, 27 * Cin);
+    if (splits > 1) {           // small token grids (8^3, 4^3 stages): split the 27*Cin reduction over workgroups
+      if (hipMemsetAsync(y, 0, sizeof(float) * (size_t)T * N, s) != hipSuccess) return MICF_ELAUNCH;
+      return RC(launch_gemm(wgt, tok, Conv3FwdClSplitEpi{bias, y, N}, N, T, 27 * Cin, splits, s));
+    }
+    const int vec = (N % 4 == 0) && aligned16(y) && (!bias || aligned16(bias));
+    return RC(launch_gemm(wgt, tok, Conv3FwdClEpi{bias, y, N, vec}, N, T, 27 * Cin, 1, s));
   }
-  Conv3FwdEpi epi{bias, y, y_layout, N, (int64_t)D * H * W};
-  return launch_gemm(pa, qa, epi, T, N, 27 * Cin, 1, s) == hipSuccess ? MICF_OK : MICF_ELAUNCH;
+  // NCDHW: C[i = token (voxels contiguous), j = n]
+  const int vec = (DHW % 4 == 0) && aligned16(y);
+  return RC(launch_gemm(tok, wgt, Conv3FwdPlanesEpi{bias, y, N, DHW, FastDiv((uint32_t)DHW), vec}, (int)T, N, 27 * Cin, 1, s));
 }
 
 extern "C" int micf_conv3_bwd_data(const float* dy, int dy_layout, const float* w, float* dx1, int c1, int acc1,
@@ -183,10 +225,14 @@ extern "C" int micf_conv3_bwd_data(const float* dy, int dy_layout, const float* 
   const Geo g{B, D, H, W};
   const int Cin = c1 + c2;
   const int64_t T = g.tokens();
-  auto pa = make_elem<true>(Conv3DyGather{dy, dy_layout, N, g, (int64_t)D * H * W}, (int)T);
-  auto qa = make_elem<false>(Conv3WBwd{w, Cin, N}, Cin);
-  Conv3DataEpi epi{dx1, dx2, c1, c2 > 0 ? c2 : 1, acc1, acc2};
-  return launch_gemm(pa, qa, epi, T, Cin, 27 * N, 1, (hipStream_t)stream) == hipSuccess ? MICF_OK : MICF_ELAUNCH;
+  // C[i = c, j = token] = sum_{tap, n} w[n][c][tap] * dy[token - (tap - 1), n]
+  auto pa = make_elem<false>(Conv3WBwd{w, Cin, FastDiv((uint32_t)N)}, Cin);
+  const Conv3DyGather gat{dy, dy_layout, N, g, (int64_t)D * H * W, FastDiv((uint32_t)N)};
+  const int vec = (c1 % 4 == 0) && (c2 % 4 == 0) && (!dx1 || aligned16(dx1)) && (!dx2 || aligned16(dx2));
+  Conv3DataEpi epi{dx1, dx2, c1, c2 > 0 ? c2 : 1, acc1, acc2, vec};
+  hipStream_t s = (hipStream_t)stream;
+  if (dy_layout == 0) return RC(launch_gemm(pa, make_elem<true>(gat, (int)T), epi, Cin, T, 27 * N, 1, s));   // n contiguous
+  return RC(launch_gemm(pa, make_elem<false>(gat, (int)T), epi, Cin, T, 27 * N, 1, s));                      // voxels contiguous
 }
 
 extern "C" int micf_conv3_bwd_weight(const float* dy, int dy_layout, const float* x1, int c1, const float* x2, int c2,
@@ -196,28 +242,19 @@ extern "C" int micf_conv3_bwd_weight(const float* dy, int dy_layout, const float
   const int Cin = c1 + c2;
   const int64_t T = g.tokens();
   const int64_t DHW = (int64_t)D * H * W;
-  const int vec = (c1 % 4 == 0) && (c2 % 4 == 0) && aligned16(x1) && (!x2 || aligned16(x2));
-  // dW^T[tap*Cin + c, n] = sum_t in[nbr(t, tap), c] * dy[t, n]: the long 27*Cin axis is the tile's I side (full MFMA rows),
-  // the narrow N (16 / 8) is its J side; the reduction over tokens is split across workgroups (atomic epilogue).
-  Conv3WgtQ pa{Conv3In{x1, x2 ? x2 : x1, c1, c2 > 0 ? c2 : 1, Cin, g, (int)T, vec}, 27 * Cin};
-  Conv3WgtEpi epi{dw, Cin};
+  // dW^T[i = tap*Cin + c, j = n] = sum_t in[nbr(t, tap), c] * dy[t, n]: the long 27*Cin axis is the tile's I side, the narrow
+  // N (16 / 8) its J side; the reduction over tokens is split across workgroups (atomic epilogue).
+  Conv3ColD pa{make_in(x1, c1, x2, c2, g), 27 * Cin};
+  Conv3WgtEpi epi{dw, Cin, FastDiv((uint32_t)Cin)};
   hipStream_t s = (hipStream_t)stream;
   const int splits = pick_splits(27 * Cin, N, T);
   hipError_t e;
   if (dy_layout == 0) {
-    RowsD qa{dy, dy, N, N, 1, N, nullptr, 1, 0, (N % 4 == 0) && aligned16(dy)};
-    e = launch_gemm(pa, qa, epi, 27 * Cin, N, (int)T, splits, s);
-  } else {
-    auto qa = make_elem<true>(Conv3DyT{dy, dy_layout, N, DHW}, N);
-    e = launch_gemm(pa, qa, epi, 27 * Cin, N, (int)T, splits, s);
+    // dbias = column sums of the dy slab in LDS (colsum side 2)
+    e = launch_gemm(pa, rows_d(dy, N, N), epi, 27 * Cin, N, (int)T, splits, s, dbias, dbias ? 2 : 0);
+    return RC(e);
   }
-  if (e != hipSuccess) return MICF_ELAUNCH;
-  if (dbias) {
-    if (dy_layout == 0) return colsum_atomic(dy, nullptr, 1, dbias, T, N, s);
-    int chunks = (int)((DHW + 65535) / 65536);
-    if (chunks < 1) chunks = 1;
-    hipLaunchKernelGGL(plane_sum_kernel, dim3(chunks, B * N), dim3(256), 0, s, dy, dbias, N, DHW, chunks);
-    MICF_RETURN_LAUNCH();
-  }
-  return MICF_OK;
+  e = launch_gemm(pa, make_elem<true>(Conv3DyPlanes{dy, N, DHW, FastDiv((uint32_t)DHW)}, N), epi, 27 * Cin, N, (int)T, splits, s,
+                  dbias, dbias ? 2 : 0);
+  return RC(e);
 }

@@ -5,21 +5,31 @@
 //   reverse_patch_embedding  ConvTranspose3d(2E->E/2, k=s=4)                        (MS.py:990, 1037)
 // Patch gather / pixel-shuffle scatter are accessor / epilogue index math on channels-last tensors; weights stay in
 // the reference's state_dict layout and are read through strided accessors (they are small and L2-resident).
+// Orientation (gemm_core.h): I = the channel axis that is contiguous in the output, J = coarse tokens.
 #include "common.h"
 
 namespace micf {
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float a, float b, float c, float d) { *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d); }
 
 // ---- geometry of a k-strided patch grid: coarse (B, Dc, Hc, Wc) <-> fine (B, D, H, W), fine = coarse*k + tap
 struct PatchGeo {
   int B, D, H, W;        // fine dims (actual, may be smaller than Dc*k: zero padding at the far end)
   int Dc, Hc, Wc, k;
+  FastDiv fWc, fHc, fDc;
   __device__ __forceinline__ void cdecode(int t, int& b, int& d, int& h, int& w) const {
-    w = t % Wc; t /= Wc; h = t % Hc; t /= Hc; d = t % Dc; b = t / Dc;
+    uint32_t q, r;
+    fWc.divmod((uint32_t)t, q, r); w = (int)r;
+    fHc.divmod(q, q, r); h = (int)r;
+    fDc.divmod(q, q, r); d = (int)r; b = (int)q;
   }
-  // fine voxel/token index of (coarse token, tap) or -1 when it falls in the zero padding
+  // fine voxel/token index of (coarse token, tap) or -1 when it falls in the zero padding (k is 2 or 4)
   __device__ __forceinline__ int64_t fine(int tc, int tap) const {
     int b, d, h, w; cdecode(tc, b, d, h, w);
-    const int kd = tap / (k * k), kh = (tap / k) % k, kw = tap % k;
+    int kd, kh, kw;
+    if (k == 2) { kd = tap >> 2; kh = (tap >> 1) & 1; kw = tap & 1; }
+    else { kd = tap >> 4; kh = (tap >> 2) & 3; kw = tap & 3; }
     const int fd = d * k + kd, fh = h * k + kh, fw = w * k + kw;
     if (fd >= D || fh >= H || fw >= W) return -1;
     return (((int64_t)b * D + fd) * H + fh) * W + fw;
@@ -30,32 +40,42 @@ struct PatchGeo {
 struct EmbedVol {
   const float* vol; int nmod, mod; PatchGeo g; int64_t DHW;
   __device__ __forceinline__ float operator()(int x, int r) const {
-    int b, d, h, w; g.cdecode(x, b, d, h, w);
-    const int k = g.k;
-    const int fd = d * k + r / (k * k), fh = h * k + (r / k) % k, fw = w * k + r % k;
-    if (fd >= g.D || fh >= g.H || fw >= g.W) return 0.f;
-    return vol[((int64_t)b * nmod + mod) * DHW + ((int64_t)fd * g.H + fh) * g.W + fw];
+    const int64_t f = g.fine(x, r);
+    if (f < 0) return 0.f;
+    const int64_t b = f / DHW;       // fine() indexes (b, d, h, w); re-base onto the modality plane
+    return vol[(b * nmod + mod) * DHW + (f - b * DHW)];
   }
 };
 struct EmbedVolT {   // (x = tap, r = coarse token)
   EmbedVol e;
   __device__ __forceinline__ float operator()(int x, int r) const { return e(r, x); }
 };
-struct StoreRowsEpi {
-  const float* bias; float* y; int N;
-  __device__ __forceinline__ void operator()(int i, int j, float v) const { y[(int64_t)i * N + j] = v + (bias ? bias[j] : 0.f); }
+struct StoreRowsEpi {   // out[token j, feature i .. i+3] (+ bias)
+  const float* bias; float* y; int N, vec;
+  __device__ __forceinline__ void operator()(int i, int j, f32x4 v, int n) const {
+    float* p = y + (int64_t)j * N + i;
+    if (vec && n == 4) {
+      if (bias) { const float4 b = ld4(bias + i); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+      st4(p, v[0], v[1], v[2], v[3]);
+    } else {
+      MICF_FOR_N(n, e) p[e] = v[e] + (bias ? bias[i + e] : 0.f);
+    }
+  }
 };
-struct AtomicRowsEpi {
+struct AtomicRowsEpi {  // out[j, i] += v
   float* out; int64_t ld;
-  __device__ __forceinline__ void operator()(int i, int j, float v) const { atomicAdd(out + (int64_t)i * ld + j, v); }
+  __device__ __forceinline__ void operator()(int i, int j, f32x4 v, int n) const {
+    float* p = out + (int64_t)j * ld + i;
+    MICF_FOR_N(n, e) atomicAdd(p + e, v[e]);
+  }
 };
 
 // ---------------- conv_down (k = 2): x [B,D,H,W,C] -> y [B,Dc,Hc,Wc,N];  w [N][C][tap]
 struct DownIn {       // (x = coarse token, r = tap*C + c) -> x_fine[token(tc,tap), c]
-  const float* x; int C; PatchGeo g;
+  const float* x; int C; PatchGeo g; FastDiv fC;
   __device__ __forceinline__ float operator()(int tc, int r) const {
-    const int tap = r / C, c = r - tap * C;
-    const int64_t f = g.fine(tc, tap);
+    uint32_t tap, c; fC.divmod((uint32_t)r, tap, c);
+    const int64_t f = g.fine(tc, (int)tap);
     return f < 0 ? 0.f : x[f * C + c];
   }
 };
@@ -64,9 +84,9 @@ struct DownInT {      // (x = tap*C + c, r = coarse token)
   __device__ __forceinline__ float operator()(int x, int r) const { return d(r, x); }
 };
 struct DownW {        // (x = n, r = tap*C + c) -> w[n][c][tap]
-  const float* w; int C, K3;
+  const float* w; int C, K3; FastDiv fC;
   __device__ __forceinline__ float operator()(int n, int r) const {
-    const int tap = r / C, c = r - tap * C;
+    uint32_t tap, c; fC.divmod((uint32_t)r, tap, c);
     return w[((int64_t)n * C + c) * K3 + tap];
   }
 };
@@ -74,27 +94,37 @@ struct DownWT {       // (x = tap*C + c, r = n)
   DownW q;
   __device__ __forceinline__ float operator()(int x, int r) const { return q(r, x); }
 };
-struct DownDataEpi {  // (i = coarse token, j = tap*C + c) -> dx_fine
-  float* dx; int C; PatchGeo g;
-  __device__ __forceinline__ void operator()(int i, int j, float v) const {
-    const int tap = j / C, c = j - tap * C;
-    const int64_t f = g.fine(i, tap);
-    if (f >= 0) dx[f * C + c] = v;
+struct DownDataEpi {  // (i = tap*C + c, j = coarse token) -> dx_fine[token(j, tap), c .. c+3]
+  float* dx; int C; PatchGeo g; FastDiv fC; int vec;
+  __device__ __forceinline__ void operator()(int i, int j, f32x4 v, int n) const {
+    if (vec && n == 4) {             // C % 4 == 0: one tap for the 4 channels
+      uint32_t tap, c; fC.divmod((uint32_t)i, tap, c);
+      const int64_t f = g.fine(j, (int)tap);
+      if (f >= 0) st4(dx + f * C + c, v[0], v[1], v[2], v[3]);
+    } else {
+      MICF_FOR_N(n, e) {
+        uint32_t tap, c; fC.divmod((uint32_t)(i + e), tap, c);
+        const int64_t f = g.fine(j, (int)tap);
+        if (f >= 0) dx[f * C + c] = v[e];
+      }
+    }
   }
 };
-struct DownWgtEpi {   // (i = n, j = tap*C + c) -> dw[n][c][tap]
-  float* dw; int C, K3;
-  __device__ __forceinline__ void operator()(int i, int j, float v) const {
-    const int tap = j / C, c = j - tap * C;
-    atomicAdd(dw + ((int64_t)i * C + c) * K3 + tap, v);
+struct DownWgtEpi {   // (i = tap*C + c, j = n) -> dw[n][c][tap]
+  float* dw; int C, K3; FastDiv fC;
+  __device__ __forceinline__ void operator()(int i, int j, f32x4 v, int n) const {
+    MICF_FOR_N(n, e) {
+      uint32_t tap, c; fC.divmod((uint32_t)(i + e), tap, c);
+      atomicAdd(dw + ((int64_t)j * C + c) * K3 + tap, v[e]);
+    }
   }
 };
 
 // ---------------- conv_up (k in {2,4}): x [B,Dc,Hc,Wc,C] -> y [B,D,H,W,N] (D = k*Dc ...);  w [C][N][tap]
 struct UpW {          // (x = tap*N + n, r = c) -> w[c][n][tap]
-  const float* w; int N, K3;
+  const float* w; int N, K3; FastDiv fN;
   __device__ __forceinline__ float operator()(int x, int r) const {
-    const int tap = x / N, n = x - tap * N;
+    uint32_t tap, n; fN.divmod((uint32_t)x, tap, n);
     return w[((int64_t)r * N + n) * K3 + tap];
   }
 };
@@ -102,19 +132,29 @@ struct UpWT {         // (x = c, r = tap*N + n)
   UpW q;
   __device__ __forceinline__ float operator()(int x, int r) const { return q(r, x); }
 };
-struct UpFwdEpi {     // (i = coarse token, j = tap*N + n) -> y_fine[token, n] + bias[n]
-  const float* bias; float* y; int N; PatchGeo g;
-  __device__ __forceinline__ void operator()(int i, int j, float v) const {
-    const int tap = j / N, n = j - tap * N;
-    const int64_t f = g.fine(i, tap);
-    if (f >= 0) y[f * N + n] = v + (bias ? bias[n] : 0.f);
+struct UpFwdEpi {     // (i = tap*N + n, j = coarse token) -> y_fine[token(j, tap), n .. n+3] + bias
+  const float* bias; float* y; int N; PatchGeo g; FastDiv fN; int vec;
+  __device__ __forceinline__ void operator()(int i, int j, f32x4 v, int n4) const {
+    if (vec && n4 == 4) {
+      uint32_t tap, n; fN.divmod((uint32_t)i, tap, n);
+      const int64_t f = g.fine(j, (int)tap);
+      if (f < 0) return;
+      if (bias) { const float4 b = ld4(bias + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+      st4(y + f * N + n, v[0], v[1], v[2], v[3]);
+    } else {
+      MICF_FOR_N(n4, e) {
+        uint32_t tap, n; fN.divmod((uint32_t)(i + e), tap, n);
+        const int64_t f = g.fine(j, (int)tap);
+        if (f >= 0) y[f * N + n] = v[e] + (bias ? bias[n] : 0.f);
+      }
+    }
   }
 };
 struct UpDy {         // (x = coarse token, r = tap*N + n) -> dy_fine[token(tc,tap), n]
-  const float* dy; int N; PatchGeo g;
+  const float* dy; int N; PatchGeo g; FastDiv fN;
   __device__ __forceinline__ float operator()(int tc, int r) const {
-    const int tap = r / N, n = r - tap * N;
-    const int64_t f = g.fine(tc, tap);
+    uint32_t tap, n; fN.divmod((uint32_t)r, tap, n);
+    const int64_t f = g.fine(tc, (int)tap);
     return f < 0 ? 0.f : dy[f * N + n];
   }
 };
@@ -122,17 +162,20 @@ struct UpDyT {        // (x = tap*N + n, r = coarse token)
   UpDy d;
   __device__ __forceinline__ float operator()(int x, int r) const { return d(r, x); }
 };
-struct UpWgtEpi {     // (i = c, j = tap*N + n) -> dw[c][n][tap]
-  float* dw; int N, K3;
-  __device__ __forceinline__ void operator()(int i, int j, float v) const {
-    const int tap = j / N, n = j - tap * N;
-    atomicAdd(dw + ((int64_t)i * N + n) * K3 + tap, v);
+struct UpWgtEpi {     // (i = tap*N + n, j = c) -> dw[c][n][tap]
+  float* dw; int N, K3; FastDiv fN;
+  __device__ __forceinline__ void operator()(int i, int j, f32x4 v, int n4) const {
+    MICF_FOR_N(n4, e) {
+      uint32_t tap, n; fN.divmod((uint32_t)(i + e), tap, n);
+      atomicAdd(dw + ((int64_t)j * N + n) * K3 + tap, v[e]);
+    }
   }
 };
 
 static bool mk_geo(PatchGeo& g, int B, int D, int H, int W, int k) {
-  if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || k <= 0) return false;
-  g = PatchGeo{B, D, H, W, (D + k - 1) / k, (H + k - 1) / k, (W + k - 1) / k, k};
+  if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || (k != 2 && k != 4)) return false;
+  const int Dc = (D + k - 1) / k, Hc = (H + k - 1) / k, Wc = (W + k - 1) / k;
+  g = PatchGeo{B, D, H, W, Dc, Hc, Wc, k, FastDiv((uint32_t)Wc), FastDiv((uint32_t)Hc), FastDiv((uint32_t)Dc)};
   return (int64_t)B * D * H * W < (1LL << 31);
 }
 
@@ -147,9 +190,10 @@ extern "C" int micf_patch_embed_fwd(const float* vol, int nmod, int mod, const f
   if (!vol || !w || !y || E <= 0 || nmod <= 0 || mod < 0 || mod >= nmod || !mk_geo(g, B, D, H, W, p)) return MICF_EINVAL;
   const int64_t Tc = (int64_t)B * g.Dc * g.Hc * g.Wc;
   const int K = p * p * p;
-  auto pa = make_elem<true>(EmbedVol{vol, nmod, mod, g, (int64_t)D * H * W}, (int)Tc);
-  RowsT qa{w, w, K, K, 1, E, nullptr, 1, 0, (K % 4 == 0) && aligned16(w)};
-  return RC(launch_gemm(pa, qa, StoreRowsEpi{bias, y, E}, Tc, E, K, 1, S_(stream)));
+  // C[i = e, j = coarse token] = sum_tap w[e, tap] * patch[token, tap]
+  auto qa = make_elem<true>(EmbedVol{vol, nmod, mod, g, (int64_t)D * H * W}, (int)Tc);
+  const int vec = (E % 4 == 0) && aligned16(y) && (!bias || aligned16(bias));
+  return RC(launch_gemm(rows_t(w, K, E, K), qa, StoreRowsEpi{bias, y, E, vec}, E, Tc, K, 1, S_(stream)));
 }
 
 extern "C" int micf_patch_embed_bwd_weight(const float* dy, const float* vol, int nmod, int mod, float* dw, float* dbias,
@@ -158,11 +202,10 @@ extern "C" int micf_patch_embed_bwd_weight(const float* dy, const float* vol, in
   if (!dy || !vol || !dw || E <= 0 || nmod <= 0 || mod < 0 || mod >= nmod || !mk_geo(g, B, D, H, W, p)) return MICF_EINVAL;
   const int64_t Tc = (int64_t)B * g.Dc * g.Hc * g.Wc;
   const int K = p * p * p;
-  // dW[e, tap] = sum_t dy[t, e] * patch[t, tap]
-  RowsD pa{dy, dy, E, E, 1, E, nullptr, 1, 0, (E % 4 == 0) && aligned16(dy)};
-  auto qa = make_elem<false>(EmbedVolT{EmbedVol{vol, nmod, mod, g, (int64_t)D * H * W}}, K);
-  if (launch_gemm(pa, qa, AtomicRowsEpi{dw, K}, E, K, (int)Tc, pick_splits(E, K, Tc), S_(stream), dbias) != hipSuccess) return MICF_ELAUNCH;
-  return MICF_OK;
+  // dW[e, tap] = sum_t dy[t, e] * patch[t, tap]:  C[i = tap, j = e]
+  auto pa = make_elem<false>(EmbedVolT{EmbedVol{vol, nmod, mod, g, (int64_t)D * H * W}}, K);
+  return RC(launch_gemm(pa, rows_d(dy, E, E), AtomicRowsEpi{dw, K}, K, E, (int)Tc, pick_splits(K, E, Tc), S_(stream), dbias,
+                        dbias ? 2 : 0));
 }
 
 extern "C" int micf_conv_down_fwd(const float* x, const float* w, const float* bias, float* y, int B, int D, int H, int W,
@@ -170,9 +213,12 @@ extern "C" int micf_conv_down_fwd(const float* x, const float* w, const float* b
   PatchGeo g;
   if (!x || !w || !y || C <= 0 || N <= 0 || !mk_geo(g, B, D, H, W, 2)) return MICF_EINVAL;
   const int64_t Tc = (int64_t)B * g.Dc * g.Hc * g.Wc;
-  auto pa = make_elem<true>(DownIn{x, C, g}, (int)Tc);
-  auto qa = make_elem<true>(DownW{w, C, 8}, N);
-  return RC(launch_gemm(pa, qa, StoreRowsEpi{bias, y, N}, Tc, N, 8 * C, 1, S_(stream)));
+  const FastDiv fC((uint32_t)C);
+  // C[i = n, j = coarse token]
+  auto pa = make_elem<false>(DownW{w, C, 8, fC}, N);
+  auto qa = make_elem<true>(DownIn{x, C, g, fC}, (int)Tc);
+  const int vec = (N % 4 == 0) && aligned16(y) && (!bias || aligned16(bias));
+  return RC(launch_gemm(pa, qa, StoreRowsEpi{bias, y, N, vec}, N, Tc, 8 * C, 1, S_(stream)));
 }
 
 extern "C" int micf_conv_down_bwd_data(const float* dy, const float* w, float* dx, int B, int D, int H, int W, int C, int N,
@@ -180,10 +226,11 @@ extern "C" int micf_conv_down_bwd_data(const float* dy, const float* w, float* d
   PatchGeo g;
   if (!dy || !w || !dx || C <= 0 || N <= 0 || !mk_geo(g, B, D, H, W, 2)) return MICF_EINVAL;
   const int64_t Tc = (int64_t)B * g.Dc * g.Hc * g.Wc;
-  // dXcols[tc, tap*C + c] = sum_n dy[tc, n] * w[n][c][tap]  -> scattered to the fine grid (every fine token exactly once)
-  RowsT pa{dy, dy, N, N, 1, (int)Tc, nullptr, 1, 0, (N % 4 == 0) && aligned16(dy)};
-  auto qa = make_elem<false>(DownWT{DownW{w, C, 8}}, 8 * C);
-  return RC(launch_gemm(pa, qa, DownDataEpi{dx, C, g}, Tc, 8 * C, N, 1, S_(stream)));
+  const FastDiv fC((uint32_t)C);
+  // dXcols[i = tap*C + c, j = tc] = sum_n w[n][c][tap] * dy[tc, n]  -> scattered to the fine grid (every fine token exactly once)
+  auto pa = make_elem<false>(DownWT{DownW{w, C, 8, fC}}, 8 * C);
+  const int vec = (C % 4 == 0) && aligned16(dx);
+  return RC(launch_gemm(pa, rows_t(dy, N, (int)Tc, N), DownDataEpi{dx, C, g, fC, vec}, 8 * C, Tc, N, 1, S_(stream)));
 }
 
 extern "C" int micf_conv_down_bwd_weight(const float* dy, const float* x, float* dw, float* dbias, int B, int D, int H, int W,
@@ -191,11 +238,11 @@ extern "C" int micf_conv_down_bwd_weight(const float* dy, const float* x, float*
   PatchGeo g;
   if (!dy || !x || !dw || C <= 0 || N <= 0 || !mk_geo(g, B, D, H, W, 2)) return MICF_EINVAL;
   const int64_t Tc = (int64_t)B * g.Dc * g.Hc * g.Wc;
-  RowsD pa{dy, dy, N, N, 1, N, nullptr, 1, 0, (N % 4 == 0) && aligned16(dy)};
-  auto qa = make_elem<false>(DownInT{DownIn{x, C, g}}, 8 * C);
-  if (launch_gemm(pa, qa, DownWgtEpi{dw, C, 8}, N, 8 * C, (int)Tc, pick_splits(N, 8 * C, Tc), S_(stream), dbias) != hipSuccess)
-    return MICF_ELAUNCH;
-  return MICF_OK;
+  const FastDiv fC((uint32_t)C);
+  // dW^T[i = tap*C + c, j = n] = sum_tc x_fine[token(tc,tap), c] * dy[tc, n]
+  auto pa = make_elem<false>(DownInT{DownIn{x, C, g, fC}}, 8 * C);
+  return RC(launch_gemm(pa, rows_d(dy, N, N), DownWgtEpi{dw, C, 8, fC}, 8 * C, N, (int)Tc, pick_splits(8 * C, N, Tc), S_(stream),
+                        dbias, dbias ? 2 : 0));
 }
 
 extern "C" int micf_conv_up_fwd(const float* x, const float* w, const float* bias, float* y, int B, int D, int H, int W, int C,
@@ -205,9 +252,11 @@ extern "C" int micf_conv_up_fwd(const float* x, const float* w, const float* bia
   if (!x || !w || !y || C <= 0 || N <= 0 || (k != 2 && k != 4) || !mk_geo(g, B, D * k, H * k, W * k, k)) return MICF_EINVAL;
   const int64_t Tc = (int64_t)B * D * H * W;
   const int K3 = k * k * k;
-  RowsT pa{x, x, C, C, 1, (int)Tc, nullptr, 1, 0, (C % 4 == 0) && aligned16(x)};
-  auto qa = make_elem<false>(UpW{w, N, K3}, K3 * N);
-  return RC(launch_gemm(pa, qa, UpFwdEpi{bias, y, N, g}, Tc, K3 * N, C, 1, S_(stream)));
+  const FastDiv fN((uint32_t)N);
+  // C[i = tap*N + n, j = tc] = sum_c w[c][n][tap] * x[tc, c]
+  auto pa = make_elem<false>(UpW{w, N, K3, fN}, K3 * N);
+  const int vec = (N % 4 == 0) && aligned16(y) && (!bias || aligned16(bias));
+  return RC(launch_gemm(pa, rows_t(x, C, (int)Tc, C), UpFwdEpi{bias, y, N, g, fN, vec}, K3 * N, Tc, C, 1, S_(stream)));
 }
 
 extern "C" int micf_conv_up_bwd_data(const float* dy, const float* w, float* dx, int B, int D, int H, int W, int C, int N, int k,
@@ -216,10 +265,12 @@ extern "C" int micf_conv_up_bwd_data(const float* dy, const float* w, float* dx,
   if (!dy || !w || !dx || C <= 0 || N <= 0 || (k != 2 && k != 4) || !mk_geo(g, B, D * k, H * k, W * k, k)) return MICF_EINVAL;
   const int64_t Tc = (int64_t)B * D * H * W;
   const int K3 = k * k * k;
-  // dx[tc, c] = sum_{tap,n} dy_fine[token(tc,tap), n] * w[c][n][tap]
-  auto pa = make_elem<true>(UpDy{dy, N, g}, (int)Tc);
-  auto qa = make_elem<true>(UpWT{UpW{w, N, K3}}, C);
-  return RC(launch_gemm(pa, qa, StoreRowsEpi{nullptr, dx, C}, Tc, C, K3 * N, 1, S_(stream)));
+  const FastDiv fN((uint32_t)N);
+  // dx[i = c, j = tc] = sum_{tap,n} w[c][n][tap] * dy_fine[token(tc,tap), n]
+  auto pa = make_elem<false>(UpWT{UpW{w, N, K3, fN}}, C);
+  auto qa = make_elem<true>(UpDy{dy, N, g, fN}, (int)Tc);
+  const int vec = (C % 4 == 0) && aligned16(dx);
+  return RC(launch_gemm(pa, qa, StoreRowsEpi{nullptr, dx, C, vec}, C, Tc, K3 * N, 1, S_(stream)));
 }
 
 extern "C" int micf_conv_up_bwd_weight(const float* dy, const float* x, float* dw, float* dbias, int B, int D, int H, int W,
@@ -228,10 +279,10 @@ extern "C" int micf_conv_up_bwd_weight(const float* dy, const float* x, float* d
   if (!dy || !x || !dw || C <= 0 || N <= 0 || (k != 2 && k != 4) || !mk_geo(g, B, D * k, H * k, W * k, k)) return MICF_EINVAL;
   const int64_t Tc = (int64_t)B * D * H * W;
   const int K3 = k * k * k;
-  // dw[c][n][tap] = sum_tc x[tc, c] * dy_fine[token(tc,tap), n]
-  RowsD pa{x, x, C, C, 1, C, nullptr, 1, 0, (C % 4 == 0) && aligned16(x)};
-  auto qa = make_elem<false>(UpDyT{UpDy{dy, N, g}}, K3 * N);
-  if (launch_gemm(pa, qa, UpWgtEpi{dw, N, K3}, C, K3 * N, (int)Tc, pick_splits(C, K3 * N, Tc), S_(stream)) != hipSuccess)
+  const FastDiv fN((uint32_t)N);
+  // dw^T[i = tap*N + n, j = c] = sum_tc dy_fine[token(tc,tap), n] * x[tc, c]
+  auto pa = make_elem<false>(UpDyT{UpDy{dy, N, g, fN}}, K3 * N);
+  if (launch_gemm(pa, rows_d(x, C, C), UpWgtEpi{dw, N, K3, fN}, K3 * N, C, (int)Tc, pick_splits(K3 * N, C, Tc), S_(stream)) != hipSuccess)
     return MICF_ELAUNCH;
   if (dbias) return colsum_atomic(dy, nullptr, 1, dbias, Tc * K3, N, S_(stream));
   return MICF_OK;

@@ -291,6 +291,6 @@ def test_base_128_properties_full_size(M):
     assert y2.shape == (2, 8, 128, 128, 128)
     assert torch.isfinite(y2).all()
     # small token grids split the offset-conv reduction over workgroups with fp32 atomics: run-to-run equal to rounding
-    close(y2, y2b, atol=1e-6, rtol=0, what="forward repeatability")
+    close(y2, y2b, atol=1e-5, rtol=0, what="forward repeatability")
     close(y2[:1], y0, atol=1e-5, what="batch independence, sample 0")
     close(y2[1:], y1, atol=1e-5, what="batch independence, sample 1")

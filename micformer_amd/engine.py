@@ -16,6 +16,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops
+from .dist import FlatGradSync, flatten_views
 from .loss.dice import MDiceLoss
 
 
@@ -26,14 +27,10 @@ class TrainEngine:
         self.criterion = criterion if criterion is not None else MDiceLoss()
         self.base_lr, self.t_max, self.eta_min = base_lr, t_max, eta_min
         self.betas, self.eps = betas, eps
-        self.pg = process_group
-        self.world = dist.get_world_size(process_group) if (process_group is not None or dist.is_initialized()) else 1
-        if self.world > 1 and process_group is None:
-            self.pg = dist.group.WORLD
-        self.bucket_elems = max(int(grad_bucket_bytes) // 4, 1)
+        self.sync = FlatGradSync(process_group, grad_bucket_bytes)
+        self.world = self.sync.world
         self._flatten()
-        if self.world > 1:
-            dist.broadcast(self.flat_p, src=0, group=self.pg)      # rank-identical initial weights
+        self.sync.broadcast_params(self.flat_p)                    # rank-identical initial weights
         self.use_graph = use_graph
         self._graph = None
         self._static = None
@@ -47,10 +44,7 @@ class TrainEngine:
             raise RuntimeError("TrainEngine needs the model on a CUDA (ROCm) device")
         sizes = [p.numel() for p in params]
         # 4-element (16 B) alignment of every tensor so kernels can use 16-byte accesses on parameter views
-        offs, total = [], 0
-        for n in sizes:
-            offs.append(total)
-            total += (n + 3) // 4 * 4
+        offs, total = flatten_views(params)
         self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -60,6 +54,7 @@ class TrainEngine:
                 self.flat_p[o:o + n].copy_(p.reshape(-1))
                 p.data = self.flat_p[o:o + n].view(p.shape)
                 p.grad = self.flat_g[o:o + n].view(p.shape)
+                p._micf_grad = p.grad       # backward kernels accumulate straight into the flat gradient buffer
         self.params, self.offsets, self.sizes = params, offs, sizes
         self.adam_state = ops.adam_state(dev)
 
@@ -85,14 +80,7 @@ class TrainEngine:
 
     def _allreduce_grads(self):
         """Gradient all-reduce(sum)/world over RCCL/xGMI in a few large buckets of the flat buffer."""
-        n = self.flat_g.numel()
-        works = []
-        for s in range(0, n, self.bucket_elems):
-            works.append(dist.all_reduce(self.flat_g[s:s + self.bucket_elems], op=dist.ReduceOp.SUM, group=self.pg,
-                                         async_op=True))
-        for w in works:
-            w.wait()
-        self.flat_g.div_(self.world)
+        self.sync.allreduce_mean_(self.flat_g)
 
     def step(self, x, target):
         """Run one training step; returns the (device) loss of this rank's batch."""

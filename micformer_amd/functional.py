@@ -22,6 +22,20 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _targets(params):
+    """Engine mode: a parameter may carry `_micf_grad`, a view of the flat gradient buffer.  The backward kernels then
+    accumulate straight into it (they atomically add anyway) and autograd gets None -- no zero-fill, no `grad += g` pass."""
+    return tuple(getattr(p, "_micf_grad", None) for p in params)
+
+
+def _grad_buf(target, like):
+    return target if target is not None else torch.zeros_like(like)
+
+
+def _ret(target, buf):
+    return None if target is not None else buf
+
+
 # ============================================================================= LayerNorm
 class LayerNormFn(torch.autograd.Function):
     """nn.LayerNorm over the last dim of [..., C] (optionally over cat[x, x2], MS.py:1033-1034)."""
@@ -33,15 +47,17 @@ class LayerNormFn(torch.autograd.Function):
         x2f = _c(x2).reshape(-1, x2.shape[-1]) if x2 is not None else None
         y, mean, rstd = ops.layernorm_fwd(x.reshape(-1, C1), gamma, beta, eps, x2f)
         ctx.save_for_backward(x, x2 if x2 is None else _c(x2), gamma, mean, rstd)
+        ctx.tg = _targets((gamma, beta))
         return y.reshape(x.shape[:-1] + (gamma.numel(),))
 
     @staticmethod
     def backward(ctx, dy):
         x, x2, gamma, mean, rstd = ctx.saved_tensors
         dy = _c(dy).reshape(-1, gamma.numel())
-        dg, db = _zl(gamma), _zl(gamma)
+        dg, db = _grad_buf(ctx.tg[0], gamma), _grad_buf(ctx.tg[1], gamma)
         x2f = x2.reshape(-1, x2.shape[-1]) if x2 is not None else None
         r = ops.layernorm_bwd(dy, x.reshape(-1, x.shape[-1]), mean, rstd, gamma, dg, db, x2f)
+        dg, db = _ret(ctx.tg[0], dg), _ret(ctx.tg[1], db)
         if x2 is None:
             return r.reshape(x.shape), None, dg, db, None
         return r[0].reshape(x.shape), r[1].reshape(x2.shape), dg, db, None
@@ -58,6 +74,7 @@ class LinearFn(torch.autograd.Function):
         y = ops.linear_fwd(a.reshape(-1, a.shape[-1]), w, b, a2.reshape(-1, a2.shape[-1]) if a2 is not None else None)
         ctx.save_for_backward(a, a2, w)
         ctx.has_bias = b is not None
+        ctx.tg = _targets((w, b))
         return y.reshape(a.shape[:-1] + (w.shape[0],))
 
     @staticmethod
@@ -67,10 +84,11 @@ class LinearFn(torch.autograd.Function):
         k1 = a.shape[-1]
         af = a.reshape(-1, k1)
         a2f = a2.reshape(-1, a2.shape[-1]) if a2 is not None else None
-        dw = _zl(w)
-        db = torch.zeros(w.shape[0], dtype=w.dtype, device=w.device) if ctx.has_bias else None
+        dw = _grad_buf(ctx.tg[0], w)
+        db = (ctx.tg[1] if ctx.tg[1] is not None else torch.zeros(w.shape[0], dtype=w.dtype, device=w.device)) if ctx.has_bias else None
         ops.linear_bwd_weight(dy, af, dw, db, a2f)
         r = ops.linear_bwd_data(dy, w, k1=k1)
+        dw, db = _ret(ctx.tg[0], dw), _ret(ctx.tg[1], db)
         if a2 is None:
             return r.reshape(a.shape), None, dw, db
         return r[0].reshape(a.shape), r[1].reshape(a2.shape), dw, db
@@ -135,6 +153,7 @@ class SelfBlockFn(torch.autograd.Function):
         y, mlp_saved = _mlp_fwd(x1, dims, P, s2, eps)
         ctx.save_for_backward(xf, m1, r1, xnp, q, kv, o, x1, s1, s2, *mlp_saved, *params)
         ctx.meta = (dims, ws, pd, padded, heads, scale)
+        ctx.tg = _targets(params)
         return y.reshape(x.shape)
 
     @staticmethod
@@ -144,7 +163,7 @@ class SelfBlockFn(torch.autograd.Function):
         mlp_saved = sv[10:14]
         params = sv[14:]
         P = dict(zip(SELF_KEYS, params))
-        G = {k: _zl(v) for k, v in P.items()}
+        G = {k: _grad_buf(t, v) for (k, v), t in zip(P.items(), ctx.tg)}
         dims, ws, pd, padded, heads, scale = ctx.meta
         B, D, H, W = dims
         pdims = (B,) + pd
@@ -164,7 +183,8 @@ class SelfBlockFn(torch.autograd.Function):
         if padded:
             dxn = ops.crop3d(dxn, dims, pd)
         dx = ops.layernorm_bwd(dxn, xf, m1, r1, P["norm1.weight"], G["norm1.weight"], G["norm1.bias"], add=dx1)
-        return (dx.reshape(B, D, H, W, C), None, None, None, None, None) + tuple(G[k] for k in SELF_KEYS)
+        return (dx.reshape(B, D, H, W, C), None, None, None, None, None) + \
+            tuple(_ret(t, G[k]) for k, t in zip(SELF_KEYS, ctx.tg))
 
 
 # ============================================================================= CrossTransformerBlock3D (MS.py:277-426)
@@ -199,7 +219,7 @@ class CrossBlockFn(torch.autograd.Function):
         y, mlp_saved = _mlp_fwd(x1, dims, P, s2, eps)
         ctx.save_for_backward(xf, m1, r1, xnp, xap, hid, flow, xs, q, kv, o, x1, s1, s2, *mlp_saved, *params)
         ctx.meta = (dims, ws, pd, padded, heads, scale, eps)
-        ctx.aux = None
+        ctx.tg = _targets(params)
         return y.reshape(x.shape)
 
     @staticmethod
@@ -209,7 +229,7 @@ class CrossBlockFn(torch.autograd.Function):
         mlp_saved = sv[14:18]
         params = sv[18:]
         P = dict(zip(CROSS_KEYS, params))
-        G = {k: _zl(v) for k, v in P.items()}
+        G = {k: _grad_buf(t, v) for (k, v), t in zip(P.items(), ctx.tg)}
         dims, ws, pd, padded, heads, scale, eps = ctx.meta
         B, D, H, W = dims
         pdims = (B,) + pd
@@ -239,7 +259,7 @@ class CrossBlockFn(torch.autograd.Function):
             dxn, dxa = dxnp, dxap
         dx = ops.layernorm_bwd(dxn, xf, m1, r1, P["norm1.weight"], G["norm1.weight"], G["norm1.bias"], add=dx1)
         return (dx.reshape(B, D, H, W, C), dxa.reshape(B, D, H, W, C), None, None, None, None, None) + \
-            tuple(G[k] for k in CROSS_KEYS)
+            tuple(_ret(t, G[k]) for k, t in zip(CROSS_KEYS, ctx.tg))
 
 
 # ============================================================================= patch embed / merging / expand / head
@@ -252,16 +272,17 @@ class PatchEmbedFn(torch.autograd.Function):
         y = ops.patch_embed_fwd(vol, mod, w, b, p)
         ctx.save_for_backward(vol, w)
         ctx.meta = (mod, p)
+        ctx.tg = _targets((w, b))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         vol, w = ctx.saved_tensors
         mod, p = ctx.meta
-        dw = _zl(w)
-        db = torch.zeros(w.shape[0], dtype=w.dtype, device=w.device)
+        dw = _grad_buf(ctx.tg[0], w)
+        db = ctx.tg[1] if ctx.tg[1] is not None else torch.zeros(w.shape[0], dtype=w.dtype, device=w.device)
         ops.patch_embed_bwd_weight(_c(dy), vol, mod, dw, db, p)
-        return None, None, dw, db, None          # the input volume is data: no gradient (train.py:177-185)
+        return None, None, _ret(ctx.tg[0], dw), _ret(ctx.tg[1], db), None   # the input volume is data: no gradient (train.py:177-185)
 
 
 class ConvDownFn(torch.autograd.Function):
@@ -271,16 +292,17 @@ class ConvDownFn(torch.autograd.Function):
     def forward(ctx, x, w, b):
         x = _c(x)
         ctx.save_for_backward(x, w)
+        ctx.tg = _targets((w, b))
         return ops.conv_down_fwd(x, w, b)
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dy = _c(dy)
-        dw = _zl(w)
-        db = torch.zeros(w.shape[0], dtype=w.dtype, device=w.device)
+        dw = _grad_buf(ctx.tg[0], w)
+        db = ctx.tg[1] if ctx.tg[1] is not None else torch.zeros(w.shape[0], dtype=w.dtype, device=w.device)
         ops.conv_down_bwd_weight(dy, x, dw, db)
-        return ops.conv_down_bwd_data(dy, w, tuple(x.shape)), dw, db
+        return ops.conv_down_bwd_data(dy, w, tuple(x.shape)), _ret(ctx.tg[0], dw), _ret(ctx.tg[1], db)
 
 
 class ConvUpFn(torch.autograd.Function):
@@ -291,16 +313,17 @@ class ConvUpFn(torch.autograd.Function):
         x = _c(x)
         ctx.save_for_backward(x, w)
         ctx.k = k
+        ctx.tg = _targets((w, b))
         return ops.conv_up_fwd(x, w, b, k)
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dy = _c(dy)
-        dw = _zl(w)
-        db = torch.zeros(w.shape[1], dtype=w.dtype, device=w.device)
+        dw = _grad_buf(ctx.tg[0], w)
+        db = ctx.tg[1] if ctx.tg[1] is not None else torch.zeros(w.shape[1], dtype=w.dtype, device=w.device)
         ops.conv_up_bwd_weight(dy, x, dw, db, ctx.k)
-        return ops.conv_up_bwd_data(dy, w, tuple(x.shape), ctx.k), dw, db, None
+        return ops.conv_up_bwd_data(dy, w, tuple(x.shape), ctx.k), _ret(ctx.tg[0], dw), _ret(ctx.tg[1], db), None
 
 
 class OutConvFn(torch.autograd.Function):
@@ -311,6 +334,7 @@ class OutConvFn(torch.autograd.Function):
         feat = _c(feat)
         B, D, H, W, C = feat.shape
         ctx.save_for_backward(feat, w)
+        ctx.tg = _targets((w, b))
         return ops.conv3_fwd(feat.reshape(-1, C), w, b, (B, D, H, W), ncdhw_out=True)
 
     @staticmethod
@@ -318,12 +342,12 @@ class OutConvFn(torch.autograd.Function):
         feat, w = ctx.saved_tensors
         B, D, H, W, C = feat.shape
         dy = _c(dy)
-        dw = _zl(w)
-        db = torch.zeros(w.shape[0], dtype=w.dtype, device=w.device)
+        dw = _grad_buf(ctx.tg[0], w)
+        db = ctx.tg[1] if ctx.tg[1] is not None else torch.zeros(w.shape[0], dtype=w.dtype, device=w.device)
         f2 = feat.reshape(-1, C)
         ops.conv3_bwd_weight(dy, f2, dw, db, (B, D, H, W), ncdhw=True)
         dx, _ = ops.conv3_bwd_data(dy, w, (B, D, H, W), C, 0, ncdhw=True)
-        return dx.reshape(feat.shape), dw, db
+        return dx.reshape(feat.shape), _ret(ctx.tg[0], dw), _ret(ctx.tg[1], db)
 
 
 class ResizeTrilinearFn(torch.autograd.Function):

@@ -224,6 +224,16 @@ class LayerNormProxy(nn.Module):
         return y.permute(0, 4, 1, 2, 3)
 
 
+def _block_scales(block, x):
+    """The two DropPath draws of a block (part1, part2).  MicFormer pre-draws all of them in one batched RNG call per
+    forward (`_predraw_drop_path`); a standalone block draws its own."""
+    pre = block.__dict__.pop("_pending_scales", None)
+    if pre is not None:
+        return pre
+    B = x.shape[0]
+    return block.drop_path.sample_scale(B, x.device), block.drop_path.sample_scale(B, x.device)
+
+
 def _block_params(block, keys):
     sd = dict(block.named_parameters())
     return [sd[k] for k in keys]
@@ -261,9 +271,7 @@ class CrossTransformerBlock3D(nn.Module):
         self.stn = SpatialTransformer()
 
     def forward(self, x, xa):
-        B = x.shape[0]
-        s1 = self.drop_path.sample_scale(B, x.device)
-        s2 = self.drop_path.sample_scale(B, x.device)
+        s1, s2 = _block_scales(self, x)
         return Fn.CrossBlockFn.apply(x, xa, s1, s2, self.num_heads, self.window_size, self.norm1.eps,
                                      *_block_params(self, Fn.CROSS_KEYS))
 
@@ -293,9 +301,7 @@ class TransformerBlock3D(nn.Module):
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
 
     def forward(self, x):
-        B = x.shape[0]
-        s1 = self.drop_path.sample_scale(B, x.device)
-        s2 = self.drop_path.sample_scale(B, x.device)
+        s1, s2 = _block_scales(self, x)
         return Fn.SelfBlockFn.apply(x, s1, s2, self.num_heads, self.window_size, self.norm1.eps,
                                     *_block_params(self, Fn.SELF_KEYS))
 
@@ -453,8 +459,25 @@ class MicFormer(nn.Module):
         self.reverse_patch_embedding = nn.ConvTranspose3d(2 * embed_dim, embed_dim // 2, self.patch_size,
                                                           stride=self.patch_size[0])
 
+    def _predraw_drop_path(self, batch, device):
+        """One batched draw of every block's two per-sample DropPath scales (mask / keep_prob, timm semantics)."""
+        blocks = [b for b in self.modules() if isinstance(b, (TransformerBlock3D, CrossTransformerBlock3D))
+                  and isinstance(b.drop_path, DropPath) and b.drop_path.drop_prob > 0.0]
+        if not self.training or not blocks:
+            return
+        cache = self.__dict__.setdefault("_dp_keep_cache", {})          # device-resident keep-probabilities (not a buffer:
+        keep = cache.get(device)                                        # state_dict stays the reference's)
+        if keep is None or keep.shape[0] != 2 * len(blocks):
+            keep = torch.tensor([1.0 - b.drop_path.drop_prob for b in blocks for _ in (0, 1)],
+                                dtype=torch.float32).unsqueeze(1).to(device)
+            cache[device] = keep
+        s = (torch.rand(keep.shape[0], batch, device=device) < keep).float() / keep
+        for i, b in enumerate(blocks):
+            b.__dict__["_pending_scales"] = (s[2 * i], s[2 * i + 1])
+
     def features(self, vol_m, mod_m, vol_f, mod_f):
         """Channels-last (B, D', H', W', E/2) feature that feeds Head.out_conv."""
+        self._predraw_drop_path(vol_m.shape[0], vol_m.device)
         m = self.patch_embed.tokens(vol_m, mod_m)
         f = self.patch_embed.tokens(vol_f, mod_f)
         skips = []

@@ -1,0 +1,115 @@
+"""N > 1 path on CPU: two gloo processes exercise the SAME gradient-exchange code the engine uses on RCCL
+(micformer_amd.dist.FlatGradSync) with the CPU oracle standing in for the model: the 2-rank result must equal the 1-rank
+result on the concatenated batch under the per-rank-loss definition, weights must stay rank-identical,
+and the unused parameters (concat_back_dim.0.*) must survive as exact zeros in the flat bucket."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _tiny_setup():
+    from oracle import fill
+    from oracle import micformer_ref as R
+    from oracle.shapes import filled_params
+    # two stages on 24^3: token grids 6^3 -> 3^3 (padded to 4^3 inside the windows); no S == 1 axis, so gradients are finite
+    cfg = R.Cfg(embed_dim=24, depths=(1, 1), num_heads=(3, 6))
+    P = filled_params(cfg)
+    x = fill.make_volume(2, 24, 24, 24)                     # global batch 2 -> one pair per rank
+    t = fill.one_hot(fill.make_label_map(2, 24, 24, 24))
+    return cfg, P, x, t, R
+
+
+def _flat_grads(R, cfg, P, x, t, names, offs, total):
+    leaves = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    loss = R.mdice_loss(R.head_forward(leaves, x, cfg), t)
+    grads = torch.autograd.grad(loss, [leaves[n] for n in names], allow_unused=True)
+    flat = torch.zeros(total)
+    for n, o, g in zip(names, offs, grads):
+        if g is not None:
+            flat[o:o + g.numel()] = g.reshape(-1)
+    return loss.detach(), flat
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from micformer_amd.dist import FlatGradSync, flatten_views
+    cfg, P, x, t, R = _tiny_setup()
+    names = list(P)
+    offs, total = flatten_views([P[n] for n in names])
+    sync = FlatGradSync(bucket_bytes=1 << 20)                # several buckets
+    assert sync.world == world
+    # rank 1 starts from perturbed weights: broadcast must make them rank-identical
+    flat_p = torch.zeros(total)
+    for n, o in zip(names, offs):
+        flat_p[o:o + P[n].numel()] = P[n].reshape(-1) + (0.01 * rank)
+    sync.broadcast_params(flat_p)
+    for n, o in zip(names, offs):
+        P[n] = flat_p[o:o + P[n].numel()].view(P[n].shape).clone()
+    loss, flat_g = _flat_grads(R, cfg, P, x[rank:rank + 1], t[rank:rank + 1], names, offs, total)
+    sync.allreduce_mean_(flat_g)
+    mx = sync.max_over_ranks(float(rank + 1), "cpu")
+    if rank == 0:
+        torch.save({"flat_g": flat_g, "loss": loss, "flat_p": flat_p, "max": mx}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_gloo_matches_single_process(tmp_path):
+    out = str(tmp_path / "r0.pt")
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    sys.path.insert(0, ROOT)
+    from micformer_amd.dist import flatten_views
+    cfg, P, x, t, R = _tiny_setup()
+    names = list(P)
+    offs, total = flatten_views([P[n] for n in names])
+    # broadcast from rank 0 (perturbation 0): weights identical to the unperturbed fill
+    ref_p = torch.zeros(total)
+    for n, o in zip(names, offs):
+        ref_p[o:o + P[n].numel()] = P[n].reshape(-1)
+    assert torch.equal(got["flat_p"], ref_p)
+    assert got["max"] == 2.0
+    # 1-rank reference under the per-rank-loss definition: mean over ranks of the per-shard loss gradients
+    g = torch.zeros(total)
+    for r in range(2):
+        _, fg = _flat_grads(R, cfg, P, x[r:r + 1], t[r:r + 1], names, offs, total)
+        g += fg
+    g /= 2
+    err = float((got["flat_g"] - g).abs().max())
+    scale = float(g.abs().max())
+    assert scale == scale and scale > 0
+    assert err <= 1e-6 * max(scale, 1.0) + 1e-9, f"2-rank grads differ from the 1-rank reference: {err} (scale {scale})"
+    # the dead parameters never receive a gradient: their slice of the bucket stays exactly zero
+    for n, o in zip(names, offs):
+        if n.startswith("swin.concat_back_dim.0."):
+            assert float(got["flat_g"][o:o + P[n].numel()].abs().max()) == 0.0
+
+
+def test_flatten_views_alignment():
+    sys.path.insert(0, ROOT)
+    from micformer_amd.dist import flatten_views
+    ts = [torch.zeros(3), torch.zeros(8), torch.zeros(5, 5), torch.zeros(1)]
+    offs, total = flatten_views(ts)
+    assert offs == [0, 4, 12, 40] and total == 44
+    assert all(o % 4 == 0 for o in offs)

@@ -49,9 +49,9 @@ struct Conv3In {
 
 struct Conv3TokT {   // T mapping: x = token, r = tap*Cin + c
   Conv3In in;
-  template <int BX> using Stage = StageT<BX>;
-  template <int BX>
-  __device__ __forceinline__ void fetch(Stage<BX>& st, int x0, int r0, int r_end, int tid) const {
+  template <int BX, int BR> using Stage = StageT<BX, BR>;
+  template <int BX, int BR>
+  __device__ __forceinline__ void fetch(Stage<BX, BR>& st, int x0, int r0, int r_end, int tid) const {
     st.fetch(x0, r0, tid, [&](int x, int r, float* v) {
       if (x < in.X) in.load4(x, r, r_end, v); else v[0] = v[1] = v[2] = v[3] = 0.f;
     });
@@ -60,9 +60,9 @@ struct Conv3TokT {   // T mapping: x = token, r = tap*Cin + c
 
 struct Conv3ColD {   // D mapping: x = tap*Cin + c (4 consecutive c), r = token
   Conv3In in; int J;
-  template <int BX> using Stage = StageD<BX>;
-  template <int BX>
-  __device__ __forceinline__ void fetch(Stage<BX>& st, int x0, int r0, int r_end, int tid) const {
+  template <int BX, int BR> using Stage = StageD<BX, BR>;
+  template <int BX, int BR>
+  __device__ __forceinline__ void fetch(Stage<BX, BR>& st, int x0, int r0, int r_end, int tid) const {
     st.fetch(x0, r0, tid, [&](int x, int r, float* v) {
       if (r < r_end) in.load4(r, x, J, v); else v[0] = v[1] = v[2] = v[3] = 0.f;
     });
@@ -180,6 +180,9 @@ __global__ void __launch_bounds__(256) plane_sum_kernel(const float* __restrict_
   if (threadIdx.x == 0) atomicAdd(out + plane % N, part[0] + part[1] + part[2] + part[3]);
 }
 
+int conv3_wgrad_direct(const float* dy, int dy_layout, const float* x1, int c1, const float* x2, int c2, float* dw,
+                       float* dbias, int B, int D, int H, int W, int N, hipStream_t stream);   // conv3_wgrad.hip
+
 }  // namespace micf
 using namespace micf;
 #define RC(e) ((e) == hipSuccess ? MICF_OK : MICF_ELAUNCH)
@@ -238,6 +241,10 @@ extern "C" int micf_conv3_bwd_data(const float* dy, int dy_layout, const float* 
 extern "C" int micf_conv3_bwd_weight(const float* dy, int dy_layout, const float* x1, int c1, const float* x2, int c2,
                                      float* dw, float* dbias, int B, int D, int H, int W, int N, micf_stream_t stream) {
   if (!dy || !x1 || !dw || (c2 > 0 && !x2) || !conv3_args_ok(B, D, H, W, N, c1, c2)) return MICF_EINVAL;
+  {   // direct LDS-tiled kernel for the shapes of the model (N = 16 offset conv, N = 8 out_conv)
+    const int rc = conv3_wgrad_direct(dy, dy_layout, x1, c1, x2, c2, dw, dbias, B, D, H, W, N, (hipStream_t)stream);
+    if (rc != MICF_EUNSUPPORTED) return rc;
+  }
   const Geo g{B, D, H, W};
   const int Cin = c1 + c2;
   const int64_t T = g.tokens();

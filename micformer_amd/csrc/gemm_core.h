@@ -32,7 +32,6 @@ namespace micf {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kThreads = 256;
-constexpr int kBR = 32;  // reduction depth staged per LDS slab
 
 // LDS row strides (in floats), chosen per staging kind so that both the MFMA fragment reads and the commits are
 // (nearly) conflict-free WITHOUT any address swizzle -- fragment reads are then `base + compile-time offset`:
@@ -55,9 +54,10 @@ struct FastDiv {
   __device__ __forceinline__ void divmod(uint32_t n, uint32_t& q, uint32_t& r) const { q = div(n); r = n - q * d; }
 };
 
-template <int BI_, int BJ_, int WI_, int WJ_>
+template <int BI_, int BJ_, int WI_, int WJ_, int BR_ = 32>
 struct Tile {
   static constexpr int BI = BI_, BJ = BJ_, WI = WI_, WJ = WJ_;
+  static constexpr int BR = BR_;   // reduction depth staged per LDS slab (128 for the latency-bound small-token stages)
   static constexpr int TI = BI / WI / 16, TJ = BJ / WJ / 16;
   static_assert(WI * WJ == 4, "4 waves per workgroup");
   static_assert(TI * 16 * WI == BI && TJ * 16 * WJ == BJ, "tile must split into 16x16 MFMA tiles");
@@ -65,7 +65,7 @@ struct Tile {
 
 // ------------------------------------------------------------------ staging: fetch (HBM -> registers), commit (-> LDS)
 // "T" mapping: the source is contiguous along r.  A thread handles 4 consecutive r of one x (float4 from HBM).
-template <int BX>
+template <int BX, int kBR>
 struct StageT {
   static constexpr int NIT = (BX * (kBR / 4) + kThreads - 1) / kThreads;
   static constexpr int STRIDE = lds_stride_t(BX);
@@ -91,7 +91,7 @@ struct StageT {
   }
 };
 // "D" mapping: the source is contiguous along x.  A thread handles 4 consecutive x of one r (float4 both sides).
-template <int BX>
+template <int BX, int kBR>
 struct StageD {
   static constexpr int XV = BX / 4;
   static constexpr int NIT = (kBR * XV + kThreads - 1) / kThreads;
@@ -117,7 +117,7 @@ struct StageD {
   }
 };
 // "E" mapping: per-element functor, threads walk x fastest (scalar both sides).
-template <int BX>
+template <int BX, int kBR>
 struct StageE {
   static constexpr int NIT = (BX * kBR + kThreads - 1) / kThreads;
   static constexpr int STRIDE = lds_stride_d(BX);
@@ -161,9 +161,9 @@ struct RowsT {
   const float* scale;   // XF only
   FastDiv rps;
   int gelu;
-  template <int BX> using Stage = StageT<BX>;
-  template <int BX>
-  __device__ __forceinline__ void fetch(Stage<BX>& st, int x0, int r0, int r_end, int tid) const {
+  template <int BX, int BR> using Stage = StageT<BX, BR>;
+  template <int BX, int BR>
+  __device__ __forceinline__ void fetch(Stage<BX, BR>& st, int x0, int r0, int r_end, int tid) const {
     st.fetch(x0, r0, tid, [&](int x, int r, float* v) {
       v[0] = v[1] = v[2] = v[3] = 0.f;
       if (x >= X || r >= r_end) return;
@@ -206,9 +206,9 @@ struct RowsD {
   const float* scale;
   FastDiv rps;
   int gelu;
-  template <int BX> using Stage = StageD<BX>;
-  template <int BX>
-  __device__ __forceinline__ void fetch(Stage<BX>& st, int x0, int r0, int r_end, int tid) const {
+  template <int BX, int BR> using Stage = StageD<BX, BR>;
+  template <int BX, int BR>
+  __device__ __forceinline__ void fetch(Stage<BX, BR>& st, int x0, int r0, int r_end, int tid) const {
     st.fetch(x0, r0, tid, [&](int x, int r, float* v) {
       v[0] = v[1] = v[2] = v[3] = 0.f;
       if (r >= r_end || x >= X) return;
@@ -252,9 +252,9 @@ template <class F, bool MAP_T>
 struct Elem {
   F f;
   int X;
-  template <int BX> using Stage = typename std::conditional<MAP_T, StageT<BX>, StageE<BX>>::type;
-  template <int BX>
-  __device__ __forceinline__ void fetch(Stage<BX>& st, int x0, int r0, int r_end, int tid) const {
+  template <int BX, int BR> using Stage = typename std::conditional<MAP_T, StageT<BX, BR>, StageE<BX, BR>>::type;
+  template <int BX, int BR>
+  __device__ __forceinline__ void fetch(Stage<BX, BR>& st, int x0, int r0, int r_end, int tid) const {
     if constexpr (MAP_T) {
       st.fetch(x0, r0, tid, [&](int x, int r, float* v) {
 #pragma unroll
@@ -277,8 +277,9 @@ template <class T, class PAcc, class QAcc, class Epi>
 __global__ void __launch_bounds__(kThreads) gemm_kernel(PAcc pa, QAcc qa, Epi epi, int I, int J, int R, int r_chunk,
                                                         int tiles_i, int tiles_j, int jpb, float* colsum,
                                                         int colsum_side) {
-  using SPt = typename PAcc::template Stage<T::BI>;
-  using SQt = typename QAcc::template Stage<T::BJ>;
+  constexpr int kBR = T::BR;
+  using SPt = typename PAcc::template Stage<T::BI, T::BR>;
+  using SQt = typename QAcc::template Stage<T::BJ, T::BR>;
   constexpr int SP = SPt::STRIDE, SQ = SQt::STRIDE;
   __shared__ __attribute__((aligned(16))) float Ps[2][kBR * SP];
   __shared__ __attribute__((aligned(16))) float Qs[2][kBR * SQ];
@@ -309,8 +310,8 @@ __global__ void __launch_bounds__(kThreads) gemm_kernel(PAcc pa, QAcc qa, Epi ep
 
   const int li = lane & 15, lr = lane >> 4;
   if (n_it <= 0) return;
-  pa.template fetch<T::BI>(sp, i0, r_begin, r_end, tid);
-  qa.template fetch<T::BJ>(sq, jt_begin * T::BJ, r_begin, r_end, tid);
+  pa.template fetch<T::BI, T::BR>(sp, i0, r_begin, r_end, tid);
+  qa.template fetch<T::BJ, T::BR>(sq, jt_begin * T::BJ, r_begin, r_end, tid);
   sp.commit(Ps[0], tid);
   sq.commit(Qs[0], tid);
   __syncthreads();
@@ -320,8 +321,8 @@ __global__ void __launch_bounds__(kThreads) gemm_kernel(PAcc pa, QAcc qa, Epi ep
     int njt = jt, nslb = slab + 1;
     if (nslb == nslab) { nslb = 0; ++njt; }
     if (more) {                                   // prefetch the next slab (possibly of the next token tile) into registers
-      pa.template fetch<T::BI>(sp, i0, r_begin + nslb * kBR, r_end, tid);
-      qa.template fetch<T::BJ>(sq, njt * T::BJ, r_begin + nslb * kBR, r_end, tid);
+      pa.template fetch<T::BI, T::BR>(sp, i0, r_begin + nslb * kBR, r_end, tid);
+      qa.template fetch<T::BJ, T::BR>(sq, njt * T::BJ, r_begin + nslb * kBR, r_end, tid);
     }
     // per-lane fragment bases: every read below is base + compile-time offset
     const float* P = Ps[cur] + lr * SP + wi * (T::BI / T::WI) + li;
@@ -402,7 +403,7 @@ inline hipError_t launch_gemm(PAcc pa, QAcc qa, Epi epi, int I, int64_t J, int R
                               float* colsum = nullptr, int colsum_side = 0) {
   if (I <= 0 || J <= 0 || R <= 0) return hipSuccess;
   if (splits < 1) splits = 1;
-  int r_chunk = ceil_div(ceil_div(R, splits), kBR) * kBR;
+  int r_chunk = ceil_div(ceil_div(R, splits), 32) * 32;
   splits = ceil_div(R, r_chunk);
 #define MICF_LT(...) launch_tile<Tile<__VA_ARGS__>>(pa, qa, epi, I, J, R, r_chunk, splits, colsum, colsum_side, stream)
   const int64_t big = (int64_t)ceil_div(I, 64) * ceil_div(J, 64) * splits;

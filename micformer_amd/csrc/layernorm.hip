@@ -76,6 +76,158 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const float* dy, const floa
   }
 }
 
+
+// ------------------------------------------------------------------ v2: register-resident rows, 16-byte accesses
+// A row of C floats is held by LPR lanes (VPL float4 each), so a wave normalises 64/LPR rows at once with ONE pass over
+// HBM (the v1 kernels re-read the row three times through L1 and keep 16 of 64 lanes idle at C = 48).  The backward keeps
+// the per-column dgamma / dbeta partials in registers across all rows a lane visits and flushes once per workgroup.
+__device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int LPR, int VPL>
+__global__ void __launch_bounds__(256) ln_fwd_v2(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                 const float* __restrict__ beta, float* __restrict__ y,
+                                                 float* __restrict__ mean, float* __restrict__ rstd, int64_t rows, int C,
+                                                 float eps, int rpb) {
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane % LPR, rg = lane / LPR;
+  const int64_t r_end = ((int64_t)(blockIdx.x + 1) * rpb < rows) ? (int64_t)(blockIdx.x + 1) * rpb : rows;
+  float4 g[VPL], b[VPL];
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) {
+    const int c = (sub + k * LPR) * 4;
+    g[k] = c < C ? ldg4(gamma + c) : make_float4(0, 0, 0, 0);
+    b[k] = c < C ? ldg4(beta + c) : make_float4(0, 0, 0, 0);
+  }
+  const float invC = 1.0f / (float)C;
+  for (int64_t row = (int64_t)blockIdx.x * rpb + wave * RPW + rg; row < r_end; row += 4 * RPW) {
+    float4 v[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+      const int c = (sub + k * LPR) * 4;
+      v[k] = c < C ? ldg4(x + row * C + c) : make_float4(0, 0, 0, 0);
+      s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    }
+    const float mu = group_sum<LPR>(s) * invC;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+      const int c = (sub + k * LPR) * 4;
+      if (c < C) { const float a0 = v[k].x - mu, a1 = v[k].y - mu, a2 = v[k].z - mu, a3 = v[k].w - mu; q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3); }
+    }
+    const float rs = 1.0f / sqrtf(group_sum<LPR>(q) * invC + eps);
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+      const int c = (sub + k * LPR) * 4;
+      if (c < C)
+        *reinterpret_cast<float4*>(y + row * C + c) =
+            make_float4((v[k].x - mu) * rs * g[k].x + b[k].x, (v[k].y - mu) * rs * g[k].y + b[k].y,
+                        (v[k].z - mu) * rs * g[k].z + b[k].z, (v[k].w - mu) * rs * g[k].w + b[k].w);
+    }
+    if (sub == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
+  }
+}
+
+template <int LPR, int VPL>
+__global__ void __launch_bounds__(256) ln_bwd_v2(const float* dy, const float* __restrict__ x, const float* __restrict__ mean,
+                                                 const float* __restrict__ rstd, const float* __restrict__ gamma, float* dx,
+                                                 float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int C,
+                                                 const float* add, int rpb) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // [2][C]
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane % LPR, rg = lane / LPR;
+  for (int c = threadIdx.x; c < 2 * C; c += 256) sm[c] = 0.f;
+  __syncthreads();
+  const int64_t r_end = ((int64_t)(blockIdx.x + 1) * rpb < rows) ? (int64_t)(blockIdx.x + 1) * rpb : rows;
+  float4 g[VPL], ag[VPL], ab[VPL];
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) {
+    const int c = (sub + k * LPR) * 4;
+    g[k] = c < C ? ldg4(gamma + c) : make_float4(0, 0, 0, 0);
+    ag[k] = make_float4(0, 0, 0, 0);
+    ab[k] = make_float4(0, 0, 0, 0);
+  }
+  const float invC = 1.0f / (float)C;
+  for (int64_t row = (int64_t)blockIdx.x * rpb + wave * RPW + rg; row < r_end; row += 4 * RPW) {
+    const float mu = mean[row], rs = rstd[row];
+    float4 xh[VPL], d[VPL];
+    float sa = 0.f, sb = 0.f;
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+      const int c = (sub + k * LPR) * 4;
+      if (c < C) {
+        const float4 v = ldg4(x + row * C + c);
+        d[k] = ldg4(dy + row * C + c);
+        xh[k] = make_float4((v.x - mu) * rs, (v.y - mu) * rs, (v.z - mu) * rs, (v.w - mu) * rs);
+        const float g0 = g[k].x * d[k].x, g1 = g[k].y * d[k].y, g2 = g[k].z * d[k].z, g3 = g[k].w * d[k].w;
+        sa += (g0 + g1) + (g2 + g3);
+        sb += (g0 * xh[k].x + g1 * xh[k].y) + (g2 * xh[k].z + g3 * xh[k].w);
+        ag[k].x += d[k].x * xh[k].x; ag[k].y += d[k].y * xh[k].y; ag[k].z += d[k].z * xh[k].z; ag[k].w += d[k].w * xh[k].w;
+        ab[k].x += d[k].x; ab[k].y += d[k].y; ab[k].z += d[k].z; ab[k].w += d[k].w;
+      } else { xh[k] = make_float4(0, 0, 0, 0); d[k] = make_float4(0, 0, 0, 0); }
+    }
+    const float A = group_sum<LPR>(sa) * invC, Bv = group_sum<LPR>(sb) * invC;
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+      const int c = (sub + k * LPR) * 4;
+      if (c < C) {
+        float4 o = make_float4(rs * (g[k].x * d[k].x - A - xh[k].x * Bv), rs * (g[k].y * d[k].y - A - xh[k].y * Bv),
+                               rs * (g[k].z * d[k].z - A - xh[k].z * Bv), rs * (g[k].w * d[k].w - A - xh[k].w * Bv));
+        if (add) { const float4 a = ldg4(add + row * C + c); o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w; }
+        *reinterpret_cast<float4*>(dx + row * C + c) = o;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) {
+    const int c = (sub + k * LPR) * 4;
+    if (c < C) {
+      atomicAdd(&sm[c], ag[k].x); atomicAdd(&sm[c + 1], ag[k].y); atomicAdd(&sm[c + 2], ag[k].z); atomicAdd(&sm[c + 3], ag[k].w);
+      atomicAdd(&sm[C + c], ab[k].x); atomicAdd(&sm[C + c + 1], ab[k].y); atomicAdd(&sm[C + c + 2], ab[k].z); atomicAdd(&sm[C + c + 3], ab[k].w);
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    if (dgamma) atomicAdd(dgamma + c, sm[c]);
+    if (dbeta) atomicAdd(dbeta + c, sm[C + c]);
+  }
+}
+
+// pick (LPR, VPL) for C (C % 4 == 0): smallest lane group that covers C/4 vectors, up to 8 vectors per lane
+static bool ln_v2_shape(int C, int& lpr, int& vpl) {
+  if (C % 4) return false;
+  const int nv = C / 4;
+  lpr = nv <= 16 ? 16 : (nv <= 32 ? 32 : 64);
+  vpl = (nv + lpr - 1) / lpr;
+  return vpl <= 8;
+}
+static int ln_v2_rpb(int64_t rows, int lpr, int max_blocks) {
+  const int step = 4 * (64 / lpr);
+  int64_t rpb = (rows + max_blocks - 1) / max_blocks;
+  rpb = (rpb + step - 1) / step * step;
+  return (int)(rpb < step ? step : rpb);
+}
+
+#define MICF_LN_DISPATCH(KERNEL, SMEM, MAXB, ...)                                                        \
+  do {                                                                                                   \
+    const int rpb = ln_v2_rpb(rows, lpr, MAXB);                                                          \
+    const dim3 grid(ceil_div(rows, rpb));                                                                \
+    hipStream_t s_ = (hipStream_t)stream;                                                                \
+    if (lpr == 16 && vpl == 1) hipLaunchKernelGGL((KERNEL<16, 1>), grid, dim3(256), SMEM, s_, __VA_ARGS__, rpb); \
+    else if (lpr == 32 && vpl == 1) hipLaunchKernelGGL((KERNEL<32, 1>), grid, dim3(256), SMEM, s_, __VA_ARGS__, rpb); \
+    else if (vpl == 1) hipLaunchKernelGGL((KERNEL<64, 1>), grid, dim3(256), SMEM, s_, __VA_ARGS__, rpb); \
+    else if (vpl == 2) hipLaunchKernelGGL((KERNEL<64, 2>), grid, dim3(256), SMEM, s_, __VA_ARGS__, rpb); \
+    else if (vpl <= 4) hipLaunchKernelGGL((KERNEL<64, 4>), grid, dim3(256), SMEM, s_, __VA_ARGS__, rpb); \
+    else hipLaunchKernelGGL((KERNEL<64, 8>), grid, dim3(256), SMEM, s_, __VA_ARGS__, rpb);               \
+  } while (0)
+
 }  // namespace micf
 using namespace micf;
 
@@ -84,6 +236,11 @@ extern "C" int micf_layernorm_fwd(const float* x1, const float* x2, int c1, cons
                                   micf_stream_t stream) {
   if (!x1 || !gamma || !beta || !y || rows < 0 || C <= 0 || c1 <= 0 || c1 > C || (c1 < C && !x2)) return MICF_EINVAL;
   if (rows == 0) return MICF_OK;
+  int lpr, vpl;
+  if (!x2 && ln_v2_shape(C, lpr, vpl) && aligned16(x1) && aligned16(y) && aligned16(gamma) && aligned16(beta)) {
+    MICF_LN_DISPATCH(ln_fwd_v2, 0, 2048, x1, gamma, beta, y, mean, rstd, rows, C, eps);
+    MICF_RETURN_LAUNCH();
+  }
   const int rpb = ln_rows_per_block(rows);
   const int blocks = ceil_div(rows, rpb);
   hipLaunchKernelGGL(ln_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x1, x2 ? x2 : x1, c1, gamma, beta, y,
@@ -99,6 +256,12 @@ extern "C" int micf_layernorm_bwd(const float* dy, const float* x1, const float*
     return MICF_EINVAL;
   if (C > kLnMaxC) return MICF_EUNSUPPORTED;
   if (rows == 0) return MICF_OK;
+  int lpr, vpl;
+  if (!x2 && ln_v2_shape(C, lpr, vpl) && aligned16(x1) && aligned16(dy) && aligned16(dx1) && aligned16(gamma) &&
+      (!add || aligned16(add))) {
+    MICF_LN_DISPATCH(ln_bwd_v2, 2 * C * sizeof(float), 512, dy, x1, mean, rstd, gamma, dx1, dgamma, dbeta, rows, C, add);
+    MICF_RETURN_LAUNCH();
+  }
   const int rpb = ln_rows_per_block(rows);
   const int blocks = ceil_div(rows, rpb);
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 2 * C * sizeof(float), (hipStream_t)stream, dy, x1,

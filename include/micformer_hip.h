@@ -64,10 +64,15 @@ int micf_linear_fwd(const float* a1, const float* a2, int k1, const float* w, co
 int micf_linear_bwd_data(const float* dy, const float* dp_scale, int64_t rows_per_sample, const float* w,
                          const float* pre_act, float* da1, float* da2, int k1, int accumulate, int64_t M, int N, int K,
                          micf_stream_t stream);
-/* dW += (s*dy)^T @ A, dbias += colsum(s*dy);  A = [a1|a2], or GELU(a1) when a_gelu != 0 (a1 = saved pre-activation). */
+/* dW += (s*dy)^T @ A, dbias += colsum(s*dy);  A = [a1|a2], or GELU(a1) when a_gelu != 0 (a1 = saved pre-activation).
+ * workspace (optional, caller-owned scratch of workspace_floats fp32, see micf_linear_bwd_weight_workspace): when large
+ * enough the token-split partial products are written there with plain 16-byte stores and reduced by a second launch
+ * instead of being atomically added (device-scope fp32 atomics cost one fabric transaction each). */
 int micf_linear_bwd_weight(const float* dy, const float* dp_scale, int64_t rows_per_sample, const float* a1,
                            const float* a2, int k1, int a_gelu, float* dw, float* dbias, int64_t M, int N, int K,
-                           micf_stream_t stream);
+                           float* workspace, int64_t workspace_floats, micf_stream_t stream);
+/* Upper bound of the scratch (in floats) micf_linear_bwd_weight can use for (M, N, K). */
+int64_t micf_linear_bwd_weight_workspace(int64_t M, int N, int K);
 
 /* ---- (Cross)WindowAttention3D core on channels-last token grids, windows by index math (never materialised):
  * softmax((q*scale) k^T) v per head and per non-overlapping (wd,wh,ww) window (MS.py:193-200, 251-258;

@@ -21,7 +21,8 @@ SIGNATURES = {
     "micf_layernorm_bwd": "pppippppppplipp",
     "micf_linear_fwd": "ppipppplppliiip",
     "micf_linear_bwd_data": "pplppppiiliip",
-    "micf_linear_bwd_weight": "pplppiippliip",
+    "micf_linear_bwd_weight": "pplppiippliiplp",
+    "micf_linear_bwd_weight_workspace": "lii",
     "micf_window_attn_fwd": "pippipiiiiiiiiiifp",
     "micf_window_attn_bwd": "pippipipippiiiiiiiiiifp",
     "micf_conv3_fwd": "pipipppiiiiiip",
@@ -65,6 +66,7 @@ def _load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing: fail loudly
         fn.argtypes = [_T[c] for c in sig]
         fn.restype = _I
+    lib.micf_linear_bwd_weight_workspace.restype = _L
     lib.micf_strerror.argtypes = [_I]
     lib.micf_strerror.restype = ctypes.c_char_p
     lib.micf_abi_version.argtypes = []

@@ -50,6 +50,7 @@ __global__ void __launch_bounds__(256) conv3_wgrad_kernel(const float* __restric
     const int d0 = td * kTD, h0 = th * kTH, w0 = tw * kTW;
     __syncthreads();                                 // previous tile fully consumed
     // ---- stage the halo of the input chunk: 600 voxels x 6 float4
+#pragma unroll 5
     for (int idx = tid; idx < kHaloTok * 6; idx += 256) {
       const int v = idx / 6, g = idx % 6;
       const int hw = v % kHW, hh = (v / kHW) % kHH, hd = v / (kHW * kHH);
@@ -73,6 +74,7 @@ __global__ void __launch_bounds__(256) conv3_wgrad_kernel(const float* __restric
       *reinterpret_cast<float4*>(sx + v * kCC + 4 * g) = val;
     }
     // ---- stage dy of the 256 tile tokens (zero outside the volume)
+#pragma unroll
     for (int idx = tid; idx < kTileTok * N; idx += 256) {
       int tok, n;
       if (dy_layout == 0) { tok = idx / N; n = idx % N; } else { n = idx / kTileTok; tok = idx % kTileTok; }

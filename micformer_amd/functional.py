@@ -102,15 +102,15 @@ def _mlp_fwd(x1f, dims, P, s2, eps):
     xn2, m2, r2 = ops.layernorm_fwd(x1f, P["norm2.weight"], P["norm2.bias"], eps)
     g, h = ops.linear_fwd(xn2, P["mlp.fc1.weight"], P["mlp.fc1.bias"], act=1, want_pre=True)
     y = ops.linear_fwd(g, P["mlp.fc2.weight"], P["mlp.fc2.bias"], resid=x1f, dp_scale=s2, rows_per_sample=rps)
-    return y, (xn2, m2, r2, h)
+    return y, (xn2, m2, r2, h, g)
 
 
 def _mlp_bwd(dy, x1f, saved, dims, P, G, s2):
     """Returns dx1 = dy + LN2'(...) and accumulates the part2 parameter gradients into G."""
     B, D, H, W = dims
     rps = D * H * W
-    xn2, m2, r2, h = saved
-    ops.linear_bwd_weight(dy, h, G["mlp.fc2.weight"], G["mlp.fc2.bias"], dp_scale=s2, rows_per_sample=rps, a_gelu=True)
+    xn2, m2, r2, h, g = saved      # g = GELU(h) is kept (HBM is plentiful) so the fc2 weight gradient is a plain GEMM
+    ops.linear_bwd_weight(dy, g, G["mlp.fc2.weight"], G["mlp.fc2.bias"], dp_scale=s2, rows_per_sample=rps)
     dh = ops.linear_bwd_data(dy, P["mlp.fc2.weight"], dp_scale=s2, rows_per_sample=rps, pre_act=h)
     ops.linear_bwd_weight(dh, xn2, G["mlp.fc1.weight"], G["mlp.fc1.bias"])
     dxn2 = ops.linear_bwd_data(dh, P["mlp.fc1.weight"])
@@ -160,8 +160,8 @@ class SelfBlockFn(torch.autograd.Function):
     def backward(ctx, dy):
         sv = ctx.saved_tensors
         xf, m1, r1, xnp, q, kv, o, x1, s1, s2 = sv[:10]
-        mlp_saved = sv[10:14]
-        params = sv[14:]
+        mlp_saved = sv[10:15]
+        params = sv[15:]
         P = dict(zip(SELF_KEYS, params))
         G = {k: _grad_buf(t, v) for (k, v), t in zip(P.items(), ctx.tg)}
         dims, ws, pd, padded, heads, scale = ctx.meta
@@ -226,8 +226,8 @@ class CrossBlockFn(torch.autograd.Function):
     def backward(ctx, dy):
         sv = ctx.saved_tensors
         xf, m1, r1, xnp, xap, hid, flow, xs, q, kv, o, x1, s1, s2 = sv[:14]
-        mlp_saved = sv[14:18]
-        params = sv[18:]
+        mlp_saved = sv[14:19]
+        params = sv[19:]
         P = dict(zip(CROSS_KEYS, params))
         G = {k: _grad_buf(t, v) for (k, v), t in zip(P.items(), ctx.tg)}
         dims, ws, pd, padded, heads, scale, eps = ctx.meta

@@ -83,13 +83,28 @@ def linear_bwd_data(dy, w, dp_scale=None, rows_per_sample=0, pre_act=None, k1=No
     return (da1, da2) if da2 is not None else da1
 
 
+_SCRATCH = {}
+
+
+def scratch(device, nfloats):
+    """Per-device fp32 scratch reused by every launch that wants a workspace (stream-ordered, so sharing is safe on one stream).
+    It only grows; under HIP-graph capture it is allocated during the eager warm-up steps."""
+    buf = _SCRATCH.get(device)
+    if buf is None or buf.numel() < nfloats:
+        buf = torch.empty(max(int(nfloats), 1 << 22), dtype=torch.float32, device=device)
+        _SCRATCH[device] = buf
+    return buf
+
+
 def linear_bwd_weight(dy, a1, dw, dbias, a2=None, dp_scale=None, rows_per_sample=0, a_gelu=False):
     """dw += (s*dy)^T [a1|a2] (or GELU(a1)); dbias += colsum(s*dy).  dw/dbias are accumulated in place."""
     M, N = dy.shape
     k1 = a1.shape[1]
     K = dw.shape[1]
+    need = _lib.lib.micf_linear_bwd_weight_workspace(M, N, K)
+    ws = scratch(dy.device, need) if need > 0 else None
     call("micf_linear_bwd_weight", f32(dy), f32(dp_scale), rows_per_sample, f32(a1), f32(a2), k1, 1 if a_gelu else 0,
-         f32(dw), f32(dbias), M, N, K,
+         f32(dw), f32(dbias), M, N, K, f32(ws), ws.numel() if ws is not None else 0,
          cost=_cost(2 * M * N * K, dy, a1, a2, dw, tag=f'{M}x{N}x{K}'))
 
 

@@ -12,7 +12,7 @@ def parse_header():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     decls = {}
-    for m in re.finditer(r"\b(int|const char\*)\s+(micf_\w+)\s*\(([^)]*)\)\s*;", src):
+    for m in re.finditer(r"\b(int64_t|int|const char\*)\s+(micf_\w+)\s*\(([^)]*)\)\s*;", src):
         ret, name, args = m.group(1), m.group(2), m.group(3)
         sig = ""
         for a in [a.strip() for a in args.split(",") if a.strip() and a.strip() != "void"]:
@@ -34,8 +34,9 @@ def parse_header():
 
 def test_header_declares_expected_entry_points():
     d = parse_header()
-    assert len(d) == 33, sorted(d)
-    assert all(sig.endswith("p") for n, sig in d.items() if n not in ("micf_abi_version", "micf_strerror"))
+    assert len(d) == 34, sorted(d)
+    assert all(sig.endswith("p") for n, sig in d.items()
+               if n not in ("micf_abi_version", "micf_strerror", "micf_linear_bwd_weight_workspace"))
 
 
 def test_library_exports_every_declared_symbol():

@@ -155,7 +155,11 @@ def test_window_attention(ops, dims, C, heads, ws):
 # ----------------------------------------------------------------------------- conv 3x3x3
 @pytest.mark.parametrize("dims,c1,c2,N,ncdhw", [((2, 4, 5, 6), 24, 24, 16, False), ((1, 6, 4, 4), 48, 48, 16, False),
                                                 ((2, 5, 4, 7), 12, 0, 8, True), ((1, 3, 3, 3), 24, 0, 8, True),
-                                                ((1, 2, 1, 3), 6, 6, 16, False)])
+                                                ((1, 2, 1, 3), 6, 6, 16, False),
+                                                # large enough token grids for the direct LDS-halo kernels (>= 32 tiles), ragged edges
+                                                ((2, 9, 10, 19), 24, 24, 16, False), ((1, 8, 16, 32), 48, 48, 16, False),
+                                                ((1, 16, 12, 20), 24, 0, 8, True), ((2, 7, 9, 17), 12, 0, 8, True),
+                                                ((1, 10, 16, 16), 24, 24, 16, False)])
 def test_conv3(ops, dims, c1, c2, N, ncdhw):
     B, D, H, W = dims
     T = B * D * H * W

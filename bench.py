@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--serial-modalities", action="store_true", help="do not overlap the CT / MR branches on two streams")
     ap.add_argument("--detail", action="store_true", help="roofline leg: key kernels by shape too (diagnostic)")
     ap.add_argument("--eval-mode", action="store_true", help="DropPath off (default: train mode, DropPath active)")
     args = ap.parse_args()
@@ -112,7 +113,8 @@ def main():
     torch.manual_seed(1234 + rank)                              # rank-distinct DropPath stream and data
     vol = (args.vol,) * 3
     x, tgt = synthetic_batch(args.batch, vol, 8, dev, 1234 + rank)
-    eng = TrainEngine(model, base_lr=1e-4, t_max=150, use_graph=not args.no_graph)
+    eng = TrainEngine(model, base_lr=1e-4, t_max=150, use_graph=not args.no_graph,
+                      parallel_modalities=not args.serial_modalities)
 
     def barrier():
         if world > 1:

@@ -131,8 +131,40 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ d
   }
 }
 
+// narrow matrices (N % 4 == 0, N <= 256, no scale): thread (column group g, row lane r) streams float4 rows, LDS-reduces over r
+__global__ void __launch_bounds__(256) colsum4_kernel(const float* __restrict__ dy, float* __restrict__ out, int64_t M, int N,
+                                                      int64_t rows_per_block) {
+  __shared__ float4 part[256];
+  const int ng = N / 4, rl = 256 / ng;                     // row lanes per column group
+  const int g = threadIdx.x % ng, r = threadIdx.x / ng;
+  const int64_t m0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t m1 = (m0 + rows_per_block < M) ? m0 + rows_per_block : M;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (r < rl) {
+    for (int64_t m = m0 + r; m < m1; m += rl) {
+      const float4 v = *reinterpret_cast<const float4*>(dy + m * N + 4 * g);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x < ng) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < rl; ++k) { const float4 v = part[k * ng + threadIdx.x]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+    atomicAdd(out + 4 * threadIdx.x + 0, s.x); atomicAdd(out + 4 * threadIdx.x + 1, s.y);
+    atomicAdd(out + 4 * threadIdx.x + 2, s.z); atomicAdd(out + 4 * threadIdx.x + 3, s.w);
+  }
+}
+
 int colsum_atomic(const float* dy, const float* scale, int64_t rps, float* out, int64_t M, int N, hipStream_t s) {
   if (M <= 0 || N <= 0) return MICF_OK;
+  if (!scale && N % 4 == 0 && N <= 256 && aligned16(dy)) {
+    int64_t rpb = (M + 1023) / 1024;
+    if (rpb < 256) rpb = 256;
+    const int blocks = (int)((M + rpb - 1) / rpb);
+    hipLaunchKernelGGL(colsum4_kernel, dim3(blocks), dim3(256), 0, s, dy, out, M, N, rpb);
+    MICF_RETURN_LAUNCH();
+  }
   int rpb = (int)((M + 1023) / 1024);
   if (rpb < 32) rpb = 32;
   const int blocks = (int)((M + rpb - 1) / rpb);

@@ -12,7 +12,9 @@
 namespace micf {
 
 constexpr int kHid = 16;
-constexpr int kTokPerWave = 8;
+// tokens walked by one wave: 8 amortises the per-wave flush of the head's parameter gradients on big grids; small grids
+// (8^3, 4^3 stages) take 1 so that every CU gets a wave
+static inline int tok_per_wave(int64_t T) { return T >= 32768 ? 8 : (T >= 4096 ? 2 : 1); }
 
 __device__ __forceinline__ float sum16(float v) {   // all-reduce inside each 16-lane group
 #pragma unroll
@@ -67,11 +69,11 @@ __device__ __forceinline__ void head_fwd(const float* hrow, const float* ln_g, c
 __global__ void __launch_bounds__(256) offset_sample_fwd_kernel(const float* __restrict__ h, const float* __restrict__ ln_g,
                                                                 const float* __restrict__ ln_b, const float* __restrict__ w1,
                                                                 const float* __restrict__ xa, float* __restrict__ flow_out,
-                                                                float* __restrict__ xs, Geo g, int C, float eps) {
+                                                                float* __restrict__ xs, Geo g, int C, float eps, int tpw) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, k = lane & 15;
   const int64_t T = g.tokens();
-  for (int it = 0; it < kTokPerWave; ++it) {
-    const int64_t t = ((int64_t)blockIdx.x * 4 + wave) * kTokPerWave + it;
+  for (int it = 0; it < tpw; ++it) {
+    const int64_t t = ((int64_t)blockIdx.x * 4 + wave) * tpw + it;
     if (t >= T) return;
     float xh, rs, ln, gl, off[3];
     head_fwd(h + t * kHid, ln_g, ln_b, w1, eps, k, xh, rs, ln, gl, off);
@@ -106,12 +108,13 @@ __global__ void __launch_bounds__(256) offset_sample_fwd_kernel(const float* __r
 __global__ void __launch_bounds__(256) offset_sample_bwd_kernel(
     const float* __restrict__ dxs, const float* __restrict__ h, const float* __restrict__ ln_g, const float* __restrict__ ln_b,
     const float* __restrict__ w1, const float* __restrict__ xa, const float* __restrict__ flow, float* __restrict__ dxa,
-    float* __restrict__ dh, float* __restrict__ dln_g, float* __restrict__ dln_b, float* __restrict__ dw1, Geo g, int C, float eps) {
+    float* __restrict__ dh, float* __restrict__ dln_g, float* __restrict__ dln_b, float* __restrict__ dw1, Geo g, int C, float eps,
+    int tpw) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, k = lane & 15;
   const int64_t T = g.tokens();
   float acc_w[3] = {0.f, 0.f, 0.f}, acc_g = 0.f, acc_b = 0.f;       // per-lane (channel k) partials, lanes 0..15 flush
-  for (int it = 0; it < kTokPerWave; ++it) {
-    const int64_t t = ((int64_t)blockIdx.x * 4 + wave) * kTokPerWave + it;
+  for (int it = 0; it < tpw; ++it) {
+    const int64_t t = ((int64_t)blockIdx.x * 4 + wave) * tpw + it;
     if (t >= T) break;
     float xh, rs, ln, gl, off[3];
     head_fwd(h + t * kHid, ln_g, ln_b, w1, eps, k, xh, rs, ln, gl, off);
@@ -250,9 +253,10 @@ extern "C" int micf_offset_sample_fwd(const float* h, const float* ln_g, const f
   if (!h || !ln_g || !ln_b || !w1 || !xa || !flow || !xs || B <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0) return MICF_EINVAL;
   const Geo g{B, D, H, W};
   if (g.tokens() >= (1LL << 31)) return MICF_EUNSUPPORTED;
-  const int blocks = ceil_div(g.tokens(), 4 * kTokPerWave);
+  const int tpw = tok_per_wave(g.tokens());
+  const int blocks = ceil_div(g.tokens(), 4 * tpw);
   hipLaunchKernelGGL(offset_sample_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, h, ln_g, ln_b, w1, xa, flow,
-                     xs, g, C, eps);
+                     xs, g, C, eps, tpw);
   MICF_RETURN_LAUNCH();
 }
 
@@ -265,9 +269,10 @@ extern "C" int micf_offset_sample_bwd(const float* dxs, const float* h, const fl
     return MICF_EINVAL;
   const Geo g{B, D, H, W};
   if (g.tokens() >= (1LL << 31)) return MICF_EUNSUPPORTED;
-  const int blocks = ceil_div(g.tokens(), 4 * kTokPerWave);
+  const int tpw = tok_per_wave(g.tokens());
+  const int blocks = ceil_div(g.tokens(), 4 * tpw);
   hipLaunchKernelGGL(offset_sample_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dxs, h, ln_g, ln_b, w1, xa,
-                     flow, dxa, dh, dln_g, dln_b, dw1, g, C, eps);
+                     flow, dxa, dh, dln_g, dln_b, dw1, g, C, eps, tpw);
   MICF_RETURN_LAUNCH();
 }
 

@@ -22,7 +22,7 @@ from .loss.dice import MDiceLoss
 
 class TrainEngine:
     def __init__(self, model, base_lr=1e-4, t_max=150, eta_min=0.0, betas=(0.9, 0.999), eps=1e-8, criterion=None,
-                 use_graph=False, process_group=None, grad_bucket_bytes=64 << 20):
+                 use_graph=False, process_group=None, grad_bucket_bytes=64 << 20, parallel_modalities=True):
         self.model = model
         self.criterion = criterion if criterion is not None else MDiceLoss()
         self.base_lr, self.t_max, self.eta_min = base_lr, t_max, eta_min
@@ -31,6 +31,9 @@ class TrainEngine:
         self.world = self.sync.world
         self._flatten()
         self.sync.broadcast_params(self.flat_p)                    # rank-identical initial weights
+        # the CT and MR branches of every depth slot are independent: issue them on two streams (see BasicLayer.forward)
+        from .models import MICFormer_self as _ms
+        _ms.PARALLEL_MODALITIES = bool(parallel_modalities)
         self.use_graph = use_graph
         self._graph = None
         self._static = None

@@ -224,6 +224,19 @@ class LayerNormProxy(nn.Module):
         return y.permute(0, 4, 1, 2, 3)
 
 
+# Run the two modalities' independent blocks on two HIP streams (engine / bench switch; off = the reference's serial order).
+PARALLEL_MODALITIES = False
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    s = _SIDE_STREAMS.get(device)
+    if s is None:
+        s = torch.cuda.Stream(device=device)
+        _SIDE_STREAMS[device] = s
+    return s
+
+
 def _block_scales(block, x):
     """The two DropPath draws of a block (part1, part2).  MicFormer pre-draws all of them in one batched RNG call per
     forward (`_predraw_drop_path`); a standalone block draws its own."""
@@ -364,9 +377,30 @@ class BasicLayer(nn.Module):
         setattr(self, self._resample_attr, resample)
 
     def forward(self, x, xa):
-        for i in range(self.depth):
-            x, xa = self.self_blocks1[i](x), self.self_blocks2[i](xa)
-            x, xa = self.blocks1[i](x, xa), self.blocks2[i](xa, x)
+        side = _side_stream(x.device) if (PARALLEL_MODALITIES and x.is_cuda) else None
+        if side is None:
+            for i in range(self.depth):
+                x, xa = self.self_blocks1[i](x), self.self_blocks2[i](xa)
+                x, xa = self.blocks1[i](x, xa), self.blocks2[i](xa, x)
+        else:
+            # The two modalities' blocks of one depth slot are independent (MS.py:700-701): issue them on two HIP streams so the
+            # launch-/latency-bound kernels of the 8^3 / 4^3 stages overlap on the 256 CUs.  autograd replays each op's
+            # backward on its forward stream, so the backward pass forks the same way; a captured HIP graph keeps the branches.
+            main = torch.cuda.current_stream()
+            for i in range(self.depth):
+                side.wait_stream(main)                              # xa (and, later, x) were produced / consumed on main
+                x1 = self.self_blocks1[i](x)
+                with torch.cuda.stream(side):
+                    xa1 = self.self_blocks2[i](xa)
+                main.wait_stream(side)
+                side.wait_stream(main)
+                xa1.record_stream(main)
+                x1.record_stream(side)
+                x = self.blocks1[i](x1, xa1)
+                with torch.cuda.stream(side):
+                    xa = self.blocks2[i](xa1, x1)
+                main.wait_stream(side)
+                xa.record_stream(main)
         resample = getattr(self, self._resample_attr)
         if resample is not None:
             return x, xa, resample(x), resample(xa)

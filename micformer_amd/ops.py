@@ -89,10 +89,11 @@ _SCRATCH = {}
 def scratch(device, nfloats):
     """Per-device fp32 scratch reused by every launch that wants a workspace (stream-ordered, so sharing is safe on one stream).
     It only grows; under HIP-graph capture it is allocated during the eager warm-up steps."""
-    buf = _SCRATCH.get(device)
+    key = (device, torch.cuda.current_stream(device).cuda_stream)      # one scratch per stream: launches on different
+    buf = _SCRATCH.get(key)                                            # streams may run concurrently
     if buf is None or buf.numel() < nfloats:
         buf = torch.empty(max(int(nfloats), 1 << 22), dtype=torch.float32, device=device)
-        _SCRATCH[device] = buf
+        _SCRATCH[key] = buf
     return buf
 
 

@@ -22,6 +22,48 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+# ----------------------------------------------------------------------------- weight-gradient side streams (engine mode)
+# Nothing downstream of a backward pass consumes the parameter gradients until the optimiser step, so in engine mode (the
+# kernels accumulate straight into the flat gradient buffer) every weight-gradient launch is issued on a side stream and
+# overlaps the data-gradient chain, which is the critical path.  TrainEngine joins the side streams before Adam.
+WGRAD_STREAMS = False
+_WG = {}
+
+
+def wgrad_streams():
+    return list(_WG.values())
+
+
+class _wgrad:
+    """`with _wgrad(on, t1, t2, ...)`: run the enclosed launches on the weight-gradient stream paired with the current one;
+    t_i are the tensors those launches read (kept alive across streams)."""
+
+    def __init__(self, on, *tensors):
+        self.on = on and WGRAD_STREAMS
+        self.tensors = tensors
+
+    def __enter__(self):
+        if not self.on:
+            return self
+        cur = torch.cuda.current_stream()
+        side = _WG.get(cur.cuda_stream)
+        if side is None:
+            side = torch.cuda.Stream(device=cur.device)
+            _WG[cur.cuda_stream] = side
+        side.wait_stream(cur)
+        for t in self.tensors:
+            if t is not None:
+                t.record_stream(side)
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.ctx.__exit__(*exc)
+        return False
+
+
 def _targets(params):
     """Engine mode: a parameter may carry `_micf_grad`, a view of the flat gradient buffer.  The backward kernels then
     accumulate straight into it (they atomically add anyway) and autograd gets None -- no zero-fill, no `grad += g` pass."""
@@ -105,14 +147,16 @@ def _mlp_fwd(x1f, dims, P, s2, eps):
     return y, (xn2, m2, r2, h, g)
 
 
-def _mlp_bwd(dy, x1f, saved, dims, P, G, s2):
+def _mlp_bwd(dy, x1f, saved, dims, P, G, s2, side=False):
     """Returns dx1 = dy + LN2'(...) and accumulates the part2 parameter gradients into G."""
     B, D, H, W = dims
     rps = D * H * W
     xn2, m2, r2, h, g = saved      # g = GELU(h) is kept (HBM is plentiful) so the fc2 weight gradient is a plain GEMM
-    ops.linear_bwd_weight(dy, g, G["mlp.fc2.weight"], G["mlp.fc2.bias"], dp_scale=s2, rows_per_sample=rps)
+    with _wgrad(side, dy, g):
+        ops.linear_bwd_weight(dy, g, G["mlp.fc2.weight"], G["mlp.fc2.bias"], dp_scale=s2, rows_per_sample=rps)
     dh = ops.linear_bwd_data(dy, P["mlp.fc2.weight"], dp_scale=s2, rows_per_sample=rps, pre_act=h)
-    ops.linear_bwd_weight(dh, xn2, G["mlp.fc1.weight"], G["mlp.fc1.bias"])
+    with _wgrad(side, dh, xn2):
+        ops.linear_bwd_weight(dh, xn2, G["mlp.fc1.weight"], G["mlp.fc1.bias"])
     dxn2 = ops.linear_bwd_data(dh, P["mlp.fc1.weight"])
     return ops.layernorm_bwd(dxn2, x1f, m2, r2, P["norm2.weight"], G["norm2.weight"], G["norm2.bias"], add=dy)
 
@@ -170,14 +214,17 @@ class SelfBlockFn(torch.autograd.Function):
         rps = D * H * W
         C = xf.shape[1]
         dy = _c(dy).reshape(-1, C)
-        dx1 = _mlp_bwd(dy, x1, mlp_saved, dims, P, G, s2)
-        ops.linear_bwd_weight(dx1, o, G["self_attn.proj.weight"], G["self_attn.proj.bias"], dp_scale=s1, rows_per_sample=rps)
+        side = all(t is not None for t in ctx.tg)      # engine mode: gradients land in the flat buffer, nobody waits for them
+        dx1 = _mlp_bwd(dy, x1, mlp_saved, dims, P, G, s2, side)
+        with _wgrad(side, dx1, o):
+            ops.linear_bwd_weight(dx1, o, G["self_attn.proj.weight"], G["self_attn.proj.bias"], dp_scale=s1, rows_per_sample=rps)
         do = ops.linear_bwd_data(dx1, P["self_attn.proj.weight"], dp_scale=s1, rows_per_sample=rps)
         if padded:
             do = ops.pad3d(do, dims, pd)
         dq, dkv = ops.window_attn_bwd(q, kv, do, pdims, heads, ws, scale)
-        ops.linear_bwd_weight(dq, xnp, G["self_attn.q.weight"], G["self_attn.q.bias"])
-        ops.linear_bwd_weight(dkv, xnp, G["self_attn.kv.weight"], G["self_attn.kv.bias"])
+        with _wgrad(side, dq, dkv, xnp):
+            ops.linear_bwd_weight(dq, xnp, G["self_attn.q.weight"], G["self_attn.q.bias"])
+            ops.linear_bwd_weight(dkv, xnp, G["self_attn.kv.weight"], G["self_attn.kv.bias"])
         dxn = ops.linear_bwd_data(dq, P["self_attn.q.weight"])
         ops.linear_bwd_data(dkv, P["self_attn.kv.weight"], out=dxn, accumulate=True)
         if padded:
@@ -236,21 +283,25 @@ class CrossBlockFn(torch.autograd.Function):
         rps = D * H * W
         C = xf.shape[1]
         dy = _c(dy).reshape(-1, C)
-        dx1 = _mlp_bwd(dy, x1, mlp_saved, dims, P, G, s2)
-        ops.linear_bwd_weight(dx1, o, G["cross_attn.proj.weight"], G["cross_attn.proj.bias"], dp_scale=s1, rows_per_sample=rps)
+        side = all(t is not None for t in ctx.tg)
+        dx1 = _mlp_bwd(dy, x1, mlp_saved, dims, P, G, s2, side)
+        with _wgrad(side, dx1, o):
+            ops.linear_bwd_weight(dx1, o, G["cross_attn.proj.weight"], G["cross_attn.proj.bias"], dp_scale=s1, rows_per_sample=rps)
         do = ops.linear_bwd_data(dx1, P["cross_attn.proj.weight"], dp_scale=s1, rows_per_sample=rps)
         if padded:
             do = ops.pad3d(do, dims, pd)
         dq, dkv = ops.window_attn_bwd(q, kv, do, pdims, heads, ws, scale)
-        ops.linear_bwd_weight(dq, xnp, G["cross_attn.q.weight"], G["cross_attn.q.bias"])
-        ops.linear_bwd_weight(dkv, xs, G["cross_attn.kv.weight"], G["cross_attn.kv.bias"])
+        with _wgrad(side, dq, dkv, xnp, xs):
+            ops.linear_bwd_weight(dq, xnp, G["cross_attn.q.weight"], G["cross_attn.q.bias"])
+            ops.linear_bwd_weight(dkv, xs, G["cross_attn.kv.weight"], G["cross_attn.kv.bias"])
         dxnp = ops.linear_bwd_data(dq, P["cross_attn.q.weight"])
         dxs = ops.linear_bwd_data(dkv, P["cross_attn.kv.weight"])
         dxap = _zl(xap)                                            # atomic scatter target of the sampler
         dhid = ops.offset_sample_bwd(dxs, hid, P["conv_offset.1.norm.weight"], P["conv_offset.1.norm.bias"],
                                      P["conv_offset.3.weight"], xap, flow, dxap, G["conv_offset.1.norm.weight"],
                                      G["conv_offset.1.norm.bias"], G["conv_offset.3.weight"], pdims, eps)
-        ops.conv3_bwd_weight(dhid, xnp, G["conv_offset.0.weight"], G["conv_offset.0.bias"], pdims, x2=xap)
+        with _wgrad(side, dhid, xnp, xap):
+            ops.conv3_bwd_weight(dhid, xnp, G["conv_offset.0.weight"], G["conv_offset.0.bias"], pdims, x2=xap)
         ops.conv3_bwd_data(dhid, P["conv_offset.0.weight"], pdims, C, C, dx1=dxnp, dx2=dxap, acc1=True, acc2=True)
         if padded:
             dxn = ops.crop3d(dxnp, dims, pd)
@@ -301,7 +352,8 @@ class ConvDownFn(torch.autograd.Function):
         dy = _c(dy)
         dw = _grad_buf(ctx.tg[0], w)
         db = ctx.tg[1] if ctx.tg[1] is not None else torch.zeros(w.shape[0], dtype=w.dtype, device=w.device)
-        ops.conv_down_bwd_weight(dy, x, dw, db)
+        with _wgrad(ctx.tg[0] is not None and ctx.tg[1] is not None, dy, x):
+            ops.conv_down_bwd_weight(dy, x, dw, db)
         return ops.conv_down_bwd_data(dy, w, tuple(x.shape)), _ret(ctx.tg[0], dw), _ret(ctx.tg[1], db)
 
 
@@ -322,7 +374,8 @@ class ConvUpFn(torch.autograd.Function):
         dy = _c(dy)
         dw = _grad_buf(ctx.tg[0], w)
         db = ctx.tg[1] if ctx.tg[1] is not None else torch.zeros(w.shape[1], dtype=w.dtype, device=w.device)
-        ops.conv_up_bwd_weight(dy, x, dw, db, ctx.k)
+        with _wgrad(ctx.tg[0] is not None and ctx.tg[1] is not None, dy, x):
+            ops.conv_up_bwd_weight(dy, x, dw, db, ctx.k)
         return ops.conv_up_bwd_data(dy, w, tuple(x.shape), ctx.k), _ret(ctx.tg[0], dw), _ret(ctx.tg[1], db), None
 
 
@@ -345,7 +398,8 @@ class OutConvFn(torch.autograd.Function):
         dw = _grad_buf(ctx.tg[0], w)
         db = ctx.tg[1] if ctx.tg[1] is not None else torch.zeros(w.shape[0], dtype=w.dtype, device=w.device)
         f2 = feat.reshape(-1, C)
-        ops.conv3_bwd_weight(dy, f2, dw, db, (B, D, H, W), ncdhw=True)
+        with _wgrad(ctx.tg[0] is not None and ctx.tg[1] is not None, dy, f2):
+            ops.conv3_bwd_weight(dy, f2, dw, db, (B, D, H, W), ncdhw=True)
         dx, _ = ops.conv3_bwd_data(dy, w, (B, D, H, W), C, 0, ncdhw=True)
         return dx.reshape(feat.shape), _ret(ctx.tg[0], dw), _ret(ctx.tg[1], db)
 

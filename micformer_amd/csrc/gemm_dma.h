@@ -28,7 +28,8 @@
 namespace micf {
 
 constexpr int kDmaBR = 16;      // slab depth
-constexpr int kDmaNS = 4;       // ring depth
+constexpr int kDmaNS = 4;       // ring depth of the throughput variant (32 KiB of LDS: 4-5 workgroups per CU)
+   // ring depth of the latency variant (64 KiB): small grids, one workgroup per CU
 
 struct DmaOperand {             // plain row-major operand
   const float* p;
@@ -45,33 +46,34 @@ __device__ __forceinline__ void dma16(const float* gsrc, unsigned lds_byte) {
                : "memory");
 }
 
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+// wait until at most `younger` slabs (2 loads each) of this wave are still in flight
+__device__ __forceinline__ void wait_younger(int younger) {
+  switch (younger) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+  }
 }
 
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
 }
 
-// PX / QX: operand is kind X (x contiguous) instead of kind R.  R must be a multiple of 16; rows/cols beyond the extents are
-// clamped on load (their products are discarded by the epilogue bounds).
-template <bool PX, bool QX, class Epi>
-__global__ void __launch_bounds__(256) gemm_dma_kernel(DmaOperand P, DmaOperand Q, Epi epi, int I, int J, int R, int r_chunk,
-                                                       int tiles_i, float* colsum) {
-  __shared__ __attribute__((aligned(1024))) float Ps[kDmaNS][64 * kDmaBR];
-  __shared__ __attribute__((aligned(1024))) float Qs[kDmaNS][64 * kDmaBR];
+// The 64 x 64 tile loop shared by the kernels of this core: acc[t] += P[i0.., r_begin..r_begin+16*nslab) * Q[.., j0..].
+// Ps / Qs are NS-deep rings of 4 KiB slab images.  csum (lanes of wave 0 when do_cs) gets the column sums of the Q slabs.
+// All waves of the workgroup must call it together (it contains barriers); on return every DMA of this wave has landed
+// and a trailing barrier makes the rings reusable.
+template <bool PX, bool QX, int NS>
+__device__ __forceinline__ void dma_tile_loop(const DmaOperand& P, const DmaOperand& Q, int i0, int j0, int r_begin, int nslab,
+                                              float* Ps, float* Qs, f32x4 (&acc)[4], bool do_cs, float& csum) {
+  static_assert(NS >= 3 && NS <= 8, "ring depth");
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lr = lane >> 4;
-  const int bi = blockIdx.x % tiles_i, bj = blockIdx.x / tiles_i;
-  const int i0 = bi * 64, j0 = bj * 64;
-  const int r_begin = blockIdx.y * r_chunk;
-  const int r_end = (r_begin + r_chunk < R) ? r_begin + r_chunk : R;
-  const int nslab = (r_end - r_begin) / kDmaBR;
-
+  constexpr int SLAB = 64 * kDmaBR;                    // floats per slab image
   // per-lane source pointers of this wave's 1 KiB piece of each slab (advance by one slab per issue)
   const int p = wave * 64 + lane;                      // 16-byte position inside the 4 KiB slab image
   const float* psrc;
@@ -90,36 +92,29 @@ __global__ void __launch_bounds__(256) gemm_dma_kernel(DmaOperand P, DmaOperand 
     else    { int x = j0 + (p >> 2); if (x > Q.X - 1) x = Q.X - 1; const int c = p & 3;
               qsrc = Q.p + (int64_t)x * Q.ld + r_begin + 4 * c; qstep = kDmaBR; }
   }
-  const unsigned pl = lds_addr(&Ps[0][0]) + wave * 1024, ql = lds_addr(&Qs[0][0]) + wave * 1024;
-
-  f32x4 acc[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const bool do_cs = QX && (colsum != nullptr) && (bi == 0) && (tid < 64);   // column sums of the Q slabs (bias gradient)
-  float csum = 0.f;
+  const unsigned pl = lds_addr(Ps) + wave * 1024, ql = lds_addr(Qs) + wave * 1024;
 
   // prologue: slabs 0 .. NS-2 in flight
 #pragma unroll
-  for (int s = 0; s < kDmaNS - 1; ++s) {
+  for (int s = 0; s < NS - 1; ++s) {
     if (s < nslab) {
-      dma16(psrc, pl + s * (64 * kDmaBR * 4));
-      dma16(qsrc, ql + s * (64 * kDmaBR * 4));
+      dma16(psrc, pl + s * (SLAB * 4));
+      dma16(qsrc, ql + s * (SLAB * 4));
       psrc += pstep; qsrc += qstep;
     }
   }
   for (int it = 0; it < nslab; ++it) {
     // slab `it` has landed when at most the (up to NS-2) younger slabs of THIS wave are still outstanding
-    const int younger = (nslab - 1 - it < kDmaNS - 2) ? nslab - 1 - it : kDmaNS - 2;
-    if (younger >= 2) wait_vmcnt<4>(); else if (younger == 1) wait_vmcnt<2>(); else wait_vmcnt<0>();
+    wait_younger((nslab - 1 - it < NS - 2) ? nslab - 1 - it : NS - 2);
     __builtin_amdgcn_s_barrier();                         // every wave's piece of slab `it` is in LDS; slab it-1 is free
-    if (it + kDmaNS - 1 < nslab) {                        // refill the buffer consumed in the previous iteration
-      const int buf = (it + kDmaNS - 1) % kDmaNS;
-      dma16(psrc, pl + buf * (64 * kDmaBR * 4));
-      dma16(qsrc, ql + buf * (64 * kDmaBR * 4));
+    if (it + NS - 1 < nslab) {                            // refill the buffer consumed in the previous iteration
+      const int buf = (it + NS - 1) % NS;
+      dma16(psrc, pl + buf * (SLAB * 4));
+      dma16(qsrc, ql + buf * (SLAB * 4));
       psrc += pstep; qsrc += qstep;
     }
-    const float* Pb = Ps[it % kDmaNS];
-    const float* Qb = Qs[it % kDmaNS];
+    const float* Pb = Ps + (it % NS) * SLAB;
+    const float* Qb = Qs + (it % NS) * SLAB;
     if (do_cs) {
 #pragma unroll
       for (int r = 0; r < kDmaBR; ++r) csum += Qb[r * 64 + tid];
@@ -156,6 +151,30 @@ __global__ void __launch_bounds__(256) gemm_dma_kernel(DmaOperand P, DmaOperand 
       }
     }
   }
+}
+
+// PX / QX: operand is kind X (x contiguous) instead of kind R.  R must be a multiple of 16; rows/cols beyond the extents are
+// clamped on load (their products are discarded by the epilogue bounds).
+template <bool PX, bool QX, class Epi, int NS>
+__global__ void __launch_bounds__(256) gemm_dma_kernel(DmaOperand P, DmaOperand Q, Epi epi, int I, int J, int R, int r_chunk,
+                                                       int tiles_i, float* colsum) {
+  __shared__ __attribute__((aligned(1024))) float Ps[NS * 64 * kDmaBR];
+  __shared__ __attribute__((aligned(1024))) float Qs[NS * 64 * kDmaBR];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lr = lane >> 4;
+  const int bi = blockIdx.x % tiles_i, bj = blockIdx.x / tiles_i;
+  const int i0 = bi * 64, j0 = bj * 64;
+  const int r_begin = blockIdx.y * r_chunk;
+  const int r_end = (r_begin + r_chunk < R) ? r_begin + r_chunk : R;
+  const int nslab = (r_end - r_begin) / kDmaBR;
+
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool do_cs = QX && (colsum != nullptr) && (bi == 0) && (tid < 64);   // column sums of the Q slabs (bias gradient)
+  float csum = 0.f;
+  dma_tile_loop<PX, QX, NS>(P, Q, i0, j0, r_begin, nslab, Ps, Qs, acc, do_cs, csum);
+
   if (do_cs && j0 + tid < J) atomicAdd(colsum + j0 + tid, csum * epi.block_scale());
   // epilogue
   const int j = QX ? j0 + 4 * li + wave : j0 + 16 * wave + li;
@@ -176,6 +195,124 @@ __global__ void __launch_bounds__(256) gemm_dma_kernel(DmaOperand P, DmaOperand 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Skinny variant (Q kind R only): workgroup tile 64 (i) x 16 (j); the FOUR WAVES SPLIT THE REDUCTION instead of the j axis.
+// Every wave owns a private LDS ring (P slab 4 KiB + Q slab 1 KiB per stage), so the main loop needs no barrier at all --
+// only the counted vmcnt wait of the wave's own DMAs.  The four partial 64 x 16 accumulators meet in LDS at the end and each
+// wave finishes (and stores) one quarter of the tile.  4x the workgroups of the 64 x 64 kernel for the same problem.
+constexpr int kSkinnyNS = 5;                                  // ring depth per wave
+constexpr int kSkinnyStage = 5 * 256;                         // floats per stage: P image 1024 + Q image 256
+constexpr int kSkinnyLds = 4 * kSkinnyNS * kSkinnyStage * 4;  // bytes of dynamic LDS (100 KiB: one workgroup per CU)
+constexpr int kSkinnyMaxBlocks = 128;                         // use it when the 64 x 64 tiling yields at most this many tiles
+
+__device__ __forceinline__ void wait_younger5(int younger) {  // 5 loads per stage per wave
+  switch (younger) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+  }
+}
+
+template <bool PX, class Epi>
+__global__ void __launch_bounds__(256) gemm_dma_skinny_kernel(DmaOperand P, DmaOperand Q, Epi epi, int I, int J, int R, int tiles_i) {
+  extern __shared__ __attribute__((aligned(1024))) float skinny_lds[];
+  constexpr int NS = kSkinnyNS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lr = lane >> 4;
+  const int bi = blockIdx.x % tiles_i, bj = blockIdx.x / tiles_i;
+  const int i0 = bi * 64, j0 = bj * 16;
+  // this wave's share of the R / 16 slabs
+  const int total = R / kDmaBR, per = total / 4, extra = total % 4;
+  const int s_begin = wave * per + (wave < extra ? wave : extra);
+  const int nslab = per + (wave < extra ? 1 : 0);
+  const int r_begin = s_begin * kDmaBR;
+  float* ring = skinny_lds + wave * (NS * kSkinnyStage);
+
+  // P: four 1 KiB pieces per stage (position p = 64*piece + lane of the 4 KiB image); Q: one piece
+  const float* psrc[4];
+  int64_t pstep;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int p = q * 64 + lane;
+    if (PX) { const int r = p >> 4, x4 = (p & 15) * 4; int xx = i0 + x4; if (xx > P.X - 4) xx = P.X - 4 < 0 ? 0 : P.X - 4;
+              psrc[q] = P.p + (int64_t)(r_begin + r) * P.ld + xx; }
+    else    { int x = i0 + (p >> 2); if (x > P.X - 1) x = P.X - 1;
+              psrc[q] = P.p + (int64_t)x * P.ld + r_begin + 4 * (p & 3); }
+  }
+  pstep = PX ? (int64_t)kDmaBR * P.ld : kDmaBR;
+  const float* qsrc;
+  { int x = j0 + (lane >> 2); if (x > Q.X - 1) x = Q.X - 1; qsrc = Q.p + (int64_t)x * Q.ld + r_begin + 4 * (lane & 3); }
+  const unsigned base = lds_addr(ring);
+
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto issue = [&](int buf) {
+    const unsigned b = base + buf * (kSkinnyStage * 4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { dma16(psrc[q], b + q * 1024); psrc[q] += pstep; }
+    dma16(qsrc, b + 4096);
+    qsrc += kDmaBR;
+  };
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nslab) issue(s);
+  for (int it = 0; it < nslab; ++it) {
+    wait_younger5((nslab - 1 - it < NS - 2) ? nslab - 1 - it : NS - 2);
+    if (it + NS - 1 < nslab) issue((it + NS - 1) % NS);   // the buffer this wave finished reading in the previous iteration
+    const float* Pb = ring + (it % NS) * kSkinnyStage;
+    const float* Qb = Pb + 1024;
+    float4 pv[4];
+    if (PX) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) pv[s] = *reinterpret_cast<const float4*>(Pb + (4 * lr + s) * 64 + 4 * li);
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) pv[t] = *reinterpret_cast<const float4*>(Pb + (16 * t + li) * kDmaBR + 4 * lr);
+    }
+    const float4 qv = *reinterpret_cast<const float4*>(Qb + li * kDmaBR + 4 * lr);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float b = s == 0 ? qv.x : (s == 1 ? qv.y : (s == 2 ? qv.z : qv.w));
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        float a;
+        if (PX) { const float4 v = pv[s]; a = t == 0 ? v.x : (t == 1 ? v.y : (t == 2 ? v.z : v.w)); }
+        else    { const float4 v = pv[t]; a = s == 0 ? v.x : (s == 1 ? v.y : (s == 2 ? v.z : v.w)); }
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+      }
+    }
+  }
+  // meet: red[src wave][t][v][lane]  (16 KiB at the start of the ring area; every wave has drained its DMAs above)
+  __syncthreads();
+  float* red = skinny_lds;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) red[((wave * 4 + t) * 4 + v) * 64 + lane] = acc[t][v];
+  __syncthreads();
+  const int j = j0 + li;
+  f32x4 out = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (PX) {             // this wave finishes v = wave: i = i0 + 16*lr + 4*wave + t, float4 over t
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int src = 0; src < 4; ++src) out[t] += red[((src * 4 + t) * 4 + wave) * 64 + lane];
+    const int i = i0 + 16 * lr + 4 * wave;
+    if (j < J && i < I) epi(i, j, out, (I - i < 4) ? I - i : 4);
+  } else {              // this wave finishes tile t = wave: i = i0 + 16*wave + 4*lr + v, float4 over v
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+      for (int src = 0; src < 4; ++src) out[v] += red[((src * 4 + wave) * 4 + v) * 64 + lane];
+    const int i = i0 + 16 * wave + 4 * lr;
+    if (j < J && i < I) epi(i, j, out, (I - i < 4) ? I - i : 4);
+  }
+}
+
 // shape gate: 16-byte aligned bases, leading dims multiples of 4, reduction a multiple of the slab depth
 inline bool dma_ok(const DmaOperand& P, bool px, const DmaOperand& Q, bool qx, int64_t R, int r_chunk) {
   auto ok = [](const DmaOperand& o, bool x) {
@@ -193,8 +330,24 @@ inline hipError_t launch_gemm_dma(DmaOperand P, DmaOperand Q, Epi epi, int I, in
   splits = ceil_div(R, r_chunk);
   const int tiles_i = ceil_div(I, 64);
   const int64_t blocks = (int64_t)tiles_i * ceil_div(J, 64);
-  hipLaunchKernelGGL((gemm_dma_kernel<PX, QX, Epi>), dim3((unsigned)blocks, splits), dim3(256), 0, stream, P, Q, epi, I, (int)J, R,
-                     r_chunk, tiles_i, colsum);
+  if constexpr (!QX) {
+    // Few 64 x 64 tiles: each CU then crunches its tile at the per-CU fp32 MFMA rate (0.21 us per 16-deep slab) while most
+    // of the chip idles.  The skinny variant cuts the tile to 64 x 16 and splits the reduction over the 4 waves.
+    if (splits == 1 && blocks <= kSkinnyMaxBlocks && R >= 64) {
+      const int64_t sblocks = (int64_t)tiles_i * ceil_div(J, 16);
+      static bool attr_done = false;
+      if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dma_skinny_kernel<PX, Epi>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kSkinnyLds) != hipSuccess) return hipGetLastError();
+        attr_done = true;
+      }
+      hipLaunchKernelGGL((gemm_dma_skinny_kernel<PX, Epi>), dim3((unsigned)sblocks), dim3(256), kSkinnyLds, stream, P, Q, epi, I,
+                         (int)J, R, tiles_i);
+      return hipGetLastError();
+    }
+  }
+  hipLaunchKernelGGL((gemm_dma_kernel<PX, QX, Epi, kDmaNS>), dim3((unsigned)blocks, splits), dim3(256), 0, stream, P, Q, epi, I,
+                     (int)J, R, r_chunk, tiles_i, colsum);
   return hipGetLastError();
 }
 

@@ -74,6 +74,29 @@ int micf_linear_bwd_weight(const float* dy, const float* dp_scale, int64_t rows_
 /* Upper bound of the scratch (in floats) micf_linear_bwd_weight can use for (M, N, K). */
 int64_t micf_linear_bwd_weight_workspace(int64_t M, int N, int K);
 
+/* Weight gradients of MANY linear layers in one call (what autograd computes layer by layer for F.linear, MS.py:28-34,
+ * 188-201, 246-259).  Nothing on the backward chain consumes a weight gradient, so the host may queue
+ * (input, output-gradient) pairs during backward and flush them here once: a handful of chip-filling launches instead of
+ * two small ones per layer.  Per item: dw[N,K] += (s*dy)^T @ a, dbias[N] += colsum(s*dy) (both accumulated).
+ * Requirements (else MICF_EUNSUPPORTED): M % 16 == 0, N % 4 == 0, K % 4 == 0, 16-byte aligned a / dy / dw, and with
+ * dp_scale: rows_per_sample % 16 == 0 and M % rows_per_sample == 0.  `items` is HOST memory (read during the call only);
+ * the buffers it points to are device memory and must stay valid until the stream has run the launches. */
+typedef struct micf_wgrad_item {
+  const float* a;          /* [M, K] layer input */
+  const float* dy;         /* [M, N] gradient of the layer output */
+  const float* dp_scale;   /* [M / rows_per_sample] DropPath scale per sample, or NULL */
+  float* dw;               /* [N, K] */
+  float* dbias;            /* [N] or NULL */
+  int64_t M;
+  int64_t rows_per_sample;
+  int32_t N;
+  int32_t K;
+} micf_wgrad_item;
+int micf_linear_bwd_weight_grouped(const micf_wgrad_item* items, int n, float* workspace, int64_t workspace_floats,
+                                   micf_stream_t stream);
+/* Scratch floats the grouped call needs for these items (layers longer than one token split), or -1 if an item is unsupported. */
+int64_t micf_linear_bwd_weight_grouped_workspace(const micf_wgrad_item* items, int n);
+
 /* ---- (Cross)WindowAttention3D core on channels-last token grids, windows by index math (never materialised):
  * softmax((q*scale) k^T) v per head and per non-overlapping (wd,wh,ww) window (MS.py:193-200, 251-258;
  * window_partition/reverse MS.py:37-50,117-132).  q [T,ldq], k/v [T,ldkv] (k = kv, v = kv + C), o [T,ldo].

@@ -23,6 +23,8 @@ SIGNATURES = {
     "micf_linear_bwd_data": "pplppppiiliip",
     "micf_linear_bwd_weight": "pplppiippliiplp",
     "micf_linear_bwd_weight_workspace": "lii",
+    "micf_linear_bwd_weight_grouped": "piplp",
+    "micf_linear_bwd_weight_grouped_workspace": "pi",
     "micf_window_attn_fwd": "pippipiiiiiiiiiifp",
     "micf_window_attn_bwd": "pippipipippiiiiiiiiiifp",
     "micf_conv3_fwd": "pipipppiiiiiip",
@@ -52,6 +54,13 @@ SIGNATURES = {
 }
 
 
+class WgradItem(ctypes.Structure):
+    """struct micf_wgrad_item (include/micformer_hip.h)."""
+    _fields_ = [("a", ctypes.c_void_p), ("dy", ctypes.c_void_p), ("dp_scale", ctypes.c_void_p), ("dw", ctypes.c_void_p),
+                ("dbias", ctypes.c_void_p), ("M", ctypes.c_int64), ("rows_per_sample", ctypes.c_int64),
+                ("N", ctypes.c_int32), ("K", ctypes.c_int32)]
+
+
 class MicfError(RuntimeError):
     pass
 
@@ -67,6 +76,7 @@ def _load():
         fn.argtypes = [_T[c] for c in sig]
         fn.restype = _I
     lib.micf_linear_bwd_weight_workspace.restype = _L
+    lib.micf_linear_bwd_weight_grouped_workspace.restype = _L
     lib.micf_strerror.argtypes = [_I]
     lib.micf_strerror.restype = ctypes.c_char_p
     lib.micf_abi_version.argtypes = []

@@ -1,0 +1,189 @@
+// linear_grouped.hip -- the weight gradients of MANY nn.Linear layers in one launch.
+// Reference ops replaced: the dW / dbias halves of autograd's backward for F.linear in q/kv/proj (MS.py:188-201, 246-259)
+// and Mlp fc1/fc2 (MS.py:28-34), for all layers of a training step whose token count is small.
+//
+// Why: nobody on the backward chain waits for a weight gradient -- only the optimizer does.  At the 8^3 / 4^3 token stages
+// each dW is a 10-20 us launch of a few dozen workgroups plus a split-reduction launch, ~400 of them per step.  The host
+// queues (input, output-gradient) pairs during backward and hands the list over once; a workgroup of the grouped kernel
+// finds its (layer, tile, token split) from a prefix table carried in the kernel arguments, so a few launches fill the chip.
+// Layers whose tokens fit one split accumulate into dW directly (each element has one owner: plain read-modify-write, no
+// atomics); longer ones store per-split partials in the workspace and a grouped reduction adds them.
+#include "common.h"
+#include "gemm_dma.h"
+
+namespace micf {
+
+constexpr int kGroupMax = 32;          // layers per launch (kernel-argument budget: 32 * 88 B + table < 4 KiB)
+constexpr int kGroupChunk = 1024;      // tokens per split
+
+struct GItem {
+  const float* a; const float* dy; const float* scale; float* out; float* dbias; float* dw;
+  int M, N, K, rps;
+  int tiles_i, tiles, splits, direct;
+  int64_t split_stride;
+};
+struct GArgs {
+  int n;
+  int end[kGroupMax];                  // running total of workgroups up to and including item k
+  GItem it[kGroupMax];
+};
+
+__global__ void __launch_bounds__(256) wgrad_grouped_kernel(const GArgs g) {
+  __shared__ __attribute__((aligned(1024))) float Ps[kDmaNS * 64 * kDmaBR];
+  __shared__ __attribute__((aligned(1024))) float Qs[kDmaNS * 64 * kDmaBR];
+  const int w = blockIdx.x;
+  int k = 0;
+  while (k < g.n - 1 && w >= g.end[k]) ++k;
+  const GItem& it = g.it[k];
+  const int local = w - (k ? g.end[k - 1] : 0);
+  const int split = local / it.tiles, t = local % it.tiles;
+  const int bi = t % it.tiles_i, bj = t / it.tiles_i;
+  const int i0 = bi * 64, j0 = bj * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lr = lane >> 4;
+  const int r_begin = split * kGroupChunk;
+  const int r_end = (r_begin + kGroupChunk < it.M) ? r_begin + kGroupChunk : it.M;
+  const DmaOperand P{it.a, it.K, it.K}, Q{it.dy, it.N, it.N};
+  const bool do_cs = (it.dbias != nullptr) && (bi == 0) && (tid < 64);
+
+  f32x4 tot[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) tot[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float ctot = 0.f;
+  // one pass per sample segment: the DropPath scale is constant inside a sample, so it multiplies the segment's product
+  for (int r = r_begin; r < r_end;) {
+    int seg_end = r_end;
+    float s = 1.f;
+    if (it.scale) {
+      const int b = r / it.rps;
+      s = it.scale[b];
+      const int lim = (b + 1) * it.rps;
+      if (lim < seg_end) seg_end = lim;
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float csum = 0.f;
+    if (r != r_begin) __syncthreads();                       // the rings are reused by the next segment
+    dma_tile_loop<true, true, kDmaNS>(P, Q, i0, j0, r, (seg_end - r) / kDmaBR, Ps, Qs, acc, do_cs, csum);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { tot[q][0] += s * acc[q][0]; tot[q][1] += s * acc[q][1]; tot[q][2] += s * acc[q][2]; tot[q][3] += s * acc[q][3]; }
+    ctot += s * csum;
+    r = seg_end;
+  }
+  if (do_cs && j0 + tid < it.N) atomicAdd(it.dbias + j0 + tid, ctot);
+  const int j = j0 + 4 * li + wave;
+  if (j >= it.N) return;
+  float* base = it.direct ? it.dw : it.out + (int64_t)split * it.split_stride;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int i = i0 + 16 * lr + 4 * v;
+    if (i >= it.K) continue;
+    float* p = base + (int64_t)j * it.K + i;
+    float4 o = make_float4(tot[0][v], tot[1][v], tot[2][v], tot[3][v]);
+    if (i + 4 <= it.K) {
+      if (it.direct) { const float4 old = *reinterpret_cast<const float4*>(p); o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+      *reinterpret_cast<float4*>(p) = o;
+    } else {
+      const float e[4] = {o.x, o.y, o.z, o.w};
+      for (int q = 0; q < it.K - i; ++q) p[q] = it.direct ? p[q] + e[q] : e[q];
+    }
+  }
+}
+
+// dw += sum over splits of the workspace partials, for every non-direct item of the group
+__global__ void __launch_bounds__(256) wgrad_grouped_reduce_kernel(const GArgs g) {
+  const int w = blockIdx.x;
+  int k = 0;
+  while (k < g.n - 1 && w >= g.end[k]) ++k;
+  const GItem& it = g.it[k];
+  const int local = w - (k ? g.end[k - 1] : 0);
+  const int64_t n4 = (int64_t)it.N * it.K / 4;
+  const int64_t e = (int64_t)local * 256 + threadIdx.x;
+  if (e >= n4) return;
+  float4 acc = *reinterpret_cast<const float4*>(it.dw + 4 * e);
+  int s = 0;
+  for (; s + 4 <= it.splits; s += 4) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(it.out + (s + u) * it.split_stride + 4 * e);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+  }
+  for (; s < it.splits; ++s) {
+    const float4 v = *reinterpret_cast<const float4*>(it.out + s * it.split_stride + 4 * e);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  *reinterpret_cast<float4*>(it.dw + 4 * e) = acc;
+}
+
+static bool item_ok(const micf_wgrad_item& x) {
+  if (!x.a || !x.dy || !x.dw || x.M <= 0 || x.N < 4 || x.K < 4) return false;
+  if (x.M % kDmaBR || x.M >= (1LL << 30) || x.N % 4 || x.K % 4) return false;
+  if ((reinterpret_cast<uintptr_t>(x.a) | reinterpret_cast<uintptr_t>(x.dy) | reinterpret_cast<uintptr_t>(x.dw)) & 15) return false;
+  if (x.dp_scale && (x.rows_per_sample <= 0 || x.rows_per_sample % kDmaBR || x.M % x.rows_per_sample)) return false;
+  return true;
+}
+
+static int item_splits(const micf_wgrad_item& x) { return (int)((x.M + kGroupChunk - 1) / kGroupChunk); }
+
+}  // namespace micf
+
+using namespace micf;
+
+extern "C" int64_t micf_linear_bwd_weight_grouped_workspace(const micf_wgrad_item* items, int n) {
+  if (!items || n <= 0) return 0;
+  int64_t total = 0;
+  for (int k = 0; k < n; ++k) {
+    if (!item_ok(items[k])) return -1;
+    const int sp = item_splits(items[k]);
+    if (sp > 1) total += (int64_t)sp * items[k].N * items[k].K;
+  }
+  return total;
+}
+
+extern "C" int micf_linear_bwd_weight_grouped(const micf_wgrad_item* items, int n, float* workspace, int64_t workspace_floats,
+                                              micf_stream_t stream) {
+  if (n < 0 || (n > 0 && !items)) return MICF_EINVAL;
+  if (n == 0) return MICF_OK;
+  const int64_t need = micf_linear_bwd_weight_grouped_workspace(items, n);
+  if (need < 0) return MICF_EUNSUPPORTED;
+  if (need > 0 && (!workspace || workspace_floats < need || (reinterpret_cast<uintptr_t>(workspace) & 15))) return MICF_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  int64_t ws_off = 0;
+  for (int first = 0; first < n; first += kGroupMax) {
+    const int cnt = (n - first < kGroupMax) ? n - first : kGroupMax;
+    GArgs g, rg;
+    g.n = cnt;
+    rg.n = 0;
+    int blocks = 0, rblocks = 0;
+    for (int k = 0; k < cnt; ++k) {
+      const micf_wgrad_item& x = items[first + k];
+      GItem& d = g.it[k];
+      d.a = x.a; d.dy = x.dy; d.scale = x.dp_scale; d.dbias = x.dbias; d.dw = x.dw;
+      d.M = (int)x.M; d.N = x.N; d.K = x.K; d.rps = x.dp_scale ? (int)x.rows_per_sample : (int)x.M;
+      d.tiles_i = ceil_div(x.K, 64);
+      d.tiles = d.tiles_i * ceil_div(x.N, 64);
+      d.splits = item_splits(x);
+      d.direct = d.splits == 1;
+      d.split_stride = (int64_t)x.N * x.K;
+      d.out = d.direct ? nullptr : workspace + ws_off;
+      if (!d.direct) ws_off += d.splits * d.split_stride;
+      blocks += d.tiles * d.splits;
+      g.end[k] = blocks;
+      if (!d.direct) {
+        rg.it[rg.n] = d;
+        rblocks += (int)((d.split_stride / 4 + 255) / 256);
+        rg.end[rg.n] = rblocks;
+        ++rg.n;
+      }
+    }
+    hipLaunchKernelGGL(wgrad_grouped_kernel, dim3(blocks), dim3(256), 0, s, g);
+    if (hipGetLastError() != hipSuccess) return MICF_ELAUNCH;
+    if (rg.n > 0) {
+      hipLaunchKernelGGL(wgrad_grouped_reduce_kernel, dim3(rblocks), dim3(256), 0, s, rg);
+      if (hipGetLastError() != hipSuccess) return MICF_ELAUNCH;
+    }
+  }
+  return MICF_OK;
+}

@@ -23,7 +23,7 @@ from .loss.dice import MDiceLoss
 class TrainEngine:
     def __init__(self, model, base_lr=1e-4, t_max=150, eta_min=0.0, betas=(0.9, 0.999), eps=1e-8, criterion=None,
                  use_graph=False, process_group=None, grad_bucket_bytes=64 << 20, parallel_modalities=True,
-                 wgrad_streams=False):
+                 defer_wgrad=True):
         self.model = model
         self.criterion = criterion if criterion is not None else MDiceLoss()
         self.base_lr, self.t_max, self.eta_min = base_lr, t_max, eta_min
@@ -36,7 +36,7 @@ class TrainEngine:
         from . import functional as _fn
         from .models import MICFormer_self as _ms
         _ms.PARALLEL_MODALITIES = bool(parallel_modalities)
-        _fn.WGRAD_STREAMS = bool(wgrad_streams)    # measured slower (50.7 vs 42.1 ms/step): off by default
+        _fn.DEFER_WGRAD = bool(defer_wgrad)      # linear weight gradients: queued in backward, one grouped flush
         self.use_graph = use_graph
         self._graph = None
         self._static = None
@@ -71,9 +71,7 @@ class TrainEngine:
         loss = self.criterion(logits, target)                       #                              train.py:187
         loss.backward()                                             #                              train.py:200
         from . import functional as _fn
-        cur = torch.cuda.current_stream()
-        for s in _fn.wgrad_streams():                               # weight-gradient side streams join before the optimiser
-            cur.wait_stream(s)
+        _fn.flush_wgrad()                                           # queued linear weight gradients, grouped launches
         return loss.detach()
 
     def _update(self):

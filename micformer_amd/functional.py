@@ -22,45 +22,43 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
-# ----------------------------------------------------------------------------- weight-gradient side streams (engine mode)
-# Nothing downstream of a backward pass consumes the parameter gradients until the optimiser step, so in engine mode (the
-# kernels accumulate straight into the flat gradient buffer) every weight-gradient launch is issued on a side stream and
-# overlaps the data-gradient chain, which is the critical path.  TrainEngine joins the side streams before Adam.
-WGRAD_STREAMS = False
-_WG = {}
+# ----------------------------------------------------------------------------- deferred weight gradients (engine mode)
+# Nothing downstream of a backward pass consumes the parameter gradients until the optimiser step.  In engine mode (the
+# kernels accumulate straight into the flat gradient buffer) the weight gradients of the linear layers are therefore not
+# launched where autograd reaches them: the (output-gradient, input) pair is queued and TrainEngine flushes the queue once
+# after backward through micf_linear_bwd_weight_grouped -- a few chip-filling launches instead of two small ones per
+# layer, and the data-gradient chain (the critical path) gets shorter.  The queue holds references, so the caching
+# allocator cannot hand the queued buffers to anyone else before the flush.
+DEFER_WGRAD = False
+DEFER_MAX_TOKENS = 1 << 14          # larger layers launch immediately (their operands are still hot in L2 / MALL)
+_DEFERRED = []
 
 
-def wgrad_streams():
-    return list(_WG.values())
+def _lin_wgrad(defer, dy, a, dw, db, dp_scale=None, rows_per_sample=0):
+    if defer and DEFER_WGRAD and dy.shape[0] <= DEFER_MAX_TOKENS and ops.wgrad_groupable(dy, a, dp_scale, rows_per_sample):
+        _DEFERRED.append((dy, a, dw, db, dp_scale, rows_per_sample))
+    else:
+        ops.linear_bwd_weight(dy, a, dw, db, dp_scale=dp_scale, rows_per_sample=rows_per_sample)
+
+
+def flush_wgrad():
+    """Launch every queued weight gradient on the current stream (which must be ordered after their producers)."""
+    if _DEFERRED:
+        items = list(_DEFERRED)
+        _DEFERRED.clear()
+        ops.linear_bwd_weight_grouped(items)
 
 
 class _wgrad:
-    """`with _wgrad(on, t1, t2, ...)`: run the enclosed launches on the weight-gradient stream paired with the current one;
-    t_i are the tensors those launches read (kept alive across streams)."""
+    """Placeholder context (kept so the conv weight-gradient call sites read the same)."""
 
     def __init__(self, on, *tensors):
-        self.on = on and WGRAD_STREAMS
-        self.tensors = tensors
+        pass
 
     def __enter__(self):
-        if not self.on:
-            return self
-        cur = torch.cuda.current_stream()
-        side = _WG.get(cur.cuda_stream)
-        if side is None:
-            side = torch.cuda.Stream(device=cur.device)
-            _WG[cur.cuda_stream] = side
-        side.wait_stream(cur)
-        for t in self.tensors:
-            if t is not None:
-                t.record_stream(side)
-        self.ctx = torch.cuda.stream(side)
-        self.ctx.__enter__()
         return self
 
     def __exit__(self, *exc):
-        if self.on:
-            self.ctx.__exit__(*exc)
         return False
 
 
@@ -152,11 +150,9 @@ def _mlp_bwd(dy, x1f, saved, dims, P, G, s2, side=False):
     B, D, H, W = dims
     rps = D * H * W
     xn2, m2, r2, h, g = saved      # g = GELU(h) is kept (HBM is plentiful) so the fc2 weight gradient is a plain GEMM
-    with _wgrad(side, dy, g):
-        ops.linear_bwd_weight(dy, g, G["mlp.fc2.weight"], G["mlp.fc2.bias"], dp_scale=s2, rows_per_sample=rps)
+    _lin_wgrad(side, dy, g, G["mlp.fc2.weight"], G["mlp.fc2.bias"], s2, rps)
     dh = ops.linear_bwd_data(dy, P["mlp.fc2.weight"], dp_scale=s2, rows_per_sample=rps, pre_act=h)
-    with _wgrad(side, dh, xn2):
-        ops.linear_bwd_weight(dh, xn2, G["mlp.fc1.weight"], G["mlp.fc1.bias"])
+    _lin_wgrad(side, dh, xn2, G["mlp.fc1.weight"], G["mlp.fc1.bias"])
     dxn2 = ops.linear_bwd_data(dh, P["mlp.fc1.weight"])
     return ops.layernorm_bwd(dxn2, x1f, m2, r2, P["norm2.weight"], G["norm2.weight"], G["norm2.bias"], add=dy)
 
@@ -216,15 +212,13 @@ class SelfBlockFn(torch.autograd.Function):
         dy = _c(dy).reshape(-1, C)
         side = all(t is not None for t in ctx.tg)      # engine mode: gradients land in the flat buffer, nobody waits for them
         dx1 = _mlp_bwd(dy, x1, mlp_saved, dims, P, G, s2, side)
-        with _wgrad(side, dx1, o):
-            ops.linear_bwd_weight(dx1, o, G["self_attn.proj.weight"], G["self_attn.proj.bias"], dp_scale=s1, rows_per_sample=rps)
+        _lin_wgrad(side, dx1, o, G["self_attn.proj.weight"], G["self_attn.proj.bias"], s1, rps)
         do = ops.linear_bwd_data(dx1, P["self_attn.proj.weight"], dp_scale=s1, rows_per_sample=rps)
         if padded:
             do = ops.pad3d(do, dims, pd)
         dq, dkv = ops.window_attn_bwd(q, kv, do, pdims, heads, ws, scale)
-        with _wgrad(side, dq, dkv, xnp):
-            ops.linear_bwd_weight(dq, xnp, G["self_attn.q.weight"], G["self_attn.q.bias"])
-            ops.linear_bwd_weight(dkv, xnp, G["self_attn.kv.weight"], G["self_attn.kv.bias"])
+        _lin_wgrad(side, dq, xnp, G["self_attn.q.weight"], G["self_attn.q.bias"])
+        _lin_wgrad(side, dkv, xnp, G["self_attn.kv.weight"], G["self_attn.kv.bias"])
         dxn = ops.linear_bwd_data(dq, P["self_attn.q.weight"])
         ops.linear_bwd_data(dkv, P["self_attn.kv.weight"], out=dxn, accumulate=True)
         if padded:
@@ -285,15 +279,13 @@ class CrossBlockFn(torch.autograd.Function):
         dy = _c(dy).reshape(-1, C)
         side = all(t is not None for t in ctx.tg)
         dx1 = _mlp_bwd(dy, x1, mlp_saved, dims, P, G, s2, side)
-        with _wgrad(side, dx1, o):
-            ops.linear_bwd_weight(dx1, o, G["cross_attn.proj.weight"], G["cross_attn.proj.bias"], dp_scale=s1, rows_per_sample=rps)
+        _lin_wgrad(side, dx1, o, G["cross_attn.proj.weight"], G["cross_attn.proj.bias"], s1, rps)
         do = ops.linear_bwd_data(dx1, P["cross_attn.proj.weight"], dp_scale=s1, rows_per_sample=rps)
         if padded:
             do = ops.pad3d(do, dims, pd)
         dq, dkv = ops.window_attn_bwd(q, kv, do, pdims, heads, ws, scale)
-        with _wgrad(side, dq, dkv, xnp, xs):
-            ops.linear_bwd_weight(dq, xnp, G["cross_attn.q.weight"], G["cross_attn.q.bias"])
-            ops.linear_bwd_weight(dkv, xs, G["cross_attn.kv.weight"], G["cross_attn.kv.bias"])
+        _lin_wgrad(side, dq, xnp, G["cross_attn.q.weight"], G["cross_attn.q.bias"])
+        _lin_wgrad(side, dkv, xs, G["cross_attn.kv.weight"], G["cross_attn.kv.bias"])
         dxnp = ops.linear_bwd_data(dq, P["cross_attn.q.weight"])
         dxs = ops.linear_bwd_data(dkv, P["cross_attn.kv.weight"])
         dxap = _zl(xap)                                            # atomic scatter target of the sampler

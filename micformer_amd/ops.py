@@ -3,6 +3,8 @@
 PyTorch is used here only for device memory and streams.  Every function takes contiguous fp32 CUDA tensors;
 argument order follows include/micformer_hip.h.
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -107,6 +109,41 @@ def linear_bwd_weight(dy, a1, dw, dbias, a2=None, dp_scale=None, rows_per_sample
     call("micf_linear_bwd_weight", f32(dy), f32(dp_scale), rows_per_sample, f32(a1), f32(a2), k1, 1 if a_gelu else 0,
          f32(dw), f32(dbias), M, N, K, f32(ws), ws.numel() if ws is not None else 0,
          cost=_cost(2 * M * N * K, dy, a1, a2, dw, tag=f'{M}x{N}x{K}'))
+
+
+def wgrad_groupable(dy, a1, dp_scale=None, rows_per_sample=0):
+    """Shape / alignment gate of micf_linear_bwd_weight_grouped for one layer."""
+    M, N = dy.shape
+    K = a1.shape[1]
+    if M % 16 or N % 4 or K % 4 or (dy.data_ptr() | a1.data_ptr()) & 15:
+        return False
+    if dp_scale is not None and (rows_per_sample <= 0 or rows_per_sample % 16 or M % rows_per_sample):
+        return False
+    return True
+
+
+def linear_bwd_weight_grouped(items):
+    """items: list of (dy [M,N], a [M,K], dw [N,K], dbias [N] | None, dp_scale | None, rows_per_sample).  One call."""
+    n = len(items)
+    if n == 0:
+        return
+    arr = (_lib.WgradItem * n)()
+    flops, nbytes = 0, 0
+    for it, (dy, a, dw, db, sc, rps) in zip(arr, items):
+        M, N = dy.shape
+        K = a.shape[1]
+        it.a, it.dy, it.dp_scale, it.dw, it.dbias = f32(a), f32(dy), f32(sc), f32(dw), f32(db)
+        it.M, it.rows_per_sample, it.N, it.K = M, int(rps) if sc is not None else 0, N, K
+        flops += 2 * M * N * K
+        nbytes += 4 * (dy.numel() + a.numel() + 2 * dw.numel())
+    dev = items[0][0].device
+    ptr = ctypes.cast(arr, ctypes.c_void_p)
+    need = _lib.lib.micf_linear_bwd_weight_grouped_workspace(ptr, n)
+    if need < 0:
+        raise _lib.MicfError("micf_linear_bwd_weight_grouped: unsupported item")
+    ws = scratch(dev, need) if need > 0 else None
+    call("micf_linear_bwd_weight_grouped", ptr, n, f32(ws), ws.numel() if ws is not None else 0,
+         cost=(nbytes, flops) + ((f"{n}",) if DETAIL else ()))
 
 
 # ----------------------------------------------------------------------------- window attention

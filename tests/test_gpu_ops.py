@@ -119,6 +119,32 @@ def test_linear_large_rows_split_reduction(ops):
     close(db, dy.double().sum(0).float(), rtol=3e-4, what="db split")
 
 
+def test_linear_bwd_weight_grouped(ops):
+    """micf_linear_bwd_weight_grouped: 40 layers of mixed shape in one call (two launch groups), some with a DropPath
+    scale per sample, some longer than one token split (workspace + grouped reduction), accumulating into non-zero dW."""
+    shapes = [(128, 384, 384), (128, 1536, 384), (1024, 192, 768), (1024, 192, 192), (2048, 96, 96), (4096, 52, 100),
+              (64, 48, 48), (3072, 384, 96), (16, 8, 4), (1024, 768, 192)]
+    items, want = [], []
+    for n in range(40):
+        M, N, K = shapes[n % len(shapes)]
+        a, dy = rnd(M, K, seed=100 + n), rnd(M, N, seed=200 + n)
+        dw0, db0 = rnd(N, K, seed=300 + n), rnd(N, seed=400 + n)
+        use_scale, use_bias = n % 3 == 0, n % 4 != 1
+        B = 2 if M % 32 == 0 else 1
+        s = torch.tensor([0.0, 1.25][:B]) if n % 6 == 0 else torch.tensor([1.1, 0.7][:B])
+        rps = M // B
+        dys = dy * s.repeat_interleave(rps)[:, None] if use_scale else dy
+        want.append((dw0.double() + dys.double().t() @ a.double(), db0.double() + dys.double().sum(0)))
+        items.append((dev(dy), dev(a), dev(dw0), dev(db0) if use_bias else None, dev(s) if use_scale else None, rps))
+        assert ops.wgrad_groupable(items[-1][0], items[-1][1], items[-1][4], rps)
+    ops.linear_bwd_weight_grouped(items)
+    for n, ((dy, a, dw, db, sc, rps), (wdw, wdb)) in enumerate(zip(items, want)):
+        close(dw, wdw.float(), rtol=3e-4, what=f"grouped dW[{n}] {tuple(dw.shape)} M={dy.shape[0]}")
+        if db is not None:
+            close(db, wdb.float(), rtol=3e-4, what=f"grouped db[{n}]")
+    assert not ops.wgrad_groupable(dev(rnd(40, 48)), dev(rnd(40, 48)))          # M % 16 != 0 -> per-layer path
+
+
 # ----------------------------------------------------------------------------- window attention
 def _attn_ref(q, kv, dims, heads, ws):
     B, D, H, W = dims

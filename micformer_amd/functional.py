@@ -30,7 +30,7 @@ def _c(t):
 # layer, and the data-gradient chain (the critical path) gets shorter.  The queue holds references, so the caching
 # allocator cannot hand the queued buffers to anyone else before the flush.
 DEFER_WGRAD = False
-DEFER_MAX_TOKENS = 1 << 14          # larger layers launch immediately (their operands are still hot in L2 / MALL)
+DEFER_MAX_TOKENS = 1 << 17          # larger layers launch immediately (their operands are still hot in L2 / MALL)
 _DEFERRED = []
 
 

@@ -97,6 +97,24 @@ int micf_linear_bwd_weight_grouped(const micf_wgrad_item* items, int n, float* w
 /* Scratch floats the grouped call needs for these items (layers longer than one token split), or -1 if an item is unsupported. */
 int64_t micf_linear_bwd_weight_grouped_workspace(const micf_wgrad_item* items, int n);
 
+/* ---- reverse_patch_embedding (ConvTranspose3d(Ci -> Cm, k = s = P), MS.py:1037) followed by Head.out_conv
+ * (Conv3d(Cm -> Co, 3, padding=1), MS.py:1053) as one linear map on the coarse token grid (no norm / activation sits
+ * between them): with F = P + 2,
+ *   T[q, (f, o)] = Bf[f, o] + sum_k Wb[f, o, k] x[q, k]       -- micf_linear_fwd(x, w = Wb [F^3*Co, Ci], bias = Bf)
+ *   y[b, o, u]   = b_out[o] + sum of T[q, (u - P*q + 1, o)] over the in-volume coarse voxels q whose patch covers u
+ * compose: Wb / Bf from (w_up [Ci,Cm,P,P,P], b_up [Cm], w_out [Co,Cm,3,3,3]).  col2im: T [B*Dc*Hc*Wc, F^3*Co] -> NCDHW
+ * logits y [B, Co, P*Dc, P*Hc, P*Wc].  im2col: the transpose gather, U[q, (f, o)] = dy[b, o, P*q - 1 + f] (0 outside).
+ * decompose: the chain rule through the composition, given dWb = U^T x and dBf = colsum(U) (micf_linear_bwd_weight):
+ * dw_up, db_up, dw_out, db_out are ACCUMULATED.  Co <= 32, 2 <= P <= 8. */
+int micf_head_tail_compose(const float* w_up, const float* b_up, const float* w_out, float* wb, float* bf, int Ci, int Cm,
+                           int Co, int P, micf_stream_t stream);
+int micf_head_tail_col2im(const float* t, const float* b_out, float* y, int B, int Dc, int Hc, int Wc, int Co, int P,
+                          micf_stream_t stream);
+int micf_head_tail_im2col(const float* dy, float* u, int B, int Dc, int Hc, int Wc, int Co, int P, micf_stream_t stream);
+int micf_head_tail_decompose(const float* dwb, const float* dbf, const float* w_up, const float* b_up, const float* w_out,
+                             float* dw_up, float* db_up, float* dw_out, float* db_out, int Ci, int Cm, int Co, int P,
+                             micf_stream_t stream);
+
 /* ---- (Cross)WindowAttention3D core on channels-last token grids, windows by index math (never materialised):
  * softmax((q*scale) k^T) v per head and per non-overlapping (wd,wh,ww) window (MS.py:193-200, 251-258;
  * window_partition/reverse MS.py:37-50,117-132).  q [T,ldq], k/v [T,ldkv] (k = kv, v = kv + C), o [T,ldo].

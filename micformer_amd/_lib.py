@@ -25,6 +25,10 @@ SIGNATURES = {
     "micf_linear_bwd_weight_workspace": "lii",
     "micf_linear_bwd_weight_grouped": "piplp",
     "micf_linear_bwd_weight_grouped_workspace": "pi",
+    "micf_head_tail_compose": "pppppiiiip",
+    "micf_head_tail_col2im": "pppiiiiiip",
+    "micf_head_tail_im2col": "ppiiiiiip",
+    "micf_head_tail_decompose": "pppppppppiiiip",
     "micf_window_attn_fwd": "pippipiiiiiiiiiifp",
     "micf_window_attn_bwd": "pippipipippiiiiiiiiiifp",
     "micf_conv3_fwd": "pipipppiiiiiip",

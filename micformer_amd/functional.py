@@ -396,6 +396,39 @@ class OutConvFn(torch.autograd.Function):
         return dx.reshape(feat.shape), _ret(ctx.tg[0], dw), _ret(ctx.tg[1], db)
 
 
+class HeadTailFn(torch.autograd.Function):
+    """reverse_patch_embedding (ConvTranspose3d 2E -> E/2, k = s = P; MS.py:1037) + Head.out_conv (Conv3d E/2 -> classes, 3,
+    padding=1; MS.py:1053) composed into one linear map on the coarse grid (csrc/head_tail.hip): channels-last coarse
+    feature x (B, Dc, Hc, Wc, 2E) -> NCDHW logits (B, classes, P*Dc, P*Hc, P*Wc).  The E/2-channel fine feature is never built."""
+
+    @staticmethod
+    def forward(ctx, x, w_up, b_up, w_out, b_out):
+        x = _c(x)
+        B, Dc, Hc, Wc, Ci = x.shape
+        P = w_up.shape[2]
+        wb, bf = ops.head_tail_compose(w_up, b_up, w_out)
+        xf = x.reshape(-1, Ci)
+        t = ops.linear_fwd(xf, wb, bf)
+        y = ops.head_tail_col2im(t, b_out, (B, Dc, Hc, Wc), P)
+        ctx.save_for_backward(xf, wb, w_up, b_up, w_out)
+        ctx.dims = (B, Dc, Hc, Wc)
+        ctx.tg = _targets((w_up, b_up, w_out, b_out))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xf, wb, w_up, b_up, w_out = ctx.saved_tensors
+        B, Dc, Hc, Wc = ctx.dims
+        P = w_up.shape[2]
+        u = ops.head_tail_im2col(_c(dy), ctx.dims, P)
+        dx = ops.linear_bwd_data(u, wb)
+        dwb, dbf = torch.zeros_like(wb), torch.zeros(wb.shape[0], dtype=wb.dtype, device=wb.device)
+        ops.linear_bwd_weight(u, xf, dwb, dbf)
+        grads = [_grad_buf(t, p) for t, p in zip(ctx.tg, (w_up, b_up, w_out, w_out.new_empty(w_out.shape[0])))]
+        ops.head_tail_decompose(dwb, dbf, w_up, b_up, w_out, *grads)
+        return (dx.reshape(B, Dc, Hc, Wc, -1),) + tuple(_ret(t, g) for t, g in zip(ctx.tg, grads))
+
+
 class ResizeTrilinearFn(torch.autograd.Function):
     """F.interpolate(mode='trilinear', align_corners=True) on channels-last volumes (MS.py:1018-1025)."""
 

@@ -226,6 +226,8 @@ class LayerNormProxy(nn.Module):
 
 # Run the two modalities' independent blocks on two HIP streams (engine / bench switch; off = the reference's serial order).
 PARALLEL_MODALITIES = False
+# Head: run reverse_patch_embedding + out_conv as their composition (off = the reference's two separate convolutions).
+FUSE_HEAD_TAIL = True
 _SIDE_STREAMS = {}
 
 
@@ -511,6 +513,12 @@ class MicFormer(nn.Module):
 
     def features(self, vol_m, mod_m, vol_f, mod_f):
         """Channels-last (B, D', H', W', E/2) feature that feeds Head.out_conv."""
+        x = self.coarse_features(vol_m, mod_m, vol_f, mod_f)
+        rp = self.reverse_patch_embedding
+        return Fn.ConvUpFn.apply(x, rp.weight, rp.bias, self.patch_size[0])
+
+    def coarse_features(self, vol_m, mod_m, vol_f, mod_f):
+        """Channels-last (B, D/P, H/P, W/P, 2E) tokens after norm2, the input of reverse_patch_embedding (MS.py:1033-1036)."""
         self._predraw_drop_path(vol_m.shape[0], vol_m.device)
         m = self.patch_embed.tokens(vol_m, mod_m)
         f = self.patch_embed.tokens(vol_f, mod_f)
@@ -532,9 +540,7 @@ class MicFormer(nn.Module):
                 m = Fn.LinearFn.apply(m, sm, lin.weight, lin.bias)
                 f = Fn.LinearFn.apply(f, sf, lin.weight, lin.bias)
             _, _, m, f = up(m, f)
-        x = Fn.LayerNormFn.apply(m, f, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        rp = self.reverse_patch_embedding
-        return Fn.ConvUpFn.apply(x, rp.weight, rp.bias, self.patch_size[0])
+        return Fn.LayerNormFn.apply(m, f, self.norm2.weight, self.norm2.bias, self.norm2.eps)
 
     def forward(self, moving, fixed):
         """(B,1,D,H,W) x 2 -> (B, E/2, D', H', W'), as the reference (a channels-first VIEW of the kernel output)."""
@@ -558,5 +564,10 @@ class Head(nn.Module):
             raise RuntimeError("micformer_amd.Head runs on the MI355X HIP kernels only (no CPU path): move the model "
                                "and the input to cuda")
         x = x.float().contiguous()
+        rp, oc = self.swin.reverse_patch_embedding, self.out_conv
+        if FUSE_HEAD_TAIL and 2 <= rp.kernel_size[0] <= 8 and oc.out_channels <= 32:
+            # ConvTranspose3d(k = s = P) and the 3^3 Conv3d have nothing between them: one composed linear map (head_tail.hip)
+            coarse = self.swin.coarse_features(x, 0, x, 1)
+            return Fn.HeadTailFn.apply(coarse, rp.weight, rp.bias, oc.weight, oc.bias)
         feat = self.swin.features(x, 0, x, 1)
-        return Fn.OutConvFn.apply(feat, self.out_conv.weight, self.out_conv.bias)
+        return Fn.OutConvFn.apply(feat, oc.weight, oc.bias)

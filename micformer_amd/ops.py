@@ -294,6 +294,41 @@ def conv_up_fwd(x, w, bias, k):
     return y
 
 
+# ----------------------------------------------------------------------------- reverse_patch_embedding + out_conv, composed
+def head_tail_compose(w_up, b_up, w_out):
+    Ci, Cm, P = w_up.shape[0], w_up.shape[1], w_up.shape[2]
+    Co = w_out.shape[0]
+    rows = (P + 2) ** 3 * Co
+    wb, bf = _new(w_up, rows, Ci), _new(w_up, rows)
+    call("micf_head_tail_compose", f32(w_up), f32(b_up), f32(w_out), f32(wb), f32(bf), Ci, Cm, Co, P,
+         cost=_cost(2 * rows * (Ci + 1) * Cm * 4, w_up, w_out, wb))
+    return wb, bf
+
+
+def head_tail_col2im(t, b_out, dims, P):
+    B, Dc, Hc, Wc = dims
+    Co = b_out.shape[0]
+    y = _new(t, B, Co, Dc * P, Hc * P, Wc * P)
+    call("micf_head_tail_col2im", f32(t), f32(b_out), f32(y), B, Dc, Hc, Wc, Co, P, cost=_cost(t.numel(), t, y))
+    return y
+
+
+def head_tail_im2col(dy, dims, P):
+    B, Dc, Hc, Wc = dims
+    Co = dy.shape[1]
+    u = _new(dy, B * Dc * Hc * Wc, (P + 2) ** 3 * Co)
+    call("micf_head_tail_im2col", f32(dy), f32(u), B, Dc, Hc, Wc, Co, P, cost=_cost(0, dy, u))
+    return u
+
+
+def head_tail_decompose(dwb, dbf, w_up, b_up, w_out, dw_up, db_up, dw_out, db_out):
+    Ci, Cm, P = w_up.shape[0], w_up.shape[1], w_up.shape[2]
+    Co = w_out.shape[0]
+    call("micf_head_tail_decompose", f32(dwb), f32(dbf), f32(w_up), f32(b_up), f32(w_out), f32(dw_up), f32(db_up),
+         f32(dw_out), f32(db_out), Ci, Cm, Co, P,
+         cost=_cost(4 * dwb.numel() * Cm * 27 // (P + 2) ** 3 * P ** 3, dwb, w_up, w_out))
+
+
 def conv_up_bwd_data(dy, w, xshape, k):
     B, D, H, W, C = xshape
     N = w.shape[1]

@@ -145,6 +145,31 @@ def test_linear_bwd_weight_grouped(ops):
     assert not ops.wgrad_groupable(dev(rnd(40, 48)), dev(rnd(40, 48)))          # M % 16 != 0 -> per-layer path
 
 
+@pytest.mark.parametrize("dims,Ci,Cm,Co,P", [((2, 3, 2, 4), 96, 24, 8, 4), ((1, 1, 1, 1), 48, 12, 8, 4), ((1, 2, 3, 1), 48, 12, 14, 4),
+                                             ((1, 3, 3, 3), 32, 8, 5, 2), ((1, 4, 4, 4), 96, 24, 8, 4)])
+def test_head_tail_composed(dims, Ci, Cm, Co, P):
+    """HeadTailFn (ConvTranspose3d(k=s=P) + Conv3d(3, pad 1) composed, csrc/head_tail.hip) against the two torch convolutions:
+    logits and all five gradients."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from micformer_amd import functional as Fn
+    B, Dc, Hc, Wc = dims
+    x = rnd(B, Dc, Hc, Wc, Ci, seed=1)
+    w_up, b_up = rnd(Ci, Cm, P, P, P, seed=2, scale=0.1), rnd(Cm, seed=3)
+    w_out, b_out = rnd(Co, Cm, 3, 3, 3, seed=4, scale=0.1), rnd(Co, seed=5)
+    dy = rnd(B, Co, Dc * P, Hc * P, Wc * P, seed=6)
+    ref_in = [t.clone().double().requires_grad_(True) for t in (x, w_up, b_up, w_out, b_out)]
+    z = F.conv_transpose3d(ref_in[0].permute(0, 4, 1, 2, 3), ref_in[1], ref_in[2], stride=P)
+    y_ref = F.conv3d(z, ref_in[3], ref_in[4], padding=1)
+    y_ref.backward(dy.double())
+    got_in = [dev(t).requires_grad_(True) for t in (x, w_up, b_up, w_out, b_out)]
+    y = Fn.HeadTailFn.apply(*got_in)
+    y.backward(dev(dy))
+    close(y, y_ref.float(), what="logits")
+    for name, g, r in zip(("dx", "dw_up", "db_up", "dw_out", "db_out"), got_in, ref_in):
+        close(g.grad, r.grad.float(), rtol=3e-4, what=name)
+
+
 # ----------------------------------------------------------------------------- window attention
 def _attn_ref(q, kv, dims, heads, ws):
     B, D, H, W = dims

@@ -131,8 +131,12 @@ int micf_window_attn_bwd(const float* q, int ldq, const float* k, const float* v
  * and Head.out_conv (MS.py:1046,1053).  w [N, c1+c2, 3,3,3].  y_layout 0: channels-last [T,N]; 1: NCDHW. */
 int micf_conv3_fwd(const float* x1, int c1, const float* x2, int c2, const float* w, const float* bias, float* y,
                    int y_layout, int B, int D, int H, int W, int N, micf_stream_t stream);
+/* workspace (optional scratch, micf_conv3_bwd_data_workspace floats): enables the direct data-gradient kernel for
+ * channels-last dy with N <= 16 (the weights are re-laid out as [tap][c][16 n] there by the same call). */
 int micf_conv3_bwd_data(const float* dy, int dy_layout, const float* w, float* dx1, int c1, int acc1, float* dx2,
-                        int c2, int acc2, int B, int D, int H, int W, int N, micf_stream_t stream);
+                        int c2, int acc2, int B, int D, int H, int W, int N, float* workspace, int64_t workspace_floats,
+                        micf_stream_t stream);
+int64_t micf_conv3_bwd_data_workspace(int N, int c1, int c2);
 int micf_conv3_bwd_weight(const float* dy, int dy_layout, const float* x1, int c1, const float* x2, int c2, float* dw,
                           float* dbias, int B, int D, int H, int W, int N, micf_stream_t stream);
 

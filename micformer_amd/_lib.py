@@ -32,7 +32,8 @@ SIGNATURES = {
     "micf_window_attn_fwd": "pippipiiiiiiiiiifp",
     "micf_window_attn_bwd": "pippipipippiiiiiiiiiifp",
     "micf_conv3_fwd": "pipipppiiiiiip",
-    "micf_conv3_bwd_data": "pippiipiiiiiiip",
+    "micf_conv3_bwd_data": "pippiipiiiiiiiplp",
+    "micf_conv3_bwd_data_workspace": "iii",
     "micf_conv3_bwd_weight": "pipipippiiiiip",
     "micf_offset_sample_fwd": "pppppppiiiiifp",
     "micf_offset_sample_bwd": "ppppppppppppiiiiifp",
@@ -81,6 +82,7 @@ def _load():
         fn.restype = _I
     lib.micf_linear_bwd_weight_workspace.restype = _L
     lib.micf_linear_bwd_weight_grouped_workspace.restype = _L
+    lib.micf_conv3_bwd_data_workspace.restype = _L
     lib.micf_strerror.argtypes = [_I]
     lib.micf_strerror.restype = ctypes.c_char_p
     lib.micf_abi_version.argtypes = []

@@ -38,4 +38,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 // column sums of (scale * dy) [M, N] accumulated into out[N] (bias gradients)
 int colsum_atomic(const float* dy, const float* scale, int64_t rps, float* out, int64_t M, int N, hipStream_t s);
 
+// direct data gradient for N <= 16 channels-last dy (conv3_bwdx.hip); wt = 27*(c1+c2)*16 floats of scratch
+int conv3_bwd_data_x(const float* dy, const float* w, float* wt, float* dx1, int c1, int acc1, float* dx2, int c2, int acc2, int B,
+                     int D, int H, int W, int N, hipStream_t stream);
+
 }  // namespace micf

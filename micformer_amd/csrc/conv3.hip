@@ -230,12 +230,17 @@ extern "C" int micf_conv3_fwd(const float* x1, int c1, const float* x2, int c2, 
   return RC(launch_gemm(tok, wgt, Conv3FwdPlanesEpi{bias, y, N, DHW, FastDiv((uint32_t)DHW), vec}, (int)T, N, 27 * Cin, 1, s));
 }
 
+extern "C" int64_t micf_conv3_bwd_data_workspace(int N, int c1, int c2) {
+  return (N > 0 && N <= 16 && c1 + c2 > 0) ? (int64_t)27 * (c1 + c2) * 16 : 0;
+}
+
 extern "C" int micf_conv3_bwd_data(const float* dy, int dy_layout, const float* w, float* dx1, int c1, int acc1,
-                                   float* dx2, int c2, int acc2, int B, int D, int H, int W, int N,
-                                   micf_stream_t stream) {
+                                   float* dx2, int c2, int acc2, int B, int D, int H, int W, int N, float* workspace,
+                                   int64_t workspace_floats, micf_stream_t stream) {
   if (!dy || !w || (!dx1 && !dx2) || !conv3_args_ok(B, D, H, W, N, c1, c2)) return MICF_EINVAL;
-  if (false) {   // the direct data-gradient kernel is correct (tests) but not yet faster than the implicit GEMM: kept off
-    const int rc = conv3_bwd_data_direct(dy, dy_layout, w, dx1, c1, acc1, dx2, c2, acc2, B, D, H, W, N, (hipStream_t)stream);
+  if (dy_layout == 0 && workspace && workspace_floats >= micf_conv3_bwd_data_workspace(N, c1, c2)) {
+    // few dy channels, channels-last: direct convolution with pre-transposed weights (conv3_bwdx.hip)
+    const int rc = conv3_bwd_data_x(dy, w, workspace, dx1, c1, acc1, dx2, c2, acc2, B, D, H, W, N, (hipStream_t)stream);
     if (rc != MICF_EUNSUPPORTED) return rc;
   }
   const Geo g{B, D, H, W};

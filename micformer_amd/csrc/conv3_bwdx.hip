@@ -1,0 +1,176 @@
+// conv3_bwdx.hip -- data gradient of the 3x3x3 / pad 1 convolution with FEW output channels (N <= 16: conv_offset[0],
+// MS.py:314, 354-356) as a direct convolution on the matrix cores.
+//
+//   dx[t, c] (=|+=) sum_{tap} sum_{n < 16} dy[t - off(tap), n] * w[n][c][tap]        c in [x1 | x2] (2C input channels)
+//
+// The reduction side is tiny (27 taps x 16 channels, the whole dy halo of a 128-token tile is 34 KB of LDS) and the output
+// side is wide, so: rows (MFMA i) = input channels c, columns (j) = 16 tokens, k = the 16 dy channels of one tap.
+//   * dy halo: staged once per workgroup, voxel stride 20 floats -> one conflict-free ds_read_b128 per (tap, token row) gives
+//     the B operand of 4 k-steps (k-permutation r = 4*lr + s, as in gemm_dma.h).
+//   * weights: pre-transposed to wt[tap][c][16 n] (a 27*Cin*16-float scratch, written by a tiny kernel of the same call), so
+//     the A operand of 4 k-steps for 16 channels is ONE coalesced 16-byte load per lane straight from L2 into registers --
+//     no LDS staging, no barrier inside the tap loop; the next tap's weights are prefetched under the current tap's MFMAs.
+//   * every wave owns 2 token rows x NCT channel tiles (2*NCT accumulators); per tap: 2 LDS reads + NCT loads for 8*NCT MFMAs.
+// The implicit-GEMM path (conv3.hip) needed 360 us for the 32^3 x 2 stage (15 TFLOP/s); see DESIGN.md for this kernel's numbers.
+#include "common.h"
+
+namespace micf {
+
+constexpr int xKS = 20;      // LDS voxel stride (floats): 16 channels + 4 pad
+
+struct BwdxArgs {
+  const float* dy; int N;                       // channels-last [T, N], N <= 16, N % 4 == 0
+  const float* wt;                              // [27][O][16]
+  float* d1; float* d2; int oc1, oc2, acc1, acc2;
+  int O;                                        // oc1 + oc2, multiple of 16
+  int B, D, H, W, tiles_d, tiles_h, tiles_w;
+};
+
+__global__ void __launch_bounds__(256) conv3_wt_kernel(const float* __restrict__ w, float* __restrict__ wt, int N, int Cin) {
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (id >= (int64_t)27 * Cin * 16) return;
+  const int n = (int)(id & 15);
+  const int c = (int)((id >> 4) % Cin);
+  const int tap = (int)((id >> 4) / Cin);
+  wt[id] = n < N ? w[((int64_t)n * Cin + c) * 27 + tap] : 0.f;
+}
+
+// TW: tokens of a tile along w (16 or 8); a column tile is 16/TW h-rows x TW.  Tile = 2 (d) x 4*(16/TW) (h) x TW = 128 tokens.
+template <int TW, int NCT>
+__global__ void __launch_bounds__(256) conv3_bwdx_kernel(BwdxArgs a) {
+  constexpr int CH = 16 / TW, TH = 4 * CH, TD = 2;
+  constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2, HALO = HD * HH * HW;
+  __shared__ __attribute__((aligned(16))) float Xs[HALO * xKS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lr = lane >> 4;
+  int q = blockIdx.x;
+  const int tw = q % a.tiles_w; q /= a.tiles_w;
+  const int th = q % a.tiles_h; q /= a.tiles_h;
+  const int td = q % a.tiles_d; const int b = q / a.tiles_d;
+  const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;
+  const int64_t DHW = (int64_t)a.D * a.H * a.W;
+  const int ct0 = blockIdx.y * NCT;                       // first channel tile of this workgroup
+  const int nct = min(NCT, a.O / 16 - ct0);
+
+  // ---- dy halo -> LDS (all loads first, then the stores)
+  {
+    constexpr int NH = (HALO * 4 + 255) / 256;
+    float4 hv4[NH];
+#pragma unroll
+    for (int it = 0; it < NH; ++it) {
+      const int idx = tid + it * 256;
+      hv4[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < HALO * 4) {
+        const int hv = idx >> 2, g = idx & 3;
+        const int hw = hv % HW, hh = (hv / HW) % HH, hd = hv / (HW * HH);
+        const int dd = d0 + hd - 1, yy = h0 + hh - 1, ww = w0 + hw - 1;
+        if ((unsigned)dd < (unsigned)a.D && (unsigned)yy < (unsigned)a.H && (unsigned)ww < (unsigned)a.W && 4 * g < a.N)
+          hv4[it] = *reinterpret_cast<const float4*>(a.dy + ((int64_t)b * DHW + ((int64_t)dd * a.H + yy) * a.W + ww) * a.N + 4 * g);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NH; ++it) {
+      const int idx = tid + it * 256;
+      if (idx < HALO * 4) *reinterpret_cast<float4*>(&Xs[(idx >> 2) * xKS + 4 * (idx & 3)]) = hv4[it];
+    }
+  }
+  // ---- this wave's two column tiles: ct = 2*wave + tj -> (ld, h group); lane li -> (lh, lw) inside it
+  int ld[2], lh[2], lw[2];
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj) {
+    const int ct = 2 * wave + tj;
+    ld[tj] = ct / 4;
+    lh[tj] = (ct % 4) * CH + li / TW;
+    lw[tj] = li % TW;
+  }
+  f32x4 acc[NCT][2];
+#pragma unroll
+  for (int t = 0; t < NCT; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  const float* wp = a.wt + ((int64_t)(ct0 * 16 + li)) * 16 + 4 * lr;      // + tap * O * 16 + t * 256
+  const int64_t tap_stride = (int64_t)a.O * 16;
+  float4 av[NCT], an[NCT];
+#pragma unroll
+  for (int t = 0; t < NCT; ++t) av[t] = (t < nct) ? *reinterpret_cast<const float4*>(wp + t * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+#pragma unroll 1
+  for (int tap = 0; tap < 27; ++tap) {
+    if (tap + 1 < 27) {
+#pragma unroll
+      for (int t = 0; t < NCT; ++t)
+        an[t] = (t < nct) ? *reinterpret_cast<const float4*>(wp + (tap + 1) * tap_stride + t * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+    float4 bv[2];
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+      const int zd = ld[tj] + 2 - kd, zh = lh[tj] + 2 - kh, zw = lw[tj] + 2 - kw;      // source voxel = token - (k - 1), halo origin -1
+      bv[tj] = *reinterpret_cast<const float4*>(&Xs[((zd * HH + zh) * HW + zw) * xKS + 4 * lr]);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float b0 = s == 0 ? bv[0].x : (s == 1 ? bv[0].y : (s == 2 ? bv[0].z : bv[0].w));
+      const float b1 = s == 0 ? bv[1].x : (s == 1 ? bv[1].y : (s == 2 ? bv[1].z : bv[1].w));
+#pragma unroll
+      for (int t = 0; t < NCT; ++t) {
+        const float av_s = s == 0 ? av[t].x : (s == 1 ? av[t].y : (s == 2 ? av[t].z : av[t].w));
+        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_s, b0, acc[t][0], 0, 0, 0);
+        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_s, b1, acc[t][1], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NCT; ++t) av[t] = an[t];
+  }
+  // ---- epilogue: D row = channel 4*lr + v of tile t (float4 over v), column = token li
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj) {
+    const int dd = d0 + ld[tj], yy = h0 + lh[tj], ww = w0 + lw[tj];
+    if (dd >= a.D || yy >= a.H || ww >= a.W) continue;
+    const int64_t tok = (int64_t)b * DHW + ((int64_t)dd * a.H + yy) * a.W + ww;
+#pragma unroll
+    for (int t = 0; t < NCT; ++t) {
+      if (t >= nct) continue;
+      const int c = (ct0 + t) * 16 + 4 * lr;
+      float* p; int accf;
+      if (c < a.oc1) { p = a.d1 ? a.d1 + tok * a.oc1 + c : nullptr; accf = a.acc1; }
+      else { p = a.d2 ? a.d2 + tok * a.oc2 + (c - a.oc1) : nullptr; accf = a.acc2; }
+      if (!p) continue;
+      f32x4 v = acc[t][tj];
+      if (accf) { const float4 old = *reinterpret_cast<const float4*>(p); v[0] += old.x; v[1] += old.y; v[2] += old.z; v[3] += old.w; }
+      *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
+template <int TW>
+static hipError_t launch_bwdx(BwdxArgs& a, hipStream_t stream) {
+  constexpr int CH = 16 / TW, TH = 4 * CH;
+  a.tiles_d = (a.D + 1) / 2;
+  a.tiles_h = (a.H + TH - 1) / TH;
+  a.tiles_w = (a.W + TW - 1) / TW;
+  const int64_t blocks = (int64_t)a.B * a.tiles_d * a.tiles_h * a.tiles_w;
+  const int cts = a.O / 16;
+  // many token tiles: 6 channel tiles per workgroup (the halo is staged once per 96 channels); few: 2, to spread over the CUs
+  if (blocks * ((cts + 5) / 6) >= 384)
+    hipLaunchKernelGGL((conv3_bwdx_kernel<TW, 6>), dim3((unsigned)blocks, (cts + 5) / 6), dim3(256), 0, stream, a);
+  else
+    hipLaunchKernelGGL((conv3_bwdx_kernel<TW, 2>), dim3((unsigned)blocks, (cts + 1) / 2), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+
+// MICF_EUNSUPPORTED when the shape is outside what this kernel covers (caller falls back to the implicit GEMM).
+int conv3_bwd_data_x(const float* dy, const float* w, float* wt, float* dx1, int c1, int acc1, float* dx2, int c2, int acc2, int B,
+                     int D, int H, int W, int N, hipStream_t stream) {
+  const int O = c1 + c2;
+  if (N > 16 || (N & 3) || (O & 15) || (c1 & 3) || (c2 & 3) || W < 8 || !aligned16(dy) || !aligned16(wt) ||
+      (dx1 && !aligned16(dx1)) || (dx2 && !aligned16(dx2)))
+    return MICF_EUNSUPPORTED;
+  const int64_t n = (int64_t)27 * O * 16;
+  hipLaunchKernelGGL(conv3_wt_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, wt, N, O);
+  if (hipGetLastError() != hipSuccess) return MICF_ELAUNCH;
+  BwdxArgs a{};
+  a.dy = dy; a.N = N; a.wt = wt; a.d1 = dx1; a.d2 = dx2; a.oc1 = c1; a.oc2 = c2; a.acc1 = acc1; a.acc2 = acc2; a.O = O;
+  a.B = B; a.D = D; a.H = H; a.W = W;
+  const hipError_t e = (W >= 12) ? launch_bwdx<16>(a, stream) : launch_bwdx<8>(a, stream);
+  return e == hipSuccess ? MICF_OK : MICF_ELAUNCH;
+}
+
+}  // namespace micf

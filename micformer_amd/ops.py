@@ -188,8 +188,10 @@ def conv3_bwd_data(dy, w, dims, c1, c2=0, ncdhw=False, dx1=None, dx2=None, acc1=
         dx1 = _new(dy, T, c1)
     if dx2 is None and want2 and c2 > 0:
         dx2 = _new(dy, T, c2)
+    need = 0 if ncdhw else _lib.lib.micf_conv3_bwd_data_workspace(N, c1, c2)
+    ws = scratch(dy.device, need) if need > 0 else None
     call("micf_conv3_bwd_data", f32(dy), 1 if ncdhw else 0, f32(w), f32(dx1), c1, 1 if acc1 else 0, f32(dx2), c2,
-         1 if acc2 else 0, B, D, H, W, N,
+         1 if acc2 else 0, B, D, H, W, N, f32(ws), ws.numel() if ws is not None else 0,
          cost=_cost(2 * T * 27 * (c1 + c2) * N, dy, w, dx1, dx2))
     return dx1, dx2
 

@@ -38,6 +38,20 @@ def synthetic_batch(B, vol, num_classes, device, seed):
     return x, tgt
 
 
+def pmc_traffic(kernel_key):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, written
+    by tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE passes with the gfx950 corrections of MI355X_MICROARCH.md);
+    None when no PMC summary covers this kernel."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            table = json.load(f)
+    except (OSError, ValueError):
+        return None
+    rec = table.get(kernel_key)
+    return int(rec["hbm_bytes_per_launch"]) if rec else None
+
+
 def cpu_baseline(vol, threads, budget_s=25.0):
     """The CPU restatement (oracle/, 'port') timed on the host cores on a BOUNDED sample of the same workload: full fp32
     train steps (fwd + MDiceLoss + bwd + Adam) of the base model on one (vol/2)^3 CT+MR pair -- 1/8 of the voxels of a
@@ -156,23 +170,25 @@ def main():
         "final_loss": round(loss_val, 6),
     }
 
-    # ---- roofline of the dominant kernel: HIP events around every C-ABI launch of 2 eager steps on the launch stream
+    # ---- roofline of the dominant kernel: HIP events around every C-ABI launch of 2 eager steps on the launch stream(s),
+    # keyed by (entry point, shape).  The dominant kernel is the (entry point, shape) with the largest total time.
     if not args.no_roofline:
+        from micformer_amd import ops as _ops
         eng_graph = eng.use_graph
         eng.use_graph = False
         eng.step(x, tgt)
         torch.cuda.synchronize()
-        if args.detail:
-            from micformer_amd import ops as _ops
-            _ops.DETAIL = True
+        _ops.DETAIL = True
         _lib.profile_start()
         nprof = 2
         for _ in range(nprof):
             eng.step(x, tgt)
         prof = _lib.profile_stop()
+        _ops.DETAIL = False
         eng.use_graph = eng_graph
         total_ms = sum(v["ms"] for v in prof.values())
         name, top = max(prof.items(), key=lambda kv: kv[1]["ms"])
+        per = top["calls"]
         sec = top["ms"] / 1e3
         gbs = top["bytes"] / sec / 1e9
         tfl = top["flops"] / sec / 1e12
@@ -184,19 +200,29 @@ def main():
             roof = {"bound": "mfma", "achieved": round(tfl, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(frac_mfma, 4)}
         else:
             roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(frac_hbm, 4)}
-        roof.update({"traffic": None, "kernel": name, "launches_per_step": top["calls"] // nprof,
-                     "avg_launch_us": round(1e3 * top["ms"] / top["calls"], 2),
+        roof.update({"traffic": pmc_traffic(name), "kernel": name, "launches_per_step": per // nprof,
+                     "avg_launch_us": round(1e3 * top["ms"] / per, 2),
                      "share_of_kernel_time": round(top["ms"] / total_ms, 4),
-                     "algorithmic_bytes_per_step": top["bytes"] // nprof, "flops_per_step": top["flops"] // nprof,
+                     "algorithmic_bytes_per_launch": top["bytes"] // per, "flops_per_launch": top["flops"] // per,
                      "hbm_frac": round(frac_hbm, 4), "mfma_f32_frac": round(frac_mfma, 4)})
         out["roofline"] = roof
-        # whole-step view: all kernels' algorithmic bytes over the sum of their event times
+        # whole-step view: entry points (all shapes merged), algorithmic bytes / flops over the sum of their event times
+        merged = {}
+        for k, v in prof.items():
+            m = merged.setdefault(k.split("|")[0], dict(calls=0, ms=0.0, bytes=0, flops=0))
+            for f in ("calls", "ms", "bytes", "flops"):
+                m[f] += v[f]
         tot_b = sum(v["bytes"] for v in prof.values())
         tot_f = sum(v["flops"] for v in prof.values())
         out["kernels"] = {k: {"ms_per_step": round(v["ms"] / nprof, 3), "calls_per_step": v["calls"] // nprof,
                               "GB/s": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1),
                               "TFLOP/s": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2)}
-                          for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+                          for k, v in sorted(merged.items(), key=lambda kv: -kv[1]["ms"])}
+        if args.detail:
+            out["kernels_by_shape"] = {k: {"ms_per_step": round(v["ms"] / nprof, 3), "calls_per_step": v["calls"] // nprof,
+                                           "GB/s": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1),
+                                           "TFLOP/s": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2)}
+                                       for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:60]}
         out["step_summary"] = {"kernel_ms_per_step": round(total_ms / nprof, 3), "launches_per_step": sum(v["calls"] for v in prof.values()) // nprof,
                                "algorithmic_GB_per_step": round(tot_b / nprof / 1e9, 3), "GFLOP_per_step": round(tot_f / nprof / 1e9, 1)}
 

@@ -151,7 +151,11 @@ int micf_offset_sample_fwd(const float* h, const float* ln_g, const float* ln_b,
 /* dxa += (atomic scatter), dh [T,16] written, dln_g/dln_b/dw1 accumulated. */
 int micf_offset_sample_bwd(const float* dxs, const float* h, const float* ln_g, const float* ln_b, const float* w1,
                            const float* xa, const float* flow, float* dxa, float* dh, float* dln_g, float* dln_b,
-                           float* dw1, int B, int D, int H, int W, int C, float eps, micf_stream_t stream);
+                           float* dw1, int B, int D, int H, int W, int C, float eps, float* workspace,
+                           int64_t workspace_floats, micf_stream_t stream);
+/* Scratch (in floats) that lets micf_offset_sample_bwd turn the atomic d(xa) scatter into a gather over per-cell token
+ * lists (big grids only; 0 = the grid is small enough that the single atomic kernel is used anyway). */
+int64_t micf_offset_sample_bwd_workspace(int B, int D, int H, int W);
 
 /* Standalone SpatialTransformer.forward (STN.py:9-32) on channels-last src [B,D,H,W,C] with a given flow [T,3]
  * (voxel displacement, z,y,x): out [T,C].  Backward: dsrc += (atomic scatter, caller zero-fills), dflow [T,3] written. */

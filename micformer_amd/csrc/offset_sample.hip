@@ -5,8 +5,15 @@
 //                                                                         (STN.py:9-32, MS.py:379)
 // One 64-lane wave per token: the 16-wide offset head is computed redundantly in each 16-lane group, then the lanes
 // stride over the C channels of the 8 tap rows (each a contiguous channels-last token row: coalesced).
-// Backward scatters d(xa) with atomics (taps of neighbouring tokens collide), reduces d(flow) across the wave, and
-// runs the 16-wide head backwards, accumulating the tiny parameter gradients per wave before one atomic flush.
+// Backward reduces d(flow) across the wave and runs the 16-wide head backwards, accumulating the tiny parameter gradients per
+// wave before one atomic flush.  d(xa) is a scatter (taps of neighbouring tokens collide).  Device-scope fp32 atomics cost a
+// fabric transaction each (8 taps x C channels per token: 317 us for the 32^3 x 2 stage), so on big grids the scatter is
+// turned into a GATHER: every token registers itself in the list of its base cell floor(coord) (one int atomic per token,
+// capacity kCellCap, overflow -> a small atomic fallback pass), and a second kernel walks, for every voxel, the lists of
+// the 8 cells that have it as a corner, accumulating w * dxs[token] rows with coalesced 16-byte loads and ONE plain
+// read-modify-write per output element.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace micf {
@@ -105,11 +112,30 @@ __global__ void __launch_bounds__(256) offset_sample_fwd_kernel(const float* __r
   }
 }
 
+constexpr int kCellCap = 8;      // tokens per cell list
+
+struct CellLists {               // workspace carved by the launcher (all int32)
+  int* count;                    // [B*(D+1)*(H+1)*(W+1)] tokens registered per cell (may exceed kCellCap: the rest overflowed)
+  int* ovf_count;                // [1]
+  int* list;                     // [cells][kCellCap]
+  int* ovf;                      // [T] tokens that did not fit their cell's list
+  int cap;                       // list entries actually used (kCellCap; smaller only under MICF_CELL_CAP, a test hook)
+};
+
+// cell of a token: base corner floor(coord) + 1 per axis, or -1 when no corner of the cell lies inside the volume
+__device__ __forceinline__ int cell_of(const Taps& tp, int b, int D, int H, int W) {
+  if (!tp.finite) return -1;
+  if (!(tp.z0 >= -1.f && tp.z0 <= (float)(D - 1) && tp.y0 >= -1.f && tp.y0 <= (float)(H - 1) && tp.x0 >= -1.f && tp.x0 <= (float)(W - 1)))
+    return -1;
+  return ((b * (D + 1) + (int)tp.z0 + 1) * (H + 1) + (int)tp.y0 + 1) * (W + 1) + (int)tp.x0 + 1;
+}
+
+template <bool SCATTER>
 __global__ void __launch_bounds__(256) offset_sample_bwd_kernel(
     const float* __restrict__ dxs, const float* __restrict__ h, const float* __restrict__ ln_g, const float* __restrict__ ln_b,
     const float* __restrict__ w1, const float* __restrict__ xa, const float* __restrict__ flow, float* __restrict__ dxa,
     float* __restrict__ dh, float* __restrict__ dln_g, float* __restrict__ dln_b, float* __restrict__ dw1, Geo g, int C, float eps,
-    int tpw) {
+    int tpw, CellLists cl, float* __restrict__ partials, int nwaves) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, k = lane & 15;
   const int64_t T = g.tokens();
   float acc_w[3] = {0.f, 0.f, 0.f}, acc_g = 0.f, acc_b = 0.f;       // per-lane (channel k) partials, lanes 0..15 flush
@@ -139,11 +165,19 @@ __global__ void __launch_bounds__(256) offset_sample_bwd_kernel(
         if (!ok[q]) continue;
         const int dz = q >> 2, dy = (q >> 1) & 1, dx = q & 1;
         const int64_t a = boff + (int64_t)lin[q] * C + c;
-        atomicAdd(dxa + a, wx[q] * wy[q] * wz[q] * go);
+        if (SCATTER) atomicAdd(dxa + a, wx[q] * wy[q] * wz[q] * go);
         const float val = xa[a] * go;
         gx += (dx ? val : -val) * wy[q] * wz[q];
         gy += (dy ? val : -val) * wx[q] * wz[q];
         gz += (dz ? val : -val) * wx[q] * wy[q];
+      }
+    }
+    if (!SCATTER && lane == 0) {
+      const int cell = cell_of(tp, b, g.D, g.H, g.W);
+      if (cell >= 0) {
+        const int slot = atomicAdd(cl.count + cell, 1);
+        if (slot < cl.cap) cl.list[(int64_t)cell * kCellCap + slot] = (int)t;
+        else cl.ovf[atomicAdd(cl.ovf_count, 1)] = (int)t;
       }
     }
     gz = wave_sum(gz); gy = wave_sum(gy); gx = wave_sum(gx);
@@ -165,10 +199,97 @@ __global__ void __launch_bounds__(256) offset_sample_bwd_kernel(
     if (lane < kHid) dh[t * kHid + k] = rs * (gd - ma - xh * mb);
   }
   if (lane < kHid) {
+    if (partials) {      // partials[address][wave]: summed by sample_finish_kernel (thousands of waves hitting the same 80 addresses
+                         // with device-scope atomics serialise: that, not the scatter, was most of this kernel's time)
+      const int wg = blockIdx.x * 4 + wave;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) atomicAdd(dw1 + a * kHid + k, acc_w[a]);
-    atomicAdd(dln_g + k, acc_g);
-    atomicAdd(dln_b + k, acc_b);
+      for (int a = 0; a < 3; ++a) partials[(int64_t)(a * kHid + k) * nwaves + wg] = acc_w[a];
+      partials[(int64_t)(3 * kHid + k) * nwaves + wg] = acc_g;
+      partials[(int64_t)(4 * kHid + k) * nwaves + wg] = acc_b;
+    } else {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) atomicAdd(dw1 + a * kHid + k, acc_w[a]);
+      atomicAdd(dln_g + k, acc_g);
+      atomicAdd(dln_b + k, acc_b);
+    }
+  }
+}
+
+
+// d(xa)[v, :] += sum over the tokens registered in the 8 cells that have voxel v as a corner.  Thread = (voxel, 4 channels).
+__global__ void __launch_bounds__(256) sample_gather_kernel(const float* __restrict__ dxs, const float* __restrict__ flow,
+                                                            float* __restrict__ dxa, Geo g, int C, CellLists cl) {
+  const int q4 = C >> 2;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t v = idx / q4;
+  if (v >= g.tokens()) return;
+  const int c4 = (int)(idx % q4) * 4;
+  int b, z, y, x; g.decode((int)v, b, z, y, x);
+  float4 acc = *reinterpret_cast<const float4*>(dxa + v * C + c4);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int dz = q >> 2, dy = (q >> 1) & 1, dx = q & 1;
+    const int cell = ((b * (g.D + 1) + z - dz + 1) * (g.H + 1) + y - dy + 1) * (g.W + 1) + x - dx + 1;
+    int n = cl.count[cell];
+    n = n < cl.cap ? n : cl.cap;
+    for (int i = 0; i < n; ++i) {
+      const int t = cl.list[(int64_t)cell * kCellCap + i];
+      int tb, td, th, tw; g.decode(t, tb, td, th, tw);
+      const float fl[3] = {flow[(int64_t)t * 3 + 0], flow[(int64_t)t * 3 + 1], flow[(int64_t)t * 3 + 2]};
+      const Taps tp = make_taps(td, th, tw, fl, g.D, g.H, g.W);
+      const float wx = dx ? tp.cx - tp.x0 : (tp.x0 + 1.f) - tp.cx;
+      const float wy = dy ? tp.cy - tp.y0 : (tp.y0 + 1.f) - tp.cy;
+      const float wz = dz ? tp.cz - tp.z0 : (tp.z0 + 1.f) - tp.cz;
+      const float wgt = wx * wy * wz;
+      const float4 go = *reinterpret_cast<const float4*>(dxs + (int64_t)t * C + c4);
+      acc.x += wgt * go.x; acc.y += wgt * go.y; acc.z += wgt * go.z; acc.w += wgt * go.w;
+    }
+  }
+  *reinterpret_cast<float4*>(dxa + v * C + c4) = acc;
+}
+
+// Second pass of the backward.  (1) blocks 0..79: sum the per-wave partials of one head-parameter gradient element and add it
+// to dw1 / dln_g / dln_b (one writer per element).  (2) all blocks: tokens whose cell list was full -- the atomic scatter, one
+// wave per token (normally zero tokens).
+__global__ void __launch_bounds__(256) sample_finish_kernel(const float* __restrict__ dxs, const float* __restrict__ flow,
+                                                            float* __restrict__ dxa, Geo g, int C, CellLists cl,
+                                                            const float* __restrict__ partials, int nwaves, float* __restrict__ dw1,
+                                                            float* __restrict__ dln_g, float* __restrict__ dln_b) {
+  const int lane = threadIdx.x & 63;
+  if (partials && blockIdx.x < 5 * kHid) {
+    __shared__ float red[4];
+    const float* p = partials + (int64_t)blockIdx.x * nwaves;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < nwaves; i += 256) acc += p[i];
+    acc = wave_sum(acc);
+    if (lane == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float tot = red[0] + red[1] + red[2] + red[3];
+      const int a = blockIdx.x;
+      if (a < 3 * kHid) dw1[a] += tot;
+      else if (a < 4 * kHid) dln_g[a - 3 * kHid] += tot;
+      else dln_b[a - 4 * kHid] += tot;
+    }
+  }
+  if (!cl.count) return;
+  const int n = *cl.ovf_count;
+  for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += gridDim.x * 4) {
+    const int t = cl.ovf[i];
+    int b, d, hh, w; g.decode(t, b, d, hh, w);
+    const float fl[3] = {flow[(int64_t)t * 3 + 0], flow[(int64_t)t * 3 + 1], flow[(int64_t)t * 3 + 2]};
+    const Taps tp = make_taps(d, hh, w, fl, g.D, g.H, g.W);
+    const int64_t boff = (int64_t)b * g.D * g.H * g.W * C;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int dz = q >> 2, dy = (q >> 1) & 1, dx = q & 1;
+      int lin;
+      if (!(tp.finite && corner(tp, dz, dy, dx, g.D, g.H, g.W, lin))) continue;
+      const float wx = dx ? tp.cx - tp.x0 : (tp.x0 + 1.f) - tp.cx;
+      const float wy = dy ? tp.cy - tp.y0 : (tp.y0 + 1.f) - tp.cy;
+      const float wz = dz ? tp.cz - tp.z0 : (tp.z0 + 1.f) - tp.cz;
+      for (int c = lane; c < C; c += 64) atomicAdd(dxa + boff + (int64_t)lin * C + c, wx * wy * wz * dxs[(int64_t)t * C + c]);
+    }
   }
 }
 
@@ -260,19 +381,66 @@ extern "C" int micf_offset_sample_fwd(const float* h, const float* ln_g, const f
   MICF_RETURN_LAUNCH();
 }
 
+static int64_t cell_count(int B, int D, int H, int W) { return (int64_t)B * (D + 1) * (H + 1) * (W + 1); }
+static int64_t partial_floats(int64_t T) {           // [80][waves], rounded up to a 16-byte multiple
+  const int64_t waves = ceil_div(T, (int64_t)4 * tok_per_wave(T)) * 4;
+  return (5 * kHid * waves + 3) / 4 * 4;
+}
+static bool use_cells(int64_t T) { return T >= 4096; }   // small grids keep the atomic scatter (launch-bound anyway)
+
+extern "C" int64_t micf_offset_sample_bwd_workspace(int B, int D, int H, int W) {
+  if (B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+  const int64_t T = (int64_t)B * D * H * W;
+  int64_t need = partial_floats(T);
+  if (use_cells(T)) {
+    const int64_t nc = (cell_count(B, D, H, W) + 3) / 4 * 4;
+    need += nc + 4 + nc * kCellCap + T;
+  }
+  return need;
+}
+
 extern "C" int micf_offset_sample_bwd(const float* dxs, const float* h, const float* ln_g, const float* ln_b,
                                       const float* w1, const float* xa, const float* flow, float* dxa, float* dh,
                                       float* dln_g, float* dln_b, float* dw1, int B, int D, int H, int W, int C, float eps,
-                                      micf_stream_t stream) {
+                                      float* workspace, int64_t workspace_floats, micf_stream_t stream) {
   if (!dxs || !h || !ln_g || !ln_b || !w1 || !xa || !flow || !dxa || !dh || !dln_g || !dln_b || !dw1 || B <= 0 || D <= 0 ||
       H <= 0 || W <= 0 || C <= 0)
     return MICF_EINVAL;
   const Geo g{B, D, H, W};
-  if (g.tokens() >= (1LL << 31)) return MICF_EUNSUPPORTED;
-  const int tpw = tok_per_wave(g.tokens());
-  const int blocks = ceil_div(g.tokens(), 4 * tpw);
-  hipLaunchKernelGGL(offset_sample_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dxs, h, ln_g, ln_b, w1, xa,
-                     flow, dxa, dh, dln_g, dln_b, dw1, g, C, eps, tpw);
+  const int64_t T = g.tokens();
+  if (T >= (1LL << 31) / 4) return MICF_EUNSUPPORTED;
+  const int tpw = tok_per_wave(T);
+  const int blocks = ceil_div(T, 4 * tpw);
+  const int nwaves = blocks * 4;
+  hipStream_t s = (hipStream_t)stream;
+  const CellLists none{nullptr, nullptr, nullptr, nullptr, 0};
+  if (!workspace || workspace_floats < micf_offset_sample_bwd_workspace(B, D, H, W) || !aligned16(workspace)) {
+    hipLaunchKernelGGL(offset_sample_bwd_kernel<true>, dim3(blocks), dim3(256), 0, s, dxs, h, ln_g, ln_b, w1, xa, flow, dxa, dh,
+                       dln_g, dln_b, dw1, g, C, eps, tpw, none, (float*)nullptr, 0);
+    MICF_RETURN_LAUNCH();
+  }
+  float* partials = workspace;
+  CellLists cl = none;
+  if (use_cells(T) && (C % 4 == 0) && aligned16(dxs) && aligned16(dxa) && cell_count(B, D, H, W) * kCellCap < (1LL << 31)) {
+    const int64_t nc = (cell_count(B, D, H, W) + 3) / 4 * 4;
+    int* base = reinterpret_cast<int*>(workspace + partial_floats(T));
+    const char* env = getenv("MICF_CELL_CAP");           // test hook: force the overflow pass
+    int cap = env ? atoi(env) : kCellCap;
+    cap = cap < 0 ? 0 : (cap > kCellCap ? kCellCap : cap);
+    cl = CellLists{base, base + nc, base + nc + 4, base + nc + 4 + nc * kCellCap, cap};
+    if (hipMemsetAsync(base, 0, sizeof(int) * (size_t)(nc + 4), s) != hipSuccess) return MICF_ELAUNCH;
+    hipLaunchKernelGGL(offset_sample_bwd_kernel<false>, dim3(blocks), dim3(256), 0, s, dxs, h, ln_g, ln_b, w1, xa, flow, dxa, dh,
+                       dln_g, dln_b, dw1, g, C, eps, tpw, cl, partials, nwaves);
+    if (hipGetLastError() != hipSuccess) return MICF_ELAUNCH;
+    const int64_t threads = T * (C / 4);
+    hipLaunchKernelGGL(sample_gather_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, dxs, flow, dxa, g, C, cl);
+  } else {
+    hipLaunchKernelGGL(offset_sample_bwd_kernel<true>, dim3(blocks), dim3(256), 0, s, dxs, h, ln_g, ln_b, w1, xa, flow, dxa, dh,
+                       dln_g, dln_b, dw1, g, C, eps, tpw, none, partials, nwaves);
+  }
+  if (hipGetLastError() != hipSuccess) return MICF_ELAUNCH;
+  hipLaunchKernelGGL(sample_finish_kernel, dim3(5 * kHid), dim3(256), 0, s, dxs, flow, dxa, g, C, cl, partials, nwaves, dw1, dln_g,
+                     dln_b);
   MICF_RETURN_LAUNCH();
 }
 

@@ -222,8 +222,10 @@ def offset_sample_bwd(dxs, h, ln_g, ln_b, w1, xa, flow, dxa, dln_g, dln_b, dw1, 
     B, D, H, W = dims
     T, C = xa.shape
     dh = _new(xa, T, h.shape[1])
+    need = _lib.lib.micf_offset_sample_bwd_workspace(B, D, H, W)
+    ws = scratch(xa.device, need) if need > 0 else None
     call("micf_offset_sample_bwd", f32(dxs), f32(h), f32(ln_g), f32(ln_b), f32(w1), f32(xa), f32(flow), f32(dxa), f32(dh),
-         f32(dln_g), f32(dln_b), f32(dw1), B, D, H, W, C, float(eps),
+         f32(dln_g), f32(dln_b), f32(dw1), B, D, H, W, C, float(eps), f32(ws), ws.numel() if ws is not None else 0,
          cost=_cost(T * (40 * C + 800), dxs, h, xa, flow, dxa, dxa, dh))
     return dh
 

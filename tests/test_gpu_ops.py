@@ -243,16 +243,25 @@ def test_conv3(ops, dims, c1, c2, N, ncdhw):
 
 
 # ----------------------------------------------------------------------------- offset head + deformable sampling
-@pytest.mark.parametrize("dims,C", [((2, 4, 6, 4), 24), ((1, 5, 5, 5), 48), ((1, 2, 2, 2), 24), ((1, 1, 1, 1), 96),
-                                    ((1, 3, 5, 2), 96), ((1, 1, 4, 4), 24)])
-def test_offset_sample(ops, dims, C):
+@pytest.mark.parametrize("case", [((2, 4, 6, 4), 24), ((1, 5, 5, 5), 48), ((1, 2, 2, 2), 24), ((1, 1, 1, 1), 96),
+                                  ((1, 3, 5, 2), 96), ((1, 1, 4, 4), 24),
+                                  ((1, 16, 16, 16), 48), ((2, 8, 16, 16), 24, 8.0), ((1, 16, 16, 16), 96, 0.5, 1),
+                                  ((1, 16, 8, 32), 24, 2.0, 0)])
+def test_offset_sample(ops, case, monkeypatch):
+    """case = (dims, C[, offset scale[, MICF_CELL_CAP]]).  The last four grids are big enough (>= 4096 tokens) for the
+    cell-list gather of d(xa); the offset scale pushes taps far out of the volume; the cap shrinks the per-cell lists so
+    that tokens overflow into the atomic fallback pass (cap 0: every token)."""
+    dims, C = case[0], case[1]
+    wscale = case[2] if len(case) > 2 else 0.5
+    if len(case) > 3:
+        monkeypatch.setenv("MICF_CELL_CAP", str(case[3]))
     B, D, H, W = dims
     T = B * D * H * W
     h = rnd(T, 16, seed=1).requires_grad_(True)
     xa = rnd(T, C, seed=2).requires_grad_(True)
     lg = (1 + 0.1 * rnd(16, seed=3)).requires_grad_(True)
     lb = (0.1 * rnd(16, seed=4)).requires_grad_(True)
-    w1 = (rnd(3, 16, seed=5) * 0.5).requires_grad_(True)
+    w1 = (rnd(3, 16, seed=5) * wscale).requires_grad_(True)
     dxs = rnd(T, C, seed=6)
     off = F.linear(R.gelu(R.layer_norm(h.reshape(B, D, H, W, 16), lg, lb)), w1)
     flow = off + R.reference_points(D, H, W)

@@ -137,8 +137,12 @@ int micf_conv3_bwd_data(const float* dy, int dy_layout, const float* w, float* d
                         int c2, int acc2, int B, int D, int H, int W, int N, float* workspace, int64_t workspace_floats,
                         micf_stream_t stream);
 int64_t micf_conv3_bwd_data_workspace(int N, int c1, int c2);
+/* workspace (optional scratch, micf_conv3_bwd_weight_workspace floats; 0 = not used for this shape): enables the
+ * register-resident MFMA weight-gradient kernel for channels-last dy with N == 16. */
 int micf_conv3_bwd_weight(const float* dy, int dy_layout, const float* x1, int c1, const float* x2, int c2, float* dw,
-                          float* dbias, int B, int D, int H, int W, int N, micf_stream_t stream);
+                          float* dbias, int B, int D, int H, int W, int N, float* workspace, int64_t workspace_floats,
+                          micf_stream_t stream);
+int64_t micf_conv3_bwd_weight_workspace(int B, int D, int H, int W, int N, int c1, int c2);
 
 /* ---- deformable re-sampling of the key/value modality (MS.py:313-318 tail, 326-337, 360-384; STN.py:9-32):
  *   off = W1 @ GELU(LN16(h))           h [T,16] = conv_offset.0 output, W1 [3,16] (no bias)

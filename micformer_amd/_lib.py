@@ -34,7 +34,8 @@ SIGNATURES = {
     "micf_conv3_fwd": "pipipppiiiiiip",
     "micf_conv3_bwd_data": "pippiipiiiiiiiplp",
     "micf_conv3_bwd_data_workspace": "iii",
-    "micf_conv3_bwd_weight": "pipipippiiiiip",
+    "micf_conv3_bwd_weight": "pipipippiiiiiplp",
+    "micf_conv3_bwd_weight_workspace": "iiiiiii",
     "micf_offset_sample_fwd": "pppppppiiiiifp",
     "micf_offset_sample_bwd": "ppppppppppppiiiiifplp",
     "micf_offset_sample_bwd_workspace": "iiii",
@@ -85,6 +86,7 @@ def _load():
     lib.micf_linear_bwd_weight_grouped_workspace.restype = _L
     lib.micf_conv3_bwd_data_workspace.restype = _L
     lib.micf_offset_sample_bwd_workspace.restype = _L
+    lib.micf_conv3_bwd_weight_workspace.restype = _L
     lib.micf_strerror.argtypes = [_I]
     lib.micf_strerror.restype = ctypes.c_char_p
     lib.micf_abi_version.argtypes = []

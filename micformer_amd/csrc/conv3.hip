@@ -256,9 +256,19 @@ extern "C" int micf_conv3_bwd_data(const float* dy, int dy_layout, const float* 
   return RC(launch_gemm(pa, make_elem<false>(gat, (int)T), epi, Cin, T, 27 * N, 1, s));                      // voxels contiguous
 }
 
+extern "C" int64_t micf_conv3_bwd_weight_workspace(int B, int D, int H, int W, int N, int c1, int c2) {
+  if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || c1 < 0 || c2 < 0) return 0;
+  return conv3_wgradx_workspace(B, D, H, W, N, c1, c2);
+}
+
 extern "C" int micf_conv3_bwd_weight(const float* dy, int dy_layout, const float* x1, int c1, const float* x2, int c2,
-                                     float* dw, float* dbias, int B, int D, int H, int W, int N, micf_stream_t stream) {
+                                     float* dw, float* dbias, int B, int D, int H, int W, int N, float* workspace,
+                                     int64_t workspace_floats, micf_stream_t stream) {
   if (!dy || !x1 || !dw || (c2 > 0 && !x2) || !conv3_args_ok(B, D, H, W, N, c1, c2)) return MICF_EINVAL;
+  if (dy_layout == 0 && workspace) {   // 16 dy channels, channels-last: register-resident MFMA kernel (conv3_wgradx.hip)
+    const int rc = conv3_wgradx(dy, x1, c1, x2, c2, dw, dbias, B, D, H, W, N, workspace, workspace_floats, (hipStream_t)stream);
+    if (rc != MICF_EUNSUPPORTED) return rc;
+  }
   {   // direct LDS-tiled kernel for the shapes of the model (N = 16 offset conv, N = 8 out_conv)
     const int rc = conv3_wgrad_direct(dy, dy_layout, x1, c1, x2, c2, dw, dbias, B, D, H, W, N, (hipStream_t)stream);
     if (rc != MICF_EUNSUPPORTED) return rc;

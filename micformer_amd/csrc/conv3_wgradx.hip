@@ -1,0 +1,243 @@
+// conv3_wgradx.hip -- weight gradient of the 3x3x3 / pad 1 convolution with 16 output channels (conv_offset[0], MS.py:314)
+// on the matrix cores, with the WHOLE gradient slab of a workgroup resident in accumulator registers.
+//
+//   dW[n][c][tap] = sum_t dy[t, n] * in[t + off(tap), c]                 in = [x1 | x2], n < 16
+//
+// MFMA 16x16x4 fp32: rows i = 16 input channels, columns j = the 16 dy channels, k = 4 tokens.  A workgroup owns a slab of
+// 96 input channels x 27 taps = 162 (tap, channel tile) pairs -> 41 accumulator tiles (164 VGPRs) in each of its 4 waves,
+// and walks token tiles of 64 tokens: the input halo of the tile (all 96 channels, voxel stride 100 floats: the four k
+// lanes land on banks 0/16/32/48, conflict-free) is staged in LDS once, the dy fragment of a 16-token group is 4 registers,
+// and every MFMA then costs exactly one 4-byte LDS read.  Partial slabs go to a workspace with coalesced 16-byte stores
+// and a second kernel sums them over the workgroups and scatters into the [N][Cin][27] layout (+=).
+// The LDS-tiled VALU kernel this replaces (conv3_wgrad.hip) reached 28 TFLOP/s at the 32^3 x 2 stage.
+#include "common.h"
+
+namespace micf {
+
+constexpr int wCS = 96;                 // channels per slab (6 channel tiles)
+constexpr int wXS = 100;                // LDS voxel stride (floats)
+constexpr int wPairs = 27 * (wCS / 16); // 162 (tap, channel tile) pairs per slab
+constexpr int wTPW = (wPairs + 3) / 4;  // 41 accumulator tiles per wave
+constexpr int wSlabFloats = 4 * wTPW * 256;   // partial slab of one workgroup in the workspace (42 K floats)
+
+struct WgxArgs {
+  const float* dy;                      // channels-last [T, 16]
+  const float* x1; const float* x2; int c1, c2;
+  float* ws;                            // [slabs][groups][wSlabFloats]
+  float* bias_ws;                       // [groups][16]  (slab 0 only) or nullptr
+  int B, D, H, W, tiles_d, tiles_h, tiles_w, tiles_per_group, groups;
+};
+
+// TW: tile extent along w (16 or 8).  Tile = 1 (d) x 64/TW (h) x TW (w) = 64 tokens; a token group is 16/TW h-rows x TW.
+template <int TW>
+__global__ void __launch_bounds__(256) conv3_wgradx_kernel(WgxArgs a) {
+  constexpr int CH = 16 / TW, TH = 64 / TW;
+  constexpr int HH = TH + 2, HW = TW + 2, HALO = 3 * HH * HW;
+  extern __shared__ __attribute__((aligned(16))) float Xs[];           // [HALO][wXS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lr = lane >> 4;
+  const int slab = blockIdx.x, group = blockIdx.y;
+  const int Cin = a.c1 + a.c2;
+  const int cbase = slab * wCS;
+  const int64_t DHW = (int64_t)a.D * a.H * a.W;
+
+  f32x4 acc[wTPW];
+#pragma unroll
+  for (int p = 0; p < wTPW; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;                                                    // colsum(dy) partial of column li (wave 0 only)
+  int offs[wTPW];                                                      // LDS offset of (tap, channel tile) p of this wave
+#pragma unroll
+  for (int p = 0; p < wTPW; ++p) {
+    const int pair = min(wave * wTPW + p, wPairs - 1);                  // the 2 surplus tiles of wave 3 recompute the last pair
+    const int tap = pair / (wCS / 16), ct = pair % (wCS / 16);          // (never read back): no branch in the MFMA stream
+    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+    offs[p] = (((kd - 1) * HH + (kh - 1)) * HW + (kw - 1)) * wXS + ct * 16;
+  }
+
+  const int ntiles = a.B * a.tiles_d * a.tiles_h * a.tiles_w;
+  const int t_begin = group * a.tiles_per_group;
+  const int t_end = min(ntiles, t_begin + a.tiles_per_group);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    int q = tile;
+    const int tw = q % a.tiles_w; q /= a.tiles_w;
+    const int th = q % a.tiles_h; q /= a.tiles_h;
+    const int d0 = q % a.tiles_d; const int b = q / a.tiles_d;
+    const int h0 = th * TH, w0 = tw * TW;
+    __syncthreads();                                                   // previous tile fully consumed
+    // ---- stage the halo: HALO voxels x 24 float4 (channels cbase .. cbase+95 of [x1 | x2]), loads batched 16 deep
+    constexpr int NQ = HALO * (wCS / 4);
+    constexpr int NB = 16;
+    for (int base = 0; base < NQ; base += 256 * NB) {
+      float4 v[NB];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const int idx = base + u * 256 + tid;
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < NQ) {
+          const int hv = idx / (wCS / 4), g = idx % (wCS / 4);
+          const int hw = hv % HW, hh = (hv / HW) % HH, hd = hv / (HW * HH);
+          const int dd = d0 + hd - 1, yy = h0 + hh - 1, ww = w0 + hw - 1;
+          const int c = cbase + 4 * g;
+          if ((unsigned)dd < (unsigned)a.D && (unsigned)yy < (unsigned)a.H && (unsigned)ww < (unsigned)a.W && c < Cin) {
+            const int64_t tok = (int64_t)b * DHW + ((int64_t)dd * a.H + yy) * a.W + ww;
+            v[u] = c < a.c1 ? *reinterpret_cast<const float4*>(a.x1 + tok * a.c1 + c)
+                            : *reinterpret_cast<const float4*>(a.x2 + tok * a.c2 + (c - a.c1));
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const int idx = base + u * 256 + tid;
+        if (idx < NQ) *reinterpret_cast<float4*>(&Xs[(idx / (wCS / 4)) * wXS + 4 * (idx % (wCS / 4))]) = v[u];
+      }
+    }
+    // dy fragment of a 16-token group (k-permutation: in step s lane group lr supplies token j = 4*lr + s of the group);
+    // the fragment of group g+1 is fetched under the MFMAs of group g, the first one before the barrier
+    auto load_dy = [&](int g, float (&bv)[4]) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int j = 4 * lr + s;
+        const int yy = h0 + g * CH + j / TW, ww = w0 + j % TW;
+        bv[s] = 0.f;
+        if (g < 4 && yy < a.H && ww < a.W) bv[s] = a.dy[((int64_t)b * DHW + ((int64_t)d0 * a.H + yy) * a.W + ww) * 16 + li];
+      }
+    };
+    float bv[4], bn[4];
+    load_dy(0, bv);
+    __syncthreads();
+    // ---- 4 token groups of 16 tokens
+#pragma unroll 1
+    for (int g = 0; g < 4; ++g) {
+      load_dy(g + 1, bn);
+      int vox[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int j = 4 * lr + s;
+        const int lh = g * CH + j / TW, lw = j % TW;
+        vox[s] = ((1 * HH + lh + 1) * HW + lw + 1) * wXS + li;          // centre voxel of the token, + channel li
+      }
+      if (a.bias_ws && wave == 0) bsum += bv[0] + bv[1] + bv[2] + bv[3];
+      // s outer / pair inner: consecutive MFMAs hit different accumulators (no back-to-back dependency on one tile)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int p = 0; p < wTPW; ++p) {
+          acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(Xs[vox[s] + offs[p]], bv[s], acc[p], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) bv[s] = bn[s];
+    }
+  }
+  // ---- partial slab -> workspace: [(wave*TPW + p)][lane][4], 16-byte stores
+  float* out = a.ws + ((int64_t)slab * a.groups + group) * wSlabFloats;
+#pragma unroll
+  for (int p = 0; p < wTPW; ++p)
+    *reinterpret_cast<float4*>(out + ((wave * wTPW + p) * 64 + lane) * 4) = make_float4(acc[p][0], acc[p][1], acc[p][2], acc[p][3]);
+  if (a.bias_ws && slab == 0 && wave == 0) {
+    bsum += __shfl_xor(bsum, 16, 64);
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (lane < 16) a.bias_ws[group * 16 + lane] = bsum;
+  }
+}
+
+// dw[n][c][tap] += sum over the groups' partial slabs;  dbias[n] += sum of the groups' column sums.
+// Block = 64 slab elements x 4 slices of the group range (independent loads, unrolled), combined through LDS.
+__global__ void __launch_bounds__(256) conv3_wgradx_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ bias_ws,
+                                                                  float* __restrict__ dw, float* __restrict__ dbias, int Cin,
+                                                                  int slabs, int groups) {
+  __shared__ float red[256];
+  const int el = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int64_t id = (int64_t)blockIdx.x * 64 + el;
+  const int64_t per_slab = (int64_t)wPairs * 256;
+  const bool main = id < per_slab * slabs;
+  const bool bias = !main && bias_ws && dbias && id < per_slab * slabs + 16;
+  float acc = 0.f;
+  int slab = 0, e = 0;
+  if (main) {
+    slab = (int)(id / per_slab);
+    e = (int)(id % per_slab);
+    const float* p = ws + (int64_t)slab * groups * wSlabFloats + e;
+    int g = slice;
+    for (; g + 28 < groups; g += 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(g + 4 * u) * wSlabFloats];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; g < groups; g += 4) acc += p[(int64_t)g * wSlabFloats];
+  } else if (bias) {
+    const int n = (int)(id - per_slab * slabs);
+    for (int g = slice; g < groups; g += 4) acc += bias_ws[g * 16 + n];
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (slice != 0) return;
+  acc = red[el] + red[64 + el] + red[128 + el] + red[192 + el];
+  if (main) {
+    const int pair = e >> 8, lane = (e >> 2) & 63, v = e & 3;
+    const int tap = pair / (wCS / 16), ct = pair % (wCS / 16);
+    const int n = lane & 15, c = slab * wCS + ct * 16 + 4 * (lane >> 4) + v;
+    if (c < Cin) dw[((int64_t)n * Cin + c) * 27 + tap] += acc;
+  } else if (bias) {
+    dbias[(int)(id - per_slab * slabs)] += acc;
+  }
+}
+
+struct WgxPlan { int slabs, groups, tiles_per_group, tw; int64_t floats; };
+
+static WgxPlan wgx_plan(int B, int D, int H, int W, int Cin) {
+  WgxPlan p;
+  p.tw = W >= 12 ? 16 : 8;
+  const int th = 64 / p.tw;
+  const int ntiles = B * D * ((H + th - 1) / th) * ((W + p.tw - 1) / p.tw);
+  p.slabs = (Cin + wCS - 1) / wCS;
+  int groups = (256 + p.slabs - 1) / p.slabs;                 // ~one workgroup per CU (100+ KiB of LDS each)
+  if (groups > ntiles) groups = ntiles;
+  p.tiles_per_group = (ntiles + groups - 1) / groups;
+  p.groups = (ntiles + p.tiles_per_group - 1) / p.tiles_per_group;
+  p.floats = (int64_t)p.slabs * p.groups * wSlabFloats + (int64_t)p.groups * 16;
+  return p;
+}
+
+int64_t conv3_wgradx_workspace(int B, int D, int H, int W, int N, int c1, int c2) {
+  if (N != 16 || W < 8 || (c1 & 3) || (c2 & 3)) return 0;
+  return wgx_plan(B, D, H, W, c1 + c2).floats;
+}
+
+// MICF_EUNSUPPORTED when the shape / workspace is outside what this kernel covers (caller falls back).
+int conv3_wgradx(const float* dy, const float* x1, int c1, const float* x2, int c2, float* dw, float* dbias, int B, int D, int H,
+                 int W, int N, float* ws, int64_t ws_floats, hipStream_t stream) {
+  const int64_t need = conv3_wgradx_workspace(B, D, H, W, N, c1, c2);
+  if (need == 0 || !ws || ws_floats < need || !aligned16(ws) || !aligned16(dy) || !aligned16(x1) || (x2 && !aligned16(x2)))
+    return MICF_EUNSUPPORTED;
+  const WgxPlan p = wgx_plan(B, D, H, W, c1 + c2);
+  WgxArgs a{};
+  a.dy = dy; a.x1 = x1; a.x2 = x2 ? x2 : x1; a.c1 = c1; a.c2 = c2;
+  a.ws = ws; a.bias_ws = dbias ? ws + (int64_t)p.slabs * p.groups * wSlabFloats : nullptr;
+  a.B = B; a.D = D; a.H = H; a.W = W;
+  const int th = 64 / p.tw;
+  a.tiles_d = D; a.tiles_h = (H + th - 1) / th; a.tiles_w = (W + p.tw - 1) / p.tw;
+  a.tiles_per_group = p.tiles_per_group; a.groups = p.groups;
+  static bool attr_set = false;          // > 64 KiB of dynamic LDS needs the opt-in once per process
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgradx_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgradx_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+    attr_set = true;
+  }
+  const dim3 grid(p.slabs, p.groups);
+  if (p.tw == 16) {
+    constexpr int HALO = 3 * (4 + 2) * (16 + 2);
+    hipLaunchKernelGGL(conv3_wgradx_kernel<16>, grid, dim3(256), sizeof(float) * HALO * wXS, stream, a);
+  } else {
+    constexpr int HALO = 3 * (8 + 2) * (8 + 2);
+    hipLaunchKernelGGL(conv3_wgradx_kernel<8>, grid, dim3(256), sizeof(float) * HALO * wXS, stream, a);
+  }
+  if (hipGetLastError() != hipSuccess) return MICF_ELAUNCH;
+  const int64_t n = (int64_t)wPairs * 256 * p.slabs + 16;
+  hipLaunchKernelGGL(conv3_wgradx_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, stream, ws, a.bias_ws, dw, dbias,
+                     c1 + c2, p.slabs, p.groups);
+  return hipGetLastError() == hipSuccess ? MICF_OK : MICF_ELAUNCH;
+}
+
+}  // namespace micf

@@ -201,7 +201,10 @@ def conv3_bwd_weight(dy, x1, dw, dbias, dims, x2=None, ncdhw=False):
     c1 = x1.shape[-1]
     c2 = x2.shape[-1] if x2 is not None else 0
     N = dw.shape[0]
+    need = 0 if ncdhw else _lib.lib.micf_conv3_bwd_weight_workspace(B, D, H, W, N, c1, c2)
+    ws = scratch(dy.device, need) if need > 0 else None
     call("micf_conv3_bwd_weight", f32(dy), 1 if ncdhw else 0, f32(x1), c1, f32(x2), c2, f32(dw), f32(dbias), B, D, H, W, N,
+         f32(ws), ws.numel() if ws is not None else 0,
          cost=_cost(2 * B * D * H * W * 27 * (c1 + c2) * N, dy, x1, x2, dw))
 
 

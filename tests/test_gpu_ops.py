@@ -210,7 +210,9 @@ def test_window_attention(ops, dims, C, heads, ws):
                                                 # large enough token grids for the direct LDS-halo kernels (>= 32 tiles), ragged edges
                                                 ((2, 9, 10, 19), 24, 24, 16, False), ((1, 8, 16, 32), 48, 48, 16, False),
                                                 ((1, 16, 12, 20), 24, 0, 8, True), ((2, 7, 9, 17), 12, 0, 8, True),
-                                                ((1, 10, 16, 16), 24, 24, 16, False)])
+                                                ((1, 10, 16, 16), 24, 24, 16, False),
+                                                # two 96-channel slabs / the 8-wide tile of the MFMA data- and weight-gradient kernels
+                                                ((1, 8, 8, 8), 96, 96, 16, False), ((2, 4, 8, 9), 48, 48, 16, False)])
 def test_conv3(ops, dims, c1, c2, N, ncdhw):
     B, D, H, W = dims
     T = B * D * H * W

@@ -31,6 +31,8 @@ tot = t1 - t0
 print(f"step wall {tot/1e6:.3f} ms, kernels {len(step)}, sum of kernel time {sum(e-s for s,e,_ in step)/1e6:.3f} ms")
 for k in (0, 1, 2):
     print(f"  {k}{'+' if k == 2 else ' '} kernels in flight: {busy[k]/1e6:7.3f} ms ({100*busy[k]/tot:4.1f} %)")
+cnt = collections.Counter(re.sub(r"\(.*", "", n).replace("void ", "")[:60] for _, _, n in step)
+print("non-micf kernels in the step:", {k: v for k, v in cnt.items() if "micf" not in k})
 print("kernels running ALONE (ms):")
 for k, v in alone.most_common(25):
     print(f"  {v/1e6:7.3f}  {k}")

@@ -63,6 +63,15 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
 }
 
+// XCD-aware launch order.  The hardware deals workgroup ids round-robin over the 8 XCDs, each with its own 4 MiB L2.  Mapping
+// id -> (id % 8) * ceil(n / 8) + id / 8 makes CONSECUTIVE logical tiles (which share an operand panel: same tokens, next
+// feature tile) run on the SAME XCD, so the panel is fetched into one L2 instead of several (measured with FETCH_SIZE:
+// 9.3 -> 5.3 GB per step for the grouped weight gradients).  Launch ceil(n / 8) * 8 workgroups; ids >= n exit.
+__device__ __forceinline__ int xcd_order(int id, int n) {
+  const int per = (n + 7) >> 3;
+  return (id & 7) * per + (id >> 3);
+}
+
 // The 64 x 64 tile loop shared by the kernels of this core: acc[t] += P[i0.., r_begin..r_begin+16*nslab) * Q[.., j0..].
 // Ps / Qs are NS-deep rings of 4 KiB slab images.  csum (lanes of wave 0 when do_cs) gets the column sums of the Q slabs.
 // All waves of the workgroup must call it together (it contains barriers); on return every DMA of this wave has landed
@@ -157,12 +166,14 @@ __device__ __forceinline__ void dma_tile_loop(const DmaOperand& P, const DmaOper
 // clamped on load (their products are discarded by the epilogue bounds).
 template <bool PX, bool QX, class Epi, int NS>
 __global__ void __launch_bounds__(256) gemm_dma_kernel(DmaOperand P, DmaOperand Q, Epi epi, int I, int J, int R, int r_chunk,
-                                                       int tiles_i, float* colsum) {
+                                                       int tiles_i, int nblocks, float* colsum) {
   __shared__ __attribute__((aligned(1024))) float Ps[NS * 64 * kDmaBR];
   __shared__ __attribute__((aligned(1024))) float Qs[NS * 64 * kDmaBR];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lr = lane >> 4;
-  const int bi = blockIdx.x % tiles_i, bj = blockIdx.x / tiles_i;
+  const int bid = xcd_order(blockIdx.x, nblocks);
+  if (bid >= nblocks) return;
+  const int bi = bid % tiles_i, bj = bid / tiles_i;
   const int i0 = bi * 64, j0 = bj * 64;
   const int r_begin = blockIdx.y * r_chunk;
   const int r_end = (r_begin + r_chunk < R) ? r_begin + r_chunk : R;
@@ -216,12 +227,15 @@ __device__ __forceinline__ void wait_younger5(int younger) {  // 5 loads per sta
 }
 
 template <bool PX, class Epi>
-__global__ void __launch_bounds__(256) gemm_dma_skinny_kernel(DmaOperand P, DmaOperand Q, Epi epi, int I, int J, int R, int tiles_i) {
+__global__ void __launch_bounds__(256) gemm_dma_skinny_kernel(DmaOperand P, DmaOperand Q, Epi epi, int I, int J, int R, int tiles_i,
+                                                              int nblocks) {
   extern __shared__ __attribute__((aligned(1024))) float skinny_lds[];
   constexpr int NS = kSkinnyNS;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lr = lane >> 4;
-  const int bi = blockIdx.x % tiles_i, bj = blockIdx.x / tiles_i;
+  const int bid = xcd_order(blockIdx.x, nblocks);
+  if (bid >= nblocks) return;
+  const int bi = bid % tiles_i, bj = bid / tiles_i;
   const int i0 = bi * 64, j0 = bj * 16;
   // this wave's share of the R / 16 slabs
   const int total = R / kDmaBR, per = total / 4, extra = total % 4;
@@ -341,13 +355,13 @@ inline hipError_t launch_gemm_dma(DmaOperand P, DmaOperand Q, Epi epi, int I, in
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kSkinnyLds) != hipSuccess) return hipGetLastError();
         attr_done = true;
       }
-      hipLaunchKernelGGL((gemm_dma_skinny_kernel<PX, Epi>), dim3((unsigned)sblocks), dim3(256), kSkinnyLds, stream, P, Q, epi, I,
-                         (int)J, R, tiles_i);
+      hipLaunchKernelGGL((gemm_dma_skinny_kernel<PX, Epi>), dim3((unsigned)((sblocks + 7) / 8 * 8)), dim3(256), kSkinnyLds, stream,
+                         P, Q, epi, I, (int)J, R, tiles_i, (int)sblocks);
       return hipGetLastError();
     }
   }
-  hipLaunchKernelGGL((gemm_dma_kernel<PX, QX, Epi, kDmaNS>), dim3((unsigned)blocks, splits), dim3(256), 0, stream, P, Q, epi, I,
-                     (int)J, R, r_chunk, tiles_i, colsum);
+  hipLaunchKernelGGL((gemm_dma_kernel<PX, QX, Epi, kDmaNS>), dim3((unsigned)((blocks + 7) / 8 * 8), splits), dim3(256), 0, stream, P,
+                     Q, epi, I, (int)J, R, r_chunk, tiles_i, (int)blocks, colsum);
   return hipGetLastError();
 }
 

@@ -31,7 +31,10 @@ struct GArgs {
 __global__ void __launch_bounds__(256) wgrad_grouped_kernel(const GArgs g) {
   __shared__ __attribute__((aligned(1024))) float Ps[kDmaNS * 64 * kDmaBR];
   __shared__ __attribute__((aligned(1024))) float Qs[kDmaNS * 64 * kDmaBR];
-  const int w = blockIdx.x;
+  // XCD-aware order (gemm_dma.h): the tiles of one (layer, token split) read the same input / output-gradient rows
+  const int total = g.end[g.n - 1];
+  const int w = xcd_order(blockIdx.x, total);
+  if (w >= total) return;
   int k = 0;
   while (k < g.n - 1 && w >= g.end[k]) ++k;
   const GItem& it = g.it[k];
@@ -178,7 +181,7 @@ extern "C" int micf_linear_bwd_weight_grouped(const micf_wgrad_item* items, int 
         ++rg.n;
       }
     }
-    hipLaunchKernelGGL(wgrad_grouped_kernel, dim3(blocks), dim3(256), 0, s, g);
+    hipLaunchKernelGGL(wgrad_grouped_kernel, dim3((blocks + 7) / 8 * 8), dim3(256), 0, s, g);
     if (hipGetLastError() != hipSuccess) return MICF_ELAUNCH;
     if (rg.n > 0) {
       hipLaunchKernelGGL(wgrad_grouped_reduce_kernel, dim3(rblocks), dim3(256), 0, s, rg);

@@ -191,6 +191,17 @@ int micf_conv_up_bwd_data(const float* dy, const float* w, float* dx, int B, int
 int micf_conv_up_bwd_weight(const float* dy, const float* x, float* dw, float* dbias, int B, int D, int H, int W,
                             int C, int N, int k, micf_stream_t stream);
 
+/* ---- sliding-window inference plumbing (utils.py:226-234: monai.inferers.sliding_window_inference(roi, sw_batch_size,
+ * predictor, overlap), mode="constant"), one batch element, NCDHW fp32:
+ *   window:     win[c, z, y, x] = vol[c, z0+z, y0+y, x0+x]                  (the predictor's input crop)
+ *   accumulate: out[k, z0+z, y0+y, x0+x] += pred[k, z, y, x];  count[z0+z, y0+y, x0+x] += 1
+ *   normalize:  out[k, v] /= count[v]                                       (every voxel is covered at least once) */
+int micf_sw_window(const float* vol, float* win, int C, int D, int H, int W, int rd, int rh, int rw, int z0, int y0, int x0,
+                   micf_stream_t stream);
+int micf_sw_accumulate(const float* pred, float* out, float* count, int K, int D, int H, int W, int rd, int rh, int rw, int z0,
+                       int y0, int x0, micf_stream_t stream);
+int micf_sw_normalize(float* out, const float* count, int K, int64_t V, micf_stream_t stream);
+
 /* ---- zero-pad / crop of channels-last volumes (F.pad to window multiples MS.py:349-350,483; crop MS.py:399-400,497-498) */
 int micf_pad3d(const float* src, float* dst, int B, int D, int H, int W, int Dp, int Hp, int Wp, int C,
                micf_stream_t stream);

@@ -29,6 +29,9 @@ SIGNATURES = {
     "micf_head_tail_col2im": "pppiiiiiip",
     "micf_head_tail_im2col": "ppiiiiiip",
     "micf_head_tail_decompose": "pppppppppiiiip",
+    "micf_sw_window": "ppiiiiiiiiiip",
+    "micf_sw_accumulate": "pppiiiiiiiiiip",
+    "micf_sw_normalize": "ppilp",
     "micf_window_attn_fwd": "pippipiiiiiiiiiifp",
     "micf_window_attn_bwd": "pippipipippiiiiiiiiiifp",
     "micf_conv3_fwd": "pipipppiiiiiip",

@@ -53,6 +53,36 @@ __global__ void __launch_bounds__(256) resize_kernel(const float* __restrict__ a
   }
 }
 
+
+// ---- sliding-window inference (utils.py:226-234: monai sliding_window_inference, mode="constant"): accumulate one window's
+// logits into the full-volume fp32 sum and bump the per-voxel visit count; then out = sum / count.
+__global__ void __launch_bounds__(256) sw_window_kernel(const float* __restrict__ vol, float* __restrict__ win, int C, int D, int H,
+                                                        int W, int rd, int rh, int rw, int z0, int y0, int x0, int64_t total) {
+  // win[c, z, y, x] = vol[c, z0+z, y0+y, x0+x]   (one batch element; NCDHW)
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int x = (int)(i % rw); int64_t r = i / rw;
+    const int y = (int)(r % rh); r /= rh;
+    const int z = (int)(r % rd); const int c = (int)(r / rd);
+    win[i] = vol[(((int64_t)c * D + z0 + z) * H + y0 + y) * W + x0 + x];
+  }
+}
+__global__ void __launch_bounds__(256) sw_accumulate_kernel(const float* __restrict__ pred, float* __restrict__ out,
+                                                            float* __restrict__ count, int K, int D, int H, int W, int rd, int rh,
+                                                            int rw, int z0, int y0, int x0, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int x = (int)(i % rw); int64_t r = i / rw;
+    const int y = (int)(r % rh); r /= rh;
+    const int z = (int)(r % rd); const int k = (int)(r / rd);
+    const int64_t v = ((int64_t)(z0 + z) * H + y0 + y) * W + x0 + x;
+    out[(int64_t)k * D * H * W + v] += pred[i];
+    if (k == 0) count[v] += 1.f;
+  }
+}
+__global__ void __launch_bounds__(256) sw_normalize_kernel(float* __restrict__ out, const float* __restrict__ count, int64_t V,
+                                                           int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) out[i] /= count[i % V];
+}
+
 }  // namespace micf
 using namespace micf;
 
@@ -99,5 +129,32 @@ extern "C" int micf_resize_trilinear_bwd(const float* ddst, float* dsrc, int B, 
   if (hipMemsetAsync(dsrc, 0, sizeof(float) * (size_t)B * D * H * W * C, s) != hipSuccess) return MICF_ELAUNCH;
   const int64_t total = (int64_t)B * Do * Ho * Wo * C;
   hipLaunchKernelGGL(resize_kernel<true>, dim3(grid_for(total)), dim3(256), 0, s, ddst, dsrc, B, D, H, W, Do, Ho, Wo, C, total);
+  MICF_RETURN_LAUNCH();
+}
+
+extern "C" int micf_sw_window(const float* vol, float* win, int C, int D, int H, int W, int rd, int rh, int rw, int z0, int y0,
+                              int x0, micf_stream_t stream) {
+  if (!vol || !win || C <= 0 || rd <= 0 || rh <= 0 || rw <= 0 || z0 < 0 || y0 < 0 || x0 < 0 || z0 + rd > D || y0 + rh > H ||
+      x0 + rw > W)
+    return MICF_EINVAL;
+  const int64_t total = (int64_t)C * rd * rh * rw;
+  hipLaunchKernelGGL(sw_window_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, vol, win, C, D, H, W, rd, rh, rw, z0,
+                     y0, x0, total);
+  MICF_RETURN_LAUNCH();
+}
+extern "C" int micf_sw_accumulate(const float* pred, float* out, float* count, int K, int D, int H, int W, int rd, int rh, int rw,
+                                  int z0, int y0, int x0, micf_stream_t stream) {
+  if (!pred || !out || !count || K <= 0 || rd <= 0 || rh <= 0 || rw <= 0 || z0 < 0 || y0 < 0 || x0 < 0 || z0 + rd > D ||
+      y0 + rh > H || x0 + rw > W)
+    return MICF_EINVAL;
+  const int64_t total = (int64_t)K * rd * rh * rw;
+  hipLaunchKernelGGL(sw_accumulate_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, pred, out, count, K, D, H, W, rd,
+                     rh, rw, z0, y0, x0, total);
+  MICF_RETURN_LAUNCH();
+}
+extern "C" int micf_sw_normalize(float* out, const float* count, int K, int64_t V, micf_stream_t stream) {
+  if (!out || !count || K <= 0 || V <= 0) return MICF_EINVAL;
+  const int64_t total = (int64_t)K * V;
+  hipLaunchKernelGGL(sw_normalize_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, out, count, V, total);
   MICF_RETURN_LAUNCH();
 }

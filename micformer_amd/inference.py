@@ -1,0 +1,68 @@
+"""Sliding-window inference on the device -- the counterpart of `monai.inferers.sliding_window_inference` as the reference
+calls it (utils.py:226-240: roi 128^3, sw_batch_size 1, overlap 0.5, default mode "constant", under autocast / no_grad).
+
+MONAI is not vendored under /root/reference (un-pinned dependency), so the algorithm is restated from its documentation:
+scan interval int(roi * (1 - overlap)) per axis, ceil((L - roi) / interval) + 1 windows with starts min(k * interval, L - roi),
+symmetric zero padding when the image is smaller than the ROI, constant importance map, output = sum(pred) / count in fp32.
+The referee is oracle/micformer_ref.py::sliding_window_inference (parity with MONAI itself is UNPINNED).
+
+The full-volume fp32 accumulator (8 x 512 x 512 x 256 = 2.1 GB for BASELINE config 5) and the visit counts stay in HBM; window
+crops, the accumulate and the final divide are HIP kernels (csrc/misc.hip); the predictor sees `sw_batch_size` windows per
+call -- the network is batch-independent, so any sw_batch_size gives the same result and large ones fill the GPU better.
+"""
+import math
+
+import torch
+
+from . import _lib
+from ._lib import call, f32
+
+
+def sliding_window_starts(L, roi, overlap=0.5):
+    if L <= roi:
+        return [0]
+    interval = max(int(roi * (1 - overlap)), 1)
+    n = int(math.ceil((L - roi) / interval)) + 1
+    return [min(k * interval, L - roi) for k in range(n)]
+
+
+def sliding_window_inference(inputs, roi_size, sw_batch_size, predictor, overlap=0.5, mode="constant"):
+    """inputs (B, C, D, H, W) on the GPU -> (B, K, D, H, W) fp32, K = the predictor's output channels."""
+    if mode != "constant":
+        raise NotImplementedError("only MONAI's default mode='constant' (what utils.py:228-234 uses) is implemented")
+    if inputs.dim() != 5 or not inputs.is_cuda:
+        raise ValueError("sliding_window_inference expects a (B, C, D, H, W) CUDA (ROCm) tensor")
+    if isinstance(roi_size, int):
+        roi_size = (roi_size,) * 3
+    rd, rh, rw = (int(r) for r in roi_size)
+    x = inputs.float().contiguous()
+    B, C, D, H, W = x.shape
+    pd, ph, pw = max(rd - D, 0), max(rh - H, 0), max(rw - W, 0)
+    if pd or ph or pw:       # image smaller than the ROI: symmetric zero padding, cropped away again at the end
+        x = torch.nn.functional.pad(x, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2, pd // 2, pd - pd // 2)).contiguous()
+    Dp, Hp, Wp = x.shape[2:]
+    V = Dp * Hp * Wp
+    slices = [(b, z, y, xx) for z in sliding_window_starts(Dp, rd, overlap) for y in sliding_window_starts(Hp, rh, overlap)
+              for xx in sliding_window_starts(Wp, rw, overlap) for b in range(B)]
+    sw = max(int(sw_batch_size), 1)
+    out = count = None
+    with torch.no_grad():
+        for i in range(0, len(slices), sw):
+            chunk = slices[i:i + sw]
+            win = torch.empty((len(chunk), C, rd, rh, rw), dtype=torch.float32, device=x.device)
+            for n, (b, z, y, xx) in enumerate(chunk):
+                call("micf_sw_window", f32(x[b]), f32(win[n]), C, Dp, Hp, Wp, rd, rh, rw, z, y, xx)
+            pred = predictor(win).float().contiguous()
+            if pred.shape[0] != len(chunk) or tuple(pred.shape[2:]) != (rd, rh, rw):
+                raise ValueError(f"predictor returned {tuple(pred.shape)} for windows {tuple(win.shape)}")
+            if out is None:
+                K = pred.shape[1]
+                out = torch.zeros((B, K, Dp, Hp, Wp), dtype=torch.float32, device=x.device)
+                count = torch.zeros((B, Dp, Hp, Wp), dtype=torch.float32, device=x.device)
+            for n, (b, z, y, xx) in enumerate(chunk):
+                call("micf_sw_accumulate", f32(pred[n]), f32(out[b]), f32(count[b]), K, Dp, Hp, Wp, rd, rh, rw, z, y, xx)
+        for b in range(B):
+            call("micf_sw_normalize", f32(out[b]), f32(count[b]), K, V)
+    if pd or ph or pw:
+        out = out[:, :, pd // 2:pd // 2 + D, ph // 2:ph // 2 + H, pw // 2:pw // 2 + W].contiguous()
+    return out

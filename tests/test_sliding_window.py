@@ -75,7 +75,9 @@ def test_tiny_head_as_predictor_matches_oracle():
         want = R.sliding_window_inference(x, lambda w: R.head_forward(P, w, cfg), roi=(32, 32, 32), overlap=0.5)
         with torch.autocast("cuda", dtype=torch.float16):            # utils.py:236-238 runs the predictor under autocast
             got = sliding_window_inference(x.cuda(), (32, 32, 32), 4, head, overlap=0.5)
+            got_g = sliding_window_inference(x.cuda(), (32, 32, 32), 3, head, overlap=0.5, graph=True)   # HIP-graph replayed predictor
     assert got.shape == want.shape
+    assert float((got_g - got).abs().max()) <= 1e-5
     assert float((got.cpu() - want).abs().max()) <= 1e-4
     assert torch.equal(got.argmax(1).cpu(), want.argmax(1)) or \
         float((got.argmax(1).cpu() != want.argmax(1)).float().mean()) < 1e-3

@@ -123,6 +123,69 @@ class TrainEngine:
             sl = self._step_impl(sx, st) if self.world == 1 else self._fwd_bwd(sx, st)
         self._graph, self._static = g, (sx, st, sl)
 
+    # ------------------------------------------------------------------ checkpoints (utils.py:57-65, 108-138)
+    def optimizer_state_dict(self):
+        """State of the fused Adam in `torch.optim.Adam.state_dict()` layout (what train.py:233-241 saves under 'optimizer'),
+        so a checkpoint written here resumes under the reference's optimizer and vice versa."""
+        step = int(self.adam_state[0].item())
+        state = {}
+        if step > 0:
+            for i, (o, n, p) in enumerate(zip(self.offsets, self.sizes, self.params)):
+                state[i] = {"step": torch.tensor(float(step)), "exp_avg": self.flat_m[o:o + n].view(p.shape).clone(),
+                            "exp_avg_sq": self.flat_v[o:o + n].view(p.shape).clone()}
+        group = {"lr": self.lr() if step > 0 else self.base_lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0,
+                 "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+                 "fused": None, "initial_lr": self.base_lr, "params": list(range(len(self.params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, sd):
+        steps = {int(float(v["step"])) for v in sd["state"].values()}
+        if len(steps) > 1:
+            raise ValueError("per-parameter Adam step counts differ; the fused optimizer keeps one")
+        with torch.no_grad():
+            self.flat_m.zero_()
+            self.flat_v.zero_()
+            for i, st in sd["state"].items():
+                o, n = self.offsets[int(i)], self.sizes[int(i)]
+                self.flat_m[o:o + n].copy_(st["exp_avg"].reshape(-1))
+                self.flat_v[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+            self.adam_state[0] = steps.pop() if steps else 0
+        g = sd["param_groups"][0]
+        self.betas, self.eps = tuple(g["betas"]), g["eps"]
+        self.base_lr = g.get("initial_lr", self.base_lr)
+        self._graph = None                                      # betas / eps / lr constants are baked into a captured step
+
+    def scheduler_state_dict(self):
+        """CosineAnnealingLR.state_dict() layout (stepped once per iteration, train.py:148, 206-207)."""
+        step = int(self.adam_state[0].item())
+        return {"T_max": self.t_max, "eta_min": self.eta_min, "base_lrs": [self.base_lr], "last_epoch": step,
+                "_step_count": step + 1, "_last_lr": [self.lr() if step > 0 else self.base_lr]}
+
+    def load_scheduler_state_dict(self, sd):
+        self.t_max, self.eta_min = sd["T_max"], sd["eta_min"]
+        self.base_lr = sd["base_lrs"][0]
+        self._graph = None
+
+    def checkpoint(self, epoch):
+        """The dict the reference writes with torch.save (train.py:233-241): epoch, state_dict, optimizer, scheduler."""
+        return {"epoch": epoch, "state_dict": {k: v.detach().clone() for k, v in self.model.state_dict().items()},
+                "optimizer": self.optimizer_state_dict(), "scheduler": self.scheduler_state_dict()}
+
+    def load_checkpoint(self, ckpt):
+        """Counterpart of utils.reload_ckpt (utils.py:108-122).  Parameters stay views of the flat buffer."""
+        with torch.no_grad():
+            own = self.model.state_dict()
+            missing = set(own) ^ set(ckpt["state_dict"])
+            if missing:
+                raise KeyError(f"state_dict keys differ: {sorted(missing)[:5]} ...")
+            for k, v in ckpt["state_dict"].items():
+                own[k].copy_(v)
+        if "optimizer" in ckpt:
+            self.load_optimizer_state_dict(ckpt["optimizer"])
+        if "scheduler" in ckpt:
+            self.load_scheduler_state_dict(ckpt["scheduler"])
+        return ckpt.get("epoch", 0)
+
     # ------------------------------------------------------------------ helpers
     def lr(self):
         st = self.adam_state.cpu()

@@ -278,6 +278,44 @@ def test_two_train_steps_against_reference(M):
         close(sub(sd[n]), g["w2." + n], atol=2e-6, rtol=0, what="w2." + n)
 
 
+def test_checkpoint_round_trip_and_resume(M, tmp_path):
+    """the checkpoint dict of train.py:233-241 / utils.py:57-65,108-138 ({'epoch','state_dict','optimizer',
+    'scheduler'}, torch.save).  (1) resume: 1 step + save + load into a fresh engine + 2 steps == 3 steps straight;
+    (2) the 'optimizer' entry loads into a real torch.optim.Adam over the same parameters (reference-side resume);
+    (3) state_dict keys are the reference's (golden key list)."""
+    from micformer_amd.engine import TrainEngine
+    x = fill.make_volume(1, 32, 32, 32).cuda()
+    t = fill.one_hot(fill.make_label_map(1, 32, 32, 32)).cuda()
+    mk = lambda: TrainEngine(build_head(M, 24, (1, 1, 1, 1)), base_lr=1e-3, t_max=7, use_graph=False)
+    a = mk()
+    for _ in range(3):
+        a.step(x, t)
+    b = mk()
+    b.step(x, t)
+    path = str(tmp_path / "model_best.pth.tar")
+    torch.save(b.checkpoint(epoch=5), path)
+    ck = torch.load(path, map_location="cuda", weights_only=False)
+    with open(os.path.join(G, "state_dict_tiny.json")) as f:
+        assert list(ck["state_dict"]) == [k for k, _ in json.load(f)["keys"]]          # the reference's keys, in its order
+    c = mk()
+    assert c.load_checkpoint(ck) == 5
+    for _ in range(2):
+        c.step(x, t)
+    sa, sc = a.model.state_dict(), c.model.state_dict()
+    for k in sa:
+        fin = torch.isfinite(sa[k])
+        assert torch.equal(fin, torch.isfinite(sc[k])), k
+        close(torch.where(fin, sc[k], torch.zeros_like(sc[k])), torch.where(fin, sa[k], torch.zeros_like(sa[k])), atol=1e-6, rtol=1e-5, what=k)
+    # reference-side resume: torch.optim.Adam accepts the optimizer entry and sees the same moments
+    opt = torch.optim.Adam(c.model.parameters(), lr=1e-3)
+    osd = b.optimizer_state_dict()
+    opt.load_state_dict(osd)
+    st = opt.state_dict()["state"]
+    assert len(st) == len(b.params) and float(st[0]["step"]) == 1.0
+    for i in (0, 3, len(b.params) - 1):          # (the tiny 32^3 config has NaN gradients at its 1^3 stage, as the reference)
+        torch.testing.assert_close(st[i]["exp_avg"], osd["state"][i]["exp_avg"], rtol=0, atol=0, equal_nan=True)
+
+
 def test_base_128_properties_full_size(M):
     """BASELINE's full size (base, 128^3, batch 2): size-independent properties instead of an oracle run --
     batch independence (sample b of a batch == the same sample alone) and determinism of the forward."""

@@ -220,6 +220,12 @@ int micf_dice_bce_fwd(const float* logits, const float* target, double* sums, fl
                       micf_stream_t stream);
 int micf_dice_bce_bwd(const float* logits, const float* target, const double* sums, const float* grad_out,
                       float* dlogits, int B, int K, int64_t V, micf_stream_t stream);
+/* Same loss with the target given as the uint8 class map [B, V] the one-hot planes are expanded from (train.py:177):
+ * t[b, k, v] = (label[b, v] == k).  8x fewer target bytes in HBM and over PCIe. */
+int micf_dice_bce_label_fwd(const float* logits, const uint8_t* label, double* sums, float* loss, int B, int K, int64_t V,
+                            micf_stream_t stream);
+int micf_dice_bce_label_bwd(const float* logits, const uint8_t* label, const double* sums, const float* grad_out,
+                            float* dlogits, int B, int K, int64_t V, micf_stream_t stream);
 /* meandice of argmax masks (train.py:392-407, :305): classes 1..K-1, smooth 1e-6, batch-joint.
  * counts [3*K] int64 scratch (zero-filled by the call); label is the integer class map [B,V] (uint8); out [1] double. */
 int micf_argmax_meandice(const float* logits, const uint8_t* label, uint8_t* mask_out, int64_t* counts, double* out,

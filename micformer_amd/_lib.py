@@ -58,6 +58,8 @@ SIGNATURES = {
     "micf_resize_trilinear_bwd": "ppiiiiiiiip",
     "micf_dice_bce_fwd": "ppppiilp",
     "micf_dice_bce_bwd": "pppppiilp",
+    "micf_dice_bce_label_fwd": "ppppiilp",
+    "micf_dice_bce_label_bwd": "pppppiilp",
     "micf_argmax_meandice": "pppppiilp",
     "micf_adam_tick": "pddlp",
     "micf_adam_step": "pppplpfffp",

@@ -5,18 +5,22 @@
 namespace micf {
 
 // ---- loss forward: per (b, channel) plane partial sums {sum p t, sum p^2, sum t^2, sum bce} -> double atomics
-__global__ void __launch_bounds__(256) dice_bce_partial_kernel(const float* __restrict__ z, const float* __restrict__ t,
+// Target: one-hot float planes [B, K, V] (what train.py:177 feeds) or, LABEL, the uint8 class map [B, V] it was expanded from
+// (t = label == channel): 8x fewer target bytes in HBM and over PCIe.
+template <bool LABEL>
+__global__ void __launch_bounds__(256) dice_bce_partial_kernel(const float* __restrict__ z, const void* __restrict__ tv,
                                                                double* __restrict__ sums, int K, int64_t V, int chunks) {
   const int plane = blockIdx.y;             // b*K + ch
   const int ch = plane % K;
   const int64_t per = (V + chunks - 1) / chunks;
   const int64_t v0 = blockIdx.x * per, v1 = (v0 + per < V) ? v0 + per : V;
   const float* zp = z + (int64_t)plane * V;
-  const float* tp = t + (int64_t)plane * V;
+  const float* tp = static_cast<const float*>(tv) + (int64_t)plane * V;
+  const uint8_t* lp8 = static_cast<const uint8_t*>(tv) + (int64_t)(plane / K) * V;
   float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
   for (int64_t i = v0 + threadIdx.x; i < v1; i += 256) {
     const float p = 1.0f / (1.0f + expf(-zp[i]));          // torch.sigmoid
-    const float tt = tp[i];
+    const float tt = LABEL ? (lp8[i] == ch ? 1.f : 0.f) : tp[i];
     a += p * tt; b += p * p; c += tt * tt;
     // nn.BCELoss on the sigmoid output: log clamped at -100
     const float lp = fmaxf(logf(p), -100.f), lq = fmaxf(logf(1.0f - p), -100.f);
@@ -44,7 +48,8 @@ __global__ void dice_bce_final_kernel(const double* __restrict__ sums, float* __
   *loss = (float)((0.7 * dice + 0.3 * ce) / K);
 }
 
-__global__ void __launch_bounds__(256) dice_bce_bwd_kernel(const float* __restrict__ z, const float* __restrict__ t,
+template <bool LABEL>
+__global__ void __launch_bounds__(256) dice_bce_bwd_kernel(const float* __restrict__ z, const void* __restrict__ tv,
                                                            const double* __restrict__ sums, const float* __restrict__ gout,
                                                            float* __restrict__ dz, int K, int64_t V, double count) {
   const int plane = blockIdx.y;
@@ -55,9 +60,11 @@ __global__ void __launch_bounds__(256) dice_bce_bwd_kernel(const float* __restri
   const float cd = g * 0.7f / (float)K, cb = g * 0.3f / (float)K / (float)count;
   const float inv_den2 = 1.0f / (den * den);
   const int64_t base = (int64_t)plane * V;
+  const float* t = static_cast<const float*>(tv);
+  const uint8_t* l8 = static_cast<const uint8_t*>(tv) + (int64_t)(plane / K) * V;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < V; i += (int64_t)gridDim.x * 256) {
     const float p = 1.0f / (1.0f + expf(-z[base + i]));
-    const float tt = t[base + i];
+    const float tt = LABEL ? (l8[i] == ch ? 1.f : 0.f) : t[base + i];
     // d(1 - (2I+1)/den)/dp = -(2 t den - (2I+1) 2 p)/den^2 ;  dBCE/dp = (p - t)/max(p(1-p), 1e-12)  (ATen)
     const float ddice = -(2.0f * tt * den - I2 * 2.0f * p) * inv_den2;
     const float dbce = (p - tt) / fmaxf((1.0f - p) * p, 1e-12f);
@@ -143,25 +150,43 @@ __global__ void __launch_bounds__(256) adam_step_kernel(float* __restrict__ p, c
 }  // namespace micf
 using namespace micf;
 
-extern "C" int micf_dice_bce_fwd(const float* logits, const float* target, double* sums, float* loss, int B, int K, int64_t V,
-                                 micf_stream_t stream) {
+static int dice_fwd(const float* logits, const void* target, bool label, double* sums, float* loss, int B, int K, int64_t V,
+                    hipStream_t s) {
   if (!logits || !target || !sums || !loss || B <= 0 || K <= 0 || V <= 0) return MICF_EINVAL;
-  hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(sums, 0, sizeof(double) * 4 * K, s) != hipSuccess) return MICF_ELAUNCH;
   int chunks = (int)((V + 32767) / 32768);
-  hipLaunchKernelGGL(dice_bce_partial_kernel, dim3(chunks, B * K), dim3(256), 0, s, logits, target, sums, K, V, chunks);
+  if (label) hipLaunchKernelGGL(dice_bce_partial_kernel<true>, dim3(chunks, B * K), dim3(256), 0, s, logits, target, sums, K, V, chunks);
+  else hipLaunchKernelGGL(dice_bce_partial_kernel<false>, dim3(chunks, B * K), dim3(256), 0, s, logits, target, sums, K, V, chunks);
   hipLaunchKernelGGL(dice_bce_final_kernel, dim3(1), dim3(64), 0, s, sums, loss, K, (double)B * (double)V);
   MICF_RETURN_LAUNCH();
 }
-
-extern "C" int micf_dice_bce_bwd(const float* logits, const float* target, const double* sums, const float* grad_out,
-                                 float* dlogits, int B, int K, int64_t V, micf_stream_t stream) {
+static int dice_bwd(const float* logits, const void* target, bool label, const double* sums, const float* grad_out, float* dlogits,
+                    int B, int K, int64_t V, hipStream_t s) {
   if (!logits || !target || !sums || !dlogits || B <= 0 || K <= 0 || V <= 0) return MICF_EINVAL;
   int bx = (int)((V + 256 * 8 - 1) / (256 * 8));
   if (bx > 4096) bx = 4096;
-  hipLaunchKernelGGL(dice_bce_bwd_kernel, dim3(bx, B * K), dim3(256), 0, (hipStream_t)stream, logits, target, sums, grad_out,
-                     dlogits, K, V, (double)B * (double)V);
+  if (label) hipLaunchKernelGGL(dice_bce_bwd_kernel<true>, dim3(bx, B * K), dim3(256), 0, s, logits, target, sums, grad_out, dlogits, K, V, (double)B * (double)V);
+  else hipLaunchKernelGGL(dice_bce_bwd_kernel<false>, dim3(bx, B * K), dim3(256), 0, s, logits, target, sums, grad_out, dlogits, K, V, (double)B * (double)V);
   MICF_RETURN_LAUNCH();
+}
+
+extern "C" int micf_dice_bce_fwd(const float* logits, const float* target, double* sums, float* loss, int B, int K, int64_t V,
+                                 micf_stream_t stream) {
+  return dice_fwd(logits, target, false, sums, loss, B, K, V, (hipStream_t)stream);
+}
+extern "C" int micf_dice_bce_bwd(const float* logits, const float* target, const double* sums, const float* grad_out,
+                                 float* dlogits, int B, int K, int64_t V, micf_stream_t stream) {
+  return dice_bwd(logits, target, false, sums, grad_out, dlogits, B, K, V, (hipStream_t)stream);
+}
+extern "C" int micf_dice_bce_label_fwd(const float* logits, const uint8_t* label, double* sums, float* loss, int B, int K, int64_t V,
+                                       micf_stream_t stream) {
+  if (K > 255) return MICF_EUNSUPPORTED;
+  return dice_fwd(logits, label, true, sums, loss, B, K, V, (hipStream_t)stream);
+}
+extern "C" int micf_dice_bce_label_bwd(const float* logits, const uint8_t* label, const double* sums, const float* grad_out,
+                                       float* dlogits, int B, int K, int64_t V, micf_stream_t stream) {
+  if (K > 255) return MICF_EUNSUPPORTED;
+  return dice_bwd(logits, label, true, sums, grad_out, dlogits, B, K, V, (hipStream_t)stream);
 }
 
 extern "C" int micf_argmax_meandice(const float* logits, const uint8_t* label, uint8_t* mask_out, int64_t* counts, double* out,

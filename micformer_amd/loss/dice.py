@@ -11,6 +11,13 @@ from .. import functional as Fn
 from .. import ops
 
 
+def _as_target(inputs, target):
+    """float one-hot planes stay as they are; an integer class map (one dim fewer, or a singleton channel) becomes uint8."""
+    if not target.is_floating_point() and (target.dim() == inputs.dim() - 1 or target.shape[1] == 1 != inputs.shape[1]):
+        return target.reshape((target.shape[0],) + tuple(inputs.shape[2:])).to(torch.uint8)
+    return target.float()
+
+
 class MDiceLoss(nn.Module):
     def __init__(self, do_sigmoid=True):
         super().__init__()
@@ -20,7 +27,9 @@ class MDiceLoss(nn.Module):
         self.labels = ['backgroud', 'CT-A', 'CT-B', 'CT-C', 'CT-D', 'CT-E', 'CT-F', 'CT-G']
 
     def forward(self, inputs, target):
-        return Fn.DiceBCEFn.apply(inputs.float(), target.float())
+        """target: one-hot float planes (B, K, D, H, W) as the reference feeds (train.py:177), or -- extension -- the integer
+        class map (B, D, H, W) / (B, 1, D, H, W) they are expanded from (uint8 on the wire: 8x fewer bytes)."""
+        return Fn.DiceBCEFn.apply(inputs.float(), _as_target(inputs, target))
 
     def metric(self, inputs, target):
         """Thresholded-sigmoid per-class Dice per sample (dice.py:168-175, binary_dice metric_mode)."""
@@ -42,7 +51,7 @@ class MDiceLoss_Val(MDiceLoss):
     """Validation loss = the Dice part only (dice.py:216-221); computed from the same fused sums."""
 
     def forward(self, inputs, target):
-        inputs, target = inputs.float().contiguous(), target.float().contiguous()
+        inputs, target = inputs.float().contiguous(), _as_target(inputs, target).contiguous()
         _, sums = ops.dice_bce_fwd(inputs, target)
         s = sums.reshape(-1, 4)
         dice = 1.0 - (2.0 * s[:, 0] + 1.0) / (s[:, 1] + s[:, 2] + 1.0)

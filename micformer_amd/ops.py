@@ -391,8 +391,12 @@ def dice_bce_fwd(logits, target):
     V = logits[0, 0].numel()
     sums = _new(logits, K * 4, dtype=torch.float64)
     loss = _new(logits, 1)
-    call("micf_dice_bce_fwd", f32(logits), f32(target), ptr(sums), f32(loss), B, K, V,
-         cost=_cost(30 * logits.numel(), logits, target))
+    if target.dtype == torch.uint8:        # class map [B, ...] instead of one-hot planes [B, K, ...]
+        call("micf_dice_bce_label_fwd", f32(logits), ptr(target), ptr(sums), f32(loss), B, K, V,
+             cost=_cost(30 * logits.numel(), logits, target))
+    else:
+        call("micf_dice_bce_fwd", f32(logits), f32(target), ptr(sums), f32(loss), B, K, V,
+             cost=_cost(30 * logits.numel(), logits, target))
     return loss, sums
 
 
@@ -400,7 +404,8 @@ def dice_bce_bwd(logits, target, sums, grad_out):
     B, K = logits.shape[:2]
     V = logits[0, 0].numel()
     dz = torch.empty_like(logits)
-    call("micf_dice_bce_bwd", f32(logits), f32(target), ptr(sums), f32(grad_out), f32(dz), B, K, V,
+    name = "micf_dice_bce_label_bwd" if target.dtype == torch.uint8 else "micf_dice_bce_bwd"
+    call(name, f32(logits), ptr(target), ptr(sums), f32(grad_out), f32(dz), B, K, V,
          cost=_cost(30 * logits.numel(), logits, target, dz))
     return dz
 

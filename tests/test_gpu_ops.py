@@ -404,6 +404,25 @@ def test_dice_bce_against_reference_golden(ops):
     close(MDiceLoss_Val()(dev(z), dev(t)), torch.from_numpy(g["val_loss"]), atol=2e-6, what="val loss")
 
 
+def test_dice_bce_from_class_map(ops):
+    """uint8 class-map target == one-hot float target (forward loss, sums and gradient), incl. the nn.Module front end."""
+    from micformer_amd.loss.dice import MDiceLoss, MDiceLoss_Val
+    B, K, D = 2, 8, 20
+    z = rnd(B, K, D, D, D, seed=3, scale=2.0)
+    lab = fill.make_label_map(B, D, D, D, K)
+    onehot = fill.one_hot(lab, K)
+    zc = dev(z).requires_grad_(True)
+    zo = dev(z).requires_grad_(True)
+    l_map = MDiceLoss()(zc, dev(lab))                  # int64 (B, D, H, W) -> uint8 inside
+    l_hot = MDiceLoss()(zo, dev(onehot))
+    l_map.backward(); l_hot.backward()
+    assert float((l_map - l_hot).detach().abs()) <= 1e-7
+    close(zc.grad, zo.grad, atol=1e-9, rtol=1e-6, what="dlogits from class map")
+    close(MDiceLoss_Val()(zc.detach(), dev(lab).unsqueeze(1)), MDiceLoss_Val()(zo.detach(), dev(onehot)), atol=1e-7, what="val loss")
+    want = R.mdice_loss(z, onehot)
+    close(l_map.reshape(()), want.reshape(()), atol=2e-6, what="loss vs oracle")
+
+
 def test_dice_bce_larger(ops):
     z = rnd(2, 8, 12, 10, 14, seed=1) * 3
     t = fill.one_hot(fill.make_label_map(2, 12, 10, 14))

@@ -50,7 +50,27 @@ class TrainEngine:
             raise RuntimeError("TrainEngine needs the model on a CUDA (ROCm) device")
         sizes = [p.numel() for p in params]
         # 4-element (16 B) alignment of every tensor so kernels can use 16-byte accesses on parameter views
-        offs, total = flatten_views(params)
+        # Flat order = model order, except that every self-attention's q.weight | kv.weight and q.bias | kv.bias are made
+        # neighbours, so the two projections (same input) run as ONE [3C, C] GEMM (functional._packed_qkv).
+        names = [n for n, _ in self.model.named_parameters()]
+        pos = {n: i for i, n in enumerate(names)}
+        order, seen = [], set()
+        for i, n in enumerate(names):
+            if i in seen:
+                continue
+            if n.endswith("self_attn.q.weight"):
+                base = n[:-len("q.weight")]
+                group = [pos.get(base + k) for k in ("q.weight", "kv.weight", "q.bias", "kv.bias")]
+                if all(g is not None for g in group):
+                    order += group
+                    seen.update(group)
+                    continue
+            order.append(i)
+            seen.add(i)
+        offs_perm, total = flatten_views([params[i] for i in order])
+        offs = [0] * len(params)
+        for o, i in zip(offs_perm, order):
+            offs[i] = o
         self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)

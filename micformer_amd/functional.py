@@ -166,6 +166,22 @@ CROSS_KEYS = ("norm1.weight", "norm1.bias", "cross_attn.q.weight", "cross_attn.q
               "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias")
 
 
+def _packed_qkv(P, G):
+    """If q.weight | kv.weight and q.bias | kv.bias (and their gradient targets) sit back to back in memory -- TrainEngine lays
+    the flat buffers out that way -- return ([3C, C] weight view, [3C] bias view, gradient views); else None."""
+    wq, wkv, bq, bkv = (P[k] for k in ("self_attn.q.weight", "self_attn.kv.weight", "self_attn.q.bias", "self_attn.kv.bias"))
+    gs = [G.get(k) for k in ("self_attn.q.weight", "self_attn.kv.weight", "self_attn.q.bias", "self_attn.kv.bias")]
+    if any(g is None for g in gs):
+        return None
+    C = wq.shape[0]
+    def adj(a, b):
+        return a.data_ptr() + 4 * a.numel() == b.data_ptr()
+    if not (adj(wq, wkv) and adj(bq, bkv) and adj(gs[0], gs[1]) and adj(gs[2], gs[3])):
+        return None
+    return (wq.as_strided((3 * C, C), (C, 1)), bq.as_strided((3 * C,), (1,)),
+            gs[0].as_strided((3 * C, C), (C, 1)), gs[2].as_strided((3 * C,), (1,)))
+
+
 # ============================================================================= TransformerBlock3D (MS.py:430-524)
 class SelfBlockFn(torch.autograd.Function):
     @staticmethod
@@ -183,17 +199,24 @@ class SelfBlockFn(torch.autograd.Function):
         xf = x.reshape(-1, C)
         xn, m1, r1 = ops.layernorm_fwd(xf, P["norm1.weight"], P["norm1.bias"], eps)
         xnp = ops.pad3d(xn, dims, pd) if padded else xn             # F.pad AFTER the norm (MS.py:477-483)
-        q = ops.linear_fwd(xnp, P["self_attn.q.weight"], P["self_attn.q.bias"])
-        kv = ops.linear_fwd(xnp, P["self_attn.kv.weight"], P["self_attn.kv.bias"])
-        o = ops.window_attn_fwd(q, kv, pdims, heads, ws, scale)
+        ctx.tg = _targets(params)
+        fused = _packed_qkv(P, dict(zip(SELF_KEYS, ctx.tg)))
+        if fused is not None:
+            # engine mode: q.weight | kv.weight (and the biases) are adjacent in the flat buffer -> ONE [3C, C] projection
+            q = ops.linear_fwd(xnp, fused[0], fused[1])             # packed [T, 3C] = [q | k | v]
+            kv = q
+            o = ops.window_attn_fwd_qkv(q, pdims, heads, ws, scale)
+        else:
+            q = ops.linear_fwd(xnp, P["self_attn.q.weight"], P["self_attn.q.bias"])
+            kv = ops.linear_fwd(xnp, P["self_attn.kv.weight"], P["self_attn.kv.bias"])
+            o = ops.window_attn_fwd(q, kv, pdims, heads, ws, scale)
         if padded:
             o = ops.crop3d(o, dims, pd)                              # proj is per token: crop before it (MS.py:497-498)
         x1 = ops.linear_fwd(o, P["self_attn.proj.weight"], P["self_attn.proj.bias"], resid=xf, dp_scale=s1,
                             rows_per_sample=rps)
         y, mlp_saved = _mlp_fwd(x1, dims, P, s2, eps)
         ctx.save_for_backward(xf, m1, r1, xnp, q, kv, o, x1, s1, s2, *mlp_saved, *params)
-        ctx.meta = (dims, ws, pd, padded, heads, scale)
-        ctx.tg = _targets(params)
+        ctx.meta = (dims, ws, pd, padded, heads, scale, fused is not None)
         return y.reshape(x.shape)
 
     @staticmethod
@@ -204,7 +227,7 @@ class SelfBlockFn(torch.autograd.Function):
         params = sv[15:]
         P = dict(zip(SELF_KEYS, params))
         G = {k: _grad_buf(t, v) for (k, v), t in zip(P.items(), ctx.tg)}
-        dims, ws, pd, padded, heads, scale = ctx.meta
+        dims, ws, pd, padded, heads, scale, packed = ctx.meta
         B, D, H, W = dims
         pdims = (B,) + pd
         rps = D * H * W
@@ -216,11 +239,17 @@ class SelfBlockFn(torch.autograd.Function):
         do = ops.linear_bwd_data(dx1, P["self_attn.proj.weight"], dp_scale=s1, rows_per_sample=rps)
         if padded:
             do = ops.pad3d(do, dims, pd)
-        dq, dkv = ops.window_attn_bwd(q, kv, do, pdims, heads, ws, scale)
-        _lin_wgrad(side, dq, xnp, G["self_attn.q.weight"], G["self_attn.q.bias"])
-        _lin_wgrad(side, dkv, xnp, G["self_attn.kv.weight"], G["self_attn.kv.bias"])
-        dxn = ops.linear_bwd_data(dq, P["self_attn.q.weight"])
-        ops.linear_bwd_data(dkv, P["self_attn.kv.weight"], out=dxn, accumulate=True)
+        if packed:
+            wqkv, _, gw, gb = _packed_qkv(P, G)
+            dqkv = ops.window_attn_bwd_qkv(q, do, pdims, heads, ws, scale)
+            _lin_wgrad(side, dqkv, xnp, gw, gb)
+            dxn = ops.linear_bwd_data(dqkv, wqkv)
+        else:
+            dq, dkv = ops.window_attn_bwd(q, kv, do, pdims, heads, ws, scale)
+            _lin_wgrad(side, dq, xnp, G["self_attn.q.weight"], G["self_attn.q.bias"])
+            _lin_wgrad(side, dkv, xnp, G["self_attn.kv.weight"], G["self_attn.kv.bias"])
+            dxn = ops.linear_bwd_data(dq, P["self_attn.q.weight"])
+            ops.linear_bwd_data(dkv, P["self_attn.kv.weight"], out=dxn, accumulate=True)
         if padded:
             dxn = ops.crop3d(dxn, dims, pd)
         dx = ops.layernorm_bwd(dxn, xf, m1, r1, P["norm1.weight"], G["norm1.weight"], G["norm1.bias"], add=dx1)

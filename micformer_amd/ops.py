@@ -168,6 +168,32 @@ def window_attn_bwd(q, kv, d_o, dims, heads, ws, scale):
     return dq, dkv
 
 
+def window_attn_fwd_qkv(qkv, dims, heads, ws, scale):
+    """Self attention on a packed [T, 3C] = [q | k | v] token matrix (one fused q/kv projection)."""
+    B, D, H, W = dims
+    T, C3 = qkv.shape
+    C = C3 // 3
+    o = _new(qkv, T, C)
+    base = qkv.data_ptr()
+    call("micf_window_attn_fwd", base, C3, base + 4 * C, base + 8 * C, C3, f32(o), C, B, D, H, W, C, heads,
+         ws[0], ws[1], ws[2], float(scale),
+         cost=_cost(4 * T * C * ws[0] * ws[1] * ws[2], qkv, o))
+    return o
+
+
+def window_attn_bwd_qkv(qkv, d_o, dims, heads, ws, scale):
+    """-> dqkv [T, 3C] = [dq | dk | dv] for the packed layout."""
+    B, D, H, W = dims
+    T, C3 = qkv.shape
+    C = C3 // 3
+    dqkv = _new(qkv, T, C3)
+    base, dbase = qkv.data_ptr(), dqkv.data_ptr()
+    call("micf_window_attn_bwd", base, C3, base + 4 * C, base + 8 * C, C3, f32(d_o), C, dbase, C3, dbase + 4 * C,
+         dbase + 8 * C, C3, B, D, H, W, C, heads, ws[0], ws[1], ws[2], float(scale),
+         cost=_cost(8 * T * C * ws[0] * ws[1] * ws[2], qkv, d_o, dqkv))
+    return dqkv
+
+
 # ----------------------------------------------------------------------------- conv 3x3x3
 def conv3_fwd(x1, w, bias, dims, x2=None, ncdhw_out=False):
     B, D, H, W = dims

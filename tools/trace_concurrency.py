@@ -33,6 +33,20 @@ for k in (0, 1, 2):
     print(f"  {k}{'+' if k == 2 else ' '} kernels in flight: {busy[k]/1e6:7.3f} ms ({100*busy[k]/tot:4.1f} %)")
 cnt = collections.Counter(re.sub(r"\(.*", "", n).replace("void ", "")[:60] for _, _, n in step)
 print("non-micf kernels in the step:", {k: v for k, v in cnt.items() if "micf" not in k})
+def first(name):
+    return next(((st, en) for st, en, n in step if name in n), None)
+marks_ = [("forward (until tail_col2im ends)", "tail_col2im"), ("loss fwd+bwd (until dice_bce_bwd ends)", "dice_bce_bwd"),
+          ("head backward (until tail_dwout ends)", "tail_dwout"), ("blocks backward (until first wgrad_grouped starts)", "wgrad_grouped_kernel"),
+          ("grouped weight gradients (until adam_tick starts)", "adam_tick"), ("adam", None)]
+prev = t0
+for label, name in marks_:
+    if name is None:
+        print(f"  phase {label}: {(t1 - prev)/1e6:.3f} ms"); break
+    f = first(name)
+    if f is None: continue
+    edge = f[0] if ("starts" in label) else f[1]
+    print(f"  phase {label}: {(edge - prev)/1e6:.3f} ms")
+    prev = edge
 print("kernels running ALONE (ms):")
 for k, v in alone.most_common(25):
     print(f"  {v/1e6:7.3f}  {k}")

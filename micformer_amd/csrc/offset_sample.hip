@@ -22,6 +22,9 @@ constexpr int kHid = 16;
 // tokens walked by one wave: 8 amortises the per-wave flush of the head's parameter gradients on big grids; small grids
 // (8^3, 4^3 stages) take 1 so that every CU gets a wave
 static inline int tok_per_wave(int64_t T) { return T >= 32768 ? 8 : (T >= 4096 ? 2 : 1); }
+// quad kernels: iterations of 4 tokens per wave
+static inline int quads_per_wave(int64_t T) { return T >= 32768 ? 2 : 1; }
+static inline int quad_waves_per_block(int64_t T) { return T >= 16384 ? 4 : 1; }
 
 __device__ __forceinline__ float sum16(float v) {   // all-reduce inside each 16-lane group
 #pragma unroll
@@ -108,6 +111,56 @@ __global__ void __launch_bounds__(256) offset_sample_fwd_kernel(const float* __r
       for (int q = 0; q < 8; ++q)
         if (ok[q]) acc += base[(int64_t)lin[q] * C + c] * wgt[q];
       xs[t * C + c] = acc;
+    }
+  }
+}
+
+
+// ---- quad variants: FOUR tokens per wave, one per 16-lane group.  The 16-wide head is computed once per group (not 4x
+// redundantly), the lanes of a group cover the C channels with 16-byte loads, and four tokens' dependent chains
+// (h row -> LN/GELU/1^3 conv -> taps -> gather) are in flight per wave instead of one: these kernels are latency-bound.
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+__global__ void __launch_bounds__(256) offset_sample_fwd4_kernel(const float* __restrict__ h, const float* __restrict__ ln_g,
+                                                                 const float* __restrict__ ln_b, const float* __restrict__ w1,
+                                                                 const float* __restrict__ xa, float* __restrict__ flow_out,
+                                                                 float* __restrict__ xs, Geo g, int C, float eps, int tpw) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, k = lane & 15, grp = lane >> 4;
+  const int64_t T = g.tokens();
+  for (int it = 0; it < tpw; ++it) {
+    const int64_t t0 = (((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * tpw + it) * 4;
+    if (t0 >= T) return;                                     // wave-uniform
+    const bool live = t0 + grp < T;
+    const int64_t t = live ? t0 + grp : T - 1;               // idle groups shadow the last token (no stores)
+    float xh, rs, ln, gl, off[3];
+    head_fwd(h + t * kHid, ln_g, ln_b, w1, eps, k, xh, rs, ln, gl, off);
+    int b, d, hh, w; g.decode((int)t, b, d, hh, w);
+    float fl[3];
+    fl[0] = off[0] + (((float)d + 0.5f) / (float)g.H * 2.f - 1.f);      // MS.py:335  ref[...,0] /= H_key
+    fl[1] = off[1] + (((float)hh + 0.5f) / (float)g.W * 2.f - 1.f);     // MS.py:334  ref[...,1] /= W_key
+    fl[2] = off[2] + (((float)w + 0.5f) / (float)g.D * 2.f - 1.f);      // MS.py:333  ref[...,2] /= D_key
+    if (live && k < 3) flow_out[t * 3 + k] = k == 0 ? fl[0] : (k == 1 ? fl[1] : fl[2]);
+    const Taps tp = make_taps(d, hh, w, fl, g.D, g.H, g.W);
+    const float* base = xa + (int64_t)b * g.D * g.H * g.W * C;
+    int lin[8]; float wgt[8]; bool ok[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int dz = q >> 2, dy = (q >> 1) & 1, dx = q & 1;
+      ok[q] = tp.finite && corner(tp, dz, dy, dx, g.D, g.H, g.W, lin[q]);
+      const float wx = dx ? tp.cx - tp.x0 : (tp.x0 + 1.f) - tp.cx;
+      const float wy = dy ? tp.cy - tp.y0 : (tp.y0 + 1.f) - tp.cy;
+      const float wz = dz ? tp.cz - tp.z0 : (tp.z0 + 1.f) - tp.cz;
+      wgt[q] = wx * wy * wz;
+    }
+    for (int c = 4 * k; c < C; c += 64) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (ok[q]) {
+          const float4 v = ld4(base + (int64_t)lin[q] * C + c);
+          acc.x += v.x * wgt[q]; acc.y += v.y * wgt[q]; acc.z += v.z * wgt[q]; acc.w += v.w * wgt[q];
+        }
+      if (live) *reinterpret_cast<float4*>(xs + t * C + c) = acc;
     }
   }
 }
@@ -215,6 +268,106 @@ __global__ void __launch_bounds__(256) offset_sample_bwd_kernel(
   }
 }
 
+
+
+template <bool SCATTER>
+__global__ void __launch_bounds__(256) offset_sample_bwd4_kernel(
+    const float* __restrict__ dxs, const float* __restrict__ h, const float* __restrict__ ln_g, const float* __restrict__ ln_b,
+    const float* __restrict__ w1, const float* __restrict__ xa, const float* __restrict__ flow, float* __restrict__ dxa,
+    float* __restrict__ dh, float* __restrict__ dln_g, float* __restrict__ dln_b, float* __restrict__ dw1, Geo g, int C, float eps,
+    int tpw, CellLists cl, float* __restrict__ partials, int nwaves) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, k = lane & 15, grp = lane >> 4;
+  const int64_t T = g.tokens();
+  float acc_w[3] = {0.f, 0.f, 0.f}, acc_g = 0.f, acc_b = 0.f;       // per-lane (group, channel k) partials
+  for (int it = 0; it < tpw; ++it) {
+    const int64_t t0 = (((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * tpw + it) * 4;
+    if (t0 >= T) break;                                      // wave-uniform
+    const bool live = t0 + grp < T;
+    const int64_t t = live ? t0 + grp : T - 1;
+    float xh, rs, ln, gl, off[3];
+    head_fwd(h + t * kHid, ln_g, ln_b, w1, eps, k, xh, rs, ln, gl, off);
+    int b, d, hh, w; g.decode((int)t, b, d, hh, w);
+    const float fl[3] = {flow[t * 3 + 0], flow[t * 3 + 1], flow[t * 3 + 2]};
+    const Taps tp = make_taps(d, hh, w, fl, g.D, g.H, g.W);
+    const int64_t boff = (int64_t)b * g.D * g.H * g.W * C;
+    int lin[8]; bool ok[8]; float wx[8], wy[8], wz[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int dz = q >> 2, dy = (q >> 1) & 1, dx = q & 1;
+      ok[q] = tp.finite && corner(tp, dz, dy, dx, g.D, g.H, g.W, lin[q]);
+      wx[q] = dx ? tp.cx - tp.x0 : (tp.x0 + 1.f) - tp.cx;
+      wy[q] = dy ? tp.cy - tp.y0 : (tp.y0 + 1.f) - tp.cy;
+      wz[q] = dz ? tp.cz - tp.z0 : (tp.z0 + 1.f) - tp.cz;
+    }
+    float gz = 0.f, gy = 0.f, gx = 0.f;
+    for (int c = 4 * k; c < C; c += 64) {
+      const float4 go = ld4(dxs + t * C + c);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        if (!ok[q]) continue;
+        const int dz = q >> 2, dy = (q >> 1) & 1, dx = q & 1;
+        const int64_t a = boff + (int64_t)lin[q] * C + c;
+        if (SCATTER && live) {
+          const float wq = wx[q] * wy[q] * wz[q];
+          atomicAdd(dxa + a, wq * go.x); atomicAdd(dxa + a + 1, wq * go.y);
+          atomicAdd(dxa + a + 2, wq * go.z); atomicAdd(dxa + a + 3, wq * go.w);
+        }
+        const float4 xv = ld4(xa + a);
+        const float val = xv.x * go.x + xv.y * go.y + xv.z * go.z + xv.w * go.w;
+        gx += (dx ? val : -val) * wy[q] * wz[q];
+        gy += (dy ? val : -val) * wx[q] * wz[q];
+        gz += (dz ? val : -val) * wx[q] * wy[q];
+      }
+    }
+    if (!SCATTER && live && k == 0) {
+      const int cell = cell_of(tp, b, g.D, g.H, g.W);
+      if (cell >= 0) {
+        const int slot = atomicAdd(cl.count + cell, 1);
+        if (slot < cl.cap) cl.list[(int64_t)cell * kCellCap + slot] = (int)t;
+        else cl.ovf[atomicAdd(cl.ovf_count, 1)] = (int)t;
+      }
+    }
+    gz = sum16(gz); gy = sum16(gy); gx = sum16(gx);
+    // grid_sample: d/dn = d/dcoord * S/2 ; STN.py:24: d/dnew = 2 * d/dn / (S-1)      (S == 1 -> 0/0 = NaN, as the reference)
+    float go3[3];
+    go3[0] = (2.f * ((float)g.D / 2.f * gz)) / (float)(g.D - 1);
+    go3[1] = (2.f * ((float)g.H / 2.f * gy)) / (float)(g.H - 1);
+    go3[2] = (2.f * ((float)g.W / 2.f * gx)) / (float)(g.W - 1);
+    float dgl = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) dgl += w1[a * kHid + k] * go3[a];
+    const float dln = dgl * gelu_grad_f(ln);
+    if (live) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) acc_w[a] += go3[a] * gl;
+      acc_g += dln * xh;
+      acc_b += dln;
+    }
+    const float gd = ln_g[k] * dln;
+    const float ma = sum16(gd) * (1.f / kHid);
+    const float mb = sum16(gd * xh) * (1.f / kHid);
+    if (live) dh[t * kHid + k] = rs * (gd - ma - xh * mb);
+  }
+  // fold the four groups, then lanes 0..15 flush
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { acc_w[a] += __shfl_xor(acc_w[a], 16, 64); acc_w[a] += __shfl_xor(acc_w[a], 32, 64); }
+  acc_g += __shfl_xor(acc_g, 16, 64); acc_g += __shfl_xor(acc_g, 32, 64);
+  acc_b += __shfl_xor(acc_b, 16, 64); acc_b += __shfl_xor(acc_b, 32, 64);
+  if (lane < kHid) {
+    if (partials) {
+      const int wg = blockIdx.x * (blockDim.x >> 6) + wave;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) partials[(int64_t)(a * kHid + k) * nwaves + wg] = acc_w[a];
+      partials[(int64_t)(3 * kHid + k) * nwaves + wg] = acc_g;
+      partials[(int64_t)(4 * kHid + k) * nwaves + wg] = acc_b;
+    } else {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) atomicAdd(dw1 + a * kHid + k, acc_w[a]);
+      atomicAdd(dln_g + k, acc_g);
+      atomicAdd(dln_b + k, acc_b);
+    }
+  }
+}
 
 // d(xa)[v, :] += sum over the tokens registered in the 8 cells that have voxel v as a corner.  Thread = (voxel, 4 channels).
 __global__ void __launch_bounds__(256) sample_gather_kernel(const float* __restrict__ dxs, const float* __restrict__ flow,
@@ -374,6 +527,13 @@ extern "C" int micf_offset_sample_fwd(const float* h, const float* ln_g, const f
   if (!h || !ln_g || !ln_b || !w1 || !xa || !flow || !xs || B <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0) return MICF_EINVAL;
   const Geo g{B, D, H, W};
   if (g.tokens() >= (1LL << 31)) return MICF_EUNSUPPORTED;
+  if (g.tokens() >= 4096 && C % 4 == 0 && aligned16(xa) && aligned16(xs)) {   // tiny grids: one token per wave spreads wider
+    const int qpw = quads_per_wave(g.tokens());
+    const int wpb = quad_waves_per_block(g.tokens());      // small grids: one-wave workgroups, so every CU gets one
+    hipLaunchKernelGGL(offset_sample_fwd4_kernel, dim3(ceil_div(g.tokens(), 4 * wpb * qpw)), dim3(64 * wpb), 0, (hipStream_t)stream,
+                       h, ln_g, ln_b, w1, xa, flow, xs, g, C, eps, qpw);
+    MICF_RETURN_LAUNCH();
+  }
   const int tpw = tok_per_wave(g.tokens());
   const int blocks = ceil_div(g.tokens(), 4 * tpw);
   hipLaunchKernelGGL(offset_sample_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, h, ln_g, ln_b, w1, xa, flow,
@@ -409,19 +569,31 @@ extern "C" int micf_offset_sample_bwd(const float* dxs, const float* h, const fl
   const Geo g{B, D, H, W};
   const int64_t T = g.tokens();
   if (T >= (1LL << 31) / 4) return MICF_EUNSUPPORTED;
-  const int tpw = tok_per_wave(T);
-  const int blocks = ceil_div(T, 4 * tpw);
-  const int nwaves = blocks * 4;
+  // quad kernels (4 tokens per wave) when the channel rows allow 16-byte accesses
+  const bool quad = T >= 4096 && (C % 4 == 0) && aligned16(dxs) && aligned16(xa) && aligned16(dxa);   // tiny grids: 1 token per wave
+  const int tpw = quad ? quads_per_wave(T) : tok_per_wave(T);
+  const int wpb = quad ? quad_waves_per_block(T) : 4;
+  const int blocks = ceil_div(T, (quad ? 4 * wpb : 4) * tpw);
+  const int nwaves = blocks * wpb;
   hipStream_t s = (hipStream_t)stream;
   const CellLists none{nullptr, nullptr, nullptr, nullptr, 0};
-  if (!workspace || workspace_floats < micf_offset_sample_bwd_workspace(B, D, H, W) || !aligned16(workspace)) {
-    hipLaunchKernelGGL(offset_sample_bwd_kernel<true>, dim3(blocks), dim3(256), 0, s, dxs, h, ln_g, ln_b, w1, xa, flow, dxa, dh,
-                       dln_g, dln_b, dw1, g, C, eps, tpw, none, (float*)nullptr, 0);
-    MICF_RETURN_LAUNCH();
-  }
+  auto launch_main = [&](bool scatter, const CellLists& lists, float* partials, int nw) {
+#define MICF_SAMPLE_ARGS dim3(blocks), dim3(64 * wpb), 0, s, dxs, h, ln_g, ln_b, w1, xa, flow, dxa, dh, dln_g, dln_b, dw1, g, C, eps, tpw, lists, partials, nw
+    if (quad) {
+      if (scatter) hipLaunchKernelGGL(offset_sample_bwd4_kernel<true>, MICF_SAMPLE_ARGS);
+      else hipLaunchKernelGGL(offset_sample_bwd4_kernel<false>, MICF_SAMPLE_ARGS);
+    } else {
+      if (scatter) hipLaunchKernelGGL(offset_sample_bwd_kernel<true>, MICF_SAMPLE_ARGS);
+      else hipLaunchKernelGGL(offset_sample_bwd_kernel<false>, MICF_SAMPLE_ARGS);
+    }
+#undef MICF_SAMPLE_ARGS
+    return hipGetLastError() == hipSuccess;
+  };
+  if (!workspace || workspace_floats < micf_offset_sample_bwd_workspace(B, D, H, W) || !aligned16(workspace))
+    return launch_main(true, none, nullptr, 0) ? MICF_OK : MICF_ELAUNCH;
   float* partials = workspace;
   CellLists cl = none;
-  if (use_cells(T) && (C % 4 == 0) && aligned16(dxs) && aligned16(dxa) && cell_count(B, D, H, W) * kCellCap < (1LL << 31)) {
+  if (use_cells(T) && quad && cell_count(B, D, H, W) * kCellCap < (1LL << 31)) {
     const int64_t nc = (cell_count(B, D, H, W) + 3) / 4 * 4;
     int* base = reinterpret_cast<int*>(workspace + partial_floats(T));
     const char* env = getenv("MICF_CELL_CAP");           // test hook: force the overflow pass
@@ -429,16 +601,13 @@ extern "C" int micf_offset_sample_bwd(const float* dxs, const float* h, const fl
     cap = cap < 0 ? 0 : (cap > kCellCap ? kCellCap : cap);
     cl = CellLists{base, base + nc, base + nc + 4, base + nc + 4 + nc * kCellCap, cap};
     if (hipMemsetAsync(base, 0, sizeof(int) * (size_t)(nc + 4), s) != hipSuccess) return MICF_ELAUNCH;
-    hipLaunchKernelGGL(offset_sample_bwd_kernel<false>, dim3(blocks), dim3(256), 0, s, dxs, h, ln_g, ln_b, w1, xa, flow, dxa, dh,
-                       dln_g, dln_b, dw1, g, C, eps, tpw, cl, partials, nwaves);
-    if (hipGetLastError() != hipSuccess) return MICF_ELAUNCH;
+    if (!launch_main(false, cl, partials, nwaves)) return MICF_ELAUNCH;
     const int64_t threads = T * (C / 4);
     hipLaunchKernelGGL(sample_gather_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, dxs, flow, dxa, g, C, cl);
-  } else {
-    hipLaunchKernelGGL(offset_sample_bwd_kernel<true>, dim3(blocks), dim3(256), 0, s, dxs, h, ln_g, ln_b, w1, xa, flow, dxa, dh,
-                       dln_g, dln_b, dw1, g, C, eps, tpw, none, partials, nwaves);
+    if (hipGetLastError() != hipSuccess) return MICF_ELAUNCH;
+  } else if (!launch_main(true, none, partials, nwaves)) {
+    return MICF_ELAUNCH;
   }
-  if (hipGetLastError() != hipSuccess) return MICF_ELAUNCH;
   hipLaunchKernelGGL(sample_finish_kernel, dim3(5 * kHid), dim3(256), 0, s, dxs, flow, dxa, g, C, cl, partials, nwaves, dw1, dln_g,
                      dln_b);
   MICF_RETURN_LAUNCH();

@@ -130,7 +130,10 @@ int micf_window_attn_bwd(const float* q, int ldq, const float* k, const float* v
  * Input channels are [x1 (c1) | x2 (c2)] (x2 may be NULL): conv_offset.0 on cat[LN(x), xa] (MS.py:314,354-356)
  * and Head.out_conv (MS.py:1046,1053).  w [N, c1+c2, 3,3,3].  y_layout 0: channels-last [T,N]; 1: NCDHW. */
 int micf_conv3_fwd(const float* x1, int c1, const float* x2, int c2, const float* w, const float* bias, float* y,
-                   int y_layout, int B, int D, int H, int W, int N, micf_stream_t stream);
+                   int y_layout, int B, int D, int H, int W, int N, float* workspace, int64_t workspace_floats,
+                   micf_stream_t stream);
+/* scratch (floats) that enables the direct forward kernel for channels-last outputs with N <= 16 (0 = not applicable) */
+int64_t micf_conv3_fwd_workspace(int N, int c1, int c2);
 /* workspace (optional scratch, micf_conv3_bwd_data_workspace floats): enables the direct data-gradient kernel for
  * channels-last dy with N <= 16 (the weights are re-laid out as [tap][c][16 n] there by the same call). */
 int micf_conv3_bwd_data(const float* dy, int dy_layout, const float* w, float* dx1, int c1, int acc1, float* dx2,

@@ -34,7 +34,8 @@ SIGNATURES = {
     "micf_sw_normalize": "ppilp",
     "micf_window_attn_fwd": "pippipiiiiiiiiiifp",
     "micf_window_attn_bwd": "pippipipippiiiiiiiiiifp",
-    "micf_conv3_fwd": "pipipppiiiiiip",
+    "micf_conv3_fwd": "pipipppiiiiiiplp",
+    "micf_conv3_fwd_workspace": "iii",
     "micf_conv3_bwd_data": "pippiipiiiiiiiplp",
     "micf_conv3_bwd_data_workspace": "iii",
     "micf_conv3_bwd_weight": "pipipippiiiiiplp",
@@ -92,6 +93,7 @@ def _load():
     lib.micf_conv3_bwd_data_workspace.restype = _L
     lib.micf_offset_sample_bwd_workspace.restype = _L
     lib.micf_conv3_bwd_weight_workspace.restype = _L
+    lib.micf_conv3_fwd_workspace.restype = _L
     lib.micf_strerror.argtypes = [_I]
     lib.micf_strerror.restype = ctypes.c_char_p
     lib.micf_abi_version.argtypes = []

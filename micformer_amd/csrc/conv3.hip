@@ -201,9 +201,17 @@ static Conv3In make_in(const float* x1, int c1, const float* x2, int c2, const G
   return Conv3In{x1, x2 ? x2 : x1, c1, c2 > 0 ? c2 : 1, c1 + c2, g, (int)g.tokens(), vec, FastDiv((uint32_t)(c1 + c2))};
 }
 
+extern "C" int64_t micf_conv3_fwd_workspace(int N, int c1, int c2) { return conv3_fwdx_workspace(N, c1, c2); }
+
 extern "C" int micf_conv3_fwd(const float* x1, int c1, const float* x2, int c2, const float* w, const float* bias,
-                              float* y, int y_layout, int B, int D, int H, int W, int N, micf_stream_t stream) {
+                              float* y, int y_layout, int B, int D, int H, int W, int N, float* workspace,
+                              int64_t workspace_floats, micf_stream_t stream) {
   if (!x1 || !w || !y || (c2 > 0 && !x2) || !conv3_args_ok(B, D, H, W, N, c1, c2)) return MICF_EINVAL;
+  if (y_layout == 0 && workspace && workspace_floats >= conv3_fwdx_workspace(N, c1, c2)) {
+    // few output channels, channels-last: direct convolution with pre-transposed weights streamed from L2 (conv3_fwdx.hip)
+    const int rc = conv3_fwd_x(x1, c1, x2, c2, w, bias, y, workspace, B, D, H, W, N, (hipStream_t)stream);
+    if (rc != MICF_EUNSUPPORTED) return rc;
+  }
   if (y_layout == 0) {   // LDS-halo direct convolution on the matrix cores: measured faster than the implicit GEMM for the
                          // channels-last offset conv (126 vs 224 us at 32^3 x 96 ch, batch 2); the NCDHW out_conv stays on the GEMM
     const int rc = conv3_fwd_direct(x1, c1, x2, c2, w, bias, y, y_layout, B, D, H, W, N, (hipStream_t)stream);

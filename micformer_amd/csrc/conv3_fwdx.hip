@@ -1,0 +1,179 @@
+// conv3_fwdx.hip -- forward of the 3x3x3 / pad 1 convolution with FEW output channels (N <= 16: conv_offset[0], MS.py:314,
+// 354-356), channels-last output, as a direct convolution on the matrix cores.
+//
+//   y[t, n] = bias[n] + sum_{tap} sum_c in[t + off(tap), c] * w[n][c][tap]              in = [x1 | x2]
+//
+// rows (MFMA i) = the 16 output channels, columns (j) = 16 tokens, k = 16 input channels of one (chunk, tap).
+//   * input halo of a 128-token tile: staged in LDS one 16-channel chunk at a time (voxel stride 20 floats -> one conflict-free
+//     ds_read_b128 per (tap, token row) is the B operand of 4 k-steps); the NEXT chunk is fetched into registers before the
+//     MFMAs of the current one and committed after them, so the global latency hides under the matrix work;
+//   * weights: pre-transposed to wt[chunk][tap][16 n][16 c] (scratch, written by a tiny kernel of the same call): the A operand
+//     of 4 k-steps is ONE coalesced 16-byte load per lane from L2, prefetched 3 taps ahead in a register ring -- no LDS staging
+//     of weights, no barrier inside the 27-tap loop;
+//   * few token tiles (8^3 / 16^3 stages): the channel chunks are split over blockIdx.y and the partial sums added atomically
+//     into the pre-zeroed output.
+// The LDS-weights direct kernel this replaces (conv3_direct.hip) needed 129 us at the 32^3 x 2 stage (41 TFLOP/s).
+#include "common.h"
+
+namespace micf {
+
+constexpr int fKS = 20;      // LDS voxel stride (floats): 16 channels + 4 pad
+constexpr int fAhead = 3;    // taps of weight prefetch
+
+struct FwdxArgs {
+  const float* x1; const float* x2; int c1, c2;
+  const float* wt;                              // [chunks][27][16][16]
+  const float* bias; float* y; int N;           // channels-last [T, N]
+  int B, D, H, W, tiles_d, tiles_h, tiles_w;
+  int chunks, chunks_per_block;                 // gridDim.y = ceil(chunks / chunks_per_block); > 1 block per tile -> atomic output
+};
+
+__global__ void __launch_bounds__(256) conv3_wtf_kernel(const float* __restrict__ w, float* __restrict__ wt, int N, int Cin, int chunks) {
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (id >= (int64_t)chunks * 27 * 256) return;
+  const int c = (int)(id & 15), n = (int)((id >> 4) & 15);
+  const int tap = (int)((id >> 8) % 27), chunk = (int)((id >> 8) / 27);
+  const int cc = chunk * 16 + c;
+  wt[id] = (n < N && cc < Cin) ? w[((int64_t)n * Cin + cc) * 27 + tap] : 0.f;
+}
+
+template <int TW>
+__global__ void __launch_bounds__(256) conv3_fwdx_kernel(FwdxArgs a) {
+  constexpr int CH = 16 / TW, TH = 4 * CH, TD = 2;
+  constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2, HALO = HD * HH * HW;
+  constexpr int NH = (HALO * 4 + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float Xs[HALO * fKS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lr = lane >> 4;
+  int q = blockIdx.x;
+  const int tw = q % a.tiles_w; q /= a.tiles_w;
+  const int th = q % a.tiles_h; q /= a.tiles_h;
+  const int td = q % a.tiles_d; const int b = q / a.tiles_d;
+  const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;
+  const int64_t DHW = (int64_t)a.D * a.H * a.W;
+  const int Cin = a.c1 + a.c2;
+  const int kc_begin = blockIdx.y * a.chunks_per_block;
+  const int kc_end = min(a.chunks, kc_begin + a.chunks_per_block);
+
+  // halo chunk -> registers (global loads only)
+  auto fetch = [&](int kc, float4 (&hv)[NH]) {
+#pragma unroll
+    for (int it = 0; it < NH; ++it) {
+      const int idx = tid + it * 256;
+      hv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < HALO * 4) {
+        const int v = idx >> 2, g = idx & 3;
+        const int hw = v % HW, hh = (v / HW) % HH, hd = v / (HW * HH);
+        const int dd = d0 + hd - 1, yy = h0 + hh - 1, ww = w0 + hw - 1;
+        const int c = kc * 16 + 4 * g;
+        if ((unsigned)dd < (unsigned)a.D && (unsigned)yy < (unsigned)a.H && (unsigned)ww < (unsigned)a.W && c < Cin) {
+          const int64_t tok = (int64_t)b * DHW + ((int64_t)dd * a.H + yy) * a.W + ww;
+          hv[it] = c < a.c1 ? *reinterpret_cast<const float4*>(a.x1 + tok * a.c1 + c)
+                            : *reinterpret_cast<const float4*>(a.x2 + tok * a.c2 + (c - a.c1));
+        }
+      }
+    }
+  };
+  auto commit = [&](const float4 (&hv)[NH]) {
+#pragma unroll
+    for (int it = 0; it < NH; ++it) {
+      const int idx = tid + it * 256;
+      if (idx < HALO * 4) *reinterpret_cast<float4*>(&Xs[(idx >> 2) * fKS + 4 * (idx & 3)]) = hv[it];
+    }
+  };
+
+  // this wave's two column tiles: ct = 2*wave + tj -> (ld, h group); lane li -> (lh, lw) inside it
+  int vbase[2];
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj) {
+    const int ct = 2 * wave + tj;
+    const int ld = ct / 4, lh = (ct % 4) * CH + li / TW, lw = li % TW;
+    vbase[tj] = ((ld * HH + lh) * HW + lw) * fKS + 4 * lr;            // halo voxel of tap (0,0,0) for this token, k slot 4*lr
+  }
+  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  float4 hv[NH];
+  fetch(kc_begin, hv);
+  for (int kc = kc_begin; kc < kc_end; ++kc) {
+    __syncthreads();                                                    // previous chunk fully consumed
+    commit(hv);
+    __syncthreads();
+    if (kc + 1 < kc_end) fetch(kc + 1, hv);                             // lands while the MFMAs below run
+    const float* wp = a.wt + ((int64_t)kc * 27 * 16 + li) * 16 + 4 * lr;  // + tap * 256
+    float4 ring[fAhead + 1];
+#pragma unroll
+    for (int t = 0; t < fAhead; ++t) ring[t] = *reinterpret_cast<const float4*>(wp + t * 256);
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+      if (tap + fAhead < 27) ring[(tap + fAhead) % (fAhead + 1)] = *reinterpret_cast<const float4*>(wp + (tap + fAhead) * 256);
+      const float4 av = ring[tap % (fAhead + 1)];
+      const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+      const int off = ((kd * HH + kh) * HW + kw) * fKS;                 // source voxel = token + (k - 1), halo origin -1
+      const float4 b0 = *reinterpret_cast<const float4*>(&Xs[vbase[0] + off]);
+      const float4 b1 = *reinterpret_cast<const float4*>(&Xs[vbase[1] + off]);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b0.x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b1.x, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b0.y, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b1.y, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b0.z, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b1.z, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b0.w, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b1.w, acc[1], 0, 0, 0);
+    }
+  }
+  // epilogue: D row = output channel 4*lr + v (float4 over v), column = token li of column tile tj
+  const bool atomic_out = gridDim.y > 1;
+  const int n0 = 4 * lr;
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj) {
+    const int ct = 2 * wave + tj;
+    const int dd = d0 + ct / 4, yy = h0 + (ct % 4) * CH + li / TW, ww = w0 + li % TW;
+    if (dd >= a.D || yy >= a.H || ww >= a.W || n0 >= a.N) continue;
+    float* p = a.y + ((int64_t)b * DHW + ((int64_t)dd * a.H + yy) * a.W + ww) * a.N + n0;
+    f32x4 v = acc[tj];
+    if (a.bias && blockIdx.y == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (n0 + e < a.N) v[e] += a.bias[n0 + e];
+    }
+    if (atomic_out) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (n0 + e < a.N) atomicAdd(p + e, v[e]);
+    } else if (n0 + 3 < a.N && (a.N & 3) == 0) {
+      *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (n0 + e < a.N) p[e] = v[e];
+    }
+  }
+}
+
+int64_t conv3_fwdx_workspace(int N, int c1, int c2) {
+  if (N <= 0 || N > 16 || c1 + c2 <= 0) return 0;
+  return (int64_t)((c1 + c2 + 15) / 16) * 27 * 256;
+}
+
+// MICF_EUNSUPPORTED when the shape is outside what this kernel covers (caller falls back).
+int conv3_fwd_x(const float* x1, int c1, const float* x2, int c2, const float* w, const float* bias, float* y, float* wt, int B, int D,
+                int H, int W, int N, hipStream_t stream) {
+  if (N > 16 || (c1 & 3) || (c2 & 3) || W < 8 || !aligned16(x1) || (x2 && !aligned16(x2)) || !aligned16(y) || !aligned16(wt))
+    return MICF_EUNSUPPORTED;
+  const int Cin = c1 + c2, chunks = (Cin + 15) / 16;
+  const int64_t nw = (int64_t)chunks * 27 * 256;
+  hipLaunchKernelGGL(conv3_wtf_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, w, wt, N, Cin, chunks);
+  if (hipGetLastError() != hipSuccess) return MICF_ELAUNCH;
+  FwdxArgs a{};
+  a.x1 = x1; a.x2 = x2 ? x2 : x1; a.c1 = c1; a.c2 = c2; a.wt = wt; a.bias = bias; a.y = y; a.N = N;
+  a.B = B; a.D = D; a.H = H; a.W = W; a.chunks = chunks;
+  const int tw_ = W >= 12 ? 16 : 8, th_ = 4 * (16 / tw_);
+  a.tiles_d = (D + 1) / 2; a.tiles_h = (H + th_ - 1) / th_; a.tiles_w = (W + tw_ - 1) / tw_;
+  const int64_t blocks = (int64_t)B * a.tiles_d * a.tiles_h * a.tiles_w;
+  // enough token tiles: one workgroup walks all channel chunks; otherwise spread the chunks (atomic accumulation into y)
+  int ysplit = 1;
+  if (blocks < 256) { ysplit = (int)((512 + blocks - 1) / blocks); if (ysplit > chunks) ysplit = chunks; }
+  a.chunks_per_block = (chunks + ysplit - 1) / ysplit;
+  ysplit = (chunks + a.chunks_per_block - 1) / a.chunks_per_block;
+  if (ysplit > 1 && hipMemsetAsync(y, 0, sizeof(float) * (size_t)B * D * H * W * N, stream) != hipSuccess) return MICF_ELAUNCH;
+  if (tw_ == 16) hipLaunchKernelGGL(conv3_fwdx_kernel<16>, dim3((unsigned)blocks, ysplit), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(conv3_fwdx_kernel<8>, dim3((unsigned)blocks, ysplit), dim3(256), 0, stream, a);
+  return hipGetLastError() == hipSuccess ? MICF_OK : MICF_ELAUNCH;
+}
+
+}  // namespace micf

@@ -201,7 +201,10 @@ def conv3_fwd(x1, w, bias, dims, x2=None, ncdhw_out=False):
     c2 = x2.shape[-1] if x2 is not None else 0
     N = w.shape[0]
     y = _new(x1, B, N, D, H, W) if ncdhw_out else _new(x1, B * D * H * W, N)
+    need = 0 if ncdhw_out else _lib.lib.micf_conv3_fwd_workspace(N, c1, c2)
+    ws = scratch(x1.device, need) if need > 0 else None
     call("micf_conv3_fwd", f32(x1), c1, f32(x2), c2, f32(w), f32(bias), f32(y), 1 if ncdhw_out else 0, B, D, H, W, N,
+         f32(ws), ws.numel() if ws is not None else 0,
          cost=_cost(2 * B * D * H * W * 27 * (c1 + c2) * N, x1, x2, w, y))
     return y
 

@@ -182,8 +182,6 @@ __global__ void __launch_bounds__(256) plane_sum_kernel(const float* __restrict_
 
 int conv3_fwd_direct(const float* x1, int c1, const float* x2, int c2, const float* w, const float* bias, float* y,
                      int y_layout, int B, int D, int H, int W, int N, hipStream_t stream);                 // conv3_direct.hip
-int conv3_bwd_data_direct(const float* dy, int dy_layout, const float* w, float* dx1, int c1, int acc1, float* dx2, int c2,
-                          int acc2, int B, int D, int H, int W, int N, hipStream_t stream);               // conv3_direct.hip
 int conv3_wgrad_direct(const float* dy, int dy_layout, const float* x1, int c1, const float* x2, int c2, float* dw,
                        float* dbias, int B, int D, int H, int W, int N, hipStream_t stream);   // conv3_wgrad.hip
 

@@ -1,6 +1,8 @@
-// conv3_direct.hip -- forward and data-gradient of the 3x3x3 / pad 1 convolution as DIRECT convolutions on the matrix
-// cores, with the input halo staged in LDS once per token tile (27x reuse) instead of being gathered 27 times through L1
-// by the implicit-GEMM path.   (conv_offset[0] on cat[LN(x), xa]: MS.py:314, 354-356;  Head.out_conv: MS.py:1046, 1053)
+// conv3_direct.hip -- forward of the 3x3x3 / pad 1 convolution as a DIRECT convolution on the matrix cores, with the input
+// halo staged in LDS once per token tile (27x reuse) instead of being gathered 27 times through L1 by the implicit-GEMM
+// path.  Scratch-free fallback of conv3_fwdx.hip (used when the caller passes no workspace) and the reason the template
+// still carries a BWD parameter: the data gradient now lives in conv3_bwdx.hip.
+// (conv_offset[0] on cat[LN(x), xa]: MS.py:314, 354-356)
 //
 //   out[t, o] = sum_{tap, k} Wt(o, k, tap) * in[t (+/-) off(tap), k]
 //     forward : k = input channel c (16-channel chunks of [x1 | x2]), o = output channel n (<= 16), Wt = w[o][k][tap]
@@ -240,28 +242,6 @@ int conv3_fwd_direct(const float* x1, int c1, const float* x2, int c2, const flo
     if (a.ysplit > 1 && hipMemsetAsync(y, 0, sizeof(float) * (size_t)B * D * H * W * N, stream) != hipSuccess) return MICF_ELAUNCH;
   }
   hipLaunchKernelGGL(conv3_direct_kernel<false>, dim3((unsigned)blocks, a.ysplit), dim3(256), 0, stream, a);
-  return hipGetLastError() == hipSuccess ? MICF_OK : MICF_ELAUNCH;
-}
-
-int conv3_bwd_data_direct(const float* dy, int dy_layout, const float* w, float* dx1, int c1, int acc1, float* dx2, int c2,
-                          int acc2, int B, int D, int H, int W, int N, hipStream_t stream) {
-  if (N > 16 || (dy_layout == 0 && ((N & 3) || !aligned16(dy))) || (dx1 && !aligned16(dx1)) || (dx2 && !aligned16(dx2)))
-    return MICF_EUNSUPPORTED;
-  DirectArgs a{};
-  a.in1 = dy; a.in2 = dy; a.ic1 = N; a.ic2 = 1; a.in_layout = dy_layout; a.K = N;
-  a.w = w; a.Cin = c1 + c2; a.O = c1 + c2;
-  a.d1 = dx1; a.d2 = dx2; a.oc1 = c1; a.oc2 = c2; a.acc1 = acc1; a.acc2 = acc2;
-  a.B = B; a.D = D; a.H = H; a.W = W;
-  tile_counts(a);
-  const int64_t blocks = (int64_t)B * a.tiles_d * a.tiles_h * a.tiles_w;
-  if (blocks < 16 || W < 8) return MICF_EUNSUPPORTED;
-  const int n_ochunk = (a.O + 15) / 16;
-  a.ysplit = 1;
-  if (blocks < 1024 && n_ochunk > 1) {                  // the dy halo is cheap to re-stage: one workgroup per few output chunks
-    int want = (int)((2048 + blocks - 1) / blocks);
-    a.ysplit = want < n_ochunk ? want : n_ochunk;
-  }
-  hipLaunchKernelGGL(conv3_direct_kernel<true>, dim3((unsigned)blocks, a.ysplit), dim3(256), 0, stream, a);
   return hipGetLastError() == hipSuccess ? MICF_OK : MICF_ELAUNCH;
 }
 

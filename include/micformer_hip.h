@@ -237,10 +237,11 @@ int micf_argmax_meandice(const float* logits, const uint8_t* label, uint8_t* mas
 /* ---- torch.optim.Adam(lr, betas, eps, weight_decay=0) over a flat fp32 buffer + CosineAnnealingLR stepped per
  * iteration (train.py:114,148,206-207).  state = {int64 step; double lr} on the device so a captured graph advances:
  * micf_adam_tick increments step and recomputes lr = eta_min + (base-eta_min)*(1+cos(pi*(step-1)/t_max))/2,
- * micf_adam_step applies the update with bias corrections for `step`. */
+ * micf_adam_step applies the update with bias corrections for `step`; the gradient is read as grad_scale * g (1/world after a
+ * sum all-reduce, 1 on one GPU). */
 int micf_adam_tick(void* state, double base_lr, double eta_min, int64_t t_max, micf_stream_t stream);
 int micf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const void* state, float beta1,
-                   float beta2, float eps, micf_stream_t stream);
+                   float beta2, float eps, float grad_scale, micf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -63,7 +63,7 @@ SIGNATURES = {
     "micf_dice_bce_label_bwd": "pppppiilp",
     "micf_argmax_meandice": "pppppiilp",
     "micf_adam_tick": "pddlp",
-    "micf_adam_step": "pppplpfffp",
+    "micf_adam_step": "pppplpffffp",
 }
 
 

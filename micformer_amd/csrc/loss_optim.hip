@@ -119,7 +119,8 @@ __global__ void adam_tick_kernel(AdamState* st, double base_lr, double eta_min, 
 
 __global__ void __launch_bounds__(256) adam_step_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v, int64_t n,
-                                                        const AdamState* __restrict__ st, float beta1, float beta2, float eps) {
+                                                        const AdamState* __restrict__ st, float beta1, float beta2, float eps,
+                                                        float gscale) {
   const double step = (double)st->step;
   const float bc1 = (float)(1.0 - pow((double)beta1, step));
   const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, step));
@@ -127,7 +128,8 @@ __global__ void __launch_bounds__(256) adam_step_kernel(float* __restrict__ p, c
   for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
     if (i + 3 < n) {
       float4 P = *reinterpret_cast<float4*>(p + i), M = *reinterpret_cast<float4*>(m + i), Vv = *reinterpret_cast<float4*>(v + i);
-      const float4 G = *reinterpret_cast<const float4*>(g + i);
+      float4 G = *reinterpret_cast<const float4*>(g + i);
+      G.x *= gscale; G.y *= gscale; G.z *= gscale; G.w *= gscale;        // data parallel: sum over ranks -> mean (1 on one GPU)
       float* pp = &P.x; float* mm = &M.x; float* vv = &Vv.x; const float* gg = &G.x;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -139,8 +141,9 @@ __global__ void __launch_bounds__(256) adam_step_kernel(float* __restrict__ p, c
       *reinterpret_cast<float4*>(p + i) = P; *reinterpret_cast<float4*>(m + i) = M; *reinterpret_cast<float4*>(v + i) = Vv;
     } else {
       for (int64_t j = i; j < n; ++j) {
-        m[j] = m[j] + (g[j] - m[j]) * (1.0f - beta1);
-        v[j] = v[j] * beta2 + (1.0f - beta2) * g[j] * g[j];
+        const float gj = g[j] * gscale;
+        m[j] = m[j] + (gj - m[j]) * (1.0f - beta1);
+        v[j] = v[j] * beta2 + (1.0f - beta2) * gj * gj;
         p[j] = p[j] - step_size * (m[j] / (sqrtf(v[j]) / bc2_sqrt + eps));
       }
     }
@@ -210,13 +213,13 @@ extern "C" int micf_adam_tick(void* state, double base_lr, double eta_min, int64
 }
 
 extern "C" int micf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const void* state, float beta1,
-                              float beta2, float eps, micf_stream_t stream) {
+                              float beta2, float eps, float grad_scale, micf_stream_t stream) {
   if (!p || !g || !m || !v || !state || n < 0) return MICF_EINVAL;
   if (n == 0) return MICF_OK;
   if (!aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v)) return MICF_EINVAL;
   int blocks = (int)((n + 1023) / 1024);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(adam_step_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, (const AdamState*)state,
-                     beta1, beta2, eps);
+                     beta1, beta2, eps, grad_scale);
   MICF_RETURN_LAUNCH();
 }

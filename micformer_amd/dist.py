@@ -33,6 +33,14 @@ class FlatGradSync:
         flat_grads.div_(self.world)
         return flat_grads
 
+    def allreduce_sum_async(self, view):
+        """Start sum-all-reduce of one contiguous slice of the flat gradient; returns a work handle (None on one rank).
+        torch.distributed orders it after everything already enqueued on the current stream and runs it on the backend's own
+        stream, so launches issued afterwards overlap with it; `handle.wait()` re-joins."""
+        if self.world <= 1:
+            return None
+        return dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+
     def max_over_ranks(self, value, device):
         t = torch.tensor([value], dtype=torch.float64, device=device)
         if self.world > 1:
@@ -47,3 +55,32 @@ def flatten_views(tensors, align=4):
         offs.append(total)
         total += (t.numel() + align - 1) // align * align
     return offs, total
+
+
+def module_buckets(names, offsets, sizes, total, min_elems=1 << 20, depth=3):
+    """Contiguous [start, end) slices of the flat buffer, cut where the first `depth` dotted components of the parameter name
+    change (swin.layers.2 | swin.layers.3 | ...), tiny groups merged into their successor: the stages finish their weight
+    gradients at different times of the step, so each slice can be all-reduced as soon as its last writer is done."""
+    order = sorted(range(len(names)), key=lambda i: offsets[i])
+    cuts, prev = [0], None
+    for i in order:
+        key = ".".join(names[i].split(".")[:depth])
+        if prev is not None and key != prev and offsets[i] - cuts[-1] >= min_elems:
+            cuts.append(offsets[i])
+        prev = key
+    cuts.append(total)
+    return [(a, b) for a, b in zip(cuts, cuts[1:]) if b > a]
+
+
+def last_writer_per_bucket(buckets, writes):
+    """writes: iterable of (launch index, start offset, numel).  -> for every bucket the largest launch index that writes into it
+    (-1: nothing queued writes there, it is complete when backward is)."""
+    import bisect
+    starts = [b[0] for b in buckets]
+    last = [-1] * len(buckets)
+    for gi, off, n in writes:
+        lo = bisect.bisect_right(starts, off) - 1
+        hi = bisect.bisect_right(starts, off + max(n, 1) - 1) - 1
+        for b in range(lo, hi + 1):
+            last[b] = max(last[b], gi)
+    return last

@@ -16,14 +16,14 @@ import torch
 import torch.distributed as dist
 
 from . import ops
-from .dist import FlatGradSync, flatten_views
+from .dist import FlatGradSync, flatten_views, last_writer_per_bucket, module_buckets
 from .loss.dice import MDiceLoss
 
 
 class TrainEngine:
     def __init__(self, model, base_lr=1e-4, t_max=150, eta_min=0.0, betas=(0.9, 0.999), eps=1e-8, criterion=None,
                  use_graph=False, process_group=None, grad_bucket_bytes=64 << 20, parallel_modalities=True,
-                 defer_wgrad=True):
+                 defer_wgrad=True, split_step=None):
         self.model = model
         self.criterion = criterion if criterion is not None else MDiceLoss()
         self.base_lr, self.t_max, self.eta_min = base_lr, t_max, eta_min
@@ -37,6 +37,11 @@ class TrainEngine:
         from .models import MICFormer_self as _ms
         _ms.PARALLEL_MODALITIES = bool(parallel_modalities)
         _fn.DEFER_WGRAD = bool(defer_wgrad)      # linear weight gradients: queued in backward, one grouped flush
+        # Data parallel (or split_step=True, a single-GPU test hook): the graph holds forward + backward only; the queued weight
+        # gradients are then launched group by group and every gradient slice is all-reduced as soon as its last writer is
+        # done, overlapping RCCL with the remaining weight-gradient launches (see _flush_and_reduce).
+        self.split_step = (self.world > 1) if split_step is None else bool(split_step)
+        self._wplan = None
         self.use_graph = use_graph
         self._graph = None
         self._static = None
@@ -85,30 +90,72 @@ class TrainEngine:
         self.adam_state = ops.adam_state(dev)
 
     # ------------------------------------------------------------------ one optimisation step
-    def _fwd_bwd(self, x, target):
+    def _fwd_bwd(self, x, target, flush=True):
         self.flat_g.zero_()                                         # optimizer.zero_grad()        train.py:183
         logits = self.model(x)                                      #                              train.py:185
         loss = self.criterion(logits, target)                       #                              train.py:187
         loss.backward()                                             #                              train.py:200
-        from . import functional as _fn
-        _fn.flush_wgrad()                                           # queued linear weight gradients, grouped launches
+        if flush:
+            from . import functional as _fn
+            _fn.flush_wgrad()                                       # queued linear weight gradients, grouped launches
         return loss.detach()
 
-    def _update(self):
-        if self.world > 1:
-            self._allreduce_grads()
+    def _update(self, reduced=False):
+        if self.world > 1 and not reduced:
+            self._allreduce_grads(mean=False)
         ops.adam_tick(self.adam_state, self.base_lr, self.eta_min, self.t_max)   # scheduler (per iteration) train.py:206-207
         ops.adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.adam_state,
-                      self.betas[0], self.betas[1], self.eps)       # optimizer.step()             train.py:201
+                      self.betas[0], self.betas[1], self.eps, grad_scale=1.0 / self.world)   # optimizer.step()   train.py:201
+
+    # ------------------------------------------------------------------ data-parallel tail of a replayed step
+    def _plan_split(self, items):
+        """After capturing forward + backward: the queued weight gradients (tensors in graph memory: same addresses at every
+        replay) become a reusable launch plan; the flat gradient is cut into per-stage slices and each slice learns which
+        grouped launch writes into it last."""
+        self._wplan = ops.GroupedWgradPlan(items)
+        names = [n for n, _ in self.model.named_parameters()]
+        self._buckets = module_buckets(names, self.offsets, self.sizes, self.flat_g.numel())
+        base = self.flat_g.data_ptr()
+        writes = []
+        for k, (dy, a, dw, db, sc, rps) in enumerate(items):
+            for t in (dw, db):
+                if t is not None:
+                    writes.append((k // ops.GROUP_ITEMS, (t.data_ptr() - base) // 4, t.numel()))
+        self._bucket_last = last_writer_per_bucket(self._buckets, writes)
+
+    def _flush_and_reduce(self):
+        """Launch the queued weight gradients group by group; all-reduce every slice of the flat gradient right after the
+        launch that completes it (slices nothing queued writes to go first), so RCCL runs under the remaining launches."""
+        plan = self._wplan
+        ngroups = (plan.n + ops.GROUP_ITEMS - 1) // ops.GROUP_ITEMS
+        works = []
+        def reduce_ready(gi):
+            for (a, b), last in zip(self._buckets, self._bucket_last):
+                if last == gi:
+                    w = self.sync.allreduce_sum_async(self.flat_g[a:b])
+                    if w is not None:
+                        works.append(w)
+        reduce_ready(-1)
+        for gi in range(ngroups):
+            plan.launch(gi * ops.GROUP_ITEMS, min(ops.GROUP_ITEMS, plan.n - gi * ops.GROUP_ITEMS))
+            reduce_ready(gi)
+        for w in works:
+            w.wait()
 
     def _step_impl(self, x, target):
         loss = self._fwd_bwd(x, target)
         self._update()
         return loss
 
-    def _allreduce_grads(self):
-        """Gradient all-reduce(sum)/world over RCCL/xGMI in a few large buckets of the flat buffer."""
-        self.sync.allreduce_mean_(self.flat_g)
+    def _allreduce_grads(self, mean=True):
+        """Gradient all-reduce(sum) over RCCL/xGMI in a few large buckets of the flat buffer (the 1/world goes into Adam)."""
+        works = [self.sync.allreduce_sum_async(self.flat_g[s:s + self.sync.bucket_elems])
+                 for s in range(0, self.flat_g.numel(), self.sync.bucket_elems)]
+        for w in works:
+            if w is not None:
+                w.wait()
+        if mean and self.world > 1:
+            self.flat_g.div_(self.world)
 
     def step(self, x, target):
         """Run one training step; returns the (device) loss of this rank's batch."""
@@ -120,8 +167,9 @@ class TrainEngine:
             self._static[0].copy_(x, non_blocking=True)
             self._static[1].copy_(target, non_blocking=True)
             self._graph.replay()
-            if self.world > 1:
-                self._update()                                      # RCCL all-reduce + Adam stay outside the graph
+            if self.split_step:                                     # weight-gradient groups, RCCL and Adam stay outside the graph
+                self._flush_and_reduce()
+                self._update(reduced=True)
             loss = self._static[2]
         self.steps_done += 1
         return loss
@@ -139,8 +187,12 @@ class TrainEngine:
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            # single GPU: the whole step; data parallel: forward+backward only (the collective is issued eagerly)
-            sl = self._step_impl(sx, st) if self.world == 1 else self._fwd_bwd(sx, st)
+            # single GPU: the whole step; data parallel: forward + backward only (weight-gradient groups, collective and Adam
+            # are issued eagerly after the replay)
+            sl = self._fwd_bwd(sx, st, flush=False) if self.split_step else self._step_impl(sx, st)
+        if self.split_step:
+            from . import functional as _fn
+            self._plan_split(_fn.take_deferred())                   # (capture records, it does not run: step() replays next)
         self._graph, self._static = g, (sx, st, sl)
 
     # ------------------------------------------------------------------ checkpoints (utils.py:57-65, 108-138)

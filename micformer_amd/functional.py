@@ -41,6 +41,13 @@ def _lin_wgrad(defer, dy, a, dw, db, dp_scale=None, rows_per_sample=0):
         ops.linear_bwd_weight(dy, a, dw, db, dp_scale=dp_scale, rows_per_sample=rows_per_sample)
 
 
+def take_deferred():
+    """Hand the queued (not yet launched) weight gradients to the caller (TrainEngine's data-parallel step)."""
+    items = list(_DEFERRED)
+    _DEFERRED.clear()
+    return items
+
+
 def flush_wgrad():
     """Launch every queued weight gradient on the current stream (which must be ordered after their producers)."""
     if _DEFERRED:

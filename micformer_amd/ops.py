@@ -122,28 +122,48 @@ def wgrad_groupable(dy, a1, dp_scale=None, rows_per_sample=0):
     return True
 
 
+GROUP_ITEMS = 32          # layers per kernel launch inside micf_linear_bwd_weight_grouped (linear_grouped.hip::kGroupMax)
+
+
+class GroupedWgradPlan:
+    """The ctypes item array of a list of queued weight gradients, reusable while the tensors keep their addresses (HIP-graph
+    memory): `launch(first, count)` issues the layers [first, first+count) on the current stream."""
+
+    def __init__(self, items):
+        self.items = list(items)                      # holds the tensors (and so their addresses) alive
+        n = self.n = len(self.items)
+        self.arr = (_lib.WgradItem * max(n, 1))()
+        self.flops = [0] * n
+        self.nbytes = [0] * n
+        for k, (it, (dy, a, dw, db, sc, rps)) in enumerate(zip(self.arr, self.items)):
+            M, N = dy.shape
+            K = a.shape[1]
+            it.a, it.dy, it.dp_scale, it.dw, it.dbias = f32(a), f32(dy), f32(sc), f32(dw), f32(db)
+            it.M, it.rows_per_sample, it.N, it.K = M, int(rps) if sc is not None else 0, N, K
+            self.flops[k] = 2 * M * N * K
+            self.nbytes[k] = 4 * (dy.numel() + a.numel() + 2 * dw.numel())
+        self.device = self.items[0][0].device if n else None
+        self.item_bytes = ctypes.sizeof(_lib.WgradItem)
+
+    def launch(self, first=0, count=None):
+        count = self.n - first if count is None else count
+        if count <= 0:
+            return
+        ptr_ = ctypes.c_void_p(ctypes.addressof(self.arr) + first * self.item_bytes)
+        need = _lib.lib.micf_linear_bwd_weight_grouped_workspace(ptr_, count)
+        if need < 0:
+            raise _lib.MicfError("micf_linear_bwd_weight_grouped: unsupported item")
+        ws = scratch(self.device, need) if need > 0 else None
+        cost = None
+        if _lib.PROFILE is not None:
+            cost = (sum(self.nbytes[first:first + count]), sum(self.flops[first:first + count])) + ((f"{count}",) if DETAIL else ())
+        call("micf_linear_bwd_weight_grouped", ptr_, count, f32(ws), ws.numel() if ws is not None else 0, cost=cost)
+
+
 def linear_bwd_weight_grouped(items):
     """items: list of (dy [M,N], a [M,K], dw [N,K], dbias [N] | None, dp_scale | None, rows_per_sample).  One call."""
-    n = len(items)
-    if n == 0:
-        return
-    arr = (_lib.WgradItem * n)()
-    flops, nbytes = 0, 0
-    for it, (dy, a, dw, db, sc, rps) in zip(arr, items):
-        M, N = dy.shape
-        K = a.shape[1]
-        it.a, it.dy, it.dp_scale, it.dw, it.dbias = f32(a), f32(dy), f32(sc), f32(dw), f32(db)
-        it.M, it.rows_per_sample, it.N, it.K = M, int(rps) if sc is not None else 0, N, K
-        flops += 2 * M * N * K
-        nbytes += 4 * (dy.numel() + a.numel() + 2 * dw.numel())
-    dev = items[0][0].device
-    ptr = ctypes.cast(arr, ctypes.c_void_p)
-    need = _lib.lib.micf_linear_bwd_weight_grouped_workspace(ptr, n)
-    if need < 0:
-        raise _lib.MicfError("micf_linear_bwd_weight_grouped: unsupported item")
-    ws = scratch(dev, need) if need > 0 else None
-    call("micf_linear_bwd_weight_grouped", ptr, n, f32(ws), ws.numel() if ws is not None else 0,
-         cost=(nbytes, flops) + ((f"{n}",) if DETAIL else ()))
+    if items:
+        GroupedWgradPlan(items).launch()
 
 
 # ----------------------------------------------------------------------------- window attention
@@ -461,6 +481,7 @@ def adam_tick(state, base_lr, eta_min, t_max):
     call("micf_adam_tick", ptr(state), float(base_lr), float(eta_min), int(t_max))
 
 
-def adam_step(p, g, m, v, state, beta1=0.9, beta2=0.999, eps=1e-8):
+def adam_step(p, g, m, v, state, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
     call("micf_adam_step", f32(p), f32(g), f32(m), f32(v), p.numel(), ptr(state), float(beta1), float(beta2), float(eps),
+         float(grad_scale),
          cost=_cost(12 * p.numel(), p, p, g, m, m, v, v))

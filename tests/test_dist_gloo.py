@@ -113,3 +113,33 @@ def test_flatten_views_alignment():
     offs, total = flatten_views(ts)
     assert offs == [0, 4, 12, 40] and total == 44
     assert all(o % 4 == 0 for o in offs)
+
+
+def test_gradient_bucket_plan():
+    """Host logic of the overlapped data-parallel step: per-stage slices of the flat gradient and, per slice, the last grouped
+    weight-gradient launch that writes into it."""
+    from micformer_amd.dist import last_writer_per_bucket, module_buckets
+    names = ["swin.patch_embed.proj.weight", "swin.layers.0.blocks1.0.mlp.fc1.weight", "swin.layers.0.blocks1.0.mlp.fc1.bias",
+             "swin.layers.1.x.weight", "swin.layers.2.x.weight", "swin.layers.2.y.weight", "swin.up_layers.0.z.weight", "out_conv.weight"]
+    sizes = [100, 4000, 40, 5000, 90000, 70000, 120000, 300]
+    offs, tot = [], 0
+    for n in sizes:
+        offs.append(tot)
+        tot += (n + 3) // 4 * 4
+    buckets = module_buckets(names, offs, sizes, tot, min_elems=8000)
+    assert buckets[0][0] == 0 and buckets[-1][1] == tot
+    assert all(a[1] == b[0] for a, b in zip(buckets, buckets[1:]))                      # contiguous cover
+    assert all(b - a >= 8000 for a, b in buckets[:-1])                                  # tiny groups are merged forward
+    starts = [a for a, _ in buckets]
+    assert offs[4] in starts and offs[6] in starts                                       # cuts sit on stage boundaries
+    # writes: (launch, offset, numel): layers.2.y in launch 3, up_layers.0 in launch 1, fc1.weight in launch 5
+    writes = [(3, offs[5], sizes[5]), (1, offs[6], sizes[6]), (5, offs[1], sizes[1]), (0, offs[4], sizes[4])]
+    last = last_writer_per_bucket(buckets, writes)
+    def bucket_of(off):
+        return max(i for i, (a, _) in enumerate(buckets) if a <= off)
+    assert last[bucket_of(offs[5])] == 3 and last[bucket_of(offs[6])] == 1 and last[bucket_of(offs[1])] == 5
+    assert all(l >= -1 for l in last)
+    # a write that straddles a cut marks both slices
+    a, b = buckets[1]
+    last2 = last_writer_per_bucket(buckets, [(7, b - 2, 4)])
+    assert last2[1] == 7 and last2[2] == 7

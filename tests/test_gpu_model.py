@@ -286,23 +286,34 @@ def test_split_step_matches_fused_step(M):
     from micformer_amd.engine import TrainEngine
     x = fill.make_volume(2, 64, 64, 64).cuda()               # 64^3: the coarsest grid is 2^3 (1^3 would give the reference's NaNs)
     t = fill.one_hot(fill.make_label_map(2, 64, 64, 64)).cuda()
-    # Adam normalises tiny early gradients, so parameter differences after a few steps amplify atomic-order noise; the sharp check
-    # is on the GRADIENT buffer of one identical step (same weights, same data), the loose one on the parameters after 3 steps
-    engines = [TrainEngine(build_head(M, 24, (1, 1, 1, 1)), base_lr=1e-3, t_max=9, use_graph=True, split_step=s) for s in (False, True)]
+    # Same weights (a vanishing learning rate keeps the 3 eager capture warm-ups from moving them), same data.  What the split
+    # layout could get wrong is a dropped, stale or doubly-counted weight gradient of a QUEUED layer: an O(1) relative error on
+    # that layer's dW / dbias.  Accumulation-order noise is ~1e-4 of a weight gradient's scale (LayerNorm gains with heavy
+    # cancellation are noisier, but they are not queued), so 2 % per queued tensor separates the two cleanly.
+    engines = [TrainEngine(build_head(M, 24, (1, 1, 1, 1)), base_lr=1e-9, t_max=9, use_graph=True, split_step=s) for s in (False, True)]
     losses = [e.step(x, t) for e in engines]
-    assert engines[1]._wplan is not None and engines[1]._wplan.n > 0
+    plan = engines[1]._wplan
+    assert plan is not None and plan.n > 50
     assert min(engines[1]._bucket_last) >= -1 and max(engines[1]._bucket_last) >= 0
-    # both engines ran the same 4 steps (3 eager warm-ups + 1 replay) from the same weights
+    assert sorted(set(engines[1]._bucket_last) - {-1}) == sorted(set(l for l in engines[1]._bucket_last if l >= 0))
     close(losses[1], losses[0], atol=1e-5, what="loss of the replayed step")
     g0, g1 = engines[0].flat_g, engines[1].flat_g
     assert torch.isfinite(g0).all() and torch.isfinite(g1).all()
-    for (a_, b_) in engines[1]._buckets:
-        close(g1[a_:b_], g0[a_:b_], atol=1e-7, rtol=2e-3, what=f"gradient slice [{a_}, {b_})")
+    base = g1.data_ptr()
+    for dy, a_, dw, db, sc, rps in plan.items:
+        for tns in (dw, db):
+            if tns is None:
+                continue
+            o = (tns.data_ptr() - base) // 4
+            ref, got = g0[o:o + tns.numel()], g1[o:o + tns.numel()]
+            scale = float(ref.abs().max())
+            assert float((ref - got).abs().max()) <= 0.02 * scale + 1e-12, f"queued gradient at flat offset {o} ({tuple(tns.shape)})"
+    close(g1, g0, atol=0, rtol=2e-2, what="whole gradient buffer (scale = its largest entry)")
     for _ in range(2):
-        losses = [e.step(x, t) for e in engines]
-    sa, sc = (e.model.state_dict() for e in engines)
+        [e.step(x, t) for e in engines]
+    sa, sc_ = (e.model.state_dict() for e in engines)
     for k in sa:
-        assert float((sa[k] - sc[k]).abs().max()) < 2e-3, k      # never more than a fraction of the 6 x lr any weight can move
+        assert torch.isfinite(sc_[k]).all() and float((sa[k] - sc_[k]).abs().max()) < 1e-7, k
 
 
 def test_checkpoint_round_trip_and_resume(M, tmp_path):

@@ -256,6 +256,36 @@ def test_noncubic_pad_and_odd_resize_against_reference(M):
     close(logits[:, :, ::2, ::2, ::2], g["logits_stride"], atol=1e-4, what="odd36 logits")
 
 
+def test_large_config_against_oracle(M):
+    """BASELINE config 4's network -- embed_dim 96 (C = 96 / 192 / 384 / 768, head_dim 32), depths 2-2-6-2 -- at a small
+    non-cubic volume (48 x 32 x 32: token grids 12x8x8, 6x4x4, 3x2x2 (padded to the window), 2x1x1 (S == 1 sampling)) against
+    the pinned CPU oracle: logits, loss and the per-tensor gradient norms with the oracle's NaN pattern."""
+    from micformer_amd import MDiceLoss
+    cfg = R.Cfg(embed_dim=96)
+    P = filled_params(cfg)
+    h = build_head(M, 96, (2, 2, 6, 2))
+    x = fill.make_volume(1, 48, 32, 32)
+    t = fill.one_hot(fill.make_label_map(1, 48, 32, 32))
+    loss_ref, logits_ref, grads_ref = R.train_step({k: v.clone() for k, v in P.items()}, {}, x, t, cfg, step=1)
+    logits = h(x.cuda())
+    close(logits, logits_ref, atol=1e-4, what="large logits")
+    loss = MDiceLoss()(logits, t.cuda())
+    close(loss, loss_ref, atol=1e-5, what="large loss")
+    loss.backward()
+    bad = []
+    for n, p in h.named_parameters():
+        if n not in grads_ref:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n      # concat_back_dim.0: never used (MS.py:1015-1016)
+            continue
+        want, got = float(grads_ref[n].double().norm()), float(p.grad.double().norm())
+        if want != want:
+            if got == got:
+                bad.append((n, got, want))
+        elif not abs(got - want) <= 2e-3 * want + 1e-10:
+            bad.append((n, got, want))
+    assert not bad, f"{len(bad)} gradient norms off, e.g. {bad[:4]}"
+
+
 def test_two_train_steps_against_reference(M):
     """zero_grad -> fwd -> MDiceLoss -> bwd -> Adam(1e-4) -> cosine LR (train.py:183-207), two iterations, vs torch.optim.Adam
     on the reference model (fixture f5)."""

@@ -47,9 +47,22 @@ int micf_layernorm_fwd(const float* x1, const float* x2, int c1, const float* ga
                        float* mean, float* rstd, int64_t rows, int C, float eps, micf_stream_t stream);
 /* dx = LN'(dy) + add, where add [rows,C] is optional (NULL = 0; it may alias dx1 when c1 == C) -- this fuses the
  * residual-branch gradient sum of a block (d(shortcut) + d(norm(x))); dgamma/dbeta are accumulated. */
+/* partials (optional): when non-NULL, dgamma / dbeta are NOT touched; instead every workgroup stores its [2C] partial sums at
+ * partials[block * 2C] (micf_layernorm_bwd_partial_rows blocks; 0 = this shape has no partial form, pass NULL) and the caller
+ * adds them later with micf_layernorm_bwd_finish -- many LayerNorms per launch, off the backward chain, no atomics. */
 int micf_layernorm_bwd(const float* dy, const float* x1, const float* x2, int c1, const float* mean,
                        const float* rstd, const float* gamma, float* dx1, float* dx2, float* dgamma, float* dbeta,
-                       int64_t rows, int C, const float* add, micf_stream_t stream);
+                       int64_t rows, int C, const float* add, float* partials, micf_stream_t stream);
+int micf_layernorm_bwd_partial_rows(int64_t rows, int C, int c1);
+typedef struct micf_ln_finish_item {
+  const float* partials;   /* [blocks, 2C] as written by micf_layernorm_bwd */
+  float* dgamma;           /* [C] accumulated (may be NULL) */
+  float* dbeta;            /* [C] accumulated (may be NULL) */
+  int32_t blocks;
+  int32_t C;
+} micf_ln_finish_item;
+/* `items` is HOST memory, read during the call only. */
+int micf_layernorm_bwd_finish(const micf_ln_finish_item* items, int n, micf_stream_t stream);
 
 /* ---- nn.Linear + fused epilogue (q/kv/proj MS.py:188-201,246-259; Mlp MS.py:28-34; concat_back_dim MS.py:1027-1030).
  *   lin = [a1 | a2] @ W^T + bias        a1 [M,k1], a2 [M,K-k1] (NULL when k1 == K), W [N,K]

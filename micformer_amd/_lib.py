@@ -18,7 +18,9 @@ _T = {"p": _P, "i": _I, "l": _L, "f": _F, "d": _D}
 # except micf_strerror.  Mirrors include/micformer_hip.h one to one (tests/test_abi.py checks the header).
 SIGNATURES = {
     "micf_layernorm_fwd": "ppippppplifp",
-    "micf_layernorm_bwd": "pppippppppplipp",
+    "micf_layernorm_bwd": "pppippppppplippp",
+    "micf_layernorm_bwd_partial_rows": "lii",
+    "micf_layernorm_bwd_finish": "pip",
     "micf_linear_fwd": "ppipppplppliiip",
     "micf_linear_bwd_data": "pplppppiiliip",
     "micf_linear_bwd_weight": "pplppiippliiplp",
@@ -72,6 +74,12 @@ class WgradItem(ctypes.Structure):
     _fields_ = [("a", ctypes.c_void_p), ("dy", ctypes.c_void_p), ("dp_scale", ctypes.c_void_p), ("dw", ctypes.c_void_p),
                 ("dbias", ctypes.c_void_p), ("M", ctypes.c_int64), ("rows_per_sample", ctypes.c_int64),
                 ("N", ctypes.c_int32), ("K", ctypes.c_int32)]
+
+
+class LnFinishItem(ctypes.Structure):
+    """struct micf_ln_finish_item (include/micformer_hip.h)."""
+    _fields_ = [("partials", ctypes.c_void_p), ("dgamma", ctypes.c_void_p), ("dbeta", ctypes.c_void_p),
+                ("blocks", ctypes.c_int32), ("C", ctypes.c_int32)]
 
 
 class MicfError(RuntimeError):

@@ -139,7 +139,7 @@ template <int LPR, int VPL>
 __global__ void __launch_bounds__(256) ln_bwd_v2(const float* dy, const float* __restrict__ x, const float* __restrict__ mean,
                                                  const float* __restrict__ rstd, const float* __restrict__ gamma, float* dx,
                                                  float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int C,
-                                                 const float* add, int rpb) {
+                                                 const float* add, float* __restrict__ partials, int rpb) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // [2][C]
   constexpr int RPW = 64 / LPR;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane % LPR, rg = lane / LPR;
@@ -194,9 +194,46 @@ __global__ void __launch_bounds__(256) ln_bwd_v2(const float* dy, const float* _
     }
   }
   __syncthreads();
+  if (partials) {     // [block][2C]: summed later by micf_layernorm_bwd_finish -- hundreds of workgroups adding into the same 2C
+                      // addresses with device-scope atomics serialise, and nobody on the backward chain needs dgamma / dbeta
+    for (int c = threadIdx.x; c < 2 * C; c += 256) partials[(int64_t)blockIdx.x * 2 * C + c] = sm[c];
+    return;
+  }
   for (int c = threadIdx.x; c < C; c += 256) {
     if (dgamma) atomicAdd(dgamma + c, sm[c]);
     if (dbeta) atomicAdd(dbeta + c, sm[C + c]);
+  }
+}
+
+// grouped finish: dgamma[c] += sum_b partials[b][c], dbeta[c] += sum_b partials[b][C + c] for up to kLnFinishMax LayerNorms
+constexpr int kLnFinishMax = 64;
+struct LnFinishArgs {
+  int n;
+  int end[kLnFinishMax];                                   // running total of workgroups (one per 256 columns of [2C])
+  const float* partials[kLnFinishMax]; float* dgamma[kLnFinishMax]; float* dbeta[kLnFinishMax];
+  int blocks[kLnFinishMax]; int C[kLnFinishMax];
+};
+__global__ void __launch_bounds__(256) ln_finish_kernel(const LnFinishArgs a) {
+  const int w = blockIdx.x;
+  int k = 0;
+  while (k < a.n - 1 && w >= a.end[k]) ++k;
+  const int local = w - (k ? a.end[k - 1] : 0);
+  const int C = a.C[k], nb = a.blocks[k];
+  const int c = local * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;      // 64 columns x 4 slices of the block range
+  __shared__ float red[256];
+  float acc = 0.f;
+  if (c < 2 * C) {
+    const float* p = a.partials[k] + c;
+    for (int b = slice; b < nb; b += 4) acc += p[(int64_t)b * 2 * C];
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (slice == 0 && c < 2 * C) {
+    acc = red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192];
+    // atomic: modules shared by the two modalities (swin.norm, PatchMerging / PatchExpand norms) appear as two items with the
+    // same destination in one launch (2-way contention at most)
+    if (c < C) { if (a.dgamma[k]) atomicAdd(a.dgamma[k] + c, acc); }
+    else if (a.dbeta[k]) atomicAdd(a.dbeta[k] + (c - C), acc);
   }
 }
 
@@ -248,9 +285,36 @@ extern "C" int micf_layernorm_fwd(const float* x1, const float* x2, int c1, cons
   MICF_RETURN_LAUNCH();
 }
 
+extern "C" int micf_layernorm_bwd_partial_rows(int64_t rows, int C, int c1) {
+  int lpr, vpl;
+  if (rows <= 0 || C <= 0 || c1 != C || C > kLnMaxC || !ln_v2_shape(C, lpr, vpl)) return 0;
+  return ceil_div(rows, ln_v2_rpb(rows, lpr, 512));
+}
+
+extern "C" int micf_layernorm_bwd_finish(const micf_ln_finish_item* items, int n, micf_stream_t stream) {
+  if (n < 0 || (n > 0 && !items)) return MICF_EINVAL;
+  for (int first = 0; first < n; first += kLnFinishMax) {
+    const int cnt = (n - first < kLnFinishMax) ? n - first : kLnFinishMax;
+    LnFinishArgs a;
+    a.n = cnt;
+    int blocks = 0;
+    for (int k = 0; k < cnt; ++k) {
+      const micf_ln_finish_item& it = items[first + k];
+      if (!it.partials || it.blocks <= 0 || it.C <= 0) return MICF_EINVAL;
+      a.partials[k] = it.partials; a.dgamma[k] = it.dgamma; a.dbeta[k] = it.dbeta; a.blocks[k] = it.blocks; a.C[k] = it.C;
+      blocks += ceil_div(2 * it.C, 64);
+      a.end[k] = blocks;
+    }
+    hipLaunchKernelGGL(ln_finish_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    if (hipGetLastError() != hipSuccess) return MICF_ELAUNCH;
+  }
+  return MICF_OK;
+}
+
 extern "C" int micf_layernorm_bwd(const float* dy, const float* x1, const float* x2, int c1, const float* mean,
                                   const float* rstd, const float* gamma, float* dx1, float* dx2, float* dgamma,
-                                  float* dbeta, int64_t rows, int C, const float* add, micf_stream_t stream) {
+                                  float* dbeta, int64_t rows, int C, const float* add, float* partials,
+                                  micf_stream_t stream) {
   if (!dy || !x1 || !mean || !rstd || !gamma || !dx1 || rows < 0 || C <= 0 || c1 <= 0 || c1 > C ||
       (c1 < C && (!x2 || !dx2)))
     return MICF_EINVAL;
@@ -259,9 +323,10 @@ extern "C" int micf_layernorm_bwd(const float* dy, const float* x1, const float*
   int lpr, vpl;
   if (!x2 && ln_v2_shape(C, lpr, vpl) && aligned16(x1) && aligned16(dy) && aligned16(dx1) && aligned16(gamma) &&
       (!add || aligned16(add))) {
-    MICF_LN_DISPATCH(ln_bwd_v2, 2 * C * sizeof(float), 512, dy, x1, mean, rstd, gamma, dx1, dgamma, dbeta, rows, C, add);
+    MICF_LN_DISPATCH(ln_bwd_v2, 2 * C * sizeof(float), 512, dy, x1, mean, rstd, gamma, dx1, dgamma, dbeta, rows, C, add, partials);
     MICF_RETURN_LAUNCH();
   }
+  if (partials) return MICF_EUNSUPPORTED;          // the partial form exists for the vector kernel only (see ..._partial_rows)
   const int rpb = ln_rows_per_block(rows);
   const int blocks = ceil_div(rows, rpb);
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 2 * C * sizeof(float), (hipStream_t)stream, dy, x1,

@@ -108,11 +108,12 @@ class TrainEngine:
                       self.betas[0], self.betas[1], self.eps, grad_scale=1.0 / self.world)   # optimizer.step()   train.py:201
 
     # ------------------------------------------------------------------ data-parallel tail of a replayed step
-    def _plan_split(self, items):
+    def _plan_split(self, items, ln_items=()):
         """After capturing forward + backward: the queued weight gradients (tensors in graph memory: same addresses at every
         replay) become a reusable launch plan; the flat gradient is cut into per-stage slices and each slice learns which
         grouped launch writes into it last."""
         self._wplan = ops.GroupedWgradPlan(items)
+        self._lnplan = ops.LnFinishPlan(ln_items)               # LayerNorm gain / bias partials: one grouped finish, first
         names = [n for n, _ in self.model.named_parameters()]
         self._buckets = module_buckets(names, self.offsets, self.sizes, self.flat_g.numel())
         base = self.flat_g.data_ptr()
@@ -129,6 +130,7 @@ class TrainEngine:
         plan = self._wplan
         ngroups = (plan.n + ops.GROUP_ITEMS - 1) // ops.GROUP_ITEMS
         works = []
+        self._lnplan.launch()
         def reduce_ready(gi):
             for (a, b), last in zip(self._buckets, self._bucket_last):
                 if last == gi:
@@ -192,7 +194,7 @@ class TrainEngine:
             sl = self._fwd_bwd(sx, st, flush=False) if self.split_step else self._step_impl(sx, st)
         if self.split_step:
             from . import functional as _fn
-            self._plan_split(_fn.take_deferred())                   # (capture records, it does not run: step() replays next)
+            self._plan_split(*_fn.take_deferred())                  # (capture records, it does not run: step() replays next)
         self._graph, self._static = g, (sx, st, sl)
 
     # ------------------------------------------------------------------ checkpoints (utils.py:57-65, 108-138)

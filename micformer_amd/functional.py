@@ -32,27 +32,45 @@ def _c(t):
 DEFER_WGRAD = False
 DEFER_MAX_TOKENS = 1 << 17          # larger layers launch immediately (their operands are still hot in L2 / MALL)
 _DEFERRED = []
+_DEFERRED_LN = []                   # (partials, blocks, C, dgamma, dbeta) of LayerNorm backward calls
+
+
+_QUEUED_DW = set()                  # destinations already in the queue: the grouped kernel owns each dW element exclusively
 
 
 def _lin_wgrad(defer, dy, a, dw, db, dp_scale=None, rows_per_sample=0):
-    if defer and DEFER_WGRAD and dy.shape[0] <= DEFER_MAX_TOKENS and ops.wgrad_groupable(dy, a, dp_scale, rows_per_sample):
+    if defer and DEFER_WGRAD and dy.shape[0] <= DEFER_MAX_TOKENS and ops.wgrad_groupable(dy, a, dp_scale, rows_per_sample) \
+            and dw.data_ptr() not in _QUEUED_DW:          # (a layer applied twice in one step launches its second use at once)
+        _QUEUED_DW.add(dw.data_ptr())
         _DEFERRED.append((dy, a, dw, db, dp_scale, rows_per_sample))
     else:
         ops.linear_bwd_weight(dy, a, dw, db, dp_scale=dp_scale, rows_per_sample=rows_per_sample)
 
 
 def take_deferred():
-    """Hand the queued (not yet launched) weight gradients to the caller (TrainEngine's data-parallel step)."""
-    items = list(_DEFERRED)
+    """Hand the queued (not yet launched) weight gradients and LayerNorm partials to the caller (TrainEngine's data-parallel step)."""
+    items, ln = list(_DEFERRED), list(_DEFERRED_LN)
     _DEFERRED.clear()
-    return items
+    _DEFERRED_LN.clear()
+    _QUEUED_DW.clear()
+    return items, ln
+
+
+def _ln_defer(on):
+    """The list LayerNorm backward should queue its parameter-gradient partials in, or None (accumulate immediately)."""
+    return _DEFERRED_LN if (on and DEFER_WGRAD) else None
 
 
 def flush_wgrad():
     """Launch every queued weight gradient on the current stream (which must be ordered after their producers)."""
+    if _DEFERRED_LN:
+        ln = list(_DEFERRED_LN)
+        _DEFERRED_LN.clear()
+        ops.layernorm_bwd_finish(ln)
     if _DEFERRED:
         items = list(_DEFERRED)
         _DEFERRED.clear()
+        _QUEUED_DW.clear()
         ops.linear_bwd_weight_grouped(items)
 
 
@@ -103,7 +121,8 @@ class LayerNormFn(torch.autograd.Function):
         dy = _c(dy).reshape(-1, gamma.numel())
         dg, db = _grad_buf(ctx.tg[0], gamma), _grad_buf(ctx.tg[1], gamma)
         x2f = x2.reshape(-1, x2.shape[-1]) if x2 is not None else None
-        r = ops.layernorm_bwd(dy, x.reshape(-1, x.shape[-1]), mean, rstd, gamma, dg, db, x2f)
+        r = ops.layernorm_bwd(dy, x.reshape(-1, x.shape[-1]), mean, rstd, gamma, dg, db, x2f,
+                              defer=_ln_defer(ctx.tg[0] is not None and ctx.tg[1] is not None))
         dg, db = _ret(ctx.tg[0], dg), _ret(ctx.tg[1], db)
         if x2 is None:
             return r.reshape(x.shape), None, dg, db, None
@@ -161,7 +180,7 @@ def _mlp_bwd(dy, x1f, saved, dims, P, G, s2, side=False):
     dh = ops.linear_bwd_data(dy, P["mlp.fc2.weight"], dp_scale=s2, rows_per_sample=rps, pre_act=h)
     _lin_wgrad(side, dh, xn2, G["mlp.fc1.weight"], G["mlp.fc1.bias"])
     dxn2 = ops.linear_bwd_data(dh, P["mlp.fc1.weight"])
-    return ops.layernorm_bwd(dxn2, x1f, m2, r2, P["norm2.weight"], G["norm2.weight"], G["norm2.bias"], add=dy)
+    return ops.layernorm_bwd(dxn2, x1f, m2, r2, P["norm2.weight"], G["norm2.weight"], G["norm2.bias"], add=dy, defer=_ln_defer(side))
 
 
 SELF_KEYS = ("norm1.weight", "norm1.bias", "self_attn.q.weight", "self_attn.q.bias", "self_attn.kv.weight",
@@ -259,7 +278,7 @@ class SelfBlockFn(torch.autograd.Function):
             ops.linear_bwd_data(dkv, P["self_attn.kv.weight"], out=dxn, accumulate=True)
         if padded:
             dxn = ops.crop3d(dxn, dims, pd)
-        dx = ops.layernorm_bwd(dxn, xf, m1, r1, P["norm1.weight"], G["norm1.weight"], G["norm1.bias"], add=dx1)
+        dx = ops.layernorm_bwd(dxn, xf, m1, r1, P["norm1.weight"], G["norm1.weight"], G["norm1.bias"], add=dx1, defer=_ln_defer(side))
         return (dx.reshape(B, D, H, W, C), None, None, None, None, None) + \
             tuple(_ret(t, G[k]) for k, t in zip(SELF_KEYS, ctx.tg))
 
@@ -336,7 +355,7 @@ class CrossBlockFn(torch.autograd.Function):
             dxa = ops.crop3d(dxap, dims, pd)
         else:
             dxn, dxa = dxnp, dxap
-        dx = ops.layernorm_bwd(dxn, xf, m1, r1, P["norm1.weight"], G["norm1.weight"], G["norm1.bias"], add=dx1)
+        dx = ops.layernorm_bwd(dxn, xf, m1, r1, P["norm1.weight"], G["norm1.weight"], G["norm1.bias"], add=dx1, defer=_ln_defer(side))
         return (dx.reshape(B, D, H, W, C), dxa.reshape(B, D, H, W, C), None, None, None, None, None) + \
             tuple(_ret(t, G[k]) for k, t in zip(CROSS_KEYS, ctx.tg))
 

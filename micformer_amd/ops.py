@@ -44,16 +44,44 @@ def layernorm_fwd(x1, gamma, beta, eps, x2=None):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x1, mean, rstd, gamma, dgamma, dbeta, x2=None, add=None):
-    """Returns dx1 (and dx2); dgamma/dbeta are accumulated in place.  dx = LN'(dy) + add."""
+def layernorm_bwd(dy, x1, mean, rstd, gamma, dgamma, dbeta, x2=None, add=None, defer=None):
+    """Returns dx1 (and dx2); dgamma/dbeta are accumulated in place.  dx = LN'(dy) + add.
+    defer: a list -> the parameter gradients are left as per-workgroup partials and (partials, blocks, C, dgamma, dbeta) is
+    appended to it for a later `layernorm_bwd_finish` (shapes without a partial form accumulate immediately as usual)."""
     rows, c1 = x1.shape
     C = dy.shape[1]
     dx1 = _new(x1, rows, c1)
     dx2 = _new(x1, rows, C - c1) if x2 is not None else None
+    partials = None
+    if defer is not None and x2 is None:
+        nb = _lib.lib.micf_layernorm_bwd_partial_rows(rows, C, c1)
+        if nb > 0 and not ((dy.data_ptr() | x1.data_ptr() | gamma.data_ptr() | (add.data_ptr() if add is not None else 0)) & 15):
+            partials = _new(x1, nb, 2 * C)
+            defer.append((partials, nb, C, dgamma, dbeta))
     call("micf_layernorm_bwd", f32(dy), f32(x1), f32(x2), c1, f32(mean), f32(rstd), f32(gamma), f32(dx1), f32(dx2),
-         f32(dgamma), f32(dbeta), rows, C, f32(add),
+         f32(dgamma), f32(dbeta), rows, C, f32(add), f32(partials),
          cost=_cost(12 * rows * C, dy, x1, x2, dx1, dx2, add))
     return (dx1, dx2) if x2 is not None else dx1
+
+
+class LnFinishPlan:
+    """ctypes item array of queued LayerNorm parameter-gradient partials (reusable while the tensors keep their addresses)."""
+
+    def __init__(self, items):
+        self.items = list(items)
+        self.n = len(self.items)
+        self.arr = (_lib.LnFinishItem * max(self.n, 1))()
+        for it, (partials, nb, C, dg, db) in zip(self.arr, self.items):
+            it.partials, it.dgamma, it.dbeta, it.blocks, it.C = f32(partials), f32(dg), f32(db), nb, C
+
+    def launch(self):
+        if self.n:
+            call("micf_layernorm_bwd_finish", ctypes.cast(self.arr, ctypes.c_void_p), self.n,
+                 cost=_cost(0, *[i[0] for i in self.items[:1]]) if _lib.PROFILE is not None else None)
+
+
+def layernorm_bwd_finish(items):
+    LnFinishPlan(items).launch()
 
 
 # ----------------------------------------------------------------------------- Linear

@@ -49,6 +49,9 @@ def pmc_traffic(kernel_key):
     except (OSError, ValueError):
         return None
     rec = table.get(kernel_key)
+    if rec is None:          # same entry point, different shape tag (e.g. the number of queued layers changed): still the same kernels
+        base = kernel_key.split("|")[0]
+        rec = next((v for k, v in table.items() if k.split("|")[0] == base), None)
     return int(rec["hbm_bytes_per_launch"]) if rec else None
 
 

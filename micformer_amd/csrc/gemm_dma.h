@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(256) gemm_dma_kernel(DmaOperand P, DmaOperand 
 // Every wave owns a private LDS ring (P slab 4 KiB + Q slab 1 KiB per stage), so the main loop needs no barrier at all --
 // only the counted vmcnt wait of the wave's own DMAs.  The four partial 64 x 16 accumulators meet in LDS at the end and each
 // wave finishes (and stores) one quarter of the tile.  4x the workgroups of the 64 x 64 kernel for the same problem.
-constexpr int kSkinnyNS = 5;                                  // ring depth per wave
+constexpr int kSkinnyNS = 3;                                  // ring depth per wave
 constexpr int kSkinnyStage = 5 * 256;                         // floats per stage: P image 1024 + Q image 256
 constexpr int kSkinnyLds = 4 * kSkinnyNS * kSkinnyStage * 4;  // bytes of dynamic LDS (100 KiB: one workgroup per CU)
 constexpr int kSkinnyMaxBlocks = 256;                         // use it when the 64 x 64 tiling yields at most this many tiles

@@ -4,8 +4,8 @@
 //   dW[n][c][tap] = sum_t dy[t, n] * in[t + off(tap), c]                 in = [x1 | x2], n < 16
 //
 // MFMA 16x16x4 fp32: rows i = 16 input channels, columns j = the 16 dy channels, k = 4 tokens.  A workgroup owns a slab of
-// 96 input channels x 27 taps = 162 (tap, channel tile) pairs -> 41 accumulator tiles (164 VGPRs) in each of its 4 waves,
-// and walks token tiles of 64 tokens: the input halo of the tile (all 96 channels, voxel stride 100 floats: the four k
+// 48 input channels x 27 taps = 81 (tap, channel tile) pairs -> 21 accumulator tiles (84 AGPRs) in each of its 4 waves,
+// and walks token tiles of 64 tokens: the input halo of the tile (the slab's 48 channels, voxel stride 52 floats: the four k
 // lanes land on banks 0/16/32/48, conflict-free) is staged in LDS once, the dy fragment of a 16-token group is 4 registers,
 // and every MFMA then costs exactly one 4-byte LDS read.  Partial slabs go to a workspace with coalesced 16-byte stores
 // and a second kernel sums them over the workgroups and scatters into the [N][Cin][27] layout (+=).
@@ -14,11 +14,11 @@
 
 namespace micf {
 
-constexpr int wCS = 96;                 // channels per slab (6 channel tiles)
-constexpr int wXS = 100;                // LDS voxel stride (floats)
-constexpr int wPairs = 27 * (wCS / 16); // 162 (tap, channel tile) pairs per slab
-constexpr int wTPW = (wPairs + 3) / 4;  // 41 accumulator tiles per wave
-constexpr int wSlabFloats = 4 * wTPW * 256;   // partial slab of one workgroup in the workspace (42 K floats)
+constexpr int wCS = 48;                 // channels per slab (3 channel tiles): 67 KB of LDS, so a workgroup of the other stream fits beside it
+constexpr int wXS = 52;                 // LDS voxel stride (floats): 4 * 52 = 208 = 16 (mod 64) -> the four k lanes hit disjoint banks
+constexpr int wPairs = 27 * (wCS / 16); // 81 (tap, channel tile) pairs per slab
+constexpr int wTPW = (wPairs + 3) / 4;  // 21 accumulator tiles per wave
+constexpr int wSlabFloats = 4 * wTPW * 256;   // partial slab of one workgroup in the workspace (21.5 K floats)
 
 struct WgxArgs {
   const float* dy;                      // channels-last [T, 16]
@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(256) conv3_wgradx_kernel(WgxArgs a) {
   int offs[wTPW];                                                      // LDS offset of (tap, channel tile) p of this wave
 #pragma unroll
   for (int p = 0; p < wTPW; ++p) {
-    const int pair = min(wave * wTPW + p, wPairs - 1);                  // the 2 surplus tiles of wave 3 recompute the last pair
+    const int pair = min(wave * wTPW + p, wPairs - 1);                  // the 3 surplus tiles of wave 3 recompute the last pair
     const int tap = pair / (wCS / 16), ct = pair % (wCS / 16);          // (never read back): no branch in the MFMA stream
     const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
     offs[p] = (((kd - 1) * HH + (kh - 1)) * HW + (kw - 1)) * wXS + ct * 16;
@@ -221,8 +221,8 @@ int conv3_wgradx(const float* dy, const float* x1, int c1, const float* x2, int 
   a.tiles_per_group = p.tiles_per_group; a.groups = p.groups;
   static bool attr_set = false;          // > 64 KiB of dynamic LDS needs the opt-in once per process
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgradx_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgradx_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgradx_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgradx_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     attr_set = true;
   }
   const dim3 grid(p.slabs, p.groups);

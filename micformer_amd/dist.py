@@ -10,10 +10,12 @@ import torch.distributed as dist
 
 
 class FlatGradSync:
-    def __init__(self, process_group=None, bucket_bytes=64 << 20):
+    def __init__(self, process_group=None, bucket_bytes=64 << 20, always=False):
+        """always=True issues the collectives even on a one-rank group (a test hook: RCCL stream semantics on one GPU)."""
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
-        if self.world > 1 and self.pg is None:
+        self.always = bool(always) and dist.is_available() and dist.is_initialized()
+        if (self.world > 1 or self.always) and self.pg is None:
             self.pg = dist.group.WORLD
         self.bucket_elems = max(int(bucket_bytes) // 4, 1)
 
@@ -37,7 +39,7 @@ class FlatGradSync:
         """Start sum-all-reduce of one contiguous slice of the flat gradient; returns a work handle (None on one rank).
         torch.distributed orders it after everything already enqueued on the current stream and runs it on the backend's own
         stream, so launches issued afterwards overlap with it; `handle.wait()` re-joins."""
-        if self.world <= 1:
+        if self.world <= 1 and not self.always:
             return None
         return dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 

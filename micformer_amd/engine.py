@@ -23,12 +23,12 @@ from .loss.dice import MDiceLoss
 class TrainEngine:
     def __init__(self, model, base_lr=1e-4, t_max=150, eta_min=0.0, betas=(0.9, 0.999), eps=1e-8, criterion=None,
                  use_graph=False, process_group=None, grad_bucket_bytes=64 << 20, parallel_modalities=True,
-                 defer_wgrad=True, split_step=None):
+                 defer_wgrad=True, split_step=None, always_collective=False):
         self.model = model
         self.criterion = criterion if criterion is not None else MDiceLoss()
         self.base_lr, self.t_max, self.eta_min = base_lr, t_max, eta_min
         self.betas, self.eps = betas, eps
-        self.sync = FlatGradSync(process_group, grad_bucket_bytes)
+        self.sync = FlatGradSync(process_group, grad_bucket_bytes, always=always_collective)
         self.world = self.sync.world
         self._flatten()
         self.sync.broadcast_params(self.flat_p)                    # rank-identical initial weights

@@ -352,6 +352,30 @@ def test_split_step_matches_fused_step(M):
         assert torch.isfinite(sc_[k]).all() and float((sa[k] - sc_[k]).abs().max()) < 1e-7, k
 
 
+def test_split_step_with_rccl_on_one_rank(M):
+    """The overlapped data-parallel step with REAL RCCL calls: a one-rank `nccl` process group, collectives forced on
+    (`always_collective`), so the async all-reduces of the gradient slices, their stream ordering against the grouped
+    weight-gradient launches and the final waits all run -- the sum over one rank must leave the step unchanged."""
+    import torch.distributed as dist
+    from micformer_amd.engine import TrainEngine
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29613", world_size=1, rank=0)
+    try:
+        x = fill.make_volume(2, 64, 64, 64).cuda()
+        t = fill.one_hot(fill.make_label_map(2, 64, 64, 64)).cuda()
+        ref = TrainEngine(build_head(M, 24, (1, 1, 1, 1)), base_lr=1e-9, t_max=9, use_graph=True, split_step=False)
+        eng = TrainEngine(build_head(M, 24, (1, 1, 1, 1)), base_lr=1e-9, t_max=9, use_graph=True, split_step=True, always_collective=True)
+        assert eng.sync.always and eng.sync.pg is not None
+        for _ in range(3):
+            l0, l1 = ref.step(x, t), eng.step(x, t)
+        torch.cuda.synchronize()
+        close(l1, l0, atol=1e-5, what="loss")
+        close(eng.flat_g, ref.flat_g, atol=0, rtol=2e-2, what="gradient buffer (scale = its largest entry)")
+        assert torch.isfinite(eng.flat_p).all()
+    finally:
+        dist.destroy_process_group()
+
+
 def test_checkpoint_round_trip_and_resume(M, tmp_path):
     """the checkpoint dict of train.py:233-241 / utils.py:57-65,108-138 ({'epoch','state_dict','optimizer',
     'scheduler'}, torch.save).  (1) resume: 1 step + save + load into a fresh engine + 2 steps == 3 steps straight;

@@ -89,7 +89,7 @@ class MicfError(RuntimeError):
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
-            f"{LIB_PATH} not found: build it with `python -m micformer_amd.build` (hipcc, gfx950). "
+            f"{LIB_PATH} not found: build it with `python micformer_amd/build.py` (hipcc, gfx950). "
             "micformer_amd has no CPU / PyTorch fallback path.")
     lib = ctypes.CDLL(LIB_PATH)
     for name, sig in SIGNATURES.items():

@@ -5,12 +5,14 @@ One "step" = the reference's training iteration (train_mmwhs_noPad.py:183-207) o
 pairs: zero_grad -> Head forward -> MDiceLoss -> backward -> [RCCL grad all-reduce] -> Adam + cosine LR.
 Workload = BASELINE.json configs[1]: MicFormer base (embed 48, depths 2-2-6-2, heads 3-6-12-24, window 2^3, 8 classes),
 128^3 volumes, LOCAL batch 2 per GPU (weak scaling: configs[2] is 8 x 2 = global 16).  Inputs are generated on the device
-before the timed region.  Arithmetic is fp32 end to end (the reference trains in fp32; bf16 is a later round).
+before the timed region.  --dtype selects the arithmetic of the matrix-core products: fp32 (exact, the parity mode) or bf16
+(bf16 MFMA operands, fp32 accumulation / residual stream / LayerNorm / softmax / loss / master weights).
 
   python bench.py --gpus 1 --steps 20 --warmup 5
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields, incl. `roofline` and `cpu_baseline`).
+Every rank runs every leg (timed region, roofline leg) so no rank leaves while another still has a collective to issue.
 """
 import argparse
 import json
@@ -24,6 +26,9 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable copy rate
 MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_*_f32, dense (MI355X_MICROARCH.md)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # v_mfma_f32_*_bf16, dense
+
+BLOCK_MARKERS = (".blocks1.", ".blocks2.", ".self_blocks1.", ".self_blocks2.")
 
 
 def synthetic_batch(B, vol, num_classes, device, seed):
@@ -55,41 +60,71 @@ def pmc_traffic(kernel_key):
     return int(rec["hbm_bytes_per_launch"]) if rec else None
 
 
-def cpu_baseline(vol, threads, budget_s=25.0):
-    """The CPU restatement (oracle/, 'port') timed on the host cores on a BOUNDED sample of the same workload: full fp32
-    train steps (fwd + MDiceLoss + bwd + Adam) of the base model on one (vol/2)^3 CT+MR pair -- 1/8 of the voxels of a
-    128^3 pair (every stage keeps a token grid >= 2, so it is the same op mix) -- scaled by 1/8 to pairs/s of the full size."""
+def path_bytes(embed_dim, depths, vol, batch, elem_bytes, block_param_count):
+    """algorithmic bytes of the attention / transformer path per step with ideal whole-block fusion,
+    26 * sum_s d_s T_s C_s * e * B_local + 2 * W_block * e   (d_s = encoder + decoder depth units of stage s, T_s tokens per
+    modality per sample, C_s channels; forward 10, backward 16 activation passes per unit; block weights read fwd + bwd)."""
+    sigma = 0
+    for s, d in enumerate(depths):
+        tok = 1
+        for v in vol:
+            tok *= max(-(-v // 4) >> s, 1)
+        sigma += 2 * d * tok * embed_dim * (1 << s)
+    return 26 * sigma * elem_bytes * batch + 2 * block_param_count * elem_bytes, sigma
+
+
+def cpu_baseline(vol, threads):
+    """The CPU restatement (oracle/, 'port') timed on the host cores: ONE real train step (fwd + MDiceLoss + bwd + Adam) of
+    the base model on ONE full-size CT+MR pair (B = 1) -- the same workload unit the GPU number counts -- after one small
+    warm-up step (thread pools, allocator).  Bounded: a single step is ~20-30 s on the GPU box's cores."""
     import torch
     from oracle import micformer_ref as R
     from oracle.shapes import filled_params
     threads = max(1, min(threads, 64))          # torch CPU ops stop scaling (and oversubscribe SMT siblings) beyond this
     torch.set_num_threads(threads)
-    sub = tuple(max(v // 2, 32) for v in vol)
-    frac = (sub[0] * sub[1] * sub[2]) / float(vol[0] * vol[1] * vol[2])
     cfg = R.Cfg()
     P = filled_params(cfg)
     g = torch.Generator().manual_seed(1234)
-    x = torch.randn((1, 2) + sub, generator=g)
-    lab = torch.randint(0, 8, (1,) + sub, generator=g)
-    tgt = torch.nn.functional.one_hot(lab, 8).permute(0, 4, 1, 2, 3).float().contiguous()
-    st, times = {}, []
-    t_start = time.perf_counter()
-    step = 0
-    while True:
-        step += 1
-        t0 = time.perf_counter()
-        R.train_step(P, st, x, tgt, cfg, step=step)
-        times.append(time.perf_counter() - t0)
-        if step >= 4 or time.perf_counter() - t_start + times[-1] > budget_s:
-            break
-    best = min(times)
-    return {"value": round(frac / best, 4), "unit": "pairs/s", "cores": threads, "kind": "port",
-            "sample": f"{len(times)} full fp32 train step(s) (fwd+loss+bwd+Adam) of MicFormer base on one {sub[0]}^3 CT+MR pair "
-                      f"(= {frac:.3f} of a {vol[0]}^3 pair; value scaled by that), oracle/ torch CPU ops, {threads} threads, "
-                      f"best of {len(times)}: {best:.2f} s/step"}
+
+    def batch(v):
+        x = torch.randn((1, 2) + v, generator=g)
+        lab = torch.randint(0, 8, (1,) + v, generator=g)
+        return x, torch.nn.functional.one_hot(lab, 8).permute(0, 4, 1, 2, 3).float().contiguous()
+
+    st = {}
+    R.train_step(P, st, *batch((32, 32, 32)), cfg, step=1)           # warm-up, untimed
+    x, tgt = batch(vol)
+    t0 = time.perf_counter()
+    R.train_step(P, st, x, tgt, cfg, step=2)
+    dt = time.perf_counter() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "pairs/s", "cores": threads, "kind": "port",
+            "sample": f"1 full fp32 train step (fwd+loss+bwd+Adam) of MicFormer base on one {vol[0]}^3 CT+MR pair (B=1, the "
+                      f"unit the GPU value counts), oracle/ torch CPU ops, {threads} threads, after one untimed 32^3 warm-up "
+                      f"step: {dt:.2f} s"}
 
 
-def main():
+class _StubEngine:
+    """CPU stand-in used by tests/test_bench_flow.py (--cpu-stub): issues the collectives of a data-parallel step on gloo so the
+    rank control flow of this script (who is still inside which leg when a collective is issued) is exercised without a GPU."""
+
+    def __init__(self, world):
+        import torch
+        self.world, self.use_graph, self._graph = world, True, None
+        self.t = torch.zeros(8)
+
+    def _capture(self, x, tgt):
+        self._graph = object()
+
+    def step(self, x, tgt):
+        import torch.distributed as dist
+        if self._graph is None and self.use_graph:
+            self._capture(x, tgt)
+        if self.world > 1:
+            dist.all_reduce(self.t)
+        return self.t[0] + 0.5
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -97,13 +132,15 @@ def main():
     ap.add_argument("--batch", type=int, default=2, help="local batch (pairs per GPU)")
     ap.add_argument("--vol", type=int, default=128)
     ap.add_argument("--embed-dim", type=int, default=48)
+    ap.add_argument("--dtype", choices=("fp32", "bf16"), default=None, help="matrix-core arithmetic (default: the library's)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--serial-modalities", action="store_true", help="do not overlap the CT / MR branches on two streams")
     ap.add_argument("--detail", action="store_true", help="roofline leg: key kernels by shape too (diagnostic)")
     ap.add_argument("--eval-mode", action="store_true", help="DropPath off (default: train mode, DropPath active)")
-    args = ap.parse_args()
+    ap.add_argument("--cpu-stub", action="store_true", help="control-flow test on CPU/gloo with a stub engine (no kernels)")
+    args = ap.parse_args(argv)
 
     import torch
     import torch.distributed as dist
@@ -114,29 +151,45 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)          # backend "nccl" is RCCL on ROCm
-
-    from micformer_amd import _lib
-    from micformer_amd.engine import TrainEngine
-    from micformer_amd.models.MICFormer_self import Head
-
-    torch.manual_seed(1234)                                     # rank-identical initial weights (also broadcast by the engine)
-    model = Head(embed_dim=args.embed_dim, num_classes=8).to(dev)
-    model.train(not args.eval_mode)
-    torch.manual_seed(1234 + rank)                              # rank-distinct DropPath stream and data
+    stub = args.cpu_stub
+    depths = (2, 2, 6, 2)
     vol = (args.vol,) * 3
-    x, tgt = synthetic_batch(args.batch, vol, 8, dev, 1234 + rank)
-    eng = TrainEngine(model, base_lr=1e-4, t_max=150, use_graph=not args.no_graph,
-                      parallel_modalities=not args.serial_modalities)
+    if stub:
+        dev = torch.device("cpu")
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")
+        eng, x, tgt, dtype_name, nblock = _StubEngine(world), None, None, "fp32", 0
+        _lib = _ops = None
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", device_id=dev)          # backend "nccl" is RCCL on ROCm
+
+        from micformer_amd import _lib
+        from micformer_amd import ops as _ops
+        from micformer_amd.engine import TrainEngine
+        from micformer_amd.models.MICFormer_self import Head
+
+        if args.dtype is not None:
+            _ops.set_compute_dtype(args.dtype)
+        dtype_name = _ops.compute_dtype()
+        torch.manual_seed(1234)                                     # rank-identical initial weights (also broadcast by the engine)
+        model = Head(embed_dim=args.embed_dim, num_classes=8, depths=depths).to(dev)
+        model.train(not args.eval_mode)
+        nblock = sum(p.numel() for n, p in model.named_parameters() if any(m in n for m in BLOCK_MARKERS))
+        torch.manual_seed(1234 + rank)                              # rank-distinct DropPath stream and data
+        x, tgt = synthetic_batch(args.batch, vol, 8, dev, 1234 + rank)
+        eng = TrainEngine(model, base_lr=1e-4, t_max=150, use_graph=not args.no_graph,
+                          parallel_modalities=not args.serial_modalities)
 
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not stub:
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         eng.step(x, tgt)
@@ -154,17 +207,13 @@ def main():
         dt = float(t.item())
     loss_val = float(loss)
     assert loss_val == loss_val, "loss is NaN"
-
-    if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
-        return
+    ms_step = 1000.0 * dt / args.steps
 
     out = {
         "metric": "train volumes/sec (128^3 CT+MRI pair)", "value": round(world * args.batch * args.steps / dt, 4),
         "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(1000.0 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
+        "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
         "config": {"workload": f"MicFormer base Head(embed_dim={args.embed_dim}, depths 2-2-6-2, heads 3-6-12-24, window 2^3, "
                                f"8 classes) full train step (fwd + MDiceLoss + bwd + Adam/cosine) on {args.vol}^3 CT+MR pairs, "
                                f"{'DropPath on' if not args.eval_mode else 'eval mode'}",
@@ -173,48 +222,73 @@ def main():
         "final_loss": round(loss_val, 6),
     }
 
-    # ---- roofline of the dominant kernel: HIP events around every C-ABI launch of 2 eager steps on the launch stream(s),
-    # keyed by (entry point, shape).  The dominant kernel is the (entry point, shape) with the largest total time.
+    # ---- roofline leg: HIP events around every C-ABI launch of 2 eager steps on the launch stream(s), keyed by (entry point,
+    # shape).  EVERY rank runs it (the eager steps contain the gradient all-reduce); rank 0 reports its own numbers.
     if not args.no_roofline:
-        from micformer_amd import ops as _ops
+        nprof = 2
         eng_graph = eng.use_graph
         eng.use_graph = False
         eng.step(x, tgt)
-        torch.cuda.synchronize()
-        _ops.DETAIL = True
-        _lib.profile_start()
-        nprof = 2
-        for _ in range(nprof):
-            eng.step(x, tgt)
-        prof = _lib.profile_stop()
-        _ops.DETAIL = False
+        if stub:
+            for _ in range(nprof):
+                eng.step(x, tgt)
+            prof = {"stub|x": dict(calls=2, ms=1.0, bytes=1, flops=1, block_ms=1.0)}
+        else:
+            torch.cuda.synchronize()
+            _ops.DETAIL = True
+            _lib.profile_start()
+            for _ in range(nprof):
+                eng.step(x, tgt)
+            prof = _lib.profile_stop()
+            _ops.DETAIL = False
         eng.use_graph = eng_graph
+        barrier()
+        e = 2 if dtype_name == "bf16" else 4
+        mfma_peak = MFMA_BF16_PEAK_TFLOPS if dtype_name == "bf16" else MFMA_F32_PEAK_TFLOPS
         total_ms = sum(v["ms"] for v in prof.values())
         name, top = max(prof.items(), key=lambda kv: kv[1]["ms"])
         per = top["calls"]
         sec = top["ms"] / 1e3
         gbs = top["bytes"] / sec / 1e9
         tfl = top["flops"] / sec / 1e12
-        frac_hbm, frac_mfma = gbs / HBM_PEAK_GBS, tfl / MFMA_F32_PEAK_TFLOPS
+        frac_hbm, frac_mfma = gbs / HBM_PEAK_GBS, tfl / mfma_peak
         # the bound that applies is the one the kernel's arithmetic intensity puts it under
         ai = top["flops"] / max(top["bytes"], 1)
-        ridge = MFMA_F32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+        ridge = mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9)
         if ai > ridge:
-            roof = {"bound": "mfma", "achieved": round(tfl, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(frac_mfma, 4)}
+            roof = {"bound": "mfma", "achieved": round(tfl, 3), "peak": mfma_peak, "unit": "TFLOP/s", "frac": round(frac_mfma, 4)}
         else:
             roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(frac_hbm, 4)}
         roof.update({"traffic": pmc_traffic(name), "kernel": name, "launches_per_step": per // nprof,
                      "avg_launch_us": round(1e3 * top["ms"] / per, 2),
                      "share_of_kernel_time": round(top["ms"] / total_ms, 4),
                      "algorithmic_bytes_per_launch": top["bytes"] // per, "flops_per_launch": top["flops"] // per,
-                     "hbm_frac": round(frac_hbm, 4), "mfma_f32_frac": round(frac_mfma, 4)})
-        out["roofline"] = roof
+                     "hbm_frac": round(frac_hbm, 4), "mfma_frac": round(frac_mfma, 4)})
         # whole-step view: entry points (all shapes merged), algorithmic bytes / flops over the sum of their event times
         merged = {}
         for k, v in prof.items():
             m = merged.setdefault(k.split("|")[0], dict(calls=0, ms=0.0, bytes=0, flops=0))
             for f in ("calls", "ms", "bytes", "flops"):
                 m[f] += v[f]
+        fam_name, fam = max(merged.items(), key=lambda kv: kv[1]["ms"])
+        roof["family"] = {"kernel": fam_name, "ms_per_step": round(fam["ms"] / nprof, 3), "calls_per_step": fam["calls"] // nprof,
+                          "GB/s": round(fam["bytes"] / max(fam["ms"], 1e-9) / 1e6, 1),
+                          "TFLOP/s": round(fam["flops"] / max(fam["ms"], 1e-9) / 1e9, 2),
+                          "hbm_frac": round(fam["bytes"] / max(fam["ms"], 1e-9) / 1e6 / HBM_PEAK_GBS, 4),
+                          "share_of_kernel_time": round(fam["ms"] / total_ms, 4)}
+        # SURVEY.md 8(d) "attention path's HBM roofline": ideal-fusion bytes of the transformer blocks over the time the step
+        # spends in them = replayed step wall minus the event time of everything that is NOT a block kernel (patch embed /
+        # merging / expand, concat linears, final norms, head, loss, Adam); the serial sum of the block launches is given too.
+        pbytes, sigma = path_bytes(args.embed_dim, depths, vol, args.batch, e, nblock)
+        block_sum_ms = sum(v.get("block_ms", 0.0) for v in prof.values()) / nprof
+        other_ms = total_ms / nprof - block_sum_ms
+        t_block_ms = max(ms_step - other_ms, 1e-6)
+        roof["path"] = {"bound": "hbm", "algorithmic_bytes_per_step": int(pbytes), "sum_dTC": int(sigma), "elem_bytes": e,
+                        "t_block_kernels_ms": round(t_block_ms, 3), "block_launch_sum_ms": round(block_sum_ms, 3),
+                        "non_block_ms": round(other_ms, 3),
+                        "achieved": round(pbytes / (t_block_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(pbytes / (t_block_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+        out["roofline"] = roof
         tot_b = sum(v["bytes"] for v in prof.values())
         tot_f = sum(v["flops"] for v in prof.values())
         out["kernels"] = {k: {"ms_per_step": round(v["ms"] / nprof, 3), "calls_per_step": v["calls"] // nprof,
@@ -227,14 +301,18 @@ def main():
                                            "TFLOP/s": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2)}
                                        for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:60]}
         out["step_summary"] = {"kernel_ms_per_step": round(total_ms / nprof, 3), "launches_per_step": sum(v["calls"] for v in prof.values()) // nprof,
-                               "algorithmic_GB_per_step": round(tot_b / nprof / 1e9, 3), "GFLOP_per_step": round(tot_f / nprof / 1e9, 1)}
+                               "algorithmic_GB_per_step": round(tot_b / nprof / 1e9, 3), "GFLOP_per_step": round(tot_f / nprof / 1e9, 1),
+                               "whole_step_TFLOP/s": round(tot_f / nprof / (ms_step * 1e-3) / 1e12, 2),
+                               "whole_step_GB/s": round(tot_b / nprof / (ms_step * 1e-3) / 1e9, 1)}
 
-    if not args.no_cpu_baseline and world == 1:
-        out["cpu_baseline"] = cpu_baseline(vol, os.cpu_count() or 1)
-    elif not args.no_cpu_baseline:
-        out["cpu_baseline"] = None
-    print(json.dumps(out))
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1 and not stub:
+            out["cpu_baseline"] = cpu_baseline(vol, os.cpu_count() or 1)
+        elif not args.no_cpu_baseline:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

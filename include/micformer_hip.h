@@ -256,6 +256,16 @@ int micf_adam_tick(void* state, double base_lr, double eta_min, int64_t t_max, m
 int micf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const void* state, float beta1,
                    float beta2, float eps, float grad_scale, micf_stream_t stream);
 
+
+/* ---- step plumbing without ATen kernels.
+ * micf_zero: optimizer.zero_grad() over the flat gradient buffer (train.py:183) as ONE memset node. */
+int micf_zero(void* p, int64_t bytes, micf_stream_t stream);
+/* DropPath draws of a whole forward (timm drop_path, scale_by_keep=True; MS.py:419,424,517,522): out[i*B + b] =
+ * (u < keep[i]) / keep[i] with u ~ U[0,1) from a counter-based hash of (seed, call counter, i, b).
+ * rng = {uint64 seed; uint64 counter} on the device: the kernel advances the counter itself, so a captured
+ * graph draws fresh masks at every replay.  keep [n] (0 < keep <= 1), out [n*B]. */
+int micf_drop_path_draw(void* rng, const float* keep, float* out, int n, int B, micf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

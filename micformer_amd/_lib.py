@@ -66,6 +66,8 @@ SIGNATURES = {
     "micf_argmax_meandice": "pppppiilp",
     "micf_adam_tick": "pddlp",
     "micf_adam_step": "pppplpffffp",
+    "micf_zero": "plp",
+    "micf_drop_path_draw": "pppiip",
 }
 
 
@@ -132,6 +134,20 @@ def stream():
 # Optional per-entry-point timing with HIP events on the launch stream (bench.py's roofline leg).
 # PROFILE = None (off) or a dict  name -> [events [(start, end)], bytes, flops]
 PROFILE = None
+BLOCK_DEPTH = 0          # > 0 while a transformer-block Function is issuing launches (bench.py's path roofline)
+
+
+class block_region:
+    """Marks the launches issued inside as transformer-block kernels (SURVEY.md 8(d) `t_attention_kernels`)."""
+
+    def __enter__(self):
+        global BLOCK_DEPTH
+        BLOCK_DEPTH += 1
+
+    def __exit__(self, *exc):
+        global BLOCK_DEPTH
+        BLOCK_DEPTH -= 1
+        return False
 
 
 def call(name, *args, cost=None):
@@ -145,7 +161,7 @@ def call(name, *args, cost=None):
         e1.record()
         key = name if (cost is None or len(cost) < 3) else f"{name}|{cost[2]}"
         rec = PROFILE.setdefault(key, [[], 0, 0])
-        rec[0].append((e0, e1))
+        rec[0].append((e0, e1, BLOCK_DEPTH > 0))
         if cost is not None:
             rec[1] += cost[0]
             rec[2] += cost[1]
@@ -165,7 +181,8 @@ def profile_stop():
     torch.cuda.synchronize()
     out = {}
     for name, (evs, nbytes, flops) in (prof or {}).items():
-        out[name] = dict(calls=len(evs), ms=sum(a.elapsed_time(b) for a, b in evs), bytes=nbytes, flops=flops)
+        ms = [(a.elapsed_time(b), blk) for a, b, blk in evs]
+        out[name] = dict(calls=len(evs), ms=sum(m for m, _ in ms), bytes=nbytes, flops=flops, block_ms=sum(m for m, blk in ms if blk))
     return out
 
 

@@ -5,6 +5,8 @@
 // of dy and its 6x10x10 halo of a 24-channel input chunk in LDS ONCE and lets every thread own a (tap, 4-channel) slice of
 // the gradient: 4c x N accumulators in registers, one 16-byte LDS read of the input + N/4 broadcast reads of dy per token
 // for 4*N FMAs.  A workgroup walks many token tiles before flushing its partial with atomicAdd.
+#include <mutex>
+
 #include "common.h"
 
 namespace micf {
@@ -143,12 +145,11 @@ int conv3_wgrad_direct(const float* dy, int dy_layout, const float* x1, int c1, 
   const int tpb = (ntiles + groups - 1) / groups;
   groups = (ntiles + tpb - 1) / tpb;
   const size_t smem = sizeof(float) * (kHaloTok * kCC + kTileTok * N);
-  static bool attr_set = false;          // > 64 KiB of dynamic LDS needs the opt-in once per process (not a stream operation)
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgrad_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgrad_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    attr_set = true;
-  }
+  static std::once_flag attr_once;       // > 64 KiB of dynamic LDS needs the opt-in once per process (not a stream operation)
+  std::call_once(attr_once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgrad_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgrad_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  });
   dim3 grid(chunks, groups);
   if (N == 8) {
     hipLaunchKernelGGL(conv3_wgrad_kernel<8>, grid, dim3(256), smem, stream, dy, dy_layout, x1, c1, x2 ? x2 : x1, c2,

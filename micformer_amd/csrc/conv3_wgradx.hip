@@ -10,6 +10,8 @@
 // and every MFMA then costs exactly one 4-byte LDS read.  Partial slabs go to a workspace with coalesced 16-byte stores
 // and a second kernel sums them over the workgroups and scatters into the [N][Cin][27] layout (+=).
 // The LDS-tiled VALU kernel this replaces (conv3_wgrad.hip) reached 28 TFLOP/s at the 32^3 x 2 stage.
+#include <mutex>
+
 #include "common.h"
 
 namespace micf {
@@ -219,12 +221,11 @@ int conv3_wgradx(const float* dy, const float* x1, int c1, const float* x2, int 
   const int th = 64 / p.tw;
   a.tiles_d = D; a.tiles_h = (H + th - 1) / th; a.tiles_w = (W + p.tw - 1) / p.tw;
   a.tiles_per_group = p.tiles_per_group; a.groups = p.groups;
-  static bool attr_set = false;          // > 64 KiB of dynamic LDS needs the opt-in once per process
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgradx_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgradx_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    attr_set = true;
-  }
+  static std::once_flag attr_once;       // > 64 KiB of dynamic LDS needs the opt-in once per process
+  std::call_once(attr_once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgradx_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgradx_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+  });
   const dim3 grid(p.slabs, p.groups);
   if (p.tw == 16) {
     constexpr int HALO = 3 * (4 + 2) * (16 + 2);

@@ -23,6 +23,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "gemm_core.h"
 
 namespace micf {
@@ -349,12 +351,11 @@ inline hipError_t launch_gemm_dma(DmaOperand P, DmaOperand Q, Epi epi, int I, in
     // of the chip idles.  The skinny variant cuts the tile to 64 x 16 and splits the reduction over the 4 waves.
     if (splits == 1 && blocks <= kSkinnyMaxBlocks && R >= 64) {
       const int64_t sblocks = (int64_t)tiles_i * ceil_div(J, 16);
-      static bool attr_done = false;
-      if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dma_skinny_kernel<PX, Epi>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, kSkinnyLds) != hipSuccess) return hipGetLastError();
-        attr_done = true;
-      }
+      static std::once_flag attr_once;      // per instantiation; std::call_once keeps the C-ABI re-entrant from several host threads
+      std::call_once(attr_once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dma_skinny_kernel<PX, Epi>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kSkinnyLds);
+      });
       hipLaunchKernelGGL((gemm_dma_skinny_kernel<PX, Epi>), dim3((unsigned)((sblocks + 7) / 8 * 8)), dim3(256), kSkinnyLds, stream,
                          P, Q, epi, I, (int)J, R, tiles_i, (int)sblocks);
       return hipGetLastError();

@@ -86,9 +86,9 @@ __global__ void __launch_bounds__(256) argmax_count_kernel(const float* __restri
     for (int c = 1; c < K; ++c) { const float v = zp[(int64_t)c * V]; if (v > best) { best = v; arg = c; } }   // first max wins (torch.argmax)
     if (mask) mask[i] = (uint8_t)arg;
     if (label) {
-      const int l = label[i];
+      const int l = label[i];             // labels >= K (e.g. a 255 ignore index) belong to no class: counted nowhere
       atomicAdd(&sc[arg], 1u);
-      atomicAdd(&sc[32 + l], 1u);
+      if (l < K) atomicAdd(&sc[32 + l], 1u);
       if (l == arg) atomicAdd(&sc[64 + arg], 1u);
     }
   }

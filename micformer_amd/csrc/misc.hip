@@ -158,3 +158,38 @@ extern "C" int micf_sw_normalize(float* out, const float* count, int K, int64_t 
   hipLaunchKernelGGL(sw_normalize_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, out, count, V, total);
   MICF_RETURN_LAUNCH();
 }
+
+// ---- step plumbing
+extern "C" int micf_zero(void* p, int64_t bytes, micf_stream_t stream) {
+  if (!p || bytes < 0) return MICF_EINVAL;
+  if (bytes == 0) return MICF_OK;
+  return hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)stream) == hipSuccess ? MICF_OK : MICF_ELAUNCH;
+}
+
+namespace micf {
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {      // splitmix64 finaliser
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__global__ void __launch_bounds__(256) drop_path_draw_kernel(uint64_t* __restrict__ rng, const float* __restrict__ keep,
+                                                             float* __restrict__ out, int n, int B) {
+  const uint64_t seed = rng[0], ctr = rng[1];
+  for (int e = threadIdx.x; e < n * B; e += 256) {
+    const float k = keep[e / B];
+    const uint64_t h = mix64(mix64(seed ^ mix64(ctr)) + (uint64_t)e);
+    const float u = (float)(h >> 40) * (1.0f / 16777216.0f);          // 24 random bits -> [0, 1)
+    out[e] = (u < k) ? 1.0f / k : 0.0f;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) rng[1] = ctr + 1;
+}
+}  // namespace micf
+
+extern "C" int micf_drop_path_draw(void* rng, const float* keep, float* out, int n, int B, micf_stream_t stream) {
+  if (!rng || !keep || !out || n < 0 || B <= 0) return MICF_EINVAL;
+  if (n == 0) return MICF_OK;
+  hipLaunchKernelGGL(micf::drop_path_draw_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, static_cast<uint64_t*>(rng), keep, out, n, B);
+  MICF_RETURN_LAUNCH();
+}

@@ -24,17 +24,6 @@ class FlatGradSync:
         if self.world > 1:
             dist.broadcast(flat_params, src=src, group=self.pg)
 
-    def allreduce_mean_(self, flat_grads):
-        """In place: flat_grads <- sum over ranks / world, issued as a few large async buckets."""
-        if self.world <= 1:
-            return flat_grads
-        works = [dist.all_reduce(flat_grads[s:s + self.bucket_elems], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-                 for s in range(0, flat_grads.numel(), self.bucket_elems)]
-        for w in works:
-            w.wait()
-        flat_grads.div_(self.world)
-        return flat_grads
-
     def allreduce_sum_async(self, view):
         """Start sum-all-reduce of one contiguous slice of the flat gradient; returns a work handle (None on one rank).
         torch.distributed orders it after everything already enqueued on the current stream and runs it on the backend's own
@@ -86,3 +75,39 @@ def last_writer_per_bucket(buckets, writes):
         for b in range(lo, hi + 1):
             last[b] = max(last[b], gi)
     return last
+
+
+
+class OverlappedGradReduce:
+    """The data-parallel tail of a step, device-agnostic: the queued weight-gradient launches are issued group by
+    group and every slice of the flat gradient is sum-all-reduced right after the launch that writes into it last (slices
+    nothing queued writes to go first), so the collective runs under the remaining launches; then the optimiser consumes
+    the SUM with grad_scale = 1/world (the mean is never materialised).  TrainEngine drives it with HIP launches + RCCL;
+    tests/test_dist_gloo.py drives the same object with CPU tensors + gloo."""
+
+    def __init__(self, sync, flat_g, buckets, bucket_last):
+        self.sync, self.flat_g = sync, flat_g
+        self.buckets, self.bucket_last = list(buckets), list(bucket_last)
+
+    def _reduce_ready(self, gi, works):
+        for (a, b), last in zip(self.buckets, self.bucket_last):
+            if last == gi:
+                w = self.sync.allreduce_sum_async(self.flat_g[a:b])
+                if w is not None:
+                    works.append(w)
+
+    def run(self, ngroups, launch_group, pre=None):
+        works = []
+        if pre is not None:
+            pre()
+        self._reduce_ready(-1, works)
+        for gi in range(ngroups):
+            launch_group(gi)
+            self._reduce_ready(gi, works)
+        for w in works:
+            w.wait()
+
+    def step_tail(self, ngroups, launch_group, optimizer_step, pre=None):
+        """flush + reduce, then optimizer_step(grad_scale) with grad_scale = 1 / world."""
+        self.run(ngroups, launch_group, pre)
+        optimizer_step(1.0 / self.sync.world)

@@ -16,7 +16,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops
-from .dist import FlatGradSync, flatten_views, last_writer_per_bucket, module_buckets
+from .dist import FlatGradSync, OverlappedGradReduce, flatten_views, last_writer_per_bucket, module_buckets
 from .loss.dice import MDiceLoss
 
 
@@ -33,10 +33,11 @@ class TrainEngine:
         self._flatten()
         self.sync.broadcast_params(self.flat_p)                    # rank-identical initial weights
         # the CT and MR branches of every depth slot are independent: issue them on two streams (see BasicLayer.forward)
-        from . import functional as _fn
-        from .models import MICFormer_self as _ms
-        _ms.PARALLEL_MODALITIES = bool(parallel_modalities)
-        _fn.DEFER_WGRAD = bool(defer_wgrad)      # linear weight gradients: queued in backward, one grouped flush
+        # Both switches are process-global module flags of functional / models: the engine sets them only for the duration of
+        # its own forward + backward (see _scoped_flags) so a manual loss.backward(), a second model or a gradient check
+        # outside step() still gets its weight gradients computed in place.
+        self.parallel_modalities = bool(parallel_modalities)
+        self.defer_wgrad = bool(defer_wgrad)     # linear weight gradients: queued in backward, one grouped flush
         # Data parallel (or split_step=True, a single-GPU test hook): the graph holds forward + backward only; the queued weight
         # gradients are then launched group by group and every gradient slice is all-reduced as soon as its last writer is
         # done, overlapping RCCL with the remaining weight-gradient launches (see _flush_and_reduce).
@@ -90,22 +91,44 @@ class TrainEngine:
         self.adam_state = ops.adam_state(dev)
 
     # ------------------------------------------------------------------ one optimisation step
+    def _scoped_flags(self):
+        """Context manager: this engine's launch-layout switches are in force inside, the previous values outside."""
+        import contextlib
+        from . import functional as _fn
+        from .models import MICFormer_self as _ms
+
+        @contextlib.contextmanager
+        def scope():
+            prev = (_ms.PARALLEL_MODALITIES, _fn.DEFER_WGRAD)
+            _ms.PARALLEL_MODALITIES, _fn.DEFER_WGRAD = self.parallel_modalities, self.defer_wgrad
+            try:
+                yield
+            finally:
+                _ms.PARALLEL_MODALITIES, _fn.DEFER_WGRAD = prev
+        return scope()
+
     def _fwd_bwd(self, x, target, flush=True):
-        self.flat_g.zero_()                                         # optimizer.zero_grad()        train.py:183
-        logits = self.model(x)                                      #                              train.py:185
-        loss = self.criterion(logits, target)                       #                              train.py:187
-        loss.backward()                                             #                              train.py:200
-        if flush:
-            from . import functional as _fn
-            _fn.flush_wgrad()                                       # queued linear weight gradients, grouped launches
+        from . import functional as _fn
+        _fn.drop_deferred()                                         # nothing left over from a backward that raised
+        with self._scoped_flags():
+            ops.zero_(self.flat_g)                                  # optimizer.zero_grad()        train.py:183
+            logits = self.model(x)                                  #                              train.py:185
+            loss = self.criterion(logits, target)                   #                              train.py:187
+            loss.backward()                                         #                              train.py:200
+            if flush:
+                _fn.flush_wgrad()                                   # queued linear weight gradients, grouped launches
         return loss.detach()
 
-    def _update(self, reduced=False):
-        if self.world > 1 and not reduced:
-            self._allreduce_grads(mean=False)
+    def _adam(self, grad_scale):
         ops.adam_tick(self.adam_state, self.base_lr, self.eta_min, self.t_max)   # scheduler (per iteration) train.py:206-207
         ops.adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.adam_state,
-                      self.betas[0], self.betas[1], self.eps, grad_scale=1.0 / self.world)   # optimizer.step()   train.py:201
+                      self.betas[0], self.betas[1], self.eps, grad_scale=grad_scale)          # optimizer.step()   train.py:201
+
+    def _update(self):
+        """Un-overlapped form (eager steps): all-reduce(sum) the whole flat gradient, then Adam reads it as g / world."""
+        if self.world > 1:
+            self._allreduce_grads()
+        self._adam(1.0 / self.world)
 
     # ------------------------------------------------------------------ data-parallel tail of a replayed step
     def _plan_split(self, items, ln_items=()):
@@ -123,45 +146,49 @@ class TrainEngine:
                 if t is not None:
                     writes.append((k // ops.GROUP_ITEMS, (t.data_ptr() - base) // 4, t.numel()))
         self._bucket_last = last_writer_per_bucket(self._buckets, writes)
+        self._overlap = OverlappedGradReduce(self.sync, self.flat_g, self._buckets, self._bucket_last)
 
-    def _flush_and_reduce(self):
+    def _flush_and_reduce(self, then_update=False):
         """Launch the queued weight gradients group by group; all-reduce every slice of the flat gradient right after the
-        launch that completes it (slices nothing queued writes to go first), so RCCL runs under the remaining launches."""
+        launch that completes it (slices nothing queued writes to go first), so RCCL runs under the remaining launches
+        (dist.OverlappedGradReduce -- the same object the 2-rank gloo test drives on CPU)."""
+        from ._lib import block_region
         plan = self._wplan
         ngroups = (plan.n + ops.GROUP_ITEMS - 1) // ops.GROUP_ITEMS
-        works = []
-        self._lnplan.launch()
-        def reduce_ready(gi):
-            for (a, b), last in zip(self._buckets, self._bucket_last):
-                if last == gi:
-                    w = self.sync.allreduce_sum_async(self.flat_g[a:b])
-                    if w is not None:
-                        works.append(w)
-        reduce_ready(-1)
-        for gi in range(ngroups):
-            plan.launch(gi * ops.GROUP_ITEMS, min(ops.GROUP_ITEMS, plan.n - gi * ops.GROUP_ITEMS))
-            reduce_ready(gi)
-        for w in works:
-            w.wait()
+
+        def launch_group(gi):
+            with block_region():
+                plan.launch(gi * ops.GROUP_ITEMS, min(ops.GROUP_ITEMS, plan.n - gi * ops.GROUP_ITEMS))
+
+        def pre():
+            with block_region():
+                self._lnplan.launch()
+
+        if then_update:
+            self._overlap.step_tail(ngroups, launch_group, self._adam, pre)
+        else:
+            self._overlap.run(ngroups, launch_group, pre)
 
     def _step_impl(self, x, target):
         loss = self._fwd_bwd(x, target)
         self._update()
         return loss
 
-    def _allreduce_grads(self, mean=True):
+    def _allreduce_grads(self):
         """Gradient all-reduce(sum) over RCCL/xGMI in a few large buckets of the flat buffer (the 1/world goes into Adam)."""
         works = [self.sync.allreduce_sum_async(self.flat_g[s:s + self.sync.bucket_elems])
                  for s in range(0, self.flat_g.numel(), self.sync.bucket_elems)]
         for w in works:
             if w is not None:
                 w.wait()
-        if mean and self.world > 1:
-            self.flat_g.div_(self.world)
 
     def step(self, x, target):
         """Run one training step; returns the (device) loss of this rank's batch."""
         if not self.use_graph:
+            loss = self._step_impl(x, target)
+        elif self._graph is not None and not self._matches_static(x, target):
+            # e.g. the smaller last batch of an epoch (the reference's loader has drop_last=False): the captured graph bakes in
+            # the shapes, so this batch runs eagerly (same kernels, same update) instead of being broadcast into the static buffers
             loss = self._step_impl(x, target)
         else:
             if self._graph is None:
@@ -170,23 +197,36 @@ class TrainEngine:
             self._static[1].copy_(target, non_blocking=True)
             self._graph.replay()
             if self.split_step:                                     # weight-gradient groups, RCCL and Adam stay outside the graph
-                self._flush_and_reduce()
-                self._update(reduced=True)
+                self._flush_and_reduce(then_update=True)
             loss = self._static[2]
         self.steps_done += 1
         return loss
 
+    def _matches_static(self, x, target):
+        sx, st = self._static[0], self._static[1]
+        return x.shape == sx.shape and target.shape == st.shape and x.dtype == sx.dtype and target.dtype == st.dtype
+
     def _capture(self, x, target):
-        """Warm up eagerly on a side stream (3 real steps), then capture ONE step into a HIP graph."""
+        """Warm up eagerly on a side stream, then capture ONE step into a HIP graph.  The warm-up runs real kernels (it sizes the
+        scratch buffers and the allocator pools) but must not train: parameters, Adam moments, the device step counter / LR and
+        the RNG streams are snapshotted before and restored after, so the first step() applies exactly one update to its batch
+        (the reference does one optimizer.step() + scheduler.step() per batch, train.py:200-207)."""
         sx, st = x.clone(), target.clone()
+        keep = [t.clone() for t in (self.flat_p, self.flat_m, self.flat_v, self.adam_state)]
+        rng_cpu, rng_dev = torch.get_rng_state(), torch.cuda.get_rng_state(sx.device)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(3):
+            for _ in range(2):
                 self._step_impl(sx, st)
-                self.steps_done += 1
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        with torch.no_grad():
+            for dst, src in zip((self.flat_p, self.flat_m, self.flat_v, self.adam_state), keep):
+                dst.copy_(src)
+        torch.set_rng_state(rng_cpu)
+        torch.cuda.set_rng_state(rng_dev, sx.device)
+        del keep
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             # single GPU: the whole step; data parallel: forward + backward only (weight-gradient groups, collective and Adam
@@ -207,7 +247,7 @@ class TrainEngine:
             for i, (o, n, p) in enumerate(zip(self.offsets, self.sizes, self.params)):
                 state[i] = {"step": torch.tensor(float(step)), "exp_avg": self.flat_m[o:o + n].view(p.shape).clone(),
                             "exp_avg_sq": self.flat_v[o:o + n].view(p.shape).clone()}
-        group = {"lr": self.lr() if step > 0 else self.base_lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0,
+        group = {"lr": self.scheduled_lr(step), "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0,
                  "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
                  "fused": None, "initial_lr": self.base_lr, "params": list(range(len(self.params)))}
         return {"state": state, "param_groups": [group]}
@@ -233,7 +273,7 @@ class TrainEngine:
         """CosineAnnealingLR.state_dict() layout (stepped once per iteration, train.py:148, 206-207)."""
         step = int(self.adam_state[0].item())
         return {"T_max": self.t_max, "eta_min": self.eta_min, "base_lrs": [self.base_lr], "last_epoch": step,
-                "_step_count": step + 1, "_last_lr": [self.lr() if step > 0 else self.base_lr]}
+                "_step_count": step + 1, "_last_lr": [self.scheduled_lr(step)]}
 
     def load_scheduler_state_dict(self, sd):
         self.t_max, self.eta_min = sd["T_max"], sd["eta_min"]
@@ -262,5 +302,12 @@ class TrainEngine:
 
     # ------------------------------------------------------------------ helpers
     def lr(self):
+        """The learning rate the LAST optimiser step used (device-side schedule: cosine at scheduler epoch step - 1)."""
         st = self.adam_state.cpu()
         return float(st[1:2].view(torch.float64)[0])
+
+    def scheduled_lr(self, epoch):
+        """CosineAnnealingLR closed form at scheduler epoch `epoch`: after N iterations torch has called scheduler.step() N
+        times, so param_groups[0]['lr'] and _last_lr hold cosine(N) -- the rate the NEXT step will use (train.py:206-207)."""
+        import math
+        return self.eta_min + (self.base_lr - self.eta_min) * (1.0 + math.cos(math.pi * epoch / self.t_max)) / 2.0

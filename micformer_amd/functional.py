@@ -5,8 +5,20 @@ state_dict layout.  Parameter gradients are accumulated by the kernels into zero
 import torch
 
 from . import ops
+from ._lib import block_region
 
 _zl = torch.zeros_like
+
+
+def _in_block(fn):
+    """Decorator: the launches of this forward / backward are transformer-block kernels (profiler region tag)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*a, **k):
+        with block_region():
+            return fn(*a, **k)
+    return wrapped
 
 
 def effective_window(dims, window):
@@ -56,11 +68,20 @@ def take_deferred():
     return items, ln
 
 
+def drop_deferred():
+    """Forget anything still queued (TrainEngine calls this at the start of a step: entries left behind by a backward that
+    raised must not be flushed into the next step's gradients)."""
+    _DEFERRED.clear()
+    _DEFERRED_LN.clear()
+    _QUEUED_DW.clear()
+
+
 def _ln_defer(on):
     """The list LayerNorm backward should queue its parameter-gradient partials in, or None (accumulate immediately)."""
     return _DEFERRED_LN if (on and DEFER_WGRAD) else None
 
 
+@_in_block
 def flush_wgrad():
     """Launch every queued weight gradient on the current stream (which must be ordered after their producers)."""
     if _DEFERRED_LN:
@@ -72,19 +93,6 @@ def flush_wgrad():
         _DEFERRED.clear()
         _QUEUED_DW.clear()
         ops.linear_bwd_weight_grouped(items)
-
-
-class _wgrad:
-    """Placeholder context (kept so the conv weight-gradient call sites read the same)."""
-
-    def __init__(self, on, *tensors):
-        pass
-
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *exc):
-        return False
 
 
 def _targets(params):
@@ -211,6 +219,7 @@ def _packed_qkv(P, G):
 # ============================================================================= TransformerBlock3D (MS.py:430-524)
 class SelfBlockFn(torch.autograd.Function):
     @staticmethod
+    @_in_block
     def forward(ctx, x, s1, s2, heads, window, eps, *params):
         P = dict(zip(SELF_KEYS, params))
         x = _c(x)
@@ -246,6 +255,7 @@ class SelfBlockFn(torch.autograd.Function):
         return y.reshape(x.shape)
 
     @staticmethod
+    @_in_block
     def backward(ctx, dy):
         sv = ctx.saved_tensors
         xf, m1, r1, xnp, q, kv, o, x1, s1, s2 = sv[:10]
@@ -286,6 +296,7 @@ class SelfBlockFn(torch.autograd.Function):
 # ============================================================================= CrossTransformerBlock3D (MS.py:277-426)
 class CrossBlockFn(torch.autograd.Function):
     @staticmethod
+    @_in_block
     def forward(ctx, x, xa, s1, s2, heads, window, eps, *params):
         P = dict(zip(CROSS_KEYS, params))
         x, xa = _c(x), _c(xa)
@@ -319,6 +330,7 @@ class CrossBlockFn(torch.autograd.Function):
         return y.reshape(x.shape)
 
     @staticmethod
+    @_in_block
     def backward(ctx, dy):
         sv = ctx.saved_tensors
         xf, m1, r1, xnp, xap, hid, flow, xs, q, kv, o, x1, s1, s2 = sv[:14]
@@ -347,8 +359,7 @@ class CrossBlockFn(torch.autograd.Function):
         dhid = ops.offset_sample_bwd(dxs, hid, P["conv_offset.1.norm.weight"], P["conv_offset.1.norm.bias"],
                                      P["conv_offset.3.weight"], xap, flow, dxap, G["conv_offset.1.norm.weight"],
                                      G["conv_offset.1.norm.bias"], G["conv_offset.3.weight"], pdims, eps)
-        with _wgrad(side, dhid, xnp, xap):
-            ops.conv3_bwd_weight(dhid, xnp, G["conv_offset.0.weight"], G["conv_offset.0.bias"], pdims, x2=xap)
+        ops.conv3_bwd_weight(dhid, xnp, G["conv_offset.0.weight"], G["conv_offset.0.bias"], pdims, x2=xap)
         ops.conv3_bwd_data(dhid, P["conv_offset.0.weight"], pdims, C, C, dx1=dxnp, dx2=dxap, acc1=True, acc2=True)
         if padded:
             dxn = ops.crop3d(dxnp, dims, pd)
@@ -399,8 +410,7 @@ class ConvDownFn(torch.autograd.Function):
         dy = _c(dy)
         dw = _grad_buf(ctx.tg[0], w)
         db = ctx.tg[1] if ctx.tg[1] is not None else torch.zeros(w.shape[0], dtype=w.dtype, device=w.device)
-        with _wgrad(ctx.tg[0] is not None and ctx.tg[1] is not None, dy, x):
-            ops.conv_down_bwd_weight(dy, x, dw, db)
+        ops.conv_down_bwd_weight(dy, x, dw, db)
         return ops.conv_down_bwd_data(dy, w, tuple(x.shape)), _ret(ctx.tg[0], dw), _ret(ctx.tg[1], db)
 
 
@@ -421,8 +431,7 @@ class ConvUpFn(torch.autograd.Function):
         dy = _c(dy)
         dw = _grad_buf(ctx.tg[0], w)
         db = ctx.tg[1] if ctx.tg[1] is not None else torch.zeros(w.shape[1], dtype=w.dtype, device=w.device)
-        with _wgrad(ctx.tg[0] is not None and ctx.tg[1] is not None, dy, x):
-            ops.conv_up_bwd_weight(dy, x, dw, db, ctx.k)
+        ops.conv_up_bwd_weight(dy, x, dw, db, ctx.k)
         return ops.conv_up_bwd_data(dy, w, tuple(x.shape), ctx.k), _ret(ctx.tg[0], dw), _ret(ctx.tg[1], db), None
 
 
@@ -445,8 +454,7 @@ class OutConvFn(torch.autograd.Function):
         dw = _grad_buf(ctx.tg[0], w)
         db = ctx.tg[1] if ctx.tg[1] is not None else torch.zeros(w.shape[0], dtype=w.dtype, device=w.device)
         f2 = feat.reshape(-1, C)
-        with _wgrad(ctx.tg[0] is not None and ctx.tg[1] is not None, dy, f2):
-            ops.conv3_bwd_weight(dy, f2, dw, db, (B, D, H, W), ncdhw=True)
+        ops.conv3_bwd_weight(dy, f2, dw, db, (B, D, H, W), ncdhw=True)
         dx, _ = ops.conv3_bwd_data(dy, w, (B, D, H, W), C, 0, ncdhw=True)
         return dx.reshape(feat.shape), _ret(ctx.tg[0], dw), _ret(ctx.tg[1], db)
 

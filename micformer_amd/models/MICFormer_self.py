@@ -242,8 +242,8 @@ def _side_stream(device):
 def _block_scales(block, x):
     """The two DropPath draws of a block (part1, part2).  MicFormer pre-draws all of them in one batched RNG call per
     forward (`_predraw_drop_path`); a standalone block draws its own."""
-    pre = block.__dict__.pop("_pending_scales", None)
-    if pre is not None:
+    pre = block.__dict__.pop("_pending_scales", None)       # (always popped: a stale draw must not outlive its forward)
+    if pre is not None and block.training:
         return pre
     B = x.shape[0]
     return block.drop_path.sample_scale(B, x.device), block.drop_path.sample_scale(B, x.device)
@@ -501,13 +501,16 @@ class MicFormer(nn.Module):
                   and isinstance(b.drop_path, DropPath) and b.drop_path.drop_prob > 0.0]
         if not self.training or not blocks:
             return
-        cache = self.__dict__.setdefault("_dp_keep_cache", {})          # device-resident keep-probabilities (not a buffer:
-        keep = cache.get(device)                                        # state_dict stays the reference's)
-        if keep is None or keep.shape[0] != 2 * len(blocks):
-            keep = torch.tensor([1.0 - b.drop_path.drop_prob for b in blocks for _ in (0, 1)],
-                                dtype=torch.float32).unsqueeze(1).to(device)
-            cache[device] = keep
-        s = (torch.rand(keep.shape[0], batch, device=device) < keep).float() / keep
+        cache = self.__dict__.setdefault("_dp_keep_cache", {})          # device-resident keep-probabilities + RNG state (not
+        ent = cache.get(device)                                         # buffers: state_dict stays the reference's)
+        if ent is None or ent[0].shape[0] != 2 * len(blocks):
+            from .. import ops
+            keep = torch.tensor([1.0 - b.drop_path.drop_prob for b in blocks for _ in (0, 1)], dtype=torch.float32).to(device)
+            # seeded from torch's CPU generator: torch.manual_seed(1234 + rank) makes the DropPath stream rank-distinct
+            ent = (keep, ops.drop_path_rng(device, int(torch.randint(0, 2 ** 62, (1,)).item())))
+            cache[device] = ent
+        from .. import ops
+        s = ops.drop_path_draw(ent[1], ent[0], batch)                   # ONE launch; the device counter advances per replay
         for i, b in enumerate(blocks):
             b.__dict__["_pending_scales"] = (s[2 * i], s[2 * i + 1])
 

@@ -13,6 +13,23 @@ from ._lib import call, f32, ptr
 
 DETAIL = False   # profiler: key entries by shape as well as by entry point
 
+# Arithmetic of the matrix-core products (include/micformer_hip.h micf_dtype): "fp32" = v_mfma_f32_16x16x4_f32, exact (the
+# parity mode); "bf16" = v_mfma_f32_16x16x32_bf16 operands rounded to bf16 at the fragment read, fp32 accumulation.
+_COMPUTE_DTYPE = "fp32"
+
+
+def compute_dtype():
+    return _COMPUTE_DTYPE
+
+
+def set_compute_dtype(name):
+    global _COMPUTE_DTYPE
+    if name not in ("fp32", "bf16"):
+        raise ValueError("compute dtype must be 'fp32' or 'bf16'")
+    if name == "bf16" and not hasattr(_lib.lib, "micf_set_dtype"):
+        raise _lib.MicfError("this build of libmicformer_hip.so has no bf16 mode")
+    _COMPUTE_DTYPE = name
+
 
 def _cost(flops, *tensors, tag=None):
     """(algorithmic bytes, flops[, shape tag]) of one launch for bench.py's profiler: every listed tensor is moved once."""
@@ -513,3 +530,23 @@ def adam_step(p, g, m, v, state, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.
     call("micf_adam_step", f32(p), f32(g), f32(m), f32(v), p.numel(), ptr(state), float(beta1), float(beta2), float(eps),
          float(grad_scale),
          cost=_cost(12 * p.numel(), p, p, g, m, m, v, v))
+
+
+# ----------------------------------------------------------------------------- step plumbing
+def zero_(t):
+    """In-place zero fill as one memset node (optimizer.zero_grad() over the flat gradient buffer)."""
+    call("micf_zero", ptr(t), t.numel() * t.element_size())
+    return t
+
+
+def drop_path_rng(device, seed):
+    """{uint64 seed; uint64 counter} on the device for micf_drop_path_draw."""
+    return torch.tensor([int(seed) & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=device)
+
+
+def drop_path_draw(rng, keep, batch):
+    """keep [n] fp32 keep-probabilities -> [n, batch] per-sample scales (mask / keep); advances the device counter."""
+    n = keep.numel()
+    out = _new(keep, n, batch)
+    call("micf_drop_path_draw", ptr(rng), f32(keep), f32(out), n, batch)
+    return out

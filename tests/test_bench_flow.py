@@ -1,0 +1,51 @@
+"""bench.py at N > 1: every rank must stay in every leg (timed region, roofline leg, final barrier) so that no rank issues a
+collective its peers never join (the round-1 script returned on ranks != 0 before rank 0's eager roofline steps all-reduced).
+Runs the REAL bench.py control flow on CPU with 2 gloo ranks and a stub engine (--cpu-stub: same collectives, no kernels)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(nproc, extra=()):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "3", "--warmup", "1",
+           "--cpu-stub", *extra]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env, cwd=ROOT)
+
+
+@pytest.mark.timeout(300)
+def test_bench_two_ranks_complete_with_roofline_leg():
+    r = _run(2)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                       # exactly one JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
+    assert "roofline" in out and "path" in out["roofline"] and "family" in out["roofline"]
+    assert out["cpu_baseline"] is None                     # N > 1: the CPU leg is a rank-0, N = 1 item
+
+
+@pytest.mark.timeout(300)
+def test_bench_single_process_stub_and_no_roofline():
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "0", "--cpu-stub", "--no-roofline",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 1 and "roofline" not in out and "cpu_baseline" not in out

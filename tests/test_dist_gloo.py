@@ -1,7 +1,10 @@
-"""N > 1 path on CPU: two gloo processes exercise the SAME gradient-exchange code the engine uses on RCCL
-(micformer_amd.dist.FlatGradSync) with the CPU oracle standing in for the model: the 2-rank result must equal the 1-rank
-result on the concatenated batch under the per-rank-loss definition, weights must stay rank-identical,
-and the unused parameters (concat_back_dim.0.*) must survive as exact zeros in the flat bucket."""
+"""N > 1 path on CPU: two gloo processes drive the SAME objects TrainEngine drives on RCCL -- dist.FlatGradSync,
+dist.module_buckets / last_writer_per_bucket (the per-stage slice plan) and dist.OverlappedGradReduce.step_tail (grouped
+weight-gradient launches interleaved with per-slice sum all-reduces, then the optimiser with grad_scale = 1/world) -- with the
+CPU oracle standing in for the model and a torch restatement of the fused Adam standing in for micf_adam_step: the 2-rank
+result (gradient SUM in the flat buffer, post-Adam weights) must equal the 1-rank result on the concatenated batch under the
+per-rank-loss definition, weights must stay rank-identical, and the unused parameters
+(concat_back_dim.0.*) must survive as exact zeros in the flat bucket."""
 import os
 import socket
 import sys
@@ -45,6 +48,49 @@ def _flat_grads(R, cfg, P, x, t, names, offs, total):
     return loss.detach(), flat
 
 
+def _adam(p, g, m, v, step, lr, grad_scale, b1=0.9, b2=0.999, eps=1e-8):
+    """torch restatement of micf_adam_step (csrc/loss_optim.hip): the gradient is read as grad_scale * g."""
+    g = g * grad_scale
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    p.addcdiv_(m / (1 - b1 ** step), (v / (1 - b2 ** step)).sqrt_().add_(eps), value=-lr)
+
+
+def _engine_tail(flat_g_backward, deferred, names, offs, sizes, total, flat_p, world_sync, group_items=3):
+    """What TrainEngine.step does after the replayed forward + backward (engine._plan_split / _flush_and_reduce): `flat_g_backward`
+    holds what backward itself wrote; `deferred` = [(offset, values)] are the queued weight gradients, launched in groups of
+    `group_items`; every per-stage slice is all-reduced after its last writer; Adam consumes the sum with 1/world."""
+    from micformer_amd.dist import OverlappedGradReduce, last_writer_per_bucket, module_buckets
+    flat_g = flat_g_backward.clone()
+    buckets = module_buckets(names, offs, sizes, total, min_elems=20000)
+    writes = [(k // group_items, off, vals.numel()) for k, (off, vals) in enumerate(deferred)]
+    last = last_writer_per_bucket(buckets, writes)
+    ov = OverlappedGradReduce(world_sync, flat_g, buckets, last)
+    ngroups = (len(deferred) + group_items - 1) // group_items
+    issued = []
+
+    def launch_group(gi):
+        for off, vals in deferred[gi * group_items:(gi + 1) * group_items]:
+            flat_g[off:off + vals.numel()] += vals                  # the grouped kernel accumulates into the flat buffer
+        issued.append(gi)
+
+    m, v = torch.zeros(total), torch.zeros(total)
+    ov.step_tail(ngroups, launch_group, lambda gs: _adam(flat_p, flat_g, m, v, 1, 1e-2, gs))
+    assert issued == list(range(ngroups))
+    return flat_g, len(buckets), last
+
+
+def _split_deferred(flat, names, offs, sizes):
+    """Mimic the engine: the nn.Linear weight gradients are queued (deferred), everything else is written by backward."""
+    backward = flat.clone()
+    deferred = []
+    for n, o, sz in zip(names, offs, sizes):
+        if n.endswith(".weight") and (".mlp." in n or "attn." in n) and ".norm" not in n:
+            deferred.append((o, flat[o:o + sz].clone()))
+            backward[o:o + sz] = 0
+    return backward, deferred
+
+
 def _worker(rank, world, port, out):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -55,6 +101,7 @@ def _worker(rank, world, port, out):
     cfg, P, x, t, R = _tiny_setup()
     names = list(P)
     offs, total = flatten_views([P[n] for n in names])
+    sizes = [P[n].numel() for n in names]
     sync = FlatGradSync(bucket_bytes=1 << 20)                # several buckets
     assert sync.world == world
     # rank 1 starts from perturbed weights: broadcast must make them rank-identical
@@ -65,10 +112,14 @@ def _worker(rank, world, port, out):
     for n, o in zip(names, offs):
         P[n] = flat_p[o:o + P[n].numel()].view(P[n].shape).clone()
     loss, flat_g = _flat_grads(R, cfg, P, x[rank:rank + 1], t[rank:rank + 1], names, offs, total)
-    sync.allreduce_mean_(flat_g)
+    backward, deferred = _split_deferred(flat_g, names, offs, sizes)
+    assert len(deferred) > 6
+    p_before = flat_p.clone()
+    g_sum, nb, last = _engine_tail(backward, deferred, names, offs, sizes, total, flat_p, sync)
     mx = sync.max_over_ranks(float(rank + 1), "cpu")
     if rank == 0:
-        torch.save({"flat_g": flat_g, "loss": loss, "flat_p": flat_p, "max": mx}, out)
+        torch.save({"g_sum": g_sum, "loss": loss, "p_before": p_before, "p_after": flat_p, "max": mx, "nbuckets": nb,
+                    "last": last}, out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -80,30 +131,43 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
     got = torch.load(out)
     sys.path.insert(0, ROOT)
-    from micformer_amd.dist import flatten_views
+    from micformer_amd.dist import FlatGradSync, flatten_views
     cfg, P, x, t, R = _tiny_setup()
     names = list(P)
     offs, total = flatten_views([P[n] for n in names])
+    sizes = [P[n].numel() for n in names]
     # broadcast from rank 0 (perturbation 0): weights identical to the unperturbed fill
     ref_p = torch.zeros(total)
     for n, o in zip(names, offs):
         ref_p[o:o + P[n].numel()] = P[n].reshape(-1)
-    assert torch.equal(got["flat_p"], ref_p)
+    assert torch.equal(got["p_before"], ref_p)
     assert got["max"] == 2.0
-    # 1-rank reference under the per-rank-loss definition: mean over ranks of the per-shard loss gradients
+    assert got["nbuckets"] >= 2 and max(got["last"]) >= 1 and min(got["last"]) == -1      # the plan really interleaves
+    # 1-rank reference under the per-rank-loss definition: the flat buffer holds the SUM over ranks of the per-shard gradients
     g = torch.zeros(total)
     for r in range(2):
         _, fg = _flat_grads(R, cfg, P, x[r:r + 1], t[r:r + 1], names, offs, total)
         g += fg
-    g /= 2
-    err = float((got["flat_g"] - g).abs().max())
+    err = float((got["g_sum"] - g).abs().max())
     scale = float(g.abs().max())
     assert scale == scale and scale > 0
     assert err <= 1e-6 * max(scale, 1.0) + 1e-9, f"2-rank grads differ from the 1-rank reference: {err} (scale {scale})"
+    # ... and Adam read it as the MEAN: same weights as one process stepping on the mean gradient through the same tail
+    p1 = ref_p.clone()
+    backward, deferred = _split_deferred(g / 2, names, offs, sizes)
+    _engine_tail(backward, deferred, names, offs, sizes, total, p1, FlatGradSync())
+    assert float((p1 - ref_p).abs().max()) > 1e-3                                          # the step moved the weights
+    # (a first Adam step is lr * g / (|g| + eps): elements with |g| near eps = 1e-8 amplify fp32 summation-order noise, so the
+    # tight bound is taken where the gradient is well above eps and a loose one -- 0.5 % of the step -- everywhere)
+    diff = (got["p_after"] - p1).abs()
+    strong = (g / 2).abs() > 1e-5
+    assert int(strong.sum()) > 1000
+    assert float(diff[strong].max()) <= 2e-6, f"2-rank post-Adam weights differ from the 1-rank step: {float(diff[strong].max())}"
+    assert float(diff.max()) <= 5e-5, f"2-rank post-Adam weights differ from the 1-rank step on the mean gradient: {float(diff.max())}"
     # the dead parameters never receive a gradient: their slice of the bucket stays exactly zero
     for n, o in zip(names, offs):
         if n.startswith("swin.concat_back_dim.0."):
-            assert float(got["flat_g"][o:o + P[n].numel()].abs().max()) == 0.0
+            assert float(got["g_sum"][o:o + P[n].numel()].abs().max()) == 0.0
 
 
 def test_flatten_views_alignment():

@@ -1,0 +1,176 @@
+"""GPU tests of the step engine's contract with the reference's loop (train.py:183-207): one optimiser update and one
+scheduler tick per batch also on the HIP-graph path (the capture warm-up must not train), ragged last batches, the LR written
+into checkpoints, process-global launch switches scoped to the engine's own step, the HIP DropPath draw, label range guards."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import fill  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def M():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import micformer_amd.models.MICFormer_self as m
+    return m
+
+
+def _head(M, train=False):
+    h = M.Head(embed_dim=24, num_classes=8, depths=(1, 1, 1, 1))
+    with torch.no_grad():
+        for name, t in h.state_dict().items():
+            t.copy_(fill.fill_tensor(name, t))
+    h = h.cuda()
+    return h.train() if train else h.eval()
+
+
+def _data(B, n=64):
+    return fill.make_volume(B, n, n, n).cuda(), fill.one_hot(fill.make_label_map(B, n, n, n)).cuda()
+
+
+def _max_diff(a, b):
+    return max(float((a[k] - b[k]).abs().max()) for k in a)
+
+
+def test_graph_capture_warmup_does_not_train(M):
+    """the first step() of a graph engine used to apply 4 updates (3 warm-ups + the replay) and run the cosine
+    schedule 3 ticks ahead.  Now: N graph steps == N eager steps, Adam's step counter == N, and the same again after a
+    checkpoint load (which drops the captured graph)."""
+    from micformer_amd.engine import TrainEngine
+    x, t = _data(2)
+    eager = TrainEngine(_head(M), base_lr=1e-3, t_max=5, use_graph=False)
+    graph = TrainEngine(_head(M), base_lr=1e-3, t_max=5, use_graph=True)
+    for n in (1, 2):
+        le, lg = eager.step(x, t), graph.step(x, t)
+        assert int(graph.adam_state[0].item()) == n == int(eager.adam_state[0].item())
+        assert abs(float(le) - float(lg)) < 1e-5
+        assert abs(graph.lr() - eager.lr()) < 1e-15
+        assert _max_diff(eager.model.state_dict(), graph.model.state_dict()) < 2e-6
+    assert graph.steps_done == 2
+    ck = graph.checkpoint(epoch=0)
+    graph.load_checkpoint(ck)                      # drops the graph: the next step re-captures (and must again not train)
+    assert graph._graph is None
+    le, lg = eager.step(x, t), graph.step(x, t)
+    assert int(graph.adam_state[0].item()) == 3
+    assert _max_diff(eager.model.state_dict(), graph.model.state_dict()) < 4e-6
+
+
+def test_ragged_last_batch_runs_eagerly(M):
+    """a B=1 batch fed to a graph captured at B=2 was broadcast into the static buffers (the sample trained twice).
+    The reference's loader has drop_last=False, so this happens at the end of every epoch."""
+    from micformer_amd.engine import TrainEngine
+    x2, t2 = _data(2)
+    x1, t1 = x2[:1].contiguous(), t2[:1].contiguous()
+    a = TrainEngine(_head(M), base_lr=1e-3, t_max=5, use_graph=True)
+    b = TrainEngine(_head(M), base_lr=1e-3, t_max=5, use_graph=False)
+    a.step(x2, t2), b.step(x2, t2)
+    la, lb = a.step(x1, t1), b.step(x1, t1)        # graph engine: shape mismatch -> eager fallback
+    assert abs(float(la) - float(lb)) < 1e-5
+    assert _max_diff(a.model.state_dict(), b.model.state_dict()) < 2e-6
+    la, lb = a.step(x2, t2), b.step(x2, t2)        # and the captured graph is still valid for the full batch
+    assert abs(float(la) - float(lb)) < 1e-5
+    assert int(a.adam_state[0].item()) == 3
+
+
+def test_checkpoint_lr_is_torchs_after_n_scheduler_steps(M):
+    """after N iterations torch holds cosine(N) in param_groups[0]['lr'] and scheduler._last_lr (scheduler.step() has
+    already run); the engine used to write cosine(N-1)."""
+    from micformer_amd.engine import TrainEngine
+    x, t = _data(1, 32)
+    eng = TrainEngine(_head(M), base_lr=1e-3, t_max=7, use_graph=False)
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=1e-3)
+    sch = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=7)
+    assert abs(eng.optimizer_state_dict()["param_groups"][0]["lr"] - 1e-3) < 1e-18
+    for n in range(1, 4):
+        eng.step(x, t)
+        p.grad = torch.ones(1)
+        opt.step()
+        sch.step()
+        want = opt.param_groups[0]["lr"]
+        assert abs(eng.optimizer_state_dict()["param_groups"][0]["lr"] - want) < 1e-12 * 1e3
+        ssd = eng.scheduler_state_dict()
+        assert abs(ssd["_last_lr"][0] - sch.state_dict()["_last_lr"][0]) < 1e-15 and ssd["last_epoch"] == sch.last_epoch == n
+        # the rate the last optimiser step USED is the previous epoch's
+        assert abs(eng.lr() - (0.5e-3 * (1 + math.cos(math.pi * (n - 1) / 7)))) < 1e-15
+
+
+def test_engine_switches_are_scoped_to_its_step(M):
+    """TrainEngine used to flip the process-global DEFER_WGRAD / PARALLEL_MODALITIES flags for good, so any backward
+    outside engine.step() silently lost its linear / LayerNorm parameter gradients."""
+    from micformer_amd import functional as Fn
+    from micformer_amd.engine import TrainEngine
+    import micformer_amd.models.MICFormer_self as ms
+    x, t = _data(1, 32)
+    eng = TrainEngine(_head(M), use_graph=False)
+    eng.step(x, t)
+    assert Fn.DEFER_WGRAD is False and ms.PARALLEL_MODALITIES is False
+    assert not Fn._DEFERRED and not Fn._DEFERRED_LN and not Fn._QUEUED_DW
+    # a manual backward through the SAME (flattened) model: weight gradients are computed in place, nothing is queued
+    eng.flat_g.zero_()
+    loss = eng.criterion(eng.model(x), t)
+    loss.backward()
+    assert not Fn._DEFERRED and not Fn._DEFERRED_LN
+    w = dict(eng.model.named_parameters())["swin.layers.0.self_blocks1.0.mlp.fc1.weight"]
+    assert float(w.grad.abs().max()) > 0
+    g_manual = eng.flat_g.clone()
+    eng._fwd_bwd(x, t)
+    scale = float(g_manual[torch.isfinite(g_manual)].abs().max())
+    fin = torch.isfinite(g_manual) & torch.isfinite(eng.flat_g)
+    assert float((g_manual - eng.flat_g)[fin].abs().max()) <= 2e-3 * scale
+
+
+def test_drop_path_draw_kernel():
+    from micformer_amd import ops
+    dev = torch.device("cuda")
+    keep = torch.tensor([1.0, 0.9, 0.5, 0.8182], device=dev)
+    rng = ops.drop_path_rng(dev, 1234)
+    draws = torch.stack([ops.drop_path_draw(rng, keep, 512) for _ in range(8)])       # [8, 4, 512]
+    assert int(rng[1].item()) == 8                                                       # the device counter advanced
+    assert torch.all(draws[:, 0] == 1.0)
+    for i, k in enumerate(keep.tolist()):
+        vals = draws[:, i].unique().tolist()
+        assert all(abs(v) < 1e-12 or abs(v - 1.0 / k) < 1e-6 for v in vals)
+        frac = float((draws[:, i] > 0).float().mean())
+        assert abs(frac - k) < 0.03, (i, frac)
+    assert not torch.equal(draws[0], draws[1])                                          # fresh masks per call
+    rng2 = ops.drop_path_rng(dev, 1234)
+    assert torch.equal(ops.drop_path_draw(rng2, keep, 512), draws[0])                   # reproducible from (seed, counter)
+    assert not torch.equal(ops.drop_path_draw(ops.drop_path_rng(dev, 1235), keep, 512), draws[0])
+    # a captured graph draws fresh masks at every replay (the counter lives on the device)
+    static = ops.drop_path_draw(rng, keep, 512)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        static = ops.drop_path_draw(rng, keep, 512)
+    g.replay()
+    a = static.clone()
+    g.replay()
+    assert not torch.equal(a, static)
+
+
+def test_label_values_outside_the_class_range_are_ignored():
+    """a label >= K (e.g. a 255 ignore index) indexed the shared counters out of bounds."""
+    from micformer_amd import ops
+    g = torch.Generator().manual_seed(3)
+    logits = torch.randn(2, 8, 6, 6, 6, generator=g).cuda()
+    lab = torch.randint(0, 8, (2, 6, 6, 6), generator=g, dtype=torch.uint8)
+    ign = lab.clone()
+    ign[0, :2] = 255
+    ign[1, 3] = 40
+    mask, md = ops.argmax_meandice(logits, ign.cuda())
+    pred = logits.argmax(1).cpu()
+    assert torch.equal(mask.cpu().long(), pred)
+    s = 0.0
+    for c in range(1, 8):
+        p, l = pred == c, ign == c
+        s += (2.0 * float((p & l).sum()) + 1e-6) / (float(p.sum()) + float(l.sum()) + 1e-6)
+    assert abs(float(md) - s / 7) < 1e-9
+    # the class-map loss treats such voxels as belonging to no class (t = 0 in every channel)
+    loss, _ = ops.dice_bce_fwd(logits, ign.cuda())
+    onehot = torch.stack([(ign == c) for c in range(8)], 1).float().cuda()
+    ref, _ = ops.dice_bce_fwd(logits, onehot)
+    assert abs(float(loss) - float(ref)) < 1e-6

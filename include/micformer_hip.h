@@ -257,6 +257,46 @@ int micf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, cons
                    float beta2, float eps, float grad_scale, micf_stream_t stream);
 
 
+/* ---- Fused window-local transformer block (csrc/block_fwd.hip, block_bwd.hip): everything of a TransformerBlock3D
+ * (MS.py:430-524), and everything of a CrossTransformerBlock3D (MS.py:277-426) downstream of the deformable sampling, in ONE
+ * launch per direction for up to two independent blocks of the same shape (the CT and MR branches of a depth slot,
+ * MS.py:699-701).  Token grid (B, D, H, W) with even D, H, W and 2x2x2 windows, C % 16 == 0, head_dim 16 or 32,
+ * hidden % 16 == 0; micf_block_tile_tokens returns 0 for shapes the fused kernels do not take (callers then use the
+ * per-op entry points above).  dtype: arithmetic of the matrix-core products. */
+#define MICF_DTYPE_F32 0  /* v_mfma_f32_16x16x4_f32: exact fp32 (bitwise a k-ordered fmaf chain) -- the parity mode */
+#define MICF_DTYPE_BF16 1 /* v_mfma_f32_16x16x32_bf16: operands rounded to bf16 at the fragment read, fp32 accumulate;
+                             residual stream, LayerNorm, softmax, GELU and everything stored stay fp32 */
+typedef struct micf_block_fwd_group {
+  const float* x;      /* [T, C] block input (residual stream), T = B*D*H*W tokens in natural order */
+  const float* kvsrc;  /* cross: [T, C] deformably sampled raw other modality (K/V source, never normed); NULL = self attention */
+  const float *ln1_g, *ln1_b, *wq, *bq, *wkv, *bkv, *wp, *bp, *ln2_g, *ln2_b, *w1, *b1, *w2, *b2; /* state_dict layout */
+  const float *s1, *s2; /* DropPath scales [B] of the two residual branches (NULL = 1) */
+  float* y;            /* [T, C] block output */
+  /* saved for backward / the deferred weight gradients, natural token order: */
+  float *xn, *q, *kv, *o, *x1, *xn2; /* LN1(x) [T,C] (may be NULL: not written); q [T,C]; k|v [T,2C]; attention out [T,C]; x + s1*attn [T,C]; LN2(x1) [T,C] */
+  float *h, *g;        /* fc1 pre-activation and GELU(h), [T, hidden] */
+  float* stats;        /* [4, T]: mean1, rstd1, mean2, rstd2 */
+} micf_block_fwd_group;
+typedef struct micf_block_bwd_group {
+  const float* dy;     /* [T, C] gradient w.r.t. the block output (also fc2's output gradient for the weight-gradient GEMM) */
+  const float *x, *x1, *stats, *q, *kv, *h; /* as saved by micf_block_fwd (x and ln1_g may be NULL for a cross block) */
+  const float *ln1_g, *ln2_g, *wq, *wkv, *wp, *w1, *w2, *s1, *s2;
+  float* dx;           /* self: [T, C] gradient w.r.t. the block input.  cross: the q path's PRE-LayerNorm gradient dq Wq (the
+                          caller adds the offset-conv path and applies LN1 backward with add = dx1) */
+  float* dxs;          /* cross: [T, C] gradient w.r.t. kvsrc; NULL = self attention */
+  float *dx1, *dh, *dq, *dkv; /* [T,C], [T,hidden], [T,C], [T,2C]: output gradients of proj (before s1), fc1, q, kv */
+  float *ln1_part, *ln2_part; /* [tiles, 2C] per-tile partial dgamma | dbeta for micf_layernorm_bwd_finish (NULL = skip;
+                                 tiles = ceil(T / micf_block_tile_tokens)) */
+  float* dx1_copy;     /* optional second copy of dx1 [T, C]: the buffer a cross PAIR then accumulates the other block's
+                          K/V-source gradient and its own LN1 backward into (no zero fill, no separate add) */
+} micf_block_bwd_group;
+int micf_block_tile_tokens(int B, int D, int H, int W, int C, int heads, int hidden);
+/* `groups` is HOST memory, read during the call only. */
+int micf_block_fwd(const micf_block_fwd_group* groups, int ngroups, int B, int D, int H, int W, int C, int heads,
+                   int hidden, float eps, float scale, int dtype, micf_stream_t stream);
+int micf_block_bwd(const micf_block_bwd_group* groups, int ngroups, int B, int D, int H, int W, int C, int heads,
+                   int hidden, float scale, int dtype, micf_stream_t stream);
+
 /* ---- step plumbing without ATen kernels.
  * micf_zero: optimizer.zero_grad() over the flat gradient buffer (train.py:183) as ONE memset node. */
 int micf_zero(void* p, int64_t bytes, micf_stream_t stream);

@@ -66,6 +66,9 @@ SIGNATURES = {
     "micf_argmax_meandice": "pppppiilp",
     "micf_adam_tick": "pddlp",
     "micf_adam_step": "pppplpffffp",
+    "micf_block_tile_tokens": "iiiiiii",
+    "micf_block_fwd": "piiiiiiiiffip",
+    "micf_block_bwd": "piiiiiiiifip",
     "micf_zero": "plp",
     "micf_drop_path_draw": "pppiip",
 }
@@ -82,6 +85,23 @@ class LnFinishItem(ctypes.Structure):
     """struct micf_ln_finish_item (include/micformer_hip.h)."""
     _fields_ = [("partials", ctypes.c_void_p), ("dgamma", ctypes.c_void_p), ("dbeta", ctypes.c_void_p),
                 ("blocks", ctypes.c_int32), ("C", ctypes.c_int32)]
+
+
+_VP = ctypes.c_void_p
+
+
+class BlockFwdGroup(ctypes.Structure):
+    """struct micf_block_fwd_group (include/micformer_hip.h)."""
+    FIELDS = ("x", "kvsrc", "ln1_g", "ln1_b", "wq", "bq", "wkv", "bkv", "wp", "bp", "ln2_g", "ln2_b", "w1", "b1", "w2", "b2",
+              "s1", "s2", "y", "xn", "q", "kv", "o", "x1", "xn2", "h", "g", "stats")
+    _fields_ = [(n, _VP) for n in FIELDS]
+
+
+class BlockBwdGroup(ctypes.Structure):
+    """struct micf_block_bwd_group (include/micformer_hip.h)."""
+    FIELDS = ("dy", "x", "x1", "stats", "q", "kv", "h", "ln1_g", "ln2_g", "wq", "wkv", "wp", "w1", "w2", "s1", "s2",
+              "dx", "dxs", "dx1", "dh", "dq", "dkv", "ln1_part", "ln2_part", "dx1_copy")
+    _fields_ = [(n, _VP) for n in FIELDS]
 
 
 class MicfError(RuntimeError):
@@ -104,6 +124,7 @@ def _load():
     lib.micf_offset_sample_bwd_workspace.restype = _L
     lib.micf_conv3_bwd_weight_workspace.restype = _L
     lib.micf_conv3_fwd_workspace.restype = _L
+    lib.micf_block_tile_tokens.argtypes = [_I] * 7          # (no stream argument: a pure shape query)
     lib.micf_strerror.argtypes = [_I]
     lib.micf_strerror.restype = ctypes.c_char_p
     lib.micf_abi_version.argtypes = []

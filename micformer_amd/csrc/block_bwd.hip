@@ -1,0 +1,378 @@
+// block_bwd.hip -- ONE launch for the data-gradient chain of the window-local part of a (Cross)TransformerBlock3D, both
+// modalities (the adjoint of block_fwd.hip; MS.py:277-524 through autograd in the reference):
+//
+//   dh  = (s2 dy W2) * GELU'(h)            -> HBM (fc1 weight gradient)          dy itself is fc2's output gradient
+//   dx1 = dy + LN2'(dh W1)                 -> HBM (proj weight gradient; the cross block's LN1 backward adds it)
+//   do  = s1 dx1 Wp ;  (dq, dk, dv) = attention'(q, k, v, do)   -> HBM dq, dkv (q / kv weight gradients)
+//   self : dx  = dx1 + LN1'(dq Wq + dkv Wkv)
+//   cross: dxq = dq Wq  (pre-LayerNorm; the offset-conv path adds its part before LN1')   and   dxs = dkv Wkv
+//
+// plus per-tile partial sums of the LayerNorm gain / bias gradients ([tiles][2C], summed by micf_layernorm_bwd_finish).
+// Weight gradients stay deferred (linear_grouped.hip): this kernel only leaves their operands in HBM.  Same tiling, LDS
+// budget (A1, A2 [TM][C+4]; U [TM][3C+4]) and weight streaming as the forward; the attention backward runs in place on the
+// q|k|v tile with the 8x8 P / dS rows exchanged through the (idle) ring area.
+#include "block_fused.h"
+
+namespace micf {
+
+struct BlkBwdArgs {
+  micf_block_bwd_group g[2];
+  TileGeo geo;
+  int G, tiles, C, heads, hidden;
+  float scale;
+};
+
+constexpr size_t block_lds_bytes_b(int TM, int C) { return sizeof(float) * (size_t)(kFusedRing + TM * (2 * (C + 4) + 3 * C + 4) + 3 * TM); }
+
+// LayerNorm backward of the rows held in LDS tile `D` (gradient w.r.t. the normalised output, pre-gain) against the HBM rows
+// `xsrc`: out = addt + rs * (g d - mean(g d) - xh mean(g d xh)).  addt / out are LDS tile A (in place) and HBM `hout`.
+// The per-tile column sums of d * xh and d go through `scratch` (LDS, >= 16 * 2C floats) to part[2C].
+template <int TJ, int VPL>
+__device__ __forceinline__ void ln_bwd_tile(const float* D, float* A, int S, int C, const float* __restrict__ xsrc,
+                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                            const float* __restrict__ gamma, const int* tok, float* __restrict__ hout,
+                                            float* __restrict__ hout2, float* scratch, float* __restrict__ part) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, rg = lane >> 4;
+  const int C4 = C >> 2;
+  const float invC = 1.0f / (float)C;
+  float4 ag[VPL], ab[VPL], gm[VPL];
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) {
+    ag[k] = make_float4(0.f, 0.f, 0.f, 0.f); ab[k] = ag[k];
+    const int c4 = l16 + 16 * k;
+    gm[k] = c4 < C4 ? ld4g(gamma + 4 * c4) : ag[k];
+  }
+#pragma unroll 1
+  for (int pass = 0; pass < TJ; ++pass) {
+    const int row = pass * 16 + wave * 4 + rg;
+    const int tk = tok[row];
+    const float mu = tk >= 0 ? mean[tk] : 0.f, rs = tk >= 0 ? rstd[tk] : 0.f;
+    float4 xh[VPL], d[VPL];
+    float sa = 0.f, sb = 0.f;
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+      const int c4 = l16 + 16 * k;
+      xh[k] = make_float4(0.f, 0.f, 0.f, 0.f); d[k] = xh[k];
+      if (c4 < C4 && tk >= 0) {
+        const float4 v = ld4g(xsrc + (int64_t)tk * C + 4 * c4);
+        d[k] = *reinterpret_cast<const float4*>(D + row * S + 4 * c4);
+        xh[k] = make_float4((v.x - mu) * rs, (v.y - mu) * rs, (v.z - mu) * rs, (v.w - mu) * rs);
+        const float g0 = gm[k].x * d[k].x, g1 = gm[k].y * d[k].y, g2 = gm[k].z * d[k].z, g3 = gm[k].w * d[k].w;
+        sa += (g0 + g1) + (g2 + g3);
+        sb += (g0 * xh[k].x + g1 * xh[k].y) + (g2 * xh[k].z + g3 * xh[k].w);
+        ag[k].x += d[k].x * xh[k].x; ag[k].y += d[k].y * xh[k].y; ag[k].z += d[k].z * xh[k].z; ag[k].w += d[k].w * xh[k].w;
+        ab[k].x += d[k].x; ab[k].y += d[k].y; ab[k].z += d[k].z; ab[k].w += d[k].w;
+      }
+    }
+    const float Am = sum16(sa) * invC, Bm = sum16(sb) * invC;
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+      const int c4 = l16 + 16 * k;
+      if (c4 < C4) {
+        float* ap = A + row * S + 4 * c4;
+        float4 o = *reinterpret_cast<const float4*>(ap);
+        o.x += rs * (gm[k].x * d[k].x - Am - xh[k].x * Bm); o.y += rs * (gm[k].y * d[k].y - Am - xh[k].y * Bm);
+        o.z += rs * (gm[k].z * d[k].z - Am - xh[k].z * Bm); o.w += rs * (gm[k].w * d[k].w - Am - xh[k].w * Bm);
+        if (tk < 0) o = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(ap) = o;
+        if (tk >= 0) {
+          st4g(hout + (int64_t)tk * C + 4 * c4, o);
+          if (hout2) st4g(hout2 + (int64_t)tk * C + 4 * c4, o);
+        }
+      }
+    }
+  }
+  // column sums over the tile: 16 (wave, lane group) partial rows -> scratch -> part
+  float* mine = scratch + (wave * 4 + rg) * 2 * C;
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) {
+    const int c4 = l16 + 16 * k;
+    if (c4 < C4) {
+      *reinterpret_cast<float4*>(mine + 4 * c4) = ag[k];
+      *reinterpret_cast<float4*>(mine + C + 4 * c4) = ab[k];
+    }
+  }
+  __syncthreads();
+  if (part) {
+    for (int c = tid; c < 2 * C; c += 256) {
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += scratch[r * 2 * C + c];
+      part[c] = s;
+    }
+  }
+  __syncthreads();
+}
+
+template <int TJ, int HD, int VPL, bool BF16>
+__global__ void __launch_bounds__(256) block_bwd_kernel(const BlkBwdArgs a) {
+  constexpr int TM = 16 * TJ;
+  extern __shared__ __attribute__((aligned(1024))) float lds[];
+  const int C = a.C, C4 = C >> 2, S = C + 4, SU = 3 * C + 4, Hd = a.hidden;
+  float* ring = lds;
+  float* A1 = ring + kFusedRing;
+  float* A2 = A1 + TM * S;
+  float* U = A2 + TM * S;
+  float* sc1 = U + TM * SU;
+  float* sc2 = sc1 + TM;
+  int* tok = reinterpret_cast<int*>(sc2 + TM);
+
+  int grp, tile;
+  if (a.G == 2) { const int xcd = blockIdx.x & 7; grp = xcd >> 2; tile = (int)(blockIdx.x >> 3) * 4 + (xcd & 3); }
+  else { grp = 0; tile = blockIdx.x; }
+  if (tile >= a.tiles) return;
+  const micf_block_bwd_group& g = a.g[grp];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, rg = lane >> 4;
+  const int64_t T = a.geo.T;
+
+  if (tid < TM) {
+    const int win = tile * (TM / 8) + (tid >> 3);
+    int tk = -1;
+    float v1 = 1.f, v2 = 1.f;
+    if (win < a.geo.nwin) {
+      tk = a.geo.token(win, tid & 7);
+      const int b = (int)a.geo.f_rps.div((uint32_t)tk);
+      if (g.s1) v1 = g.s1[b];
+      if (g.s2) v2 = g.s2[b];
+    }
+    tok[tid] = tk; sc1[tid] = v1; sc2[tid] = v2;
+  }
+  __syncthreads();
+
+  // ---- dy rows -> A1
+#pragma unroll 1
+  for (int pass = 0; pass < TJ; ++pass) {
+    const int row = pass * 16 + wave * 4 + rg;
+    const int tk = tok[row];
+    for (int c4 = l16; c4 < C4; c4 += 16)
+      *reinterpret_cast<float4*>(A1 + row * S + 4 * c4) = tk >= 0 ? ld4g(g.dy + (int64_t)tk * C + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
+  // ---- MLP backward in hidden chunks: h chunk -> U;  U <- s2 (dy W2) GELU'(h) = dh (saved);  A2 (+)= dh W1
+  const int HC = 2 * C;
+  for (int c0 = 0; c0 < Hd; c0 += HC) {
+    const int hc = (Hd - c0 < HC) ? Hd - c0 : HC;
+    const int X4 = hc >> 2;
+#pragma unroll 1
+    for (int pass = 0; pass < TJ; ++pass) {
+      const int row = pass * 16 + wave * 4 + rg;
+      const int tk = tok[row];
+      for (int c4 = l16; c4 < X4; c4 += 16)
+        *reinterpret_cast<float4*>(U + row * SU + 4 * c4) = tk >= 0 ? ld4g(g.h + (int64_t)tk * Hd + c0 + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    gemm_phase<TJ, true, EPI_GELU_GRAD, BF16>(g.w2 + c0, Hd, hc, C, A1, S, U, SU, sc2, ring);
+#pragma unroll 1
+    for (int pass = 0; pass < TJ; ++pass) {
+      const int row = pass * 16 + wave * 4 + rg;
+      const int tk = tok[row];
+      if (tk < 0) continue;
+      for (int c4 = l16; c4 < X4; c4 += 16)
+        st4g(g.dh + (int64_t)tk * Hd + c0 + 4 * c4, *reinterpret_cast<const float4*>(U + row * SU + 4 * c4));
+    }
+    if (c0 == 0) gemm_phase<TJ, true, EPI_STORE, BF16>(g.w1 + (int64_t)c0 * C, C, C, hc, U, SU, A2, S, nullptr, ring);
+    else gemm_phase<TJ, true, EPI_ACC, BF16>(g.w1 + (int64_t)c0 * C, C, C, hc, U, SU, A2, S, nullptr, ring);
+  }
+
+  // ---- dx1 = dy + LN2'(A2) -> A1 + HBM; LN2 gain / bias partials
+  ln_bwd_tile<TJ, VPL>(A2, A1, S, C, g.x1, g.stats + 2 * T, g.stats + 3 * T, g.ln2_g, tok, g.dx1, g.dx1_copy, U,
+                       g.ln2_part ? g.ln2_part + (int64_t)tile * 2 * C : nullptr);
+
+  // ---- do = s1 dx1 Wp -> A2;  q | k | v rows -> U
+  gemm_phase<TJ, true, EPI_STORE_SCALE, BF16>(g.wp, C, C, C, A1, S, A2, S, sc1, ring);
+#pragma unroll 1
+  for (int pass = 0; pass < TJ; ++pass) {
+    const int row = pass * 16 + wave * 4 + rg;
+    const int tk = tok[row];
+    for (int c4 = l16; c4 < 3 * C4; c4 += 16) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (tk >= 0) v = c4 < C4 ? ld4g(g.q + (int64_t)tk * C + 4 * c4) : ld4g(g.kv + (int64_t)tk * 2 * C + 4 * (c4 - C4));
+      *reinterpret_cast<float4*>(U + row * SU + 4 * c4) = v;
+    }
+  }
+  __syncthreads();
+
+  // ---- attention backward in place on U.  Thread = (window, row i, head); batches of whole windows.
+  {
+    const int heads = a.heads, per = 8 * heads, wpb = 256 / per;
+    float* PS = ring;                                   // [256][16]: P row | dS row of every thread of the batch
+    for (int w0 = 0; w0 < TM / 8; w0 += wpb) {
+      const int wl = tid / per, rem = tid - wl * per;
+      const bool active = wl < wpb && (w0 + wl) < TM / 8;
+      const int i = rem / heads, hh = rem - i * heads;
+      const int row = (w0 + wl) * 8 + i, r0 = row - i, hoff = hh * HD;
+      float dq[HD], dk[HD], dv[HD];
+      if (active) {
+        float qr[HD], dor[HD];
+        const float* qp = U + row * SU + hoff;
+        const float* dop = A2 + row * S + hoff;
+#pragma unroll
+        for (int d = 0; d < HD; d += 4) {
+          const float4 t = *reinterpret_cast<const float4*>(qp + d);
+          qr[d] = t.x * a.scale; qr[d + 1] = t.y * a.scale; qr[d + 2] = t.z * a.scale; qr[d + 3] = t.w * a.scale;
+          const float4 u = *reinterpret_cast<const float4*>(dop + d);
+          dor[d] = u.x; dor[d + 1] = u.y; dor[d + 2] = u.z; dor[d + 3] = u.w;
+        }
+        float p[8], dp[8], mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float* kp = U + (r0 + j) * SU + C + hoff;
+          const float* vp = U + (r0 + j) * SU + 2 * C + hoff;
+          float sacc = 0.f, dacc = 0.f;
+#pragma unroll
+          for (int d = 0; d < HD; d += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(kp + d);
+            sacc += qr[d] * t.x; sacc += qr[d + 1] * t.y; sacc += qr[d + 2] * t.z; sacc += qr[d + 3] * t.w;
+            const float4 u = *reinterpret_cast<const float4*>(vp + d);
+            dacc += dor[d] * u.x; dacc += dor[d + 1] * u.y; dacc += dor[d + 2] * u.z; dacc += dor[d + 3] * u.w;
+          }
+          p[j] = sacc; dp[j] = dacc;
+          mx = fmaxf(mx, sacc);
+        }
+        float den = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { p[j] = expf(p[j] - mx); den += p[j]; }
+        const float inv = 1.0f / den;
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { p[j] *= inv; dot += p[j] * dp[j]; }
+#pragma unroll
+        for (int d = 0; d < HD; ++d) dq[d] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float ds = p[j] * (dp[j] - dot);
+          PS[tid * 16 + j] = p[j];
+          PS[tid * 16 + 8 + j] = ds;
+          const float* kp = U + (r0 + j) * SU + C + hoff;
+          const float dss = ds * a.scale;
+#pragma unroll
+          for (int d = 0; d < HD; d += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(kp + d);
+            dq[d] += dss * t.x; dq[d + 1] += dss * t.y; dq[d + 2] += dss * t.z; dq[d + 3] += dss * t.w;
+          }
+        }
+      }
+      __syncthreads();
+      if (active) {                                     // now as key / value row j = i: gather column j of P and dS from the mates
+#pragma unroll
+        for (int d = 0; d < HD; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+        const int base = tid - i * heads;               // thread of (window, row 0, head hh)
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          const float pm = PS[(base + m * heads) * 16 + i];
+          const float dsm = PS[(base + m * heads) * 16 + 8 + i] * a.scale;
+          const float* qp = U + (r0 + m) * SU + hoff;
+          const float* dop = A2 + (r0 + m) * S + hoff;
+#pragma unroll
+          for (int d = 0; d < HD; d += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(qp + d);
+            dk[d] += dsm * t.x; dk[d + 1] += dsm * t.y; dk[d + 2] += dsm * t.z; dk[d + 3] += dsm * t.w;
+            const float4 u = *reinterpret_cast<const float4*>(dop + d);
+            dv[d] += pm * u.x; dv[d + 1] += pm * u.y; dv[d + 2] += pm * u.z; dv[d + 3] += pm * u.w;
+          }
+        }
+      }
+      __syncthreads();                                  // every read of this batch's q / k / v rows is done: overwrite in place
+      if (active) {
+#pragma unroll
+        for (int d = 0; d < HD; d += 4) {
+          *reinterpret_cast<float4*>(U + row * SU + hoff + d) = make_float4(dq[d], dq[d + 1], dq[d + 2], dq[d + 3]);
+          *reinterpret_cast<float4*>(U + row * SU + C + hoff + d) = make_float4(dk[d], dk[d + 1], dk[d + 2], dk[d + 3]);
+          *reinterpret_cast<float4*>(U + row * SU + 2 * C + hoff + d) = make_float4(dv[d], dv[d + 1], dv[d + 2], dv[d + 3]);
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- dq | dk | dv rows -> HBM (operands of the q / kv weight gradients)
+#pragma unroll 1
+  for (int pass = 0; pass < TJ; ++pass) {
+    const int row = pass * 16 + wave * 4 + rg;
+    const int tk = tok[row];
+    if (tk < 0) continue;
+    for (int c4 = l16; c4 < 3 * C4; c4 += 16) {
+      const float4 v = *reinterpret_cast<const float4*>(U + row * SU + 4 * c4);
+      if (c4 < C4) st4g(g.dq + (int64_t)tk * C + 4 * c4, v);
+      else st4g(g.dkv + (int64_t)tk * 2 * C + 4 * (c4 - C4), v);
+    }
+  }
+
+  if (!g.dxs) {
+    // ---- self: dxn = dq Wq + dkv Wkv -> A2;  dx = dx1 + LN1'(dxn) -> HBM; LN1 partials
+    gemm_phase<TJ, true, EPI_STORE, BF16>(g.wq, C, C, C, U, SU, A2, S, nullptr, ring);
+    gemm_phase<TJ, true, EPI_ACC, BF16>(g.wkv, C, C, 2 * C, U + C, SU, A2, S, nullptr, ring);
+    ln_bwd_tile<TJ, VPL>(A2, A1, S, C, g.x, g.stats, g.stats + T, g.ln1_g, tok, g.dx, nullptr, U,
+                         g.ln1_part ? g.ln1_part + (int64_t)tile * 2 * C : nullptr);
+  } else {
+    // ---- cross: the q path's pre-LayerNorm gradient and the sampled K/V source's gradient leave separately
+    gemm_phase<TJ, true, EPI_STORE, BF16>(g.wq, C, C, C, U, SU, A2, S, nullptr, ring);
+#pragma unroll 1
+    for (int pass = 0; pass < TJ; ++pass) {
+      const int row = pass * 16 + wave * 4 + rg;
+      const int tk = tok[row];
+      if (tk < 0) continue;
+      for (int c4 = l16; c4 < C4; c4 += 16) st4g(g.dx + (int64_t)tk * C + 4 * c4, *reinterpret_cast<const float4*>(A2 + row * S + 4 * c4));
+    }
+    __syncthreads();
+    gemm_phase<TJ, true, EPI_STORE, BF16>(g.wkv, C, C, 2 * C, U + C, SU, A2, S, nullptr, ring);
+#pragma unroll 1
+    for (int pass = 0; pass < TJ; ++pass) {
+      const int row = pass * 16 + wave * 4 + rg;
+      const int tk = tok[row];
+      if (tk < 0) continue;
+      for (int c4 = l16; c4 < C4; c4 += 16) st4g(g.dxs + (int64_t)tk * C + 4 * c4, *reinterpret_cast<const float4*>(A2 + row * S + 4 * c4));
+    }
+  }
+}
+
+template <int TJ, int HD, int VPL>
+static int launch_bwd(const BlkBwdArgs& a, int dtype, hipStream_t s) {
+  constexpr int TM = 16 * TJ;
+  const size_t lds = block_lds_bytes_b(TM, a.C);
+  if (lds > 160 * 1024) return MICF_EUNSUPPORTED;
+  const unsigned grid = a.G == 2 ? (unsigned)((a.tiles + 3) / 4 * 8) : (unsigned)a.tiles;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_bwd_kernel<TJ, HD, VPL, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_bwd_kernel<TJ, HD, VPL, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  });
+  if (dtype == MICF_DTYPE_BF16) hipLaunchKernelGGL((block_bwd_kernel<TJ, HD, VPL, true>), dim3(grid), dim3(256), lds, s, a);
+  else hipLaunchKernelGGL((block_bwd_kernel<TJ, HD, VPL, false>), dim3(grid), dim3(256), lds, s, a);
+  MICF_RETURN_LAUNCH();
+}
+
+}  // namespace micf
+
+using namespace micf;
+
+extern "C" int micf_block_bwd(const micf_block_bwd_group* groups, int ngroups, int B, int D, int H, int W, int C, int heads,
+                              int hidden, float scale, int dtype, micf_stream_t stream) {
+  if (!groups || ngroups < 1 || ngroups > 2) return MICF_EINVAL;
+  const int TM = micf_block_tile_tokens(B, D, H, W, C, heads, hidden);
+  if (TM == 0) return MICF_EUNSUPPORTED;
+  if (dtype != MICF_DTYPE_F32 && dtype != MICF_DTYPE_BF16) return MICF_EINVAL;
+  BlkBwdArgs a;
+  for (int i = 0; i < ngroups; ++i) {
+    const micf_block_bwd_group& g = groups[i];
+    const void* need[] = {g.dy, g.x1, g.stats, g.q, g.kv, g.h, g.ln2_g, g.wq, g.wkv, g.wp, g.w1, g.w2, g.dx, g.dx1, g.dh, g.dq, g.dkv};
+    for (const void* p : need)
+      if (!p || (reinterpret_cast<uintptr_t>(p) & 15)) return MICF_EINVAL;
+    if (!g.dxs && (!g.x || !g.ln1_g)) return MICF_EINVAL;          // self: LayerNorm-1 backward runs in the kernel
+    const void* opt[] = {g.x, g.ln1_g, g.dxs, g.ln1_part, g.ln2_part, g.dx1_copy};
+    for (const void* p : opt)
+      if (p && (reinterpret_cast<uintptr_t>(p) & 15)) return MICF_EINVAL;
+    a.g[i] = g;
+  }
+  if (ngroups == 1) a.g[1] = a.g[0];
+  a.geo = make_tile_geo(B, D, H, W);
+  a.G = ngroups; a.C = C; a.heads = heads; a.hidden = hidden; a.scale = scale;
+  a.tiles = (a.geo.nwin + TM / 8 - 1) / (TM / 8);
+  hipStream_t s = (hipStream_t)stream;
+  const int hd = C / heads, vpl = (C + 63) / 64, tj = TM / 16;
+#define MICF_BB(TJ_, HD_, VPL_) if (tj == TJ_ && hd == HD_ && vpl == VPL_) return launch_bwd<TJ_, HD_, VPL_>(a, dtype, s)
+  MICF_BB(4, 16, 1); MICF_BB(2, 16, 1); MICF_BB(2, 16, 2); MICF_BB(1, 16, 2); MICF_BB(1, 16, 3); MICF_BB(1, 16, 6);
+  MICF_BB(2, 32, 2); MICF_BB(1, 32, 3); MICF_BB(1, 32, 6);
+#undef MICF_BB
+  return MICF_EUNSUPPORTED;
+}

@@ -26,8 +26,6 @@ def set_compute_dtype(name):
     global _COMPUTE_DTYPE
     if name not in ("fp32", "bf16"):
         raise ValueError("compute dtype must be 'fp32' or 'bf16'")
-    if name == "bf16" and not hasattr(_lib.lib, "micf_set_dtype"):
-        raise _lib.MicfError("this build of libmicformer_hip.so has no bf16 mode")
     _COMPUTE_DTYPE = name
 
 
@@ -530,6 +528,81 @@ def adam_step(p, g, m, v, state, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.
     call("micf_adam_step", f32(p), f32(g), f32(m), f32(v), p.numel(), ptr(state), float(beta1), float(beta2), float(eps),
          float(grad_scale),
          cost=_cost(12 * p.numel(), p, p, g, m, m, v, v))
+
+
+# ----------------------------------------------------------------------------- fused window-local transformer block
+_DT = {"fp32": 0, "bf16": 1}
+
+FWD_W = (("ln1_g", "norm1.weight"), ("ln1_b", "norm1.bias"), ("wq", "{a}.q.weight"), ("bq", "{a}.q.bias"), ("wkv", "{a}.kv.weight"),
+         ("bkv", "{a}.kv.bias"), ("wp", "{a}.proj.weight"), ("bp", "{a}.proj.bias"), ("ln2_g", "norm2.weight"), ("ln2_b", "norm2.bias"),
+         ("w1", "mlp.fc1.weight"), ("b1", "mlp.fc1.bias"), ("w2", "mlp.fc2.weight"), ("b2", "mlp.fc2.bias"))
+BWD_W = (("ln1_g", "norm1.weight"), ("ln2_g", "norm2.weight"), ("wq", "{a}.q.weight"), ("wkv", "{a}.kv.weight"),
+         ("wp", "{a}.proj.weight"), ("w1", "mlp.fc1.weight"), ("w2", "mlp.fc2.weight"))
+
+
+def block_tile_tokens(dims, C, heads, hidden):
+    """Tokens per workgroup tile of the fused block kernels for this shape; 0 = not handled (use the per-op path)."""
+    B, D, H, W = dims
+    return int(_lib.lib.micf_block_tile_tokens(B, D, H, W, C, heads, hidden))
+
+
+def block_fwd(groups, dims, C, heads, eps, scale):
+    """groups: 1 or 2 dicts {x [T,C], kvsrc [T,C] | None, P {state_dict-style name: tensor}, attn 'self_attn' | 'cross_attn',
+    s1, s2 [B] | None, want_xn bool}.  ONE launch.  Returns per group a dict of the tensors saved for backward (+ 'y')."""
+    B, D, H, W = dims
+    T = B * D * H * W
+    hidden = groups[0]["P"]["mlp.fc1.weight"].shape[0]
+    arr = (_lib.BlockFwdGroup * 2)()
+    outs = []
+    nb = fl = 0
+    for it, gd in zip(arr, groups):
+        x, P, a = gd["x"], gd["P"], gd["attn"]
+        o = {"y": _new(x, T, C), "q": _new(x, T, C), "kv": _new(x, T, 2 * C), "o": _new(x, T, C), "x1": _new(x, T, C),
+             "xn2": _new(x, T, C), "h": _new(x, T, hidden), "g": _new(x, T, hidden), "stats": _new(x, 4, T),
+             "xn": _new(x, T, C) if gd.get("want_xn", True) else None}
+        it.x, it.kvsrc, it.s1, it.s2 = f32(x), f32(gd.get("kvsrc")), f32(gd.get("s1")), f32(gd.get("s2"))
+        for field, key in FWD_W:
+            setattr(it, field, f32(P[key.format(a=a)]))
+        for k, v in o.items():
+            setattr(it, k, f32(v))
+        outs.append(o)
+        nb += 4 * (T * C * (9 if o["xn"] is not None else 8) + 2 * T * hidden + 12 * C * C)
+        fl += 2 * T * 12 * C * C + 4 * T * C * 8
+    call("micf_block_fwd", ctypes.cast(arr, ctypes.c_void_p), len(groups), B, D, H, W, C, heads, hidden, float(eps), float(scale),
+         _DT[_COMPUTE_DTYPE], cost=(nb, fl, f"{len(groups)}x{T}x{C}") if _lib.PROFILE is not None and DETAIL else ((nb, fl) if _lib.PROFILE is not None else None))
+    return outs
+
+
+def block_bwd(groups, dims, C, heads, scale):
+    """groups: 1 or 2 dicts {dy, x, x1, stats, q, kv, h, P, attn, s1, s2, cross bool, want_copy bool, want_ln1 bool}.  ONE launch.
+    Returns per group {dx, dxs | None, dx1, dh, dq, dkv, ln1_part | None, ln2_part, tiles, dx1_copy | None}."""
+    B, D, H, W = dims
+    T = B * D * H * W
+    hidden = groups[0]["P"]["mlp.fc1.weight"].shape[0]
+    tm = block_tile_tokens(dims, C, heads, hidden)
+    tiles = (T + tm - 1) // tm
+    arr = (_lib.BlockBwdGroup * 2)()
+    outs = []
+    nb = fl = 0
+    for it, gd in zip(arr, groups):
+        dy, P, a, cross = gd["dy"], gd["P"], gd["attn"], gd["cross"]
+        o = {"dx": _new(dy, T, C), "dxs": _new(dy, T, C) if cross else None, "dx1": _new(dy, T, C), "dh": _new(dy, T, hidden),
+             "dq": _new(dy, T, C), "dkv": _new(dy, T, 2 * C), "ln2_part": _new(dy, tiles, 2 * C),
+             "ln1_part": None if cross else _new(dy, tiles, 2 * C),
+             "dx1_copy": _new(dy, T, C) if gd.get("want_copy") else None}
+        for k in ("dy", "x", "x1", "stats", "q", "kv", "h", "s1", "s2"):
+            setattr(it, k, f32(gd.get(k)))
+        for field, key in BWD_W:
+            setattr(it, field, f32(P[key.format(a=a)]))
+        for k, v in o.items():
+            setattr(it, k, f32(v))
+        o["tiles"] = tiles
+        outs.append(o)
+        nb += 4 * (T * C * (11 if cross else 9) + 2 * T * hidden + 12 * C * C)
+        fl += 2 * T * 12 * C * C + 8 * T * C * 8
+    call("micf_block_bwd", ctypes.cast(arr, ctypes.c_void_p), len(groups), B, D, H, W, C, heads, hidden, float(scale),
+         _DT[_COMPUTE_DTYPE], cost=(nb, fl, f"{len(groups)}x{T}x{C}") if _lib.PROFILE is not None and DETAIL else ((nb, fl) if _lib.PROFILE is not None else None))
+    return outs
 
 
 # ----------------------------------------------------------------------------- step plumbing

@@ -1,0 +1,195 @@
+"""GPU parity of the fused window-local block kernels (csrc/block_fwd.hip, block_bwd.hip) against the per-op entry points of
+round 1 (each of which is pinned against the oracle / the reference goldens in test_gpu_ops.py): every tensor the fused
+forward saves and every gradient the fused backward emits, self and cross form, one and two groups per launch, every tile
+width, partial tiles, with and without DropPath scales.  fp32 mode: same arithmetic, different summation order -> 1e-5-class."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from micformer_amd import ops as o
+    return o
+
+
+def rnd(shape, seed, scale=1.0):
+    return (torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale).cuda()
+
+
+def make_params(C, hidden, attn, seed):
+    k = 1.0 / math.sqrt(C)
+    kh = 1.0 / math.sqrt(hidden)
+    P = {"norm1.weight": 1 + rnd((C,), seed + 1, 0.1), "norm1.bias": rnd((C,), seed + 2, 0.1),
+         f"{attn}.q.weight": rnd((C, C), seed + 3, k), f"{attn}.q.bias": rnd((C,), seed + 4, 0.1),
+         f"{attn}.kv.weight": rnd((2 * C, C), seed + 5, k), f"{attn}.kv.bias": rnd((2 * C,), seed + 6, 0.1),
+         f"{attn}.proj.weight": rnd((C, C), seed + 7, k), f"{attn}.proj.bias": rnd((C,), seed + 8, 0.1),
+         "norm2.weight": 1 + rnd((C,), seed + 9, 0.1), "norm2.bias": rnd((C,), seed + 10, 0.1),
+         "mlp.fc1.weight": rnd((hidden, C), seed + 11, k), "mlp.fc1.bias": rnd((hidden,), seed + 12, 0.1),
+         "mlp.fc2.weight": rnd((C, hidden), seed + 13, kh), "mlp.fc2.bias": rnd((C,), seed + 14, 0.1)}
+    return P
+
+
+def ref_fwd(ops, x, kvsrc, P, attn, s1, s2, dims, heads, eps, scale):
+    """The round-1 launch sequence (functional.SelfBlockFn / CrossBlockFn tail)."""
+    B, D, H, W = dims
+    rps = D * H * W
+    xn, m1, r1 = ops.layernorm_fwd(x, P["norm1.weight"], P["norm1.bias"], eps)
+    q = ops.linear_fwd(xn, P[f"{attn}.q.weight"], P[f"{attn}.q.bias"])
+    kv = ops.linear_fwd(kvsrc if kvsrc is not None else xn, P[f"{attn}.kv.weight"], P[f"{attn}.kv.bias"])
+    o = ops.window_attn_fwd(q, kv, dims, heads, (2, 2, 2), scale)
+    x1 = ops.linear_fwd(o, P[f"{attn}.proj.weight"], P[f"{attn}.proj.bias"], resid=x, dp_scale=s1, rows_per_sample=rps)
+    xn2, m2, r2 = ops.layernorm_fwd(x1, P["norm2.weight"], P["norm2.bias"], eps)
+    g, h = ops.linear_fwd(xn2, P["mlp.fc1.weight"], P["mlp.fc1.bias"], act=1, want_pre=True)
+    y = ops.linear_fwd(g, P["mlp.fc2.weight"], P["mlp.fc2.bias"], resid=x1, dp_scale=s2, rows_per_sample=rps)
+    return {"y": y, "xn": xn, "q": q, "kv": kv, "o": o, "x1": x1, "xn2": xn2, "h": h, "g": g,
+            "stats": torch.stack([m1, r1, m2, r2])}
+
+
+def ref_bwd(ops, dy, x, sv, P, attn, s1, s2, dims, heads, scale, cross):
+    B, D, H, W = dims
+    rps = D * H * W
+    C = x.shape[1]
+    m1, r1, m2, r2 = sv["stats"]
+    dh = ops.linear_bwd_data(dy, P["mlp.fc2.weight"], dp_scale=s2, rows_per_sample=rps, pre_act=sv["h"])
+    dxn2 = ops.linear_bwd_data(dh, P["mlp.fc1.weight"])
+    dg2, db2 = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    dx1 = ops.layernorm_bwd(dxn2, sv["x1"], m2.contiguous(), r2.contiguous(), P["norm2.weight"], dg2, db2, add=dy)
+    do = ops.linear_bwd_data(dx1, P[f"{attn}.proj.weight"], dp_scale=s1, rows_per_sample=rps)
+    dq, dkv = ops.window_attn_bwd(sv["q"], sv["kv"], do, dims, heads, (2, 2, 2), scale)
+    dxq = ops.linear_bwd_data(dq, P[f"{attn}.q.weight"])
+    dxk = ops.linear_bwd_data(dkv, P[f"{attn}.kv.weight"])
+    out = {"dx1": dx1, "dh": dh, "dq": dq, "dkv": dkv, "dg2": dg2, "db2": db2}
+    if cross:
+        out["dx"], out["dxs"] = dxq, dxk
+    else:
+        dg1, db1 = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        out["dx"] = ops.layernorm_bwd(dxq + dxk, x, m1.contiguous(), r1.contiguous(), P["norm1.weight"], dg1, db1, add=dx1)
+        out["dg1"], out["db1"] = dg1, db1
+    return out
+
+
+def check(name, got, want, tol, errs):
+    got, want = got.detach().double().cpu(), want.detach().double().cpu()
+    if got.shape != want.shape:
+        errs.append(f"{name}: shape {tuple(got.shape)} vs {tuple(want.shape)}")
+        return
+    scale = max(float(want.abs().max()), 1e-20)
+    err = float((got - want).abs().max())
+    if not (err <= tol * scale + 1e-7):
+        bad = (got - want).abs() > tol * scale + 1e-7
+        errs.append(f"{name}: max abs err {err:.3e} (scale {scale:.3e}), {int(bad.sum())}/{bad.numel()} bad, first bad index {bad.nonzero()[0].tolist() if bad.any() else None}")
+
+
+CASES = [  # (B, D, H, W, C, heads)
+    (2, 4, 4, 4, 48, 3),      # TM 64, 2 full tiles
+    (1, 2, 2, 2, 48, 3),      # one window in a 64-token tile: masked rows
+    (1, 4, 6, 4, 96, 6),      # TM 32, 3 tiles
+    (1, 2, 6, 2, 96, 3),      # head_dim 32, 3 windows: partial last tile
+    (2, 4, 4, 2, 192, 12),    # TM 16
+    (1, 2, 2, 4, 384, 24),    # TM 16, the 160 KB LDS configuration
+    (1, 4, 2, 2, 192, 6),     # head_dim 32 at C 192
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("cross", [False, True])
+@pytest.mark.parametrize("ngroups", [1, 2])
+def test_fused_block_matches_per_op_path(ops, case, cross, ngroups):
+    B, D, H, W, C, heads = case
+    dims = (B, D, H, W)
+    T = B * D * H * W
+    hidden = 4 * C
+    tm = ops.block_tile_tokens(dims, C, heads, hidden)
+    assert tm in (16, 32, 64), f"shape {case} should be handled by the fused kernels"
+    attn = "cross_attn" if cross else "self_attn"
+    eps, scale = 1e-5, (C // heads) ** -0.5
+    groups_f, refs, extra = [], [], []
+    for gi in range(ngroups):
+        seed = 1000 * gi + 17 * C + T
+        P = make_params(C, hidden, attn, seed)
+        x = rnd((T, C), seed + 50)
+        kvsrc = rnd((T, C), seed + 51) if cross else None
+        if B == 2:
+            s1 = torch.tensor([0.0, 1.25] if gi == 0 else [1.25, 1.25]).cuda()
+            s2 = torch.tensor([1.25, 0.0]).cuda()
+        else:
+            s1 = None if gi == 0 else torch.tensor([1.25]).cuda()
+            s2 = None if gi == 0 else torch.tensor([0.8]).cuda()
+        groups_f.append({"x": x, "kvsrc": kvsrc, "P": P, "attn": attn, "s1": s1, "s2": s2, "want_xn": True})
+        refs.append(ref_fwd(ops, x, kvsrc, P, attn, s1, s2, dims, heads, eps, scale))
+        extra.append((x, kvsrc, P, s1, s2, seed))
+    outs = ops.block_fwd(groups_f, dims, C, heads, eps, scale)
+    errs = []
+    for gi, (o, r) in enumerate(zip(outs, refs)):
+        for k in ("xn", "q", "kv", "o", "x1", "xn2", "h", "g", "y", "stats"):
+            check(f"fwd g{gi} {k}", o[k], r[k], 2e-5, errs)
+    assert not errs, "\n".join(errs)
+
+    groups_b, brefs = [], []
+    for gi, (o, (x, kvsrc, P, s1, s2, seed)) in enumerate(zip(outs, extra)):
+        dy = rnd((T, C), seed + 60)
+        groups_b.append({"dy": dy, "x": x, "x1": o["x1"], "stats": o["stats"], "q": o["q"], "kv": o["kv"], "h": o["h"], "P": P,
+                         "attn": attn, "s1": s1, "s2": s2, "cross": cross, "want_copy": cross})
+        brefs.append(ref_bwd(ops, dy, x, refs[gi], P, attn, s1, s2, dims, heads, scale, cross))
+    bouts = ops.block_bwd(groups_b, dims, C, heads, scale)
+    for gi, (o, r) in enumerate(zip(bouts, brefs)):
+        for k in ("dh", "dx1", "dq", "dkv", "dx"):
+            check(f"bwd g{gi} {k}", o[k], r[k], 5e-5, errs)
+        if cross:
+            check(f"bwd g{gi} dxs", o["dxs"], r["dxs"], 5e-5, errs)
+            check(f"bwd g{gi} dx1_copy", o["dx1_copy"], r["dx1"], 5e-5, errs)
+        p2 = o["ln2_part"].sum(0)
+        check(f"bwd g{gi} dgamma2", p2[:C], r["dg2"], 2e-4, errs)
+        check(f"bwd g{gi} dbeta2", p2[C:], r["db2"], 2e-4, errs)
+        if not cross:
+            p1 = o["ln1_part"].sum(0)
+            check(f"bwd g{gi} dgamma1", p1[:C], r["dg1"], 2e-4, errs)
+            check(f"bwd g{gi} dbeta1", p1[C:], r["db1"], 2e-4, errs)
+        # the partial rows feed the round-1 finish kernel unchanged
+        dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        ops.layernorm_bwd_finish([(o["ln2_part"], o["tiles"], C, dg, db)])
+        check(f"bwd g{gi} finish dgamma2", dg, r["dg2"], 2e-4, errs)
+        check(f"bwd g{gi} finish dbeta2", db, r["db2"], 2e-4, errs)
+    assert not errs, "\n".join(errs)
+
+
+def test_unsupported_shapes_are_reported(ops):
+    assert ops.block_tile_tokens((1, 3, 4, 4), 48, 3, 192) == 0          # odd token grid: pad-to-window path
+    assert ops.block_tile_tokens((1, 4, 4, 4), 24, 3, 96) == 0           # head_dim 8 (tiny config)
+    assert ops.block_tile_tokens((1, 4, 4, 4), 768, 24, 3072) == 0       # does not fit the LDS budget
+    assert ops.block_tile_tokens((2, 32, 32, 32), 48, 3, 192) == 64
+
+
+@pytest.mark.parametrize("case", [(2, 4, 4, 4, 48, 3), (1, 4, 6, 4, 96, 6), (2, 4, 4, 2, 192, 12)])
+def test_fused_block_bf16_mode_is_close(ops, case):
+    """bf16 matrix-core operands (fp32 accumulate, fp32 everywhere else): 8-bit mantissas on the GEMM inputs only."""
+    B, D, H, W, C, heads = case
+    dims = (B, D, H, W)
+    T = B * D * H * W
+    attn = "self_attn"
+    P = make_params(C, 4 * C, attn, 5)
+    x = rnd((T, C), 7)
+    eps, scale = 1e-5, (C // heads) ** -0.5
+    ref = ref_fwd(ops, x, None, P, attn, None, None, dims, heads, eps, scale)
+    ops.set_compute_dtype("bf16")
+    try:
+        o = ops.block_fwd([{"x": x, "kvsrc": None, "P": P, "attn": attn, "s1": None, "s2": None}], dims, C, heads, eps, scale)[0]
+        dy = rnd((T, C), 9)
+        b = ops.block_bwd([{"dy": dy, "x": x, "x1": o["x1"], "stats": o["stats"], "q": o["q"], "kv": o["kv"], "h": o["h"], "P": P,
+                            "attn": attn, "s1": None, "s2": None, "cross": False}], dims, C, heads, scale)[0]
+    finally:
+        ops.set_compute_dtype("fp32")
+    errs = []
+    for k in ("q", "kv", "o", "x1", "h", "y"):
+        check(f"bf16 fwd {k}", o[k], ref[k], 2e-2, errs)
+    rb = ref_bwd(ops, dy, x, ref, P, attn, None, None, dims, heads, scale, False)
+    for k in ("dh", "dx1", "dq", "dkv", "dx"):
+        check(f"bf16 bwd {k}", b[k], rb[k], 3e-2, errs)
+    assert float((o["y"] - ref["y"]).abs().max()) > 0                      # it really is a different arithmetic
+    assert not errs, "\n".join(errs)

@@ -32,8 +32,21 @@ def _data(B, n=64):
     return fill.make_volume(B, n, n, n).cuda(), fill.one_hot(fill.make_label_map(B, n, n, n)).cuda()
 
 
-def _max_diff(a, b):
-    return max(float((a[k] - b[k]).abs().max()) for k in a)
+def _same_training_state(a, b, what=""):
+    """Two engines took the same number of the same updates.  The first Adam steps are lr * g / (|g| + eps): an element whose
+    gradient is accumulation-order noise around 0 can land a whole 2 * lr apart, so the weights are compared by the FRACTION
+    of elements that moved differently, and the update count by the first moment (m = sum of (1 - b1) b1^k g over the updates
+    taken: one extra update changes it by O(1) relative) and the device step counter."""
+    assert int(a.adam_state[0].item()) == int(b.adam_state[0].item()), what
+    ma, mb = a.flat_m, b.flat_m
+    fin = torch.isfinite(ma) & torch.isfinite(mb)
+    scale = float(ma[fin].abs().max())
+    assert scale > 0 and float((ma - mb)[fin].abs().max()) <= 3e-2 * scale, f"{what}: Adam first moments differ"
+    pa, pb = a.flat_p, b.flat_p
+    strong = fin & torch.isfinite(pa) & torch.isfinite(pb) & (ma.abs() > 1e-3 * scale)      # gradients well above the noise
+    assert int(strong.sum()) > 100
+    worst = float((pa - pb)[strong].abs().max())
+    assert worst < 2e-5, f"{what}: weights with a clear gradient differ by {worst} (one extra lr = 1e-3 update would be ~1e-3)"
 
 
 def test_graph_capture_warmup_does_not_train(M):
@@ -47,16 +60,16 @@ def test_graph_capture_warmup_does_not_train(M):
     for n in (1, 2):
         le, lg = eager.step(x, t), graph.step(x, t)
         assert int(graph.adam_state[0].item()) == n == int(eager.adam_state[0].item())
-        assert abs(float(le) - float(lg)) < 1e-5
+        assert abs(float(le) - float(lg)) < 1e-4
         assert abs(graph.lr() - eager.lr()) < 1e-15
-        assert _max_diff(eager.model.state_dict(), graph.model.state_dict()) < 2e-6
+        _same_training_state(eager, graph, f"after {n} steps")
     assert graph.steps_done == 2
     ck = graph.checkpoint(epoch=0)
     graph.load_checkpoint(ck)                      # drops the graph: the next step re-captures (and must again not train)
     assert graph._graph is None
     le, lg = eager.step(x, t), graph.step(x, t)
     assert int(graph.adam_state[0].item()) == 3
-    assert _max_diff(eager.model.state_dict(), graph.model.state_dict()) < 4e-6
+    _same_training_state(eager, graph, "after reload + 1 step")
 
 
 def test_ragged_last_batch_runs_eagerly(M):
@@ -69,11 +82,12 @@ def test_ragged_last_batch_runs_eagerly(M):
     b = TrainEngine(_head(M), base_lr=1e-3, t_max=5, use_graph=False)
     a.step(x2, t2), b.step(x2, t2)
     la, lb = a.step(x1, t1), b.step(x1, t1)        # graph engine: shape mismatch -> eager fallback
-    assert abs(float(la) - float(lb)) < 1e-5
-    assert _max_diff(a.model.state_dict(), b.model.state_dict()) < 2e-6
+    assert abs(float(la) - float(lb)) < 1e-4
+    _same_training_state(a, b, "after the ragged batch")
     la, lb = a.step(x2, t2), b.step(x2, t2)        # and the captured graph is still valid for the full batch
-    assert abs(float(la) - float(lb)) < 1e-5
+    assert abs(float(la) - float(lb)) < 1e-4
     assert int(a.adam_state[0].item()) == 3
+    _same_training_state(a, b, "after the next full batch")
 
 
 def test_checkpoint_lr_is_torchs_after_n_scheduler_steps(M):
@@ -105,7 +119,7 @@ def test_engine_switches_are_scoped_to_its_step(M):
     from micformer_amd import functional as Fn
     from micformer_amd.engine import TrainEngine
     import micformer_amd.models.MICFormer_self as ms
-    x, t = _data(1, 32)
+    x, t = _data(1, 64)                # (32^3 would give the tiny config a 1^3 stage: NaN gradients, as the reference)
     eng = TrainEngine(_head(M), use_graph=False)
     eng.step(x, t)
     assert Fn.DEFER_WGRAD is False and ms.PARALLEL_MODALITIES is False

@@ -280,7 +280,10 @@ typedef struct micf_block_fwd_group {
 typedef struct micf_block_bwd_group {
   const float* dy;     /* [T, C] gradient w.r.t. the block output (also fc2's output gradient for the weight-gradient GEMM) */
   const float *x, *x1, *stats, *q, *kv, *h; /* as saved by micf_block_fwd (x and ln1_g may be NULL for a cross block) */
-  const float *ln1_g, *ln2_g, *wq, *wkv, *wp, *w1, *w2, *s1, *s2;
+  const float *ln1_g, *ln2_g;
+  const float *wqt, *wkvt, *wpt, *w1t, *w2t; /* TRANSPOSED weights: q^T [C,C], kv^T [C,2C], proj^T [C,C], fc1^T [C,hidden],
+                                                fc2^T [hidden,C] (micf_transpose_grouped) */
+  const float *s1, *s2;
   float* dx;           /* self: [T, C] gradient w.r.t. the block input.  cross: the q path's PRE-LayerNorm gradient dq Wq (the
                           caller adds the offset-conv path and applies LN1 backward with add = dx1) */
   float* dxs;          /* cross: [T, C] gradient w.r.t. kvsrc; NULL = self attention */
@@ -290,7 +293,15 @@ typedef struct micf_block_bwd_group {
   float* dx1_copy;     /* optional second copy of dx1 [T, C]: the buffer a cross PAIR then accumulates the other block's
                           K/V-source gradient and its own LN1 backward into (no zero fill, no separate add) */
 } micf_block_bwd_group;
-int micf_block_tile_tokens(int B, int D, int H, int W, int C, int heads, int hidden);
+int micf_block_tile_tokens(int B, int D, int H, int W, int C, int heads, int hidden, int backward);
+/* dst[c, r] = src[r, c] for a list of row-major matrices in one launch per 64 items (the block weights' transposes the fused
+ * backward streams; refreshed once per step).  `items` is HOST memory, read during the call only. */
+typedef struct micf_transpose_item {
+  const float* src; /* [rows, cols] */
+  float* dst;       /* [cols, rows] */
+  int32_t rows, cols;
+} micf_transpose_item;
+int micf_transpose_grouped(const micf_transpose_item* items, int n, micf_stream_t stream);
 /* `groups` is HOST memory, read during the call only. */
 int micf_block_fwd(const micf_block_fwd_group* groups, int ngroups, int B, int D, int H, int W, int C, int heads,
                    int hidden, float eps, float scale, int dtype, micf_stream_t stream);

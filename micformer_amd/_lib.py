@@ -66,7 +66,8 @@ SIGNATURES = {
     "micf_argmax_meandice": "pppppiilp",
     "micf_adam_tick": "pddlp",
     "micf_adam_step": "pppplpffffp",
-    "micf_block_tile_tokens": "iiiiiii",
+    "micf_block_tile_tokens": "iiiiiiii",
+    "micf_transpose_grouped": "pip",
     "micf_block_fwd": "piiiiiiiiffip",
     "micf_block_bwd": "piiiiiiiifip",
     "micf_zero": "plp",
@@ -99,9 +100,14 @@ class BlockFwdGroup(ctypes.Structure):
 
 class BlockBwdGroup(ctypes.Structure):
     """struct micf_block_bwd_group (include/micformer_hip.h)."""
-    FIELDS = ("dy", "x", "x1", "stats", "q", "kv", "h", "ln1_g", "ln2_g", "wq", "wkv", "wp", "w1", "w2", "s1", "s2",
+    FIELDS = ("dy", "x", "x1", "stats", "q", "kv", "h", "ln1_g", "ln2_g", "wqt", "wkvt", "wpt", "w1t", "w2t", "s1", "s2",
               "dx", "dxs", "dx1", "dh", "dq", "dkv", "ln1_part", "ln2_part", "dx1_copy")
     _fields_ = [(n, _VP) for n in FIELDS]
+
+
+class TransposeItem(ctypes.Structure):
+    """struct micf_transpose_item (include/micformer_hip.h)."""
+    _fields_ = [("src", _VP), ("dst", _VP), ("rows", ctypes.c_int32), ("cols", ctypes.c_int32)]
 
 
 class MicfError(RuntimeError):
@@ -124,7 +130,7 @@ def _load():
     lib.micf_offset_sample_bwd_workspace.restype = _L
     lib.micf_conv3_bwd_weight_workspace.restype = _L
     lib.micf_conv3_fwd_workspace.restype = _L
-    lib.micf_block_tile_tokens.argtypes = [_I] * 7          # (no stream argument: a pure shape query)
+    lib.micf_block_tile_tokens.argtypes = [_I] * 8          # (no stream argument: a pure shape query)
     lib.micf_strerror.argtypes = [_I]
     lib.micf_strerror.restype = ctypes.c_char_p
     lib.micf_abi_version.argtypes = []

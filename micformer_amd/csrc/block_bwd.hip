@@ -4,7 +4,8 @@
 //   dh  = (s2 dy W2) * GELU'(h)            -> HBM (fc1 weight gradient)          dy itself is fc2's output gradient
 //   dx1 = dy + LN2'(dh W1)                 -> HBM (proj weight gradient; the cross block's LN1 backward adds it)
 //   do  = s1 dx1 Wp ;  (dq, dk, dv) = attention'(q, k, v, do)   -> HBM dq, dkv (q / kv weight gradients)
-//   self : dx  = dx1 + LN1'(dq Wq + dkv Wkv)
+//   self : dx  = dx1 + LN1'(dq Wq + dkv Wkv)                 (all "dY W" products read the TRANSPOSED weights W^T [K, N], which
+//                                                            micf_transpose_grouped refreshes once per step: contiguous rows)
 //   cross: dxq = dq Wq  (pre-LayerNorm; the offset-conv path adds its part before LN1')   and   dxs = dkv Wkv
 //
 // plus per-tile partial sums of the LayerNorm gain / bias gradients ([tiles][2C], summed by micf_layernorm_bwd_finish).
@@ -21,8 +22,6 @@ struct BlkBwdArgs {
   int G, tiles, C, heads, hidden;
   float scale;
 };
-
-constexpr size_t block_lds_bytes_b(int TM, int C) { return sizeof(float) * (size_t)(kFusedRing + TM * (2 * (C + 4) + 3 * C + 4) + 3 * TM); }
 
 // LayerNorm backward of the rows held in LDS tile `D` (gradient w.r.t. the normalised output, pre-gain) against the HBM rows
 // `xsrc`: out = addt + rs * (g d - mean(g d) - xh mean(g d xh)).  addt / out are LDS tile A (in place) and HBM `hout`.
@@ -104,13 +103,13 @@ __device__ __forceinline__ void ln_bwd_tile(const float* D, float* A, int S, int
   __syncthreads();
 }
 
-template <int TJ, int HD, int VPL, bool BF16>
-__global__ void __launch_bounds__(256) block_bwd_kernel(const BlkBwdArgs a) {
-  constexpr int TM = 16 * TJ;
+template <int C, int HD, int TJ, bool BF16>
+__global__ void __launch_bounds__(256, 2) block_bwd_kernel(const BlkBwdArgs a) {
+  constexpr int TM = 16 * TJ, VPL = (C + 63) / 64, NSL = C / 16;
   extern __shared__ __attribute__((aligned(1024))) float lds[];
-  const int C = a.C, C4 = C >> 2, S = C + 4, SU = 3 * C + 4, Hd = a.hidden;
+  constexpr int C4 = C >> 2, S = C + 4, SU = 3 * C + 4, Hd = 4 * C;
   float* ring = lds;
-  float* A1 = ring + kFusedRing;
+  float* A1 = ring + kFusedScratch;
   float* A2 = A1 + TM * S;
   float* U = A2 + TM * S;
   float* sc1 = U + TM * SU;
@@ -149,10 +148,10 @@ __global__ void __launch_bounds__(256) block_bwd_kernel(const BlkBwdArgs a) {
   }
 
   // ---- MLP backward in hidden chunks: h chunk -> U;  U <- s2 (dy W2) GELU'(h) = dh (saved);  A2 (+)= dh W1
-  const int HC = 2 * C;
+  constexpr int HC = 2 * C;
   for (int c0 = 0; c0 < Hd; c0 += HC) {
-    const int hc = (Hd - c0 < HC) ? Hd - c0 : HC;
-    const int X4 = hc >> 2;
+    constexpr int hc = HC;
+    constexpr int X4 = hc >> 2;
 #pragma unroll 1
     for (int pass = 0; pass < TJ; ++pass) {
       const int row = pass * 16 + wave * 4 + rg;
@@ -161,7 +160,7 @@ __global__ void __launch_bounds__(256) block_bwd_kernel(const BlkBwdArgs a) {
         *reinterpret_cast<float4*>(U + row * SU + 4 * c4) = tk >= 0 ? ld4g(g.h + (int64_t)tk * Hd + c0 + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
-    gemm_phase<TJ, true, EPI_GELU_GRAD, BF16>(g.w2 + c0, Hd, hc, C, A1, S, U, SU, sc2, ring);
+    gemm_phase<TJ, NSL, 1, C, BF16>(g.w2t + (int64_t)c0 * C, hc, A1, nullptr, 0, nullptr, S, U, SU, EpiGeluGrad{sc2});
 #pragma unroll 1
     for (int pass = 0; pass < TJ; ++pass) {
       const int row = pass * 16 + wave * 4 + rg;
@@ -170,8 +169,8 @@ __global__ void __launch_bounds__(256) block_bwd_kernel(const BlkBwdArgs a) {
       for (int c4 = l16; c4 < X4; c4 += 16)
         st4g(g.dh + (int64_t)tk * Hd + c0 + 4 * c4, *reinterpret_cast<const float4*>(U + row * SU + 4 * c4));
     }
-    if (c0 == 0) gemm_phase<TJ, true, EPI_STORE, BF16>(g.w1 + (int64_t)c0 * C, C, C, hc, U, SU, A2, S, nullptr, ring);
-    else gemm_phase<TJ, true, EPI_ACC, BF16>(g.w1 + (int64_t)c0 * C, C, C, hc, U, SU, A2, S, nullptr, ring);
+    if (c0 == 0) gemm_phase<TJ, NSL, 2, Hd, BF16>(g.w1t + c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiStore{});
+    else gemm_phase<TJ, NSL, 2, Hd, BF16>(g.w1t + c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiAcc{});
   }
 
   // ---- dx1 = dy + LN2'(A2) -> A1 + HBM; LN2 gain / bias partials
@@ -179,7 +178,7 @@ __global__ void __launch_bounds__(256) block_bwd_kernel(const BlkBwdArgs a) {
                        g.ln2_part ? g.ln2_part + (int64_t)tile * 2 * C : nullptr);
 
   // ---- do = s1 dx1 Wp -> A2;  q | k | v rows -> U
-  gemm_phase<TJ, true, EPI_STORE_SCALE, BF16>(g.wp, C, C, C, A1, S, A2, S, sc1, ring);
+  gemm_phase<TJ, NSL, 1, C, BF16>(g.wpt, C, A1, nullptr, 0, nullptr, S, A2, S, EpiStoreScale{sc1});
 #pragma unroll 1
   for (int pass = 0; pass < TJ; ++pass) {
     const int row = pass * 16 + wave * 4 + rg;
@@ -194,7 +193,7 @@ __global__ void __launch_bounds__(256) block_bwd_kernel(const BlkBwdArgs a) {
 
   // ---- attention backward in place on U.  Thread = (window, row i, head); batches of whole windows.
   {
-    const int heads = a.heads, per = 8 * heads, wpb = 256 / per;
+    constexpr int heads = C / HD, per = 8 * heads, wpb = 256 / per;
     float* PS = ring;                                   // [256][16]: P row | dS row of every thread of the batch
     for (int w0 = 0; w0 < TM / 8; w0 += wpb) {
       const int wl = tid / per, rem = tid - wl * per;
@@ -300,13 +299,13 @@ __global__ void __launch_bounds__(256) block_bwd_kernel(const BlkBwdArgs a) {
 
   if (!g.dxs) {
     // ---- self: dxn = dq Wq + dkv Wkv -> A2;  dx = dx1 + LN1'(dxn) -> HBM; LN1 partials
-    gemm_phase<TJ, true, EPI_STORE, BF16>(g.wq, C, C, C, U, SU, A2, S, nullptr, ring);
-    gemm_phase<TJ, true, EPI_ACC, BF16>(g.wkv, C, C, 2 * C, U + C, SU, A2, S, nullptr, ring);
+    gemm_phase<TJ, NSL, 1, C, BF16>(g.wqt, C, U, nullptr, 0, nullptr, SU, A2, S, EpiStore{});
+    gemm_phase<TJ, NSL, 2, 2 * C, BF16>(g.wkvt, C, U + C, nullptr, 0, nullptr, SU, A2, S, EpiAcc{});
     ln_bwd_tile<TJ, VPL>(A2, A1, S, C, g.x, g.stats, g.stats + T, g.ln1_g, tok, g.dx, nullptr, U,
                          g.ln1_part ? g.ln1_part + (int64_t)tile * 2 * C : nullptr);
   } else {
     // ---- cross: the q path's pre-LayerNorm gradient and the sampled K/V source's gradient leave separately
-    gemm_phase<TJ, true, EPI_STORE, BF16>(g.wq, C, C, C, U, SU, A2, S, nullptr, ring);
+    gemm_phase<TJ, NSL, 1, C, BF16>(g.wqt, C, U, nullptr, 0, nullptr, SU, A2, S, EpiStore{});
 #pragma unroll 1
     for (int pass = 0; pass < TJ; ++pass) {
       const int row = pass * 16 + wave * 4 + rg;
@@ -315,7 +314,7 @@ __global__ void __launch_bounds__(256) block_bwd_kernel(const BlkBwdArgs a) {
       for (int c4 = l16; c4 < C4; c4 += 16) st4g(g.dx + (int64_t)tk * C + 4 * c4, *reinterpret_cast<const float4*>(A2 + row * S + 4 * c4));
     }
     __syncthreads();
-    gemm_phase<TJ, true, EPI_STORE, BF16>(g.wkv, C, C, 2 * C, U + C, SU, A2, S, nullptr, ring);
+    gemm_phase<TJ, NSL, 2, 2 * C, BF16>(g.wkvt, C, U + C, nullptr, 0, nullptr, SU, A2, S, EpiStore{});
 #pragma unroll 1
     for (int pass = 0; pass < TJ; ++pass) {
       const int row = pass * 16 + wave * 4 + rg;
@@ -326,19 +325,19 @@ __global__ void __launch_bounds__(256) block_bwd_kernel(const BlkBwdArgs a) {
   }
 }
 
-template <int TJ, int HD, int VPL>
+template <int C, int HD, int TJ>
 static int launch_bwd(const BlkBwdArgs& a, int dtype, hipStream_t s) {
   constexpr int TM = 16 * TJ;
-  const size_t lds = block_lds_bytes_b(TM, a.C);
+  const size_t lds = block_lds_floats(TM, C, 4 * C) * sizeof(float);
   if (lds > 160 * 1024) return MICF_EUNSUPPORTED;
   const unsigned grid = a.G == 2 ? (unsigned)((a.tiles + 3) / 4 * 8) : (unsigned)a.tiles;
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_bwd_kernel<TJ, HD, VPL, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_bwd_kernel<TJ, HD, VPL, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_bwd_kernel<C, HD, TJ, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_bwd_kernel<C, HD, TJ, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
-  if (dtype == MICF_DTYPE_BF16) hipLaunchKernelGGL((block_bwd_kernel<TJ, HD, VPL, true>), dim3(grid), dim3(256), lds, s, a);
-  else hipLaunchKernelGGL((block_bwd_kernel<TJ, HD, VPL, false>), dim3(grid), dim3(256), lds, s, a);
+  if (dtype == MICF_DTYPE_BF16) hipLaunchKernelGGL((block_bwd_kernel<C, HD, TJ, true>), dim3(grid), dim3(256), lds, s, a);
+  else hipLaunchKernelGGL((block_bwd_kernel<C, HD, TJ, false>), dim3(grid), dim3(256), lds, s, a);
   MICF_RETURN_LAUNCH();
 }
 
@@ -349,13 +348,13 @@ using namespace micf;
 extern "C" int micf_block_bwd(const micf_block_bwd_group* groups, int ngroups, int B, int D, int H, int W, int C, int heads,
                               int hidden, float scale, int dtype, micf_stream_t stream) {
   if (!groups || ngroups < 1 || ngroups > 2) return MICF_EINVAL;
-  const int TM = micf_block_tile_tokens(B, D, H, W, C, heads, hidden);
+  const int TM = micf_block_tile_tokens(B, D, H, W, C, heads, hidden, 1);
   if (TM == 0) return MICF_EUNSUPPORTED;
   if (dtype != MICF_DTYPE_F32 && dtype != MICF_DTYPE_BF16) return MICF_EINVAL;
   BlkBwdArgs a;
   for (int i = 0; i < ngroups; ++i) {
     const micf_block_bwd_group& g = groups[i];
-    const void* need[] = {g.dy, g.x1, g.stats, g.q, g.kv, g.h, g.ln2_g, g.wq, g.wkv, g.wp, g.w1, g.w2, g.dx, g.dx1, g.dh, g.dq, g.dkv};
+    const void* need[] = {g.dy, g.x1, g.stats, g.q, g.kv, g.h, g.ln2_g, g.wqt, g.wkvt, g.wpt, g.w1t, g.w2t, g.dx, g.dx1, g.dh, g.dq, g.dkv};
     for (const void* p : need)
       if (!p || (reinterpret_cast<uintptr_t>(p) & 15)) return MICF_EINVAL;
     if (!g.dxs && (!g.x || !g.ln1_g)) return MICF_EINVAL;          // self: LayerNorm-1 backward runs in the kernel
@@ -369,10 +368,10 @@ extern "C" int micf_block_bwd(const micf_block_bwd_group* groups, int ngroups, i
   a.G = ngroups; a.C = C; a.heads = heads; a.hidden = hidden; a.scale = scale;
   a.tiles = (a.geo.nwin + TM / 8 - 1) / (TM / 8);
   hipStream_t s = (hipStream_t)stream;
-  const int hd = C / heads, vpl = (C + 63) / 64, tj = TM / 16;
-#define MICF_BB(TJ_, HD_, VPL_) if (tj == TJ_ && hd == HD_ && vpl == VPL_) return launch_bwd<TJ_, HD_, VPL_>(a, dtype, s)
-  MICF_BB(4, 16, 1); MICF_BB(2, 16, 1); MICF_BB(2, 16, 2); MICF_BB(1, 16, 2); MICF_BB(1, 16, 3); MICF_BB(1, 16, 6);
-  MICF_BB(2, 32, 2); MICF_BB(1, 32, 3); MICF_BB(1, 32, 6);
+  const int hd = C / heads, tj = TM / 16;
+#define MICF_BB(C_, HD_, TJ_) if (C == C_ && hd == HD_ && tj == TJ_) return launch_bwd<C_, HD_, TJ_>(a, dtype, s)
+  MICF_BB(48, 16, 2); MICF_BB(48, 16, 1); MICF_BB(48, 16, 4); MICF_BB(96, 16, 1); MICF_BB(96, 16, 2); MICF_BB(192, 16, 1);
+  MICF_BB(96, 32, 1); MICF_BB(192, 32, 1);
 #undef MICF_BB
   return MICF_EUNSUPPORTED;
 }

@@ -4,16 +4,17 @@
 // source: LayerNorm, the q/kv/proj/fc1/fc2 linears, GELU, the residual adds are per token and attention is per window.  A
 // workgroup therefore takes a tile of TM = 16 * TJ tokens (TM / 8 whole windows), keeps every intermediate of the block in
 // LDS, and streams only the WEIGHTS from L2 / HBM:
-//   * weights arrive through the gfx950 LDS-DMA engine (`global_load_lds_dwordx4`, gemm_dma.h) as [64][16] slab images in a
-//     4-deep ring, one counted `s_waitcnt vmcnt` + one `s_barrier` per slab;
+//   * a wave owns whole 16-wide output-feature tiles, so no weight is shared between waves: each lane loads its MFMA
+//     A-fragments straight from L2 / HBM into registers, 8 slabs ahead (no LDS staging, no barrier inside a GEMM phase);
 //   * the activation operand of every GEMM is an LDS-resident tile [TM][K + 4] (row = token, natural k order), read as one
 //     ds_read_b128 per 4 k-steps with the k-permutation of gemm_dma.h (lane group lr supplies k = 4*lr + s in step s);
-//   * results go back to an LDS tile (store / accumulate / scale / GELU'-combine epilogues): the GEMM loop issues NO vector
-//     memory operation besides its DMAs, so the counted vmcnt waits stay exact; HBM traffic happens in row-coalesced
-//     element-wise passes between the GEMM phases.
+//   * results go back to an LDS tile (store / accumulate / scale / GELU'-combine epilogues); HBM traffic of the activations
+//     happens in row-coalesced element-wise passes between the GEMM phases.
 // MFMA is v_mfma_f32_16x16x4_f32 (exact fp32: bitwise a k-ordered fmaf chain) or, in bf16 mode, v_mfma_f32_16x16x32_bf16
 // on operands rounded to bf16 at the fragment read (fp32 LDS tiles and weights, fp32 accumulation).
 #pragma once
+#include <cstdlib>
+
 #include "common.h"
 #include "gemm_dma.h"
 
@@ -33,181 +34,150 @@ __device__ __forceinline__ bf16x8 to_bf16x8(const float4& lo, const float4& hi) 
   return __builtin_bit_cast(bf16x8, r);
 }
 
-__device__ __forceinline__ void wait_dma1(int younger) {     // one DMA per slab per wave
-  switch (younger) {
-    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-  }
-}
-
-constexpr int kFusedNS = 4;            // weight-slab ring depth
-constexpr int kFusedRing = kFusedNS * 1024;   // floats
-
-enum { EPI_STORE = 0, EPI_ACC = 1, EPI_STORE_SCALE = 2, EPI_ACC_SCALE = 3, EPI_GELU_GRAD = 4 };
-
-template <int EPI>
-__device__ __forceinline__ void epi_apply(float* o, const float4 v, float rs) {
-  float4 r;
-  if constexpr (EPI == EPI_STORE) r = v;
-  else if constexpr (EPI == EPI_STORE_SCALE) r = make_float4(rs * v.x, rs * v.y, rs * v.z, rs * v.w);
-  else {
+// ---- epilogues of a GEMM phase: called with the LDS destination of 4 consecutive outputs x..x+3 of token row `trow`.
+// They touch LDS only (the GEMM loop must not issue vector memory operations besides its DMAs).
+struct EpiStore {
+  __device__ __forceinline__ void operator()(float* o, int, int, const float4& v) const { *reinterpret_cast<float4*>(o) = v; }
+};
+struct EpiAcc {
+  __device__ __forceinline__ void operator()(float* o, int, int, const float4& v) const {
     const float4 c = *reinterpret_cast<const float4*>(o);
-    if constexpr (EPI == EPI_ACC) r = make_float4(c.x + v.x, c.y + v.y, c.z + v.z, c.w + v.w);
-    else if constexpr (EPI == EPI_ACC_SCALE) r = make_float4(c.x + rs * v.x, c.y + rs * v.y, c.z + rs * v.z, c.w + rs * v.w);
-    else r = make_float4(rs * v.x * gelu_grad_f(c.x), rs * v.y * gelu_grad_f(c.y), rs * v.z * gelu_grad_f(c.z), rs * v.w * gelu_grad_f(c.w));
+    *reinterpret_cast<float4*>(o) = make_float4(c.x + v.x, c.y + v.y, c.z + v.z, c.w + v.w);
   }
-  *reinterpret_cast<float4*>(o) = r;
-}
+};
+struct EpiBias {              // + bias[x] (bias vector in LDS)
+  const float* bias;
+  __device__ __forceinline__ void operator()(float* o, int x, int, const float4& v) const {
+    const float4 b = *reinterpret_cast<const float4*>(bias + x);
+    *reinterpret_cast<float4*>(o) = make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w);
+  }
+};
+struct EpiStoreScale {        // rowscale[trow] * v
+  const float* rowscale;
+  __device__ __forceinline__ void operator()(float* o, int, int trow, const float4& v) const {
+    const float rs = rowscale[trow];
+    *reinterpret_cast<float4*>(o) = make_float4(rs * v.x, rs * v.y, rs * v.z, rs * v.w);
+  }
+};
+struct EpiAccScale {          // += rowscale[trow] * v
+  const float* rowscale;
+  __device__ __forceinline__ void operator()(float* o, int, int trow, const float4& v) const {
+    const float rs = rowscale[trow];
+    const float4 c = *reinterpret_cast<const float4*>(o);
+    *reinterpret_cast<float4*>(o) = make_float4(c.x + rs * v.x, c.y + rs * v.y, c.z + rs * v.z, c.w + rs * v.w);
+  }
+};
+struct EpiGeluGrad {          // rowscale[trow] * v * GELU'(what the tile holds: the saved pre-activation)
+  const float* rowscale;
+  __device__ __forceinline__ void operator()(float* o, int, int trow, const float4& v) const {
+    const float rs = rowscale[trow];
+    const float4 c = *reinterpret_cast<const float4*>(o);
+    *reinterpret_cast<float4*>(o) = make_float4(rs * v.x * gelu_grad_f(c.x), rs * v.y * gelu_grad_f(c.y), rs * v.z * gelu_grad_f(c.z),
+                                                 rs * v.w * gelu_grad_f(c.w));
+  }
+};
 
 // One GEMM phase of a fused block kernel:
-//   O[t][x] (op)= sum_r A(x, r) * Bs[t][r]      t < 16 * TJ, x < X (X % 16 == 0), r < R (R % 16 == 0)
-//   AX == false: A(x, r) = Wg[x * ld + r]   (nn.Linear forward: x = output feature n, r = input feature k)
-//   AX == true : A(x, r) = Wg[r * ld + x]   (data gradient: x = input feature k, r = output feature n)
-// Bs / Os are LDS tiles with row strides SB / SO (floats, multiples of 4); rowscale (LDS, [16*TJ]) is used by the *_SCALE and
-// GELU_GRAD epilogues.  All 256 threads call it together.  On return every DMA has landed, Os is complete and visible to the
-// workgroup, and the ring may be reused.
-template <int TJ, bool AX, int EPI, bool BF16>
-__device__ __forceinline__ void gemm_phase(const float* __restrict__ Wg, int ld, int X, int R, const float* Bs, int SB,
-                                           float* Os, int SO, const float* rowscale, float* ring) {
-  constexpr int NT = TJ;
+//   O[t][x] (epi)= sum_r A(x, r) * B[t][r]      t < 16 * TG, r < R = 16 * NSL * NK
+// over one or two weight SEGMENTS (x in [0, X0) from W0 against activation tile Bs0, x in [X0, X0 + X1) from W1 against Bs1;
+// X0, X1 multiples of 16, same R and leading dimension LD) -- q | kv in one phase although they are separate tensors:
+//   A(x, r) = W[x * LD + r]: rows of W are the outputs.  nn.Linear forward: W = the weight [N, K]; data gradients
+//   (dA = dY W): W = the TRANSPOSED weight [K, N] (micf_transpose_grouped, once per step), so both directions stream
+//   contiguous 64-byte row pieces.
+// The 16-wide x tiles are dealt round-robin to the four waves.  Nothing about a tile's weights is shared between waves, so
+// they do not go through LDS at all: every lane loads ITS MFMA A-fragments straight from L2 / HBM into registers (one
+// 16-byte load per 16-deep slab = A(x = li, r = 4 lr .. 4 lr + 3)).  The unit of work is
+// (tile, k-chunk of NSL slabs); NSL, NK and LD are compile-time, so a unit is ONE base-pointer computation plus NSL loads at
+// immediate offsets, fully unrolled, and the loop is software-pipelined in registers: the fragments of unit u + 1 are in
+// flight while unit u feeds 4 * TG * NSL MFMAs.  (The first version streamed weights through an LDS-DMA ring with a barrier
+// per slab: at 16-32 tokens per workgroup the per-slab bookkeeping -- ~80 instructions for 4-8 MFMAs -- was the bound.)
+// The activation operand Bs is an LDS tile [16 TG][SB] read as one ds_read_b128 per token group and slab (k-permutation:
+// lane group lr supplies k = 4 lr + s in step s, both operands alike); a wave writes only its own x columns of the LDS output
+// tile Os.  Two accumulator chains per token group (even / odd k-steps) keep the fp32 MFMA pipe at its issue rate.
+// All 256 threads call it together; on return Os is complete and visible to the workgroup.
+template <int TG, int NSL, int NK, int LD, bool BF16, class Epi>
+__device__ __forceinline__ void gemm_phase(const float* __restrict__ W0, int X0, const float* Bs0, const float* __restrict__ W1,
+                                           int X1, const float* Bs1, int SB, float* Os, int SO, const Epi epi) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lr = lane >> 4;
-  const int wj = wave % TJ, wi = wave / TJ;
-  const int nxb = (X + 63) >> 6, nsl = R >> 4, total = nxb * nsl;
-  const int p = wave * 64 + lane;                       // 16-byte position inside the 4 KiB slab image
-  const unsigned ldsbase = lds_addr(ring) + wave * 1024;
+  const int nt0 = X0 >> 4, ntiles = nt0 + (X1 >> 4);
+  const int mytiles = (ntiles - wave + 3) >> 2;            // tiles wave, wave + 4, ...
+  const int nunits = mytiles * NK;
 
-  auto issue = [&](int step) {
-    const int xb = step / nsl, sl = step - xb * nsl;
-    const float* src;
-    if constexpr (AX) {
-      const int r = p >> 4;
-      int xx = xb * 64 + (p & 15) * 4;
-      if (xx > X - 4) xx = X - 4;
-      src = Wg + (int64_t)(sl * 16 + r) * ld + xx;
-    } else {
-      int x = xb * 64 + (p >> 2);
-      if (x > X - 1) x = X - 1;
-      src = Wg + (int64_t)x * ld + sl * 16 + 4 * (p & 3);
-    }
-    dma16(src, ldsbase + (unsigned)(step % kFusedNS) * 4096u);
+  struct Frag { float4 v[NSL]; };
+  // fragments of unit `u` (clamped to the wave's last unit: loads are unconditional so the pipelined loop stays straight-line)
+  auto load_unit = [&](int u, Frag& f) {
+    if (u > nunits - 1) u = nunits - 1;
+    const int tile = wave + 4 * (NK == 1 ? u : u / NK), kc = NK == 1 ? 0 : u % NK;
+    const bool seg1 = tile >= nt0;
+    const float* Wb = seg1 ? W1 : W0;
+    const int xt = (seg1 ? tile - nt0 : tile) * 16;
+    const float* p = Wb + (int64_t)(xt + li) * LD + kc * NSL * 16 + 4 * lr;
+#pragma unroll
+    for (int s = 0; s < NSL; ++s) f.v[s] = *reinterpret_cast<const float4*>(p + 16 * s);
   };
 
+  f32x4 acc0[TG], acc1[TG];
 #pragma unroll
-  for (int s = 0; s < kFusedNS - 1; ++s)
-    if (s < total) issue(s);
-
-  f32x4 acc[NT];
+  for (int g = 0; g < TG; ++g) { acc0[g] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[g] = acc0[g]; }
+  auto compute_unit = [&](int u, const Frag& f) {
+    const int tile = wave + 4 * (NK == 1 ? u : u / NK), kc = NK == 1 ? 0 : u % NK;
+    const float* brow = ((tile >= nt0) ? Bs1 : Bs0) + li * SB + kc * NSL * 16 + 4 * lr;
+    float4 qprev[TG], aprev = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int trow = 16 * wj + li;                        // token row of this lane's B fragment and of its outputs
-  const float* brow = Bs + trow * SB + 4 * lr;
-  float4 qprev = make_float4(0.f, 0.f, 0.f, 0.f);       // bf16: the even slab's fragments wait for the odd slab
-  float4 aprev[NT];
-  float aprevx[4][NT];
-
-  for (int it = 0; it < total; ++it) {
-    const int rem = total - 1 - it;
-    wait_dma1(rem < kFusedNS - 2 ? rem : kFusedNS - 2);
-    __builtin_amdgcn_s_barrier();                       // every wave's piece of slab `it` is in LDS; slab it-1 is free
-    if (it + kFusedNS - 1 < total) issue(it + kFusedNS - 1);
-    const int xb = it / nsl, sl = it - xb * nsl;
-    const float* Ab = ring + (it % kFusedNS) * 1024;
-    const float4 qv = *reinterpret_cast<const float4*>(brow + sl * 16);
-    const float qs[4] = {qv.x, qv.y, qv.z, qv.w};
-    if constexpr (!AX) {
-      float4 pv[NT];
+    for (int s = 0; s < NSL; ++s) {
+      const float4 av = f.v[s];
+      float4 qv[TG];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) pv[t] = *reinterpret_cast<const float4*>(Ab + (16 * (wi * NT + t) + li) * 16 + 4 * lr);
+      for (int g = 0; g < TG; ++g) qv[g] = *reinterpret_cast<const float4*>(brow + g * 16 * SB + 16 * s);
       if constexpr (!BF16) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            const float a = s == 0 ? pv[t].x : (s == 1 ? pv[t].y : (s == 2 ? pv[t].z : pv[t].w));
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, qs[s], acc[t], 0, 0, 0);
-          }
-      } else {
-        const bool odd = sl & 1, last = sl == nsl - 1;
-        if (odd || last) {        // k = 32 per MFMA: (even slab, odd slab) pairs; an unpaired last slab is padded with zeros
-          const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-          const bf16x8 bq = odd ? to_bf16x8(qprev, qv) : to_bf16x8(qv, z);
-#pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            const bf16x8 ba = odd ? to_bf16x8(aprev[t], pv[t]) : to_bf16x8(pv[t], z);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ba, bq, acc[t], 0, 0, 0);
-          }
-        } else {
-          qprev = qv;
-#pragma unroll
-          for (int t = 0; t < NT; ++t) aprev[t] = pv[t];
+        for (int g = 0; g < TG; ++g) {
+          acc0[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, qv[g].x, acc0[g], 0, 0, 0);
+          acc1[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, qv[g].y, acc1[g], 0, 0, 0);
         }
-      }
-    } else {
-      // lane li holds NT consecutive x of its wave's 16*NT-wide slice: x = 16*NT*wi + NT*li + t  (tile t)
-      float av[4][NT];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const float* ap = Ab + (4 * lr + s) * 64 + 16 * NT * wi + NT * li;
-        if constexpr (NT == 4) { const float4 v = *reinterpret_cast<const float4*>(ap); av[s][0] = v.x; av[s][1] = v.y; av[s][2] = v.z; av[s][3] = v.w; }
-        else if constexpr (NT == 2) { const float2 v = *reinterpret_cast<const float2*>(ap); av[s][0] = v.x; av[s][1] = v.y; }
-        else av[s][0] = *ap;
-      }
-      if constexpr (!BF16) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-          for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][t], qs[s], acc[t], 0, 0, 0);
+        for (int g = 0; g < TG; ++g) {
+          acc0[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, qv[g].z, acc0[g], 0, 0, 0);
+          acc1[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, qv[g].w, acc1[g], 0, 0, 0);
+        }
       } else {
-        const bool odd = sl & 1, last = sl == nsl - 1;
-        if (odd || last) {
+        // k = 32 per MFMA: (even slab, odd slab) pairs; an unpaired last slab of the chunk is padded with zeros
+        if ((s & 1) || s == NSL - 1) {
           const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-          const bf16x8 bq = odd ? to_bf16x8(qprev, qv) : to_bf16x8(qv, z);
+          const bf16x8 ba = (s & 1) ? to_bf16x8(aprev, av) : to_bf16x8(av, z);
 #pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            const float4 cur = make_float4(av[0][t], av[1][t], av[2][t], av[3][t]);
-            const float4 prv = make_float4(aprevx[0][t], aprevx[1][t], aprevx[2][t], aprevx[3][t]);
-            const bf16x8 ba = odd ? to_bf16x8(prv, cur) : to_bf16x8(cur, z);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ba, bq, acc[t], 0, 0, 0);
+          for (int g = 0; g < TG; ++g) {
+            const bf16x8 bq = (s & 1) ? to_bf16x8(qprev[g], qv[g]) : to_bf16x8(qv[g], z);
+            acc0[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ba, bq, acc0[g], 0, 0, 0);
           }
         } else {
-          qprev = qv;
+          aprev = av;
 #pragma unroll
-          for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) aprevx[s][t] = av[s][t];
+          for (int g = 0; g < TG; ++g) qprev[g] = qv[g];
         }
       }
     }
-    if (sl == nsl - 1) {                                // the 64-wide x block `xb` is complete: epilogue into the LDS tile
-      const float rs = (EPI >= EPI_STORE_SCALE) ? rowscale[trow] : 1.f;
-      float* orow = Os + trow * SO;
-      if constexpr (!AX) {
+    if (kc == NK - 1) {                                 // tile complete: epilogue into the LDS output tile (own columns only)
+      const int x = tile * 16 + 4 * lr;                 // output feature index over both segments
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const int x = xb * 64 + 16 * (wi * NT + t) + 4 * lr;
-          if (x < X) epi_apply<EPI>(orow + x, make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]), rs);
-          acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-      } else {
-        if constexpr (NT == 4) {
-#pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            const int x = xb * 64 + 16 * lr + 4 * v;
-            if (x < X) epi_apply<EPI>(orow + x, make_float4(acc[0][v], acc[1][v], acc[2][v], acc[3][v]), rs);
-          }
-        } else if constexpr (NT == 2) {
-          const int x = xb * 64 + 32 * wi + 8 * lr;
-          if (x < X) epi_apply<EPI>(orow + x, make_float4(acc[0][0], acc[1][0], acc[0][1], acc[1][1]), rs);
-          if (x + 4 < X) epi_apply<EPI>(orow + x + 4, make_float4(acc[0][2], acc[1][2], acc[0][3], acc[1][3]), rs);
-        } else {
-          const int x = xb * 64 + 16 * wi + 4 * lr;
-          if (x < X) epi_apply<EPI>(orow + x, make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]), rs);
-        }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int g = 0; g < TG; ++g) {
+        const int trow = 16 * g + li;
+        epi(Os + trow * SO + x, x, trow, make_float4(acc0[g][0] + acc1[g][0], acc0[g][1] + acc1[g][1], acc0[g][2] + acc1[g][2],
+                                                     acc0[g][3] + acc1[g][3]));
+        acc0[g] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[g] = acc0[g];
       }
+    }
+  };
+
+  if (nunits > 0) {
+    Frag fa, fb;
+    load_unit(0, fa);
+    for (int u = 0; u < nunits; u += 2) {
+      load_unit(u + 1, fb);
+      compute_unit(u, fa);
+      load_unit(u + 2, fa);
+      if (u + 1 < nunits) compute_unit(u + 1, fb);
     }
   }
   __syncthreads();
@@ -239,6 +209,12 @@ inline TileGeo make_tile_geo(int B, int D, int H, int W) {
   return g;
 }
 
+constexpr int kFusedScratch = 4096;    // floats: the attention backward's P / dS exchange (16 floats per thread)
+// LDS floats of a fused block kernel: scratch + A1, A2 [TM][C+4] + U [TM][3C+4] + row scales / token ids +
+// the staged parameter vectors (9C + hidden)
+inline size_t block_lds_floats(int TM, int C, int hidden, bool scratch = true) {
+  return (size_t)(scratch ? kFusedScratch : 0) + (size_t)TM * (2 * (C + 4) + 3 * C + 4) + 3 * TM + 9 * C + hidden;
+}
 __device__ __forceinline__ float sum16(float v) {      // sum over the 16-lane group (rows are handled by 16 lanes each)
   v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
   return v;

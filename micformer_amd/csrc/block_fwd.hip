@@ -8,9 +8,10 @@
 //
 // replacing 7 (self) / 6 (cross tail) launches per modality of the round-1 decomposition.  A workgroup owns TM = 16 * TJ tokens
 // = TM / 8 whole windows of one modality (blockIdx -> (modality, tile), XCDs 0-3 take modality 0 and 4-7 modality 1 so each L2
-// caches one weight set); all intermediates live in three LDS tiles (A1, A2 [TM][C+4]; U [TM][3C+4]); only the weights
-// stream (LDS-DMA ring, block_fused.h).  Everything the backward / the weight-gradient GEMMs need is written out once, in
-// natural token order: xn, q, kv, o, x1, xn2, h (fc1 pre-activation), g = GELU(h), and the LayerNorm statistics.
+// caches one weight set); all intermediates live in three LDS tiles (A1, A2 [TM][C+4]; U [TM][3C+4]); the bias / LayerNorm
+// vectors are staged in LDS once; only the weights stream (register-prefetched fragments, block_fused.h).  Everything the backward / the
+// weight-gradient GEMMs need is written out once, in natural token order: xn, q, kv, o, x1, xn2, h (fc1 pre-activation),
+// g = GELU(h), and the LayerNorm statistics.
 #include <cstdlib>
 
 #include "block_fused.h"
@@ -20,26 +21,26 @@ namespace micf {
 struct BlkFwdArgs {
   micf_block_fwd_group g[2];
   TileGeo geo;
-  int G, tiles, C, heads, hidden;
+  int G, tiles, C, heads, hidden, debug;
   float eps, scale;
 };
 
-constexpr size_t block_lds_bytes(int TM, int C) { return sizeof(float) * (size_t)(kFusedRing + TM * (2 * (C + 4) + 3 * C + 4) + 3 * TM); }
-
 // rows of a [TM][X] tile are handled by 16-lane groups: pass p, wave w, lane group rg -> row p*16 + 4*w + rg; lane l16 covers
 // the float4 columns l16, l16 + 16, ...
-template <int TJ, int HD, int VPL, bool BF16>
+template <int C, int HD, int TJ, bool BF16>
 __global__ void __launch_bounds__(256) block_fwd_kernel(const BlkFwdArgs a) {
-  constexpr int TM = 16 * TJ;
+  constexpr int TM = 16 * TJ, VPL = (C + 63) / 64, NSL = C / 16;
   extern __shared__ __attribute__((aligned(1024))) float lds[];
-  const int C = a.C, C4 = C >> 2, S = C + 4, SU = 3 * C + 4, Hd = a.hidden;
-  float* ring = lds;
-  float* A1 = ring + kFusedRing;
+  constexpr int C4 = C >> 2, S = C + 4, SU = 3 * C + 4, Hd = 4 * C;
+  float* A1 = lds;
   float* A2 = A1 + TM * S;
   float* U = A2 + TM * S;
   float* sc1 = U + TM * SU;
   float* sc2 = sc1 + TM;
   int* tok = reinterpret_cast<int*>(sc2 + TM);
+  float* PV = sc2 + 2 * TM;                 // parameter vectors: ln1_g ln1_b bq bkv(2C) bp ln2_g ln2_b b2 | b1 (hidden)
+  float* p_ln1g = PV, *p_ln1b = PV + C, *p_bq = PV + 2 * C, *p_bkv = PV + 3 * C, *p_bp = PV + 5 * C, *p_ln2g = PV + 6 * C,
+        *p_ln2b = PV + 7 * C, *p_b2 = PV + 8 * C, *p_b1 = PV + 9 * C;
 
   int grp, tile;
   if (a.G == 2) { const int xcd = blockIdx.x & 7; grp = xcd >> 2; tile = (int)(blockIdx.x >> 3) * 4 + (xcd & 3); }
@@ -48,6 +49,7 @@ __global__ void __launch_bounds__(256) block_fwd_kernel(const BlkFwdArgs a) {
   const micf_block_fwd_group& g = a.g[grp];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, rg = lane >> 4;
   const int64_t T = a.geo.T;
+  const bool save = !(a.debug & 1), do_gelu = !(a.debug & 8);
 
   if (tid < TM) {
     const int win = tile * (TM / 8) + (tid >> 3);
@@ -61,81 +63,99 @@ __global__ void __launch_bounds__(256) block_fwd_kernel(const BlkFwdArgs a) {
     }
     tok[tid] = tk; sc1[tid] = v1; sc2[tid] = v2;
   }
-  __syncthreads();
-
-  // ---- LayerNorm 1 straight from HBM: row -> registers -> (xn -> A1 + HBM, statistics); cross: the K/V source rows -> A2
-  const float invC = 1.0f / (float)C;
-#pragma unroll 1
-  for (int pass = 0; pass < TJ; ++pass) {
-    const int row = pass * 16 + wave * 4 + rg;
-    const int tk = tok[row];
-    float4 v[VPL];
-    float s = 0.f;
+  {
+    const float* const srcs[9] = {g.ln1_g, g.ln1_b, g.bq, g.bkv, g.bp, g.ln2_g, g.ln2_b, g.b2, g.b1};
+    const int offs[10] = {0, C, 2 * C, 3 * C, 5 * C, 6 * C, 7 * C, 8 * C, 9 * C, 9 * C + Hd};
+    for (int e4 = tid; e4 < (9 * C + Hd) >> 2; e4 += 256) {
+      const int e = e4 << 2;
+      int k = 0;
 #pragma unroll
-    for (int k = 0; k < VPL; ++k) {
-      const int c4 = l16 + 16 * k;
-      v[k] = (tk >= 0 && c4 < C4) ? ld4g(g.x + (int64_t)tk * C + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-      s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
-    }
-    const float mu = sum16(s) * invC;
-    float qd = 0.f;
+      for (int j = 1; j < 9; ++j) k += (e >= offs[j]) ? 1 : 0;
+      const float* sp = srcs[0];
+      int so = offs[0];
 #pragma unroll
-    for (int k = 0; k < VPL; ++k) {
-      const int c4 = l16 + 16 * k;
-      if (c4 < C4) {
-        const float d0 = v[k].x - mu, d1 = v[k].y - mu, d2 = v[k].z - mu, d3 = v[k].w - mu;
-        qd += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-      }
+      for (int j = 1; j < 9; ++j) if (k == j) { sp = srcs[j]; so = offs[j]; }
+      *reinterpret_cast<float4*>(PV + e) = ld4g(sp + (e - so));
     }
-    const float rs = 1.0f / sqrtf(sum16(qd) * invC + a.eps);
-#pragma unroll
-    for (int k = 0; k < VPL; ++k) {
-      const int c4 = l16 + 16 * k;
-      if (c4 < C4) {
-        const float4 gm = ld4g(g.ln1_g + 4 * c4), bt = ld4g(g.ln1_b + 4 * c4);
-        float4 y = make_float4((v[k].x - mu) * rs * gm.x + bt.x, (v[k].y - mu) * rs * gm.y + bt.y,
-                               (v[k].z - mu) * rs * gm.z + bt.z, (v[k].w - mu) * rs * gm.w + bt.w);
-        if (tk < 0) y = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(A1 + row * S + 4 * c4) = y;
-        if (tk >= 0) {
-          if (g.xn) st4g(g.xn + (int64_t)tk * C + 4 * c4, y);
-          if (g.kvsrc) *reinterpret_cast<float4*>(A2 + row * S + 4 * c4) = ld4g(g.kvsrc + (int64_t)tk * C + 4 * c4);
-        } else if (g.kvsrc) {
-          *reinterpret_cast<float4*>(A2 + row * S + 4 * c4) = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-      }
-    }
-    if (l16 == 0 && tk >= 0) { g.stats[tk] = mu; g.stats[T + tk] = rs; }
   }
   __syncthreads();
 
-  // ---- q | k | v -> U
-  gemm_phase<TJ, false, EPI_STORE, BF16>(g.wq, C, C, C, A1, S, U, SU, nullptr, ring);
-  gemm_phase<TJ, false, EPI_STORE, BF16>(g.wkv, C, 2 * C, C, g.kvsrc ? A2 : A1, S, U + C, SU, nullptr, ring);
+  // ---- LayerNorm 1 straight from HBM: all rows of this lane group in flight at once -> registers -> (xn -> A1 + HBM,
+  // statistics); cross: the K/V source rows -> A2
+  const float invC = 1.0f / (float)C;
   {
-    const int X4 = 3 * C4;
+    float4 v[TJ][VPL], kvv[TJ][VPL];
+#pragma unroll
+    for (int pass = 0; pass < TJ; ++pass) {
+      const int tk = tok[pass * 16 + wave * 4 + rg];
+#pragma unroll
+      for (int k = 0; k < VPL; ++k) {
+        const int c4 = l16 + 16 * k;
+        // (branch-free: out-of-range lanes read a valid address and drop the value, so all loads of the pass are in flight together)
+        const bool ok = tk >= 0 && c4 < C4;
+        const int64_t off = (int64_t)(tk >= 0 ? tk : 0) * C + 4 * (c4 < C4 ? c4 : C4 - 1);
+        const float4 xv = ld4g(g.x + off), kv4 = ld4g((g.kvsrc ? g.kvsrc : g.x) + off);
+        v[pass][k] = ok ? xv : make_float4(0.f, 0.f, 0.f, 0.f);
+        kvv[pass][k] = ok ? kv4 : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+#pragma unroll
+    for (int pass = 0; pass < TJ; ++pass) {
+      const int row = pass * 16 + wave * 4 + rg;
+      const int tk = tok[row];
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < VPL; ++k) s += (v[pass][k].x + v[pass][k].y) + (v[pass][k].z + v[pass][k].w);
+      const float mu = sum16(s) * invC;
+      float qd = 0.f;
+#pragma unroll
+      for (int k = 0; k < VPL; ++k) {
+        if (l16 + 16 * k < C4) {
+          const float d0 = v[pass][k].x - mu, d1 = v[pass][k].y - mu, d2 = v[pass][k].z - mu, d3 = v[pass][k].w - mu;
+          qd += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+      }
+      const float rs = 1.0f / sqrtf(sum16(qd) * invC + a.eps);
+#pragma unroll
+      for (int k = 0; k < VPL; ++k) {
+        const int c4 = l16 + 16 * k;
+        if (c4 < C4) {
+          const float4 gm = *reinterpret_cast<const float4*>(p_ln1g + 4 * c4), bt = *reinterpret_cast<const float4*>(p_ln1b + 4 * c4);
+          float4 y = make_float4((v[pass][k].x - mu) * rs * gm.x + bt.x, (v[pass][k].y - mu) * rs * gm.y + bt.y,
+                                 (v[pass][k].z - mu) * rs * gm.z + bt.z, (v[pass][k].w - mu) * rs * gm.w + bt.w);
+          if (tk < 0) y = make_float4(0.f, 0.f, 0.f, 0.f);
+          *reinterpret_cast<float4*>(A1 + row * S + 4 * c4) = y;
+          if (g.kvsrc) *reinterpret_cast<float4*>(A2 + row * S + 4 * c4) = kvv[pass][k];
+          if (tk >= 0 && g.xn && save) st4g(g.xn + (int64_t)tk * C + 4 * c4, y);
+        }
+      }
+      if (l16 == 0 && tk >= 0) { g.stats[tk] = mu; g.stats[T + tk] = rs; }
+    }
+  }
+  __syncthreads();
+
+  // ---- q | k | v (+ bias) -> U, then out to HBM
+  if (!(a.debug & 4)) {
+    // q | k | v in ONE phase (two weight segments; the biases bq | bkv are contiguous in PV)
+    gemm_phase<TJ, NSL, 1, C, BF16>(g.wq, C, A1, g.wkv, 2 * C, g.kvsrc ? A2 : A1, S, U, SU, EpiBias{p_bq});
+  }
+  if (save) {
 #pragma unroll 1
     for (int pass = 0; pass < TJ; ++pass) {
       const int row = pass * 16 + wave * 4 + rg;
       const int tk = tok[row];
-      for (int c4 = l16; c4 < X4; c4 += 16) {
-        float* up = U + row * SU + 4 * c4;
-        float4 v = *reinterpret_cast<const float4*>(up);
-        const float4 b = c4 < C4 ? ld4g(g.bq + 4 * c4) : ld4g(g.bkv + 4 * (c4 - C4));
-        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-        *reinterpret_cast<float4*>(up) = v;
-        if (tk >= 0) {
-          if (c4 < C4) st4g(g.q + (int64_t)tk * C + 4 * c4, v);
-          else st4g(g.kv + (int64_t)tk * 2 * C + 4 * (c4 - C4), v);
-        }
+      if (tk < 0) continue;
+      for (int c4 = l16; c4 < 3 * C4; c4 += 16) {
+        const float4 v = *reinterpret_cast<const float4*>(U + row * SU + 4 * c4);
+        if (c4 < C4) st4g(g.q + (int64_t)tk * C + 4 * c4, v);
+        else st4g(g.kv + (int64_t)tk * 2 * C + 4 * (c4 - C4), v);
       }
     }
   }
-  __syncthreads();
 
   // ---- attention per (row, head): the 8x8 score row lives in registers; o -> A1 (xn is no longer needed) + HBM
-  {
-    const int heads = a.heads;
+  if (!(a.debug & 2)) {
+    constexpr int heads = C / HD;
     for (int item = tid; item < TM * heads; item += 256) {
       const int row = item / heads, hh = item - row * heads;
       const int r0 = row & ~7, hoff = hh * HD;
@@ -181,67 +201,79 @@ __global__ void __launch_bounds__(256) block_fwd_kernel(const BlkFwdArgs a) {
       for (int d = 0; d < HD; d += 4) {
         const float4 t = make_float4(oa[d], oa[d + 1], oa[d + 2], oa[d + 3]);
         *reinterpret_cast<float4*>(A1 + row * S + hoff + d) = t;
-        if (tk >= 0) st4g(g.o + (int64_t)tk * C + hoff + d, t);
+        if (tk >= 0 && save) st4g(g.o + (int64_t)tk * C + hoff + d, t);
       }
     }
   }
   __syncthreads();
 
-  // ---- proj -> A2; x1 = x + s1 * (proj + bp) -> A2 + HBM; LayerNorm 2 of the same registers -> A1 (xn2) + HBM
-  gemm_phase<TJ, false, EPI_STORE, BF16>(g.wp, C, C, C, A1, S, A2, S, nullptr, ring);
-#pragma unroll 1
-  for (int pass = 0; pass < TJ; ++pass) {
-    const int row = pass * 16 + wave * 4 + rg;
-    const int tk = tok[row];
-    const float s1v = sc1[row];
-    float4 v[VPL];
-    float s = 0.f;
+  // ---- proj (+ bp) -> A2; x1 = x + s1 * proj -> A2 + HBM; LayerNorm 2 of the same registers -> A1 (xn2) + HBM
+  if (!(a.debug & 4)) gemm_phase<TJ, NSL, 1, C, BF16>(g.wp, C, A1, nullptr, 0, nullptr, S, A2, S, EpiBias{p_bp});
+  {
+    float4 v[TJ][VPL];
 #pragma unroll
-    for (int k = 0; k < VPL; ++k) {
-      const int c4 = l16 + 16 * k;
-      v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c4 < C4 && tk >= 0) {
-        const float4 pr = *reinterpret_cast<const float4*>(A2 + row * S + 4 * c4);
-        const float4 xr = ld4g(g.x + (int64_t)tk * C + 4 * c4), b = ld4g(g.bp + 4 * c4);
-        v[k] = make_float4(xr.x + s1v * (pr.x + b.x), xr.y + s1v * (pr.y + b.y), xr.z + s1v * (pr.z + b.z), xr.w + s1v * (pr.w + b.w));
-        st4g(g.x1 + (int64_t)tk * C + 4 * c4, v[k]);
-      }
-      if (c4 < C4) *reinterpret_cast<float4*>(A2 + row * S + 4 * c4) = v[k];
-      s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
-    }
-    const float mu = sum16(s) * invC;
-    float qd = 0.f;
+    for (int pass = 0; pass < TJ; ++pass) {
+      const int tk = tok[pass * 16 + wave * 4 + rg];
 #pragma unroll
-    for (int k = 0; k < VPL; ++k) {
-      const int c4 = l16 + 16 * k;
-      if (c4 < C4) {
-        const float d0 = v[k].x - mu, d1 = v[k].y - mu, d2 = v[k].z - mu, d3 = v[k].w - mu;
-        qd += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+      for (int k = 0; k < VPL; ++k) {
+        const int c4 = l16 + 16 * k;
+        const float4 xv = ld4g(g.x + (int64_t)(tk >= 0 ? tk : 0) * C + 4 * (c4 < C4 ? c4 : C4 - 1));
+        v[pass][k] = (tk >= 0 && c4 < C4) ? xv : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
-    const float rs = 1.0f / sqrtf(sum16(qd) * invC + a.eps);
 #pragma unroll
-    for (int k = 0; k < VPL; ++k) {
-      const int c4 = l16 + 16 * k;
-      if (c4 < C4) {
-        const float4 gm = ld4g(g.ln2_g + 4 * c4), bt = ld4g(g.ln2_b + 4 * c4);
-        float4 y = make_float4((v[k].x - mu) * rs * gm.x + bt.x, (v[k].y - mu) * rs * gm.y + bt.y,
-                               (v[k].z - mu) * rs * gm.z + bt.z, (v[k].w - mu) * rs * gm.w + bt.w);
-        if (tk < 0) y = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(A1 + row * S + 4 * c4) = y;
-        if (tk >= 0) st4g(g.xn2 + (int64_t)tk * C + 4 * c4, y);
+    for (int pass = 0; pass < TJ; ++pass) {
+      const int row = pass * 16 + wave * 4 + rg;
+      const int tk = tok[row];
+      const float s1v = sc1[row];
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < VPL; ++k) {
+        const int c4 = l16 + 16 * k;
+        if (c4 < C4) {
+          const float4 pr = *reinterpret_cast<const float4*>(A2 + row * S + 4 * c4);
+          float4 xv = v[pass][k];
+          xv = make_float4(xv.x + s1v * pr.x, xv.y + s1v * pr.y, xv.z + s1v * pr.z, xv.w + s1v * pr.w);
+          if (tk < 0) xv = make_float4(0.f, 0.f, 0.f, 0.f);
+          v[pass][k] = xv;
+          *reinterpret_cast<float4*>(A2 + row * S + 4 * c4) = xv;
+          if (tk >= 0 && save) st4g(g.x1 + (int64_t)tk * C + 4 * c4, xv);
+          s += (xv.x + xv.y) + (xv.z + xv.w);
+        }
       }
+      const float mu = sum16(s) * invC;
+      float qd = 0.f;
+#pragma unroll
+      for (int k = 0; k < VPL; ++k) {
+        if (l16 + 16 * k < C4) {
+          const float d0 = v[pass][k].x - mu, d1 = v[pass][k].y - mu, d2 = v[pass][k].z - mu, d3 = v[pass][k].w - mu;
+          qd += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+      }
+      const float rs = 1.0f / sqrtf(sum16(qd) * invC + a.eps);
+#pragma unroll
+      for (int k = 0; k < VPL; ++k) {
+        const int c4 = l16 + 16 * k;
+        if (c4 < C4) {
+          const float4 gm = *reinterpret_cast<const float4*>(p_ln2g + 4 * c4), bt = *reinterpret_cast<const float4*>(p_ln2b + 4 * c4);
+          float4 y = make_float4((v[pass][k].x - mu) * rs * gm.x + bt.x, (v[pass][k].y - mu) * rs * gm.y + bt.y,
+                                 (v[pass][k].z - mu) * rs * gm.z + bt.z, (v[pass][k].w - mu) * rs * gm.w + bt.w);
+          if (tk < 0) y = make_float4(0.f, 0.f, 0.f, 0.f);
+          *reinterpret_cast<float4*>(A1 + row * S + 4 * c4) = y;
+          if (tk >= 0 && save) st4g(g.xn2 + (int64_t)tk * C + 4 * c4, y);
+        }
+      }
+      if (l16 == 0 && tk >= 0) { g.stats[2 * T + tk] = mu; g.stats[3 * T + tk] = rs; }
     }
-    if (l16 == 0 && tk >= 0) { g.stats[2 * T + tk] = mu; g.stats[3 * T + tk] = rs; }
   }
   __syncthreads();
 
-  // ---- MLP in hidden chunks of <= 2C (<= 3C fits U): fc1 chunk -> U, +b1, save h, GELU, save g; fc2 chunk accumulates
-  // s2 * (g W2^T) into A2 (which holds x1)
-  const int HC = 2 * C;
+  // ---- MLP in hidden chunks of <= 2C (<= 3C fits U): fc1 chunk (+ b1) -> U; save h, GELU in place, save g; fc2 chunk
+  // accumulates s2 * (g W2^T) into A2 (which holds x1)
+  constexpr int HC = 2 * C;
   for (int c0 = 0; c0 < Hd; c0 += HC) {
-    const int hc = (Hd - c0 < HC) ? Hd - c0 : HC;
-    gemm_phase<TJ, false, EPI_STORE, BF16>(g.w1 + (int64_t)c0 * C, C, hc, C, A1, S, U, SU, nullptr, ring);
+    constexpr int hc = HC;
+    if (!(a.debug & 4)) gemm_phase<TJ, NSL, 1, C, BF16>(g.w1 + (int64_t)c0 * C, hc, A1, nullptr, 0, nullptr, S, U, SU, EpiBias{p_b1 + c0});
     const int X4 = hc >> 2;
 #pragma unroll 1
     for (int pass = 0; pass < TJ; ++pass) {
@@ -249,19 +281,17 @@ __global__ void __launch_bounds__(256) block_fwd_kernel(const BlkFwdArgs a) {
       const int tk = tok[row];
       for (int c4 = l16; c4 < X4; c4 += 16) {
         float* up = U + row * SU + 4 * c4;
-        float4 v = *reinterpret_cast<const float4*>(up);
-        const float4 b = ld4g(g.b1 + c0 + 4 * c4);
-        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-        const float4 ge = make_float4(gelu_f(v.x), gelu_f(v.y), gelu_f(v.z), gelu_f(v.w));
+        const float4 v = *reinterpret_cast<const float4*>(up);
+        const float4 ge = do_gelu ? make_float4(gelu_f(v.x), gelu_f(v.y), gelu_f(v.z), gelu_f(v.w)) : v;
         *reinterpret_cast<float4*>(up) = ge;
-        if (tk >= 0) {
+        if (tk >= 0 && save) {
           st4g(g.h + (int64_t)tk * Hd + c0 + 4 * c4, v);
           st4g(g.g + (int64_t)tk * Hd + c0 + 4 * c4, ge);
         }
       }
     }
     __syncthreads();
-    gemm_phase<TJ, false, EPI_ACC_SCALE, BF16>(g.w2 + c0, Hd, C, hc, U, SU, A2, S, sc2, ring);
+    if (!(a.debug & 4)) gemm_phase<TJ, NSL, 2, Hd, BF16>(g.w2 + c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiAccScale{sc2});
   }
 
   // ---- y = x1 + s2 * (fc2 + b2)
@@ -273,26 +303,26 @@ __global__ void __launch_bounds__(256) block_fwd_kernel(const BlkFwdArgs a) {
     const float s2v = sc2[row];
     for (int c4 = l16; c4 < C4; c4 += 16) {
       float4 v = *reinterpret_cast<const float4*>(A2 + row * S + 4 * c4);
-      const float4 b = ld4g(g.b2 + 4 * c4);
+      const float4 b = *reinterpret_cast<const float4*>(p_b2 + 4 * c4);
       v.x += s2v * b.x; v.y += s2v * b.y; v.z += s2v * b.z; v.w += s2v * b.w;
       st4g(g.y + (int64_t)tk * C + 4 * c4, v);
     }
   }
 }
 
-template <int TJ, int HD, int VPL>
+template <int C, int HD, int TJ>
 static int launch_fwd(const BlkFwdArgs& a, int dtype, hipStream_t s) {
   constexpr int TM = 16 * TJ;
-  const size_t lds = block_lds_bytes(TM, a.C);
+  const size_t lds = block_lds_floats(TM, C, 4 * C, false) * sizeof(float);
   if (lds > 160 * 1024) return MICF_EUNSUPPORTED;
   const unsigned grid = a.G == 2 ? (unsigned)((a.tiles + 3) / 4 * 8) : (unsigned)a.tiles;
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_fwd_kernel<TJ, HD, VPL, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_fwd_kernel<TJ, HD, VPL, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_fwd_kernel<C, HD, TJ, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_fwd_kernel<C, HD, TJ, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
-  if (dtype == MICF_DTYPE_BF16) hipLaunchKernelGGL((block_fwd_kernel<TJ, HD, VPL, true>), dim3(grid), dim3(256), lds, s, a);
-  else hipLaunchKernelGGL((block_fwd_kernel<TJ, HD, VPL, false>), dim3(grid), dim3(256), lds, s, a);
+  if (dtype == MICF_DTYPE_BF16) hipLaunchKernelGGL((block_fwd_kernel<C, HD, TJ, true>), dim3(grid), dim3(256), lds, s, a);
+  else hipLaunchKernelGGL((block_fwd_kernel<C, HD, TJ, false>), dim3(grid), dim3(256), lds, s, a);
   MICF_RETURN_LAUNCH();
 }
 
@@ -301,33 +331,33 @@ static int launch_fwd(const BlkFwdArgs& a, int dtype, hipStream_t s) {
 using namespace micf;
 
 // tokens per tile for a block of C channels (0 = this shape is not handled by the fused kernels)
-extern "C" int micf_block_tile_tokens(int B, int D, int H, int W, int C, int heads, int hidden) {
+extern "C" int micf_block_tile_tokens(int B, int D, int H, int W, int C, int heads, int hidden, int backward) {
   if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || heads <= 0 || hidden <= 0) return 0;
   if ((D | H | W) & 1) return 0;                          // whole 2x2x2 windows only (no pad-to-window, no clamped windows)
-  if (C % 16 || C % heads || hidden % 16) return 0;
-  const int hd = C / heads;
-  if (hd != 16 && hd != 32) return 0;
-  if (8 * heads > 256) return 0;
+  if (C % heads || hidden != 4 * C) return 0;
   if ((int64_t)B * D * H * W >= (1LL << 31)) return 0;
-  int tj;
-  if (C <= 48) tj = hd == 16 ? 4 : 0;
-  else if (C <= 96) tj = 2;
-  else if (C <= 384) tj = 1;
-  else return 0;
-  if (const char* e = getenv("MICF_BLOCK_TJ")) {
+  const int hd = C / heads;
+  // The kernels are compiled per channel count (C fixes every loop bound and load offset): the shapes of MicFormer base
+  // (C = 48 / 96 / 192, head_dim 16) and large (C = 96 / 192, head_dim 32).  C >= 384 is left to the per-op path on purpose:
+  // a tile streams the whole weight set of the block through one compute unit (7 MB at C = 384 for <= 1k tokens at the base
+  // model's 4^3 stage), where the per-op kernels spread every weight matrix over the chip.
+  // token groups of 16 per workgroup (measured on MI355X, base shapes, batch 2): forward and backward tile independently
+  int tj = 0;
+  if (C == 48 && hd == 16) tj = 2;
+  else if (C == 96 && hd == 16) tj = backward ? 1 : 2;
+  else if ((C == 96 || C == 192) && (hd == 16 || hd == 32)) tj = 1;
+  if (const char* e = getenv(backward ? "MICF_BLOCK_TJ_BWD" : "MICF_BLOCK_TJ")) {
     const int v = atoi(e);
-    if (C <= 48 && hd == 16 && (v == 2 || v == 4)) tj = v;
-    if (C > 48 && C <= 96 && hd == 16 && (v == 1 || v == 2)) tj = v;
+    if (C == 48 && hd == 16 && (v == 1 || v == 2 || v == 4)) tj = v;
+    if (C == 96 && hd == 16 && (v == 1 || v == 2)) tj = v;
   }
-  if (tj == 0) return 0;
-  if (block_lds_bytes(16 * tj, C) > 160 * 1024) return 0;
   return 16 * tj;
 }
 
 extern "C" int micf_block_fwd(const micf_block_fwd_group* groups, int ngroups, int B, int D, int H, int W, int C, int heads,
                               int hidden, float eps, float scale, int dtype, micf_stream_t stream) {
   if (!groups || ngroups < 1 || ngroups > 2) return MICF_EINVAL;
-  const int TM = micf_block_tile_tokens(B, D, H, W, C, heads, hidden);
+  const int TM = micf_block_tile_tokens(B, D, H, W, C, heads, hidden, 0);
   if (TM == 0) return MICF_EUNSUPPORTED;
   if (dtype != MICF_DTYPE_F32 && dtype != MICF_DTYPE_BF16) return MICF_EINVAL;
   BlkFwdArgs a;
@@ -344,11 +374,13 @@ extern "C" int micf_block_fwd(const micf_block_fwd_group* groups, int ngroups, i
   a.geo = make_tile_geo(B, D, H, W);
   a.G = ngroups; a.C = C; a.heads = heads; a.hidden = hidden; a.eps = eps; a.scale = scale;
   a.tiles = (a.geo.nwin + TM / 8 - 1) / (TM / 8);
+  const char* dbg = getenv("MICF_BLOCK_DEBUG");
+  a.debug = dbg ? atoi(dbg) : 0;
   hipStream_t s = (hipStream_t)stream;
-  const int hd = C / heads, vpl = (C + 63) / 64, tj = TM / 16;
-#define MICF_BF(TJ_, HD_, VPL_) if (tj == TJ_ && hd == HD_ && vpl == VPL_) return launch_fwd<TJ_, HD_, VPL_>(a, dtype, s)
-  MICF_BF(4, 16, 1); MICF_BF(2, 16, 1); MICF_BF(2, 16, 2); MICF_BF(1, 16, 2); MICF_BF(1, 16, 3); MICF_BF(1, 16, 6);
-  MICF_BF(2, 32, 2); MICF_BF(1, 32, 3); MICF_BF(1, 32, 6);
+  const int hd = C / heads, tj = TM / 16;
+#define MICF_BF(C_, HD_, TJ_) if (C == C_ && hd == HD_ && tj == TJ_) return launch_fwd<C_, HD_, TJ_>(a, dtype, s)
+  MICF_BF(48, 16, 2); MICF_BF(48, 16, 1); MICF_BF(48, 16, 4); MICF_BF(96, 16, 1); MICF_BF(96, 16, 2); MICF_BF(192, 16, 1);
+  MICF_BF(96, 32, 1); MICF_BF(192, 32, 1);
 #undef MICF_BF
   return MICF_EUNSUPPORTED;
 }

@@ -193,3 +193,58 @@ extern "C" int micf_drop_path_draw(void* rng, const float* keep, float* out, int
   hipLaunchKernelGGL(micf::drop_path_draw_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, static_cast<uint64_t*>(rng), keep, out, n, B);
   MICF_RETURN_LAUNCH();
 }
+
+// ---- grouped transpose: dst[c][r] = src[r][c] for up to kTrMax matrices per launch (32 x 32 tiles through LDS)
+namespace micf {
+constexpr int kTrMax = 64;
+struct TrArgs {
+  int n;
+  int end[kTrMax];                       // running total of 32 x 32 tiles
+  const float* src[kTrMax]; float* dst[kTrMax];
+  int rows[kTrMax], cols[kTrMax];
+};
+__global__ void __launch_bounds__(256) transpose_grouped_kernel(const TrArgs a) {
+  __shared__ float t[32][33];
+  const int w = blockIdx.x;
+  int k = 0;
+  while (k < a.n - 1 && w >= a.end[k]) ++k;
+  const int local = w - (k ? a.end[k - 1] : 0);
+  const int rows = a.rows[k], cols = a.cols[k];
+  const int tc = (cols + 31) >> 5;
+  const int r0 = (local / tc) * 32, c0 = (local % tc) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+  const float* __restrict__ src = a.src[k];
+  float* __restrict__ dst = a.dst[k];
+#pragma unroll
+  for (int j = 0; j < 32; j += 8) {
+    const int r = r0 + ty + j, c = c0 + tx;
+    if (r < rows && c < cols) t[ty + j][tx] = src[(int64_t)r * cols + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 32; j += 8) {
+    const int c = c0 + ty + j, r = r0 + tx;
+    if (r < rows && c < cols) dst[(int64_t)c * rows + r] = t[tx][ty + j];
+  }
+}
+}  // namespace micf
+
+extern "C" int micf_transpose_grouped(const micf_transpose_item* items, int n, micf_stream_t stream) {
+  if (n < 0 || (n > 0 && !items)) return MICF_EINVAL;
+  for (int first = 0; first < n; first += micf::kTrMax) {
+    const int cnt = (n - first < micf::kTrMax) ? n - first : micf::kTrMax;
+    micf::TrArgs a;
+    a.n = cnt;
+    int blocks = 0;
+    for (int k = 0; k < cnt; ++k) {
+      const micf_transpose_item& it = items[first + k];
+      if (!it.src || !it.dst || it.rows <= 0 || it.cols <= 0) return MICF_EINVAL;
+      a.src[k] = it.src; a.dst[k] = it.dst; a.rows[k] = it.rows; a.cols[k] = it.cols;
+      blocks += ((it.rows + 31) / 32) * ((it.cols + 31) / 32);
+      a.end[k] = blocks;
+    }
+    hipLaunchKernelGGL(micf::transpose_grouped_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    if (hipGetLastError() != hipSuccess) return MICF_ELAUNCH;
+  }
+  return MICF_OK;
+}

@@ -89,6 +89,17 @@ class TrainEngine:
                 p._micf_grad = p.grad       # backward kernels accumulate straight into the flat gradient buffer
         self.params, self.offsets, self.sizes = params, offs, sizes
         self.adam_state = ops.adam_state(dev)
+        # Transposed copies of the block linears' weights for the fused backward (its "dY W" products stream W^T rows): one flat
+        # buffer, refreshed by ONE grouped launch at the start of every step (the weights only change in Adam).
+        tw = [p for n, p in zip(names, params) if n.endswith(("attn.q.weight", "attn.kv.weight", "attn.proj.weight", "mlp.fc1.weight",
+                                                               "mlp.fc2.weight")) and p.dim() == 2 and min(p.shape) <= 192]
+        toffs, ttotal = flatten_views(tw)
+        self.flat_wt = torch.empty(max(ttotal, 4), dtype=torch.float32, device=dev)
+        pairs = []
+        for p, o in zip(tw, toffs):
+            p._micf_wt = self.flat_wt[o:o + p.numel()].view(p.shape[1], p.shape[0])
+            pairs.append((p.data, p._micf_wt))
+        self._tplan = ops.TransposePlan(pairs)
 
     # ------------------------------------------------------------------ one optimisation step
     def _scoped_flags(self):
@@ -112,6 +123,7 @@ class TrainEngine:
         _fn.drop_deferred()                                         # nothing left over from a backward that raised
         with self._scoped_flags():
             ops.zero_(self.flat_g)                                  # optimizer.zero_grad()        train.py:183
+            self._tplan.launch()                                    # W^T of the block linears for the fused backward
             logits = self.model(x)                                  #                              train.py:185
             loss = self.criterion(logits, target)                   #                              train.py:187
             loss.backward()                                         #                              train.py:200

@@ -232,9 +232,16 @@ class SelfBlockFn(torch.autograd.Function):
         rps = D * H * W
         scale = (C // heads) ** -0.5
         xf = x.reshape(-1, C)
+        ctx.tg = _targets(params)
+        if not padded and _fusable(dims, C, heads, ws, P):
+            sv = _self_fwd_fused([xf], [P], [(s1, s2)], dims, heads, eps)[0]
+            ctx.save_for_backward(xf, *[sv[k] for k in _SV_KEYS], s1, s2, *params)
+            ctx.meta = (dims, heads)
+            ctx.fused = True
+            return sv["y"].reshape(x.shape)
+        ctx.fused = False
         xn, m1, r1 = ops.layernorm_fwd(xf, P["norm1.weight"], P["norm1.bias"], eps)
         xnp = ops.pad3d(xn, dims, pd) if padded else xn             # F.pad AFTER the norm (MS.py:477-483)
-        ctx.tg = _targets(params)
         fused = _packed_qkv(P, dict(zip(SELF_KEYS, ctx.tg)))
         if fused is not None:
             # engine mode: q.weight | kv.weight (and the biases) are adjacent in the flat buffer -> ONE [3C, C] projection
@@ -258,6 +265,16 @@ class SelfBlockFn(torch.autograd.Function):
     @_in_block
     def backward(ctx, dy):
         sv = ctx.saved_tensors
+        if ctx.fused:
+            m = len(_SV_KEYS)
+            xf, svd, (s1, s2), params = sv[0], dict(zip(_SV_KEYS, sv[1:1 + m])), sv[1 + m:3 + m], sv[3 + m:]
+            P = dict(zip(SELF_KEYS, params))
+            G = {k: _grad_buf(t, v) for (k, v), t in zip(P.items(), ctx.tg)}
+            dims, heads = ctx.meta
+            C = xf.shape[1]
+            side = all(t is not None for t in ctx.tg)
+            dx = _self_bwd_fused([_c(dy).reshape(-1, C)], [xf], [svd], [P], [G], [(s1, s2)], dims, heads, [side])[0]
+            return (dx.reshape(dims + (C,)), None, None, None, None, None) + tuple(_ret(t, G[k]) for k, t in zip(SELF_KEYS, ctx.tg))
         xf, m1, r1, xnp, q, kv, o, x1, s1, s2 = sv[:10]
         mlp_saved = sv[10:15]
         params = sv[15:]
@@ -309,6 +326,16 @@ class CrossBlockFn(torch.autograd.Function):
         rps = D * H * W
         scale = (C // heads) ** -0.5
         xf, xaf = x.reshape(-1, C), xa.reshape(-1, C)
+        if not padded and _fusable(dims, C, heads, ws, P):
+            hd = _cross_head_fwd(xf, xaf, P, dims, eps)
+            sv = ops.block_fwd([{"x": xf, "kvsrc": hd[5], "P": P, "attn": "cross_attn", "s1": s1, "s2": s2, "want_xn": False}], dims, C,
+                               heads, eps, scale)[0]
+            ctx.save_for_backward(xf, xaf, *hd, *[sv[k] for k in _CSV_KEYS], s1, s2, *params)
+            ctx.meta = (dims, heads, eps)
+            ctx.tg = _targets(params)
+            ctx.fused = True
+            return sv["y"].reshape(x.shape)
+        ctx.fused = False
         xn, m1, r1 = ops.layernorm_fwd(xf, P["norm1.weight"], P["norm1.bias"], eps)   # only x is normed (MS.py:343)
         xnp = ops.pad3d(xn, dims, pd) if padded else xn
         xap = ops.pad3d(xaf, dims, pd) if padded else xaf
@@ -333,6 +360,28 @@ class CrossBlockFn(torch.autograd.Function):
     @_in_block
     def backward(ctx, dy):
         sv = ctx.saved_tensors
+        if ctx.fused:
+            m = len(_CSV_KEYS)
+            xf, xaf, hd = sv[0], sv[1], sv[2:8]
+            svd, (s1, s2), params = dict(zip(_CSV_KEYS, sv[8:8 + m])), sv[8 + m:10 + m], sv[10 + m:]
+            P = dict(zip(CROSS_KEYS, params))
+            G = {k: _grad_buf(t, v) for (k, v), t in zip(P.items(), ctx.tg)}
+            dims, heads, eps = ctx.meta
+            C = xf.shape[1]
+            rps = dims[1] * dims[2] * dims[3]
+            side = all(t is not None for t in ctx.tg)
+            dyf = _c(dy).reshape(-1, C)
+            bo = ops.block_bwd([{"dy": dyf, "x": None, "x1": svd["x1"], "stats": svd["stats"], "q": svd["q"], "kv": svd["kv"],
+                                 "h": svd["h"], "P": P, "attn": "cross_attn", "s1": s1, "s2": s2, "cross": True}], dims, C, heads,
+                               (C // heads) ** -0.5)[0]
+            xn, m1, r1, hid, flow, xsamp = hd
+            _queue_block_wgrads(side, P, G, "cross_attn", svd, bo, dyf, xn, xsamp, s1, s2, rps)
+            _ln_partials(side, bo["ln2_part"], bo["tiles"], C, G["norm2.weight"], G["norm2.bias"])
+            dxa = ops.zero_(torch.empty_like(xaf))                  # scatter target of the sampler (one memset node)
+            dx = _cross_head_bwd(side, P, G, dims, eps, xf, xaf, xn, m1, r1, hid, flow, bo["dx"], bo["dxs"], dxa, bo["dx1"])
+            shape = dims + (C,)
+            return (dx.reshape(shape), dxa.reshape(shape), None, None, None, None, None) + \
+                tuple(_ret(t, G[k]) for k, t in zip(CROSS_KEYS, ctx.tg))
         xf, m1, r1, xnp, xap, hid, flow, xs, q, kv, o, x1, s1, s2 = sv[:14]
         mlp_saved = sv[14:19]
         params = sv[19:]
@@ -355,7 +404,7 @@ class CrossBlockFn(torch.autograd.Function):
         _lin_wgrad(side, dkv, xs, G["cross_attn.kv.weight"], G["cross_attn.kv.bias"])
         dxnp = ops.linear_bwd_data(dq, P["cross_attn.q.weight"])
         dxs = ops.linear_bwd_data(dkv, P["cross_attn.kv.weight"])
-        dxap = _zl(xap)                                            # atomic scatter target of the sampler
+        dxap = ops.zero_(torch.empty_like(xap))                    # atomic scatter target of the sampler (one memset node)
         dhid = ops.offset_sample_bwd(dxs, hid, P["conv_offset.1.norm.weight"], P["conv_offset.1.norm.bias"],
                                      P["conv_offset.3.weight"], xap, flow, dxap, G["conv_offset.1.norm.weight"],
                                      G["conv_offset.1.norm.bias"], G["conv_offset.3.weight"], pdims, eps)
@@ -369,6 +418,236 @@ class CrossBlockFn(torch.autograd.Function):
         dx = ops.layernorm_bwd(dxn, xf, m1, r1, P["norm1.weight"], G["norm1.weight"], G["norm1.bias"], add=dx1, defer=_ln_defer(side))
         return (dx.reshape(B, D, H, W, C), dxa.reshape(B, D, H, W, C), None, None, None, None, None) + \
             tuple(_ret(t, G[k]) for k, t in zip(CROSS_KEYS, ctx.tg))
+
+
+# ============================================================================= fused window-local blocks (block_fwd / block_bwd)
+def _fusable(dims, C, heads, window, P):
+    """Tokens per tile if the fused block kernels take this shape (even grid, 2x2x2 windows, head_dim 16 / 32, C <= 192), else 0."""
+    if tuple(window) != (2, 2, 2) or not FUSE_BLOCKS:
+        return 0
+    return ops.block_tile_tokens(dims, C, heads, P["mlp.fc1.weight"].shape[0])
+
+
+import os as _os
+FUSE_BLOCKS = _os.environ.get("MICF_FUSE_BLOCKS", "1") != "0"   # off = the round-1 per-op launch sequence everywhere
+
+
+def _queue_block_wgrads(side, P, G, attn, sv, bo, dy, xn, kv_in, s1, s2, rps):
+    """The five nn.Linear weight gradients of a block from the operands the fused kernels left in HBM (deferred in engine mode)."""
+    _lin_wgrad(side, dy, sv["g"], G["mlp.fc2.weight"], G["mlp.fc2.bias"], s2, rps)
+    _lin_wgrad(side, bo["dh"], sv["xn2"], G["mlp.fc1.weight"], G["mlp.fc1.bias"])
+    _lin_wgrad(side, bo["dx1"], sv["o"], G[f"{attn}.proj.weight"], G[f"{attn}.proj.bias"], s1, rps)
+    _lin_wgrad(side, bo["dq"], xn, G[f"{attn}.q.weight"], G[f"{attn}.q.bias"])
+    _lin_wgrad(side, bo["dkv"], kv_in, G[f"{attn}.kv.weight"], G[f"{attn}.kv.bias"])
+
+
+def _ln_partials(side, part, tiles, C, dg, db):
+    """Per-tile LayerNorm gain / bias partial sums of a fused backward: queued for the grouped finish, or finished now."""
+    item = (part, tiles, C, dg, db)
+    lst = _ln_defer(side)
+    if lst is not None:
+        lst.append(item)
+    else:
+        ops.layernorm_bwd_finish([item])
+
+
+def _self_fwd_fused(xs, Ps, scales, dims, heads, eps):
+    """xs: 1 or 2 [T, C] inputs (the two modalities); one launch.  Returns the per-group saved dicts."""
+    C = xs[0].shape[1]
+    groups = [{"x": x, "kvsrc": None, "P": P, "attn": "self_attn", "s1": s[0], "s2": s[1]} for x, P, s in zip(xs, Ps, scales)]
+    return ops.block_fwd(groups, dims, C, heads, eps, (C // heads) ** -0.5)
+
+
+def _self_bwd_fused(dys, xs, svs, Ps, Gs, scales, dims, heads, sides):
+    C = xs[0].shape[1]
+    rps = dims[1] * dims[2] * dims[3]
+    groups = [{"dy": dy, "x": x, "x1": sv["x1"], "stats": sv["stats"], "q": sv["q"], "kv": sv["kv"], "h": sv["h"], "P": P,
+               "attn": "self_attn", "s1": s[0], "s2": s[1], "cross": False} for dy, x, sv, P, s in zip(dys, xs, svs, Ps, scales)]
+    bos = ops.block_bwd(groups, dims, C, heads, (C // heads) ** -0.5)
+    for dy, sv, bo, P, G, s, side in zip(dys, svs, bos, Ps, Gs, scales, sides):
+        _queue_block_wgrads(side, P, G, "self_attn", sv, bo, dy, sv["xn"], sv["xn"], s[0], s[1], rps)
+        _ln_partials(side, bo["ln2_part"], bo["tiles"], C, G["norm2.weight"], G["norm2.bias"])
+        _ln_partials(side, bo["ln1_part"], bo["tiles"], C, G["norm1.weight"], G["norm1.bias"])
+    return [bo["dx"] for bo in bos]
+
+
+_SV_KEYS = ("xn", "q", "kv", "o", "x1", "xn2", "h", "g", "stats")
+
+
+class SelfPairFn(torch.autograd.Function):
+    """self_blocks1[i](x), self_blocks2[i](xa) (MS.py:700): two independent TransformerBlock3D of the same shape, ONE fused launch
+    forward and ONE backward."""
+
+    @staticmethod
+    @_in_block
+    def forward(ctx, x, xa, sa1, sa2, sb1, sb2, heads, eps, *params):
+        n = len(SELF_KEYS)
+        Ps = [dict(zip(SELF_KEYS, params[:n])), dict(zip(SELF_KEYS, params[n:]))]
+        x, xa = _c(x), _c(xa)
+        B, D, H, W, C = x.shape
+        dims = (B, D, H, W)
+        xs = [x.reshape(-1, C), xa.reshape(-1, C)]
+        scales = [(sa1, sa2), (sb1, sb2)]
+        svs = _self_fwd_fused(xs, Ps, scales, dims, heads, eps)
+        ctx.save_for_backward(*xs, *[sv[k] for sv in svs for k in _SV_KEYS], sa1, sa2, sb1, sb2, *params)
+        ctx.meta = (dims, heads)
+        ctx.tg = _targets(params)
+        return svs[0]["y"].reshape(x.shape), svs[1]["y"].reshape(x.shape)
+
+    @staticmethod
+    @_in_block
+    def backward(ctx, dy, dya):
+        sv = ctx.saved_tensors
+        dims, heads = ctx.meta
+        n, m = len(SELF_KEYS), len(_SV_KEYS)
+        xs = list(sv[:2])
+        svs = [dict(zip(_SV_KEYS, sv[2:2 + m])), dict(zip(_SV_KEYS, sv[2 + m:2 + 2 * m]))]
+        sa1, sa2, sb1, sb2 = sv[2 + 2 * m:6 + 2 * m]
+        params = sv[6 + 2 * m:]
+        Ps = [dict(zip(SELF_KEYS, params[:n])), dict(zip(SELF_KEYS, params[n:]))]
+        tgs = [ctx.tg[:n], ctx.tg[n:]]
+        Gs = [{k: _grad_buf(t, v) for (k, v), t in zip(P.items(), tg)} for P, tg in zip(Ps, tgs)]
+        sides = [all(t is not None for t in tg) for tg in tgs]
+        C = xs[0].shape[1]
+        dys = [_c(dy).reshape(-1, C), _c(dya).reshape(-1, C)]
+        dxs = _self_bwd_fused(dys, xs, svs, Ps, Gs, [(sa1, sa2), (sb1, sb2)], dims, heads, sides)
+        shape = dims + (C,)
+        grads = tuple(_ret(t, G[k]) for G, tg in zip(Gs, tgs) for k, t in zip(SELF_KEYS, tg))
+        return (dxs[0].reshape(shape), dxs[1].reshape(shape), None, None, None, None, None, None) + grads
+
+
+def _cross_head_fwd(xf, xaf, P, dims, eps):
+    """LN1(x), offset conv on cat[LN1(x), raw xa], offset head + deformable sampling of raw xa (MS.py:343-384)."""
+    xn, m1, r1 = ops.layernorm_fwd(xf, P["norm1.weight"], P["norm1.bias"], eps)
+    hid = ops.conv3_fwd(xn, P["conv_offset.0.weight"], P["conv_offset.0.bias"], dims, x2=xaf)
+    flow, xs = ops.offset_sample_fwd(hid, P["conv_offset.1.norm.weight"], P["conv_offset.1.norm.bias"], P["conv_offset.3.weight"], xaf,
+                                     dims, eps)
+    return xn, m1, r1, hid, flow, xs
+
+
+def _cross_head_bwd(side, P, G, dims, eps, xf, xaf, xn, m1, r1, hid, flow, dxq, dxs, dxa_acc, add, out=None):
+    """Adjoint of _cross_head_fwd.  dxq: the q path's pre-LayerNorm gradient (accumulated into in place); dxs: gradient of the
+    sampled K/V source; dxa_acc: buffer the raw-xa gradient is ACCUMULATED into (zero, or already holding other terms);
+    add / out: LayerNorm-1 backward computes out = add + LN1'(dxq) (out may alias add)."""
+    C = xf.shape[1]
+    dhid = ops.offset_sample_bwd(dxs, hid, P["conv_offset.1.norm.weight"], P["conv_offset.1.norm.bias"], P["conv_offset.3.weight"],
+                                 xaf, flow, dxa_acc, G["conv_offset.1.norm.weight"], G["conv_offset.1.norm.bias"],
+                                 G["conv_offset.3.weight"], dims, eps)
+    ops.conv3_bwd_weight(dhid, xn, G["conv_offset.0.weight"], G["conv_offset.0.bias"], dims, x2=xaf)
+    ops.conv3_bwd_data(dhid, P["conv_offset.0.weight"], dims, C, C, dx1=dxq, dx2=dxa_acc, acc1=True, acc2=True)
+    return ops.layernorm_bwd(dxq, xf, m1, r1, P["norm1.weight"], G["norm1.weight"], G["norm1.bias"], add=add, defer=_ln_defer(side),
+                             out=out)
+
+
+_CSV_KEYS = ("q", "kv", "o", "x1", "xn2", "h", "g", "stats")
+
+# The two offset heads of a cross pair (LN1 -> 3^3 conv -> sampling, and their adjoints) are independent per-op launch chains:
+# the second one runs on a side stream (a fork / join in the captured graph), as round 1 did for whole blocks.
+OVERLAP_CROSS_HEADS = True
+_SIDE = {}
+
+
+def _side_stream(device):
+    st = _SIDE.get(device)
+    if st is None:
+        st = _SIDE[device] = torch.cuda.Stream(device=device)
+    return st
+
+
+def _cross_head_adjoint(i, hds, bos, Ps, Gs, xs, acc, dims, eps, C):
+    """Adjoint of block i's offset head: sampler backward (raw-xa gradient -> the OTHER input's accumulator), conv weight
+    gradient, conv data gradient (-> block i's pre-LayerNorm gradient and the other input's accumulator)."""
+    xn, m1, r1, hid, flow, xsamp = hds[i]
+    dhid = ops.offset_sample_bwd(bos[i]["dxs"], hid, Ps[i]["conv_offset.1.norm.weight"], Ps[i]["conv_offset.1.norm.bias"],
+                                 Ps[i]["conv_offset.3.weight"], xs[1 - i], flow, acc[1 - i], Gs[i]["conv_offset.1.norm.weight"],
+                                 Gs[i]["conv_offset.1.norm.bias"], Gs[i]["conv_offset.3.weight"], dims, eps)
+    ops.conv3_bwd_weight(dhid, xn, Gs[i]["conv_offset.0.weight"], Gs[i]["conv_offset.0.bias"], dims, x2=xs[1 - i])
+    ops.conv3_bwd_data(dhid, Ps[i]["conv_offset.0.weight"], dims, C, C, dx1=bos[i]["dx"], dx2=acc[1 - i], acc1=True, acc2=True)
+
+
+class CrossPairFn(torch.autograd.Function):
+    """blocks1[i](x, xa), blocks2[i](xa, x) (MS.py:701; both read the PRE-update pair): per modality LN1 -> offset conv ->
+    deformable sampling (per-op kernels: they need token neighbourhoods), then ONE fused launch for both blocks' window-local
+    part.  Backward: ONE fused launch, then the two offset heads' adjoints; each input's gradient (own block's LN1 backward +
+    skip + the OTHER block's raw-K/V-source gradient) is accumulated in one buffer that starts as the fused kernel's second copy of
+    dx1 -- no zero fill, no autograd add."""
+
+    @staticmethod
+    @_in_block
+    def forward(ctx, x, xa, sa1, sa2, sb1, sb2, heads, eps, *params):
+        n = len(CROSS_KEYS)
+        Ps = [dict(zip(CROSS_KEYS, params[:n])), dict(zip(CROSS_KEYS, params[n:]))]
+        x, xa = _c(x), _c(xa)
+        B, D, H, W, C = x.shape
+        dims = (B, D, H, W)
+        xs = [x.reshape(-1, C), xa.reshape(-1, C)]
+        if OVERLAP_CROSS_HEADS:
+            main, side = torch.cuda.current_stream(), _side_stream(x.device)
+            side.wait_stream(main)
+            h0 = _cross_head_fwd(xs[0], xs[1], Ps[0], dims, eps)
+            with torch.cuda.stream(side):
+                h1 = _cross_head_fwd(xs[1], xs[0], Ps[1], dims, eps)
+            main.wait_stream(side)
+            for t in h1:
+                t.record_stream(main)
+            heads_ = [h0, h1]
+        else:
+            heads_ = [_cross_head_fwd(xs[i], xs[1 - i], Ps[i], dims, eps) for i in (0, 1)]
+        scales = [(sa1, sa2), (sb1, sb2)]
+        groups = [{"x": xs[i], "kvsrc": heads_[i][5], "P": Ps[i], "attn": "cross_attn", "s1": scales[i][0], "s2": scales[i][1],
+                   "want_xn": False} for i in (0, 1)]
+        svs = ops.block_fwd(groups, dims, C, heads, eps, (C // heads) ** -0.5)
+        ctx.save_for_backward(*xs, *[t for hd in heads_ for t in hd], *[sv[k] for sv in svs for k in _CSV_KEYS], sa1, sa2, sb1, sb2,
+                              *params)
+        ctx.meta = (dims, heads, eps)
+        ctx.tg = _targets(params)
+        return svs[0]["y"].reshape(x.shape), svs[1]["y"].reshape(x.shape)
+
+    @staticmethod
+    @_in_block
+    def backward(ctx, dy, dya):
+        sv = ctx.saved_tensors
+        dims, heads, eps = ctx.meta
+        n, m = len(CROSS_KEYS), len(_CSV_KEYS)
+        xs = list(sv[:2])
+        hds = [sv[2:8], sv[8:14]]
+        svs = [dict(zip(_CSV_KEYS, sv[14:14 + m])), dict(zip(_CSV_KEYS, sv[14 + m:14 + 2 * m]))]
+        sa1, sa2, sb1, sb2 = sv[14 + 2 * m:18 + 2 * m]
+        scales = [(sa1, sa2), (sb1, sb2)]
+        params = sv[18 + 2 * m:]
+        Ps = [dict(zip(CROSS_KEYS, params[:n])), dict(zip(CROSS_KEYS, params[n:]))]
+        tgs = [ctx.tg[:n], ctx.tg[n:]]
+        Gs = [{k: _grad_buf(t, v) for (k, v), t in zip(P.items(), tg)} for P, tg in zip(Ps, tgs)]
+        sides = [all(t is not None for t in tg) for tg in tgs]
+        C = xs[0].shape[1]
+        rps = dims[1] * dims[2] * dims[3]
+        dys = [_c(dy).reshape(-1, C), _c(dya).reshape(-1, C)]
+        groups = [{"dy": dys[i], "x": None, "x1": svs[i]["x1"], "stats": svs[i]["stats"], "q": svs[i]["q"], "kv": svs[i]["kv"],
+                   "h": svs[i]["h"], "P": Ps[i], "attn": "cross_attn", "s1": scales[i][0], "s2": scales[i][1], "cross": True,
+                   "want_copy": True} for i in (0, 1)]
+        bos = ops.block_bwd(groups, dims, C, heads, (C // heads) ** -0.5)
+        acc = [bos[0]["dx1_copy"], bos[1]["dx1_copy"]]       # acc[i] becomes d(input i): starts as dx1 of block i
+        for i in (0, 1):
+            xn, m1, r1, hid, flow, xsamp = hds[i]
+            _queue_block_wgrads(sides[i], Ps[i], Gs[i], "cross_attn", svs[i], bos[i], dys[i], xn, xsamp, scales[i][0], scales[i][1], rps)
+            _ln_partials(sides[i], bos[i]["ln2_part"], bos[i]["tiles"], C, Gs[i]["norm2.weight"], Gs[i]["norm2.bias"])
+        main = torch.cuda.current_stream()
+        side = _side_stream(dys[0].device) if OVERLAP_CROSS_HEADS else None
+        if side is not None:
+            side.wait_stream(main)
+        for i in (0, 1):
+            # block i's raw-xa gradient goes to the OTHER input's buffer; its own LN1 backward lands in acc[i] (in place)
+            with torch.cuda.stream(side if (i == 1 and side is not None) else main):
+                _cross_head_adjoint(i, hds, bos, Ps, Gs, xs, acc, dims, eps, C)
+        if side is not None:
+            main.wait_stream(side)
+        for i in (0, 1):
+            xn, m1, r1 = hds[i][:3]
+            ops.layernorm_bwd(bos[i]["dx"], xs[i], m1, r1, Ps[i]["norm1.weight"], Gs[i]["norm1.weight"], Gs[i]["norm1.bias"],
+                              add=acc[i], defer=_ln_defer(sides[i]), out=acc[i])
+        shape = dims + (C,)
+        grads = tuple(_ret(t, G[k]) for G, tg in zip(Gs, tgs) for k, t in zip(CROSS_KEYS, tg))
+        return (acc[0].reshape(shape), acc[1].reshape(shape), None, None, None, None, None, None) + grads
 
 
 # ============================================================================= patch embed / merging / expand / head

@@ -228,6 +228,10 @@ class LayerNormProxy(nn.Module):
 PARALLEL_MODALITIES = False
 # Head: run reverse_patch_embedding + out_conv as their composition (off = the reference's two separate convolutions).
 FUSE_HEAD_TAIL = True
+# Both modalities' blocks of a depth slot in one fused launch (off: one fused launch per modality, on two streams when
+# PARALLEL_MODALITIES is set).
+import os as _os
+PAIR_BLOCKS = _os.environ.get("MICF_PAIR_BLOCKS", "1") != "0"
 _SIDE_STREAMS = {}
 
 
@@ -378,7 +382,35 @@ class BasicLayer(nn.Module):
         resample = downsample(dim=dim, norm_layer=norm_layer) if downsample is not None else None
         setattr(self, self._resample_attr, resample)
 
+    def _pair_fusable(self, x, xa):
+        """Both modalities' blocks of a depth slot in ONE fused launch (functional.SelfPairFn / CrossPairFn)?"""
+        if not PAIR_BLOCKS or not x.is_cuda or x.shape != xa.shape or self.depth == 0:
+            return False
+        blk = self.self_blocks1[0]
+        B, D, H, W, C = x.shape
+        P = {"mlp.fc1.weight": blk.mlp.fc1.weight}
+        return bool(Fn._fusable((B, D, H, W), C, blk.num_heads, Fn.effective_window((D, H, W), blk.window_size), P)) and \
+            Fn._padded((D, H, W), (2, 2, 2)) == (D, H, W)
+
+    def _forward_pairs(self, x, xa):
+        for i in range(self.depth):
+            a, b = self.self_blocks1[i], self.self_blocks2[i]
+            sa, sb = _block_scales(a, x), _block_scales(b, xa)
+            x, xa = Fn.SelfPairFn.apply(x, xa, sa[0], sa[1], sb[0], sb[1], a.num_heads, a.norm1.eps,
+                                        *_block_params(a, Fn.SELF_KEYS), *_block_params(b, Fn.SELF_KEYS))
+            a, b = self.blocks1[i], self.blocks2[i]
+            sa, sb = _block_scales(a, x), _block_scales(b, xa)
+            x, xa = Fn.CrossPairFn.apply(x, xa, sa[0], sa[1], sb[0], sb[1], a.num_heads, a.norm1.eps,
+                                         *_block_params(a, Fn.CROSS_KEYS), *_block_params(b, Fn.CROSS_KEYS))
+        return x, xa
+
     def forward(self, x, xa):
+        if self._pair_fusable(x, xa):
+            x, xa = self._forward_pairs(x, xa)
+            resample = getattr(self, self._resample_attr)
+            if resample is not None:
+                return x, xa, resample(x), resample(xa)
+            return x, xa, x, xa
         side = _side_stream(x.device) if (PARALLEL_MODALITIES and x.is_cuda) else None
         if side is None:
             for i in range(self.depth):

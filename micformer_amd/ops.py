@@ -59,13 +59,13 @@ def layernorm_fwd(x1, gamma, beta, eps, x2=None):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x1, mean, rstd, gamma, dgamma, dbeta, x2=None, add=None, defer=None):
-    """Returns dx1 (and dx2); dgamma/dbeta are accumulated in place.  dx = LN'(dy) + add.
+def layernorm_bwd(dy, x1, mean, rstd, gamma, dgamma, dbeta, x2=None, add=None, defer=None, out=None):
+    """Returns dx1 (and dx2); dgamma/dbeta are accumulated in place.  dx = LN'(dy) + add (out: destination, may alias add).
     defer: a list -> the parameter gradients are left as per-workgroup partials and (partials, blocks, C, dgamma, dbeta) is
     appended to it for a later `layernorm_bwd_finish` (shapes without a partial form accumulate immediately as usual)."""
     rows, c1 = x1.shape
     C = dy.shape[1]
-    dx1 = _new(x1, rows, c1)
+    dx1 = out if out is not None else _new(x1, rows, c1)
     dx2 = _new(x1, rows, C - c1) if x2 is not None else None
     partials = None
     if defer is not None and x2 is None:
@@ -536,14 +536,47 @@ _DT = {"fp32": 0, "bf16": 1}
 FWD_W = (("ln1_g", "norm1.weight"), ("ln1_b", "norm1.bias"), ("wq", "{a}.q.weight"), ("bq", "{a}.q.bias"), ("wkv", "{a}.kv.weight"),
          ("bkv", "{a}.kv.bias"), ("wp", "{a}.proj.weight"), ("bp", "{a}.proj.bias"), ("ln2_g", "norm2.weight"), ("ln2_b", "norm2.bias"),
          ("w1", "mlp.fc1.weight"), ("b1", "mlp.fc1.bias"), ("w2", "mlp.fc2.weight"), ("b2", "mlp.fc2.bias"))
-BWD_W = (("ln1_g", "norm1.weight"), ("ln2_g", "norm2.weight"), ("wq", "{a}.q.weight"), ("wkv", "{a}.kv.weight"),
-         ("wp", "{a}.proj.weight"), ("w1", "mlp.fc1.weight"), ("w2", "mlp.fc2.weight"))
+BWD_W = (("ln1_g", "norm1.weight"), ("ln2_g", "norm2.weight"))
+BWD_WT = (("wqt", "{a}.q.weight"), ("wkvt", "{a}.kv.weight"), ("wpt", "{a}.proj.weight"), ("w1t", "mlp.fc1.weight"),
+          ("w2t", "mlp.fc2.weight"))
 
 
-def block_tile_tokens(dims, C, heads, hidden):
+def block_tile_tokens(dims, C, heads, hidden, backward=False):
     """Tokens per workgroup tile of the fused block kernels for this shape; 0 = not handled (use the per-op path)."""
     B, D, H, W = dims
-    return int(_lib.lib.micf_block_tile_tokens(B, D, H, W, C, heads, hidden))
+    return int(_lib.lib.micf_block_tile_tokens(B, D, H, W, C, heads, hidden, 1 if backward else 0))
+
+
+class TransposePlan:
+    """ctypes item array of (src [r, c] -> dst [c, r]) pairs, reusable while the tensors keep their addresses."""
+
+    def __init__(self, pairs):
+        self.pairs = list(pairs)
+        self.n = len(self.pairs)
+        self.arr = (_lib.TransposeItem * max(self.n, 1))()
+        for it, (src, dst) in zip(self.arr, self.pairs):
+            it.src, it.dst, it.rows, it.cols = f32(src), f32(dst), src.shape[0], src.shape[1]
+
+    def launch(self):
+        if self.n:
+            nb = sum(8 * s.numel() for s, _ in self.pairs) if _lib.PROFILE is not None else 0
+            call("micf_transpose_grouped", ctypes.cast(self.arr, ctypes.c_void_p), self.n, cost=(nb, 0) if _lib.PROFILE is not None else None)
+
+
+def transposed_weights(P, attn):
+    """The five transposed weight matrices the fused backward streams.  Engine mode: the parameter carries `_micf_wt`, a view of
+    the engine's transpose buffer that is refreshed once per step; otherwise they are made here (one grouped launch)."""
+    out, todo = {}, []
+    for field, key in BWD_WT:
+        w = P[key.format(a=attn)]
+        wt = getattr(w, "_micf_wt", None)
+        if wt is None:
+            wt = _new(w, w.shape[1], w.shape[0])
+            todo.append((w, wt))
+        out[field] = wt
+    if todo:
+        TransposePlan(todo).launch()
+    return out
 
 
 def block_fwd(groups, dims, C, heads, eps, scale):
@@ -579,10 +612,11 @@ def block_bwd(groups, dims, C, heads, scale):
     B, D, H, W = dims
     T = B * D * H * W
     hidden = groups[0]["P"]["mlp.fc1.weight"].shape[0]
-    tm = block_tile_tokens(dims, C, heads, hidden)
+    tm = block_tile_tokens(dims, C, heads, hidden, backward=True)
     tiles = (T + tm - 1) // tm
     arr = (_lib.BlockBwdGroup * 2)()
     outs = []
+    keep = []            # temporaries (transposed weights) must outlive the launch: the next group's outputs must not reuse them
     nb = fl = 0
     for it, gd in zip(arr, groups):
         dy, P, a, cross = gd["dy"], gd["P"], gd["attn"], gd["cross"]
@@ -594,6 +628,10 @@ def block_bwd(groups, dims, C, heads, scale):
             setattr(it, k, f32(gd.get(k)))
         for field, key in BWD_W:
             setattr(it, field, f32(P[key.format(a=a)]))
+        wts = transposed_weights(P, a)
+        keep.append(wts)
+        for field, wt in wts.items():
+            setattr(it, field, f32(wt))
         for k, v in o.items():
             setattr(it, k, f32(v))
         o["tiles"] = tiles
@@ -602,6 +640,7 @@ def block_bwd(groups, dims, C, heads, scale):
         fl += 2 * T * 12 * C * C + 8 * T * C * 8
     call("micf_block_bwd", ctypes.cast(arr, ctypes.c_void_p), len(groups), B, D, H, W, C, heads, hidden, float(scale),
          _DT[_COMPUTE_DTYPE], cost=(nb, fl, f"{len(groups)}x{T}x{C}") if _lib.PROFILE is not None and DETAIL else ((nb, fl) if _lib.PROFILE is not None else None))
+    del keep
     return outs
 
 

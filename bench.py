@@ -139,6 +139,7 @@ def main(argv=None):
     ap.add_argument("--serial-modalities", action="store_true", help="do not overlap the CT / MR branches on two streams")
     ap.add_argument("--detail", action="store_true", help="roofline leg: key kernels by shape too (diagnostic)")
     ap.add_argument("--eval-mode", action="store_true", help="DropPath off (default: train mode, DropPath active)")
+    ap.add_argument("--no-flush-points", action="store_true", help="launch all queued weight gradients after backward")
     ap.add_argument("--cpu-stub", action="store_true", help="control-flow test on CPU/gloo with a stub engine (no kernels)")
     args = ap.parse_args(argv)
 
@@ -183,7 +184,7 @@ def main(argv=None):
         torch.manual_seed(1234 + rank)                              # rank-distinct DropPath stream and data
         x, tgt = synthetic_batch(args.batch, vol, 8, dev, 1234 + rank)
         eng = TrainEngine(model, base_lr=1e-4, t_max=150, use_graph=not args.no_graph,
-                          parallel_modalities=not args.serial_modalities)
+                          parallel_modalities=not args.serial_modalities, flush_points=not args.no_flush_points)
 
     def barrier():
         if world > 1:

@@ -37,6 +37,12 @@ typedef void* micf_stream_t; /* hipStream_t */
 
 #define MICF_ABI_VERSION 1
 
+/* dtype argument of the matrix-core entry points (nn.Linear, the 3x3x3 convolutions, the fused blocks): the arithmetic of the
+ * MFMA products.  Everything in HBM stays fp32 in both modes (master weights, activations, gradients, Adam moments). */
+#define MICF_DTYPE_F32 0  /* v_mfma_f32_16x16x4_f32: exact fp32 (bitwise a k-ordered fmaf chain) -- the parity mode */
+#define MICF_DTYPE_BF16 1 /* v_mfma_f32_16x16x32_bf16: operands rounded to bf16 (RNE) at the fragment read, fp32 accumulate;
+                             residual stream, LayerNorm, softmax, GELU, loss and everything stored stay fp32 */
+
 int micf_abi_version(void);
 const char* micf_strerror(int code);
 
@@ -72,18 +78,18 @@ int micf_layernorm_bwd_finish(const micf_ln_finish_item* items, int n, micf_stre
  * The residual form fuses `shortcut + drop_path(x)` (MS.py:419,424,517,522). */
 int micf_linear_fwd(const float* a1, const float* a2, int k1, const float* w, const float* bias, const float* resid,
                     const float* dp_scale, int64_t rows_per_sample, float* y, float* pre_act, int64_t M, int N, int K,
-                    int act, micf_stream_t stream);
+                    int act, int dtype, micf_stream_t stream);
 /* d[a1|a2] (=|+=) (s * dy) @ W, optionally multiplied element-wise by GELU'(pre_act[M,K]) (fc2 -> fc1 seam). */
 int micf_linear_bwd_data(const float* dy, const float* dp_scale, int64_t rows_per_sample, const float* w,
                          const float* pre_act, float* da1, float* da2, int k1, int accumulate, int64_t M, int N, int K,
-                         micf_stream_t stream);
+                         int dtype, micf_stream_t stream);
 /* dW += (s*dy)^T @ A, dbias += colsum(s*dy);  A = [a1|a2], or GELU(a1) when a_gelu != 0 (a1 = saved pre-activation).
  * workspace (optional, caller-owned scratch of workspace_floats fp32, see micf_linear_bwd_weight_workspace): when large
  * enough the token-split partial products are written there with plain 16-byte stores and reduced by a second launch
  * instead of being atomically added (device-scope fp32 atomics cost one fabric transaction each). */
 int micf_linear_bwd_weight(const float* dy, const float* dp_scale, int64_t rows_per_sample, const float* a1,
                            const float* a2, int k1, int a_gelu, float* dw, float* dbias, int64_t M, int N, int K,
-                           float* workspace, int64_t workspace_floats, micf_stream_t stream);
+                           float* workspace, int64_t workspace_floats, int dtype, micf_stream_t stream);
 /* Upper bound of the scratch (in floats) micf_linear_bwd_weight can use for (M, N, K). */
 int64_t micf_linear_bwd_weight_workspace(int64_t M, int N, int K);
 
@@ -106,7 +112,7 @@ typedef struct micf_wgrad_item {
   int32_t K;
 } micf_wgrad_item;
 int micf_linear_bwd_weight_grouped(const micf_wgrad_item* items, int n, float* workspace, int64_t workspace_floats,
-                                   micf_stream_t stream);
+                                   int dtype, micf_stream_t stream);
 /* Scratch floats the grouped call needs for these items (layers longer than one token split), or -1 if an item is unsupported. */
 int64_t micf_linear_bwd_weight_grouped_workspace(const micf_wgrad_item* items, int n);
 
@@ -144,20 +150,20 @@ int micf_window_attn_bwd(const float* q, int ldq, const float* k, const float* v
  * and Head.out_conv (MS.py:1046,1053).  w [N, c1+c2, 3,3,3].  y_layout 0: channels-last [T,N]; 1: NCDHW. */
 int micf_conv3_fwd(const float* x1, int c1, const float* x2, int c2, const float* w, const float* bias, float* y,
                    int y_layout, int B, int D, int H, int W, int N, float* workspace, int64_t workspace_floats,
-                   micf_stream_t stream);
+                   int dtype, micf_stream_t stream);
 /* scratch (floats) that enables the direct forward kernel for channels-last outputs with N <= 16 (0 = not applicable) */
 int64_t micf_conv3_fwd_workspace(int N, int c1, int c2);
 /* workspace (optional scratch, micf_conv3_bwd_data_workspace floats): enables the direct data-gradient kernel for
  * channels-last dy with N <= 16 (the weights are re-laid out as [tap][c][16 n] there by the same call). */
 int micf_conv3_bwd_data(const float* dy, int dy_layout, const float* w, float* dx1, int c1, int acc1, float* dx2,
                         int c2, int acc2, int B, int D, int H, int W, int N, float* workspace, int64_t workspace_floats,
-                        micf_stream_t stream);
+                        int dtype, micf_stream_t stream);
 int64_t micf_conv3_bwd_data_workspace(int N, int c1, int c2);
 /* workspace (optional scratch, micf_conv3_bwd_weight_workspace floats; 0 = not used for this shape): enables the
  * register-resident MFMA weight-gradient kernel for channels-last dy with N == 16. */
 int micf_conv3_bwd_weight(const float* dy, int dy_layout, const float* x1, int c1, const float* x2, int c2, float* dw,
                           float* dbias, int B, int D, int H, int W, int N, float* workspace, int64_t workspace_floats,
-                          micf_stream_t stream);
+                          int dtype, micf_stream_t stream);
 int64_t micf_conv3_bwd_weight_workspace(int B, int D, int H, int W, int N, int c1, int c2);
 
 /* ---- deformable re-sampling of the key/value modality (MS.py:313-318 tail, 326-337, 360-384; STN.py:9-32):
@@ -263,9 +269,6 @@ int micf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, cons
  * MS.py:699-701).  Token grid (B, D, H, W) with even D, H, W and 2x2x2 windows, C % 16 == 0, head_dim 16 or 32,
  * hidden % 16 == 0; micf_block_tile_tokens returns 0 for shapes the fused kernels do not take (callers then use the
  * per-op entry points above).  dtype: arithmetic of the matrix-core products. */
-#define MICF_DTYPE_F32 0  /* v_mfma_f32_16x16x4_f32: exact fp32 (bitwise a k-ordered fmaf chain) -- the parity mode */
-#define MICF_DTYPE_BF16 1 /* v_mfma_f32_16x16x32_bf16: operands rounded to bf16 at the fragment read, fp32 accumulate;
-                             residual stream, LayerNorm, softmax, GELU and everything stored stay fp32 */
 typedef struct micf_block_fwd_group {
   const float* x;      /* [T, C] block input (residual stream), T = B*D*H*W tokens in natural order */
   const float* kvsrc;  /* cross: [T, C] deformably sampled raw other modality (K/V source, never normed); NULL = self attention */

@@ -21,11 +21,11 @@ SIGNATURES = {
     "micf_layernorm_bwd": "pppippppppplippp",
     "micf_layernorm_bwd_partial_rows": "lii",
     "micf_layernorm_bwd_finish": "pip",
-    "micf_linear_fwd": "ppipppplppliiip",
-    "micf_linear_bwd_data": "pplppppiiliip",
-    "micf_linear_bwd_weight": "pplppiippliiplp",
+    "micf_linear_fwd": "ppipppplppliiiip",
+    "micf_linear_bwd_data": "pplppppiiliiip",
+    "micf_linear_bwd_weight": "pplppiippliiplip",
     "micf_linear_bwd_weight_workspace": "lii",
-    "micf_linear_bwd_weight_grouped": "piplp",
+    "micf_linear_bwd_weight_grouped": "piplip",
     "micf_linear_bwd_weight_grouped_workspace": "pi",
     "micf_head_tail_compose": "pppppiiiip",
     "micf_head_tail_col2im": "pppiiiiiip",
@@ -36,11 +36,11 @@ SIGNATURES = {
     "micf_sw_normalize": "ppilp",
     "micf_window_attn_fwd": "pippipiiiiiiiiiifp",
     "micf_window_attn_bwd": "pippipipippiiiiiiiiiifp",
-    "micf_conv3_fwd": "pipipppiiiiiiplp",
+    "micf_conv3_fwd": "pipipppiiiiiiplip",
     "micf_conv3_fwd_workspace": "iii",
-    "micf_conv3_bwd_data": "pippiipiiiiiiiplp",
+    "micf_conv3_bwd_data": "pippiipiiiiiiiplip",
     "micf_conv3_bwd_data_workspace": "iii",
-    "micf_conv3_bwd_weight": "pipipippiiiiiplp",
+    "micf_conv3_bwd_weight": "pipipippiiiiiplip",
     "micf_conv3_bwd_weight_workspace": "iiiiiii",
     "micf_offset_sample_fwd": "pppppppiiiiifp",
     "micf_offset_sample_bwd": "ppppppppppppiiiiifplp",

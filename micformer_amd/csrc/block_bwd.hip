@@ -26,11 +26,12 @@ struct BlkBwdArgs {
 // LayerNorm backward of the rows held in LDS tile `D` (gradient w.r.t. the normalised output, pre-gain) against the HBM rows
 // `xsrc`: out = addt + rs * (g d - mean(g d) - xh mean(g d xh)).  addt / out are LDS tile A (in place) and HBM `hout`.
 // The per-tile column sums of d * xh and d go through `scratch` (LDS, >= 16 * 2C floats) to part[2C].
-template <int TJ, int VPL>
+template <int TJ, int VPL, int NW>
 __device__ __forceinline__ void ln_bwd_tile(const float* D, float* A, int S, int C, const float* __restrict__ xsrc,
                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                             const float* __restrict__ gamma, const int* tok, float* __restrict__ hout,
                                             float* __restrict__ hout2, float* scratch, float* __restrict__ part) {
+  constexpr int TM = 16 * TJ, NTHR = 64 * NW, RPP = 4 * NW, NPASS = (TM + RPP - 1) / RPP, NPR = RPP < TM ? RPP : TM;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, rg = lane >> 4;
   const int C4 = C >> 2;
   const float invC = 1.0f / (float)C;
@@ -42,8 +43,9 @@ __device__ __forceinline__ void ln_bwd_tile(const float* D, float* A, int S, int
     gm[k] = c4 < C4 ? ld4g(gamma + 4 * c4) : ag[k];
   }
 #pragma unroll 1
-  for (int pass = 0; pass < TJ; ++pass) {
-    const int row = pass * 16 + wave * 4 + rg;
+  for (int pass = 0; pass < NPASS; ++pass) {
+    const int row = pass * RPP + wave * 4 + rg;
+    if (row >= TM) continue;
     const int tk = tok[row];
     const float mu = tk >= 0 ? mean[tk] : 0.f, rs = tk >= 0 ? rstd[tk] : 0.f;
     float4 xh[VPL], d[VPL];
@@ -86,30 +88,30 @@ __device__ __forceinline__ void ln_bwd_tile(const float* D, float* A, int S, int
 #pragma unroll
   for (int k = 0; k < VPL; ++k) {
     const int c4 = l16 + 16 * k;
-    if (c4 < C4) {
+    if (c4 < C4 && wave * 4 + rg < NPR) {
       *reinterpret_cast<float4*>(mine + 4 * c4) = ag[k];
       *reinterpret_cast<float4*>(mine + C + 4 * c4) = ab[k];
     }
   }
   __syncthreads();
   if (part) {
-    for (int c = tid; c < 2 * C; c += 256) {
+    for (int c = tid; c < 2 * C; c += NTHR) {
       float s = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s += scratch[r * 2 * C + c];
+      for (int r = 0; r < NPR; ++r) s += scratch[r * 2 * C + c];
       part[c] = s;
     }
   }
   __syncthreads();
 }
 
-template <int C, int HD, int TJ, bool BF16>
-__global__ void __launch_bounds__(256, 2) block_bwd_kernel(const BlkBwdArgs a) {
-  constexpr int TM = 16 * TJ, VPL = (C + 63) / 64, NSL = C / 16;
+template <int C, int HD, int TJ, int NW, bool BF16>
+__global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) block_bwd_kernel(const BlkBwdArgs a) {
+  constexpr int TM = 16 * TJ, VPL = (C + 63) / 64, NSL = C / 16, NTHR = 64 * NW, RPP = 4 * NW, NPASS = (TM + RPP - 1) / RPP;
   extern __shared__ __attribute__((aligned(1024))) float lds[];
   constexpr int C4 = C >> 2, S = C + 4, SU = 3 * C + 4, Hd = 4 * C;
   float* ring = lds;
-  float* A1 = ring + kFusedScratch;
+  float* A1 = ring + NW * kFusedScratchPerWave;
   float* A2 = A1 + TM * S;
   float* U = A2 + TM * S;
   float* sc1 = U + TM * SU;
@@ -140,8 +142,9 @@ __global__ void __launch_bounds__(256, 2) block_bwd_kernel(const BlkBwdArgs a) {
 
   // ---- dy rows -> A1
 #pragma unroll 1
-  for (int pass = 0; pass < TJ; ++pass) {
-    const int row = pass * 16 + wave * 4 + rg;
+  for (int pass = 0; pass < NPASS; ++pass) {
+    const int row = pass * RPP + wave * 4 + rg;
+    if (row >= TM) continue;
     const int tk = tok[row];
     for (int c4 = l16; c4 < C4; c4 += 16)
       *reinterpret_cast<float4*>(A1 + row * S + 4 * c4) = tk >= 0 ? ld4g(g.dy + (int64_t)tk * C + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -153,35 +156,38 @@ __global__ void __launch_bounds__(256, 2) block_bwd_kernel(const BlkBwdArgs a) {
     constexpr int hc = HC;
     constexpr int X4 = hc >> 2;
 #pragma unroll 1
-    for (int pass = 0; pass < TJ; ++pass) {
-      const int row = pass * 16 + wave * 4 + rg;
+    for (int pass = 0; pass < NPASS; ++pass) {
+      const int row = pass * RPP + wave * 4 + rg;
+      if (row >= TM) continue;
       const int tk = tok[row];
       for (int c4 = l16; c4 < X4; c4 += 16)
         *reinterpret_cast<float4*>(U + row * SU + 4 * c4) = tk >= 0 ? ld4g(g.h + (int64_t)tk * Hd + c0 + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
-    gemm_phase<TJ, NSL, 1, C, BF16>(g.w2t + (int64_t)c0 * C, hc, A1, nullptr, 0, nullptr, S, U, SU, EpiGeluGrad{sc2});
+    gemm_phase<TJ, NSL, 1, C, NW, BF16>(g.w2t + (int64_t)c0 * C, hc, A1, nullptr, 0, nullptr, S, U, SU, EpiGeluGrad{sc2});
 #pragma unroll 1
-    for (int pass = 0; pass < TJ; ++pass) {
-      const int row = pass * 16 + wave * 4 + rg;
+    for (int pass = 0; pass < NPASS; ++pass) {
+      const int row = pass * RPP + wave * 4 + rg;
+      if (row >= TM) continue;
       const int tk = tok[row];
       if (tk < 0) continue;
       for (int c4 = l16; c4 < X4; c4 += 16)
         st4g(g.dh + (int64_t)tk * Hd + c0 + 4 * c4, *reinterpret_cast<const float4*>(U + row * SU + 4 * c4));
     }
-    if (c0 == 0) gemm_phase<TJ, NSL, 2, Hd, BF16>(g.w1t + c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiStore{});
-    else gemm_phase<TJ, NSL, 2, Hd, BF16>(g.w1t + c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiAcc{});
+    if (c0 == 0) gemm_phase<TJ, NSL, 2, Hd, NW, BF16>(g.w1t + c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiStore{});
+    else gemm_phase<TJ, NSL, 2, Hd, NW, BF16>(g.w1t + c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiAcc{});
   }
 
   // ---- dx1 = dy + LN2'(A2) -> A1 + HBM; LN2 gain / bias partials
-  ln_bwd_tile<TJ, VPL>(A2, A1, S, C, g.x1, g.stats + 2 * T, g.stats + 3 * T, g.ln2_g, tok, g.dx1, g.dx1_copy, U,
+  ln_bwd_tile<TJ, VPL, NW>(A2, A1, S, C, g.x1, g.stats + 2 * T, g.stats + 3 * T, g.ln2_g, tok, g.dx1, g.dx1_copy, U,
                        g.ln2_part ? g.ln2_part + (int64_t)tile * 2 * C : nullptr);
 
   // ---- do = s1 dx1 Wp -> A2;  q | k | v rows -> U
-  gemm_phase<TJ, NSL, 1, C, BF16>(g.wpt, C, A1, nullptr, 0, nullptr, S, A2, S, EpiStoreScale{sc1});
+  gemm_phase<TJ, NSL, 1, C, NW, BF16>(g.wpt, C, A1, nullptr, 0, nullptr, S, A2, S, EpiStoreScale{sc1});
 #pragma unroll 1
-  for (int pass = 0; pass < TJ; ++pass) {
-    const int row = pass * 16 + wave * 4 + rg;
+  for (int pass = 0; pass < NPASS; ++pass) {
+    const int row = pass * RPP + wave * 4 + rg;
+    if (row >= TM) continue;
     const int tk = tok[row];
     for (int c4 = l16; c4 < 3 * C4; c4 += 16) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -193,7 +199,7 @@ __global__ void __launch_bounds__(256, 2) block_bwd_kernel(const BlkBwdArgs a) {
 
   // ---- attention backward in place on U.  Thread = (window, row i, head); batches of whole windows.
   {
-    constexpr int heads = C / HD, per = 8 * heads, wpb = 256 / per;
+    constexpr int heads = C / HD, per = 8 * heads, wpb = NTHR / per;
     float* PS = ring;                                   // [256][16]: P row | dS row of every thread of the batch
     for (int w0 = 0; w0 < TM / 8; w0 += wpb) {
       const int wl = tid / per, rem = tid - wl * per;
@@ -286,8 +292,9 @@ __global__ void __launch_bounds__(256, 2) block_bwd_kernel(const BlkBwdArgs a) {
 
   // ---- dq | dk | dv rows -> HBM (operands of the q / kv weight gradients)
 #pragma unroll 1
-  for (int pass = 0; pass < TJ; ++pass) {
-    const int row = pass * 16 + wave * 4 + rg;
+  for (int pass = 0; pass < NPASS; ++pass) {
+    const int row = pass * RPP + wave * 4 + rg;
+    if (row >= TM) continue;
     const int tk = tok[row];
     if (tk < 0) continue;
     for (int c4 = l16; c4 < 3 * C4; c4 += 16) {
@@ -299,25 +306,27 @@ __global__ void __launch_bounds__(256, 2) block_bwd_kernel(const BlkBwdArgs a) {
 
   if (!g.dxs) {
     // ---- self: dxn = dq Wq + dkv Wkv -> A2;  dx = dx1 + LN1'(dxn) -> HBM; LN1 partials
-    gemm_phase<TJ, NSL, 1, C, BF16>(g.wqt, C, U, nullptr, 0, nullptr, SU, A2, S, EpiStore{});
-    gemm_phase<TJ, NSL, 2, 2 * C, BF16>(g.wkvt, C, U + C, nullptr, 0, nullptr, SU, A2, S, EpiAcc{});
-    ln_bwd_tile<TJ, VPL>(A2, A1, S, C, g.x, g.stats, g.stats + T, g.ln1_g, tok, g.dx, nullptr, U,
+    gemm_phase<TJ, NSL, 1, C, NW, BF16>(g.wqt, C, U, nullptr, 0, nullptr, SU, A2, S, EpiStore{});
+    gemm_phase<TJ, NSL, 2, 2 * C, NW, BF16>(g.wkvt, C, U + C, nullptr, 0, nullptr, SU, A2, S, EpiAcc{});
+    ln_bwd_tile<TJ, VPL, NW>(A2, A1, S, C, g.x, g.stats, g.stats + T, g.ln1_g, tok, g.dx, nullptr, U,
                          g.ln1_part ? g.ln1_part + (int64_t)tile * 2 * C : nullptr);
   } else {
     // ---- cross: the q path's pre-LayerNorm gradient and the sampled K/V source's gradient leave separately
-    gemm_phase<TJ, NSL, 1, C, BF16>(g.wqt, C, U, nullptr, 0, nullptr, SU, A2, S, EpiStore{});
+    gemm_phase<TJ, NSL, 1, C, NW, BF16>(g.wqt, C, U, nullptr, 0, nullptr, SU, A2, S, EpiStore{});
 #pragma unroll 1
-    for (int pass = 0; pass < TJ; ++pass) {
-      const int row = pass * 16 + wave * 4 + rg;
+    for (int pass = 0; pass < NPASS; ++pass) {
+      const int row = pass * RPP + wave * 4 + rg;
+      if (row >= TM) continue;
       const int tk = tok[row];
       if (tk < 0) continue;
       for (int c4 = l16; c4 < C4; c4 += 16) st4g(g.dx + (int64_t)tk * C + 4 * c4, *reinterpret_cast<const float4*>(A2 + row * S + 4 * c4));
     }
     __syncthreads();
-    gemm_phase<TJ, NSL, 2, 2 * C, BF16>(g.wkvt, C, U + C, nullptr, 0, nullptr, SU, A2, S, EpiStore{});
+    gemm_phase<TJ, NSL, 2, 2 * C, NW, BF16>(g.wkvt, C, U + C, nullptr, 0, nullptr, SU, A2, S, EpiStore{});
 #pragma unroll 1
-    for (int pass = 0; pass < TJ; ++pass) {
-      const int row = pass * 16 + wave * 4 + rg;
+    for (int pass = 0; pass < NPASS; ++pass) {
+      const int row = pass * RPP + wave * 4 + rg;
+      if (row >= TM) continue;
       const int tk = tok[row];
       if (tk < 0) continue;
       for (int c4 = l16; c4 < C4; c4 += 16) st4g(g.dxs + (int64_t)tk * C + 4 * c4, *reinterpret_cast<const float4*>(A2 + row * S + 4 * c4));
@@ -327,17 +336,17 @@ __global__ void __launch_bounds__(256, 2) block_bwd_kernel(const BlkBwdArgs a) {
 
 template <int C, int HD, int TJ>
 static int launch_bwd(const BlkBwdArgs& a, int dtype, hipStream_t s) {
-  constexpr int TM = 16 * TJ;
-  const size_t lds = block_lds_floats(TM, C, 4 * C) * sizeof(float);
+  constexpr int TM = 16 * TJ, NW = C >= 192 ? 8 : 4;
+  const size_t lds = block_lds_floats(TM, C, 4 * C, NW) * sizeof(float);
   if (lds > 160 * 1024) return MICF_EUNSUPPORTED;
   const unsigned grid = a.G == 2 ? (unsigned)((a.tiles + 3) / 4 * 8) : (unsigned)a.tiles;
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_bwd_kernel<C, HD, TJ, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_bwd_kernel<C, HD, TJ, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_bwd_kernel<C, HD, TJ, NW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_bwd_kernel<C, HD, TJ, NW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
-  if (dtype == MICF_DTYPE_BF16) hipLaunchKernelGGL((block_bwd_kernel<C, HD, TJ, true>), dim3(grid), dim3(256), lds, s, a);
-  else hipLaunchKernelGGL((block_bwd_kernel<C, HD, TJ, false>), dim3(grid), dim3(256), lds, s, a);
+  if (dtype == MICF_DTYPE_BF16) hipLaunchKernelGGL((block_bwd_kernel<C, HD, TJ, NW, true>), dim3(grid), dim3(64 * NW), lds, s, a);
+  else hipLaunchKernelGGL((block_bwd_kernel<C, HD, TJ, NW, false>), dim3(grid), dim3(64 * NW), lds, s, a);
   MICF_RETURN_LAUNCH();
 }
 

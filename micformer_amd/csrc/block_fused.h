@@ -20,20 +20,6 @@
 
 namespace micf {
 
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ unsigned pack_bf16(float a, float b) {   // round-to-nearest-even, a in the low half
-  unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
-  ua += 0x7FFFu + ((ua >> 16) & 1u);
-  ub += 0x7FFFu + ((ub >> 16) & 1u);
-  return (ua >> 16) | (ub & 0xFFFF0000u);
-}
-__device__ __forceinline__ bf16x8 to_bf16x8(const float4& lo, const float4& hi) {
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  u32x4 r = {pack_bf16(lo.x, lo.y), pack_bf16(lo.z, lo.w), pack_bf16(hi.x, hi.y), pack_bf16(hi.z, hi.w)};
-  return __builtin_bit_cast(bf16x8, r);
-}
-
 // ---- epilogues of a GEMM phase: called with the LDS destination of 4 consecutive outputs x..x+3 of token row `trow`.
 // They touch LDS only (the GEMM loop must not issue vector memory operations besides its DMAs).
 struct EpiStore {
@@ -84,7 +70,7 @@ struct EpiGeluGrad {          // rowscale[trow] * v * GELU'(what the tile holds:
 //   A(x, r) = W[x * LD + r]: rows of W are the outputs.  nn.Linear forward: W = the weight [N, K]; data gradients
 //   (dA = dY W): W = the TRANSPOSED weight [K, N] (micf_transpose_grouped, once per step), so both directions stream
 //   contiguous 64-byte row pieces.
-// The 16-wide x tiles are dealt round-robin to the four waves.  Nothing about a tile's weights is shared between waves, so
+// The 16-wide x tiles are dealt round-robin to the NW waves of the workgroup.  Nothing about a tile's weights is shared between waves, so
 // they do not go through LDS at all: every lane loads ITS MFMA A-fragments straight from L2 / HBM into registers (one
 // 16-byte load per 16-deep slab = A(x = li, r = 4 lr .. 4 lr + 3)).  The unit of work is
 // (tile, k-chunk of NSL slabs); NSL, NK and LD are compile-time, so a unit is ONE base-pointer computation plus NSL loads at
@@ -94,21 +80,21 @@ struct EpiGeluGrad {          // rowscale[trow] * v * GELU'(what the tile holds:
 // The activation operand Bs is an LDS tile [16 TG][SB] read as one ds_read_b128 per token group and slab (k-permutation:
 // lane group lr supplies k = 4 lr + s in step s, both operands alike); a wave writes only its own x columns of the LDS output
 // tile Os.  Two accumulator chains per token group (even / odd k-steps) keep the fp32 MFMA pipe at its issue rate.
-// All 256 threads call it together; on return Os is complete and visible to the workgroup.
-template <int TG, int NSL, int NK, int LD, bool BF16, class Epi>
+// All 64 * NW threads call it together; on return Os is complete and visible to the workgroup.
+template <int TG, int NSL, int NK, int LD, int NW, bool BF16, class Epi>
 __device__ __forceinline__ void gemm_phase(const float* __restrict__ W0, int X0, const float* Bs0, const float* __restrict__ W1,
                                            int X1, const float* Bs1, int SB, float* Os, int SO, const Epi epi) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lr = lane >> 4;
   const int nt0 = X0 >> 4, ntiles = nt0 + (X1 >> 4);
-  const int mytiles = (ntiles - wave + 3) >> 2;            // tiles wave, wave + 4, ...
+  const int mytiles = (ntiles - wave + NW - 1) / NW;       // tiles wave, wave + NW, ...
   const int nunits = mytiles * NK;
 
   struct Frag { float4 v[NSL]; };
   // fragments of unit `u` (clamped to the wave's last unit: loads are unconditional so the pipelined loop stays straight-line)
   auto load_unit = [&](int u, Frag& f) {
     if (u > nunits - 1) u = nunits - 1;
-    const int tile = wave + 4 * (NK == 1 ? u : u / NK), kc = NK == 1 ? 0 : u % NK;
+    const int tile = wave + NW * (NK == 1 ? u : u / NK), kc = NK == 1 ? 0 : u % NK;
     const bool seg1 = tile >= nt0;
     const float* Wb = seg1 ? W1 : W0;
     const int xt = (seg1 ? tile - nt0 : tile) * 16;
@@ -121,7 +107,7 @@ __device__ __forceinline__ void gemm_phase(const float* __restrict__ W0, int X0,
 #pragma unroll
   for (int g = 0; g < TG; ++g) { acc0[g] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[g] = acc0[g]; }
   auto compute_unit = [&](int u, const Frag& f) {
-    const int tile = wave + 4 * (NK == 1 ? u : u / NK), kc = NK == 1 ? 0 : u % NK;
+    const int tile = wave + NW * (NK == 1 ? u : u / NK), kc = NK == 1 ? 0 : u % NK;
     const float* brow = ((tile >= nt0) ? Bs1 : Bs0) + li * SB + kc * NSL * 16 + 4 * lr;
     float4 qprev[TG], aprev = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -209,12 +195,15 @@ inline TileGeo make_tile_geo(int B, int D, int H, int W) {
   return g;
 }
 
-constexpr int kFusedScratch = 4096;    // floats: the attention backward's P / dS exchange (16 floats per thread)
+constexpr int kFusedScratchPerWave = 1024;   // floats: the attention backward's P / dS exchange (16 floats per thread)
 // LDS floats of a fused block kernel: scratch + A1, A2 [TM][C+4] + U [TM][3C+4] + row scales / token ids +
 // the staged parameter vectors (9C + hidden)
-inline size_t block_lds_floats(int TM, int C, int hidden, bool scratch = true) {
-  return (size_t)(scratch ? kFusedScratch : 0) + (size_t)TM * (2 * (C + 4) + 3 * C + 4) + 3 * TM + 9 * C + hidden;
+inline size_t block_lds_floats(int TM, int C, int hidden, int scratch_waves) {
+  return (size_t)scratch_waves * kFusedScratchPerWave + (size_t)TM * (2 * (C + 4) + 3 * C + 4) + 3 * TM + 9 * C + hidden;
 }
+// waves per workgroup: 8 where a launch has too few tiles to fill the chip and every tile streams megabytes of weights
+// (C = 192: 128 tiles of 16 tokens at the base model's 8^3 stage) -- the x tiles of a phase are then dealt to 8 waves
+inline int block_waves(int C) { return C >= 192 ? 8 : 4; }
 __device__ __forceinline__ float sum16(float v) {      // sum over the 16-lane group (rows are handled by 16 lanes each)
   v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
   return v;

@@ -27,9 +27,9 @@ struct BlkFwdArgs {
 
 // rows of a [TM][X] tile are handled by 16-lane groups: pass p, wave w, lane group rg -> row p*16 + 4*w + rg; lane l16 covers
 // the float4 columns l16, l16 + 16, ...
-template <int C, int HD, int TJ, bool BF16>
-__global__ void __launch_bounds__(256) block_fwd_kernel(const BlkFwdArgs a) {
-  constexpr int TM = 16 * TJ, VPL = (C + 63) / 64, NSL = C / 16;
+template <int C, int HD, int TJ, int NW, bool BF16>
+__global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) {
+  constexpr int TM = 16 * TJ, VPL = (C + 63) / 64, NSL = C / 16, NTHR = 64 * NW, RPP = 4 * NW, NPASS = (TM + RPP - 1) / RPP;
   extern __shared__ __attribute__((aligned(1024))) float lds[];
   constexpr int C4 = C >> 2, S = C + 4, SU = 3 * C + 4, Hd = 4 * C;
   float* A1 = lds;
@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(256) block_fwd_kernel(const BlkFwdArgs a) {
   {
     const float* const srcs[9] = {g.ln1_g, g.ln1_b, g.bq, g.bkv, g.bp, g.ln2_g, g.ln2_b, g.b2, g.b1};
     const int offs[10] = {0, C, 2 * C, 3 * C, 5 * C, 6 * C, 7 * C, 8 * C, 9 * C, 9 * C + Hd};
-    for (int e4 = tid; e4 < (9 * C + Hd) >> 2; e4 += 256) {
+    for (int e4 = tid; e4 < (9 * C + Hd) >> 2; e4 += NTHR) {
       const int e = e4 << 2;
       int k = 0;
 #pragma unroll
@@ -84,10 +84,11 @@ __global__ void __launch_bounds__(256) block_fwd_kernel(const BlkFwdArgs a) {
   // statistics); cross: the K/V source rows -> A2
   const float invC = 1.0f / (float)C;
   {
-    float4 v[TJ][VPL], kvv[TJ][VPL];
+    float4 v[NPASS][VPL], kvv[NPASS][VPL];
 #pragma unroll
-    for (int pass = 0; pass < TJ; ++pass) {
-      const int tk = tok[pass * 16 + wave * 4 + rg];
+    for (int pass = 0; pass < NPASS; ++pass) {
+      const int rowl = pass * RPP + wave * 4 + rg;
+      const int tk = rowl < TM ? tok[rowl] : -1;
 #pragma unroll
       for (int k = 0; k < VPL; ++k) {
         const int c4 = l16 + 16 * k;
@@ -100,8 +101,9 @@ __global__ void __launch_bounds__(256) block_fwd_kernel(const BlkFwdArgs a) {
       }
     }
 #pragma unroll
-    for (int pass = 0; pass < TJ; ++pass) {
-      const int row = pass * 16 + wave * 4 + rg;
+    for (int pass = 0; pass < NPASS; ++pass) {
+      const int row = pass * RPP + wave * 4 + rg;
+      if (row >= TM) continue;
       const int tk = tok[row];
       float s = 0.f;
 #pragma unroll
@@ -137,12 +139,13 @@ __global__ void __launch_bounds__(256) block_fwd_kernel(const BlkFwdArgs a) {
   // ---- q | k | v (+ bias) -> U, then out to HBM
   if (!(a.debug & 4)) {
     // q | k | v in ONE phase (two weight segments; the biases bq | bkv are contiguous in PV)
-    gemm_phase<TJ, NSL, 1, C, BF16>(g.wq, C, A1, g.wkv, 2 * C, g.kvsrc ? A2 : A1, S, U, SU, EpiBias{p_bq});
+    gemm_phase<TJ, NSL, 1, C, NW, BF16>(g.wq, C, A1, g.wkv, 2 * C, g.kvsrc ? A2 : A1, S, U, SU, EpiBias{p_bq});
   }
   if (save) {
 #pragma unroll 1
-    for (int pass = 0; pass < TJ; ++pass) {
-      const int row = pass * 16 + wave * 4 + rg;
+    for (int pass = 0; pass < NPASS; ++pass) {
+      const int row = pass * RPP + wave * 4 + rg;
+      if (row >= TM) continue;
       const int tk = tok[row];
       if (tk < 0) continue;
       for (int c4 = l16; c4 < 3 * C4; c4 += 16) {
@@ -156,7 +159,7 @@ __global__ void __launch_bounds__(256) block_fwd_kernel(const BlkFwdArgs a) {
   // ---- attention per (row, head): the 8x8 score row lives in registers; o -> A1 (xn is no longer needed) + HBM
   if (!(a.debug & 2)) {
     constexpr int heads = C / HD;
-    for (int item = tid; item < TM * heads; item += 256) {
+    for (int item = tid; item < TM * heads; item += NTHR) {
       const int row = item / heads, hh = item - row * heads;
       const int r0 = row & ~7, hoff = hh * HD;
       float qr[HD];
@@ -208,12 +211,13 @@ __global__ void __launch_bounds__(256) block_fwd_kernel(const BlkFwdArgs a) {
   __syncthreads();
 
   // ---- proj (+ bp) -> A2; x1 = x + s1 * proj -> A2 + HBM; LayerNorm 2 of the same registers -> A1 (xn2) + HBM
-  if (!(a.debug & 4)) gemm_phase<TJ, NSL, 1, C, BF16>(g.wp, C, A1, nullptr, 0, nullptr, S, A2, S, EpiBias{p_bp});
+  if (!(a.debug & 4)) gemm_phase<TJ, NSL, 1, C, NW, BF16>(g.wp, C, A1, nullptr, 0, nullptr, S, A2, S, EpiBias{p_bp});
   {
-    float4 v[TJ][VPL];
+    float4 v[NPASS][VPL];
 #pragma unroll
-    for (int pass = 0; pass < TJ; ++pass) {
-      const int tk = tok[pass * 16 + wave * 4 + rg];
+    for (int pass = 0; pass < NPASS; ++pass) {
+      const int rowl = pass * RPP + wave * 4 + rg;
+      const int tk = rowl < TM ? tok[rowl] : -1;
 #pragma unroll
       for (int k = 0; k < VPL; ++k) {
         const int c4 = l16 + 16 * k;
@@ -222,8 +226,9 @@ __global__ void __launch_bounds__(256) block_fwd_kernel(const BlkFwdArgs a) {
       }
     }
 #pragma unroll
-    for (int pass = 0; pass < TJ; ++pass) {
-      const int row = pass * 16 + wave * 4 + rg;
+    for (int pass = 0; pass < NPASS; ++pass) {
+      const int row = pass * RPP + wave * 4 + rg;
+      if (row >= TM) continue;
       const int tk = tok[row];
       const float s1v = sc1[row];
       float s = 0.f;
@@ -273,11 +278,12 @@ __global__ void __launch_bounds__(256) block_fwd_kernel(const BlkFwdArgs a) {
   constexpr int HC = 2 * C;
   for (int c0 = 0; c0 < Hd; c0 += HC) {
     constexpr int hc = HC;
-    if (!(a.debug & 4)) gemm_phase<TJ, NSL, 1, C, BF16>(g.w1 + (int64_t)c0 * C, hc, A1, nullptr, 0, nullptr, S, U, SU, EpiBias{p_b1 + c0});
+    if (!(a.debug & 4)) gemm_phase<TJ, NSL, 1, C, NW, BF16>(g.w1 + (int64_t)c0 * C, hc, A1, nullptr, 0, nullptr, S, U, SU, EpiBias{p_b1 + c0});
     const int X4 = hc >> 2;
 #pragma unroll 1
-    for (int pass = 0; pass < TJ; ++pass) {
-      const int row = pass * 16 + wave * 4 + rg;
+    for (int pass = 0; pass < NPASS; ++pass) {
+      const int row = pass * RPP + wave * 4 + rg;
+      if (row >= TM) continue;
       const int tk = tok[row];
       for (int c4 = l16; c4 < X4; c4 += 16) {
         float* up = U + row * SU + 4 * c4;
@@ -291,13 +297,14 @@ __global__ void __launch_bounds__(256) block_fwd_kernel(const BlkFwdArgs a) {
       }
     }
     __syncthreads();
-    if (!(a.debug & 4)) gemm_phase<TJ, NSL, 2, Hd, BF16>(g.w2 + c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiAccScale{sc2});
+    if (!(a.debug & 4)) gemm_phase<TJ, NSL, 2, Hd, NW, BF16>(g.w2 + c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiAccScale{sc2});
   }
 
   // ---- y = x1 + s2 * (fc2 + b2)
 #pragma unroll 1
-  for (int pass = 0; pass < TJ; ++pass) {
-    const int row = pass * 16 + wave * 4 + rg;
+  for (int pass = 0; pass < NPASS; ++pass) {
+    const int row = pass * RPP + wave * 4 + rg;
+    if (row >= TM) continue;
     const int tk = tok[row];
     if (tk < 0) continue;
     const float s2v = sc2[row];
@@ -312,17 +319,17 @@ __global__ void __launch_bounds__(256) block_fwd_kernel(const BlkFwdArgs a) {
 
 template <int C, int HD, int TJ>
 static int launch_fwd(const BlkFwdArgs& a, int dtype, hipStream_t s) {
-  constexpr int TM = 16 * TJ;
-  const size_t lds = block_lds_floats(TM, C, 4 * C, false) * sizeof(float);
+  constexpr int TM = 16 * TJ, NW = C >= 192 ? 8 : 4;
+  const size_t lds = block_lds_floats(TM, C, 4 * C, 0) * sizeof(float);
   if (lds > 160 * 1024) return MICF_EUNSUPPORTED;
   const unsigned grid = a.G == 2 ? (unsigned)((a.tiles + 3) / 4 * 8) : (unsigned)a.tiles;
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_fwd_kernel<C, HD, TJ, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_fwd_kernel<C, HD, TJ, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_fwd_kernel<C, HD, TJ, NW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_fwd_kernel<C, HD, TJ, NW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
-  if (dtype == MICF_DTYPE_BF16) hipLaunchKernelGGL((block_fwd_kernel<C, HD, TJ, true>), dim3(grid), dim3(256), lds, s, a);
-  else hipLaunchKernelGGL((block_fwd_kernel<C, HD, TJ, false>), dim3(grid), dim3(256), lds, s, a);
+  if (dtype == MICF_DTYPE_BF16) hipLaunchKernelGGL((block_fwd_kernel<C, HD, TJ, NW, true>), dim3(grid), dim3(64 * NW), lds, s, a);
+  else hipLaunchKernelGGL((block_fwd_kernel<C, HD, TJ, NW, false>), dim3(grid), dim3(64 * NW), lds, s, a);
   MICF_RETURN_LAUNCH();
 }
 

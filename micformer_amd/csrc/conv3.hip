@@ -203,11 +203,11 @@ extern "C" int64_t micf_conv3_fwd_workspace(int N, int c1, int c2) { return conv
 
 extern "C" int micf_conv3_fwd(const float* x1, int c1, const float* x2, int c2, const float* w, const float* bias,
                               float* y, int y_layout, int B, int D, int H, int W, int N, float* workspace,
-                              int64_t workspace_floats, micf_stream_t stream) {
+                              int64_t workspace_floats, int dtype, micf_stream_t stream) {
   if (!x1 || !w || !y || (c2 > 0 && !x2) || !conv3_args_ok(B, D, H, W, N, c1, c2)) return MICF_EINVAL;
   if (y_layout == 0 && workspace && workspace_floats >= conv3_fwdx_workspace(N, c1, c2)) {
     // few output channels, channels-last: direct convolution with pre-transposed weights streamed from L2 (conv3_fwdx.hip)
-    const int rc = conv3_fwd_x(x1, c1, x2, c2, w, bias, y, workspace, B, D, H, W, N, (hipStream_t)stream);
+    const int rc = conv3_fwd_x(x1, c1, x2, c2, w, bias, y, workspace, B, D, H, W, N, (hipStream_t)stream, dtype);
     if (rc != MICF_EUNSUPPORTED) return rc;
   }
   if (y_layout == 0) {   // LDS-halo direct convolution on the matrix cores: measured faster than the implicit GEMM for the
@@ -242,11 +242,11 @@ extern "C" int64_t micf_conv3_bwd_data_workspace(int N, int c1, int c2) {
 
 extern "C" int micf_conv3_bwd_data(const float* dy, int dy_layout, const float* w, float* dx1, int c1, int acc1,
                                    float* dx2, int c2, int acc2, int B, int D, int H, int W, int N, float* workspace,
-                                   int64_t workspace_floats, micf_stream_t stream) {
+                                   int64_t workspace_floats, int dtype, micf_stream_t stream) {
   if (!dy || !w || (!dx1 && !dx2) || !conv3_args_ok(B, D, H, W, N, c1, c2)) return MICF_EINVAL;
   if (dy_layout == 0 && workspace && workspace_floats >= micf_conv3_bwd_data_workspace(N, c1, c2)) {
     // few dy channels, channels-last: direct convolution with pre-transposed weights (conv3_bwdx.hip)
-    const int rc = conv3_bwd_data_x(dy, w, workspace, dx1, c1, acc1, dx2, c2, acc2, B, D, H, W, N, (hipStream_t)stream);
+    const int rc = conv3_bwd_data_x(dy, w, workspace, dx1, c1, acc1, dx2, c2, acc2, B, D, H, W, N, (hipStream_t)stream, dtype);
     if (rc != MICF_EUNSUPPORTED) return rc;
   }
   const Geo g{B, D, H, W};
@@ -269,10 +269,10 @@ extern "C" int64_t micf_conv3_bwd_weight_workspace(int B, int D, int H, int W, i
 
 extern "C" int micf_conv3_bwd_weight(const float* dy, int dy_layout, const float* x1, int c1, const float* x2, int c2,
                                      float* dw, float* dbias, int B, int D, int H, int W, int N, float* workspace,
-                                     int64_t workspace_floats, micf_stream_t stream) {
+                                     int64_t workspace_floats, int dtype, micf_stream_t stream) {
   if (!dy || !x1 || !dw || (c2 > 0 && !x2) || !conv3_args_ok(B, D, H, W, N, c1, c2)) return MICF_EINVAL;
   if (dy_layout == 0 && workspace) {   // 16 dy channels, channels-last: register-resident MFMA kernel (conv3_wgradx.hip)
-    const int rc = conv3_wgradx(dy, x1, c1, x2, c2, dw, dbias, B, D, H, W, N, workspace, workspace_floats, (hipStream_t)stream);
+    const int rc = conv3_wgradx(dy, x1, c1, x2, c2, dw, dbias, B, D, H, W, N, workspace, workspace_floats, (hipStream_t)stream, dtype);
     if (rc != MICF_EUNSUPPORTED) return rc;
   }
   {   // direct LDS-tiled kernel for the shapes of the model (N = 16 offset conv, N = 8 out_conv)

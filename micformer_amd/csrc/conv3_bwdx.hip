@@ -13,6 +13,7 @@
 //   * every wave owns 2 token rows x NCT channel tiles (2*NCT accumulators); per tap: 2 LDS reads + NCT loads for 8*NCT MFMAs.
 // The implicit-GEMM path (conv3.hip) needed 360 us for the 32^3 x 2 stage (15 TFLOP/s); see DESIGN.md for this kernel's numbers.
 #include "common.h"
+#include "gemm_dma.h"
 
 namespace micf {
 
@@ -36,7 +37,7 @@ __global__ void __launch_bounds__(256) conv3_wt_kernel(const float* __restrict__
 }
 
 // TW: tokens of a tile along w (16 or 8); a column tile is 16/TW h-rows x TW.  Tile = 2 (d) x 4*(16/TW) (h) x TW = 128 tokens.
-template <int TW, int NCT>
+template <int TW, int NCT, bool BF16>
 __global__ void __launch_bounds__(256) conv3_bwdx_kernel(BwdxArgs a) {
   constexpr int CH = 16 / TW, TH = 4 * CH, TD = 2;
   constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2, HALO = HD * HH * HW;
@@ -87,7 +88,7 @@ __global__ void __launch_bounds__(256) conv3_bwdx_kernel(BwdxArgs a) {
   for (int t = 0; t < NCT; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   const float* wp = a.wt + ((int64_t)(ct0 * 16 + li)) * 16 + 4 * lr;      // + tap * O * 16 + t * 256
   const int64_t tap_stride = (int64_t)a.O * 16;
-  float4 av[NCT], an[NCT];
+  float4 av[NCT], an[NCT], aprev[NCT], bprev[2];
 #pragma unroll
   for (int t = 0; t < NCT; ++t) av[t] = (t < nct) ? *reinterpret_cast<const float4*>(wp + t * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
@@ -105,15 +106,35 @@ __global__ void __launch_bounds__(256) conv3_bwdx_kernel(BwdxArgs a) {
       const int zd = ld[tj] + 2 - kd, zh = lh[tj] + 2 - kh, zw = lw[tj] + 2 - kw;      // source voxel = token - (k - 1), halo origin -1
       bv[tj] = *reinterpret_cast<const float4*>(&Xs[((zd * HH + zh) * HW + zw) * xKS + 4 * lr]);
     }
+    if constexpr (!BF16) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const float b0 = s == 0 ? bv[0].x : (s == 1 ? bv[0].y : (s == 2 ? bv[0].z : bv[0].w));
-      const float b1 = s == 0 ? bv[1].x : (s == 1 ? bv[1].y : (s == 2 ? bv[1].z : bv[1].w));
+      for (int s = 0; s < 4; ++s) {
+        const float b0 = s == 0 ? bv[0].x : (s == 1 ? bv[0].y : (s == 2 ? bv[0].z : bv[0].w));
+        const float b1 = s == 0 ? bv[1].x : (s == 1 ? bv[1].y : (s == 2 ? bv[1].z : bv[1].w));
 #pragma unroll
-      for (int t = 0; t < NCT; ++t) {
-        const float av_s = s == 0 ? av[t].x : (s == 1 ? av[t].y : (s == 2 ? av[t].z : av[t].w));
-        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_s, b0, acc[t][0], 0, 0, 0);
-        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_s, b1, acc[t][1], 0, 0, 0);
+        for (int t = 0; t < NCT; ++t) {
+          const float av_s = s == 0 ? av[t].x : (s == 1 ? av[t].y : (s == 2 ? av[t].z : av[t].w));
+          acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_s, b0, acc[t][0], 0, 0, 0);
+          acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_s, b1, acc[t][1], 0, 0, 0);
+        }
+      }
+    } else {
+      // bf16: k = 32 = (16 dy channels) x (two taps); the odd tap of a pair issues the MFMAs, the last tap is padded with zeros
+      if ((tap & 1) || tap == 26) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool pair = tap & 1;
+        const bf16x8 bb0 = pair ? to_bf16x8(bprev[0], bv[0]) : to_bf16x8(bv[0], z);
+        const bf16x8 bb1 = pair ? to_bf16x8(bprev[1], bv[1]) : to_bf16x8(bv[1], z);
+#pragma unroll
+        for (int t = 0; t < NCT; ++t) {
+          const bf16x8 ba = pair ? to_bf16x8(aprev[t], av[t]) : to_bf16x8(av[t], z);
+          acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ba, bb0, acc[t][0], 0, 0, 0);
+          acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ba, bb1, acc[t][1], 0, 0, 0);
+        }
+      } else {
+        bprev[0] = bv[0]; bprev[1] = bv[1];
+#pragma unroll
+        for (int t = 0; t < NCT; ++t) aprev[t] = av[t];
       }
     }
 #pragma unroll
@@ -140,7 +161,7 @@ __global__ void __launch_bounds__(256) conv3_bwdx_kernel(BwdxArgs a) {
   }
 }
 
-template <int TW>
+template <int TW, bool BF16>
 static hipError_t launch_bwdx(BwdxArgs& a, hipStream_t stream) {
   constexpr int CH = 16 / TW, TH = 4 * CH;
   a.tiles_d = (a.D + 1) / 2;
@@ -150,15 +171,15 @@ static hipError_t launch_bwdx(BwdxArgs& a, hipStream_t stream) {
   const int cts = a.O / 16;
   // many token tiles: 6 channel tiles per workgroup (the halo is staged once per 96 channels); few: 2, to spread over the CUs
   if (blocks * ((cts + 5) / 6) >= 384)
-    hipLaunchKernelGGL((conv3_bwdx_kernel<TW, 6>), dim3((unsigned)blocks, (cts + 5) / 6), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((conv3_bwdx_kernel<TW, 6, BF16>), dim3((unsigned)blocks, (cts + 5) / 6), dim3(256), 0, stream, a);
   else
-    hipLaunchKernelGGL((conv3_bwdx_kernel<TW, 2>), dim3((unsigned)blocks, (cts + 1) / 2), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((conv3_bwdx_kernel<TW, 2, BF16>), dim3((unsigned)blocks, (cts + 1) / 2), dim3(256), 0, stream, a);
   return hipGetLastError();
 }
 
 // MICF_EUNSUPPORTED when the shape is outside what this kernel covers (caller falls back to the implicit GEMM).
 int conv3_bwd_data_x(const float* dy, const float* w, float* wt, float* dx1, int c1, int acc1, float* dx2, int c2, int acc2, int B,
-                     int D, int H, int W, int N, hipStream_t stream) {
+                     int D, int H, int W, int N, hipStream_t stream, int dtype) {
   const int O = c1 + c2;
   if (N > 16 || (N & 3) || (O & 15) || (c1 & 3) || (c2 & 3) || W < 8 || !aligned16(dy) || !aligned16(wt) ||
       (dx1 && !aligned16(dx1)) || (dx2 && !aligned16(dx2)))
@@ -169,7 +190,8 @@ int conv3_bwd_data_x(const float* dy, const float* w, float* wt, float* dx1, int
   BwdxArgs a{};
   a.dy = dy; a.N = N; a.wt = wt; a.d1 = dx1; a.d2 = dx2; a.oc1 = c1; a.oc2 = c2; a.acc1 = acc1; a.acc2 = acc2; a.O = O;
   a.B = B; a.D = D; a.H = H; a.W = W;
-  const hipError_t e = (W >= 12) ? launch_bwdx<16>(a, stream) : launch_bwdx<8>(a, stream);
+  const hipError_t e = dtype == MICF_DTYPE_BF16 ? ((W >= 12) ? launch_bwdx<16, true>(a, stream) : launch_bwdx<8, true>(a, stream))
+                                                 : ((W >= 12) ? launch_bwdx<16, false>(a, stream) : launch_bwdx<8, false>(a, stream));
   return e == hipSuccess ? MICF_OK : MICF_ELAUNCH;
 }
 

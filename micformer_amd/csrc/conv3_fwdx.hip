@@ -14,6 +14,7 @@
 //     into the pre-zeroed output.
 // The LDS-weights direct kernel this replaces (conv3_direct.hip) needed 129 us at the 32^3 x 2 stage (41 TFLOP/s).
 #include "common.h"
+#include "gemm_dma.h"
 
 namespace micf {
 
@@ -37,7 +38,7 @@ __global__ void __launch_bounds__(256) conv3_wtf_kernel(const float* __restrict_
   wt[id] = (n < N && cc < Cin) ? w[((int64_t)n * Cin + cc) * 27 + tap] : 0.f;
 }
 
-template <int TW>
+template <int TW, bool BF16>
 __global__ void __launch_bounds__(256) conv3_fwdx_kernel(FwdxArgs a) {
   constexpr int CH = 16 / TW, TH = 4 * CH, TD = 2;
   constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2, HALO = HD * HH * HW;
@@ -99,6 +100,7 @@ __global__ void __launch_bounds__(256) conv3_fwdx_kernel(FwdxArgs a) {
     if (kc + 1 < kc_end) fetch(kc + 1, hv);                             // lands while the MFMAs below run
     const float* wp = a.wt + ((int64_t)kc * 27 * 16 + li) * 16 + 4 * lr;  // + tap * 256
     float4 ring[fAhead + 1];
+    float4 aprev = make_float4(0.f, 0.f, 0.f, 0.f), bprev0 = aprev, bprev1 = aprev;
 #pragma unroll
     for (int t = 0; t < fAhead; ++t) ring[t] = *reinterpret_cast<const float4*>(wp + t * 256);
 #pragma unroll
@@ -109,14 +111,27 @@ __global__ void __launch_bounds__(256) conv3_fwdx_kernel(FwdxArgs a) {
       const int off = ((kd * HH + kh) * HW + kw) * fKS;                 // source voxel = token + (k - 1), halo origin -1
       const float4 b0 = *reinterpret_cast<const float4*>(&Xs[vbase[0] + off]);
       const float4 b1 = *reinterpret_cast<const float4*>(&Xs[vbase[1] + off]);
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b0.x, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b1.x, acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b0.y, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b1.y, acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b0.z, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b1.z, acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b0.w, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b1.w, acc[1], 0, 0, 0);
+      if constexpr (!BF16) {
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b0.x, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b1.x, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b0.y, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b1.y, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b0.z, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b1.z, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b0.w, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b1.w, acc[1], 0, 0, 0);
+      } else {
+        // bf16: k = 32 = (16 channels of this chunk) x (two taps); the odd tap of a pair issues the MFMA, the last tap is padded
+        if ((tap & 1) || tap == 26) {
+          const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+          const bool pair = tap & 1;
+          const bf16x8 ba = pair ? to_bf16x8(aprev, av) : to_bf16x8(av, z);
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ba, pair ? to_bf16x8(bprev0, b0) : to_bf16x8(b0, z), acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ba, pair ? to_bf16x8(bprev1, b1) : to_bf16x8(b1, z), acc[1], 0, 0, 0);
+        } else {
+          aprev = av; bprev0 = b0; bprev1 = b1;
+        }
+      }
     }
   }
   // epilogue: D row = output channel 4*lr + v (float4 over v), column = token li of column tile tj
@@ -152,7 +167,7 @@ int64_t conv3_fwdx_workspace(int N, int c1, int c2) {
 
 // MICF_EUNSUPPORTED when the shape is outside what this kernel covers (caller falls back).
 int conv3_fwd_x(const float* x1, int c1, const float* x2, int c2, const float* w, const float* bias, float* y, float* wt, int B, int D,
-                int H, int W, int N, hipStream_t stream) {
+                int H, int W, int N, hipStream_t stream, int dtype) {
   if (N > 16 || (c1 & 3) || (c2 & 3) || W < 8 || !aligned16(x1) || (x2 && !aligned16(x2)) || !aligned16(y) || !aligned16(wt))
     return MICF_EUNSUPPORTED;
   const int Cin = c1 + c2, chunks = (Cin + 15) / 16;
@@ -171,8 +186,14 @@ int conv3_fwd_x(const float* x1, int c1, const float* x2, int c2, const float* w
   a.chunks_per_block = (chunks + ysplit - 1) / ysplit;
   ysplit = (chunks + a.chunks_per_block - 1) / a.chunks_per_block;
   if (ysplit > 1 && hipMemsetAsync(y, 0, sizeof(float) * (size_t)B * D * H * W * N, stream) != hipSuccess) return MICF_ELAUNCH;
-  if (tw_ == 16) hipLaunchKernelGGL(conv3_fwdx_kernel<16>, dim3((unsigned)blocks, ysplit), dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL(conv3_fwdx_kernel<8>, dim3((unsigned)blocks, ysplit), dim3(256), 0, stream, a);
+  const dim3 grid((unsigned)blocks, ysplit);
+  if (dtype == MICF_DTYPE_BF16) {
+    if (tw_ == 16) hipLaunchKernelGGL((conv3_fwdx_kernel<16, true>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((conv3_fwdx_kernel<8, true>), grid, dim3(256), 0, stream, a);
+  } else {
+    if (tw_ == 16) hipLaunchKernelGGL((conv3_fwdx_kernel<16, false>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((conv3_fwdx_kernel<8, false>), grid, dim3(256), 0, stream, a);
+  }
   return hipGetLastError() == hipSuccess ? MICF_OK : MICF_ELAUNCH;
 }
 

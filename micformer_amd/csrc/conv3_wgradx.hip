@@ -13,6 +13,7 @@
 #include <mutex>
 
 #include "common.h"
+#include "gemm_dma.h"
 
 namespace micf {
 
@@ -31,7 +32,7 @@ struct WgxArgs {
 };
 
 // TW: tile extent along w (16 or 8).  Tile = 1 (d) x 64/TW (h) x TW (w) = 64 tokens; a token group is 16/TW h-rows x TW.
-template <int TW>
+template <int TW, bool BF16>
 __global__ void __launch_bounds__(256) conv3_wgradx_kernel(WgxArgs a) {
   constexpr int CH = 16 / TW, TH = 64 / TW;
   constexpr int HH = TH + 2, HW = TW + 2, HALO = 3 * HH * HW;
@@ -106,6 +107,7 @@ __global__ void __launch_bounds__(256) conv3_wgradx_kernel(WgxArgs a) {
     float bv[4], bn[4];
     load_dy(0, bv);
     __syncthreads();
+    if constexpr (!BF16) {
     // ---- 4 token groups of 16 tokens
 #pragma unroll 1
     for (int g = 0; g < 4; ++g) {
@@ -128,6 +130,33 @@ __global__ void __launch_bounds__(256) conv3_wgradx_kernel(WgxArgs a) {
       }
 #pragma unroll
       for (int s = 0; s < 4; ++s) bv[s] = bn[s];
+    }
+    } else {
+    // ---- bf16: k = 32 tokens per MFMA = two 16-token groups (lane group lr supplies tokens 4 lr + s of each)
+#pragma unroll 1
+    for (int g = 0; g < 4; g += 2) {
+      float b2[4];
+      load_dy(g + 1, b2);
+      load_dy(g + 2, bn);
+      int vox[8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const int j = 4 * lr + (s & 3);
+        const int lh = (g + (s >> 2)) * CH + j / TW, lw = j % TW;
+        vox[s] = ((1 * HH + lh + 1) * HW + lw + 1) * wXS + li;
+      }
+      if (a.bias_ws && wave == 0) bsum += (bv[0] + bv[1] + bv[2] + bv[3]) + (b2[0] + b2[1] + b2[2] + b2[3]);
+      const bf16x8 bb = to_bf16x8(make_float4(bv[0], bv[1], bv[2], bv[3]), make_float4(b2[0], b2[1], b2[2], b2[3]));
+#pragma unroll
+      for (int p = 0; p < wTPW; ++p) {
+        const float* xp = Xs + offs[p];
+        const bf16x8 ba = to_bf16x8(make_float4(xp[vox[0]], xp[vox[1]], xp[vox[2]], xp[vox[3]]),
+                                    make_float4(xp[vox[4]], xp[vox[5]], xp[vox[6]], xp[vox[7]]));
+        acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ba, bb, acc[p], 0, 0, 0);
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) bv[s] = bn[s];
+    }
     }
   }
   // ---- partial slab -> workspace: [(wave*TPW + p)][lane][4], 16-byte stores
@@ -209,7 +238,7 @@ int64_t conv3_wgradx_workspace(int B, int D, int H, int W, int N, int c1, int c2
 
 // MICF_EUNSUPPORTED when the shape / workspace is outside what this kernel covers (caller falls back).
 int conv3_wgradx(const float* dy, const float* x1, int c1, const float* x2, int c2, float* dw, float* dbias, int B, int D, int H,
-                 int W, int N, float* ws, int64_t ws_floats, hipStream_t stream) {
+                 int W, int N, float* ws, int64_t ws_floats, hipStream_t stream, int dtype) {
   const int64_t need = conv3_wgradx_workspace(B, D, H, W, N, c1, c2);
   if (need == 0 || !ws || ws_floats < need || !aligned16(ws) || !aligned16(dy) || !aligned16(x1) || (x2 && !aligned16(x2)))
     return MICF_EUNSUPPORTED;
@@ -223,16 +252,20 @@ int conv3_wgradx(const float* dy, const float* x1, int c1, const float* x2, int 
   a.tiles_per_group = p.tiles_per_group; a.groups = p.groups;
   static std::once_flag attr_once;       // > 64 KiB of dynamic LDS needs the opt-in once per process
   std::call_once(attr_once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgradx_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgradx_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgradx_kernel<16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgradx_kernel<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgradx_kernel<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgradx_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   });
   const dim3 grid(p.slabs, p.groups);
   if (p.tw == 16) {
     constexpr int HALO = 3 * (4 + 2) * (16 + 2);
-    hipLaunchKernelGGL(conv3_wgradx_kernel<16>, grid, dim3(256), sizeof(float) * HALO * wXS, stream, a);
+    if (dtype == MICF_DTYPE_BF16) hipLaunchKernelGGL((conv3_wgradx_kernel<16, true>), grid, dim3(256), sizeof(float) * HALO * wXS, stream, a);
+    else hipLaunchKernelGGL((conv3_wgradx_kernel<16, false>), grid, dim3(256), sizeof(float) * HALO * wXS, stream, a);
   } else {
     constexpr int HALO = 3 * (8 + 2) * (8 + 2);
-    hipLaunchKernelGGL(conv3_wgradx_kernel<8>, grid, dim3(256), sizeof(float) * HALO * wXS, stream, a);
+    if (dtype == MICF_DTYPE_BF16) hipLaunchKernelGGL((conv3_wgradx_kernel<8, true>), grid, dim3(256), sizeof(float) * HALO * wXS, stream, a);
+    else hipLaunchKernelGGL((conv3_wgradx_kernel<8, false>), grid, dim3(256), sizeof(float) * HALO * wXS, stream, a);
   }
   if (hipGetLastError() != hipSuccess) return MICF_ELAUNCH;
   const int64_t n = (int64_t)wPairs * 256 * p.slabs + 16;

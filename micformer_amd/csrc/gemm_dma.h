@@ -29,6 +29,21 @@
 
 namespace micf {
 
+// ---- bf16 mode: MFMA operands rounded to bf16 at the fragment read (fp32 in HBM / LDS, fp32 accumulate)
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {   // round-to-nearest-even, a in the low half
+  unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+  ua += 0x7FFFu + ((ua >> 16) & 1u);
+  ub += 0x7FFFu + ((ub >> 16) & 1u);
+  return (ua >> 16) | (ub & 0xFFFF0000u);
+}
+__device__ __forceinline__ bf16x8 to_bf16x8(const float4& lo, const float4& hi) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 r = {pack_bf16(lo.x, lo.y), pack_bf16(lo.z, lo.w), pack_bf16(hi.x, hi.y), pack_bf16(hi.z, hi.w)};
+  return __builtin_bit_cast(bf16x8, r);
+}
+__device__ __forceinline__ float f4e(const float4& v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); }
+
 constexpr int kDmaBR = 16;      // slab depth
 constexpr int kDmaNS = 4;       // ring depth of the throughput variant (32 KiB of LDS: 4-5 workgroups per CU)
    // ring depth of the latency variant (64 KiB): small grids, one workgroup per CU
@@ -78,7 +93,7 @@ __device__ __forceinline__ int xcd_order(int id, int n) {
 // Ps / Qs are NS-deep rings of 4 KiB slab images.  csum (lanes of wave 0 when do_cs) gets the column sums of the Q slabs.
 // All waves of the workgroup must call it together (it contains barriers); on return every DMA of this wave has landed
 // and a trailing barrier makes the rings reusable.
-template <bool PX, bool QX, int NS>
+template <bool PX, bool QX, int NS, bool BF16 = false>
 __device__ __forceinline__ void dma_tile_loop(const DmaOperand& P, const DmaOperand& Q, int i0, int j0, int r_begin, int nslab,
                                               float* Ps, float* Qs, f32x4 (&acc)[4], bool do_cs, float& csum) {
   static_assert(NS >= 3 && NS <= 8, "ring depth");
@@ -114,6 +129,7 @@ __device__ __forceinline__ void dma_tile_loop(const DmaOperand& P, const DmaOper
       psrc += pstep; qsrc += qstep;
     }
   }
+  float4 aprev[4], bprev = make_float4(0.f, 0.f, 0.f, 0.f);     // bf16 mode: the even slab of a pair
   for (int it = 0; it < nslab; ++it) {
     // slab `it` has landed when at most the (up to NS-2) younger slabs of THIS wave are still outstanding
     wait_younger((nslab - 1 - it < NS - 2) ? nslab - 1 - it : NS - 2);
@@ -144,21 +160,46 @@ __device__ __forceinline__ void dma_tile_loop(const DmaOperand& P, const DmaOper
     } else {
       qv[0] = *reinterpret_cast<const float4*>(Qb + (16 * wave + li) * kDmaBR + 4 * lr);
     }
+    if constexpr (!BF16) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      float b;
-      if (QX) {
-        const float4 q = qv[s];
-        b = wave == 0 ? q.x : (wave == 1 ? q.y : (wave == 2 ? q.z : q.w));
-      } else {
-        b = s == 0 ? qv[0].x : (s == 1 ? qv[0].y : (s == 2 ? qv[0].z : qv[0].w));
+      for (int s = 0; s < 4; ++s) {
+        float b;
+        if (QX) {
+          const float4 q = qv[s];
+          b = wave == 0 ? q.x : (wave == 1 ? q.y : (wave == 2 ? q.z : q.w));
+        } else {
+          b = s == 0 ? qv[0].x : (s == 1 ? qv[0].y : (s == 2 ? qv[0].z : qv[0].w));
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          float a;
+          if (PX) { const float4 v = pv[s]; a = t == 0 ? v.x : (t == 1 ? v.y : (t == 2 ? v.z : v.w)); }
+          else    { const float4 v = pv[t]; a = s == 0 ? v.x : (s == 1 ? v.y : (s == 2 ? v.z : v.w)); }
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+        }
       }
+    } else {
+      // k = 32 per MFMA: the fragments of an even slab wait for the odd one; an unpaired last slab is padded with zeros.
+      // Per-lane fragments as float4 over the 4 k-steps: a4[t] = A(x of tile t, r = 4 lr + s), b4 = B(r = 4 lr + s, j).
+      float4 a4[4], b4;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        float a;
-        if (PX) { const float4 v = pv[s]; a = t == 0 ? v.x : (t == 1 ? v.y : (t == 2 ? v.z : v.w)); }
-        else    { const float4 v = pv[t]; a = s == 0 ? v.x : (s == 1 ? v.y : (s == 2 ? v.z : v.w)); }
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+      for (int t = 0; t < 4; ++t)
+        a4[t] = PX ? make_float4(f4e(pv[0], t), f4e(pv[1], t), f4e(pv[2], t), f4e(pv[3], t)) : pv[t];
+      if (QX) b4 = make_float4(f4e(qv[0], wave), f4e(qv[1], wave), f4e(qv[2], wave), f4e(qv[3], wave));
+      else b4 = qv[0];
+      const bool odd = it & 1, last = it == nslab - 1;
+      if (odd || last) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bf16x8 bb = odd ? to_bf16x8(bprev, b4) : to_bf16x8(b4, z);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const bf16x8 ba = odd ? to_bf16x8(aprev[t], a4[t]) : to_bf16x8(a4[t], z);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ba, bb, acc[t], 0, 0, 0);
+        }
+      } else {
+        bprev = b4;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) aprev[t] = a4[t];
       }
     }
   }
@@ -166,7 +207,7 @@ __device__ __forceinline__ void dma_tile_loop(const DmaOperand& P, const DmaOper
 
 // PX / QX: operand is kind X (x contiguous) instead of kind R.  R must be a multiple of 16; rows/cols beyond the extents are
 // clamped on load (their products are discarded by the epilogue bounds).
-template <bool PX, bool QX, class Epi, int NS>
+template <bool PX, bool QX, class Epi, int NS, bool BF16 = false>
 __global__ void __launch_bounds__(256) gemm_dma_kernel(DmaOperand P, DmaOperand Q, Epi epi, int I, int J, int R, int r_chunk,
                                                        int tiles_i, int nblocks, float* colsum) {
   __shared__ __attribute__((aligned(1024))) float Ps[NS * 64 * kDmaBR];
@@ -186,7 +227,7 @@ __global__ void __launch_bounds__(256) gemm_dma_kernel(DmaOperand P, DmaOperand 
   for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   const bool do_cs = QX && (colsum != nullptr) && (bi == 0) && (tid < 64);   // column sums of the Q slabs (bias gradient)
   float csum = 0.f;
-  dma_tile_loop<PX, QX, NS>(P, Q, i0, j0, r_begin, nslab, Ps, Qs, acc, do_cs, csum);
+  dma_tile_loop<PX, QX, NS, BF16>(P, Q, i0, j0, r_begin, nslab, Ps, Qs, acc, do_cs, csum);
 
   if (do_cs && j0 + tid < J) atomicAdd(colsum + j0 + tid, csum * epi.block_scale());
   // epilogue
@@ -228,7 +269,7 @@ __device__ __forceinline__ void wait_younger5(int younger) {  // 5 loads per sta
   }
 }
 
-template <bool PX, class Epi>
+template <bool PX, class Epi, bool BF16 = false>
 __global__ void __launch_bounds__(256) gemm_dma_skinny_kernel(DmaOperand P, DmaOperand Q, Epi epi, int I, int J, int R, int tiles_i,
                                                               int nblocks) {
   extern __shared__ __attribute__((aligned(1024))) float skinny_lds[];
@@ -276,6 +317,7 @@ __global__ void __launch_bounds__(256) gemm_dma_skinny_kernel(DmaOperand P, DmaO
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s)
     if (s < nslab) issue(s);
+  float4 sk_aprev[4], sk_bprev = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int it = 0; it < nslab; ++it) {
     wait_younger5((nslab - 1 - it < NS - 2) ? nslab - 1 - it : NS - 2);
     if (it + NS - 1 < nslab) issue((it + NS - 1) % NS);   // the buffer this wave finished reading in the previous iteration
@@ -290,15 +332,36 @@ __global__ void __launch_bounds__(256) gemm_dma_skinny_kernel(DmaOperand P, DmaO
       for (int t = 0; t < 4; ++t) pv[t] = *reinterpret_cast<const float4*>(Pb + (16 * t + li) * kDmaBR + 4 * lr);
     }
     const float4 qv = *reinterpret_cast<const float4*>(Qb + li * kDmaBR + 4 * lr);
+    if constexpr (!BF16) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const float b = s == 0 ? qv.x : (s == 1 ? qv.y : (s == 2 ? qv.z : qv.w));
+      for (int s = 0; s < 4; ++s) {
+        const float b = s == 0 ? qv.x : (s == 1 ? qv.y : (s == 2 ? qv.z : qv.w));
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        float a;
-        if (PX) { const float4 v = pv[s]; a = t == 0 ? v.x : (t == 1 ? v.y : (t == 2 ? v.z : v.w)); }
-        else    { const float4 v = pv[t]; a = s == 0 ? v.x : (s == 1 ? v.y : (s == 2 ? v.z : v.w)); }
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) {
+          float a;
+          if (PX) { const float4 v = pv[s]; a = t == 0 ? v.x : (t == 1 ? v.y : (t == 2 ? v.z : v.w)); }
+          else    { const float4 v = pv[t]; a = s == 0 ? v.x : (s == 1 ? v.y : (s == 2 ? v.z : v.w)); }
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+        }
+      }
+    } else {
+      float4 a4[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        a4[t] = PX ? make_float4(f4e(pv[0], t), f4e(pv[1], t), f4e(pv[2], t), f4e(pv[3], t)) : pv[t];
+      const bool odd = it & 1, last = it == nslab - 1;
+      if (odd || last) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bf16x8 bb = odd ? to_bf16x8(sk_bprev, qv) : to_bf16x8(qv, z);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const bf16x8 ba = odd ? to_bf16x8(sk_aprev[t], a4[t]) : to_bf16x8(a4[t], z);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ba, bb, acc[t], 0, 0, 0);
+        }
+      } else {
+        sk_bprev = qv;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) sk_aprev[t] = a4[t];
       }
     }
   }
@@ -337,9 +400,9 @@ inline bool dma_ok(const DmaOperand& P, bool px, const DmaOperand& Q, bool qx, i
   return ok(P, px) && ok(Q, qx) && (R % kDmaBR == 0) && (r_chunk % kDmaBR == 0);
 }
 
-template <bool PX, bool QX, class Epi>
-inline hipError_t launch_gemm_dma(DmaOperand P, DmaOperand Q, Epi epi, int I, int64_t J, int R, int splits, hipStream_t stream,
-                                  float* colsum = nullptr) {
+template <bool PX, bool QX, class Epi, bool BF16 = false>
+inline hipError_t launch_gemm_dma_t(DmaOperand P, DmaOperand Q, Epi epi, int I, int64_t J, int R, int splits, hipStream_t stream,
+                                    float* colsum) {
   if (I <= 0 || J <= 0 || R <= 0) return hipSuccess;
   if (splits < 1) splits = 1;
   int r_chunk = ceil_div(ceil_div(R, splits), kDmaBR) * kDmaBR;
@@ -353,17 +416,26 @@ inline hipError_t launch_gemm_dma(DmaOperand P, DmaOperand Q, Epi epi, int I, in
       const int64_t sblocks = (int64_t)tiles_i * ceil_div(J, 16);
       static std::once_flag attr_once;      // per instantiation; std::call_once keeps the C-ABI re-entrant from several host threads
       std::call_once(attr_once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dma_skinny_kernel<PX, Epi>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dma_skinny_kernel<PX, Epi, BF16>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, kSkinnyLds);
       });
-      hipLaunchKernelGGL((gemm_dma_skinny_kernel<PX, Epi>), dim3((unsigned)((sblocks + 7) / 8 * 8)), dim3(256), kSkinnyLds, stream,
+      hipLaunchKernelGGL((gemm_dma_skinny_kernel<PX, Epi, BF16>), dim3((unsigned)((sblocks + 7) / 8 * 8)), dim3(256), kSkinnyLds, stream,
                          P, Q, epi, I, (int)J, R, tiles_i, (int)sblocks);
       return hipGetLastError();
     }
   }
-  hipLaunchKernelGGL((gemm_dma_kernel<PX, QX, Epi, kDmaNS>), dim3((unsigned)((blocks + 7) / 8 * 8), splits), dim3(256), 0, stream, P,
+  hipLaunchKernelGGL((gemm_dma_kernel<PX, QX, Epi, kDmaNS, BF16>), dim3((unsigned)((blocks + 7) / 8 * 8), splits), dim3(256), 0, stream, P,
                      Q, epi, I, (int)J, R, r_chunk, tiles_i, (int)blocks, colsum);
   return hipGetLastError();
+}
+
+
+// dtype: MICF_DTYPE_F32 (0) exact fp32 MFMA, MICF_DTYPE_BF16 (1) bf16 MFMA operands with fp32 accumulation
+template <bool PX, bool QX, class Epi>
+inline hipError_t launch_gemm_dma(DmaOperand P, DmaOperand Q, Epi epi, int I, int64_t J, int R, int splits, hipStream_t stream,
+                                  float* colsum = nullptr, int dtype = 0) {
+  if (dtype == 1) return launch_gemm_dma_t<PX, QX, Epi, true>(P, Q, epi, I, J, R, splits, stream, colsum);
+  return launch_gemm_dma_t<PX, QX, Epi, false>(P, Q, epi, I, J, R, splits, stream, colsum);
 }
 
 }  // namespace micf

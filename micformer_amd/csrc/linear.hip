@@ -180,8 +180,8 @@ using namespace micf;
 
 extern "C" int micf_linear_fwd(const float* a1, const float* a2, int k1, const float* w, const float* bias,
                                const float* resid, const float* dp_scale, int64_t rows_per_sample, float* y,
-                               float* pre_act, int64_t M, int N, int K, int act, micf_stream_t stream) {
-  if (!a1 || !w || !y || M < 0 || N <= 0 || K <= 0 || k1 <= 0 || k1 > K || (k1 < K && !a2)) return MICF_EINVAL;
+                               float* pre_act, int64_t M, int N, int K, int act, int dtype, micf_stream_t stream) {
+  if (!a1 || !w || !y || M < 0 || N <= 0 || K <= 0 || k1 <= 0 || k1 > K || (k1 < K && !a2) || (dtype != 0 && dtype != 1)) return MICF_EINVAL;
   if (M >= (1LL << 31)) return MICF_EUNSUPPORTED;
   if (rows_per_sample <= 0) rows_per_sample = M > 0 ? M : 1;
   const int k2 = K - k1;
@@ -197,9 +197,9 @@ extern "C" int micf_linear_fwd(const float* a1, const float* a2, int k1, const f
   {   // LDS-DMA core: plain operands, K a multiple of 16
     const DmaOperand P{w, K, N}, Q{a1, K, (int)M};
     if (!a2 && N >= 48 && M >= 64 && dma_ok(P, false, Q, false, K, K)) {
-      if (act) return RC((launch_gemm_dma<false, false>(P, Q, LinFwdEpi<1, 0>{bias, nullptr, nullptr, rps, y, pre_act, N, evec}, N, M, K, 1, s)));
-      if (resid) return RC((launch_gemm_dma<false, false>(P, Q, LinFwdEpi<0, 1>{bias, resid, dp_scale, rps, y, nullptr, N, evec}, N, M, K, 1, s)));
-      return RC((launch_gemm_dma<false, false>(P, Q, LinFwdEpi<0, 0>{bias, nullptr, nullptr, rps, y, nullptr, N, evec}, N, M, K, 1, s)));
+      if (act) return RC((launch_gemm_dma<false, false>(P, Q, LinFwdEpi<1, 0>{bias, nullptr, nullptr, rps, y, pre_act, N, evec}, N, M, K, 1, s, nullptr, dtype)));
+      if (resid) return RC((launch_gemm_dma<false, false>(P, Q, LinFwdEpi<0, 1>{bias, resid, dp_scale, rps, y, nullptr, N, evec}, N, M, K, 1, s, nullptr, dtype)));
+      return RC((launch_gemm_dma<false, false>(P, Q, LinFwdEpi<0, 0>{bias, nullptr, nullptr, rps, y, nullptr, N, evec}, N, M, K, 1, s, nullptr, dtype)));
     }
   }
   if (act) return RC(launch_gemm(pa, qa, LinFwdEpi<1, 0>{bias, nullptr, nullptr, rps, y, pre_act, N, evec}, N, M, K, 1, s));
@@ -209,7 +209,7 @@ extern "C" int micf_linear_fwd(const float* a1, const float* a2, int k1, const f
 
 extern "C" int micf_linear_bwd_data(const float* dy, const float* dp_scale, int64_t rows_per_sample, const float* w,
                                     const float* pre_act, float* da1, float* da2, int k1, int accumulate, int64_t M,
-                                    int N, int K, micf_stream_t stream) {
+                                    int N, int K, int dtype, micf_stream_t stream) {
   if (!dy || !w || !da1 || M < 0 || N <= 0 || K <= 0 || k1 <= 0 || k1 > K || (k1 < K && !da2)) return MICF_EINVAL;
   if (M >= (1LL << 31)) return MICF_EUNSUPPORTED;
   if (rows_per_sample <= 0) rows_per_sample = M > 0 ? M : 1;
@@ -224,8 +224,8 @@ extern "C" int micf_linear_bwd_data(const float* dy, const float* dp_scale, int6
     const DmaOperand P{w, K, K}, Q{dy, N, (int)M};
     if (K >= 48 && M >= 64 && dma_ok(P, true, Q, false, N, N)) {
       const FastDiv rpsd((uint32_t)rows_per_sample);
-      if (pre_act) return RC((launch_gemm_dma<true, false>(P, Q, LinBwdDataEpi<1>{pre_act, da1, d2, k1, K, accumulate, evec, dp_scale, rpsd}, K, M, N, 1, s)));
-      return RC((launch_gemm_dma<true, false>(P, Q, LinBwdDataEpi<0>{nullptr, da1, d2, k1, K, accumulate, evec, dp_scale, rpsd}, K, M, N, 1, s)));
+      if (pre_act) return RC((launch_gemm_dma<true, false>(P, Q, LinBwdDataEpi<1>{pre_act, da1, d2, k1, K, accumulate, evec, dp_scale, rpsd}, K, M, N, 1, s, nullptr, dtype)));
+      return RC((launch_gemm_dma<true, false>(P, Q, LinBwdDataEpi<0>{nullptr, da1, d2, k1, K, accumulate, evec, dp_scale, rpsd}, K, M, N, 1, s, nullptr, dtype)));
     }
   }
   if (dp_scale) {
@@ -257,7 +257,7 @@ extern "C" int64_t micf_linear_bwd_weight_workspace(int64_t M, int N, int K) {
 
 extern "C" int micf_linear_bwd_weight(const float* dy, const float* dp_scale, int64_t rows_per_sample, const float* a1,
                                       const float* a2, int k1, int a_gelu, float* dw, float* dbias, int64_t M, int N,
-                                      int K, float* workspace, int64_t workspace_floats, micf_stream_t stream) {
+                                      int K, float* workspace, int64_t workspace_floats, int dtype, micf_stream_t stream) {
   if (!dy || !a1 || !dw || M < 0 || N <= 0 || K <= 0 || k1 <= 0 || k1 > K || (k1 < K && !a2)) return MICF_EINVAL;
   if (M >= (1LL << 31)) return MICF_EUNSUPPORTED;
   if (M == 0) return MICF_OK;
@@ -296,14 +296,14 @@ extern "C" int micf_linear_bwd_weight(const float* dy, const float* dp_scale, in
         const int64_t NK = (int64_t)N * K;
         if (vec_ok && dsplits > 1 && (int64_t)dsplits * NK <= workspace_floats) {
           LinWgtWsEpi wepi{workspace, K, NK, dp_scale, (int)chunk, rps};
-          if (launch_gemm_dma<true, true>(P, Q, wepi, K, N, (int)M, dsplits, s, dbias) != hipSuccess) return MICF_ELAUNCH;
+          if (launch_gemm_dma<true, true>(P, Q, wepi, K, N, (int)M, dsplits, s, dbias, dtype) != hipSuccess) return MICF_ELAUNCH;
           int blocks = (int)((NK / 4 + 255) / 256);
           if (blocks > 2048) blocks = 2048;
           hipLaunchKernelGGL(reduce_splits_kernel, dim3(blocks), dim3(256), 0, s, workspace, dw, NK / 4, dsplits, NK);
           MICF_RETURN_LAUNCH();
         }
         LinWgtEpi depi{dw, K, dp_scale, (int)chunk, rps};
-        return RC((launch_gemm_dma<true, true>(P, Q, depi, K, N, (int)M, dsplits, s, dbias)));
+        return RC((launch_gemm_dma<true, true>(P, Q, depi, K, N, (int)M, dsplits, s, dbias, dtype)));
       }
     }
   }

@@ -28,6 +28,7 @@ struct GArgs {
   GItem it[kGroupMax];
 };
 
+template <bool BF16>
 __global__ void __launch_bounds__(256) wgrad_grouped_kernel(const GArgs g) {
   __shared__ __attribute__((aligned(1024))) float Ps[kDmaNS * 64 * kDmaBR];
   __shared__ __attribute__((aligned(1024))) float Qs[kDmaNS * 64 * kDmaBR];
@@ -68,7 +69,7 @@ __global__ void __launch_bounds__(256) wgrad_grouped_kernel(const GArgs g) {
     for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     float csum = 0.f;
     if (r != r_begin) __syncthreads();                       // the rings are reused by the next segment
-    dma_tile_loop<true, true, kDmaNS>(P, Q, i0, j0, r, (seg_end - r) / kDmaBR, Ps, Qs, acc, do_cs, csum);
+    dma_tile_loop<true, true, kDmaNS, BF16>(P, Q, i0, j0, r, (seg_end - r) / kDmaBR, Ps, Qs, acc, do_cs, csum);
 #pragma unroll
     for (int q = 0; q < 4; ++q) { tot[q][0] += s * acc[q][0]; tot[q][1] += s * acc[q][1]; tot[q][2] += s * acc[q][2]; tot[q][3] += s * acc[q][3]; }
     ctot += s * csum;
@@ -146,7 +147,7 @@ extern "C" int64_t micf_linear_bwd_weight_grouped_workspace(const micf_wgrad_ite
 }
 
 extern "C" int micf_linear_bwd_weight_grouped(const micf_wgrad_item* items, int n, float* workspace, int64_t workspace_floats,
-                                              micf_stream_t stream) {
+                                              int dtype, micf_stream_t stream) {
   if (n < 0 || (n > 0 && !items)) return MICF_EINVAL;
   if (n == 0) return MICF_OK;
   const int64_t need = micf_linear_bwd_weight_grouped_workspace(items, n);
@@ -181,7 +182,8 @@ extern "C" int micf_linear_bwd_weight_grouped(const micf_wgrad_item* items, int 
         ++rg.n;
       }
     }
-    hipLaunchKernelGGL(wgrad_grouped_kernel, dim3((blocks + 7) / 8 * 8), dim3(256), 0, s, g);
+    if (dtype == MICF_DTYPE_BF16) hipLaunchKernelGGL(wgrad_grouped_kernel<true>, dim3((blocks + 7) / 8 * 8), dim3(256), 0, s, g);
+    else hipLaunchKernelGGL(wgrad_grouped_kernel<false>, dim3((blocks + 7) / 8 * 8), dim3(256), 0, s, g);
     if (hipGetLastError() != hipSuccess) return MICF_ELAUNCH;
     if (rg.n > 0) {
       hipLaunchKernelGGL(wgrad_grouped_reduce_kernel, dim3(rblocks), dim3(256), 0, s, rg);

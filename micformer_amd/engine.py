@@ -23,7 +23,7 @@ from .loss.dice import MDiceLoss
 class TrainEngine:
     def __init__(self, model, base_lr=1e-4, t_max=150, eta_min=0.0, betas=(0.9, 0.999), eps=1e-8, criterion=None,
                  use_graph=False, process_group=None, grad_bucket_bytes=64 << 20, parallel_modalities=True,
-                 defer_wgrad=True, split_step=None, always_collective=False):
+                 defer_wgrad=True, split_step=None, always_collective=False, flush_points=True):
         self.model = model
         self.criterion = criterion if criterion is not None else MDiceLoss()
         self.base_lr, self.t_max, self.eta_min = base_lr, t_max, eta_min
@@ -38,6 +38,7 @@ class TrainEngine:
         # outside step() still gets its weight gradients computed in place.
         self.parallel_modalities = bool(parallel_modalities)
         self.defer_wgrad = bool(defer_wgrad)     # linear weight gradients: queued in backward, one grouped flush
+        self.flush_points = bool(flush_points)   # ... launched stage by stage on a side stream while backward continues
         # Data parallel (or split_step=True, a single-GPU test hook): the graph holds forward + backward only; the queued weight
         # gradients are then launched group by group and every gradient slice is all-reduced as soon as its last writer is
         # done, overlapping RCCL with the remaining weight-gradient launches (see _flush_and_reduce).
@@ -110,12 +111,13 @@ class TrainEngine:
 
         @contextlib.contextmanager
         def scope():
-            prev = (_ms.PARALLEL_MODALITIES, _fn.DEFER_WGRAD)
+            prev = (_ms.PARALLEL_MODALITIES, _fn.DEFER_WGRAD, _fn.FLUSH_POINTS)
             _ms.PARALLEL_MODALITIES, _fn.DEFER_WGRAD = self.parallel_modalities, self.defer_wgrad
+            _fn.FLUSH_POINTS = self.defer_wgrad and self.flush_points and not self.split_step
             try:
                 yield
             finally:
-                _ms.PARALLEL_MODALITIES, _fn.DEFER_WGRAD = prev
+                _ms.PARALLEL_MODALITIES, _fn.DEFER_WGRAD, _fn.FLUSH_POINTS = prev
         return scope()
 
     def _fwd_bwd(self, x, target, flush=True):
@@ -129,6 +131,7 @@ class TrainEngine:
             loss.backward()                                         #                              train.py:200
             if flush:
                 _fn.flush_wgrad()                                   # queued linear weight gradients, grouped launches
+                _fn.join_wgrad_stream()                             # (stage-boundary flushes ran on a side stream)
         return loss.detach()
 
     def _adam(self, grad_scale):

@@ -81,6 +81,57 @@ def _ln_defer(on):
     return _DEFERRED_LN if (on and DEFER_WGRAD) else None
 
 
+# Flush points (engine mode, single GPU): an identity node at every stage boundary whose BACKWARD launches the weight
+# gradients queued so far on a side stream, so they run under the rest of the backward chain (which is latency-bound, not
+# throughput-bound, since the blocks were fused) instead of in a tail after it.  join_wgrad_stream() re-joins before Adam.
+FLUSH_POINTS = False
+_WSIDE = {}
+_WSIDE_USED = set()
+
+
+def _wgrad_stream(device):
+    st = _WSIDE.get(device)
+    if st is None:
+        st = _WSIDE[device] = torch.cuda.Stream(device=device)
+    return st
+
+
+def flush_wgrad_side():
+    """Launch everything queued so far on the weight-gradient side stream (ordered after the current stream's work)."""
+    if not (_DEFERRED or _DEFERRED_LN):
+        return
+    dev = (_DEFERRED[0][0] if _DEFERRED else _DEFERRED_LN[0][0]).device
+    main, side = torch.cuda.current_stream(dev), _wgrad_stream(dev)
+    side.wait_stream(main)
+    for it in _DEFERRED:                    # the queue's references die at the flush: tell the allocator who still reads them
+        for t in (it[0], it[1], it[4]):
+            if t is not None:
+                t.record_stream(side)
+    for it in _DEFERRED_LN:
+        it[0].record_stream(side)
+    with torch.cuda.stream(side):
+        flush_wgrad()
+    _WSIDE_USED.add(dev)
+
+
+def join_wgrad_stream():
+    for dev in list(_WSIDE_USED):
+        torch.cuda.current_stream(dev).wait_stream(_wgrad_stream(dev))
+    _WSIDE_USED.clear()
+
+
+class FlushPointFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, xa):
+        return x.view_as(x), xa.view_as(xa)
+
+    @staticmethod
+    def backward(ctx, dx, dxa):
+        if FLUSH_POINTS and DEFER_WGRAD:
+            flush_wgrad_side()
+        return dx, dxa
+
+
 @_in_block
 def flush_wgrad():
     """Launch every queued weight gradient on the current stream (which must be ordered after their producers)."""

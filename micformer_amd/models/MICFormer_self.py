@@ -405,6 +405,8 @@ class BasicLayer(nn.Module):
         return x, xa
 
     def forward(self, x, xa):
+        if Fn.FLUSH_POINTS and x.requires_grad:
+            x, xa = Fn.FlushPointFn.apply(x, xa)       # backward: launch this stage's queued weight gradients on a side stream
         if self._pair_fusable(x, xa):
             x, xa = self._forward_pairs(x, xa)
             resample = getattr(self, self._resample_attr)

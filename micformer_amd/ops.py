@@ -22,6 +22,10 @@ def compute_dtype():
     return _COMPUTE_DTYPE
 
 
+def _dt():
+    return 1 if _COMPUTE_DTYPE == "bf16" else 0
+
+
 def set_compute_dtype(name):
     global _COMPUTE_DTYPE
     if name not in ("fp32", "bf16"):
@@ -107,7 +111,7 @@ def linear_fwd(a1, w, bias, a2=None, resid=None, dp_scale=None, rows_per_sample=
     y = _new(a1, M, N)
     pre = _new(a1, M, N) if want_pre else None
     call("micf_linear_fwd", f32(a1), f32(a2), k1, f32(w), f32(bias), f32(resid), f32(dp_scale), rows_per_sample,
-         f32(y), f32(pre), M, N, K, act,
+         f32(y), f32(pre), M, N, K, act, _dt(),
          cost=_cost(2 * M * N * K, a1, a2, w, resid, y, pre, tag=f'{M}x{N}x{K}'))
     return (y, pre) if want_pre else y
 
@@ -123,7 +127,7 @@ def linear_bwd_data(dy, w, dp_scale=None, rows_per_sample=0, pre_act=None, k1=No
         da1 = _new(dy, M, k1)
         da2 = _new(dy, M, K - k1) if k1 < K else None
     call("micf_linear_bwd_data", f32(dy), f32(dp_scale), rows_per_sample, f32(w), f32(pre_act), f32(da1), f32(da2), k1,
-         1 if accumulate else 0, M, N, K,
+         1 if accumulate else 0, M, N, K, _dt(),
          cost=_cost(2 * M * N * K, dy, w, pre_act, da1, da2, tag=f'{M}x{N}x{K}'))
     return (da1, da2) if da2 is not None else da1
 
@@ -150,7 +154,7 @@ def linear_bwd_weight(dy, a1, dw, dbias, a2=None, dp_scale=None, rows_per_sample
     need = _lib.lib.micf_linear_bwd_weight_workspace(M, N, K)
     ws = scratch(dy.device, need) if need > 0 else None
     call("micf_linear_bwd_weight", f32(dy), f32(dp_scale), rows_per_sample, f32(a1), f32(a2), k1, 1 if a_gelu else 0,
-         f32(dw), f32(dbias), M, N, K, f32(ws), ws.numel() if ws is not None else 0,
+         f32(dw), f32(dbias), M, N, K, f32(ws), ws.numel() if ws is not None else 0, _dt(),
          cost=_cost(2 * M * N * K, dy, a1, a2, dw, tag=f'{M}x{N}x{K}'))
 
 
@@ -200,7 +204,7 @@ class GroupedWgradPlan:
         cost = None
         if _lib.PROFILE is not None:
             cost = (sum(self.nbytes[first:first + count]), sum(self.flops[first:first + count])) + ((f"{count}",) if DETAIL else ())
-        call("micf_linear_bwd_weight_grouped", ptr_, count, f32(ws), ws.numel() if ws is not None else 0, cost=cost)
+        call("micf_linear_bwd_weight_grouped", ptr_, count, f32(ws), ws.numel() if ws is not None else 0, _dt(), cost=cost)
 
 
 def linear_bwd_weight_grouped(items):
@@ -267,7 +271,7 @@ def conv3_fwd(x1, w, bias, dims, x2=None, ncdhw_out=False):
     need = 0 if ncdhw_out else _lib.lib.micf_conv3_fwd_workspace(N, c1, c2)
     ws = scratch(x1.device, need) if need > 0 else None
     call("micf_conv3_fwd", f32(x1), c1, f32(x2), c2, f32(w), f32(bias), f32(y), 1 if ncdhw_out else 0, B, D, H, W, N,
-         f32(ws), ws.numel() if ws is not None else 0,
+         f32(ws), ws.numel() if ws is not None else 0, _dt(),
          cost=_cost(2 * B * D * H * W * 27 * (c1 + c2) * N, x1, x2, w, y))
     return y
 
@@ -283,7 +287,7 @@ def conv3_bwd_data(dy, w, dims, c1, c2=0, ncdhw=False, dx1=None, dx2=None, acc1=
     need = 0 if ncdhw else _lib.lib.micf_conv3_bwd_data_workspace(N, c1, c2)
     ws = scratch(dy.device, need) if need > 0 else None
     call("micf_conv3_bwd_data", f32(dy), 1 if ncdhw else 0, f32(w), f32(dx1), c1, 1 if acc1 else 0, f32(dx2), c2,
-         1 if acc2 else 0, B, D, H, W, N, f32(ws), ws.numel() if ws is not None else 0,
+         1 if acc2 else 0, B, D, H, W, N, f32(ws), ws.numel() if ws is not None else 0, _dt(),
          cost=_cost(2 * T * 27 * (c1 + c2) * N, dy, w, dx1, dx2))
     return dx1, dx2
 
@@ -296,7 +300,7 @@ def conv3_bwd_weight(dy, x1, dw, dbias, dims, x2=None, ncdhw=False):
     need = 0 if ncdhw else _lib.lib.micf_conv3_bwd_weight_workspace(B, D, H, W, N, c1, c2)
     ws = scratch(dy.device, need) if need > 0 else None
     call("micf_conv3_bwd_weight", f32(dy), 1 if ncdhw else 0, f32(x1), c1, f32(x2), c2, f32(dw), f32(dbias), B, D, H, W, N,
-         f32(ws), ws.numel() if ws is not None else 0,
+         f32(ws), ws.numel() if ws is not None else 0, _dt(),
          cost=_cost(2 * B * D * H * W * 27 * (c1 + c2) * N, dy, x1, x2, dw))
 
 
@@ -602,7 +606,7 @@ def block_fwd(groups, dims, C, heads, eps, scale):
         nb += 4 * (T * C * (9 if o["xn"] is not None else 8) + 2 * T * hidden + 12 * C * C)
         fl += 2 * T * 12 * C * C + 4 * T * C * 8
     call("micf_block_fwd", ctypes.cast(arr, ctypes.c_void_p), len(groups), B, D, H, W, C, heads, hidden, float(eps), float(scale),
-         _DT[_COMPUTE_DTYPE], cost=(nb, fl, f"{len(groups)}x{T}x{C}") if _lib.PROFILE is not None and DETAIL else ((nb, fl) if _lib.PROFILE is not None else None))
+         _dt(), cost=(nb, fl, f"{len(groups)}x{T}x{C}") if _lib.PROFILE is not None and DETAIL else ((nb, fl) if _lib.PROFILE is not None else None))
     return outs
 
 
@@ -639,7 +643,7 @@ def block_bwd(groups, dims, C, heads, scale):
         nb += 4 * (T * C * (11 if cross else 9) + 2 * T * hidden + 12 * C * C)
         fl += 2 * T * 12 * C * C + 8 * T * C * 8
     call("micf_block_bwd", ctypes.cast(arr, ctypes.c_void_p), len(groups), B, D, H, W, C, heads, hidden, float(scale),
-         _DT[_COMPUTE_DTYPE], cost=(nb, fl, f"{len(groups)}x{T}x{C}") if _lib.PROFILE is not None and DETAIL else ((nb, fl) if _lib.PROFILE is not None else None))
+         _dt(), cost=(nb, fl, f"{len(groups)}x{T}x{C}") if _lib.PROFILE is not None and DETAIL else ((nb, fl) if _lib.PROFILE is not None else None))
     del keep
     return outs
 

@@ -229,6 +229,49 @@ def test_base_64_forward_backward_against_reference(M):
         close(sd[n].grad, g[key], atol=1e-9, rtol=3e-3, what=key)
 
 
+def test_base_128_config2_against_reference(M):
+    """BASELINE config 2's network AND size (base, one 128^3 pair) against the reference's own CPU run (f7): logits, argmax mask,
+    loss, meandice and the norm of every parameter's loss gradient."""
+    from micformer_amd import MDiceLoss, ops
+    g = load("f7_base128.npz")
+    ref_gn = json.load(open(os.path.join(G, "f7_base128_gradnorms.json")))
+    h = build_head(M, 48, (2, 2, 6, 2))
+    x = fill.make_volume(1, 128, 128, 128).cuda()
+    lab = fill.make_label_map(1, 128, 128, 128)
+    logits = h(x)
+    close(logits[:, :, ::8, ::8, ::8], g["logits_stride"], atol=1e-4, what="base128 logits")
+    loss = MDiceLoss()(logits, fill.one_hot(lab).cuda())
+    close(loss, g["loss"], atol=1e-5, what="base128 loss")
+    mask, md = ops.argmax_meandice(logits.detach(), lab.to(torch.uint8).cuda())
+    bad = (mask.cpu().long() != g["mask"].long())[:, ::2, ::2, ::2] & (g["margin_stride"].float() > 1e-3)
+    assert int(bad.sum()) == 0, "argmax differs where the reference's top-2 margin > 1e-3"
+    assert abs(float(md.item()) - float(g["meandice"])) <= 1e-3
+    loss.backward()
+    wrong = []
+    for n, p in h.named_parameters():
+        r = ref_gn[n]
+        if r == "none":
+            if p.grad is not None:
+                wrong.append((n, "grad present"))
+        else:
+            v = float(p.grad.double().norm())
+            if not abs(v - r) <= 2e-3 * r + 1e-10:
+                wrong.append((n, v, r))
+    assert not wrong, f"{len(wrong)} grad norms off, e.g. {wrong[:4]}"
+
+
+def test_large_160_config4_against_reference(M):
+    """BASELINE config 4's network and size: large Head(96) on one 160 x 160 x 128 pair, forward, against the reference (f8)."""
+    g = load("f8_large160.npz")
+    h = build_head(M, 96, (2, 2, 6, 2))
+    x = fill.make_volume(1, 160, 160, 128).cuda()
+    with torch.no_grad():
+        logits = h(x)
+    close(logits[:, :, ::8, ::8, ::8], g["logits_stride"], atol=1e-4, what="large160 logits")
+    bad = (logits.argmax(1).cpu() != g["mask"].long())[:, ::2, ::2, ::2] & (g["margin_stride"].float() > 1e-3)
+    assert int(bad.sum()) == 0
+
+
 def test_noncubic_pad_and_odd_resize_against_reference(M):
     from micformer_amd import MDiceLoss
     h = build_head(M, 24, (1, 1, 1, 1))

@@ -39,11 +39,14 @@ def main():
     ap.add_argument("--dtype", default="fp32")
     ap.add_argument("--cross", action="store_true")
     ap.add_argument("--fused-only", action="store_true")
+    ap.add_argument("--stage", type=int, default=-1, help="only this stage (0..3)")
     args = ap.parse_args()
     from micformer_amd import ops
     import test_gpu_block_fused as tb
     B = 2
-    for (n, C, heads) in ((32, 48, 3), (16, 96, 6), (8, 192, 12), (4, 384, 24)):
+    for si, (n, C, heads) in enumerate(((32, 48, 3), (16, 96, 6), (8, 192, 12), (4, 384, 24))):
+        if args.stage >= 0 and si != args.stage:
+            continue
         dims = (B, n, n, n)
         T = B * n ** 3
         if ops.block_tile_tokens(dims, C, heads, 4 * C) == 0:

@@ -132,7 +132,9 @@ def main(argv=None):
     ap.add_argument("--batch", type=int, default=2, help="local batch (pairs per GPU)")
     ap.add_argument("--vol", type=int, default=128)
     ap.add_argument("--embed-dim", type=int, default=48)
-    ap.add_argument("--dtype", choices=("fp32", "bf16"), default=None, help="matrix-core arithmetic (default: the library's)")
+    ap.add_argument("--dtype", choices=("fp32", "bf16"), default="bf16",
+                    help="matrix-core arithmetic: bf16 (BASELINE config 2; bf16 MFMA operands, fp32 accumulate / storage, passes the "
+                         "SURVEY 8(c) gates of tests/test_gpu_bf16.py) or fp32 (exact, the parity mode)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")

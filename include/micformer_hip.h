@@ -223,6 +223,24 @@ int micf_sw_window(const float* vol, float* win, int C, int D, int H, int W, int
 int micf_sw_accumulate(const float* pred, float* out, float* count, int K, int D, int H, int W, int rd, int rh, int rw, int z0,
                        int y0, int x0, micf_stream_t stream);
 int micf_sw_normalize(float* out, const float* count, int K, int64_t V, micf_stream_t stream);
+/* Batched forms: crop `n` <= 64 windows of vol [B,C,D,H,W] into win [n,C,rd,rh,rw] / accumulate `n`
+ * predictions [n,K,rd,rh,rw] into out [B,K,D,H,W] and count [B,D,H,W] in ONE launch each.  coords: HOST int32 [n,4] = (b, z0, y0,
+ * x0), read during the call.  Windows of a batch may overlap (fp32 atomic adds). */
+int micf_sw_window_batch(const float* vol, float* win, const int32_t* coords, int n, int B, int C, int D, int H, int W, int rd,
+                         int rh, int rw, micf_stream_t stream);
+int micf_sw_accumulate_batch(const float* pred, float* out, float* count, const int32_t* coords, int n, int B, int K, int D, int H,
+                             int W, int rd, int rh, int rw, micf_stream_t stream);
+
+/* ---- Input-pipeline tail on the device (train.py:116-125 MONAI dict transforms, in their order: RandFlipd x3 on image + label,
+ * NormalizeIntensityd(nonzero=True, channel_wise=True), RandScaleIntensityd(0.1), RandShiftIntensityd(0.1)) and the loader's
+ * float16 -> float32 cast (MMWHS.py:386, train.py:177).  vol [B,Cm,D,H,W] fp32 or fp16 (is_half); label map uint8 [B,D,H,W].
+ * micf_intensity_stats: sums [B*Cm*3] doubles = {sum, sum of squares, count} over the NON-ZERO voxels of each channel.
+ * micf_input_prepare: out = ((raw[flip] - mean) / std where raw != 0, else 0) * (1 + f) + o, label_out = label_in[flip];
+ * params [B,5] = {flip D, flip H, flip W (0/1), f, o} on the device, or NULL (validation: normalise only).
+ * (Normalising before or after the flips is the same: the statistics are permutation-invariant.) */
+int micf_intensity_stats(const void* vol, int is_half, double* sums, int B, int Cm, int64_t V, micf_stream_t stream);
+int micf_input_prepare(const void* vol, int is_half, const double* sums, const float* params, float* out, const uint8_t* label_in,
+                       uint8_t* label_out, int B, int Cm, int D, int H, int W, micf_stream_t stream);
 
 /* ---- zero-pad / crop of channels-last volumes (F.pad to window multiples MS.py:349-350,483; crop MS.py:399-400,497-498) */
 int micf_pad3d(const float* src, float* dst, int B, int D, int H, int W, int Dp, int Hp, int Wp, int C,
@@ -252,6 +270,12 @@ int micf_dice_bce_label_bwd(const float* logits, const uint8_t* label, const dou
  * counts [3*K] int64 scratch (zero-filled by the call); label is the integer class map [B,V] (uint8); out [1] double. */
 int micf_argmax_meandice(const float* logits, const uint8_t* label, uint8_t* mask_out, int64_t* counts, double* out,
                          int B, int K, int64_t V, micf_stream_t stream);
+
+/* MDiceLoss(_Val).metric (dice.py:168-175, 223-230): per (sample, class) Dice of the thresholded prediction sigmoid(z) > 0.5
+ * against the target plane -- one-hot float planes [B,K,V] (target_is_label = 0) or the uint8 class map [B,V] (1); an empty
+ * target plane scores 1 if the prediction is empty too, else 0.  sums [B*K*3] doubles is scratch; out [B*K] floats. */
+int micf_dice_metric(const float* logits, const void* target, int target_is_label, double* sums, float* out, int B, int K,
+                     int64_t V, micf_stream_t stream);
 
 /* ---- torch.optim.Adam(lr, betas, eps, weight_decay=0) over a flat fp32 buffer + CosineAnnealingLR stepped per
  * iteration (train.py:114,148,206-207).  state = {int64 step; double lr} on the device so a captured graph advances:

@@ -70,6 +70,11 @@ SIGNATURES = {
     "micf_transpose_grouped": "pip",
     "micf_block_fwd": "piiiiiiiiffip",
     "micf_block_bwd": "piiiiiiiifip",
+    "micf_dice_metric": "ppippiilp",
+    "micf_sw_window_batch": "pppiiiiiiiiip",
+    "micf_sw_accumulate_batch": "ppppiiiiiiiiip",
+    "micf_intensity_stats": "pipiilp",
+    "micf_input_prepare": "pipppppiiiiip",
     "micf_zero": "plp",
     "micf_drop_path_draw": "pppiip",
 }

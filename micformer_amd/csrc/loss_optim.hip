@@ -107,6 +107,41 @@ __global__ void meandice_final_kernel(const unsigned long long* __restrict__ cou
   *out = s / (K - 1);
 }
 
+// ---- MDiceLoss(_Val).metric (dice.py:168-175 / 223-230, binary_dice metric_mode): per (sample, class) plane the Dice of the
+// thresholded prediction sigmoid(z) > 0.5 (i.e. z > 0): 2 sum(p t) / (sum p + sum t); 1 / 0 when the target plane is empty and
+// the prediction is / is not.
+template <bool LABEL>
+__global__ void __launch_bounds__(256) dice_metric_partial_kernel(const float* __restrict__ z, const void* __restrict__ tv,
+                                                                  double* __restrict__ sums, int K, int64_t V, int chunks) {
+  const int plane = blockIdx.y, ch = plane % K;
+  const int64_t per = (V + chunks - 1) / chunks;
+  const int64_t v0 = blockIdx.x * per, v1 = (v0 + per < V) ? v0 + per : V;
+  const float* zp = z + (int64_t)plane * V;
+  const float* tp = static_cast<const float*>(tv) + (int64_t)plane * V;
+  const uint8_t* lp8 = static_cast<const uint8_t*>(tv) + (int64_t)(plane / K) * V;
+  float a = 0.f, b = 0.f, c = 0.f;                      // sum p t, sum p, sum t
+  for (int64_t i = v0 + threadIdx.x; i < v1; i += 256) {
+    const float p = zp[i] > 0.f ? 1.f : 0.f;
+    const float tt = LABEL ? (lp8[i] == ch ? 1.f : 0.f) : tp[i];
+    a += p * tt; b += p; c += tt;
+  }
+  a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+  __shared__ float part[4][3];
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { part[wave][0] = a; part[wave][1] = b; part[wave][2] = c; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int q = threadIdx.x;
+    atomicAdd(sums + plane * 3 + q, (double)part[0][q] + (double)part[1][q] + (double)part[2][q] + (double)part[3][q]);
+  }
+}
+__global__ void dice_metric_final_kernel(const double* __restrict__ sums, float* __restrict__ out, int planes) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= planes) return;
+  const double I = sums[i * 3], P = sums[i * 3 + 1], T = sums[i * 3 + 2];
+  out[i] = T == 0.0 ? (P == 0.0 ? 1.f : 0.f) : (float)((2.0 * I) / (P + T));
+}
+
 // ---- Adam
 struct AdamState { long long step; double lr; };
 
@@ -221,5 +256,18 @@ extern "C" int micf_adam_step(float* p, const float* g, float* m, float* v, int6
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(adam_step_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, (const AdamState*)state,
                      beta1, beta2, eps, grad_scale);
+  MICF_RETURN_LAUNCH();
+}
+
+extern "C" int micf_dice_metric(const float* logits, const void* target, int target_is_label, double* sums, float* out, int B, int K,
+                                int64_t V, micf_stream_t stream) {
+  if (!logits || !target || !sums || !out || B <= 0 || K <= 0 || V <= 0) return MICF_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(sums, 0, sizeof(double) * 3 * B * K, s) != hipSuccess) return MICF_ELAUNCH;
+  int chunks = (int)((V + 65535) / 65536);
+  if (chunks > 256) chunks = 256;
+  if (target_is_label) hipLaunchKernelGGL(micf::dice_metric_partial_kernel<true>, dim3(chunks, B * K), dim3(256), 0, s, logits, target, sums, K, V, chunks);
+  else hipLaunchKernelGGL(micf::dice_metric_partial_kernel<false>, dim3(chunks, B * K), dim3(256), 0, s, logits, target, sums, K, V, chunks);
+  hipLaunchKernelGGL(micf::dice_metric_final_kernel, dim3((B * K + 63) / 64), dim3(64), 0, s, sums, out, B * K);
   MICF_RETURN_LAUNCH();
 }

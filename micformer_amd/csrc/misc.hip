@@ -1,6 +1,8 @@
 // misc.hip -- ABI bookkeeping + the layout helpers of the block wrappers: zero-pad / crop to window multiples
 // (F.pad MS.py:349-350, 483; crop MS.py:399-400, 497-498) and the trilinear align_corners=True resize of the decoder's
 // odd-size branch (F.interpolate MS.py:1018-1025) with its adjoint.
+#include <hip/hip_fp16.h>
+
 #include "common.h"
 
 namespace micf {
@@ -247,4 +249,150 @@ extern "C" int micf_transpose_grouped(const micf_transpose_item* items, int n, m
     if (hipGetLastError() != hipSuccess) return MICF_ELAUNCH;
   }
   return MICF_OK;
+}
+
+// ---- sliding-window inference, batched: one launch crops `n` windows, one launch accumulates `n` predictions (windows of a
+// batch may overlap: fp32 atomics; the sum over <= 8 visits is order-independent to an ulp)
+namespace micf {
+constexpr int kSwMax = 64;
+struct SwCoords { int n; int b[kSwMax], z[kSwMax], y[kSwMax], x[kSwMax]; };
+__global__ void __launch_bounds__(256) sw_window_batch_kernel(const float* __restrict__ vol, float* __restrict__ win, SwCoords c, int C,
+                                                              int D, int H, int W, int rd, int rh, int rw, int64_t per) {
+  const int n = blockIdx.y;
+  const float* v = vol + (int64_t)c.b[n] * C * D * H * W;
+  float* o = win + (int64_t)n * per;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (int64_t)gridDim.x * 256) {
+    const int x = (int)(i % rw); int64_t r = i / rw;
+    const int y = (int)(r % rh); r /= rh;
+    const int z = (int)(r % rd); const int ch = (int)(r / rd);
+    o[i] = v[(((int64_t)ch * D + c.z[n] + z) * H + c.y[n] + y) * W + c.x[n] + x];
+  }
+}
+__global__ void __launch_bounds__(256) sw_accumulate_batch_kernel(const float* __restrict__ pred, float* __restrict__ out,
+                                                                  float* __restrict__ count, SwCoords c, int K, int D, int H, int W,
+                                                                  int rd, int rh, int rw, int64_t per) {
+  const int n = blockIdx.y;
+  const float* p = pred + (int64_t)n * per;
+  float* o = out + (int64_t)c.b[n] * K * D * H * W;
+  float* cn = count + (int64_t)c.b[n] * D * H * W;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (int64_t)gridDim.x * 256) {
+    const int x = (int)(i % rw); int64_t r = i / rw;
+    const int y = (int)(r % rh); r /= rh;
+    const int z = (int)(r % rd); const int k = (int)(r / rd);
+    const int64_t v = ((int64_t)(c.z[n] + z) * H + c.y[n] + y) * W + c.x[n] + x;
+    atomicAdd(o + (int64_t)k * D * H * W + v, p[i]);
+    if (k == 0) atomicAdd(cn + v, 1.f);
+  }
+}
+static bool sw_coords(SwCoords& c, const int32_t* coords, int n, int B, int D, int H, int W, int rd, int rh, int rw) {
+  if (!coords || n <= 0 || n > kSwMax) return false;
+  c.n = n;
+  for (int i = 0; i < n; ++i) {
+    c.b[i] = coords[4 * i]; c.z[i] = coords[4 * i + 1]; c.y[i] = coords[4 * i + 2]; c.x[i] = coords[4 * i + 3];
+    if (c.b[i] < 0 || c.b[i] >= B || c.z[i] < 0 || c.y[i] < 0 || c.x[i] < 0 || c.z[i] + rd > D || c.y[i] + rh > H || c.x[i] + rw > W) return false;
+  }
+  return true;
+}
+}  // namespace micf
+
+extern "C" int micf_sw_window_batch(const float* vol, float* win, const int32_t* coords, int n, int B, int C, int D, int H, int W,
+                                    int rd, int rh, int rw, micf_stream_t stream) {
+  micf::SwCoords c;
+  if (!vol || !win || C <= 0 || rd <= 0 || rh <= 0 || rw <= 0 || !micf::sw_coords(c, coords, n, B, D, H, W, rd, rh, rw)) return MICF_EINVAL;
+  const int64_t per = (int64_t)C * rd * rh * rw;
+  hipLaunchKernelGGL(micf::sw_window_batch_kernel, dim3(grid_for(per) > 2048 ? 2048 : grid_for(per), n), dim3(256), 0, (hipStream_t)stream,
+                     vol, win, c, C, D, H, W, rd, rh, rw, per);
+  MICF_RETURN_LAUNCH();
+}
+extern "C" int micf_sw_accumulate_batch(const float* pred, float* out, float* count, const int32_t* coords, int n, int B, int K, int D,
+                                        int H, int W, int rd, int rh, int rw, micf_stream_t stream) {
+  micf::SwCoords c;
+  if (!pred || !out || !count || K <= 0 || rd <= 0 || rh <= 0 || rw <= 0 || !micf::sw_coords(c, coords, n, B, D, H, W, rd, rh, rw))
+    return MICF_EINVAL;
+  const int64_t per = (int64_t)K * rd * rh * rw;
+  hipLaunchKernelGGL(micf::sw_accumulate_batch_kernel, dim3(grid_for(per) > 2048 ? 2048 : grid_for(per), n), dim3(256), 0,
+                     (hipStream_t)stream, pred, out, count, c, K, D, H, W, rd, rh, rw, per);
+  MICF_RETURN_LAUNCH();
+}
+
+// ---- input-pipeline tail (train.py:116-125: RandFlipd x3 on image + label, NormalizeIntensityd(nonzero, channel_wise),
+// RandScaleIntensityd(0.1), RandShiftIntensityd(0.1)) and the float16 -> float32 cast of the loader (MMWHS.py:386, train.py:177)
+namespace micf {
+template <class T> __device__ __forceinline__ float ldv(const T* p, int64_t i);
+template <> __device__ __forceinline__ float ldv<float>(const float* p, int64_t i) { return p[i]; }
+template <> __device__ __forceinline__ float ldv<__half>(const __half* p, int64_t i) { return __half2float(p[i]); }
+
+// sums[(b*Cm + m)*3 + {0,1,2}] = {sum, sum of squares, count} of the NON-ZERO voxels of channel m of sample b (doubles)
+template <class T>
+__global__ void __launch_bounds__(256) intensity_stats_kernel(const T* __restrict__ vol, double* __restrict__ sums, int64_t V, int chunks) {
+  const int plane = blockIdx.y;
+  const int64_t per = (V + chunks - 1) / chunks;
+  const int64_t v0 = blockIdx.x * per, v1 = (v0 + per < V) ? v0 + per : V;
+  const T* p = vol + (int64_t)plane * V;
+  float a = 0.f, b = 0.f, c = 0.f;
+  for (int64_t i = v0 + threadIdx.x; i < v1; i += 256) {
+    const float x = ldv<T>(p, i);
+    if (x != 0.f) { a += x; b += x * x; c += 1.f; }
+  }
+  a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+  __shared__ float part[4][3];
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { part[wave][0] = a; part[wave][1] = b; part[wave][2] = c; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int q = threadIdx.x;
+    atomicAdd(sums + plane * 3 + q, (double)part[0][q] + (double)part[1][q] + (double)part[2][q] + (double)part[3][q]);
+  }
+}
+// out[b, m, d, h, w] = ((raw[flip(d,h,w)] - mean)/std if raw != 0 else 0) * (1 + f_b) + o_b ; label_out = label_in[flip]
+// params [B, 5] = {flipD, flipH, flipW (0 / 1), scale factor f, shift offset o}; params == NULL: no flips, f = o = 0 (validation)
+template <class T>
+__global__ void __launch_bounds__(256) input_prepare_kernel(const T* __restrict__ vol, const double* __restrict__ sums,
+                                                            const float* __restrict__ params, float* __restrict__ out,
+                                                            const uint8_t* __restrict__ lab_in, uint8_t* __restrict__ lab_out, int Cm, int D,
+                                                            int H, int W) {
+  const int b = blockIdx.y;
+  const int64_t V = (int64_t)D * H * W;
+  int fd = 0, fh = 0, fw = 0;
+  float f = 0.f, o = 0.f;
+  if (params) { fd = params[b * 5] != 0.f; fh = params[b * 5 + 1] != 0.f; fw = params[b * 5 + 2] != 0.f; f = params[b * 5 + 3]; o = params[b * 5 + 4]; }
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < V; i += (int64_t)gridDim.x * 256) {
+    const int w = (int)(i % W); int64_t r = i / W;
+    const int h = (int)(r % H); const int d = (int)(r / H);
+    const int64_t src = ((int64_t)(fd ? D - 1 - d : d) * H + (fh ? H - 1 - h : h)) * W + (fw ? W - 1 - w : w);
+    for (int m = 0; m < Cm; ++m) {
+      const double* sp = sums + ((int64_t)b * Cm + m) * 3;
+      const double n = sp[2];
+      const double mean = n > 0 ? sp[0] / n : 0.0;
+      double var = n > 0 ? sp[1] / n - mean * mean : 0.0;
+      if (var < 0) var = 0;
+      double sd = sqrt(var);
+      if (sd == 0.0) sd = 1.0;                                  // MONAI: a constant image is only shifted
+      const float x = ldv<T>(vol, ((int64_t)b * Cm + m) * V + src);
+      float y = x != 0.f ? (float)(((double)x - mean) / sd) : 0.f;
+      out[((int64_t)b * Cm + m) * V + i] = y * (1.f + f) + o;
+    }
+    if (lab_in) lab_out[(int64_t)b * V + i] = lab_in[(int64_t)b * V + src];
+  }
+}
+}  // namespace micf
+
+extern "C" int micf_intensity_stats(const void* vol, int is_half, double* sums, int B, int Cm, int64_t V, micf_stream_t stream) {
+  if (!vol || !sums || B <= 0 || Cm <= 0 || V <= 0) return MICF_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(sums, 0, sizeof(double) * 3 * B * Cm, s) != hipSuccess) return MICF_ELAUNCH;
+  int chunks = (int)((V + 65535) / 65536);
+  if (chunks > 256) chunks = 256;
+  if (is_half) hipLaunchKernelGGL(micf::intensity_stats_kernel<__half>, dim3(chunks, B * Cm), dim3(256), 0, s, static_cast<const __half*>(vol), sums, V, chunks);
+  else hipLaunchKernelGGL(micf::intensity_stats_kernel<float>, dim3(chunks, B * Cm), dim3(256), 0, s, static_cast<const float*>(vol), sums, V, chunks);
+  MICF_RETURN_LAUNCH();
+}
+extern "C" int micf_input_prepare(const void* vol, int is_half, const double* sums, const float* params, float* out,
+                                  const uint8_t* label_in, uint8_t* label_out, int B, int Cm, int D, int H, int W, micf_stream_t stream) {
+  if (!vol || !sums || !out || B <= 0 || Cm <= 0 || D <= 0 || H <= 0 || W <= 0 || (label_in && !label_out)) return MICF_EINVAL;
+  const int64_t V = (int64_t)D * H * W;
+  const dim3 grid(grid_for(V) > 1024 ? 1024 : grid_for(V), B);
+  if (is_half) hipLaunchKernelGGL(micf::input_prepare_kernel<__half>, grid, dim3(256), 0, (hipStream_t)stream, static_cast<const __half*>(vol), sums, params, out, label_in, label_out, Cm, D, H, W);
+  else hipLaunchKernelGGL(micf::input_prepare_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, static_cast<const float*>(vol), sums, params, out, label_in, label_out, Cm, D, H, W);
+  MICF_RETURN_LAUNCH();
 }

@@ -35,7 +35,8 @@ class GraphedPredictor:
         self.predictor, self.warmup, self.graphs = predictor, warmup, {}
 
     def __call__(self, x):
-        key = (tuple(x.shape), x.dtype)
+        from . import ops
+        key = (tuple(x.shape), x.dtype, ops.compute_dtype())     # the arithmetic mode is baked into a captured graph
         entry = self.graphs.get(key)
         if entry is None:
             static_in = x.clone()
@@ -55,9 +56,12 @@ class GraphedPredictor:
         return static_out
 
 
-def sliding_window_inference(inputs, roi_size, sw_batch_size, predictor, overlap=0.5, mode="constant", *, graph=False):
+def sliding_window_inference(inputs, roi_size, sw_batch_size, predictor, overlap=0.5, mode="constant", *, graph=False,
+                             autocast=False):
     """inputs (B, C, D, H, W) on the GPU -> (B, K, D, H, W) fp32, K = the predictor's output channels.
-    graph=True wraps the predictor in a GraphedPredictor (pass your own instance as `predictor` to reuse it across volumes)."""
+    graph=True wraps the predictor in a GraphedPredictor (pass your own instance as `predictor` to reuse it across volumes).
+    autocast=True runs the predictor with bf16 matrix-core operands -- this library's counterpart of the
+    `torch.cuda.amp.autocast()` the reference wraps the call in (utils.py:236-238; fp16 there)."""
     if graph and not isinstance(predictor, GraphedPredictor):
         predictor = GraphedPredictor(predictor)
     if mode != "constant":
@@ -76,23 +80,29 @@ def sliding_window_inference(inputs, roi_size, sw_batch_size, predictor, overlap
     V = Dp * Hp * Wp
     slices = [(b, z, y, xx) for z in sliding_window_starts(Dp, rd, overlap) for y in sliding_window_starts(Hp, rh, overlap)
               for xx in sliding_window_starts(Wp, rw, overlap) for b in range(B)]
-    sw = max(int(sw_batch_size), 1)
+    sw = min(max(int(sw_batch_size), 1), 64)
     out = count = None
+    from . import ops
     with torch.no_grad():
         for i in range(0, len(slices), sw):
             chunk = slices[i:i + sw]
-            win = torch.empty((len(chunk), C, rd, rh, rw), dtype=torch.float32, device=x.device)
-            for n, (b, z, y, xx) in enumerate(chunk):
-                call("micf_sw_window", f32(x[b]), f32(win[n]), C, Dp, Hp, Wp, rd, rh, rw, z, y, xx)
-            pred = predictor(win).float().contiguous()
+            win = ops.sw_window_batch(x, chunk, (rd, rh, rw))                 # ONE launch crops the whole batch of windows
+            if autocast:
+                prev = ops.compute_dtype()
+                ops.set_compute_dtype("bf16")
+                try:
+                    pred = predictor(win).float().contiguous()
+                finally:
+                    ops.set_compute_dtype(prev)
+            else:
+                pred = predictor(win).float().contiguous()
             if pred.shape[0] != len(chunk) or tuple(pred.shape[2:]) != (rd, rh, rw):
                 raise ValueError(f"predictor returned {tuple(pred.shape)} for windows {tuple(win.shape)}")
             if out is None:
                 K = pred.shape[1]
-                out = torch.zeros((B, K, Dp, Hp, Wp), dtype=torch.float32, device=x.device)
-                count = torch.zeros((B, Dp, Hp, Wp), dtype=torch.float32, device=x.device)
-            for n, (b, z, y, xx) in enumerate(chunk):
-                call("micf_sw_accumulate", f32(pred[n]), f32(out[b]), f32(count[b]), K, Dp, Hp, Wp, rd, rh, rw, z, y, xx)
+                out = ops.zero_(torch.empty((B, K, Dp, Hp, Wp), dtype=torch.float32, device=x.device))
+                count = ops.zero_(torch.empty((B, Dp, Hp, Wp), dtype=torch.float32, device=x.device))
+            ops.sw_accumulate_batch(pred, out, count, chunk)                  # ONE launch adds it into the volume accumulator
         for b in range(B):
             call("micf_sw_normalize", f32(out[b]), f32(count[b]), K, V)
     if pd or ph or pw:

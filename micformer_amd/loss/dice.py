@@ -32,19 +32,11 @@ class MDiceLoss(nn.Module):
         return Fn.DiceBCEFn.apply(inputs.float(), _as_target(inputs, target))
 
     def metric(self, inputs, target):
-        """Thresholded-sigmoid per-class Dice per sample (dice.py:168-175, binary_dice metric_mode)."""
-        p = inputs > 0            # sigmoid(z) > 0.5
-        out = []
-        for j in range(target.size(0)):
-            row = []
-            for i in range(target.size(1)):
-                t = target[j, i]
-                if t.sum() == 0:
-                    row.append(torch.tensor(1. if p[j, i].sum() == 0 else 0., device=inputs.device))
-                else:
-                    row.append((2 * (p[j, i] * t).sum()) / ((p[j, i].sum() + t.sum()) * 1.0))
-            out.append(row)
-        return out
+        """Thresholded-sigmoid per-class Dice per sample (dice.py:168-175, binary_dice metric_mode): ONE device reduction
+        (micf_dice_metric), returned in the reference's list-of-lists-of-0-d-tensors form (views of one [B, K] tensor, no host sync).
+        The reference also prints "No <label> for this patient" for empty target planes; that message is not reproduced."""
+        m = ops.dice_metric(inputs.float().contiguous(), _as_target(inputs, target).contiguous())
+        return [[m[j, i] for i in range(m.shape[1])] for j in range(m.shape[0])]
 
 
 class MDiceLoss_Val(MDiceLoss):

@@ -519,6 +519,20 @@ def argmax_meandice(logits, label=None, want_mask=True):
     return mask, out
 
 
+def dice_metric(logits, target):
+    """MDiceLoss(_Val).metric on the device: [B, K] thresholded-sigmoid Dice per (sample, class); target = one-hot float planes
+    [B, K, ...] or a uint8 class map [B, ...]."""
+    B, K = logits.shape[:2]
+    V = logits[0, 0].numel()
+    sums = _new(logits, B * K * 3, dtype=torch.float64)
+    out = _new(logits, B, K)
+    is_label = target.dtype == torch.uint8
+    if not is_label and target.dtype != torch.float32:
+        raise TypeError("target must be float32 one-hot planes or a uint8 class map")
+    call("micf_dice_metric", f32(logits), ptr(target), 1 if is_label else 0, ptr(sums), f32(out), B, K, V)
+    return out
+
+
 def adam_state(device):
     """{int64 step; double lr} on the device, zero-initialised (16 bytes)."""
     return torch.zeros(2, dtype=torch.int64, device=device)
@@ -646,6 +660,50 @@ def block_bwd(groups, dims, C, heads, scale):
          _dt(), cost=(nb, fl, f"{len(groups)}x{T}x{C}") if _lib.PROFILE is not None and DETAIL else ((nb, fl) if _lib.PROFILE is not None else None))
     del keep
     return outs
+
+
+# ----------------------------------------------------------------------------- sliding window (batched) / input pipeline
+def _coords(chunk):
+    arr = (ctypes.c_int32 * (4 * len(chunk)))()
+    for i, (b, z, y, x) in enumerate(chunk):
+        arr[4 * i:4 * i + 4] = [b, z, y, x]
+    return arr
+
+
+def sw_window_batch(vol, chunk, roi):
+    """vol [B, C, D, H, W]; chunk: list of (b, z0, y0, x0) -> [n, C, rd, rh, rw] crops, ONE launch."""
+    B, C, D, H, W = vol.shape
+    rd, rh, rw = roi
+    win = _new(vol, len(chunk), C, rd, rh, rw)
+    arr = _coords(chunk)
+    call("micf_sw_window_batch", f32(vol), f32(win), ctypes.cast(arr, ctypes.c_void_p), len(chunk), B, C, D, H, W, rd, rh, rw)
+    return win
+
+
+def sw_accumulate_batch(pred, out, count, chunk):
+    """pred [n, K, rd, rh, rw] added into out [B, K, D, H, W] at the windows of `chunk`, count [B, D, H, W] += 1 there; ONE launch."""
+    B, K, D, H, W = out.shape
+    rd, rh, rw = pred.shape[2:]
+    arr = _coords(chunk)
+    call("micf_sw_accumulate_batch", f32(pred), f32(out), f32(count), ctypes.cast(arr, ctypes.c_void_p), len(chunk), B, K, D, H, W,
+         rd, rh, rw)
+
+
+def input_prepare(vol, label_map=None, params=None):
+    """Input-pipeline tail on the device.  vol [B, Cm, D, H, W] float16 / float32 raw intensities, label_map uint8 [B, D, H, W] or
+    None, params [B, 5] float32 {flip D, flip H, flip W, scale f, shift o} or None (validation).  -> (float32 volume, label map)."""
+    B, Cm, D, H, W = vol.shape
+    if vol.dtype not in (torch.float16, torch.float32):
+        raise TypeError("raw volume must be float16 or float32")
+    half = 1 if vol.dtype == torch.float16 else 0
+    sums = torch.empty(B * Cm * 3, dtype=torch.float64, device=vol.device)
+    call("micf_intensity_stats", ptr(vol), half, ptr(sums), B, Cm, D * H * W)
+    out = torch.empty((B, Cm, D, H, W), dtype=torch.float32, device=vol.device)
+    lab_out = torch.empty_like(label_map) if label_map is not None else None
+    if label_map is not None and label_map.dtype != torch.uint8:
+        raise TypeError("label map must be uint8")
+    call("micf_input_prepare", ptr(vol), half, ptr(sums), f32(params), f32(out), ptr(label_map), ptr(lab_out), B, Cm, D, H, W)
+    return out, lab_out
 
 
 # ----------------------------------------------------------------------------- step plumbing

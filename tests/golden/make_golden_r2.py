@@ -20,11 +20,39 @@ import make_golden as G  # noqa: E402
 from oracle import fill  # noqa: E402
 
 
+def metric_fixture(dice):
+    """f9_metric.npz: MDiceLoss_Val().metric (dice.py:223-230) on lattice logits.  The reference's empty-target branch builds its
+    return value with device="cuda" (dice.py:139-141), which cannot run in this GPU-less container: those planes are NOT called
+    through the reference; the fixture marks them (empty_target) and stores the value that branch returns by inspection."""
+    z = fill.lattice((2, 8, 6, 5, 7), "F9.z", 3.0, 0.77)
+    lab = fill.make_label_map(2, 6, 5, 7)
+    lab[0][lab[0] == 5] = 0                 # class 5 absent in sample 0 (prediction non-empty -> 0)
+    lab[1][lab[1] == 6] = 0                 # class 6 absent in sample 1 ...
+    z[1, 6] = -z[1, 6].abs() - 0.1          # ... and never predicted -> 1
+    t = fill.one_hot(lab)
+    crit = dice.MDiceLoss_Val()
+    out = np.zeros((2, 8), np.float32)
+    empty = np.zeros((2, 8), np.uint8)
+    for j in range(2):
+        for i in range(8):
+            if float(t[j, i].sum()) == 0:
+                empty[j, i] = 1
+                out[j, i] = 1.0 if int((torch.sigmoid(z[j, i]) > 0.5).sum()) == 0 else 0.0
+            else:
+                out[j, i] = float(crit.binary_dice(z[j, i], t[j, i], i, True))
+    assert empty[0, 5] and empty[1, 6] and out[0, 5] == 0.0 and out[1, 6] == 1.0 and empty.sum() < 8
+    G.save("f9_metric.npz", z=G.np32(z), label=lab.numpy().astype(np.uint8), metric=out, empty_target=empty)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     MS, dice = G.import_reference()
     crit = dice.MDiceLoss()
+    if "--metric-only" in sys.argv:
+        metric_fixture(dice)
+        return
+    metric_fixture(dice)
 
     print("F7 base 128^3 (forward + backward)")
     base = MS.Head(embed_dim=48, num_classes=8).eval()

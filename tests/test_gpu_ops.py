@@ -3,6 +3,7 @@ same op, on seeded inputs, forward and backward.  Tolerance: fp32 kernels vs fp3
 tensor's max (atomically accumulated weight gradients: 2e-4 of max).  Run on the GPU box: pytest -m gpu.
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -13,6 +14,8 @@ pytestmark = pytest.mark.gpu
 
 from oracle import fill  # noqa: E402
 from oracle import micformer_ref as R  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
 @pytest.fixture(scope="module")
@@ -492,3 +495,41 @@ def test_adam_against_oracle(ops):
     close(P, pp, atol=1e-7, rtol=0, what="adam p")
     close(M, mm, atol=1e-9, rtol=1e-5, what="adam m")
     close(V, vv, atol=1e-12, rtol=1e-5, what="adam v")
+
+
+def test_dice_metric_kernel(ops):
+    """micf_dice_metric against the reference fixture (f9) and the oracle, float one-hot and uint8 class-map targets."""
+    g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLD, "f9_metric.npz")).items()}
+    z, lab = g["z"].cuda(), g["label"]
+    m1 = ops.dice_metric(z, fill.one_hot(lab.long()).cuda())
+    m2 = ops.dice_metric(z, lab.cuda())
+    assert float((m1.cpu() - g["metric"]).abs().max()) < 1e-6 and float((m2.cpu() - g["metric"]).abs().max()) < 1e-6
+    from micformer_amd.loss.dice import MDiceLoss_Val
+    lst = MDiceLoss_Val().metric(z, fill.one_hot(lab.long()).cuda())
+    assert len(lst) == 2 and len(lst[0]) == 8 and abs(float(lst[1][6]) - 1.0) < 1e-7
+    zz = torch.randn(2, 8, 20, 24, 28, generator=torch.Generator().manual_seed(4))
+    ll = torch.randint(0, 8, (2, 20, 24, 28), generator=torch.Generator().manual_seed(5), dtype=torch.uint8)
+    want = R.dice_metric(zz, fill.one_hot(ll.long()))
+    assert float((ops.dice_metric(zz.cuda(), ll.cuda()).cpu() - want).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize("half", [True, False])
+def test_input_pipeline_tail_kernel(ops, half):
+    """micf_intensity_stats + micf_input_prepare against the oracle's restatement of train.py:116-125."""
+    g = torch.Generator().manual_seed(11)
+    B, D, H, W = 2, 12, 10, 14
+    img = torch.randn(B, 2, D, H, W, generator=g) * 40 + 100
+    img[:, :, :3] = 0
+    img = img.half() if half else img
+    lab = torch.randint(0, 8, (B, D, H, W), generator=g, dtype=torch.uint8)
+    params = torch.tensor([[1, 0, 1, 0.07, -0.03], [0, 1, 0, -0.05, 0.09]], dtype=torch.float32)
+    x, l = ops.input_prepare(img.cuda(), lab.cuda(), params.cuda())
+    for b in range(B):
+        flips = tuple(bool(v) for v in params[b, :3])
+        wx, wl = R.input_pipeline_tail(img[b], lab[b].long(), flips, float(params[b, 3]), float(params[b, 4]))
+        assert float((x[b].cpu() - wx).abs().max()) < (2e-3 if half else 2e-5)
+        assert torch.equal(l[b].cpu().long(), wl)
+    xv, lv = ops.input_prepare(img.cuda(), None, None)          # validation transform: normalise only
+    assert lv is None
+    wv = torch.stack([R.normalize_intensity_nonzero(img[b]) for b in range(B)])
+    assert float((xv.cpu() - wv).abs().max()) < (2e-3 if half else 2e-5)

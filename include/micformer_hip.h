@@ -150,14 +150,26 @@ int micf_window_attn_bwd(const float* q, int ldq, const float* k, const float* v
  * and Head.out_conv (MS.py:1046,1053).  w [N, c1+c2, 3,3,3].  y_layout 0: channels-last [T,N]; 1: NCDHW. */
 int micf_conv3_fwd(const float* x1, int c1, const float* x2, int c2, const float* w, const float* bias, float* y,
                    int y_layout, int B, int D, int H, int W, int N, float* workspace, int64_t workspace_floats,
-                   int dtype, micf_stream_t stream);
+                   int prepared, int dtype, micf_stream_t stream);
 /* scratch (floats) that enables the direct forward kernel for channels-last outputs with N <= 16 (0 = not applicable) */
 int64_t micf_conv3_fwd_workspace(int N, int c1, int c2);
 /* workspace (optional scratch, micf_conv3_bwd_data_workspace floats): enables the direct data-gradient kernel for
  * channels-last dy with N <= 16 (the weights are re-laid out as [tap][c][16 n] there by the same call). */
 int micf_conv3_bwd_data(const float* dy, int dy_layout, const float* w, float* dx1, int c1, int acc1, float* dx2,
                         int c2, int acc2, int B, int D, int H, int W, int N, float* workspace, int64_t workspace_floats,
-                        int dtype, micf_stream_t stream);
+                        int prepared, int dtype, micf_stream_t stream);
+/* `prepared` != 0 in the two calls above: `workspace` is not scratch but already holds the re-laid-out copy of w that the
+ * direct kernel streams (fwd / bwd of micf_conv3_weight_prep_grouped below), so the call skips its own re-layout launch.
+ * The weights of a training step only change in the optimiser: one grouped launch per step prepares all of them.
+ * fwd: micf_conv3_fwd_workspace(N, Cin, 0) floats; bwd: micf_conv3_bwd_data_workspace(N, Cin, 0) floats; either may be NULL.
+ * `items` is HOST memory, read during the call only. */
+typedef struct micf_conv3_prep_item {
+  const float* w; /* [N, Cin, 3, 3, 3], N <= 16 */
+  float* fwd;
+  float* bwd;
+  int32_t N, Cin;
+} micf_conv3_prep_item;
+int micf_conv3_weight_prep_grouped(const micf_conv3_prep_item* items, int n, micf_stream_t stream);
 int64_t micf_conv3_bwd_data_workspace(int N, int c1, int c2);
 /* workspace (optional scratch, micf_conv3_bwd_weight_workspace floats; 0 = not used for this shape): enables the
  * register-resident MFMA weight-gradient kernel for channels-last dy with N == 16. */
@@ -296,7 +308,9 @@ int micf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, cons
 typedef struct micf_block_fwd_group {
   const float* x;      /* [T, C] block input (residual stream), T = B*D*H*W tokens in natural order */
   const float* kvsrc;  /* cross: [T, C] deformably sampled raw other modality (K/V source, never normed); NULL = self attention */
-  const float *ln1_g, *ln1_b, *wq, *bq, *wkv, *bkv, *wp, *bp, *ln2_g, *ln2_b, *w1, *b1, *w2, *b2; /* state_dict layout */
+  const float *ln1_g, *ln1_b, *bq, *bkv, *bp, *ln2_g, *ln2_b, *b1, *b2; /* state_dict layout */
+  const void *wq, *wkv, *wp, *w1, *w2; /* the five weight matrices, state_dict layout [out, in]: float for MICF_DTYPE_F32; bf16
+                                          (uint16_t) shadow copies made by micf_weight_prep_grouped for MICF_DTYPE_BF16 */
   const float *s1, *s2; /* DropPath scales [B] of the two residual branches (NULL = 1) */
   float* y;            /* [T, C] block output */
   /* saved for backward / the deferred weight gradients, natural token order: */
@@ -308,8 +322,9 @@ typedef struct micf_block_bwd_group {
   const float* dy;     /* [T, C] gradient w.r.t. the block output (also fc2's output gradient for the weight-gradient GEMM) */
   const float *x, *x1, *stats, *q, *kv, *h; /* as saved by micf_block_fwd (x and ln1_g may be NULL for a cross block) */
   const float *ln1_g, *ln2_g;
-  const float *wqt, *wkvt, *wpt, *w1t, *w2t; /* TRANSPOSED weights: q^T [C,C], kv^T [C,2C], proj^T [C,C], fc1^T [C,hidden],
-                                                fc2^T [hidden,C] (micf_transpose_grouped) */
+  const void *wqt, *wkvt, *wpt, *w1t, *w2t;  /* TRANSPOSED weights: q^T [C,C], kv^T [C,2C], proj^T [C,C], fc1^T [C,hidden],
+                                                fc2^T [hidden,C] from micf_weight_prep_grouped (dst_t): float for MICF_DTYPE_F32,
+                                                bf16 for MICF_DTYPE_BF16 */
   const float *s1, *s2;
   float* dx;           /* self: [T, C] gradient w.r.t. the block input.  cross: the q path's PRE-LayerNorm gradient dq Wq (the
                           caller adds the offset-conv path and applies LN1 backward with add = dx1) */
@@ -321,14 +336,17 @@ typedef struct micf_block_bwd_group {
                           K/V-source gradient and its own LN1 backward into (no zero fill, no separate add) */
 } micf_block_bwd_group;
 int micf_block_tile_tokens(int B, int D, int H, int W, int C, int heads, int hidden, int backward);
-/* dst[c, r] = src[r, c] for a list of row-major matrices in one launch per 64 items (the block weights' transposes the fused
- * backward streams; refreshed once per step).  `items` is HOST memory, read during the call only. */
-typedef struct micf_transpose_item {
+/* Per-step weight preparation for the fused block kernels: for each row-major fp32 matrix of a list (one launch per 64 items,
+ * one read of the source) write dst = src and / or dst_t = src^T, as float (bf16 = 0) or as bf16 bit patterns in uint16_t,
+ * round-to-nearest-even (bf16 = 1).  fp32 mode needs dst_t only (micf_block_bwd streams W^T); bf16 mode needs both
+ * (micf_block_fwd streams bf16 W, micf_block_bwd bf16 W^T).  `items` is HOST memory, read during the call only. */
+typedef struct micf_weight_prep_item {
   const float* src; /* [rows, cols] */
-  float* dst;       /* [cols, rows] */
-  int32_t rows, cols;
-} micf_transpose_item;
-int micf_transpose_grouped(const micf_transpose_item* items, int n, micf_stream_t stream);
+  void* dst;        /* [rows, cols] or NULL */
+  void* dst_t;      /* [cols, rows] or NULL */
+  int32_t rows, cols, bf16, reserved;
+} micf_weight_prep_item;
+int micf_weight_prep_grouped(const micf_weight_prep_item* items, int n, micf_stream_t stream);
 /* `groups` is HOST memory, read during the call only. */
 int micf_block_fwd(const micf_block_fwd_group* groups, int ngroups, int B, int D, int H, int W, int C, int heads,
                    int hidden, float eps, float scale, int dtype, micf_stream_t stream);

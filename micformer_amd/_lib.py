@@ -36,9 +36,10 @@ SIGNATURES = {
     "micf_sw_normalize": "ppilp",
     "micf_window_attn_fwd": "pippipiiiiiiiiiifp",
     "micf_window_attn_bwd": "pippipipippiiiiiiiiiifp",
-    "micf_conv3_fwd": "pipipppiiiiiiplip",
+    "micf_conv3_fwd": "pipipppiiiiiipliip",
     "micf_conv3_fwd_workspace": "iii",
-    "micf_conv3_bwd_data": "pippiipiiiiiiiplip",
+    "micf_conv3_bwd_data": "pippiipiiiiiiipliip",
+    "micf_conv3_weight_prep_grouped": "pip",
     "micf_conv3_bwd_data_workspace": "iii",
     "micf_conv3_bwd_weight": "pipipippiiiiiplip",
     "micf_conv3_bwd_weight_workspace": "iiiiiii",
@@ -67,7 +68,7 @@ SIGNATURES = {
     "micf_adam_tick": "pddlp",
     "micf_adam_step": "pppplpffffp",
     "micf_block_tile_tokens": "iiiiiiii",
-    "micf_transpose_grouped": "pip",
+    "micf_weight_prep_grouped": "pip",
     "micf_block_fwd": "piiiiiiiiffip",
     "micf_block_bwd": "piiiiiiiifip",
     "micf_dice_metric": "ppippiilp",
@@ -98,7 +99,7 @@ _VP = ctypes.c_void_p
 
 class BlockFwdGroup(ctypes.Structure):
     """struct micf_block_fwd_group (include/micformer_hip.h)."""
-    FIELDS = ("x", "kvsrc", "ln1_g", "ln1_b", "wq", "bq", "wkv", "bkv", "wp", "bp", "ln2_g", "ln2_b", "w1", "b1", "w2", "b2",
+    FIELDS = ("x", "kvsrc", "ln1_g", "ln1_b", "bq", "bkv", "bp", "ln2_g", "ln2_b", "b1", "b2", "wq", "wkv", "wp", "w1", "w2",
               "s1", "s2", "y", "xn", "q", "kv", "o", "x1", "xn2", "h", "g", "stats")
     _fields_ = [(n, _VP) for n in FIELDS]
 
@@ -110,9 +111,15 @@ class BlockBwdGroup(ctypes.Structure):
     _fields_ = [(n, _VP) for n in FIELDS]
 
 
-class TransposeItem(ctypes.Structure):
-    """struct micf_transpose_item (include/micformer_hip.h)."""
-    _fields_ = [("src", _VP), ("dst", _VP), ("rows", ctypes.c_int32), ("cols", ctypes.c_int32)]
+class WeightPrepItem(ctypes.Structure):
+    """struct micf_weight_prep_item (include/micformer_hip.h)."""
+    _fields_ = [("src", _VP), ("dst", _VP), ("dst_t", _VP), ("rows", ctypes.c_int32), ("cols", ctypes.c_int32),
+                ("bf16", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class Conv3PrepItem(ctypes.Structure):
+    """struct micf_conv3_prep_item (include/micformer_hip.h)."""
+    _fields_ = [("w", _VP), ("fwd", _VP), ("bwd", _VP), ("N", ctypes.c_int32), ("Cin", ctypes.c_int32)]
 
 
 class MicfError(RuntimeError):

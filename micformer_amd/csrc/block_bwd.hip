@@ -5,7 +5,7 @@
 //   dx1 = dy + LN2'(dh W1)                 -> HBM (proj weight gradient; the cross block's LN1 backward adds it)
 //   do  = s1 dx1 Wp ;  (dq, dk, dv) = attention'(q, k, v, do)   -> HBM dq, dkv (q / kv weight gradients)
 //   self : dx  = dx1 + LN1'(dq Wq + dkv Wkv)                 (all "dY W" products read the TRANSPOSED weights W^T [K, N], which
-//                                                            micf_transpose_grouped refreshes once per step: contiguous rows)
+//                                                            micf_weight_prep_grouped refreshes once per step: contiguous rows)
 //   cross: dxq = dq Wq  (pre-LayerNorm; the offset-conv path adds its part before LN1')   and   dxs = dkv Wkv
 //
 // plus per-tile partial sums of the LayerNorm gain / bias gradients ([tiles][2C], summed by micf_layernorm_bwd_finish).
@@ -125,6 +125,9 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) block_bwd_kernel(con
   const micf_block_bwd_group& g = a.g[grp];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, rg = lane >> 4;
   const int64_t T = a.geo.T;
+  using WT = typename std::conditional<BF16, uint16_t, float>::type;      // bf16 mode streams bf16 shadow weights
+  const WT* wqt = static_cast<const WT*>(g.wqt), *wkvt = static_cast<const WT*>(g.wkvt), *wpt = static_cast<const WT*>(g.wpt),
+           *w1t = static_cast<const WT*>(g.w1t), *w2t = static_cast<const WT*>(g.w2t);
 
   if (tid < TM) {
     const int win = tile * (TM / 8) + (tid >> 3);
@@ -164,7 +167,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) block_bwd_kernel(con
         *reinterpret_cast<float4*>(U + row * SU + 4 * c4) = tk >= 0 ? ld4g(g.h + (int64_t)tk * Hd + c0 + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
-    gemm_phase<TJ, NSL, 1, C, NW, BF16>(g.w2t + (int64_t)c0 * C, hc, A1, nullptr, 0, nullptr, S, U, SU, EpiGeluGrad{sc2});
+    gemm_phase<TJ, NSL, 1, C, NW, BF16>(w2t + (int64_t)c0 * C, hc, A1, nullptr, 0, nullptr, S, U, SU, EpiGeluGrad{sc2});
 #pragma unroll 1
     for (int pass = 0; pass < NPASS; ++pass) {
       const int row = pass * RPP + wave * 4 + rg;
@@ -174,8 +177,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) block_bwd_kernel(con
       for (int c4 = l16; c4 < X4; c4 += 16)
         st4g(g.dh + (int64_t)tk * Hd + c0 + 4 * c4, *reinterpret_cast<const float4*>(U + row * SU + 4 * c4));
     }
-    if (c0 == 0) gemm_phase<TJ, NSL, 2, Hd, NW, BF16>(g.w1t + c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiStore{});
-    else gemm_phase<TJ, NSL, 2, Hd, NW, BF16>(g.w1t + c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiAcc{});
+    if (c0 == 0) gemm_phase<TJ, NSL, 2, Hd, NW, BF16>(w1t + c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiStore{});
+    else gemm_phase<TJ, NSL, 2, Hd, NW, BF16>(w1t + c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiAcc{});
   }
 
   // ---- dx1 = dy + LN2'(A2) -> A1 + HBM; LN2 gain / bias partials
@@ -183,7 +186,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) block_bwd_kernel(con
                        g.ln2_part ? g.ln2_part + (int64_t)tile * 2 * C : nullptr);
 
   // ---- do = s1 dx1 Wp -> A2;  q | k | v rows -> U
-  gemm_phase<TJ, NSL, 1, C, NW, BF16>(g.wpt, C, A1, nullptr, 0, nullptr, S, A2, S, EpiStoreScale{sc1});
+  gemm_phase<TJ, NSL, 1, C, NW, BF16>(wpt, C, A1, nullptr, 0, nullptr, S, A2, S, EpiStoreScale{sc1});
 #pragma unroll 1
   for (int pass = 0; pass < NPASS; ++pass) {
     const int row = pass * RPP + wave * 4 + rg;
@@ -306,13 +309,13 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) block_bwd_kernel(con
 
   if (!g.dxs) {
     // ---- self: dxn = dq Wq + dkv Wkv -> A2;  dx = dx1 + LN1'(dxn) -> HBM; LN1 partials
-    gemm_phase<TJ, NSL, 1, C, NW, BF16>(g.wqt, C, U, nullptr, 0, nullptr, SU, A2, S, EpiStore{});
-    gemm_phase<TJ, NSL, 2, 2 * C, NW, BF16>(g.wkvt, C, U + C, nullptr, 0, nullptr, SU, A2, S, EpiAcc{});
+    gemm_phase<TJ, NSL, 1, C, NW, BF16>(wqt, C, U, nullptr, 0, nullptr, SU, A2, S, EpiStore{});
+    gemm_phase<TJ, NSL, 2, 2 * C, NW, BF16>(wkvt, C, U + C, nullptr, 0, nullptr, SU, A2, S, EpiAcc{});
     ln_bwd_tile<TJ, VPL, NW>(A2, A1, S, C, g.x, g.stats, g.stats + T, g.ln1_g, tok, g.dx, nullptr, U,
                          g.ln1_part ? g.ln1_part + (int64_t)tile * 2 * C : nullptr);
   } else {
     // ---- cross: the q path's pre-LayerNorm gradient and the sampled K/V source's gradient leave separately
-    gemm_phase<TJ, NSL, 1, C, NW, BF16>(g.wqt, C, U, nullptr, 0, nullptr, SU, A2, S, EpiStore{});
+    gemm_phase<TJ, NSL, 1, C, NW, BF16>(wqt, C, U, nullptr, 0, nullptr, SU, A2, S, EpiStore{});
 #pragma unroll 1
     for (int pass = 0; pass < NPASS; ++pass) {
       const int row = pass * RPP + wave * 4 + rg;
@@ -322,7 +325,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) block_bwd_kernel(con
       for (int c4 = l16; c4 < C4; c4 += 16) st4g(g.dx + (int64_t)tk * C + 4 * c4, *reinterpret_cast<const float4*>(A2 + row * S + 4 * c4));
     }
     __syncthreads();
-    gemm_phase<TJ, NSL, 2, 2 * C, NW, BF16>(g.wkvt, C, U + C, nullptr, 0, nullptr, SU, A2, S, EpiStore{});
+    gemm_phase<TJ, NSL, 2, 2 * C, NW, BF16>(wkvt, C, U + C, nullptr, 0, nullptr, SU, A2, S, EpiStore{});
 #pragma unroll 1
     for (int pass = 0; pass < NPASS; ++pass) {
       const int row = pass * RPP + wave * 4 + rg;
@@ -378,6 +381,7 @@ extern "C" int micf_block_bwd(const micf_block_bwd_group* groups, int ngroups, i
   a.tiles = (a.geo.nwin + TM / 8 - 1) / (TM / 8);
   hipStream_t s = (hipStream_t)stream;
   const int hd = C / heads, tj = TM / 16;
+  if (block_wide_tile_tokens(C, hd)) return block_bwd_wide(groups, ngroups, B, D, H, W, C, heads, scale, dtype, s);
 #define MICF_BB(C_, HD_, TJ_) if (C == C_ && hd == HD_ && tj == TJ_) return launch_bwd<C_, HD_, TJ_>(a, dtype, s)
   MICF_BB(48, 16, 2); MICF_BB(48, 16, 1); MICF_BB(48, 16, 4); MICF_BB(96, 16, 1); MICF_BB(96, 16, 2); MICF_BB(192, 16, 1);
   MICF_BB(96, 32, 1); MICF_BB(192, 32, 1);

@@ -14,6 +14,7 @@
 // on operands rounded to bf16 at the fragment read (fp32 LDS tiles and weights, fp32 accumulation).
 #pragma once
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "gemm_dma.h"
@@ -68,7 +69,7 @@ struct EpiGeluGrad {          // rowscale[trow] * v * GELU'(what the tile holds:
 // over one or two weight SEGMENTS (x in [0, X0) from W0 against activation tile Bs0, x in [X0, X0 + X1) from W1 against Bs1;
 // X0, X1 multiples of 16, same R and leading dimension LD) -- q | kv in one phase although they are separate tensors:
 //   A(x, r) = W[x * LD + r]: rows of W are the outputs.  nn.Linear forward: W = the weight [N, K]; data gradients
-//   (dA = dY W): W = the TRANSPOSED weight [K, N] (micf_transpose_grouped, once per step), so both directions stream
+//   (dA = dY W): W = the TRANSPOSED weight [K, N] (micf_weight_prep_grouped, once per step), so both directions stream
 //   contiguous 64-byte row pieces.
 // The 16-wide x tiles are dealt round-robin to the NW waves of the workgroup.  Nothing about a tile's weights is shared between waves, so
 // they do not go through LDS at all: every lane loads ITS MFMA A-fragments straight from L2 / HBM into registers (one
@@ -82,7 +83,7 @@ struct EpiGeluGrad {          // rowscale[trow] * v * GELU'(what the tile holds:
 // tile Os.  Two accumulator chains per token group (even / odd k-steps) keep the fp32 MFMA pipe at its issue rate.
 // All 64 * NW threads call it together; on return Os is complete and visible to the workgroup.
 template <int TG, int NSL, int NK, int LD, int NW, bool BF16, class Epi>
-__device__ __forceinline__ void gemm_phase(const float* __restrict__ W0, int X0, const float* Bs0, const float* __restrict__ W1,
+__device__ __forceinline__ void gemm_phase_f32w(const float* __restrict__ W0, int X0, const float* Bs0, const float* __restrict__ W1,
                                            int X1, const float* Bs1, int SB, float* Os, int SO, const Epi epi) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lr = lane >> 4;
@@ -169,6 +170,92 @@ __device__ __forceinline__ void gemm_phase(const float* __restrict__ W0, int X0,
   __syncthreads();
 }
 
+// The same phase with bf16 WEIGHTS (shadow copies written once per step by micf_weight_prep_grouped: half the bytes and half
+// the load instructions of the weight stream, which is what bounds the small-token stages; no conversion on the A side).
+// MFMA 16x16x32: lane group lr supplies k = 8 lr .. 8 lr + 7 of every 32-deep chunk (the natural bf16 mapping): one 16-byte
+// load of 8 bf16 for the A fragment, two ds_read_b128 of fp32 activations (rounded to bf16, RNE) for B.  A chunk of K = 16 NSL
+// with NSL odd ends in a 16-deep half chunk: lane groups 2, 3 feed zeros on both sides.
+template <int TG, int NSL, int NK, int LD, int NW, class Epi>
+__device__ __forceinline__ void gemm_phase_bf16w(const uint16_t* __restrict__ W0, int X0, const float* Bs0, const uint16_t* __restrict__ W1,
+                                                 int X1, const float* Bs1, int SB, float* Os, int SO, const Epi epi) {
+  constexpr int N32 = NSL / 2, REM = NSL & 1, NF = N32 + REM;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lr = lane >> 4;
+  const int nt0 = X0 >> 4, ntiles = nt0 + (X1 >> 4);
+  const int mytiles = (ntiles - wave + NW - 1) / NW;
+  const int nunits = mytiles * NK;
+  const int lrh = lr & 1;                               // half chunk: lane groups 2, 3 re-read a valid address and drop the value
+
+  struct Frag { u32x4 v[NF]; };
+  auto load_unit = [&](int u, Frag& f) {
+    if (u > nunits - 1) u = nunits - 1;
+    const int tile = wave + NW * (NK == 1 ? u : u / NK), kc = NK == 1 ? 0 : u % NK;
+    const bool seg1 = tile >= nt0;
+    const uint16_t* Wb = seg1 ? W1 : W0;
+    const int xt = (seg1 ? tile - nt0 : tile) * 16;
+    const uint16_t* p = Wb + (int64_t)(xt + li) * LD + kc * NSL * 16;
+#pragma unroll
+    for (int j = 0; j < N32; ++j) f.v[j] = *reinterpret_cast<const u32x4*>(p + 32 * j + 8 * lr);
+    if constexpr (REM) f.v[N32] = *reinterpret_cast<const u32x4*>(p + 32 * N32 + 8 * lrh);
+  };
+
+  f32x4 acc[TG];
+#pragma unroll
+  for (int g = 0; g < TG; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto compute_unit = [&](int u, const Frag& f) {
+    const int tile = wave + NW * (NK == 1 ? u : u / NK), kc = NK == 1 ? 0 : u % NK;
+    const float* brow = ((tile >= nt0) ? Bs1 : Bs0) + li * SB + kc * NSL * 16;
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+      const bool half = REM && j == N32;
+      const int koff = 32 * j + 8 * (half ? lrh : lr);
+      bf16x8 ba = __builtin_bit_cast(bf16x8, f.v[j]);
+      if (half && lr >= 2) ba = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
+#pragma unroll
+      for (int g = 0; g < TG; ++g) {
+        const float* bp = brow + g * 16 * SB + koff;
+        float4 lo = *reinterpret_cast<const float4*>(bp), hi = *reinterpret_cast<const float4*>(bp + 4);
+        if (half && lr >= 2) { lo = make_float4(0.f, 0.f, 0.f, 0.f); hi = lo; }
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ba, to_bf16x8(lo, hi), acc[g], 0, 0, 0);
+      }
+    }
+    if (kc == NK - 1) {
+      const int x = tile * 16 + 4 * lr;
+#pragma unroll
+      for (int g = 0; g < TG; ++g) {
+        const int trow = 16 * g + li;
+        epi(Os + trow * SO + x, x, trow, make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]));
+        acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+
+  if (nunits > 0) {
+    Frag fa, fb;
+    load_unit(0, fa);
+    for (int u = 0; u < nunits; u += 2) {
+      load_unit(u + 1, fb);
+      compute_unit(u, fa);
+      load_unit(u + 2, fa);
+      if (u + 1 < nunits) compute_unit(u + 1, fb);
+    }
+  }
+  __syncthreads();
+}
+
+// dispatch on the weight type: float (exact fp32 MFMA) or uint16_t (bf16 shadow weights, bf16 MFMA)
+template <int TG, int NSL, int NK, int LD, int NW, bool BF16, class Epi>
+__device__ __forceinline__ void gemm_phase(const float* W0, int X0, const float* Bs0, const float* W1, int X1, const float* Bs1, int SB,
+                                           float* Os, int SO, const Epi epi) {
+  gemm_phase_f32w<TG, NSL, NK, LD, NW, false, Epi>(W0, X0, Bs0, W1, X1, Bs1, SB, Os, SO, epi);
+}
+template <int TG, int NSL, int NK, int LD, int NW, bool BF16, class Epi>
+__device__ __forceinline__ void gemm_phase(const uint16_t* W0, int X0, const float* Bs0, const uint16_t* W1, int X1, const float* Bs1,
+                                           int SB, float* Os, int SO, const Epi epi) {
+  gemm_phase_bf16w<TG, NSL, NK, LD, NW, Epi>(W0, X0, Bs0, W1, X1, Bs1, SB, Os, SO, epi);
+}
+
 // ---- tile geometry: TM = 16 * TJ tokens = TM / 8 whole 2x2x2 windows; rows are window-major (row = 8 * window + 4*id + 2*ih + iw)
 struct TileGeo {
   int B, D, H, W;                 // token grid (all even)
@@ -208,6 +295,12 @@ __device__ __forceinline__ float sum16(float v) {      // sum over the 16-lane g
   v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
   return v;
 }
+// block_wide.hip: the few-token decomposition of the same two entry points (several launches, GEMMs split over features)
+int block_wide_tile_tokens(int C, int hd);
+int block_fwd_wide(const micf_block_fwd_group* groups, int ngroups, int B, int D, int H, int W, int C, int heads, float eps, float scale,
+                   int dtype, hipStream_t s);
+int block_bwd_wide(const micf_block_bwd_group* groups, int ngroups, int B, int D, int H, int W, int C, int heads, float scale, int dtype,
+                   hipStream_t s);
 __device__ __forceinline__ float4 ld4g(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4g(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
 

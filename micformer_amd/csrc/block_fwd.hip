@@ -50,6 +50,9 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, rg = lane >> 4;
   const int64_t T = a.geo.T;
   const bool save = !(a.debug & 1), do_gelu = !(a.debug & 8);
+  using WT = typename std::conditional<BF16, uint16_t, float>::type;      // bf16 mode streams bf16 shadow weights
+  const WT* wq = static_cast<const WT*>(g.wq), *wkv = static_cast<const WT*>(g.wkv), *wp = static_cast<const WT*>(g.wp),
+           *w1 = static_cast<const WT*>(g.w1), *w2 = static_cast<const WT*>(g.w2);
 
   if (tid < TM) {
     const int win = tile * (TM / 8) + (tid >> 3);
@@ -139,7 +142,7 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
   // ---- q | k | v (+ bias) -> U, then out to HBM
   if (!(a.debug & 4)) {
     // q | k | v in ONE phase (two weight segments; the biases bq | bkv are contiguous in PV)
-    gemm_phase<TJ, NSL, 1, C, NW, BF16>(g.wq, C, A1, g.wkv, 2 * C, g.kvsrc ? A2 : A1, S, U, SU, EpiBias{p_bq});
+    gemm_phase<TJ, NSL, 1, C, NW, BF16>(wq, C, A1, wkv, 2 * C, g.kvsrc ? A2 : A1, S, U, SU, EpiBias{p_bq});
   }
   if (save) {
 #pragma unroll 1
@@ -211,7 +214,7 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
   __syncthreads();
 
   // ---- proj (+ bp) -> A2; x1 = x + s1 * proj -> A2 + HBM; LayerNorm 2 of the same registers -> A1 (xn2) + HBM
-  if (!(a.debug & 4)) gemm_phase<TJ, NSL, 1, C, NW, BF16>(g.wp, C, A1, nullptr, 0, nullptr, S, A2, S, EpiBias{p_bp});
+  if (!(a.debug & 4)) gemm_phase<TJ, NSL, 1, C, NW, BF16>(wp, C, A1, nullptr, 0, nullptr, S, A2, S, EpiBias{p_bp});
   {
     float4 v[NPASS][VPL];
 #pragma unroll
@@ -278,7 +281,7 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
   constexpr int HC = 2 * C;
   for (int c0 = 0; c0 < Hd; c0 += HC) {
     constexpr int hc = HC;
-    if (!(a.debug & 4)) gemm_phase<TJ, NSL, 1, C, NW, BF16>(g.w1 + (int64_t)c0 * C, hc, A1, nullptr, 0, nullptr, S, U, SU, EpiBias{p_b1 + c0});
+    if (!(a.debug & 4)) gemm_phase<TJ, NSL, 1, C, NW, BF16>(w1 + (int64_t)c0 * C, hc, A1, nullptr, 0, nullptr, S, U, SU, EpiBias{p_b1 + c0});
     const int X4 = hc >> 2;
 #pragma unroll 1
     for (int pass = 0; pass < NPASS; ++pass) {
@@ -297,7 +300,7 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
       }
     }
     __syncthreads();
-    if (!(a.debug & 4)) gemm_phase<TJ, NSL, 2, Hd, NW, BF16>(g.w2 + c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiAccScale{sc2});
+    if (!(a.debug & 4)) gemm_phase<TJ, NSL, 2, Hd, NW, BF16>(w2 + c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiAccScale{sc2});
   }
 
   // ---- y = x1 + s2 * (fc2 + b2)
@@ -344,10 +347,11 @@ extern "C" int micf_block_tile_tokens(int B, int D, int H, int W, int C, int hea
   if (C % heads || hidden != 4 * C) return 0;
   if ((int64_t)B * D * H * W >= (1LL << 31)) return 0;
   const int hd = C / heads;
+  if (const int wt = block_wide_tile_tokens(C, hd)) return wt;      // few-token stages: block_wide.hip
   // The kernels are compiled per channel count (C fixes every loop bound and load offset): the shapes of MicFormer base
-  // (C = 48 / 96 / 192, head_dim 16) and large (C = 96 / 192, head_dim 32).  C >= 384 is left to the per-op path on purpose:
-  // a tile streams the whole weight set of the block through one compute unit (7 MB at C = 384 for <= 1k tokens at the base
-  // model's 4^3 stage), where the per-op kernels spread every weight matrix over the chip.
+  // (C = 48 / 96 / 192, head_dim 16) and large (C = 96 / 192, head_dim 32).  C = 384 takes the few-token decomposition
+  // above: a tile would stream the whole weight set of the block through one compute unit (7 MB at C = 384 for <= 1k tokens
+  // at the base model's 4^3 stage); block_wide.hip spreads every weight matrix over the chip instead.
   // token groups of 16 per workgroup (measured on MI355X, base shapes, batch 2): forward and backward tile independently
   int tj = 0;
   if (C == 48 && hd == 16) tj = 2;
@@ -385,6 +389,7 @@ extern "C" int micf_block_fwd(const micf_block_fwd_group* groups, int ngroups, i
   a.debug = dbg ? atoi(dbg) : 0;
   hipStream_t s = (hipStream_t)stream;
   const int hd = C / heads, tj = TM / 16;
+  if (block_wide_tile_tokens(C, hd)) return block_fwd_wide(groups, ngroups, B, D, H, W, C, heads, eps, scale, dtype, s);
 #define MICF_BF(C_, HD_, TJ_) if (C == C_ && hd == HD_ && tj == TJ_) return launch_fwd<C_, HD_, TJ_>(a, dtype, s)
   MICF_BF(48, 16, 2); MICF_BF(48, 16, 1); MICF_BF(48, 16, 4); MICF_BF(96, 16, 1); MICF_BF(96, 16, 2); MICF_BF(192, 16, 1);
   MICF_BF(96, 32, 1); MICF_BF(192, 32, 1);

@@ -40,12 +40,12 @@ int colsum_atomic(const float* dy, const float* scale, int64_t rps, float* out, 
 
 // direct data gradient for N <= 16 channels-last dy (conv3_bwdx.hip); wt = 27*(c1+c2)*16 floats of scratch
 int conv3_bwd_data_x(const float* dy, const float* w, float* wt, float* dx1, int c1, int acc1, float* dx2, int c2, int acc2, int B,
-                     int D, int H, int W, int N, hipStream_t stream, int dtype = 0);
+                     int D, int H, int W, int N, hipStream_t stream, int dtype = 0, int prepared = 0);
 
 // direct forward for N <= 16 channels-last outputs (conv3_fwdx.hip); wt = conv3_fwdx_workspace floats of scratch
 int64_t conv3_fwdx_workspace(int N, int c1, int c2);
 int conv3_fwd_x(const float* x1, int c1, const float* x2, int c2, const float* w, const float* bias, float* y, float* wt, int B, int D,
-                int H, int W, int N, hipStream_t stream, int dtype = 0);
+                int H, int W, int N, hipStream_t stream, int dtype = 0, int prepared = 0);
 // MFMA weight gradient for 16 channels-last dy channels (conv3_wgradx.hip)
 int64_t conv3_wgradx_workspace(int B, int D, int H, int W, int N, int c1, int c2);
 int conv3_wgradx(const float* dy, const float* x1, int c1, const float* x2, int c2, float* dw, float* dbias, int B, int D, int H,

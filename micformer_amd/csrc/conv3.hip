@@ -201,13 +201,61 @@ static Conv3In make_in(const float* x1, int c1, const float* x2, int c2, const G
 
 extern "C" int64_t micf_conv3_fwd_workspace(int N, int c1, int c2) { return conv3_fwdx_workspace(N, c1, c2); }
 
+// ---- both re-laid-out copies of a list of few-output-channel conv weights in ONE launch (once per step: the weights only change
+// in Adam).  fwd = [chunk][tap][16 n][16 c] (conv3_fwdx.hip), bwd = [tap][c][16 n] (conv3_bwdx.hip).
+namespace micf {
+constexpr int kC3PrepMax = 64;
+struct C3PrepArgs { const float* w[kC3PrepMax]; float* fwd[kC3PrepMax]; float* bwd[kC3PrepMax]; int N[kC3PrepMax], Cin[kC3PrepMax]; };
+__global__ void __launch_bounds__(256) conv3_weight_prep_kernel(const C3PrepArgs a) {
+  const int k = blockIdx.y;
+  const float* __restrict__ w = a.w[k];
+  const int N = a.N[k], Cin = a.Cin[k], chunks = (Cin + 15) / 16;
+  const int64_t nf = a.fwd[k] ? (int64_t)chunks * 27 * 256 : 0, nb = a.bwd[k] ? (int64_t)27 * Cin * 16 : 0;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < nf + nb; id += (int64_t)gridDim.x * 256) {
+    if (id < nf) {
+      const int c = (int)(id & 15), n = (int)((id >> 4) & 15);
+      const int tap = (int)((id >> 8) % 27), chunk = (int)((id >> 8) / 27);
+      const int cc = chunk * 16 + c;
+      a.fwd[k][id] = (n < N && cc < Cin) ? w[((int64_t)n * Cin + cc) * 27 + tap] : 0.f;
+    } else {
+      const int64_t j = id - nf;
+      const int n = (int)(j & 15);
+      const int c = (int)((j >> 4) % Cin);
+      const int tap = (int)((j >> 4) / Cin);
+      a.bwd[k][j] = n < N ? w[((int64_t)n * Cin + c) * 27 + tap] : 0.f;
+    }
+  }
+}
+}  // namespace micf
+
+extern "C" int micf_conv3_weight_prep_grouped(const micf_conv3_prep_item* items, int n, micf_stream_t stream) {
+  if (n < 0 || (n > 0 && !items)) return MICF_EINVAL;
+  for (int first = 0; first < n; first += kC3PrepMax) {
+    const int cnt = (n - first < kC3PrepMax) ? n - first : kC3PrepMax;
+    C3PrepArgs a;
+    int64_t most = 0;
+    for (int k = 0; k < cnt; ++k) {
+      const micf_conv3_prep_item& it = items[first + k];
+      if (!it.w || (!it.fwd && !it.bwd) || it.N <= 0 || it.N > 16 || it.Cin <= 0) return MICF_EINVAL;
+      a.w[k] = it.w; a.fwd[k] = it.fwd; a.bwd[k] = it.bwd; a.N[k] = it.N; a.Cin[k] = it.Cin;
+      const int64_t tot = (int64_t)((it.Cin + 15) / 16) * 27 * 256 + (int64_t)27 * it.Cin * 16;
+      most = tot > most ? tot : most;
+    }
+    int bx = (int)((most + 255) / 256);
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(conv3_weight_prep_kernel, dim3(bx, cnt), dim3(256), 0, (hipStream_t)stream, a);
+    if (hipGetLastError() != hipSuccess) return MICF_ELAUNCH;
+  }
+  return MICF_OK;
+}
+
 extern "C" int micf_conv3_fwd(const float* x1, int c1, const float* x2, int c2, const float* w, const float* bias,
                               float* y, int y_layout, int B, int D, int H, int W, int N, float* workspace,
-                              int64_t workspace_floats, int dtype, micf_stream_t stream) {
+                              int64_t workspace_floats, int prepared, int dtype, micf_stream_t stream) {
   if (!x1 || !w || !y || (c2 > 0 && !x2) || !conv3_args_ok(B, D, H, W, N, c1, c2)) return MICF_EINVAL;
   if (y_layout == 0 && workspace && workspace_floats >= conv3_fwdx_workspace(N, c1, c2)) {
     // few output channels, channels-last: direct convolution with pre-transposed weights streamed from L2 (conv3_fwdx.hip)
-    const int rc = conv3_fwd_x(x1, c1, x2, c2, w, bias, y, workspace, B, D, H, W, N, (hipStream_t)stream, dtype);
+    const int rc = conv3_fwd_x(x1, c1, x2, c2, w, bias, y, workspace, B, D, H, W, N, (hipStream_t)stream, dtype, prepared);
     if (rc != MICF_EUNSUPPORTED) return rc;
   }
   if (y_layout == 0) {   // LDS-halo direct convolution on the matrix cores: measured faster than the implicit GEMM for the
@@ -242,11 +290,11 @@ extern "C" int64_t micf_conv3_bwd_data_workspace(int N, int c1, int c2) {
 
 extern "C" int micf_conv3_bwd_data(const float* dy, int dy_layout, const float* w, float* dx1, int c1, int acc1,
                                    float* dx2, int c2, int acc2, int B, int D, int H, int W, int N, float* workspace,
-                                   int64_t workspace_floats, int dtype, micf_stream_t stream) {
+                                   int64_t workspace_floats, int prepared, int dtype, micf_stream_t stream) {
   if (!dy || !w || (!dx1 && !dx2) || !conv3_args_ok(B, D, H, W, N, c1, c2)) return MICF_EINVAL;
   if (dy_layout == 0 && workspace && workspace_floats >= micf_conv3_bwd_data_workspace(N, c1, c2)) {
     // few dy channels, channels-last: direct convolution with pre-transposed weights (conv3_bwdx.hip)
-    const int rc = conv3_bwd_data_x(dy, w, workspace, dx1, c1, acc1, dx2, c2, acc2, B, D, H, W, N, (hipStream_t)stream, dtype);
+    const int rc = conv3_bwd_data_x(dy, w, workspace, dx1, c1, acc1, dx2, c2, acc2, B, D, H, W, N, (hipStream_t)stream, dtype, prepared);
     if (rc != MICF_EUNSUPPORTED) return rc;
   }
   const Geo g{B, D, H, W};

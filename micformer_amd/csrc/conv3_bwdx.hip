@@ -179,14 +179,16 @@ static hipError_t launch_bwdx(BwdxArgs& a, hipStream_t stream) {
 
 // MICF_EUNSUPPORTED when the shape is outside what this kernel covers (caller falls back to the implicit GEMM).
 int conv3_bwd_data_x(const float* dy, const float* w, float* wt, float* dx1, int c1, int acc1, float* dx2, int c2, int acc2, int B,
-                     int D, int H, int W, int N, hipStream_t stream, int dtype) {
+                     int D, int H, int W, int N, hipStream_t stream, int dtype, int prepared) {
   const int O = c1 + c2;
   if (N > 16 || (N & 3) || (O & 15) || (c1 & 3) || (c2 & 3) || W < 8 || !aligned16(dy) || !aligned16(wt) ||
       (dx1 && !aligned16(dx1)) || (dx2 && !aligned16(dx2)))
     return MICF_EUNSUPPORTED;
   const int64_t n = (int64_t)27 * O * 16;
-  hipLaunchKernelGGL(conv3_wt_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, wt, N, O);
-  if (hipGetLastError() != hipSuccess) return MICF_ELAUNCH;
+  if (!prepared) {
+    hipLaunchKernelGGL(conv3_wt_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, wt, N, O);
+    if (hipGetLastError() != hipSuccess) return MICF_ELAUNCH;
+  }
   BwdxArgs a{};
   a.dy = dy; a.N = N; a.wt = wt; a.d1 = dx1; a.d2 = dx2; a.oc1 = c1; a.oc2 = c2; a.acc1 = acc1; a.acc2 = acc2; a.O = O;
   a.B = B; a.D = D; a.H = H; a.W = W;

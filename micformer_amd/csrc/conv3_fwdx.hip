@@ -167,13 +167,15 @@ int64_t conv3_fwdx_workspace(int N, int c1, int c2) {
 
 // MICF_EUNSUPPORTED when the shape is outside what this kernel covers (caller falls back).
 int conv3_fwd_x(const float* x1, int c1, const float* x2, int c2, const float* w, const float* bias, float* y, float* wt, int B, int D,
-                int H, int W, int N, hipStream_t stream, int dtype) {
+                int H, int W, int N, hipStream_t stream, int dtype, int prepared) {
   if (N > 16 || (c1 & 3) || (c2 & 3) || W < 8 || !aligned16(x1) || (x2 && !aligned16(x2)) || !aligned16(y) || !aligned16(wt))
     return MICF_EUNSUPPORTED;
   const int Cin = c1 + c2, chunks = (Cin + 15) / 16;
   const int64_t nw = (int64_t)chunks * 27 * 256;
-  hipLaunchKernelGGL(conv3_wtf_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, w, wt, N, Cin, chunks);
-  if (hipGetLastError() != hipSuccess) return MICF_ELAUNCH;
+  if (!prepared) {      // (prepared: wt already holds this layout, written once per step by micf_conv3_weight_prep_grouped)
+    hipLaunchKernelGGL(conv3_wtf_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, w, wt, N, Cin, chunks);
+    if (hipGetLastError() != hipSuccess) return MICF_ELAUNCH;
+  }
   FwdxArgs a{};
   a.x1 = x1; a.x2 = x2 ? x2 : x1; a.c1 = c1; a.c2 = c2; a.wt = wt; a.bias = bias; a.y = y; a.N = N;
   a.B = B; a.D = D; a.H = H; a.W = W; a.chunks = chunks;

@@ -211,27 +211,38 @@ struct LnFinishArgs {
   int n;
   int end[kLnFinishMax];                                   // running total of workgroups (one per 256 columns of [2C])
   const float* partials[kLnFinishMax]; float* dgamma[kLnFinishMax]; float* dbeta[kLnFinishMax];
-  int blocks[kLnFinishMax]; int C[kLnFinishMax];
+  int blocks[kLnFinishMax]; int C[kLnFinishMax]; int nsplit[kLnFinishMax];
 };
 __global__ void __launch_bounds__(256) ln_finish_kernel(const LnFinishArgs a) {
   const int w = blockIdx.x;
   int k = 0;
   while (k < a.n - 1 && w >= a.end[k]) ++k;
   const int local = w - (k ? a.end[k - 1] : 0);
-  const int C = a.C[k], nb = a.blocks[k];
-  const int c = local * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;      // 64 columns x 4 slices of the block range
+  const int C = a.C[k], nb = a.blocks[k], nsplit = a.nsplit[k];
+  const int colblocks = (2 * C + 63) >> 6;
+  // 64 columns x 4 slices per workgroup; long partial lists (the fused block kernels write one row per 16-32 tokens) are
+  // split over `nsplit` workgroups, each row read by exactly one (workgroup, slice)
+  const int c = (local % colblocks) * 64 + (threadIdx.x & 63), slice = (local / colblocks) * 4 + (threadIdx.x >> 6);
+  const int stride = 4 * nsplit;
   __shared__ float red[256];
   float acc = 0.f;
   if (c < 2 * C) {
     const float* p = a.partials[k] + c;
-    for (int b = slice; b < nb; b += 4) acc += p[(int64_t)b * 2 * C];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int b = slice;
+    for (; b + 3 * stride < nb; b += 4 * stride) {           // four independent loads in flight
+      a0 += p[(int64_t)b * 2 * C]; a1 += p[(int64_t)(b + stride) * 2 * C];
+      a2 += p[(int64_t)(b + 2 * stride) * 2 * C]; a3 += p[(int64_t)(b + 3 * stride) * 2 * C];
+    }
+    for (; b < nb; b += stride) a0 += p[(int64_t)b * 2 * C];
+    acc = (a0 + a1) + (a2 + a3);
   }
   red[threadIdx.x] = acc;
   __syncthreads();
-  if (slice == 0 && c < 2 * C) {
+  if ((threadIdx.x >> 6) == 0 && c < 2 * C) {
     acc = red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192];
-    // atomic: modules shared by the two modalities (swin.norm, PatchMerging / PatchExpand norms) appear as two items with the
-    // same destination in one launch (2-way contention at most)
+    // atomic: the splits of one item, and modules shared by the two modalities (swin.norm, PatchMerging / PatchExpand norms)
+    // that appear as two items with the same destination in one launch
     if (c < C) { if (a.dgamma[k]) atomicAdd(a.dgamma[k] + c, acc); }
     else if (a.dbeta[k]) atomicAdd(a.dbeta[k] + (c - C), acc);
   }
@@ -302,7 +313,9 @@ extern "C" int micf_layernorm_bwd_finish(const micf_ln_finish_item* items, int n
       const micf_ln_finish_item& it = items[first + k];
       if (!it.partials || it.blocks <= 0 || it.C <= 0) return MICF_EINVAL;
       a.partials[k] = it.partials; a.dgamma[k] = it.dgamma; a.dbeta[k] = it.dbeta; a.blocks[k] = it.blocks; a.C[k] = it.C;
-      blocks += ceil_div(2 * it.C, 64);
+      int ns = it.blocks / 64;                              // >= 16 rows per slice before another split pays
+      a.nsplit[k] = ns < 1 ? 1 : (ns > 32 ? 32 : ns);
+      blocks += ceil_div(2 * it.C, 64) * a.nsplit[k];
       a.end[k] = blocks;
     }
     hipLaunchKernelGGL(ln_finish_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);

@@ -196,56 +196,95 @@ extern "C" int micf_drop_path_draw(void* rng, const float* keep, float* out, int
   MICF_RETURN_LAUNCH();
 }
 
-// ---- grouped transpose: dst[c][r] = src[r][c] for up to kTrMax matrices per launch (32 x 32 tiles through LDS)
+// ---- grouped weight preparation for the fused block kernels, refreshed once per step: per item ONE read of a row-major fp32
+// matrix writes a same-orientation copy and / or a transposed copy, in fp32 or bf16; up to kPrepMax matrices per launch,
+// 64 x 64 tiles through LDS, 16-byte global accesses when the shapes allow (all MicFormer weights: multiples of 16).
+// bf16 = round-to-nearest-even, the same rounding the bf16 GEMM kernels apply at fragment read.
 namespace micf {
-constexpr int kTrMax = 64;
-struct TrArgs {
+constexpr int kPrepMax = 64;
+struct PrepArgs {
   int n;
-  int end[kTrMax];                       // running total of 32 x 32 tiles
-  const float* src[kTrMax]; float* dst[kTrMax];
-  int rows[kTrMax], cols[kTrMax];
+  int end[kPrepMax];                       // running total of 64 x 64 tiles
+  const float* src[kPrepMax]; void* dst[kPrepMax]; void* dst_t[kPrepMax];
+  int rows[kPrepMax], cols[kPrepMax], bf16[kPrepMax];
 };
-__global__ void __launch_bounds__(256) transpose_grouped_kernel(const TrArgs a) {
-  __shared__ float t[32][33];
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {   // round-to-nearest-even, a in the low half (as gemm_dma.h)
+  unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+  ua += 0x7FFFu + ((ua >> 16) & 1u);
+  ub += 0x7FFFu + ((ub >> 16) & 1u);
+  return (ua >> 16) | (ub & 0xFFFF0000u);
+}
+__device__ __forceinline__ void prep_store4(void* base, int64_t idx, bool bf16, bool vec, int valid, float4 v) {
+  if (bf16) {
+    uint16_t* d = static_cast<uint16_t*>(base) + idx;
+    if (vec) { *reinterpret_cast<uint2*>(d) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w)); return; }
+    const float e[4] = {v.x, v.y, v.z, v.w};
+    for (int i = 0; i < valid; ++i) d[i] = (uint16_t)(pack_bf16(e[i], 0.f) & 0xFFFFu);
+  } else {
+    float* d = static_cast<float*>(base) + idx;
+    if (vec) { *reinterpret_cast<float4*>(d) = v; return; }
+    const float e[4] = {v.x, v.y, v.z, v.w};
+    for (int i = 0; i < valid; ++i) d[i] = e[i];
+  }
+}
+__global__ void __launch_bounds__(256) weight_prep_kernel(const PrepArgs a) {
+  __shared__ float t[64][65];
   const int w = blockIdx.x;
   int k = 0;
   while (k < a.n - 1 && w >= a.end[k]) ++k;
   const int local = w - (k ? a.end[k - 1] : 0);
   const int rows = a.rows[k], cols = a.cols[k];
-  const int tc = (cols + 31) >> 5;
-  const int r0 = (local / tc) * 32, c0 = (local % tc) * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+  const bool bf = a.bf16[k] != 0;
+  const int tc = (cols + 63) >> 6;
+  const int r0 = (local / tc) * 64, c0 = (local % tc) * 64;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;       // 16 float4 columns x 16 rows per pass
   const float* __restrict__ src = a.src[k];
-  float* __restrict__ dst = a.dst[k];
+  const bool vc = (cols & 3) == 0, vr = (rows & 3) == 0;
 #pragma unroll
-  for (int j = 0; j < 32; j += 8) {
-    const int r = r0 + ty + j, c = c0 + tx;
-    if (r < rows && c < cols) t[ty + j][tx] = src[(int64_t)r * cols + c];
+  for (int j = 0; j < 64; j += 16) {
+    const int r = r0 + ty + j, c = c0 + 4 * tx;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int valid = r < rows ? (cols - c < 4 ? cols - c : 4) : 0;
+    if (valid == 4 && vc) v = *reinterpret_cast<const float4*>(src + (int64_t)r * cols + c);
+    else if (valid > 0) {
+      float e[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < valid; ++i) e[i] = src[(int64_t)r * cols + c + i];
+      v = make_float4(e[0], e[1], e[2], e[3]);
+    }
+    if (a.dst[k] && valid > 0) prep_store4(a.dst[k], (int64_t)r * cols + c, bf, valid == 4 && vc, valid, v);
+    t[ty + j][4 * tx] = v.x; t[ty + j][4 * tx + 1] = v.y; t[ty + j][4 * tx + 2] = v.z; t[ty + j][4 * tx + 3] = v.w;
   }
+  if (!a.dst_t[k]) return;
   __syncthreads();
 #pragma unroll
-  for (int j = 0; j < 32; j += 8) {
-    const int c = c0 + ty + j, r = r0 + tx;
-    if (r < rows && c < cols) dst[(int64_t)c * rows + r] = t[tx][ty + j];
+  for (int j = 0; j < 64; j += 16) {
+    const int c = c0 + ty + j, r = r0 + 4 * tx;                  // transposed row c, its columns r .. r + 3
+    const int valid = c < cols ? (rows - r < 4 ? rows - r : 4) : 0;
+    if (valid <= 0) continue;
+    const float4 v = make_float4(t[4 * tx][ty + j], t[4 * tx + 1][ty + j], t[4 * tx + 2][ty + j], t[4 * tx + 3][ty + j]);
+    prep_store4(a.dst_t[k], (int64_t)c * rows + r, bf, valid == 4 && vr, valid, v);
   }
 }
 }  // namespace micf
 
-extern "C" int micf_transpose_grouped(const micf_transpose_item* items, int n, micf_stream_t stream) {
+extern "C" int micf_weight_prep_grouped(const micf_weight_prep_item* items, int n, micf_stream_t stream) {
   if (n < 0 || (n > 0 && !items)) return MICF_EINVAL;
-  for (int first = 0; first < n; first += micf::kTrMax) {
-    const int cnt = (n - first < micf::kTrMax) ? n - first : micf::kTrMax;
-    micf::TrArgs a;
+  for (int first = 0; first < n; first += micf::kPrepMax) {
+    const int cnt = (n - first < micf::kPrepMax) ? n - first : micf::kPrepMax;
+    micf::PrepArgs a;
     a.n = cnt;
     int blocks = 0;
     for (int k = 0; k < cnt; ++k) {
-      const micf_transpose_item& it = items[first + k];
-      if (!it.src || !it.dst || it.rows <= 0 || it.cols <= 0) return MICF_EINVAL;
-      a.src[k] = it.src; a.dst[k] = it.dst; a.rows[k] = it.rows; a.cols[k] = it.cols;
-      blocks += ((it.rows + 31) / 32) * ((it.cols + 31) / 32);
+      const micf_weight_prep_item& it = items[first + k];
+      const int align = it.bf16 ? 7 : 15;
+      if (!it.src || (!it.dst && !it.dst_t) || it.rows <= 0 || it.cols <= 0 || (reinterpret_cast<uintptr_t>(it.src) & 15) ||
+          (reinterpret_cast<uintptr_t>(it.dst) & align) || (reinterpret_cast<uintptr_t>(it.dst_t) & align))
+        return MICF_EINVAL;
+      a.src[k] = it.src; a.dst[k] = it.dst; a.dst_t[k] = it.dst_t; a.rows[k] = it.rows; a.cols[k] = it.cols; a.bf16[k] = it.bf16;
+      blocks += ((it.rows + 63) / 64) * ((it.cols + 63) / 64);
       a.end[k] = blocks;
     }
-    hipLaunchKernelGGL(micf::transpose_grouped_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(micf::weight_prep_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     if (hipGetLastError() != hipSuccess) return MICF_ELAUNCH;
   }
   return MICF_OK;

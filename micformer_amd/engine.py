@@ -15,7 +15,7 @@ with MI355X-first plumbing around the HIP kernels:
 import torch
 import torch.distributed as dist
 
-from . import ops
+from . import _lib, ops
 from .dist import FlatGradSync, OverlappedGradReduce, flatten_views, last_writer_per_bucket, module_buckets
 from .loss.dice import MDiceLoss
 
@@ -90,17 +90,50 @@ class TrainEngine:
                 p._micf_grad = p.grad       # backward kernels accumulate straight into the flat gradient buffer
         self.params, self.offsets, self.sizes = params, offs, sizes
         self.adam_state = ops.adam_state(dev)
-        # Transposed copies of the block linears' weights for the fused backward (its "dY W" products stream W^T rows): one flat
-        # buffer, refreshed by ONE grouped launch at the start of every step (the weights only change in Adam).
-        tw = [p for n, p in zip(names, params) if n.endswith(("attn.q.weight", "attn.kv.weight", "attn.proj.weight", "mlp.fc1.weight",
-                                                               "mlp.fc2.weight")) and p.dim() == 2 and min(p.shape) <= 192]
-        toffs, ttotal = flatten_views(tw)
-        self.flat_wt = torch.empty(max(ttotal, 4), dtype=torch.float32, device=dev)
-        pairs = []
-        for p, o in zip(tw, toffs):
-            p._micf_wt = self.flat_wt[o:o + p.numel()].view(p.shape[1], p.shape[0])
-            pairs.append((p.data, p._micf_wt))
-        self._tplan = ops.TransposePlan(pairs)
+        # Shadow copies of the block linears' weights that the fused block kernels stream (fp32: W^T for the backward's "dY W"
+        # products; bf16: bf16(W) forward and bf16(W^T) backward) and the re-laid-out offset-conv weights of the direct conv
+        # kernels: flat buffers per arithmetic mode, refreshed by grouped launches at the start of every step (the weights only
+        # change in Adam).  Built on first use of a mode.  Only the FIRST stage's forward copies are on the step's critical path:
+        # the rest is prepared on a side stream while the first stage runs.
+        pick = lambda suffixes: [(n, p) for n, p in zip(names, params) if n.endswith(suffixes)]
+        self._shadow_w = [(n, p) for n, p in pick(("attn.q.weight", "attn.kv.weight", "attn.proj.weight", "mlp.fc1.weight",
+                                                   "mlp.fc2.weight")) if p.dim() == 2 and min(p.shape) <= 384]
+        self._conv_w = [(n, p) for n, p in pick(("conv_offset.0.weight",)) if p.dim() == 5 and p.shape[0] <= 16]
+        first = next((n.split(".layers.")[0] + ".layers.0." for n in names if ".layers." in n), None)   # the first stage's prefix
+        self._early = (lambda n: first is not None and n.startswith(first))
+        self._prep_plans, self._shadow_bufs = {}, {}
+        self._prep_stream = torch.cuda.Stream(device=dev)
+
+    def _weight_prep(self):
+        """(early, late, backward) launch plans of the current arithmetic mode: what the first stage's forward streams, what the
+        later stages' forwards stream, what only the backward streams."""
+        mode = ops.compute_dtype()
+        plans = self._prep_plans.get(mode)
+        if plans is None:
+            ws = [p for _, p in self._shadow_w]
+            offs, total = flatten_views(ws, align=8)
+            views = {}
+            for backward in (False, True):
+                spec = ops.shadow_spec(backward)
+                if spec is None:
+                    continue
+                attr, transposed, dtype = spec
+                buf = self._shadow_bufs[attr] = torch.empty(max(total, 8), dtype=dtype, device=self.flat_p.device)
+                for p, o in zip(ws, offs):
+                    r, c = (p.shape[1], p.shape[0]) if transposed else (p.shape[0], p.shape[1])
+                    setattr(p, attr, buf[o:o + p.numel()].view(r, c))
+                    views[(id(p), transposed)] = getattr(p, attr)
+            fwd = lambda sel: ops.WeightPrepPlan([(p.data, views[(id(p), False)], None) for n, p in self._shadow_w
+                                                  if (id(p), False) in views and sel(n)])
+            bwd = ops.WeightPrepPlan([(p.data, None, views[(id(p), True)]) for n, p in self._shadow_w if (id(p), True) in views])
+            if "conv" not in self._shadow_bufs:
+                trip = []
+                for _, p in self._conv_w:
+                    p._micf_c3f, p._micf_c3b = ops.conv3_prepared_like(p)
+                    trip.append((p.data, p._micf_c3f, p._micf_c3b))
+                self._shadow_bufs["conv"] = ops.Conv3PrepPlan(trip)
+            plans = self._prep_plans[mode] = (fwd(self._early), fwd(lambda n: not self._early(n)), bwd, self._shadow_bufs["conv"])
+        return plans
 
     # ------------------------------------------------------------------ one optimisation step
     def _scoped_flags(self):
@@ -111,23 +144,33 @@ class TrainEngine:
 
         @contextlib.contextmanager
         def scope():
-            prev = (_ms.PARALLEL_MODALITIES, _fn.DEFER_WGRAD, _fn.FLUSH_POINTS)
+            prev = (_ms.PARALLEL_MODALITIES, _fn.DEFER_WGRAD, _fn.FLUSH_POINTS, _fn.DEFER_CALLS)
             _ms.PARALLEL_MODALITIES, _fn.DEFER_WGRAD = self.parallel_modalities, self.defer_wgrad
             _fn.FLUSH_POINTS = self.defer_wgrad and self.flush_points and not self.split_step
+            _fn.DEFER_CALLS = self.defer_wgrad and not self.split_step
             try:
                 yield
             finally:
-                _ms.PARALLEL_MODALITIES, _fn.DEFER_WGRAD, _fn.FLUSH_POINTS = prev
+                _ms.PARALLEL_MODALITIES, _fn.DEFER_WGRAD, _fn.FLUSH_POINTS, _fn.DEFER_CALLS = prev
         return scope()
 
     def _fwd_bwd(self, x, target, flush=True):
         from . import functional as _fn
         _fn.drop_deferred()                                         # nothing left over from a backward that raised
         with self._scoped_flags():
-            ops.zero_(self.flat_g)                                  # optimizer.zero_grad()        train.py:183
-            self._tplan.launch()                                    # W^T of the block linears for the fused backward
+            early, late, bwd, conv = self._weight_prep()
+            main, side = torch.cuda.current_stream(), self._prep_stream
+            side.wait_stream(main)
+            early.launch()                                          # the first stage's shadow weights + all offset-conv layouts
+            conv.launch()
+            with torch.cuda.stream(side):                           # under the first stage: everything else the step needs later
+                late.launch()
+                ops.zero_(self.flat_g)                              # optimizer.zero_grad()        train.py:183
+                bwd.launch()
+            _fn.park_entry_hook(lambda: main.wait_stream(side))     # joined where the second stage starts
             logits = self.model(x)                                  #                              train.py:185
             loss = self.criterion(logits, target)                   #                              train.py:187
+            _fn.run_entry_hook(force=True)                          # (single-stage models: joined here at the latest)
             loss.backward()                                         #                              train.py:200
             if flush:
                 _fn.flush_wgrad()                                   # queued linear weight gradients, grouped launches

@@ -5,6 +5,7 @@ state_dict layout.  Parameter gradients are accumulated by the kernels into zero
 import torch
 
 from . import ops
+from . import _lib
 from ._lib import block_region
 
 _zl = torch.zeros_like
@@ -49,6 +50,21 @@ _DEFERRED_LN = []                   # (partials, blocks, C, dgamma, dbeta) of La
 
 _QUEUED_DW = set()                  # destinations already in the queue: the grouped kernel owns each dW element exclusively
 
+# Any other parameter-gradient work (conv weight gradients, the head tail's decomposition, bias column sums ...) can leave the
+# data-gradient chain the same way: single-GPU engine mode queues it as a closure that the next flush launches (on the side
+# stream at a flush point).  Only work that accumulates into the engine's flat gradient buffer qualifies: autograd must not be
+# waiting for a returned tensor.
+DEFER_CALLS = False
+_DEFERRED_CALLS = []                # (callable, tensors it reads, queued from inside a transformer block?)
+
+
+def _defer(ok, fn, *tensors):
+    """Run `fn` now, or -- engine mode, every destination a view of the flat gradient buffer (`ok`) -- at the next flush."""
+    if ok and DEFER_CALLS and DEFER_WGRAD:
+        _DEFERRED_CALLS.append((fn, tuple(t for t in tensors if t is not None), _lib.BLOCK_DEPTH > 0))
+    else:
+        fn()
+
 
 def _lin_wgrad(defer, dy, a, dw, db, dp_scale=None, rows_per_sample=0):
     if defer and DEFER_WGRAD and dy.shape[0] <= DEFER_MAX_TOKENS and ops.wgrad_groupable(dy, a, dp_scale, rows_per_sample) \
@@ -61,6 +77,8 @@ def _lin_wgrad(defer, dy, a, dw, db, dp_scale=None, rows_per_sample=0):
 
 def take_deferred():
     """Hand the queued (not yet launched) weight gradients and LayerNorm partials to the caller (TrainEngine's data-parallel step)."""
+    if _DEFERRED_CALLS:
+        raise RuntimeError("deferred gradient closures are a single-GPU engine feature (DEFER_CALLS) and cannot be planned")
     items, ln = list(_DEFERRED), list(_DEFERRED_LN)
     _DEFERRED.clear()
     _DEFERRED_LN.clear()
@@ -73,6 +91,7 @@ def drop_deferred():
     raised must not be flushed into the next step's gradients)."""
     _DEFERRED.clear()
     _DEFERRED_LN.clear()
+    _DEFERRED_CALLS.clear()
     _QUEUED_DW.clear()
 
 
@@ -98,9 +117,9 @@ def _wgrad_stream(device):
 
 def flush_wgrad_side():
     """Launch everything queued so far on the weight-gradient side stream (ordered after the current stream's work)."""
-    if not (_DEFERRED or _DEFERRED_LN):
+    if not (_DEFERRED or _DEFERRED_LN or _DEFERRED_CALLS):
         return
-    dev = (_DEFERRED[0][0] if _DEFERRED else _DEFERRED_LN[0][0]).device
+    dev = (_DEFERRED[0][0] if _DEFERRED else (_DEFERRED_LN[0][0] if _DEFERRED_LN else _DEFERRED_CALLS[0][1][0])).device
     main, side = torch.cuda.current_stream(dev), _wgrad_stream(dev)
     side.wait_stream(main)
     for it in _DEFERRED:                    # the queue's references die at the flush: tell the allocator who still reads them
@@ -109,6 +128,9 @@ def flush_wgrad_side():
                 t.record_stream(side)
     for it in _DEFERRED_LN:
         it[0].record_stream(side)
+    for _, tensors, _blk in _DEFERRED_CALLS:
+        for t in tensors:
+            t.record_stream(side)
     with torch.cuda.stream(side):
         flush_wgrad()
     _WSIDE_USED.add(dev)
@@ -118,6 +140,23 @@ def join_wgrad_stream():
     for dev in list(_WSIDE_USED):
         torch.cuda.current_stream(dev).wait_stream(_wgrad_stream(dev))
     _WSIDE_USED.clear()
+
+
+# forward side of a flush point: the engine may park a callable here that must run before the SECOND stage starts (it joins the
+# stream that prepares the later stages' shadow weights while the first stage already runs)
+_ENTRY_HOOK = [None, 0]             # callable, stage entries seen since it was parked
+
+
+def park_entry_hook(fn):
+    _ENTRY_HOOK[0], _ENTRY_HOOK[1] = fn, 0
+
+
+def run_entry_hook(force=False):
+    """Called at every stage entry: runs the parked callable at the second entry (or now, `force`)."""
+    _ENTRY_HOOK[1] += 1
+    if _ENTRY_HOOK[0] is not None and (force or _ENTRY_HOOK[1] >= 2):
+        hook, _ENTRY_HOOK[0] = _ENTRY_HOOK[0], None
+        hook()
 
 
 class FlushPointFn(torch.autograd.Function):
@@ -132,18 +171,27 @@ class FlushPointFn(torch.autograd.Function):
         return dx, dxa
 
 
-@_in_block
 def flush_wgrad():
     """Launch every queued weight gradient on the current stream (which must be ordered after their producers)."""
-    if _DEFERRED_LN:
-        ln = list(_DEFERRED_LN)
-        _DEFERRED_LN.clear()
-        ops.layernorm_bwd_finish(ln)
-    if _DEFERRED:
-        items = list(_DEFERRED)
-        _DEFERRED.clear()
-        _QUEUED_DW.clear()
-        ops.linear_bwd_weight_grouped(items)
+    with block_region():
+        if _DEFERRED_LN:
+            ln = list(_DEFERRED_LN)
+            _DEFERRED_LN.clear()
+            ops.layernorm_bwd_finish(ln)
+        if _DEFERRED:
+            items = list(_DEFERRED)
+            _DEFERRED.clear()
+            _QUEUED_DW.clear()
+            ops.linear_bwd_weight_grouped(items)
+    if _DEFERRED_CALLS:
+        calls = list(_DEFERRED_CALLS)
+        _DEFERRED_CALLS.clear()
+        for fn, _, blk in calls:
+            if blk:
+                with block_region():
+                    fn()
+            else:
+                fn()
 
 
 def _targets(params):
@@ -211,12 +259,13 @@ class LinearFn(torch.autograd.Function):
         a2f = a2.reshape(-1, a2.shape[-1]) if a2 is not None else None
         dw = _grad_buf(ctx.tg[0], w)
         db = (ctx.tg[1] if ctx.tg[1] is not None else torch.zeros(w.shape[0], dtype=w.dtype, device=w.device)) if ctx.has_bias else None
-        ops.linear_bwd_weight(dy, af, dw, db, a2f)
+        _defer(ctx.tg[0] is not None and (ctx.tg[1] is not None or not ctx.has_bias),
+               lambda: ops.linear_bwd_weight(dy, af, dw, db, a2f), dy, af, a2f)
         r = ops.linear_bwd_data(dy, w, k1=k1)
-        dw, db = _ret(ctx.tg[0], dw), _ret(ctx.tg[1], db)
+        rdw, rdb = _ret(ctx.tg[0], dw), _ret(ctx.tg[1], db)     # (new names: the deferred closure above still reads dw / db)
         if a2 is None:
-            return r.reshape(a.shape), None, dw, db
-        return r[0].reshape(a.shape), r[1].reshape(a2.shape), dw, db
+            return r.reshape(a.shape), None, rdw, rdb
+        return r[0].reshape(a.shape), r[1].reshape(a2.shape), rdw, rdb
 
 
 # ============================================================================= shared pieces of the two block types
@@ -459,7 +508,8 @@ class CrossBlockFn(torch.autograd.Function):
         dhid = ops.offset_sample_bwd(dxs, hid, P["conv_offset.1.norm.weight"], P["conv_offset.1.norm.bias"],
                                      P["conv_offset.3.weight"], xap, flow, dxap, G["conv_offset.1.norm.weight"],
                                      G["conv_offset.1.norm.bias"], G["conv_offset.3.weight"], pdims, eps)
-        ops.conv3_bwd_weight(dhid, xnp, G["conv_offset.0.weight"], G["conv_offset.0.bias"], pdims, x2=xap)
+        _defer(side, lambda: ops.conv3_bwd_weight(dhid, xnp, G["conv_offset.0.weight"], G["conv_offset.0.bias"], pdims, x2=xap),
+               dhid, xnp, xap)
         ops.conv3_bwd_data(dhid, P["conv_offset.0.weight"], pdims, C, C, dx1=dxnp, dx2=dxap, acc1=True, acc2=True)
         if padded:
             dxn = ops.crop3d(dxnp, dims, pd)
@@ -584,7 +634,8 @@ def _cross_head_bwd(side, P, G, dims, eps, xf, xaf, xn, m1, r1, hid, flow, dxq, 
     dhid = ops.offset_sample_bwd(dxs, hid, P["conv_offset.1.norm.weight"], P["conv_offset.1.norm.bias"], P["conv_offset.3.weight"],
                                  xaf, flow, dxa_acc, G["conv_offset.1.norm.weight"], G["conv_offset.1.norm.bias"],
                                  G["conv_offset.3.weight"], dims, eps)
-    ops.conv3_bwd_weight(dhid, xn, G["conv_offset.0.weight"], G["conv_offset.0.bias"], dims, x2=xaf)
+    _defer(side, lambda: ops.conv3_bwd_weight(dhid, xn, G["conv_offset.0.weight"], G["conv_offset.0.bias"], dims, x2=xaf),
+           dhid, xn, xaf)
     ops.conv3_bwd_data(dhid, P["conv_offset.0.weight"], dims, C, C, dx1=dxq, dx2=dxa_acc, acc1=True, acc2=True)
     return ops.layernorm_bwd(dxq, xf, m1, r1, P["norm1.weight"], G["norm1.weight"], G["norm1.bias"], add=add, defer=_ln_defer(side),
                              out=out)
@@ -605,14 +656,15 @@ def _side_stream(device):
     return st
 
 
-def _cross_head_adjoint(i, hds, bos, Ps, Gs, xs, acc, dims, eps, C):
+def _cross_head_adjoint(i, hds, bos, Ps, Gs, xs, acc, dims, eps, C, sides):
     """Adjoint of block i's offset head: sampler backward (raw-xa gradient -> the OTHER input's accumulator), conv weight
     gradient, conv data gradient (-> block i's pre-LayerNorm gradient and the other input's accumulator)."""
     xn, m1, r1, hid, flow, xsamp = hds[i]
     dhid = ops.offset_sample_bwd(bos[i]["dxs"], hid, Ps[i]["conv_offset.1.norm.weight"], Ps[i]["conv_offset.1.norm.bias"],
                                  Ps[i]["conv_offset.3.weight"], xs[1 - i], flow, acc[1 - i], Gs[i]["conv_offset.1.norm.weight"],
                                  Gs[i]["conv_offset.1.norm.bias"], Gs[i]["conv_offset.3.weight"], dims, eps)
-    ops.conv3_bwd_weight(dhid, xn, Gs[i]["conv_offset.0.weight"], Gs[i]["conv_offset.0.bias"], dims, x2=xs[1 - i])
+    _defer(sides[i], lambda: ops.conv3_bwd_weight(dhid, xn, Gs[i]["conv_offset.0.weight"], Gs[i]["conv_offset.0.bias"], dims,
+                                                  x2=xs[1 - i]), dhid, xn, xs[1 - i])
     ops.conv3_bwd_data(dhid, Ps[i]["conv_offset.0.weight"], dims, C, C, dx1=bos[i]["dx"], dx2=acc[1 - i], acc1=True, acc2=True)
 
 
@@ -689,7 +741,7 @@ class CrossPairFn(torch.autograd.Function):
         for i in (0, 1):
             # block i's raw-xa gradient goes to the OTHER input's buffer; its own LN1 backward lands in acc[i] (in place)
             with torch.cuda.stream(side if (i == 1 and side is not None) else main):
-                _cross_head_adjoint(i, hds, bos, Ps, Gs, xs, acc, dims, eps, C)
+                _cross_head_adjoint(i, hds, bos, Ps, Gs, xs, acc, dims, eps, C, sides)
         if side is not None:
             main.wait_stream(side)
         for i in (0, 1):
@@ -720,7 +772,8 @@ class PatchEmbedFn(torch.autograd.Function):
         mod, p = ctx.meta
         dw = _grad_buf(ctx.tg[0], w)
         db = ctx.tg[1] if ctx.tg[1] is not None else torch.zeros(w.shape[0], dtype=w.dtype, device=w.device)
-        ops.patch_embed_bwd_weight(_c(dy), vol, mod, dw, db, p)
+        dy = _c(dy)
+        _defer(ctx.tg[0] is not None and ctx.tg[1] is not None, lambda: ops.patch_embed_bwd_weight(dy, vol, mod, dw, db, p), dy, vol)
         return None, None, _ret(ctx.tg[0], dw), _ret(ctx.tg[1], db), None   # the input volume is data: no gradient (train.py:177-185)
 
 
@@ -740,7 +793,7 @@ class ConvDownFn(torch.autograd.Function):
         dy = _c(dy)
         dw = _grad_buf(ctx.tg[0], w)
         db = ctx.tg[1] if ctx.tg[1] is not None else torch.zeros(w.shape[0], dtype=w.dtype, device=w.device)
-        ops.conv_down_bwd_weight(dy, x, dw, db)
+        _defer(ctx.tg[0] is not None and ctx.tg[1] is not None, lambda: ops.conv_down_bwd_weight(dy, x, dw, db), dy, x)
         return ops.conv_down_bwd_data(dy, w, tuple(x.shape)), _ret(ctx.tg[0], dw), _ret(ctx.tg[1], db)
 
 
@@ -761,7 +814,8 @@ class ConvUpFn(torch.autograd.Function):
         dy = _c(dy)
         dw = _grad_buf(ctx.tg[0], w)
         db = ctx.tg[1] if ctx.tg[1] is not None else torch.zeros(w.shape[1], dtype=w.dtype, device=w.device)
-        ops.conv_up_bwd_weight(dy, x, dw, db, ctx.k)
+        k = ctx.k
+        _defer(ctx.tg[0] is not None and ctx.tg[1] is not None, lambda: ops.conv_up_bwd_weight(dy, x, dw, db, k), dy, x)
         return ops.conv_up_bwd_data(dy, w, tuple(x.shape), ctx.k), _ret(ctx.tg[0], dw), _ret(ctx.tg[1], db), None
 
 
@@ -815,10 +869,14 @@ class HeadTailFn(torch.autograd.Function):
         P = w_up.shape[2]
         u = ops.head_tail_im2col(_c(dy), ctx.dims, P)
         dx = ops.linear_bwd_data(u, wb)
-        dwb, dbf = torch.zeros_like(wb), torch.zeros(wb.shape[0], dtype=wb.dtype, device=wb.device)
-        ops.linear_bwd_weight(u, xf, dwb, dbf)
         grads = [_grad_buf(t, p) for t, p in zip(ctx.tg, (w_up, b_up, w_out, w_out.new_empty(w_out.shape[0])))]
-        ops.head_tail_decompose(dwb, dbf, w_up, b_up, w_out, *grads)
+
+        def weight_grads():       # composed-map gradient, then its decomposition into the two layers' parameters
+            dwb, dbf = ops.zero_(torch.empty_like(wb)), ops.zero_(torch.empty(wb.shape[0], dtype=wb.dtype, device=wb.device))
+            ops.linear_bwd_weight(u, xf, dwb, dbf)
+            ops.head_tail_decompose(dwb, dbf, w_up, b_up, w_out, *grads)
+
+        _defer(all(t is not None for t in ctx.tg), weight_grads, u, xf, wb)
         return (dx.reshape(B, Dc, Hc, Wc, -1),) + tuple(_ret(t, g) for t, g in zip(ctx.tg, grads))
 
 

@@ -394,6 +394,8 @@ class BasicLayer(nn.Module):
 
     def _forward_pairs(self, x, xa):
         for i in range(self.depth):
+            if i and Fn.FLUSH_POINTS and x.requires_grad:
+                x, xa = Fn.FlushPointFn.apply(x, xa)   # backward: the later slots' weight gradients start under this slot's chain
             a, b = self.self_blocks1[i], self.self_blocks2[i]
             sa, sb = _block_scales(a, x), _block_scales(b, xa)
             x, xa = Fn.SelfPairFn.apply(x, xa, sa[0], sa[1], sb[0], sb[1], a.num_heads, a.norm1.eps,
@@ -405,6 +407,7 @@ class BasicLayer(nn.Module):
         return x, xa
 
     def forward(self, x, xa):
+        Fn.run_entry_hook()                            # (engine: the later stages' shadow weights are ready from the 2nd stage on)
         if Fn.FLUSH_POINTS and x.requires_grad:
             x, xa = Fn.FlushPointFn.apply(x, xa)       # backward: launch this stage's queued weight gradients on a side stream
         if self._pair_fusable(x, xa):

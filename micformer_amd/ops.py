@@ -269,9 +269,12 @@ def conv3_fwd(x1, w, bias, dims, x2=None, ncdhw_out=False):
     N = w.shape[0]
     y = _new(x1, B, N, D, H, W) if ncdhw_out else _new(x1, B * D * H * W, N)
     need = 0 if ncdhw_out else _lib.lib.micf_conv3_fwd_workspace(N, c1, c2)
-    ws = scratch(x1.device, need) if need > 0 else None
+    ws = getattr(w, "_micf_c3f", None) if need > 0 else None     # engine mode: re-laid-out copy, refreshed once per step
+    prepared = 1 if ws is not None else 0
+    if ws is None and need > 0:
+        ws = scratch(x1.device, need)
     call("micf_conv3_fwd", f32(x1), c1, f32(x2), c2, f32(w), f32(bias), f32(y), 1 if ncdhw_out else 0, B, D, H, W, N,
-         f32(ws), ws.numel() if ws is not None else 0, _dt(),
+         f32(ws), ws.numel() if ws is not None else 0, prepared, _dt(),
          cost=_cost(2 * B * D * H * W * 27 * (c1 + c2) * N, x1, x2, w, y))
     return y
 
@@ -285,9 +288,12 @@ def conv3_bwd_data(dy, w, dims, c1, c2=0, ncdhw=False, dx1=None, dx2=None, acc1=
     if dx2 is None and want2 and c2 > 0:
         dx2 = _new(dy, T, c2)
     need = 0 if ncdhw else _lib.lib.micf_conv3_bwd_data_workspace(N, c1, c2)
-    ws = scratch(dy.device, need) if need > 0 else None
+    ws = getattr(w, "_micf_c3b", None) if need > 0 else None
+    prepared = 1 if ws is not None else 0
+    if ws is None and need > 0:
+        ws = scratch(dy.device, need)
     call("micf_conv3_bwd_data", f32(dy), 1 if ncdhw else 0, f32(w), f32(dx1), c1, 1 if acc1 else 0, f32(dx2), c2,
-         1 if acc2 else 0, B, D, H, W, N, f32(ws), ws.numel() if ws is not None else 0, _dt(),
+         1 if acc2 else 0, B, D, H, W, N, f32(ws), ws.numel() if ws is not None else 0, prepared, _dt(),
          cost=_cost(2 * T * 27 * (c1 + c2) * N, dy, w, dx1, dx2))
     return dx1, dx2
 
@@ -551,9 +557,9 @@ def adam_step(p, g, m, v, state, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.
 # ----------------------------------------------------------------------------- fused window-local transformer block
 _DT = {"fp32": 0, "bf16": 1}
 
-FWD_W = (("ln1_g", "norm1.weight"), ("ln1_b", "norm1.bias"), ("wq", "{a}.q.weight"), ("bq", "{a}.q.bias"), ("wkv", "{a}.kv.weight"),
-         ("bkv", "{a}.kv.bias"), ("wp", "{a}.proj.weight"), ("bp", "{a}.proj.bias"), ("ln2_g", "norm2.weight"), ("ln2_b", "norm2.bias"),
-         ("w1", "mlp.fc1.weight"), ("b1", "mlp.fc1.bias"), ("w2", "mlp.fc2.weight"), ("b2", "mlp.fc2.bias"))
+FWD_W = (("ln1_g", "norm1.weight"), ("ln1_b", "norm1.bias"), ("bq", "{a}.q.bias"), ("bkv", "{a}.kv.bias"), ("bp", "{a}.proj.bias"),
+         ("ln2_g", "norm2.weight"), ("ln2_b", "norm2.bias"), ("b1", "mlp.fc1.bias"), ("b2", "mlp.fc2.bias"))
+FWD_WM = (("wq", "{a}.q.weight"), ("wkv", "{a}.kv.weight"), ("wp", "{a}.proj.weight"), ("w1", "mlp.fc1.weight"), ("w2", "mlp.fc2.weight"))
 BWD_W = (("ln1_g", "norm1.weight"), ("ln2_g", "norm2.weight"))
 BWD_WT = (("wqt", "{a}.q.weight"), ("wkvt", "{a}.kv.weight"), ("wpt", "{a}.proj.weight"), ("w1t", "mlp.fc1.weight"),
           ("w2t", "mlp.fc2.weight"))
@@ -565,35 +571,84 @@ def block_tile_tokens(dims, C, heads, hidden, backward=False):
     return int(_lib.lib.micf_block_tile_tokens(B, D, H, W, C, heads, hidden, 1 if backward else 0))
 
 
-class TransposePlan:
-    """ctypes item array of (src [r, c] -> dst [c, r]) pairs, reusable while the tensors keep their addresses."""
+class WeightPrepPlan:
+    """ctypes item array of (src [r, c] fp32, dst [r, c] | None, dst_t [c, r] | None) triples for micf_weight_prep_grouped (the
+    outputs of one item are both fp32 or both bfloat16); reusable while the tensors keep their addresses."""
 
-    def __init__(self, pairs):
-        self.pairs = list(pairs)
-        self.n = len(self.pairs)
-        self.arr = (_lib.TransposeItem * max(self.n, 1))()
-        for it, (src, dst) in zip(self.arr, self.pairs):
-            it.src, it.dst, it.rows, it.cols = f32(src), f32(dst), src.shape[0], src.shape[1]
+    def __init__(self, triples):
+        self.triples = list(triples)
+        self.n = len(self.triples)
+        self.arr = (_lib.WeightPrepItem * max(self.n, 1))()
+        self.nbytes = 0
+        for it, (src, dst, dst_t) in zip(self.arr, self.triples):
+            outs = [t for t in (dst, dst_t) if t is not None]
+            assert outs and len({t.dtype for t in outs}) == 1 and outs[0].dtype in (torch.float32, torch.bfloat16)
+            it.src, it.dst, it.dst_t, it.rows, it.cols = f32(src), ptr(dst), ptr(dst_t), src.shape[0], src.shape[1]
+            it.bf16 = 1 if outs[0].dtype == torch.bfloat16 else 0
+            self.nbytes += src.numel() * (4 + sum(t.element_size() for t in outs))
 
     def launch(self):
         if self.n:
-            nb = sum(8 * s.numel() for s, _ in self.pairs) if _lib.PROFILE is not None else 0
-            call("micf_transpose_grouped", ctypes.cast(self.arr, ctypes.c_void_p), self.n, cost=(nb, 0) if _lib.PROFILE is not None else None)
+            call("micf_weight_prep_grouped", ctypes.cast(self.arr, ctypes.c_void_p), self.n,
+                 cost=(self.nbytes, 0) if _lib.PROFILE is not None else None)
 
 
-def transposed_weights(P, attn):
-    """The five transposed weight matrices the fused backward streams.  Engine mode: the parameter carries `_micf_wt`, a view of
-    the engine's transpose buffer that is refreshed once per step; otherwise they are made here (one grouped launch)."""
+class Conv3PrepPlan:
+    """ctypes item array for micf_conv3_weight_prep_grouped: (w [N, Cin, 3,3,3], fwd layout | None, bwd layout | None)."""
+
+    def __init__(self, triples):
+        self.triples = list(triples)
+        self.n = len(self.triples)
+        self.arr = (_lib.Conv3PrepItem * max(self.n, 1))()
+        for it, (w, fwd, bwd) in zip(self.arr, self.triples):
+            it.w, it.fwd, it.bwd, it.N, it.Cin = f32(w), f32(fwd), f32(bwd), w.shape[0], w.shape[1]
+
+    def launch(self):
+        if self.n:
+            call("micf_conv3_weight_prep_grouped", ctypes.cast(self.arr, ctypes.c_void_p), self.n)
+
+
+def conv3_prepared_like(w):
+    """Empty (fwd, bwd) re-layout buffers for a few-output-channel conv weight, or (None, None) when the direct kernels do not apply."""
+    N, Cin = w.shape[0], w.shape[1]
+    nf, nb = _lib.lib.micf_conv3_fwd_workspace(N, Cin, 0), _lib.lib.micf_conv3_bwd_data_workspace(N, Cin, 0)
+    mk = lambda n: torch.empty(n, dtype=torch.float32, device=w.device) if n > 0 else None
+    return mk(nf), mk(nb)
+
+
+# parameter attribute holding an engine-maintained shadow copy, per (arithmetic mode, direction): (name, transposed, dtype)
+_SHADOW = {("fp32", True): ("_micf_wt", True, torch.float32), ("bf16", False): ("_micf_w16", False, torch.bfloat16),
+           ("bf16", True): ("_micf_wt16", True, torch.bfloat16)}
+
+
+def shadow_spec(backward):
+    """(attribute name, transposed, dtype) of the weight copy the fused kernels stream in the current arithmetic mode, or None
+    when they read the parameter itself (fp32 forward)."""
+    return _SHADOW.get((compute_dtype(), bool(backward)))
+
+
+def shadow_like(w, transposed, dtype):
+    return torch.empty((w.shape[1], w.shape[0]) if transposed else tuple(w.shape), dtype=dtype, device=w.device)
+
+
+def block_weights(P, attn, backward):
+    """The five weight matrices a fused block kernel streams, in the layout of the current arithmetic mode.  Engine mode: the
+    parameter carries the shadow copy (refreshed once per step); otherwise it is made here (one grouped launch)."""
+    fields = BWD_WT if backward else FWD_WM
+    spec = shadow_spec(backward)
     out, todo = {}, []
-    for field, key in BWD_WT:
+    for field, key in fields:
         w = P[key.format(a=attn)]
-        wt = getattr(w, "_micf_wt", None)
-        if wt is None:
-            wt = _new(w, w.shape[1], w.shape[0])
-            todo.append((w, wt))
-        out[field] = wt
+        if spec is None:
+            out[field] = w
+            continue
+        sh = getattr(w, spec[0], None)
+        if sh is None:
+            sh = shadow_like(w, spec[1], spec[2])
+            todo.append((w, None, sh) if spec[1] else (w, sh, None))
+        out[field] = sh
     if todo:
-        TransposePlan(todo).launch()
+        WeightPrepPlan(todo).launch()
     return out
 
 
@@ -605,6 +660,7 @@ def block_fwd(groups, dims, C, heads, eps, scale):
     hidden = groups[0]["P"]["mlp.fc1.weight"].shape[0]
     arr = (_lib.BlockFwdGroup * 2)()
     outs = []
+    keep = []            # temporary shadow weights must outlive the launch: the next group's outputs must not reuse them
     nb = fl = 0
     for it, gd in zip(arr, groups):
         x, P, a = gd["x"], gd["P"], gd["attn"]
@@ -614,10 +670,14 @@ def block_fwd(groups, dims, C, heads, eps, scale):
         it.x, it.kvsrc, it.s1, it.s2 = f32(x), f32(gd.get("kvsrc")), f32(gd.get("s1")), f32(gd.get("s2"))
         for field, key in FWD_W:
             setattr(it, field, f32(P[key.format(a=a)]))
+        wts = block_weights(P, a, backward=False)
+        keep.append(wts)
+        for field, wt in wts.items():
+            setattr(it, field, ptr(wt))
         for k, v in o.items():
             setattr(it, k, f32(v))
         outs.append(o)
-        nb += 4 * (T * C * (9 if o["xn"] is not None else 8) + 2 * T * hidden + 12 * C * C)
+        nb += 4 * (T * C * (9 if o["xn"] is not None else 8) + 2 * T * hidden) + 12 * C * C * wt.element_size()
         fl += 2 * T * 12 * C * C + 4 * T * C * 8
     call("micf_block_fwd", ctypes.cast(arr, ctypes.c_void_p), len(groups), B, D, H, W, C, heads, hidden, float(eps), float(scale),
          _dt(), cost=(nb, fl, f"{len(groups)}x{T}x{C}") if _lib.PROFILE is not None and DETAIL else ((nb, fl) if _lib.PROFILE is not None else None))
@@ -646,15 +706,15 @@ def block_bwd(groups, dims, C, heads, scale):
             setattr(it, k, f32(gd.get(k)))
         for field, key in BWD_W:
             setattr(it, field, f32(P[key.format(a=a)]))
-        wts = transposed_weights(P, a)
+        wts = block_weights(P, a, backward=True)
         keep.append(wts)
         for field, wt in wts.items():
-            setattr(it, field, f32(wt))
+            setattr(it, field, ptr(wt))
         for k, v in o.items():
             setattr(it, k, f32(v))
         o["tiles"] = tiles
         outs.append(o)
-        nb += 4 * (T * C * (11 if cross else 9) + 2 * T * hidden + 12 * C * C)
+        nb += 4 * (T * C * (11 if cross else 9) + 2 * T * hidden) + 12 * C * C * wt.element_size()
         fl += 2 * T * 12 * C * C + 8 * T * C * 8
     call("micf_block_bwd", ctypes.cast(arr, ctypes.c_void_p), len(groups), B, D, H, W, C, heads, hidden, float(scale),
          _dt(), cost=(nb, fl, f"{len(groups)}x{T}x{C}") if _lib.PROFILE is not None and DETAIL else ((nb, fl) if _lib.PROFILE is not None else None))

@@ -93,6 +93,8 @@ CASES = [  # (B, D, H, W, C, heads)
     (1, 2, 6, 2, 96, 3),      # head_dim 32, 3 windows: partial last tile
     (2, 4, 4, 2, 192, 12),    # TM 16
     (1, 4, 2, 2, 192, 6),     # head_dim 32 at C 192
+    (2, 4, 4, 4, 384, 24),    # few-token decomposition (block_wide.hip): the base model's 4^3 stage
+    (1, 2, 6, 2, 384, 12),    # ... head_dim 32, 3 windows: masked rows in the last 16-token tile
 ]
 
 
@@ -161,11 +163,12 @@ def test_fused_block_matches_per_op_path(ops, case, cross, ngroups):
 def test_unsupported_shapes_are_reported(ops):
     assert ops.block_tile_tokens((1, 3, 4, 4), 48, 3, 192) == 0          # odd token grid: pad-to-window path
     assert ops.block_tile_tokens((1, 4, 4, 4), 24, 3, 96) == 0           # head_dim 8 (tiny config)
-    assert ops.block_tile_tokens((1, 4, 4, 4), 384, 24, 1536) == 0       # weight-streaming bound per tile: left to the per-op path
+    assert ops.block_tile_tokens((1, 4, 4, 4), 768, 24, 3072) == 0       # C = 768 (large model, 5^3 stage): per-op path
+    assert ops.block_tile_tokens((1, 4, 4, 4), 384, 24, 1536) == 16      # few-token decomposition
     assert ops.block_tile_tokens((2, 32, 32, 32), 48, 3, 192) == 32
 
 
-@pytest.mark.parametrize("case", [(2, 4, 4, 4, 48, 3), (1, 4, 6, 4, 96, 6), (2, 4, 4, 2, 192, 12)])
+@pytest.mark.parametrize("case", [(2, 4, 4, 4, 48, 3), (1, 4, 6, 4, 96, 6), (2, 4, 4, 2, 192, 12), (2, 4, 4, 4, 384, 24)])
 def test_fused_block_bf16_mode_is_close(ops, case):
     """bf16 matrix-core operands (fp32 accumulate, fp32 everywhere else): 8-bit mantissas on the GEMM inputs only."""
     B, D, H, W, C, heads = case
@@ -192,3 +195,17 @@ def test_fused_block_bf16_mode_is_close(ops, case):
         check(f"bf16 bwd {k}", b[k], rb[k], 3e-2, errs)
     assert float((o["y"] - ref["y"]).abs().max()) > 0                      # it really is a different arithmetic
     assert not errs, "\n".join(errs)
+
+
+@pytest.mark.parametrize("rows,cols", [(48, 48), (96, 48), (192, 768), (33, 70), (130, 4)])
+def test_weight_prep_outputs(ops, rows, cols):
+    """micf_weight_prep_grouped: the fp32 copies are permutations (bit-exact); the bf16 copies equal torch's round-to-nearest-even."""
+    w = torch.randn(rows, cols, device="cuda")
+    wt, wc = ops.shadow_like(w, True, torch.float32), ops.shadow_like(w, False, torch.float32)
+    w16, wt16 = ops.shadow_like(w, False, torch.bfloat16), ops.shadow_like(w, True, torch.bfloat16)
+    only_t = ops.shadow_like(w, True, torch.bfloat16)
+    ops.WeightPrepPlan([(w, wc, wt), (w, w16, wt16), (w, None, only_t)]).launch()
+    torch.cuda.synchronize()
+    assert torch.equal(wc, w) and torch.equal(wt, w.t().contiguous())
+    assert torch.equal(w16, w.to(torch.bfloat16))
+    assert torch.equal(wt16, w.t().contiguous().to(torch.bfloat16)) and torch.equal(only_t, wt16)

@@ -293,10 +293,11 @@ int micf_dice_metric(const float* logits, const void* target, int target_is_labe
  * iteration (train.py:114,148,206-207).  state = {int64 step; double lr} on the device so a captured graph advances:
  * micf_adam_tick increments step and recomputes lr = eta_min + (base-eta_min)*(1+cos(pi*(step-1)/t_max))/2,
  * micf_adam_step applies the update with bias corrections for `step`; the gradient is read as grad_scale * g (1/world after a
- * sum all-reduce, 1 on one GPU). */
+ * sum all-reduce, 1 on one GPU).  p_bf16 (optional, n uint16_t): a bf16 (round-to-nearest-even) mirror of the updated
+ * parameters, written in the same pass -- what the fused block kernels stream in bf16 mode, so no per-step conversion launch. */
 int micf_adam_tick(void* state, double base_lr, double eta_min, int64_t t_max, micf_stream_t stream);
 int micf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const void* state, float beta1,
-                   float beta2, float eps, float grad_scale, micf_stream_t stream);
+                   float beta2, float eps, float grad_scale, void* p_bf16, micf_stream_t stream);
 
 
 /* ---- Fused window-local transformer block (csrc/block_fwd.hip, block_bwd.hip): everything of a TransformerBlock3D

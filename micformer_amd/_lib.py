@@ -66,7 +66,7 @@ SIGNATURES = {
     "micf_dice_bce_label_bwd": "pppppiilp",
     "micf_argmax_meandice": "pppppiilp",
     "micf_adam_tick": "pddlp",
-    "micf_adam_step": "pppplpffffp",
+    "micf_adam_step": "pppplpffffpp",
     "micf_block_tile_tokens": "iiiiiiii",
     "micf_weight_prep_grouped": "pip",
     "micf_block_fwd": "piiiiiiiiffip",

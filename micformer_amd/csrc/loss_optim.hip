@@ -152,10 +152,17 @@ __global__ void adam_tick_kernel(AdamState* st, double base_lr, double eta_min, 
   st->lr = eta_min + (base_lr - eta_min) * (1.0 + cos(3.14159265358979323846 * (double)(st->step - 1) / (double)t_max)) / 2.0;
 }
 
+__device__ __forceinline__ unsigned bf16_pair(float a, float b) {   // round-to-nearest-even, a in the low half (as gemm_dma.h)
+  unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+  ua += 0x7FFFu + ((ua >> 16) & 1u);
+  ub += 0x7FFFu + ((ub >> 16) & 1u);
+  return (ua >> 16) | (ub & 0xFFFF0000u);
+}
+
 __global__ void __launch_bounds__(256) adam_step_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                         const AdamState* __restrict__ st, float beta1, float beta2, float eps,
-                                                        float gscale) {
+                                                        float gscale, uint16_t* __restrict__ p16) {
   const double step = (double)st->step;
   const float bc1 = (float)(1.0 - pow((double)beta1, step));
   const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, step));
@@ -174,12 +181,14 @@ __global__ void __launch_bounds__(256) adam_step_kernel(float* __restrict__ p, c
         pp[e] = pp[e] - step_size * (mm[e] / denom);                      // param.addcdiv_(exp_avg, denom, -step_size)
       }
       *reinterpret_cast<float4*>(p + i) = P; *reinterpret_cast<float4*>(m + i) = M; *reinterpret_cast<float4*>(v + i) = Vv;
+      if (p16) *reinterpret_cast<uint2*>(p16 + i) = make_uint2(bf16_pair(P.x, P.y), bf16_pair(P.z, P.w));   // bf16 mirror (RNE)
     } else {
       for (int64_t j = i; j < n; ++j) {
         const float gj = g[j] * gscale;
         m[j] = m[j] + (gj - m[j]) * (1.0f - beta1);
         v[j] = v[j] * beta2 + (1.0f - beta2) * gj * gj;
         p[j] = p[j] - step_size * (m[j] / (sqrtf(v[j]) / bc2_sqrt + eps));
+        if (p16) p16[j] = (uint16_t)(bf16_pair(p[j], 0.f) & 0xFFFFu);
       }
     }
   }
@@ -248,14 +257,14 @@ extern "C" int micf_adam_tick(void* state, double base_lr, double eta_min, int64
 }
 
 extern "C" int micf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const void* state, float beta1,
-                              float beta2, float eps, float grad_scale, micf_stream_t stream) {
+                              float beta2, float eps, float grad_scale, void* p_bf16, micf_stream_t stream) {
   if (!p || !g || !m || !v || !state || n < 0) return MICF_EINVAL;
   if (n == 0) return MICF_OK;
-  if (!aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v)) return MICF_EINVAL;
+  if (!aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v) || (reinterpret_cast<uintptr_t>(p_bf16) & 7)) return MICF_EINVAL;
   int blocks = (int)((n + 1023) / 1024);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(adam_step_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, (const AdamState*)state,
-                     beta1, beta2, eps, grad_scale);
+                     beta1, beta2, eps, grad_scale, static_cast<uint16_t*>(p_bf16));
   MICF_RETURN_LAUNCH();
 }
 

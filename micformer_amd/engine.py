@@ -90,49 +90,63 @@ class TrainEngine:
                 p._micf_grad = p.grad       # backward kernels accumulate straight into the flat gradient buffer
         self.params, self.offsets, self.sizes = params, offs, sizes
         self.adam_state = ops.adam_state(dev)
-        # Shadow copies of the block linears' weights that the fused block kernels stream (fp32: W^T for the backward's "dY W"
-        # products; bf16: bf16(W) forward and bf16(W^T) backward) and the re-laid-out offset-conv weights of the direct conv
-        # kernels: flat buffers per arithmetic mode, refreshed by grouped launches at the start of every step (the weights only
-        # change in Adam).  Built on first use of a mode.  Only the FIRST stage's forward copies are on the step's critical path:
-        # the rest is prepared on a side stream while the first stage runs.
+        # What the fused kernels stream instead of the parameters themselves, all refreshed once per step (the weights only
+        # change in Adam):
+        #   * bf16 mode, forward: a bf16 mirror of the WHOLE flat parameter buffer, written by the Adam kernel in the pass that
+        #     updates the parameters (no launch; `_sync_mirror` re-derives it whenever torch code wrote the parameters);
+        #   * backward: transposed copies of the block linears' weights (W^T fp32, or bf16 in bf16 mode) -- one grouped launch
+        #     on a side stream, issued when the forward reaches the small stages, next to the zero fill of the gradient buffer;
+        #   * the re-laid-out offset-conv weights of the direct conv kernels: one small grouped launch in front of the forward.
         pick = lambda suffixes: [(n, p) for n, p in zip(names, params) if n.endswith(suffixes)]
         self._shadow_w = [(n, p) for n, p in pick(("attn.q.weight", "attn.kv.weight", "attn.proj.weight", "mlp.fc1.weight",
                                                    "mlp.fc2.weight")) if p.dim() == 2 and min(p.shape) <= 384]
         self._conv_w = [(n, p) for n, p in pick(("conv_offset.0.weight",)) if p.dim() == 5 and p.shape[0] <= 16]
-        first = next((n.split(".layers.")[0] + ".layers.0." for n in names if ".layers." in n), None)   # the first stage's prefix
-        self._early = (lambda n: first is not None and n.startswith(first))
+        self._offset_of = {id(p): o for p, o in zip(params, offs)}
         self._prep_plans, self._shadow_bufs = {}, {}
+        self.flat_p16, self._p_version = None, None
         self._prep_stream = torch.cuda.Stream(device=dev)
 
+    def _sync_mirror(self):
+        """bf16 mirror <- parameters (round-to-nearest-even, the rounding of the bf16 kernels); needed after anything but the
+        Adam kernel wrote the parameters: construction, load_state_dict, the restore after the capture warm-up."""
+        if self.flat_p16 is not None:
+            with torch.no_grad():
+                self.flat_p16.copy_(self.flat_p)
+        self._p_version = self.flat_p._version
+
+    def _mirror(self):
+        """The Adam kernel's mirror target in the current arithmetic mode (None in fp32 mode)."""
+        return self.flat_p16 if ops.compute_dtype() == "bf16" else None
+
     def _weight_prep(self):
-        """(early, late, backward) launch plans of the current arithmetic mode: what the first stage's forward streams, what the
-        later stages' forwards stream, what only the backward streams."""
+        """(backward, conv) launch plans of the current arithmetic mode; creates the shadow buffers on first use."""
         mode = ops.compute_dtype()
         plans = self._prep_plans.get(mode)
         if plans is None:
             ws = [p for _, p in self._shadow_w]
+            spec = ops.shadow_spec(False)
+            if spec is not None and self.flat_p16 is None:            # bf16 forward: views of the mirror, same offsets as flat_p
+                self.flat_p16 = torch.empty(self.flat_p.numel(), dtype=spec[2], device=self.flat_p.device)
+                for p in ws:
+                    o = self._offset_of[id(p)]
+                    setattr(p, spec[0], self.flat_p16[o:o + p.numel()].view(p.shape))
+                self._p_version = None                                # -> synchronised by the caller
+            attr, transposed, dtype = ops.shadow_spec(True)
             offs, total = flatten_views(ws, align=8)
-            views = {}
-            for backward in (False, True):
-                spec = ops.shadow_spec(backward)
-                if spec is None:
-                    continue
-                attr, transposed, dtype = spec
-                buf = self._shadow_bufs[attr] = torch.empty(max(total, 8), dtype=dtype, device=self.flat_p.device)
-                for p, o in zip(ws, offs):
-                    r, c = (p.shape[1], p.shape[0]) if transposed else (p.shape[0], p.shape[1])
-                    setattr(p, attr, buf[o:o + p.numel()].view(r, c))
-                    views[(id(p), transposed)] = getattr(p, attr)
-            fwd = lambda sel: ops.WeightPrepPlan([(p.data, views[(id(p), False)], None) for n, p in self._shadow_w
-                                                  if (id(p), False) in views and sel(n)])
-            bwd = ops.WeightPrepPlan([(p.data, None, views[(id(p), True)]) for n, p in self._shadow_w if (id(p), True) in views])
+            buf = self._shadow_bufs[attr] = torch.empty(max(total, 8), dtype=dtype, device=self.flat_p.device)
+            trip = []
+            for p, o in zip(ws, offs):
+                setattr(p, attr, buf[o:o + p.numel()].view(p.shape[1], p.shape[0]))
+                trip.append((p.data, None, getattr(p, attr)))
             if "conv" not in self._shadow_bufs:
-                trip = []
+                ctrip = []
                 for _, p in self._conv_w:
                     p._micf_c3f, p._micf_c3b = ops.conv3_prepared_like(p)
-                    trip.append((p.data, p._micf_c3f, p._micf_c3b))
-                self._shadow_bufs["conv"] = ops.Conv3PrepPlan(trip)
-            plans = self._prep_plans[mode] = (fwd(self._early), fwd(lambda n: not self._early(n)), bwd, self._shadow_bufs["conv"])
+                    ctrip.append((p.data, p._micf_c3f, p._micf_c3b))
+                self._shadow_bufs["conv"] = ops.Conv3PrepPlan(ctrip)
+            plans = self._prep_plans[mode] = (ops.WeightPrepPlan(trip), self._shadow_bufs["conv"])
+        if self._mirror() is not None and self._p_version != self.flat_p._version:
+            self._sync_mirror()
         return plans
 
     # ------------------------------------------------------------------ one optimisation step
@@ -158,19 +172,20 @@ class TrainEngine:
         from . import functional as _fn
         _fn.drop_deferred()                                         # nothing left over from a backward that raised
         with self._scoped_flags():
-            early, late, bwd, conv = self._weight_prep()
+            bwd, conv = self._weight_prep()
             main, side = torch.cuda.current_stream(), self._prep_stream
-            side.wait_stream(main)
-            early.launch()                                          # the first stage's shadow weights + all offset-conv layouts
-            conv.launch()
-            with torch.cuda.stream(side):                           # under the first stage: everything else the step needs later
-                late.launch()
-                ops.zero_(self.flat_g)                              # optimizer.zero_grad()        train.py:183
-                bwd.launch()
-            _fn.park_entry_hook(lambda: main.wait_stream(side))     # joined where the second stage starts
+            conv.launch()                                           # offset-conv weight layouts (one small launch)
+
+            def backward_prep():                                    # under the latency-bound small stages of the forward
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    ops.zero_(self.flat_g)                          # optimizer.zero_grad()        train.py:183
+                    bwd.launch()                                    # W^T shadows of the fused backward
+            _fn.park_entry_hook(backward_prep, at=3)
             logits = self.model(x)                                  #                              train.py:185
             loss = self.criterion(logits, target)                   #                              train.py:187
-            _fn.run_entry_hook(force=True)                          # (single-stage models: joined here at the latest)
+            _fn.run_entry_hook(force=True)                          # (fewer than 3 stages: launched here)
+            main.wait_stream(side)
             loss.backward()                                         #                              train.py:200
             if flush:
                 _fn.flush_wgrad()                                   # queued linear weight gradients, grouped launches
@@ -180,7 +195,7 @@ class TrainEngine:
     def _adam(self, grad_scale):
         ops.adam_tick(self.adam_state, self.base_lr, self.eta_min, self.t_max)   # scheduler (per iteration) train.py:206-207
         ops.adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.adam_state,
-                      self.betas[0], self.betas[1], self.eps, grad_scale=grad_scale)          # optimizer.step()   train.py:201
+                      self.betas[0], self.betas[1], self.eps, grad_scale=grad_scale, mirror=self._mirror())          # optimizer.step()   train.py:201
 
     def _update(self):
         """Un-overlapped form (eager steps): all-reduce(sum) the whole flat gradient, then Adam reads it as g / world."""
@@ -251,6 +266,8 @@ class TrainEngine:
         else:
             if self._graph is None:
                 self._capture(x, target)
+            if self._p_version != self.flat_p._version:             # torch code wrote the parameters (load_state_dict, ...)
+                self._sync_mirror()
             self._static[0].copy_(x, non_blocking=True)
             self._static[1].copy_(target, non_blocking=True)
             self._graph.replay()
@@ -284,6 +301,7 @@ class TrainEngine:
                 dst.copy_(src)
         torch.set_rng_state(rng_cpu)
         torch.cuda.set_rng_state(rng_dev, sx.device)
+        self._sync_mirror()                                         # the restore above is not the Adam kernel
         del keep
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):

@@ -104,6 +104,7 @@ def _ln_defer(on):
 # gradients queued so far on a side stream, so they run under the rest of the backward chain (which is latency-bound, not
 # throughput-bound, since the blocks were fused) instead of in a tail after it.  join_wgrad_stream() re-joins before Adam.
 FLUSH_POINTS = False
+FLUSH_MAX_TOKENS = int(__import__("os").environ.get("MICF_FLUSH_MAX_TOKENS", 1 << 30))   # (measured: flushing at every point wins, 19.6 vs 20.2 ms small stages only)
 _WSIDE = {}
 _WSIDE_USED = set()
 
@@ -142,19 +143,20 @@ def join_wgrad_stream():
     _WSIDE_USED.clear()
 
 
-# forward side of a flush point: the engine may park a callable here that must run before the SECOND stage starts (it joins the
-# stream that prepares the later stages' shadow weights while the first stage already runs)
-_ENTRY_HOOK = [None, 0]             # callable, stage entries seen since it was parked
+# forward side of a stage entry: the engine may park a callable here that runs when the forward reaches its n-th stage (work
+# only the backward needs -- zeroing the gradient buffer, transposed shadow weights -- is launched on a side stream under the
+# latency-bound small stages instead of in front of the step)
+_ENTRY_HOOK = [None, 0, 0]          # callable, the stage entry it waits for, stage entries seen since it was parked
 
 
-def park_entry_hook(fn):
-    _ENTRY_HOOK[0], _ENTRY_HOOK[1] = fn, 0
+def park_entry_hook(fn, at):
+    _ENTRY_HOOK[0], _ENTRY_HOOK[1], _ENTRY_HOOK[2] = fn, at, 0
 
 
 def run_entry_hook(force=False):
-    """Called at every stage entry: runs the parked callable at the second entry (or now, `force`)."""
-    _ENTRY_HOOK[1] += 1
-    if _ENTRY_HOOK[0] is not None and (force or _ENTRY_HOOK[1] >= 2):
+    """Called at every stage entry: runs the parked callable at its entry (or now, `force`)."""
+    _ENTRY_HOOK[2] += 1
+    if _ENTRY_HOOK[0] is not None and (force or _ENTRY_HOOK[2] >= _ENTRY_HOOK[1]):
         hook, _ENTRY_HOOK[0] = _ENTRY_HOOK[0], None
         hook()
 
@@ -166,7 +168,9 @@ class FlushPointFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dx, dxa):
-        if FLUSH_POINTS and DEFER_WGRAD:
+        # (a token cap exists for experiments: restricting the flushes to the latency-bound small stages was measured slower --
+        # the weight gradients of the big stages then pile up in the tail)
+        if FLUSH_POINTS and DEFER_WGRAD and dx.numel() // dx.shape[-1] <= FLUSH_MAX_TOKENS:
             flush_wgrad_side()
         return dx, dxa
 

@@ -407,7 +407,7 @@ class BasicLayer(nn.Module):
         return x, xa
 
     def forward(self, x, xa):
-        Fn.run_entry_hook()                            # (engine: the later stages' shadow weights are ready from the 2nd stage on)
+        Fn.run_entry_hook()                            # (engine: side work parked for this point of the forward)
         if Fn.FLUSH_POINTS and x.requires_grad:
             x, xa = Fn.FlushPointFn.apply(x, xa)       # backward: launch this stage's queued weight gradients on a side stream
         if self._pair_fusable(x, xa):

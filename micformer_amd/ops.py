@@ -548,9 +548,12 @@ def adam_tick(state, base_lr, eta_min, t_max):
     call("micf_adam_tick", ptr(state), float(base_lr), float(eta_min), int(t_max))
 
 
-def adam_step(p, g, m, v, state, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+def adam_step(p, g, m, v, state, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, mirror=None):
+    """mirror: optional bfloat16 tensor of p's size that receives bf16(p) after the update (same pass)."""
+    if mirror is not None and (mirror.dtype != torch.bfloat16 or mirror.numel() != p.numel()):
+        raise _lib.MicfError("the Adam mirror must be a bfloat16 tensor of the parameter buffer's size")
     call("micf_adam_step", f32(p), f32(g), f32(m), f32(v), p.numel(), ptr(state), float(beta1), float(beta2), float(eps),
-         float(grad_scale),
+         float(grad_scale), ptr(mirror),
          cost=_cost(12 * p.numel(), p, p, g, m, m, v, v))
 
 

@@ -14,6 +14,7 @@ import argparse, collections, csv, json, os, re
 ap = argparse.ArgumentParser()
 ap.add_argument("dir"); ap.add_argument("out_csv")
 ap.add_argument("--key"); ap.add_argument("--kernels"); ap.add_argument("--json")
+ap.add_argument("--calls-per-step", type=float, default=1.0, help="C-ABI calls of the --key entry point per step (bytes are divided by it)")
 args = ap.parse_args()
 
 
@@ -51,9 +52,10 @@ if args.key and args.json:
     table = {}
     if os.path.exists(args.json):
         table = json.load(open(args.json))
-    table[args.key] = {"kernels": ks, "launches_per_call": round(sum(r[2] for r in sel), 1),
-                       "fetch_bytes_per_call": round(sum(r[3] for r in sel)), "write_bytes_per_call": round(sum(r[4] for r in sel)),
-                       "hbm_bytes_per_launch": round(sum(r[0] for r in sel)),
-                       "note": "per C-ABI call (one per step); 2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes"}
+    n = args.calls_per_step
+    table[args.key] = {"kernels": ks, "launches_per_call": round(sum(r[2] for r in sel) / n, 2),
+                       "fetch_bytes_per_call": round(sum(r[3] for r in sel) / n), "write_bytes_per_call": round(sum(r[4] for r in sel) / n),
+                       "hbm_bytes_per_launch": round(sum(r[0] for r in sel) / n),
+                       "note": f"per C-ABI call ({n:g} per step); 2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes"}
     json.dump(table, open(args.json, "w"), indent=1)
     print("wrote", args.json, table[args.key])

@@ -1,28 +1,36 @@
 #!/bin/bash
-# Run ON THE GPU BOX (through gpurun) from the repo root: regenerates the evidence kept under profiles/ into gpurun_out/r01/.
-#   gpurun --timeout 1500 -- 'bash tools/refresh_profiles.sh'   then   cp gpurun_out/r01/* profiles/
+# Run ON THE GPU BOX (through gpurun) from the repo root: regenerates the evidence kept under profiles/ into gpurun_out/$R/.
+#   gpurun --timeout 1800 -- 'bash tools/refresh_profiles.sh r02'   then   cp gpurun_out/r02/* profiles/
 set -u
-OUT=gpurun_out/r01
+R=${1:-r02}
+OUT=gpurun_out/$R
 mkdir -p $OUT
-python bench.py > $OUT/r01_bench.json 2> $OUT/bench.err
+python bench.py > $OUT/${R}_bench.json 2> $OUT/bench.err
+python bench.py --dtype fp32 --no-cpu-baseline > $OUT/${R}_bench_fp32.json 2>> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 # kernel trace + stats of the bench command (graph replay); the trace itself is large: keep the derived tables only
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tmp -o b -- python bench.py --steps 10 --warmup 0 --no-cpu-baseline --no-roofline \
-  > $OUT/r01_bench_under_rocprof.json 2> $OUT/rocprof.err
-cp $OUT/tmp/b_kernel_stats.csv $OUT/r01_bench_kernel_stats.csv
-python tools/trace_concurrency.py $OUT/tmp/b_kernel_trace.csv > $OUT/r01_concurrency.txt
+  > $OUT/${R}_bench_under_rocprof.json 2> $OUT/rocprof.err
+cp $OUT/tmp/b_kernel_stats.csv $OUT/${R}_bench_kernel_stats.csv
+python tools/trace_concurrency.py $OUT/tmp/b_kernel_trace.csv > $OUT/${R}_concurrency.txt
+python tools/trace_stages.py $OUT/tmp/b_kernel_trace.csv > $OUT/${R}_stages.txt
 # by (kernel, grid) from an eager run (graph replays keep the grid too, but eager separates the warm-up cleanly)
 rocprofv3 --kernel-trace --output-format csv -d $OUT/tmp -o e -- python bench.py --steps 4 --warmup 0 --no-cpu-baseline --no-roofline --no-graph \
   > /dev/null 2>> $OUT/rocprof.err
-python tools/trace_by_shape.py $OUT/tmp/e_kernel_trace.csv 4 > $OUT/r01_kernels_by_shape.txt
+python tools/trace_by_shape.py $OUT/tmp/e_kernel_trace.csv 4 > $OUT/${R}_kernels_by_shape.txt
 # HBM-side traffic: separate PMC passes (never combined with other trace domains)
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc -o $c -- python bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-roofline --no-graph \
     > /dev/null 2>> $OUT/rocprof.err
 done
-KEY=$(python -c "import json;print(json.load(open('$OUT/r01_bench.json'))['roofline']['kernel'])")
-echo "dominant kernel: $KEY" > $OUT/r01_pmc_summary.txt
-python tools/pmc_summary.py $OUT/pmc $OUT/r01_pmc_hbm_by_kernel.csv --key "$KEY" --kernels "${PMC_KERNELS:-wgrad_grouped_kernel,wgrad_grouped_reduce_kernel}" --json $OUT/pmc_traffic.json >> $OUT/r01_pmc_summary.txt
-rm -rf $OUT/tmp $OUT/pmc/*_kernel_trace.csv $OUT/pmc/*_counter_collection.csv $OUT/pmc/*agent_info.csv
-rmdir $OUT/pmc 2>/dev/null
-tail -3 $OUT/r01_pmc_summary.txt; head -c 300 $OUT/r01_bench.json
+KEY=$(python -c "import json;print(json.load(open('$OUT/${R}_bench.json'))['roofline']['kernel'])")
+CALLS=$(python -c "import json;print(json.load(open('$OUT/${R}_bench.json'))['roofline']['launches_per_step'])")
+echo "dominant kernel: $KEY ($CALLS calls per step)" > $OUT/${R}_pmc_summary.txt
+python tools/pmc_summary.py $OUT/pmc $OUT/${R}_pmc_hbm_by_kernel.csv --key "$KEY" --kernels "${PMC_KERNELS:-block_bwd_kernel<48}" --calls-per-step $CALLS \
+  --json $OUT/pmc_traffic.json >> $OUT/${R}_pmc_summary.txt
+# matrix-core utilisation per kernel (its own pass)
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma -o m -- \
+  python bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-roofline --no-graph > /dev/null 2>> $OUT/rocprof.err
+python tools/mfma_summary.py $OUT/mfma 30 > $OUT/${R}_mfma_util.txt
+rm -rf $OUT/tmp $OUT/pmc $OUT/mfma
+tail -3 $OUT/${R}_pmc_summary.txt; head -12 $OUT/${R}_mfma_util.txt; head -c 400 $OUT/${R}_bench.json

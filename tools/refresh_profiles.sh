@@ -29,8 +29,8 @@ echo "dominant kernel: $KEY ($CALLS calls per step)" > $OUT/${R}_pmc_summary.txt
 python tools/pmc_summary.py $OUT/pmc $OUT/${R}_pmc_hbm_by_kernel.csv --key "$KEY" --kernels "${PMC_KERNELS:-block_bwd_kernel<48}" --calls-per-step $CALLS \
   --json $OUT/pmc_traffic.json >> $OUT/${R}_pmc_summary.txt
 # matrix-core utilisation per kernel (its own pass)
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma -o m -- \
-  python bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-roofline --no-graph > /dev/null 2>> $OUT/rocprof.err
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma -o m -- \
+  python bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-roofline > /dev/null 2>> $OUT/rocprof.err
 python tools/mfma_summary.py $OUT/mfma 30 > $OUT/${R}_mfma_util.txt
 rm -rf $OUT/tmp $OUT/pmc $OUT/mfma
 tail -3 $OUT/${R}_pmc_summary.txt; head -12 $OUT/${R}_mfma_util.txt; head -c 400 $OUT/${R}_bench.json

@@ -93,7 +93,7 @@ __device__ __forceinline__ void ln_bwd_tile(const float* D, float* A, int S, int
       *reinterpret_cast<float4*>(mine + C + 4 * c4) = ab[k];
     }
   }
-  __syncthreads();
+  lds_barrier();
   if (part) {
     for (int c = tid; c < 2 * C; c += NTHR) {
       float s = 0.f;
@@ -102,7 +102,7 @@ __device__ __forceinline__ void ln_bwd_tile(const float* D, float* A, int S, int
       part[c] = s;
     }
   }
-  __syncthreads();
+  lds_barrier();
 }
 
 template <int C, int HD, int TJ, int NW, bool BF16>
@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) block_bwd_kernel(con
   extern __shared__ __attribute__((aligned(1024))) float lds[];
   constexpr int C4 = C >> 2, S = C + 4, SU = 3 * C + 4, Hd = 4 * C;
   float* ring = lds;
-  float* A1 = ring + NW * kFusedScratchPerWave;
+  float* A1 = ring + block_bwd_scratch_floats(TM, C / HD, NTHR);
   float* A2 = A1 + TM * S;
   float* U = A2 + TM * S;
   float* sc1 = U + TM * SU;
@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) block_bwd_kernel(con
     }
     tok[tid] = tk; sc1[tid] = v1; sc2[tid] = v2;
   }
-  __syncthreads();
+  lds_barrier();
 
   // ---- dy rows -> A1
 #pragma unroll 1
@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) block_bwd_kernel(con
       for (int c4 = l16; c4 < X4; c4 += 16)
         *reinterpret_cast<float4*>(U + row * SU + 4 * c4) = tk >= 0 ? ld4g(g.h + (int64_t)tk * Hd + c0 + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    __syncthreads();
+    lds_barrier();
     gemm_phase<TJ, NSL, 1, C, NW, BF16>(w2t + (int64_t)c0 * C, hc, A1, nullptr, 0, nullptr, S, U, SU, EpiGeluGrad{sc2});
 #pragma unroll 1
     for (int pass = 0; pass < NPASS; ++pass) {
@@ -198,7 +198,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) block_bwd_kernel(con
       *reinterpret_cast<float4*>(U + row * SU + 4 * c4) = v;
     }
   }
-  __syncthreads();
+  lds_barrier();
 
   // ---- attention backward in place on U.  Thread = (window, row i, head); batches of whole windows.
   {
@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) block_bwd_kernel(con
           }
         }
       }
-      __syncthreads();
+      lds_barrier();
       if (active) {                                     // now as key / value row j = i: gather column j of P and dS from the mates
 #pragma unroll
         for (int d = 0; d < HD; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) block_bwd_kernel(con
           }
         }
       }
-      __syncthreads();                                  // every read of this batch's q / k / v rows is done: overwrite in place
+      lds_barrier();                                  // every read of this batch's q / k / v rows is done: overwrite in place
       if (active) {
 #pragma unroll
         for (int d = 0; d < HD; d += 4) {
@@ -289,7 +289,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) block_bwd_kernel(con
           *reinterpret_cast<float4*>(U + row * SU + 2 * C + hoff + d) = make_float4(dv[d], dv[d + 1], dv[d + 2], dv[d + 3]);
         }
       }
-      __syncthreads();
+      lds_barrier();
     }
   }
 
@@ -324,7 +324,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) block_bwd_kernel(con
       if (tk < 0) continue;
       for (int c4 = l16; c4 < C4; c4 += 16) st4g(g.dx + (int64_t)tk * C + 4 * c4, *reinterpret_cast<const float4*>(A2 + row * S + 4 * c4));
     }
-    __syncthreads();
+    lds_barrier();
     gemm_phase<TJ, NSL, 2, 2 * C, NW, BF16>(wkvt, C, U + C, nullptr, 0, nullptr, SU, A2, S, EpiStore{});
 #pragma unroll 1
     for (int pass = 0; pass < NPASS; ++pass) {
@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) block_bwd_kernel(con
 template <int C, int HD, int TJ>
 static int launch_bwd(const BlkBwdArgs& a, int dtype, hipStream_t s) {
   constexpr int TM = 16 * TJ, NW = C >= 192 ? 8 : 4;
-  const size_t lds = block_lds_floats(TM, C, 4 * C, NW) * sizeof(float);
+  const size_t lds = block_lds_floats(TM, C, block_bwd_scratch_floats(TM, C / HD, 64 * NW), 0) * sizeof(float);
   if (lds > 160 * 1024) return MICF_EUNSUPPORTED;
   const unsigned grid = a.G == 2 ? (unsigned)((a.tiles + 3) / 4 * 8) : (unsigned)a.tiles;
   static std::once_flag once;

@@ -21,6 +21,13 @@
 
 namespace micf {
 
+// Workgroup barrier of the fused block kernels.  Everything the threads of a tile exchange goes through LDS; global memory is
+// only read (inputs) and written (outputs, each address by one thread), never re-read inside the kernel.  __syncthreads()
+// would also drain the vector-memory counter (s_waitcnt vmcnt(0)): every output store and every early-issued input load would
+// be waited for at the next barrier, i.e. ~20 exposed HBM round trips per tile.  This barrier orders LDS only; the compiler still
+// waits for a load's registers where they are consumed.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ---- epilogues of a GEMM phase: called with the LDS destination of 4 consecutive outputs x..x+3 of token row `trow`.
 // They touch LDS only (the GEMM loop must not issue vector memory operations besides its DMAs).
 struct EpiStore {
@@ -167,7 +174,7 @@ __device__ __forceinline__ void gemm_phase_f32w(const float* __restrict__ W0, in
       if (u + 1 < nunits) compute_unit(u + 1, fb);
     }
   }
-  __syncthreads();
+  lds_barrier();
 }
 
 // The same phase with bf16 WEIGHTS (shadow copies written once per step by micf_weight_prep_grouped: half the bytes and half
@@ -241,7 +248,7 @@ __device__ __forceinline__ void gemm_phase_bf16w(const uint16_t* __restrict__ W0
       if (u + 1 < nunits) compute_unit(u + 1, fb);
     }
   }
-  __syncthreads();
+  lds_barrier();
 }
 
 // dispatch on the weight type: float (exact fp32 MFMA) or uint16_t (bf16 shadow weights, bf16 MFMA)
@@ -282,11 +289,13 @@ inline TileGeo make_tile_geo(int B, int D, int H, int W) {
   return g;
 }
 
-constexpr int kFusedScratchPerWave = 1024;   // floats: the attention backward's P / dS exchange (16 floats per thread)
-// LDS floats of a fused block kernel: scratch + A1, A2 [TM][C+4] + U [TM][3C+4] + row scales / token ids +
-// the staged parameter vectors (9C + hidden)
-inline size_t block_lds_floats(int TM, int C, int hidden, int scratch_waves) {
-  return (size_t)scratch_waves * kFusedScratchPerWave + (size_t)TM * (2 * (C + 4) + 3 * C + 4) + 3 * TM + 9 * C + hidden;
+// floats of the attention backward's P / dS exchange: 16 per thread that takes part (one per attention row and head, whole
+// windows per batch)
+constexpr int block_bwd_scratch_floats(int TM, int heads, int nthr) { return (TM * heads < nthr ? TM * heads : nthr) * 16; }
+// LDS floats of a fused block kernel: scratch + A1, A2 [TM][C+4] + U [TM][3C+4] + row scales / token ids + `params` (the
+// forward stages its 9C + hidden bias / LayerNorm vectors; the backward keeps none)
+inline size_t block_lds_floats(int TM, int C, int scratch, int params) {
+  return (size_t)scratch + (size_t)TM * (2 * (C + 4) + 3 * C + 4) + 3 * TM + params;
 }
 // waves per workgroup: 8 where a launch has too few tiles to fill the chip and every tile streams megabytes of weights
 // (C = 192: 128 tiles of 16 tokens at the base model's 8^3 stage) -- the x tiles of a phase are then dealt to 8 waves

@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
       *reinterpret_cast<float4*>(PV + e) = ld4g(sp + (e - so));
     }
   }
-  __syncthreads();
+  lds_barrier();
 
   // ---- LayerNorm 1 straight from HBM: all rows of this lane group in flight at once -> registers -> (xn -> A1 + HBM,
   // statistics); cross: the K/V source rows -> A2
@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
       if (l16 == 0 && tk >= 0) { g.stats[tk] = mu; g.stats[T + tk] = rs; }
     }
   }
-  __syncthreads();
+  lds_barrier();
 
   // ---- q | k | v (+ bias) -> U, then out to HBM
   if (!(a.debug & 4)) {
@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
       }
     }
   }
-  __syncthreads();
+  lds_barrier();
 
   // ---- proj (+ bp) -> A2; x1 = x + s1 * proj -> A2 + HBM; LayerNorm 2 of the same registers -> A1 (xn2) + HBM
   if (!(a.debug & 4)) gemm_phase<TJ, NSL, 1, C, NW, BF16>(wp, C, A1, nullptr, 0, nullptr, S, A2, S, EpiBias{p_bp});
@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
       if (l16 == 0 && tk >= 0) { g.stats[2 * T + tk] = mu; g.stats[3 * T + tk] = rs; }
     }
   }
-  __syncthreads();
+  lds_barrier();
 
   // ---- MLP in hidden chunks of <= 2C (<= 3C fits U): fc1 chunk (+ b1) -> U; save h, GELU in place, save g; fc2 chunk
   // accumulates s2 * (g W2^T) into A2 (which holds x1)
@@ -299,7 +299,7 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     if (!(a.debug & 4)) gemm_phase<TJ, NSL, 2, Hd, NW, BF16>(w2 + c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiAccScale{sc2});
   }
 
@@ -323,7 +323,7 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
 template <int C, int HD, int TJ>
 static int launch_fwd(const BlkFwdArgs& a, int dtype, hipStream_t s) {
   constexpr int TM = 16 * TJ, NW = C >= 192 ? 8 : 4;
-  const size_t lds = block_lds_floats(TM, C, 4 * C, 0) * sizeof(float);
+  const size_t lds = block_lds_floats(TM, C, 0, 9 * C + 4 * C) * sizeof(float);
   if (lds > 160 * 1024) return MICF_EUNSUPPORTED;
   const unsigned grid = a.G == 2 ? (unsigned)((a.tiles + 3) / 4 * 8) : (unsigned)a.tiles;
   static std::once_flag once;
@@ -354,8 +354,8 @@ extern "C" int micf_block_tile_tokens(int B, int D, int H, int W, int C, int hea
   // at the base model's 4^3 stage); block_wide.hip spreads every weight matrix over the chip instead.
   // token groups of 16 per workgroup (measured on MI355X, base shapes, batch 2): forward and backward tile independently
   int tj = 0;
-  if (C == 48 && hd == 16) tj = 2;
-  else if (C == 96 && hd == 16) tj = backward ? 1 : 2;
+  if (C == 48 && hd == 16) tj = backward ? 1 : 2;
+  else if (C == 96 && hd == 16) tj = backward ? 2 : 1;
   else if ((C == 96 || C == 192) && (hd == 16 || hd == 32)) tj = 1;
   if (const char* e = getenv(backward ? "MICF_BLOCK_TJ_BWD" : "MICF_BLOCK_TJ")) {
     const int v = atoi(e);

@@ -23,31 +23,94 @@ struct BlkBwdArgs {
   float scale;
 };
 
-// LayerNorm backward of the rows held in LDS tile `D` (gradient w.r.t. the normalised output, pre-gain) against the HBM rows
-// `xsrc`: out = addt + rs * (g d - mean(g d) - xh mean(g d xh)).  addt / out are LDS tile A (in place) and HBM `hout`.
-// The per-tile column sums of d * xh and d go through `scratch` (LDS, >= 16 * 2C floats) to part[2C].
-template <int TJ, int VPL, int NW>
-__device__ __forceinline__ void ln_bwd_tile(const float* D, float* A, int S, int C, const float* __restrict__ xsrc,
-                                            const float* __restrict__ mean, const float* __restrict__ rstd,
-                                            const float* __restrict__ gamma, const int* tok, float* __restrict__ hout,
-                                            float* __restrict__ hout2, float* scratch, float* __restrict__ part) {
+// Rows of a [TM][4 * X4] tile as the element-wise passes distribute them: pass p, wave w, lane group rg -> row p * RPP + 4 w + rg;
+// lane l16 covers the float4 columns l16, l16 + 16, ...  All of a tile's global inputs are REQUESTED at the top of the kernel into
+// such register sets (one exposed HBM round trip per tile instead of one per phase: the barriers order LDS only, so the loads stay
+// in flight across them) and committed to LDS where the phase that needs them starts.
+template <int TM, int NW, int X4>
+struct RowRegs {
+  static constexpr int RPP = 4 * NW, NPASS = (TM + RPP - 1) / RPP, K = (X4 + 15) / 16;
+  float4 v[NPASS][K];
+  template <class Addr>
+  __device__ __forceinline__ void load(const int* tok, const Addr addr) {       // addr(token, float4 column) -> const float*
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15, rg = lane >> 4;
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+      const int row = pass * RPP + wave * 4 + rg;
+      const int tk = row < TM ? tok[row] : -1;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const int c4 = l16 + 16 * k;
+        const bool ok = tk >= 0 && c4 < X4;       // (branch-free: out-of-range lanes read a valid address and drop the value)
+        const float4 t = ld4g(addr(tk >= 0 ? tk : 0, c4 < X4 ? c4 : X4 - 1));
+        v[pass][k] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  }
+  __device__ __forceinline__ void commit(float* dst, int stride) const {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15, rg = lane >> 4;
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+      const int row = pass * RPP + wave * 4 + rg;
+      if (row >= TM) continue;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const int c4 = l16 + 16 * k;
+        if (c4 < X4) *reinterpret_cast<float4*>(dst + row * stride + 4 * c4) = v[pass][k];
+      }
+    }
+  }
+};
+// ... plus the LayerNorm statistics of the rows and the gain vector: what a LayerNorm backward over the tile reads from HBM
+template <int TM, int NW, int C>
+struct LnRegs {
+  RowRegs<TM, NW, C / 4> x;
+  float mu[RowRegs<TM, NW, C / 4>::NPASS], rs[RowRegs<TM, NW, C / 4>::NPASS];
+  float4 gm[(C + 63) / 64];
+  __device__ __forceinline__ void load(const int* tok, const float* __restrict__ xsrc, const float* __restrict__ mean,
+                                       const float* __restrict__ rstd, const float* __restrict__ gamma) {
+    constexpr int RPP = 4 * NW, NPASS = RowRegs<TM, NW, C / 4>::NPASS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15, rg = lane >> 4;
+    x.load(tok, [&](int tk, int c4) { return xsrc + (int64_t)tk * C + 4 * c4; });
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+      const int row = pass * RPP + wave * 4 + rg;
+      const int tk = row < TM ? tok[row] : -1;
+      const float m = mean[tk >= 0 ? tk : 0], r = rstd[tk >= 0 ? tk : 0];
+      mu[pass] = tk >= 0 ? m : 0.f; rs[pass] = tk >= 0 ? r : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < (C + 63) / 64; ++k) {
+      const int c4 = l16 + 16 * k;
+      const float4 t = ld4g(gamma + 4 * (c4 < C / 4 ? c4 : C / 4 - 1));
+      gm[k] = c4 < C / 4 ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+};
+
+// LayerNorm backward of the rows held in LDS tile `D` (gradient w.r.t. the normalised output, pre-gain) against the preloaded
+// LayerNorm input rows `in`: out = addt + rs * (g d - mean(g d) - xh mean(g d xh)).  addt / out are LDS tile A (in place) and
+// HBM `hout`.  The per-tile column sums of d * xh and d go through `scratch` (LDS, >= 16 * 2C floats) to part[2C].
+template <int TJ, int VPL, int NW, int C>
+__device__ __forceinline__ void ln_bwd_tile(const float* D, float* A, int S, const LnRegs<16 * TJ, NW, C>& in, const int* tok,
+                                            float* __restrict__ hout, float* __restrict__ hout2, float* scratch,
+                                            float* __restrict__ part) {
   constexpr int TM = 16 * TJ, NTHR = 64 * NW, RPP = 4 * NW, NPASS = (TM + RPP - 1) / RPP, NPR = RPP < TM ? RPP : TM;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, rg = lane >> 4;
-  const int C4 = C >> 2;
+  constexpr int C4 = C >> 2;
   const float invC = 1.0f / (float)C;
   float4 ag[VPL], ab[VPL], gm[VPL];
 #pragma unroll
   for (int k = 0; k < VPL; ++k) {
     ag[k] = make_float4(0.f, 0.f, 0.f, 0.f); ab[k] = ag[k];
-    const int c4 = l16 + 16 * k;
-    gm[k] = c4 < C4 ? ld4g(gamma + 4 * c4) : ag[k];
+    gm[k] = in.gm[k];
   }
-#pragma unroll 1
+#pragma unroll
   for (int pass = 0; pass < NPASS; ++pass) {
     const int row = pass * RPP + wave * 4 + rg;
     if (row >= TM) continue;
     const int tk = tok[row];
-    const float mu = tk >= 0 ? mean[tk] : 0.f, rs = tk >= 0 ? rstd[tk] : 0.f;
+    const float mu = in.mu[pass], rs = in.rs[pass];
     float4 xh[VPL], d[VPL];
     float sa = 0.f, sb = 0.f;
 #pragma unroll
@@ -55,7 +118,7 @@ __device__ __forceinline__ void ln_bwd_tile(const float* D, float* A, int S, int
       const int c4 = l16 + 16 * k;
       xh[k] = make_float4(0.f, 0.f, 0.f, 0.f); d[k] = xh[k];
       if (c4 < C4 && tk >= 0) {
-        const float4 v = ld4g(xsrc + (int64_t)tk * C + 4 * c4);
+        const float4 v = in.x.v[pass][k];
         d[k] = *reinterpret_cast<const float4*>(D + row * S + 4 * c4);
         xh[k] = make_float4((v.x - mu) * rs, (v.y - mu) * rs, (v.z - mu) * rs, (v.w - mu) * rs);
         const float g0 = gm[k].x * d[k].x, g1 = gm[k].y * d[k].y, g2 = gm[k].z * d[k].z, g3 = gm[k].w * d[k].w;
@@ -65,7 +128,7 @@ __device__ __forceinline__ void ln_bwd_tile(const float* D, float* A, int S, int
         ab[k].x += d[k].x; ab[k].y += d[k].y; ab[k].z += d[k].z; ab[k].w += d[k].w;
       }
     }
-    const float Am = sum16(sa) * invC, Bm = sum16(sb) * invC;
+  const float Am = sum16(sa) * invC, Bm = sum16(sb) * invC;
 #pragma unroll
     for (int k = 0; k < VPL; ++k) {
       const int c4 = l16 + 16 * k;
@@ -106,7 +169,7 @@ __device__ __forceinline__ void ln_bwd_tile(const float* D, float* A, int S, int
 }
 
 template <int C, int HD, int TJ, int NW, bool BF16>
-__global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) block_bwd_kernel(const BlkBwdArgs a) {
+__global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 4 : 2)) block_bwd_kernel(const BlkBwdArgs a) {
   constexpr int TM = 16 * TJ, VPL = (C + 63) / 64, NSL = C / 16, NTHR = 64 * NW, RPP = 4 * NW, NPASS = (TM + RPP - 1) / RPP;
   extern __shared__ __attribute__((aligned(1024))) float lds[];
   constexpr int C4 = C >> 2, S = C + 4, SU = 3 * C + 4, Hd = 4 * C;
@@ -143,29 +206,31 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) block_bwd_kernel(con
   }
   lds_barrier();
 
+  // ---- request every global input of the tile (see RowRegs)
+  constexpr int HC = 2 * C;
+  RowRegs<TM, NW, C4> r_dy;
+  RowRegs<TM, NW, HC / 4> r_h[Hd / HC];
+  RowRegs<TM, NW, 3 * C4> r_qkv;
+  LnRegs<TM, NW, C> r_ln2, r_ln1;
+  r_dy.load(tok, [&](int tk, int c4) { return g.dy + (int64_t)tk * C + 4 * c4; });
+#pragma unroll
+  for (int ch = 0; ch < Hd / HC; ++ch) r_h[ch].load(tok, [&](int tk, int c4) { return g.h + (int64_t)tk * Hd + ch * HC + 4 * c4; });
+  r_ln2.load(tok, g.x1, g.stats + 2 * T, g.stats + 3 * T, g.ln2_g);
+  r_qkv.load(tok, [&](int tk, int c4) {
+    return c4 < C4 ? g.q + (int64_t)tk * C + 4 * c4 : g.kv + (int64_t)tk * 2 * C + 4 * (c4 - C4);
+  });
+  if (!g.dxs) r_ln1.load(tok, g.x, g.stats, g.stats + T, g.ln1_g);
+
   // ---- dy rows -> A1
-#pragma unroll 1
-  for (int pass = 0; pass < NPASS; ++pass) {
-    const int row = pass * RPP + wave * 4 + rg;
-    if (row >= TM) continue;
-    const int tk = tok[row];
-    for (int c4 = l16; c4 < C4; c4 += 16)
-      *reinterpret_cast<float4*>(A1 + row * S + 4 * c4) = tk >= 0 ? ld4g(g.dy + (int64_t)tk * C + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
+  r_dy.commit(A1, S);
 
   // ---- MLP backward in hidden chunks: h chunk -> U;  U <- s2 (dy W2) GELU'(h) = dh (saved);  A2 (+)= dh W1
-  constexpr int HC = 2 * C;
-  for (int c0 = 0; c0 < Hd; c0 += HC) {
+#pragma unroll
+  for (int ch = 0; ch < Hd / HC; ++ch) {
+    const int c0 = ch * HC;
     constexpr int hc = HC;
     constexpr int X4 = hc >> 2;
-#pragma unroll 1
-    for (int pass = 0; pass < NPASS; ++pass) {
-      const int row = pass * RPP + wave * 4 + rg;
-      if (row >= TM) continue;
-      const int tk = tok[row];
-      for (int c4 = l16; c4 < X4; c4 += 16)
-        *reinterpret_cast<float4*>(U + row * SU + 4 * c4) = tk >= 0 ? ld4g(g.h + (int64_t)tk * Hd + c0 + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    r_h[ch].commit(U, SU);
     lds_barrier();
     gemm_phase<TJ, NSL, 1, C, NW, BF16>(w2t + (int64_t)c0 * C, hc, A1, nullptr, 0, nullptr, S, U, SU, EpiGeluGrad{sc2});
 #pragma unroll 1
@@ -177,27 +242,16 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) block_bwd_kernel(con
       for (int c4 = l16; c4 < X4; c4 += 16)
         st4g(g.dh + (int64_t)tk * Hd + c0 + 4 * c4, *reinterpret_cast<const float4*>(U + row * SU + 4 * c4));
     }
-    if (c0 == 0) gemm_phase<TJ, NSL, 2, Hd, NW, BF16>(w1t + c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiStore{});
+    if (ch == 0) gemm_phase<TJ, NSL, 2, Hd, NW, BF16>(w1t + c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiStore{});
     else gemm_phase<TJ, NSL, 2, Hd, NW, BF16>(w1t + c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiAcc{});
   }
 
   // ---- dx1 = dy + LN2'(A2) -> A1 + HBM; LN2 gain / bias partials
-  ln_bwd_tile<TJ, VPL, NW>(A2, A1, S, C, g.x1, g.stats + 2 * T, g.stats + 3 * T, g.ln2_g, tok, g.dx1, g.dx1_copy, U,
-                       g.ln2_part ? g.ln2_part + (int64_t)tile * 2 * C : nullptr);
+  ln_bwd_tile<TJ, VPL, NW, C>(A2, A1, S, r_ln2, tok, g.dx1, g.dx1_copy, U, g.ln2_part ? g.ln2_part + (int64_t)tile * 2 * C : nullptr);
 
   // ---- do = s1 dx1 Wp -> A2;  q | k | v rows -> U
   gemm_phase<TJ, NSL, 1, C, NW, BF16>(wpt, C, A1, nullptr, 0, nullptr, S, A2, S, EpiStoreScale{sc1});
-#pragma unroll 1
-  for (int pass = 0; pass < NPASS; ++pass) {
-    const int row = pass * RPP + wave * 4 + rg;
-    if (row >= TM) continue;
-    const int tk = tok[row];
-    for (int c4 = l16; c4 < 3 * C4; c4 += 16) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (tk >= 0) v = c4 < C4 ? ld4g(g.q + (int64_t)tk * C + 4 * c4) : ld4g(g.kv + (int64_t)tk * 2 * C + 4 * (c4 - C4));
-      *reinterpret_cast<float4*>(U + row * SU + 4 * c4) = v;
-    }
-  }
+  r_qkv.commit(U, SU);
   lds_barrier();
 
   // ---- attention backward in place on U.  Thread = (window, row i, head); batches of whole windows.
@@ -311,8 +365,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) block_bwd_kernel(con
     // ---- self: dxn = dq Wq + dkv Wkv -> A2;  dx = dx1 + LN1'(dxn) -> HBM; LN1 partials
     gemm_phase<TJ, NSL, 1, C, NW, BF16>(wqt, C, U, nullptr, 0, nullptr, SU, A2, S, EpiStore{});
     gemm_phase<TJ, NSL, 2, 2 * C, NW, BF16>(wkvt, C, U + C, nullptr, 0, nullptr, SU, A2, S, EpiAcc{});
-    ln_bwd_tile<TJ, VPL, NW>(A2, A1, S, C, g.x, g.stats, g.stats + T, g.ln1_g, tok, g.dx, nullptr, U,
-                         g.ln1_part ? g.ln1_part + (int64_t)tile * 2 * C : nullptr);
+    ln_bwd_tile<TJ, VPL, NW, C>(A2, A1, S, r_ln1, tok, g.dx, nullptr, U, g.ln1_part ? g.ln1_part + (int64_t)tile * 2 * C : nullptr);
   } else {
     // ---- cross: the q path's pre-LayerNorm gradient and the sampled K/V source's gradient leave separately
     gemm_phase<TJ, NSL, 1, C, NW, BF16>(wqt, C, U, nullptr, 0, nullptr, SU, A2, S, EpiStore{});

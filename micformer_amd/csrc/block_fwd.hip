@@ -66,6 +66,24 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
     }
     tok[tid] = tk; sc1[tid] = v1; sc2[tid] = v2;
   }
+  // ---- the tile's input rows are requested first (they stay in flight under the parameter staging; x is kept for the residual)
+  float4 xr[NPASS][VPL], kvv[NPASS][VPL];
+#pragma unroll
+  for (int pass = 0; pass < NPASS; ++pass) {
+    const int rowl = pass * RPP + wave * 4 + rg;
+    const int winl = tile * (TM / 8) + (rowl >> 3);             // (tok[] is not visible yet: same index math)
+    const int tk = (rowl < TM && winl < a.geo.nwin) ? a.geo.token(winl, rowl & 7) : -1;
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+      const int c4 = l16 + 16 * k;
+      // (branch-free: out-of-range lanes read a valid address and drop the value, so all loads of the pass are in flight together)
+      const bool ok = tk >= 0 && c4 < C4;
+      const int64_t off = (int64_t)(tk >= 0 ? tk : 0) * C + 4 * (c4 < C4 ? c4 : C4 - 1);
+      const float4 xv = ld4g(g.x + off), kv4 = ld4g((g.kvsrc ? g.kvsrc : g.x) + off);
+      xr[pass][k] = ok ? xv : make_float4(0.f, 0.f, 0.f, 0.f);
+      kvv[pass][k] = ok ? kv4 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
   {
     const float* const srcs[9] = {g.ln1_g, g.ln1_b, g.bq, g.bkv, g.bp, g.ln2_g, g.ln2_b, g.b2, g.b1};
     const int offs[10] = {0, C, 2 * C, 3 * C, 5 * C, 6 * C, 7 * C, 8 * C, 9 * C, 9 * C + Hd};
@@ -87,22 +105,11 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
   // statistics); cross: the K/V source rows -> A2
   const float invC = 1.0f / (float)C;
   {
-    float4 v[NPASS][VPL], kvv[NPASS][VPL];
+    float4 v[NPASS][VPL];
 #pragma unroll
-    for (int pass = 0; pass < NPASS; ++pass) {
-      const int rowl = pass * RPP + wave * 4 + rg;
-      const int tk = rowl < TM ? tok[rowl] : -1;
+    for (int pass = 0; pass < NPASS; ++pass)
 #pragma unroll
-      for (int k = 0; k < VPL; ++k) {
-        const int c4 = l16 + 16 * k;
-        // (branch-free: out-of-range lanes read a valid address and drop the value, so all loads of the pass are in flight together)
-        const bool ok = tk >= 0 && c4 < C4;
-        const int64_t off = (int64_t)(tk >= 0 ? tk : 0) * C + 4 * (c4 < C4 ? c4 : C4 - 1);
-        const float4 xv = ld4g(g.x + off), kv4 = ld4g((g.kvsrc ? g.kvsrc : g.x) + off);
-        v[pass][k] = ok ? xv : make_float4(0.f, 0.f, 0.f, 0.f);
-        kvv[pass][k] = ok ? kv4 : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
+      for (int k = 0; k < VPL; ++k) v[pass][k] = xr[pass][k];
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
       const int row = pass * RPP + wave * 4 + rg;
@@ -218,16 +225,9 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
   {
     float4 v[NPASS][VPL];
 #pragma unroll
-    for (int pass = 0; pass < NPASS; ++pass) {
-      const int rowl = pass * RPP + wave * 4 + rg;
-      const int tk = rowl < TM ? tok[rowl] : -1;
+    for (int pass = 0; pass < NPASS; ++pass)
 #pragma unroll
-      for (int k = 0; k < VPL; ++k) {
-        const int c4 = l16 + 16 * k;
-        const float4 xv = ld4g(g.x + (int64_t)(tk >= 0 ? tk : 0) * C + 4 * (c4 < C4 ? c4 : C4 - 1));
-        v[pass][k] = (tk >= 0 && c4 < C4) ? xv : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
+      for (int k = 0; k < VPL; ++k) v[pass][k] = xr[pass][k];
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
       const int row = pass * RPP + wave * 4 + rg;
@@ -354,7 +354,7 @@ extern "C" int micf_block_tile_tokens(int B, int D, int H, int W, int C, int hea
   // at the base model's 4^3 stage); block_wide.hip spreads every weight matrix over the chip instead.
   // token groups of 16 per workgroup (measured on MI355X, base shapes, batch 2): forward and backward tile independently
   int tj = 0;
-  if (C == 48 && hd == 16) tj = backward ? 1 : 2;
+  if (C == 48 && hd == 16) tj = 2;
   else if (C == 96 && hd == 16) tj = backward ? 2 : 1;
   else if ((C == 96 || C == 192) && (hd == 16 || hd == 32)) tj = 1;
   if (const char* e = getenv(backward ? "MICF_BLOCK_TJ_BWD" : "MICF_BLOCK_TJ")) {

@@ -300,6 +300,37 @@ int micf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, cons
                    float beta2, float eps, float grad_scale, void* p_bf16, micf_stream_t stream);
 
 
+/* ---- The offset head of a cross block for both modalities of a cross pair in one call (csrc/offset_head.hip; MS.py:354-384):
+ * hid = conv3(cat[xn, xa]) ; flow = conv1(GELU(LN16(hid))) ; xs = trilinear sample of raw xa at the reference points + flow.
+ * Replaces micf_conv3_fwd + micf_offset_sample_fwd (and, backward, micf_offset_sample_bwd + micf_conv3_bwd_data) per
+ * modality; the groups' kernels run as one launch each.  The conv weight gradient stays micf_conv3_bwd_weight (deferred).
+ * conv_ws: the re-laid-out conv weight of micf_conv3_weight_prep_grouped (fwd / bwd layout; `prepared` = 1) or that many
+ * floats of scratch (`prepared` = 0), NULL = generic conv path.  `groups` is HOST memory, read during the call only. */
+typedef struct micf_offset_head_group {
+  const float* xn;      /* [T, C] LN1(x): conv input channels 0 .. C-1 */
+  const float* xa;      /* [T, C] raw other modality: conv input channels C .. 2C-1 and the sampled source */
+  const float *conv_w, *conv_b; /* conv_offset.0: [16, 2C, 3,3,3], [16] */
+  float* conv_ws;
+  const float *ln_g, *ln_b, *w1; /* conv_offset.1.norm [16], conv_offset.3.weight [3, 16] */
+  float *hid, *flow, *xs;        /* out: [T, 16] conv output, [T, 3] offsets, [T, C] sampled source */
+} micf_offset_head_group;
+typedef struct micf_offset_head_bwd_group {
+  const float* dxs;     /* [T, C] gradient of the sampled source */
+  const float *hid, *flow, *xa, *ln_g, *ln_b, *w1, *conv_w;
+  float* conv_ws;
+  float* dxa;           /* [T, C] ACCUMULATED: raw-source gradient of the sampler + the conv's input channels C .. 2C-1 */
+  float* dxn;           /* [T, C] ACCUMULATED: the conv's input channels 0 .. C-1 (pre-LayerNorm-1 gradient) */
+  float* dhid;          /* [T, 16] out: gradient of the conv output (operand of the conv weight gradient) */
+  float *dln_g, *dln_b, *dw1; /* accumulated */
+} micf_offset_head_bwd_group;
+/* 1 = the conv accumulates atomically at this shape: hid must be zero when it starts (the call clears it unless hid_zeroed) */
+int micf_offset_head_needs_zero(int B, int D, int H, int W, int C);
+int micf_offset_head_fwd(const micf_offset_head_group* groups, int ngroups, int B, int D, int H, int W, int C, float eps,
+                         int prepared, int hid_zeroed, int dtype, micf_stream_t stream);
+int64_t micf_offset_head_bwd_workspace(int ngroups, int B, int D, int H, int W);
+int micf_offset_head_bwd(const micf_offset_head_bwd_group* groups, int ngroups, int B, int D, int H, int W, int C, float eps,
+                         int prepared, float* workspace, int64_t workspace_floats, int dtype, micf_stream_t stream);
+
 /* ---- Fused window-local transformer block (csrc/block_fwd.hip, block_bwd.hip): everything of a TransformerBlock3D
  * (MS.py:430-524), and everything of a CrossTransformerBlock3D (MS.py:277-426) downstream of the deformable sampling, in ONE
  * launch per direction for up to two independent blocks of the same shape (the CT and MR branches of a depth slot,

@@ -40,6 +40,10 @@ SIGNATURES = {
     "micf_conv3_fwd_workspace": "iii",
     "micf_conv3_bwd_data": "pippiipiiiiiiipliip",
     "micf_conv3_weight_prep_grouped": "pip",
+    "micf_offset_head_needs_zero": "iiiii",
+    "micf_offset_head_fwd": "piiiiiifiiip",
+    "micf_offset_head_bwd_workspace": "iiiii",
+    "micf_offset_head_bwd": "piiiiiifiplip",
     "micf_conv3_bwd_data_workspace": "iii",
     "micf_conv3_bwd_weight": "pipipippiiiiiplip",
     "micf_conv3_bwd_weight_workspace": "iiiiiii",
@@ -117,6 +121,18 @@ class WeightPrepItem(ctypes.Structure):
                 ("bf16", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
+class OffsetHeadGroup(ctypes.Structure):
+    """struct micf_offset_head_group (include/micformer_hip.h)."""
+    FIELDS = ("xn", "xa", "conv_w", "conv_b", "conv_ws", "ln_g", "ln_b", "w1", "hid", "flow", "xs")
+    _fields_ = [(n, _VP) for n in FIELDS]
+
+
+class OffsetHeadBwdGroup(ctypes.Structure):
+    """struct micf_offset_head_bwd_group (include/micformer_hip.h)."""
+    FIELDS = ("dxs", "hid", "flow", "xa", "ln_g", "ln_b", "w1", "conv_w", "conv_ws", "dxa", "dxn", "dhid", "dln_g", "dln_b", "dw1")
+    _fields_ = [(n, _VP) for n in FIELDS]
+
+
 class Conv3PrepItem(ctypes.Structure):
     """struct micf_conv3_prep_item (include/micformer_hip.h)."""
     _fields_ = [("w", _VP), ("fwd", _VP), ("bwd", _VP), ("N", ctypes.c_int32), ("Cin", ctypes.c_int32)]
@@ -142,6 +158,7 @@ def _load():
     lib.micf_offset_sample_bwd_workspace.restype = _L
     lib.micf_conv3_bwd_weight_workspace.restype = _L
     lib.micf_conv3_fwd_workspace.restype = _L
+    lib.micf_offset_head_bwd_workspace.restype = _L
     lib.micf_block_tile_tokens.argtypes = [_I] * 8          # (no stream argument: a pure shape query)
     lib.micf_strerror.argtypes = [_I]
     lib.micf_strerror.restype = ctypes.c_char_p

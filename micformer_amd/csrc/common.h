@@ -38,6 +38,35 @@ __device__ __forceinline__ float wave_sum(float v) {
 // column sums of (scale * dy) [M, N] accumulated into out[N] (bias gradients)
 int colsum_atomic(const float* dy, const float* scale, int64_t rps, float* out, int64_t M, int N, hipStream_t s);
 
+// ---- offset head (offset_sample.hip / offset_head.hip)
+constexpr int kOffsetHidden = 16;   // channels of conv_offset[0]'s output (MS.py:314)
+struct CellLists {               // workspace carved by the launcher (all int32)
+  int* count;                    // [B*(D+1)*(H+1)*(W+1)] tokens registered per cell (may exceed kCellCap: the rest overflowed)
+  int* ovf_count;                // [1]
+  int* list;                     // [cells][kCellCap]
+  int* ovf;                      // [T] tokens that did not fit their cell's list
+  int cap;                       // list entries actually used (kCellCap; smaller only under MICF_CELL_CAP, a test hook)
+};
+struct SampleFwdSet { const float *h, *ln_g, *ln_b, *w1, *xa; float *flow, *xs; };
+struct SampleBwdSet {
+  const float *dxs, *h, *ln_g, *ln_b, *w1, *xa, *flow;
+  float *dxa, *dh, *dln_g, *dln_b, *dw1;
+  CellLists cl;                    // filled in by the launcher
+  float* partials;                 // "
+};
+int offset_sample_fwd_groups(const SampleFwdSet* sets, int n, int B, int D, int H, int W, int C, float eps, hipStream_t stream);
+int offset_sample_bwd_groups(SampleBwdSet* sets, int n, int B, int D, int H, int W, int C, float eps, float* workspace,
+                             int64_t workspace_floats, hipStream_t s);
+
+// pointer sets of the grouped (two modalities per launch) forms
+struct Conv3FwdSet { const float* x1; const float* x2; const float* w; const float* bias; float* y; float* wt; };
+struct Conv3BwdSet { const float* dy; const float* w; float* wt; float* dx1; float* dx2; };
+int conv3_fwd_x_groups(const Conv3FwdSet* sets, int n, int c1, int c2, int B, int D, int H, int W, int N, hipStream_t stream, int dtype,
+                       int prepared, int y_zeroed);
+bool conv3_fwd_x_splits(int B, int D, int H, int W, int c1, int c2);
+int conv3_bwd_data_x_groups(const Conv3BwdSet* sets, int ng, int c1, int acc1, int c2, int acc2, int B, int D, int H, int W, int N,
+                            hipStream_t stream, int dtype, int prepared);
+
 // direct data gradient for N <= 16 channels-last dy (conv3_bwdx.hip); wt = 27*(c1+c2)*16 floats of scratch
 int conv3_bwd_data_x(const float* dy, const float* w, float* wt, float* dx1, int c1, int acc1, float* dx2, int c2, int acc2, int B,
                      int D, int H, int W, int N, hipStream_t stream, int dtype = 0, int prepared = 0);

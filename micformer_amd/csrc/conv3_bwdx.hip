@@ -24,7 +24,8 @@ struct BwdxArgs {
   const float* wt;                              // [27][O][16]
   float* d1; float* d2; int oc1, oc2, acc1, acc2;
   int O;                                        // oc1 + oc2, multiple of 16
-  int B, D, H, W, tiles_d, tiles_h, tiles_w;
+  int B, D, H, W, tiles_d, tiles_h, tiles_w, ngroups;
+  const float* dyb; const float* wtb; float* d1b; float* d2b;      // second pointer set (blockIdx.z == 1)
 };
 
 __global__ void __launch_bounds__(256) conv3_wt_kernel(const float* __restrict__ w, float* __restrict__ wt, int N, int Cin) {
@@ -42,6 +43,7 @@ __global__ void __launch_bounds__(256) conv3_bwdx_kernel(BwdxArgs a) {
   constexpr int CH = 16 / TW, TH = 4 * CH, TD = 2;
   constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2, HALO = HD * HH * HW;
   __shared__ __attribute__((aligned(16))) float Xs[HALO * xKS];
+  if (blockIdx.z) { a.dy = a.dyb; a.wt = a.wtb; a.d1 = a.d1b; a.d2 = a.d2b; }      // the other modality's head
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lr = lane >> 4;
   int q = blockIdx.x;
   const int tw = q % a.tiles_w; q /= a.tiles_w;
@@ -171,25 +173,40 @@ static hipError_t launch_bwdx(BwdxArgs& a, hipStream_t stream) {
   const int cts = a.O / 16;
   // many token tiles: 6 channel tiles per workgroup (the halo is staged once per 96 channels); few: 2, to spread over the CUs
   if (blocks * ((cts + 5) / 6) >= 384)
-    hipLaunchKernelGGL((conv3_bwdx_kernel<TW, 6, BF16>), dim3((unsigned)blocks, (cts + 5) / 6), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((conv3_bwdx_kernel<TW, 6, BF16>), dim3((unsigned)blocks, (cts + 5) / 6, a.ngroups), dim3(256), 0, stream, a);
   else
-    hipLaunchKernelGGL((conv3_bwdx_kernel<TW, 2, BF16>), dim3((unsigned)blocks, (cts + 1) / 2), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((conv3_bwdx_kernel<TW, 2, BF16>), dim3((unsigned)blocks, (cts + 1) / 2, a.ngroups), dim3(256), 0, stream, a);
   return hipGetLastError();
 }
 
 // MICF_EUNSUPPORTED when the shape is outside what this kernel covers (caller falls back to the implicit GEMM).
 int conv3_bwd_data_x(const float* dy, const float* w, float* wt, float* dx1, int c1, int acc1, float* dx2, int c2, int acc2, int B,
                      int D, int H, int W, int N, hipStream_t stream, int dtype, int prepared) {
+  const Conv3BwdSet one{dy, w, wt, dx1, dx2};
+  return conv3_bwd_data_x_groups(&one, 1, c1, acc1, c2, acc2, B, D, H, W, N, stream, dtype, prepared);
+}
+
+// 1 or 2 data gradients of the same shape in ONE launch (blockIdx.z)
+int conv3_bwd_data_x_groups(const Conv3BwdSet* sets, int ng, int c1, int acc1, int c2, int acc2, int B, int D, int H, int W, int N,
+                            hipStream_t stream, int dtype, int prepared) {
+  if (!sets || ng < 1 || ng > 2) return MICF_EINVAL;
   const int O = c1 + c2;
-  if (N > 16 || (N & 3) || (O & 15) || (c1 & 3) || (c2 & 3) || W < 8 || !aligned16(dy) || !aligned16(wt) ||
-      (dx1 && !aligned16(dx1)) || (dx2 && !aligned16(dx2)))
-    return MICF_EUNSUPPORTED;
+  if (N > 16 || (N & 3) || (O & 15) || (c1 & 3) || (c2 & 3) || W < 8) return MICF_EUNSUPPORTED;
+  for (int i = 0; i < ng; ++i)
+    if (!aligned16(sets[i].dy) || !aligned16(sets[i].wt) || (sets[i].dx1 && !aligned16(sets[i].dx1)) || (sets[i].dx2 && !aligned16(sets[i].dx2)) ||
+        (!sets[i].dx1) != (!sets[0].dx1) || (!sets[i].dx2) != (!sets[0].dx2))
+      return MICF_EUNSUPPORTED;
+  const float *dy = sets[0].dy;
+  float *wt = sets[0].wt, *dx1 = sets[0].dx1, *dx2 = sets[0].dx2;
   const int64_t n = (int64_t)27 * O * 16;
   if (!prepared) {
-    hipLaunchKernelGGL(conv3_wt_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, wt, N, O);
-    if (hipGetLastError() != hipSuccess) return MICF_ELAUNCH;
+    for (int i = 0; i < ng; ++i) {
+      hipLaunchKernelGGL(conv3_wt_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, sets[i].w, sets[i].wt, N, O);
+      if (hipGetLastError() != hipSuccess) return MICF_ELAUNCH;
+    }
   }
   BwdxArgs a{};
+  a.dyb = sets[ng - 1].dy; a.wtb = sets[ng - 1].wt; a.d1b = sets[ng - 1].dx1; a.d2b = sets[ng - 1].dx2; a.ngroups = ng;
   a.dy = dy; a.N = N; a.wt = wt; a.d1 = dx1; a.d2 = dx2; a.oc1 = c1; a.oc2 = c2; a.acc1 = acc1; a.acc2 = acc2; a.O = O;
   a.B = B; a.D = D; a.H = H; a.W = W;
   const hipError_t e = dtype == MICF_DTYPE_BF16 ? ((W >= 12) ? launch_bwdx<16, true>(a, stream) : launch_bwdx<8, true>(a, stream))

@@ -25,6 +25,7 @@ struct FwdxArgs {
   const float* x1; const float* x2; int c1, c2;
   const float* wt;                              // [chunks][27][16][16]
   const float* bias; float* y; int N;           // channels-last [T, N]
+  const float* x1b; const float* x2b; const float* wtb; const float* biasb; float* yb;   // second pointer set (blockIdx.z == 1)
   int B, D, H, W, tiles_d, tiles_h, tiles_w;
   int chunks, chunks_per_block;                 // gridDim.y = ceil(chunks / chunks_per_block); > 1 block per tile -> atomic output
 };
@@ -44,6 +45,7 @@ __global__ void __launch_bounds__(256) conv3_fwdx_kernel(FwdxArgs a) {
   constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2, HALO = HD * HH * HW;
   constexpr int NH = (HALO * 4 + 255) / 256;
   __shared__ __attribute__((aligned(16))) float Xs[HALO * fKS];
+  if (blockIdx.z) { a.x1 = a.x1b; a.x2 = a.x2b; a.wt = a.wtb; a.bias = a.biasb; a.y = a.yb; }   // the other modality's head
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lr = lane >> 4;
   int q = blockIdx.x;
   const int tw = q % a.tiles_w; q /= a.tiles_w;
@@ -168,17 +170,40 @@ int64_t conv3_fwdx_workspace(int N, int c1, int c2) {
 // MICF_EUNSUPPORTED when the shape is outside what this kernel covers (caller falls back).
 int conv3_fwd_x(const float* x1, int c1, const float* x2, int c2, const float* w, const float* bias, float* y, float* wt, int B, int D,
                 int H, int W, int N, hipStream_t stream, int dtype, int prepared) {
-  if (N > 16 || (c1 & 3) || (c2 & 3) || W < 8 || !aligned16(x1) || (x2 && !aligned16(x2)) || !aligned16(y) || !aligned16(wt))
-    return MICF_EUNSUPPORTED;
+  const Conv3FwdSet one{x1, x2, w, bias, y, wt};
+  return conv3_fwd_x_groups(&one, 1, c1, c2, B, D, H, W, N, stream, dtype, prepared, 0);
+}
+
+bool conv3_fwd_x_splits(int B, int D, int H, int W, int c1, int c2) {      // does the direct kernel accumulate atomically here?
+  const int chunks = (c1 + c2 + 15) / 16;
+  const int tw_ = W >= 12 ? 16 : 8, th_ = 4 * (16 / tw_);
+  const int64_t blocks = (int64_t)B * ((D + 1) / 2) * ((H + th_ - 1) / th_) * ((W + tw_ - 1) / tw_);
+  return blocks < 256 && chunks > 1;
+}
+
+// 1 or 2 convolutions of the same shape in ONE launch (blockIdx.z).  y_zeroed: the caller already cleared the outputs (only
+// matters where the channel chunks are split over workgroups and accumulated atomically).
+int conv3_fwd_x_groups(const Conv3FwdSet* sets, int n, int c1, int c2, int B, int D, int H, int W, int N, hipStream_t stream, int dtype,
+                       int prepared, int y_zeroed) {
+  if (!sets || n < 1 || n > 2) return MICF_EINVAL;
+  if (N > 16 || (c1 & 3) || (c2 & 3) || W < 8) return MICF_EUNSUPPORTED;
+  for (int i = 0; i < n; ++i)
+    if (!aligned16(sets[i].x1) || (sets[i].x2 && !aligned16(sets[i].x2)) || !aligned16(sets[i].y) || !aligned16(sets[i].wt)) return MICF_EUNSUPPORTED;
+  const float *x1 = sets[0].x1, *x2 = sets[0].x2, *w = sets[0].w, *bias = sets[0].bias;
+  float *y = sets[0].y, *wt = sets[0].wt;
   const int Cin = c1 + c2, chunks = (Cin + 15) / 16;
   const int64_t nw = (int64_t)chunks * 27 * 256;
   if (!prepared) {      // (prepared: wt already holds this layout, written once per step by micf_conv3_weight_prep_grouped)
-    hipLaunchKernelGGL(conv3_wtf_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, w, wt, N, Cin, chunks);
-    if (hipGetLastError() != hipSuccess) return MICF_ELAUNCH;
+    for (int i = 0; i < n; ++i) {
+      hipLaunchKernelGGL(conv3_wtf_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, sets[i].w, sets[i].wt, N, Cin, chunks);
+      if (hipGetLastError() != hipSuccess) return MICF_ELAUNCH;
+    }
   }
   FwdxArgs a{};
   a.x1 = x1; a.x2 = x2 ? x2 : x1; a.c1 = c1; a.c2 = c2; a.wt = wt; a.bias = bias; a.y = y; a.N = N;
   a.B = B; a.D = D; a.H = H; a.W = W; a.chunks = chunks;
+  const Conv3FwdSet& sb = sets[n - 1];
+  a.x1b = sb.x1; a.x2b = sb.x2 ? sb.x2 : sb.x1; a.wtb = sb.wt; a.biasb = sb.bias; a.yb = sb.y;
   const int tw_ = W >= 12 ? 16 : 8, th_ = 4 * (16 / tw_);
   a.tiles_d = (D + 1) / 2; a.tiles_h = (H + th_ - 1) / th_; a.tiles_w = (W + tw_ - 1) / tw_;
   const int64_t blocks = (int64_t)B * a.tiles_d * a.tiles_h * a.tiles_w;
@@ -187,8 +212,10 @@ int conv3_fwd_x(const float* x1, int c1, const float* x2, int c2, const float* w
   if (blocks < 256) { ysplit = (int)((512 + blocks - 1) / blocks); if (ysplit > chunks) ysplit = chunks; }
   a.chunks_per_block = (chunks + ysplit - 1) / ysplit;
   ysplit = (chunks + a.chunks_per_block - 1) / a.chunks_per_block;
-  if (ysplit > 1 && hipMemsetAsync(y, 0, sizeof(float) * (size_t)B * D * H * W * N, stream) != hipSuccess) return MICF_ELAUNCH;
-  const dim3 grid((unsigned)blocks, ysplit);
+  if (ysplit > 1 && !y_zeroed)
+    for (int i = 0; i < n; ++i)
+      if (hipMemsetAsync(sets[i].y, 0, sizeof(float) * (size_t)B * D * H * W * N, stream) != hipSuccess) return MICF_ELAUNCH;
+  const dim3 grid((unsigned)blocks, ysplit, n);
   if (dtype == MICF_DTYPE_BF16) {
     if (tw_ == 16) hipLaunchKernelGGL((conv3_fwdx_kernel<16, true>), grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((conv3_fwdx_kernel<8, true>), grid, dim3(256), 0, stream, a);

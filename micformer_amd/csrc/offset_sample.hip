@@ -76,7 +76,7 @@ __device__ __forceinline__ void head_fwd(const float* hrow, const float* ln_g, c
   for (int a = 0; a < 3; ++a) off[a] = sum16(w1[a * kHid + k] * gl);
 }
 
-__global__ void __launch_bounds__(256) offset_sample_fwd_kernel(const float* __restrict__ h, const float* __restrict__ ln_g,
+__device__ __forceinline__ void offset_sample_fwd_body(const float* __restrict__ h, const float* __restrict__ ln_g,
                                                                 const float* __restrict__ ln_b, const float* __restrict__ w1,
                                                                 const float* __restrict__ xa, float* __restrict__ flow_out,
                                                                 float* __restrict__ xs, Geo g, int C, float eps, int tpw) {
@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(256) offset_sample_fwd_kernel(const float* __r
 // (h row -> LN/GELU/1^3 conv -> taps -> gather) are in flight per wave instead of one: these kernels are latency-bound.
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
-__global__ void __launch_bounds__(256) offset_sample_fwd4_kernel(const float* __restrict__ h, const float* __restrict__ ln_g,
+__device__ __forceinline__ void offset_sample_fwd4_body(const float* __restrict__ h, const float* __restrict__ ln_g,
                                                                  const float* __restrict__ ln_b, const float* __restrict__ w1,
                                                                  const float* __restrict__ xa, float* __restrict__ flow_out,
                                                                  float* __restrict__ xs, Geo g, int C, float eps, int tpw) {
@@ -167,13 +167,6 @@ __global__ void __launch_bounds__(256) offset_sample_fwd4_kernel(const float* __
 
 constexpr int kCellCap = 8;      // tokens per cell list
 
-struct CellLists {               // workspace carved by the launcher (all int32)
-  int* count;                    // [B*(D+1)*(H+1)*(W+1)] tokens registered per cell (may exceed kCellCap: the rest overflowed)
-  int* ovf_count;                // [1]
-  int* list;                     // [cells][kCellCap]
-  int* ovf;                      // [T] tokens that did not fit their cell's list
-  int cap;                       // list entries actually used (kCellCap; smaller only under MICF_CELL_CAP, a test hook)
-};
 
 // cell of a token: base corner floor(coord) + 1 per axis, or -1 when no corner of the cell lies inside the volume
 __device__ __forceinline__ int cell_of(const Taps& tp, int b, int D, int H, int W) {
@@ -184,7 +177,7 @@ __device__ __forceinline__ int cell_of(const Taps& tp, int b, int D, int H, int 
 }
 
 template <bool SCATTER>
-__global__ void __launch_bounds__(256) offset_sample_bwd_kernel(
+__device__ __forceinline__ void offset_sample_bwd_body(
     const float* __restrict__ dxs, const float* __restrict__ h, const float* __restrict__ ln_g, const float* __restrict__ ln_b,
     const float* __restrict__ w1, const float* __restrict__ xa, const float* __restrict__ flow, float* __restrict__ dxa,
     float* __restrict__ dh, float* __restrict__ dln_g, float* __restrict__ dln_b, float* __restrict__ dw1, Geo g, int C, float eps,
@@ -271,7 +264,7 @@ __global__ void __launch_bounds__(256) offset_sample_bwd_kernel(
 
 
 template <bool SCATTER>
-__global__ void __launch_bounds__(256) offset_sample_bwd4_kernel(
+__device__ __forceinline__ void offset_sample_bwd4_body(
     const float* __restrict__ dxs, const float* __restrict__ h, const float* __restrict__ ln_g, const float* __restrict__ ln_b,
     const float* __restrict__ w1, const float* __restrict__ xa, const float* __restrict__ flow, float* __restrict__ dxa,
     float* __restrict__ dh, float* __restrict__ dln_g, float* __restrict__ dln_b, float* __restrict__ dw1, Geo g, int C, float eps,
@@ -370,7 +363,7 @@ __global__ void __launch_bounds__(256) offset_sample_bwd4_kernel(
 }
 
 // d(xa)[v, :] += sum over the tokens registered in the 8 cells that have voxel v as a corner.  Thread = (voxel, 4 channels).
-__global__ void __launch_bounds__(256) sample_gather_kernel(const float* __restrict__ dxs, const float* __restrict__ flow,
+__device__ __forceinline__ void sample_gather_body(const float* __restrict__ dxs, const float* __restrict__ flow,
                                                             float* __restrict__ dxa, Geo g, int C, CellLists cl) {
   const int q4 = C >> 2;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -404,7 +397,7 @@ __global__ void __launch_bounds__(256) sample_gather_kernel(const float* __restr
 // Second pass of the backward.  (1) blocks 0..79: sum the per-wave partials of one head-parameter gradient element and add it
 // to dw1 / dln_g / dln_b (one writer per element).  (2) all blocks: tokens whose cell list was full -- the atomic scatter, one
 // wave per token (normally zero tokens).
-__global__ void __launch_bounds__(256) sample_finish_kernel(const float* __restrict__ dxs, const float* __restrict__ flow,
+__device__ __forceinline__ void sample_finish_body(const float* __restrict__ dxs, const float* __restrict__ flow,
                                                             float* __restrict__ dxa, Geo g, int C, CellLists cl,
                                                             const float* __restrict__ partials, int nwaves, float* __restrict__ dw1,
                                                             float* __restrict__ dln_g, float* __restrict__ dln_b) {
@@ -446,6 +439,40 @@ __global__ void __launch_bounds__(256) sample_finish_kernel(const float* __restr
   }
 }
 
+
+// ---- launch form of the kernels above: up to two independent pointer sets of the same shape (the two modalities' offset
+// heads of a cross pair) per launch, selected by blockIdx.y
+struct SampleFwdSets { SampleFwdSet s[2]; };
+struct SampleBwdSets { SampleBwdSet s[2]; };
+
+__global__ void __launch_bounds__(256) offset_sample_fwd_kernel(const SampleFwdSets p, Geo g, int C, float eps, int tpw) {
+  const SampleFwdSet& q = p.s[blockIdx.y];
+  offset_sample_fwd_body(q.h, q.ln_g, q.ln_b, q.w1, q.xa, q.flow, q.xs, g, C, eps, tpw);
+}
+__global__ void __launch_bounds__(256) offset_sample_fwd4_kernel(const SampleFwdSets p, Geo g, int C, float eps, int tpw) {
+  const SampleFwdSet& q = p.s[blockIdx.y];
+  offset_sample_fwd4_body(q.h, q.ln_g, q.ln_b, q.w1, q.xa, q.flow, q.xs, g, C, eps, tpw);
+}
+template <bool SCATTER>
+__global__ void __launch_bounds__(256) offset_sample_bwd_kernel(const SampleBwdSets p, Geo g, int C, float eps, int tpw, int nwaves) {
+  const SampleBwdSet& q = p.s[blockIdx.y];
+  offset_sample_bwd_body<SCATTER>(q.dxs, q.h, q.ln_g, q.ln_b, q.w1, q.xa, q.flow, q.dxa, q.dh, q.dln_g, q.dln_b, q.dw1, g, C, eps, tpw, q.cl,
+                                  q.partials, nwaves);
+}
+template <bool SCATTER>
+__global__ void __launch_bounds__(256) offset_sample_bwd4_kernel(const SampleBwdSets p, Geo g, int C, float eps, int tpw, int nwaves) {
+  const SampleBwdSet& q = p.s[blockIdx.y];
+  offset_sample_bwd4_body<SCATTER>(q.dxs, q.h, q.ln_g, q.ln_b, q.w1, q.xa, q.flow, q.dxa, q.dh, q.dln_g, q.dln_b, q.dw1, g, C, eps, tpw, q.cl,
+                                   q.partials, nwaves);
+}
+__global__ void __launch_bounds__(256) sample_gather_kernel(const SampleBwdSets p, Geo g, int C) {
+  const SampleBwdSet& q = p.s[blockIdx.y];
+  sample_gather_body(q.dxs, q.flow, q.dxa, g, C, q.cl);
+}
+__global__ void __launch_bounds__(256) sample_finish_kernel(const SampleBwdSets p, Geo g, int C, int nwaves) {
+  const SampleBwdSet& q = p.s[blockIdx.y];
+  sample_finish_body(q.dxs, q.flow, q.dxa, g, C, q.cl, q.partials, nwaves, q.dw1, q.dln_g, q.dln_b);
+}
 
 // ---- standalone SpatialTransformer (STN.py:9-32) on channels-last src with a GIVEN flow [T,3] (voxel units, z,y,x)
 __global__ void __launch_bounds__(256) stn_fwd_kernel(const float* __restrict__ src, const float* __restrict__ flow,
@@ -521,24 +548,36 @@ __global__ void __launch_bounds__(256) stn_bwd_kernel(const float* __restrict__ 
 }  // namespace micf
 using namespace micf;
 
-extern "C" int micf_offset_sample_fwd(const float* h, const float* ln_g, const float* ln_b, const float* w1,
-                                      const float* xa, float* flow, float* xs, int B, int D, int H, int W, int C,
-                                      float eps, micf_stream_t stream) {
-  if (!h || !ln_g || !ln_b || !w1 || !xa || !flow || !xs || B <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0) return MICF_EINVAL;
+// forward of 1 or 2 offset heads of the same shape: ONE launch
+int micf::offset_sample_fwd_groups(const SampleFwdSet* sets, int n, int B, int D, int H, int W, int C, float eps, hipStream_t stream) {
+  if (!sets || n < 1 || n > 2 || B <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0) return MICF_EINVAL;
+  SampleFwdSets p;
+  bool al = true;
+  for (int i = 0; i < 2; ++i) {
+    p.s[i] = sets[i < n ? i : 0];
+    const SampleFwdSet& q = p.s[i];
+    if (!q.h || !q.ln_g || !q.ln_b || !q.w1 || !q.xa || !q.flow || !q.xs) return MICF_EINVAL;
+    al = al && aligned16(q.xa) && aligned16(q.xs);
+  }
   const Geo g{B, D, H, W};
   if (g.tokens() >= (1LL << 31)) return MICF_EUNSUPPORTED;
-  if (g.tokens() >= 4096 && C % 4 == 0 && aligned16(xa) && aligned16(xs)) {   // tiny grids: one token per wave spreads wider
+  if (g.tokens() >= 4096 && C % 4 == 0 && al) {   // tiny grids: one token per wave spreads wider
     const int qpw = quads_per_wave(g.tokens());
     const int wpb = quad_waves_per_block(g.tokens());      // small grids: one-wave workgroups, so every CU gets one
-    hipLaunchKernelGGL(offset_sample_fwd4_kernel, dim3(ceil_div(g.tokens(), 4 * wpb * qpw)), dim3(64 * wpb), 0, (hipStream_t)stream,
-                       h, ln_g, ln_b, w1, xa, flow, xs, g, C, eps, qpw);
+    hipLaunchKernelGGL(offset_sample_fwd4_kernel, dim3(ceil_div(g.tokens(), 4 * wpb * qpw), n), dim3(64 * wpb), 0, stream, p, g, C, eps, qpw);
     MICF_RETURN_LAUNCH();
   }
   const int tpw = tok_per_wave(g.tokens());
   const int blocks = ceil_div(g.tokens(), 4 * tpw);
-  hipLaunchKernelGGL(offset_sample_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, h, ln_g, ln_b, w1, xa, flow,
-                     xs, g, C, eps, tpw);
+  hipLaunchKernelGGL(offset_sample_fwd_kernel, dim3(blocks, n), dim3(256), 0, stream, p, g, C, eps, tpw);
   MICF_RETURN_LAUNCH();
+}
+
+extern "C" int micf_offset_sample_fwd(const float* h, const float* ln_g, const float* ln_b, const float* w1,
+                                      const float* xa, float* flow, float* xs, int B, int D, int H, int W, int C,
+                                      float eps, micf_stream_t stream) {
+  const SampleFwdSet one{h, ln_g, ln_b, w1, xa, flow, xs};
+  return offset_sample_fwd_groups(&one, 1, B, D, H, W, C, eps, (hipStream_t)stream);
 }
 
 static int64_t cell_count(int B, int D, int H, int W) { return (int64_t)B * (D + 1) * (H + 1) * (W + 1); }
@@ -559,58 +598,82 @@ extern "C" int64_t micf_offset_sample_bwd_workspace(int B, int D, int H, int W) 
   return need;
 }
 
-extern "C" int micf_offset_sample_bwd(const float* dxs, const float* h, const float* ln_g, const float* ln_b,
-                                      const float* w1, const float* xa, const float* flow, float* dxa, float* dh,
-                                      float* dln_g, float* dln_b, float* dw1, int B, int D, int H, int W, int C, float eps,
-                                      float* workspace, int64_t workspace_floats, micf_stream_t stream) {
-  if (!dxs || !h || !ln_g || !ln_b || !w1 || !xa || !flow || !dxa || !dh || !dln_g || !dln_b || !dw1 || B <= 0 || D <= 0 ||
-      H <= 0 || W <= 0 || C <= 0)
-    return MICF_EINVAL;
+// backward of 1 or 2 offset heads of the same shape.  `sets[i]` carries the tensors (cl / partials are filled in here);
+// workspace: n * micf_offset_sample_bwd_workspace floats (or NULL: atomic scatter, atomic parameter gradients).  The
+// parameter-gradient partial sums are finished by the last launch; with `defer_finish` (allowed when no cell lists are in
+// use, i.e. small grids) that launch is left to the caller: offset_sample_bwd_finish_groups with the same arguments.
+int micf::offset_sample_bwd_groups(SampleBwdSet* sets, int n, int B, int D, int H, int W, int C, float eps, float* workspace,
+                             int64_t workspace_floats, hipStream_t s) {
+  if (!sets || n < 1 || n > 2 || B <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0) return MICF_EINVAL;
   const Geo g{B, D, H, W};
   const int64_t T = g.tokens();
   if (T >= (1LL << 31) / 4) return MICF_EUNSUPPORTED;
+  bool al = true;
+  for (int i = 0; i < n; ++i) {
+    const SampleBwdSet& q = sets[i];
+    if (!q.dxs || !q.h || !q.ln_g || !q.ln_b || !q.w1 || !q.xa || !q.flow || !q.dxa || !q.dh || !q.dln_g || !q.dln_b || !q.dw1)
+      return MICF_EINVAL;
+    al = al && aligned16(q.dxs) && aligned16(q.xa) && aligned16(q.dxa);
+  }
   // quad kernels (4 tokens per wave) when the channel rows allow 16-byte accesses
-  const bool quad = T >= 4096 && (C % 4 == 0) && aligned16(dxs) && aligned16(xa) && aligned16(dxa);   // tiny grids: 1 token per wave
+  const bool quad = T >= 4096 && (C % 4 == 0) && al;   // tiny grids: 1 token per wave
   const int tpw = quad ? quads_per_wave(T) : tok_per_wave(T);
   const int wpb = quad ? quad_waves_per_block(T) : 4;
   const int blocks = ceil_div(T, (quad ? 4 * wpb : 4) * tpw);
   const int nwaves = blocks * wpb;
-  hipStream_t s = (hipStream_t)stream;
   const CellLists none{nullptr, nullptr, nullptr, nullptr, 0};
-  auto launch_main = [&](bool scatter, const CellLists& lists, float* partials, int nw) {
-#define MICF_SAMPLE_ARGS dim3(blocks), dim3(64 * wpb), 0, s, dxs, h, ln_g, ln_b, w1, xa, flow, dxa, dh, dln_g, dln_b, dw1, g, C, eps, tpw, lists, partials, nw
-    if (quad) {
-      if (scatter) hipLaunchKernelGGL(offset_sample_bwd4_kernel<true>, MICF_SAMPLE_ARGS);
-      else hipLaunchKernelGGL(offset_sample_bwd4_kernel<false>, MICF_SAMPLE_ARGS);
-    } else {
-      if (scatter) hipLaunchKernelGGL(offset_sample_bwd_kernel<true>, MICF_SAMPLE_ARGS);
-      else hipLaunchKernelGGL(offset_sample_bwd_kernel<false>, MICF_SAMPLE_ARGS);
-    }
-#undef MICF_SAMPLE_ARGS
-    return hipGetLastError() == hipSuccess;
-  };
-  if (!workspace || workspace_floats < micf_offset_sample_bwd_workspace(B, D, H, W) || !aligned16(workspace))
-    return launch_main(true, none, nullptr, 0) ? MICF_OK : MICF_ELAUNCH;
-  float* partials = workspace;
-  CellLists cl = none;
-  if (use_cells(T) && quad && cell_count(B, D, H, W) * kCellCap < (1LL << 31)) {
-    const int64_t nc = (cell_count(B, D, H, W) + 3) / 4 * 4;
-    int* base = reinterpret_cast<int*>(workspace + partial_floats(T));
-    const char* env = getenv("MICF_CELL_CAP");           // test hook: force the overflow pass
-    int cap = env ? atoi(env) : kCellCap;
+  const int64_t per = micf_offset_sample_bwd_workspace(B, D, H, W);
+  const bool have_ws = workspace && workspace_floats >= per * n && aligned16(workspace);
+  const bool cells = have_ws && use_cells(T) && quad && cell_count(B, D, H, W) * kCellCap < (1LL << 31);
+  SampleBwdSets p;
+  const int64_t nc = (cell_count(B, D, H, W) + 3) / 4 * 4;
+  // workspace: [partials g0 | partials g1 | counters g0 | counters g1 | lists + overflow g0 | lists + overflow g1]
+  // (the counters of both groups are contiguous: one memset)
+  int* counters = have_ws ? reinterpret_cast<int*>(workspace + n * partial_floats(T)) : nullptr;
+  int* lists = counters ? counters + n * (nc + 4) : nullptr;
+  int cap = kCellCap;
+  if (const char* env = getenv("MICF_CELL_CAP")) {           // test hook: force the overflow pass
+    cap = atoi(env);
     cap = cap < 0 ? 0 : (cap > kCellCap ? kCellCap : cap);
-    cl = CellLists{base, base + nc, base + nc + 4, base + nc + 4 + nc * kCellCap, cap};
-    if (hipMemsetAsync(base, 0, sizeof(int) * (size_t)(nc + 4), s) != hipSuccess) return MICF_ELAUNCH;
-    if (!launch_main(false, cl, partials, nwaves)) return MICF_ELAUNCH;
-    const int64_t threads = T * (C / 4);
-    hipLaunchKernelGGL(sample_gather_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, dxs, flow, dxa, g, C, cl);
-    if (hipGetLastError() != hipSuccess) return MICF_ELAUNCH;
-  } else if (!launch_main(true, none, partials, nwaves)) {
-    return MICF_ELAUNCH;
   }
-  hipLaunchKernelGGL(sample_finish_kernel, dim3(5 * kHid), dim3(256), 0, s, dxs, flow, dxa, g, C, cl, partials, nwaves, dw1, dln_g,
-                     dln_b);
+  for (int i = 0; i < 2; ++i) {
+    const int k = i < n ? i : 0;
+    p.s[i] = sets[k];
+    p.s[i].partials = have_ws ? workspace + k * partial_floats(T) : nullptr;
+    p.s[i].cl = none;
+    if (cells) {
+      int* cnt = counters + k * (nc + 4);
+      int* ls = lists + k * (nc * kCellCap + T);
+      p.s[i].cl = CellLists{cnt, cnt + nc, ls, ls + nc * kCellCap, cap};
+    }
+  }
+  if (cells && hipMemsetAsync(counters, 0, sizeof(int) * (size_t)(n * (nc + 4)), s) != hipSuccess) return MICF_ELAUNCH;
+  const bool scatter = !cells;
+  const dim3 grid(blocks, n), blk(64 * wpb);
+  if (quad) {
+    if (scatter) hipLaunchKernelGGL(offset_sample_bwd4_kernel<true>, grid, blk, 0, s, p, g, C, eps, tpw, nwaves);
+    else hipLaunchKernelGGL(offset_sample_bwd4_kernel<false>, grid, blk, 0, s, p, g, C, eps, tpw, nwaves);
+  } else {
+    if (scatter) hipLaunchKernelGGL(offset_sample_bwd_kernel<true>, grid, blk, 0, s, p, g, C, eps, tpw, nwaves);
+    else hipLaunchKernelGGL(offset_sample_bwd_kernel<false>, grid, blk, 0, s, p, g, C, eps, tpw, nwaves);
+  }
+  if (hipGetLastError() != hipSuccess) return MICF_ELAUNCH;
+  if (!have_ws) return MICF_OK;                      // (atomic parameter gradients: nothing to finish)
+  if (cells) {
+    const int64_t threads = T * (C / 4);
+    hipLaunchKernelGGL(sample_gather_kernel, dim3((unsigned)((threads + 255) / 256), n), dim3(256), 0, s, p, g, C);
+    if (hipGetLastError() != hipSuccess) return MICF_ELAUNCH;
+  }
+  hipLaunchKernelGGL(sample_finish_kernel, dim3(5 * kHid, n), dim3(256), 0, s, p, g, C, nwaves);
   MICF_RETURN_LAUNCH();
+}
+
+extern "C" int micf_offset_sample_bwd(const float* dxs, const float* h, const float* ln_g, const float* ln_b,
+                                      const float* w1, const float* xa, const float* flow, float* dxa, float* dh,
+                                      float* dln_g, float* dln_b, float* dw1, int B, int D, int H, int W, int C, float eps,
+                                      float* workspace, int64_t workspace_floats, micf_stream_t stream) {
+  SampleBwdSet one{dxs, h, ln_g, ln_b, w1, xa, flow, dxa, dh, dln_g, dln_b, dw1, CellLists{nullptr, nullptr, nullptr, nullptr, 0}, nullptr};
+  return offset_sample_bwd_groups(&one, 1, B, D, H, W, C, eps, workspace, workspace_floats, (hipStream_t)stream);
 }
 
 extern "C" int micf_stn_fwd(const float* src, const float* flow, float* out, int B, int D, int H, int W, int C,

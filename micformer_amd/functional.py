@@ -650,6 +650,12 @@ _CSV_KEYS = ("q", "kv", "o", "x1", "xn2", "h", "g", "stats")
 # The two offset heads of a cross pair (LN1 -> 3^3 conv -> sampling, and their adjoints) are independent per-op launch chains:
 # the second one runs on a side stream (a fork / join in the captured graph), as round 1 did for whole blocks.
 OVERLAP_CROSS_HEADS = True
+# ... superseded by the grouped entry points: both heads of a pair in every launch (micf_offset_head_fwd / _bwd)
+GROUP_CROSS_HEADS = _os.environ.get("MICF_GROUP_HEADS", "1") != "0"
+
+
+def _conv_offset_wgrad(side, dhid, xn, xa, G, dims):
+    _defer(side, lambda: ops.conv3_bwd_weight(dhid, xn, G["conv_offset.0.weight"], G["conv_offset.0.bias"], dims, x2=xa), dhid, xn, xa)
 _SIDE = {}
 
 
@@ -688,7 +694,15 @@ class CrossPairFn(torch.autograd.Function):
         B, D, H, W, C = x.shape
         dims = (B, D, H, W)
         xs = [x.reshape(-1, C), xa.reshape(-1, C)]
-        if OVERLAP_CROSS_HEADS:
+        if GROUP_CROSS_HEADS:
+            # both offset heads per launch (micf_offset_head_fwd): no fork / join inside the captured graph
+            lns = [ops.layernorm_fwd(xs[i], Ps[i]["norm1.weight"], Ps[i]["norm1.bias"], eps) for i in (0, 1)]
+            hid = None
+            if ops.offset_head_needs_zero(dims, C):
+                hid = ops.zero_(torch.empty((2, xs[0].shape[0], 16), dtype=torch.float32, device=x.device))
+            outs = ops.offset_head_fwd([{"xn": lns[i][0], "xa": xs[1 - i], "P": Ps[i]} for i in (0, 1)], dims, eps, hid)
+            heads_ = [lns[i] + outs[i] for i in (0, 1)]
+        elif OVERLAP_CROSS_HEADS:
             main, side = torch.cuda.current_stream(), _side_stream(x.device)
             side.wait_stream(main)
             h0 = _cross_head_fwd(xs[0], xs[1], Ps[0], dims, eps)
@@ -738,16 +752,22 @@ class CrossPairFn(torch.autograd.Function):
             xn, m1, r1, hid, flow, xsamp = hds[i]
             _queue_block_wgrads(sides[i], Ps[i], Gs[i], "cross_attn", svs[i], bos[i], dys[i], xn, xsamp, scales[i][0], scales[i][1], rps)
             _ln_partials(sides[i], bos[i]["ln2_part"], bos[i]["tiles"], C, Gs[i]["norm2.weight"], Gs[i]["norm2.bias"])
-        main = torch.cuda.current_stream()
-        side = _side_stream(dys[0].device) if OVERLAP_CROSS_HEADS else None
-        if side is not None:
-            side.wait_stream(main)
-        for i in (0, 1):
+        if GROUP_CROSS_HEADS:
             # block i's raw-xa gradient goes to the OTHER input's buffer; its own LN1 backward lands in acc[i] (in place)
-            with torch.cuda.stream(side if (i == 1 and side is not None) else main):
-                _cross_head_adjoint(i, hds, bos, Ps, Gs, xs, acc, dims, eps, C, sides)
-        if side is not None:
-            main.wait_stream(side)
+            dhids = ops.offset_head_bwd([{"dxs": bos[i]["dxs"], "hid": hds[i][3], "flow": hds[i][4], "xa": xs[1 - i], "P": Ps[i],
+                                          "G": Gs[i], "dxa": acc[1 - i], "dxn": bos[i]["dx"]} for i in (0, 1)], dims, eps)
+            for i in (0, 1):
+                _conv_offset_wgrad(sides[i], dhids[i], hds[i][0], xs[1 - i], Gs[i], dims)
+        else:
+            main = torch.cuda.current_stream()
+            side = _side_stream(dys[0].device) if OVERLAP_CROSS_HEADS else None
+            if side is not None:
+                side.wait_stream(main)
+            for i in (0, 1):
+                with torch.cuda.stream(side if (i == 1 and side is not None) else main):
+                    _cross_head_adjoint(i, hds, bos, Ps, Gs, xs, acc, dims, eps, C, sides)
+            if side is not None:
+                main.wait_stream(side)
         for i in (0, 1):
             xn, m1, r1 = hds[i][:3]
             ops.layernorm_bwd(bos[i]["dx"], xs[i], m1, r1, Ps[i]["norm1.weight"], Gs[i]["norm1.weight"], Gs[i]["norm1.bias"],

@@ -335,6 +335,86 @@ def offset_sample_bwd(dxs, h, ln_g, ln_b, w1, xa, flow, dxa, dln_g, dln_b, dw1, 
     return dh
 
 
+def offset_head_needs_zero(dims, C):
+    B, D, H, W = dims
+    return bool(_lib.lib.micf_offset_head_needs_zero(B, D, H, W, C))
+
+
+def offset_head_fwd(groups, dims, eps, hid=None):
+    """groups: 1 or 2 dicts {xn [T,C], xa [T,C], P {conv_offset.* parameters}}.  The whole head(s) in one call (2-3 launches).
+    hid: optional pre-zeroed [n, T, 16] buffer (see offset_head_needs_zero).  Returns per group (hid, flow, xs)."""
+    B, D, H, W = dims
+    T, C = groups[0]["xn"].shape
+    n = len(groups)
+    zeroed = hid is not None
+    if hid is None:
+        hid = _new(groups[0]["xn"], n, T, 16)
+    arr = (_lib.OffsetHeadGroup * 2)()
+    outs, keep, prepared = [], [], None
+    for i, (it, gd) in enumerate(zip(arr, groups)):
+        P = gd["P"]
+        w = P["conv_offset.0.weight"]
+        ws = getattr(w, "_micf_c3f", None)
+        prepared = (ws is not None) if prepared is None else (prepared and ws is not None)
+        if ws is None:
+            need = _lib.lib.micf_conv3_fwd_workspace(16, C, C)
+            ws = _new(w, need) if need > 0 else None
+        keep.append(ws)
+        flow, xs = _new(gd["xn"], T, 3), _new(gd["xn"], T, C)
+        it.xn, it.xa, it.conv_w, it.conv_b, it.conv_ws = f32(gd["xn"]), f32(gd["xa"]), f32(w), f32(P["conv_offset.0.bias"]), f32(ws)
+        it.ln_g, it.ln_b, it.w1 = f32(P["conv_offset.1.norm.weight"]), f32(P["conv_offset.1.norm.bias"]), f32(P["conv_offset.3.weight"])
+        it.hid, it.flow, it.xs = f32(hid[i]), f32(flow), f32(xs)
+        outs.append((hid[i], flow, xs))
+    if not prepared:                      # mixed: let the call re-lay-out into private scratch
+        for it, gd in zip(arr, groups):
+            need = _lib.lib.micf_conv3_fwd_workspace(16, C, C)
+            ws = _new(gd["xn"], need) if need > 0 else None
+            keep.append(ws)
+            it.conv_ws = f32(ws)
+    call("micf_offset_head_fwd", ctypes.cast(arr, ctypes.c_void_p), n, B, D, H, W, C, float(eps), 1 if prepared else 0,
+         1 if zeroed else 0, _dt(), cost=_cost(n * (2 * T * 27 * 2 * C * 16 + T * (20 * C + 400)), *[g["xn"] for g in groups],
+                                                *[g["xa"] for g in groups], *[o[2] for o in outs]))
+    del keep
+    return outs
+
+
+def offset_head_bwd(groups, dims, eps):
+    """groups: 1 or 2 dicts {dxs, hid, flow, xa, P, G, dxa (accumulated), dxn (accumulated)}.  Sampler adjoint(s) + conv data
+    gradient(s) in one call; returns the dhid [T,16] of every group (operand of the conv weight gradient)."""
+    B, D, H, W = dims
+    T, C = groups[0]["xa"].shape
+    n = len(groups)
+    arr = (_lib.OffsetHeadBwdGroup * 2)()
+    outs, keep, prepared = [], [], None
+    for it, gd in zip(arr, groups):
+        P, G = gd["P"], gd["G"]
+        w = P["conv_offset.0.weight"]
+        ws = getattr(w, "_micf_c3b", None)
+        prepared = (ws is not None) if prepared is None else (prepared and ws is not None)
+        keep.append(ws)
+        dhid = _new(gd["xa"], T, 16)
+        it.dxs, it.hid, it.flow, it.xa = f32(gd["dxs"]), f32(gd["hid"]), f32(gd["flow"]), f32(gd["xa"])
+        it.ln_g, it.ln_b, it.w1 = f32(P["conv_offset.1.norm.weight"]), f32(P["conv_offset.1.norm.bias"]), f32(P["conv_offset.3.weight"])
+        it.conv_w, it.conv_ws = f32(w), f32(ws)
+        it.dxa, it.dxn, it.dhid = f32(gd["dxa"]), f32(gd["dxn"]), f32(dhid)
+        it.dln_g, it.dln_b, it.dw1 = f32(G["conv_offset.1.norm.weight"]), f32(G["conv_offset.1.norm.bias"]), f32(G["conv_offset.3.weight"])
+        outs.append(dhid)
+    if not prepared:
+        for it, gd in zip(arr, groups):
+            need = _lib.lib.micf_conv3_bwd_data_workspace(16, C, C)
+            ws = _new(gd["xa"], need) if need > 0 else None
+            keep.append(ws)
+            it.conv_ws = f32(ws)
+    need = _lib.lib.micf_offset_head_bwd_workspace(n, B, D, H, W)
+    ws = scratch(groups[0]["xa"].device, need) if need > 0 else None
+    call("micf_offset_head_bwd", ctypes.cast(arr, ctypes.c_void_p), n, B, D, H, W, C, float(eps), 1 if prepared else 0, f32(ws),
+         ws.numel() if ws is not None else 0, _dt(),
+         cost=_cost(n * (2 * T * 27 * 2 * C * 16 + T * (40 * C + 800)), *[g["dxs"] for g in groups], *[g["xa"] for g in groups],
+                    *[g["dxa"] for g in groups], *[g["dxa"] for g in groups], *[g["dxn"] for g in groups]))
+    del keep
+    return outs
+
+
 def stn_fwd(src, flow, dims):
     """src [T,C] channels-last, flow [T,3] -> out [T,C]."""
     B, D, H, W = dims

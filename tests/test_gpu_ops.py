@@ -533,3 +533,54 @@ def test_input_pipeline_tail_kernel(ops, half):
     assert lv is None
     wv = torch.stack([R.normalize_intensity_nonzero(img[b]) for b in range(B)])
     assert float((xv.cpu() - wv).abs().max()) < (2e-3 if half else 2e-5)
+
+
+@pytest.mark.parametrize("dims,C", [((1, 4, 8, 8), 96), ((2, 8, 8, 16), 48), ((1, 4, 4, 4), 384)])
+def test_offset_head_pair_matches_per_op_calls(dims, C):
+    """micf_offset_head_fwd / _bwd (both heads of a cross pair per launch) against the per-modality entry points they replace."""
+    from micformer_amd import ops
+    B, D, H, W = dims
+    T = B * D * H * W
+    g = torch.Generator().manual_seed(5)
+    rnd = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).cuda()
+    xs = [rnd(T, C), rnd(T, C)]
+    xns = [rnd(T, C), rnd(T, C)]
+    Ps = [{"conv_offset.0.weight": rnd(16, 2 * C, 3, 3, 3, sc=(54 * C) ** -0.5), "conv_offset.0.bias": rnd(16, sc=0.1),
+           "conv_offset.1.norm.weight": 1 + rnd(16, sc=0.1), "conv_offset.1.norm.bias": rnd(16, sc=0.1),
+           "conv_offset.3.weight": rnd(3, 16, 1, 1, 1, sc=0.3)} for _ in (0, 1)]
+    eps = 1e-5
+    ref = []
+    for i in (0, 1):
+        hid = ops.conv3_fwd(xns[i], Ps[i]["conv_offset.0.weight"], Ps[i]["conv_offset.0.bias"], dims, x2=xs[1 - i])
+        flow, samp = ops.offset_sample_fwd(hid, Ps[i]["conv_offset.1.norm.weight"], Ps[i]["conv_offset.1.norm.bias"],
+                                           Ps[i]["conv_offset.3.weight"], xs[1 - i], dims, eps)
+        ref.append((hid, flow, samp))
+    hid0 = torch.zeros(2, T, 16, device="cuda") if ops.offset_head_needs_zero(dims, C) else None
+    got = ops.offset_head_fwd([{"xn": xns[i], "xa": xs[1 - i], "P": Ps[i]} for i in (0, 1)], dims, eps, hid0)
+    for i in (0, 1):
+        for name, a, b in zip(("hid", "flow", "xs"), got[i], ref[i]):
+            assert float((a - b).abs().max()) <= 2e-5 * max(float(b.abs().max()), 1.0), (i, name)
+    # backward
+    dxs = [rnd(T, C), rnd(T, C)]
+    def grads():
+        return [{k: torch.zeros_like(v) for k, v in P.items()} for P in Ps]
+    Gr, acc_r, dxn_r, dh_r = grads(), [rnd(T, C), rnd(T, C)], [rnd(T, C), rnd(T, C)], []
+    acc_g, dxn_g = [t.clone() for t in acc_r], [t.clone() for t in dxn_r]
+    for i in (0, 1):
+        dh = ops.offset_sample_bwd(dxs[i], ref[i][0], Ps[i]["conv_offset.1.norm.weight"], Ps[i]["conv_offset.1.norm.bias"],
+                                   Ps[i]["conv_offset.3.weight"], xs[1 - i], ref[i][1], acc_r[1 - i], Gr[i]["conv_offset.1.norm.weight"],
+                                   Gr[i]["conv_offset.1.norm.bias"], Gr[i]["conv_offset.3.weight"], dims, eps)
+        ops.conv3_bwd_data(dh, Ps[i]["conv_offset.0.weight"], dims, C, C, dx1=dxn_r[i], dx2=acc_r[1 - i], acc1=True, acc2=True)
+        dh_r.append(dh)
+    Gg = grads()
+    dh_g = ops.offset_head_bwd([{"dxs": dxs[i], "hid": ref[i][0], "flow": ref[i][1], "xa": xs[1 - i], "P": Ps[i], "G": Gg[i],
+                                 "dxa": acc_g[1 - i], "dxn": dxn_g[i]} for i in (0, 1)], dims, eps)
+    torch.cuda.synchronize()
+    def close(a, b, what):
+        assert float((a - b).abs().max()) <= 1e-4 * max(float(b.abs().max()), 1.0), what
+    for i in (0, 1):
+        close(dh_g[i], dh_r[i], f"dhid {i}")
+        close(acc_g[i], acc_r[i], f"dxa {i}")
+        close(dxn_g[i], dxn_r[i], f"dxn {i}")
+        for k in ("conv_offset.1.norm.weight", "conv_offset.1.norm.bias", "conv_offset.3.weight"):
+            close(Gg[i][k], Gr[i][k], f"{k} {i}")

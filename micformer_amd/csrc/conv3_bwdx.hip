@@ -191,7 +191,7 @@ int conv3_bwd_data_x_groups(const Conv3BwdSet* sets, int ng, int c1, int acc1, i
                             hipStream_t stream, int dtype, int prepared) {
   if (!sets || ng < 1 || ng > 2) return MICF_EINVAL;
   const int O = c1 + c2;
-  if (N > 16 || (N & 3) || (O & 15) || (c1 & 3) || (c2 & 3) || W < 8) return MICF_EUNSUPPORTED;
+  if (N > 16 || (N & 3) || (O & 15) || (c1 & 3) || (c2 & 3) || W < 4) return MICF_EUNSUPPORTED;
   for (int i = 0; i < ng; ++i)
     if (!aligned16(sets[i].dy) || !aligned16(sets[i].wt) || (sets[i].dx1 && !aligned16(sets[i].dx1)) || (sets[i].dx2 && !aligned16(sets[i].dx2)) ||
         (!sets[i].dx1) != (!sets[0].dx1) || (!sets[i].dx2) != (!sets[0].dx2))

@@ -186,7 +186,7 @@ bool conv3_fwd_x_splits(int B, int D, int H, int W, int c1, int c2) {      // do
 int conv3_fwd_x_groups(const Conv3FwdSet* sets, int n, int c1, int c2, int B, int D, int H, int W, int N, hipStream_t stream, int dtype,
                        int prepared, int y_zeroed) {
   if (!sets || n < 1 || n > 2) return MICF_EINVAL;
-  if (N > 16 || (c1 & 3) || (c2 & 3) || W < 8) return MICF_EUNSUPPORTED;
+  if (N > 16 || (c1 & 3) || (c2 & 3) || W < 4) return MICF_EUNSUPPORTED;
   for (int i = 0; i < n; ++i)
     if (!aligned16(sets[i].x1) || (sets[i].x2 && !aligned16(sets[i].x2)) || !aligned16(sets[i].y) || !aligned16(sets[i].wt)) return MICF_EUNSUPPORTED;
   const float *x1 = sets[0].x1, *x2 = sets[0].x2, *w = sets[0].w, *bias = sets[0].bias;

@@ -11,7 +11,7 @@ using namespace micf;
 // 1 when micf_offset_head_fwd accumulates the conv output atomically for this shape, i.e. `hid` must be zero when the conv
 // starts: the call clears it itself unless told (hid_zeroed) that the caller already did, off the critical path
 extern "C" int micf_offset_head_needs_zero(int B, int D, int H, int W, int C) {
-  if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || W < 8) return 0;
+  if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || W < 4) return 0;
   return conv3_fwd_x_splits(B, D, H, W, C, C) ? 1 : 0;
 }
 
@@ -31,7 +31,7 @@ extern "C" int micf_offset_head_fwd(const micf_offset_head_group* groups, int ng
   int rc = MICF_EUNSUPPORTED;
   if (groups[0].conv_ws && (ngroups == 1 || groups[1].conv_ws))
     rc = conv3_fwd_x_groups(cs, ngroups, C, C, B, D, H, W, kOffsetHidden, s, dtype, prepared, hid_zeroed);
-  if (rc == MICF_EUNSUPPORTED) {           // shapes outside the direct kernel (W < 8: the 4^3 stage): one generic call per head
+  if (rc == MICF_EUNSUPPORTED) {           // shapes outside the direct kernel (W < 4): one generic call per head
     for (int i = 0; i < ngroups; ++i) {
       rc = micf_conv3_fwd(cs[i].x1, C, cs[i].x2, C, cs[i].w, cs[i].bias, cs[i].y, 0, B, D, H, W, kOffsetHidden, nullptr, 0, 0, dtype, stream);
       if (rc != MICF_OK) return rc;

@@ -353,6 +353,21 @@ class PatchExpand(nn.Module):
         return Fn.LayerNormFn.apply(y, None, self.norm.weight, self.norm.bias, self.norm.eps)
 
 
+def _both(fn, a, b):
+    """(fn(a), fn(b)) for the two modalities -- the second call on the side stream when they may overlap (the resampling
+    convs between the stages are 40-75 us launches each: a fork / join costs less than running them back to back)."""
+    if not (PARALLEL_MODALITIES and (a[0] if isinstance(a, tuple) else a).is_cuda):
+        return fn(a), fn(b)
+    main, side = torch.cuda.current_stream(), _side_stream((a[0] if isinstance(a, tuple) else a).device)
+    side.wait_stream(main)
+    ra = fn(a)
+    with torch.cuda.stream(side):
+        rb = fn(b)
+    main.wait_stream(side)
+    rb.record_stream(main)
+    return ra, rb
+
+
 class BasicLayer(nn.Module):
     """One stage: depth x {2 self blocks (one per modality), 2 cross blocks (both read the PRE-update pair)} + optional
     resampling module passed as `downsample` (PatchMerging in the encoder, PatchExpand in the decoder)  (MS.py:582-707)."""
@@ -414,7 +429,7 @@ class BasicLayer(nn.Module):
             x, xa = self._forward_pairs(x, xa)
             resample = getattr(self, self._resample_attr)
             if resample is not None:
-                return x, xa, resample(x), resample(xa)
+                return (x, xa) + _both(resample, x, xa)
             return x, xa, x, xa
         side = _side_stream(x.device) if (PARALLEL_MODALITIES and x.is_cuda) else None
         if side is None:
@@ -442,7 +457,7 @@ class BasicLayer(nn.Module):
                 xa.record_stream(main)
         resample = getattr(self, self._resample_attr)
         if resample is not None:
-            return x, xa, resample(x), resample(xa)
+            return (x, xa) + _both(resample, x, xa)
         return x, xa, x, xa
 
 
@@ -577,8 +592,7 @@ class MicFormer(nn.Module):
                     m = Fn.ResizeTrilinearFn.apply(m, tuple(sm.shape[1:4]))
                     f = Fn.ResizeTrilinearFn.apply(f, tuple(sf.shape[1:4]))
                 lin = self.concat_back_dim[inx]
-                m = Fn.LinearFn.apply(m, sm, lin.weight, lin.bias)
-                f = Fn.LinearFn.apply(f, sf, lin.weight, lin.bias)
+                m, f = _both(lambda t: Fn.LinearFn.apply(t[0], t[1], lin.weight, lin.bias), (m, sm), (f, sf))
             _, _, m, f = up(m, f)
         return Fn.LayerNormFn.apply(m, f, self.norm2.weight, self.norm2.bias, self.norm2.eps)
 

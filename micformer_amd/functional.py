@@ -873,11 +873,12 @@ class HeadTailFn(torch.autograd.Function):
     feature x (B, Dc, Hc, Wc, 2E) -> NCDHW logits (B, classes, P*Dc, P*Hc, P*Wc).  The E/2-channel fine feature is never built."""
 
     @staticmethod
-    def forward(ctx, x, w_up, b_up, w_out, b_out):
+    def forward(ctx, x, w_up, b_up, w_out, b_out, wb=None, bf=None):
         x = _c(x)
         B, Dc, Hc, Wc, Ci = x.shape
         P = w_up.shape[2]
-        wb, bf = ops.head_tail_compose(w_up, b_up, w_out)
+        if wb is None:                                  # (else: composed earlier, off the critical path)
+            wb, bf = ops.head_tail_compose(w_up, b_up, w_out)
         xf = x.reshape(-1, Ci)
         t = ops.linear_fwd(xf, wb, bf)
         y = ops.head_tail_col2im(t, b_out, (B, Dc, Hc, Wc), P)
@@ -901,7 +902,7 @@ class HeadTailFn(torch.autograd.Function):
             ops.head_tail_decompose(dwb, dbf, w_up, b_up, w_out, *grads)
 
         _defer(all(t is not None for t in ctx.tg), weight_grads, u, xf, wb)
-        return (dx.reshape(B, Dc, Hc, Wc, -1),) + tuple(_ret(t, g) for t, g in zip(ctx.tg, grads))
+        return (dx.reshape(B, Dc, Hc, Wc, -1),) + tuple(_ret(t, g) for t, g in zip(ctx.tg, grads)) + (None, None)
 
 
 class ResizeTrilinearFn(torch.autograd.Function):

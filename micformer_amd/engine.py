@@ -161,7 +161,7 @@ class TrainEngine:
             prev = (_ms.PARALLEL_MODALITIES, _fn.DEFER_WGRAD, _fn.FLUSH_POINTS, _fn.DEFER_CALLS)
             _ms.PARALLEL_MODALITIES, _fn.DEFER_WGRAD = self.parallel_modalities, self.defer_wgrad
             _fn.FLUSH_POINTS = self.defer_wgrad and self.flush_points and not self.split_step
-            _fn.DEFER_CALLS = self.defer_wgrad and not self.split_step
+            _fn.DEFER_CALLS = self.defer_wgrad
             try:
                 yield
             finally:
@@ -187,9 +187,8 @@ class TrainEngine:
             _fn.run_entry_hook(force=True)                          # (fewer than 3 stages: launched here)
             main.wait_stream(side)
             loss.backward()                                         #                              train.py:200
-            if flush:
-                _fn.flush_wgrad()                                   # queued linear weight gradients, grouped launches
-                _fn.join_wgrad_stream()                             # (stage-boundary flushes ran on a side stream)
+            _fn.flush_wgrad(calls_only=not flush)                   # what is still queued: grouped linear weight gradients (left
+            _fn.join_wgrad_stream()                                 # to the data-parallel tail when flush=False), closures
         return loss.detach()
 
     def _adam(self, grad_scale):

@@ -116,24 +116,28 @@ def _wgrad_stream(device):
     return st
 
 
-def flush_wgrad_side():
-    """Launch everything queued so far on the weight-gradient side stream (ordered after the current stream's work)."""
-    if not (_DEFERRED or _DEFERRED_LN or _DEFERRED_CALLS):
+def flush_wgrad_side(calls_only=False):
+    """Launch everything queued so far on the weight-gradient side stream (ordered after the current stream's work).
+    calls_only: just the deferred closures (data-parallel mode: the grouped linear weight gradients stay queued for the
+    engine, which interleaves them with the gradient all-reduce after the replay)."""
+    if not ((not calls_only and (_DEFERRED or _DEFERRED_LN)) or _DEFERRED_CALLS):
         return
-    dev = (_DEFERRED[0][0] if _DEFERRED else (_DEFERRED_LN[0][0] if _DEFERRED_LN else _DEFERRED_CALLS[0][1][0])).device
+    first = _DEFERRED_CALLS[0][1][0] if _DEFERRED_CALLS else (_DEFERRED[0][0] if _DEFERRED else _DEFERRED_LN[0][0])
+    dev = first.device
     main, side = torch.cuda.current_stream(dev), _wgrad_stream(dev)
     side.wait_stream(main)
-    for it in _DEFERRED:                    # the queue's references die at the flush: tell the allocator who still reads them
-        for t in (it[0], it[1], it[4]):
-            if t is not None:
-                t.record_stream(side)
-    for it in _DEFERRED_LN:
-        it[0].record_stream(side)
+    if not calls_only:
+        for it in _DEFERRED:                # the queue's references die at the flush: tell the allocator who still reads them
+            for t in (it[0], it[1], it[4]):
+                if t is not None:
+                    t.record_stream(side)
+        for it in _DEFERRED_LN:
+            it[0].record_stream(side)
     for _, tensors, _blk in _DEFERRED_CALLS:
         for t in tensors:
             t.record_stream(side)
     with torch.cuda.stream(side):
-        flush_wgrad()
+        flush_wgrad(calls_only)
     _WSIDE_USED.add(dev)
 
 
@@ -172,17 +176,21 @@ class FlushPointFn(torch.autograd.Function):
         # the weight gradients of the big stages then pile up in the tail)
         if FLUSH_POINTS and DEFER_WGRAD and dx.numel() // dx.shape[-1] <= FLUSH_MAX_TOKENS:
             flush_wgrad_side()
+        elif DEFER_CALLS and DEFER_WGRAD:
+            flush_wgrad_side(calls_only=True)
         return dx, dxa
 
 
-def flush_wgrad():
+def flush_wgrad(calls_only=False):
     """Launch every queued weight gradient on the current stream (which must be ordered after their producers)."""
     with block_region():
-        if _DEFERRED_LN:
+        if calls_only:
+            pass
+        elif _DEFERRED_LN:
             ln = list(_DEFERRED_LN)
             _DEFERRED_LN.clear()
             ops.layernorm_bwd_finish(ln)
-        if _DEFERRED:
+        if _DEFERRED and not calls_only:
             items = list(_DEFERRED)
             _DEFERRED.clear()
             _QUEUED_DW.clear()

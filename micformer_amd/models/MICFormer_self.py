@@ -409,7 +409,7 @@ class BasicLayer(nn.Module):
 
     def _forward_pairs(self, x, xa):
         for i in range(self.depth):
-            if i and Fn.FLUSH_POINTS and x.requires_grad:
+            if i and (Fn.FLUSH_POINTS or Fn.DEFER_CALLS) and x.requires_grad:
                 x, xa = Fn.FlushPointFn.apply(x, xa)   # backward: the later slots' weight gradients start under this slot's chain
             a, b = self.self_blocks1[i], self.self_blocks2[i]
             sa, sb = _block_scales(a, x), _block_scales(b, xa)
@@ -423,7 +423,7 @@ class BasicLayer(nn.Module):
 
     def forward(self, x, xa):
         Fn.run_entry_hook()                            # (engine: side work parked for this point of the forward)
-        if Fn.FLUSH_POINTS and x.requires_grad:
+        if (Fn.FLUSH_POINTS or Fn.DEFER_CALLS) and x.requires_grad:
             x, xa = Fn.FlushPointFn.apply(x, xa)       # backward: launch this stage's queued weight gradients on a side stream
         if self._pair_fusable(x, xa):
             x, xa = self._forward_pairs(x, xa)

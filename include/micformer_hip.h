@@ -300,6 +300,21 @@ int micf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, cons
                    float beta2, float eps, float grad_scale, void* p_bf16, micf_stream_t stream);
 
 
+/* ---- two LayerNorms of the same shape per launch (the two modalities of a pair); fields as in micf_layernorm_fwd / _bwd
+ * (single-source rows).  `items` is HOST memory, read during the call only. */
+typedef struct micf_ln_pair_item {
+  const float *x, *gamma, *beta;
+  float *y, *mean, *rstd;
+} micf_ln_pair_item;
+typedef struct micf_ln_bwd_pair_item {
+  const float *dy, *x, *mean, *rstd, *gamma;
+  float *dx, *dgamma, *dbeta; /* dgamma / dbeta: accumulated (NULL with partials) */
+  const float* add;           /* optional: dx = add + LN'(dy) */
+  float* partials;            /* optional [micf_layernorm_bwd_partial_rows][2C] for micf_layernorm_bwd_finish */
+} micf_ln_bwd_pair_item;
+int micf_layernorm_fwd_pair(const micf_ln_pair_item* items, int n, int64_t rows, int C, float eps, micf_stream_t stream);
+int micf_layernorm_bwd_pair(const micf_ln_bwd_pair_item* items, int n, int64_t rows, int C, micf_stream_t stream);
+
 /* ---- The offset head of a cross block for both modalities of a cross pair in one call (csrc/offset_head.hip; MS.py:354-384):
  * hid = conv3(cat[xn, xa]) ; flow = conv1(GELU(LN16(hid))) ; xs = trilinear sample of raw xa at the reference points + flow.
  * Replaces micf_conv3_fwd + micf_offset_sample_fwd (and, backward, micf_offset_sample_bwd + micf_conv3_bwd_data) per

@@ -40,6 +40,8 @@ SIGNATURES = {
     "micf_conv3_fwd_workspace": "iii",
     "micf_conv3_bwd_data": "pippiipiiiiiiipliip",
     "micf_conv3_weight_prep_grouped": "pip",
+    "micf_layernorm_fwd_pair": "pilifp",
+    "micf_layernorm_bwd_pair": "pilip",
     "micf_offset_head_needs_zero": "iiiii",
     "micf_offset_head_fwd": "piiiiiifiiip",
     "micf_offset_head_bwd_workspace": "iiiii",
@@ -119,6 +121,18 @@ class WeightPrepItem(ctypes.Structure):
     """struct micf_weight_prep_item (include/micformer_hip.h)."""
     _fields_ = [("src", _VP), ("dst", _VP), ("dst_t", _VP), ("rows", ctypes.c_int32), ("cols", ctypes.c_int32),
                 ("bf16", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class LnPairItem(ctypes.Structure):
+    """struct micf_ln_pair_item (include/micformer_hip.h)."""
+    FIELDS = ("x", "gamma", "beta", "y", "mean", "rstd")
+    _fields_ = [(n, _VP) for n in FIELDS]
+
+
+class LnBwdPairItem(ctypes.Structure):
+    """struct micf_ln_bwd_pair_item (include/micformer_hip.h)."""
+    FIELDS = ("dy", "x", "mean", "rstd", "gamma", "dx", "dgamma", "dbeta", "add", "partials")
+    _fields_ = [(n, _VP) for n in FIELDS]
 
 
 class OffsetHeadGroup(ctypes.Structure):

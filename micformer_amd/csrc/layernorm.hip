@@ -91,7 +91,7 @@ __device__ __forceinline__ float group_sum(float v) {
 }
 
 template <int LPR, int VPL>
-__global__ void __launch_bounds__(256) ln_fwd_v2(const float* __restrict__ x, const float* __restrict__ gamma,
+__device__ __forceinline__ void ln_fwd_v2_body(const float* __restrict__ x, const float* __restrict__ gamma,
                                                  const float* __restrict__ beta, float* __restrict__ y,
                                                  float* __restrict__ mean, float* __restrict__ rstd, int64_t rows, int C,
                                                  float eps, int rpb) {
@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(256) ln_fwd_v2(const float* __restrict__ x, co
 }
 
 template <int LPR, int VPL>
-__global__ void __launch_bounds__(256) ln_bwd_v2(const float* dy, const float* __restrict__ x, const float* __restrict__ mean,
+__device__ __forceinline__ void ln_bwd_v2_body(const float* dy, const float* __restrict__ x, const float* __restrict__ mean,
                                                  const float* __restrict__ rstd, const float* __restrict__ gamma, float* dx,
                                                  float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int C,
                                                  const float* add, float* __restrict__ partials, int rpb) {
@@ -263,10 +263,26 @@ static int ln_v2_rpb(int64_t rows, int lpr, int max_blocks) {
   return (int)(rpb < step ? step : rpb);
 }
 
-#define MICF_LN_DISPATCH(KERNEL, SMEM, MAXB, ...)                                                        \
+// launch form: up to two independent LayerNorms of the same shape per launch (blockIdx.y): the two modalities of a pair
+struct LnFwdSet { const float *x, *gamma, *beta; float *y, *mean, *rstd; };
+struct LnBwdSet { const float *dy, *x, *mean, *rstd, *gamma; float *dx, *dgamma, *dbeta; const float* add; float* partials; };
+struct LnFwdSets { LnFwdSet s[2]; };
+struct LnBwdSets { LnBwdSet s[2]; };
+template <int LPR, int VPL>
+__global__ void __launch_bounds__(256) ln_fwd_v2(const LnFwdSets p, int64_t rows, int C, float eps, int rpb) {
+  const LnFwdSet& q = p.s[blockIdx.y];
+  ln_fwd_v2_body<LPR, VPL>(q.x, q.gamma, q.beta, q.y, q.mean, q.rstd, rows, C, eps, rpb);
+}
+template <int LPR, int VPL>
+__global__ void __launch_bounds__(256) ln_bwd_v2(const LnBwdSets p, int64_t rows, int C, int rpb) {
+  const LnBwdSet& q = p.s[blockIdx.y];
+  ln_bwd_v2_body<LPR, VPL>(q.dy, q.x, q.mean, q.rstd, q.gamma, q.dx, q.dgamma, q.dbeta, rows, C, q.add, q.partials, rpb);
+}
+
+#define MICF_LN_DISPATCH(KERNEL, SMEM, MAXB, NG, ...)                                                    \
   do {                                                                                                   \
     const int rpb = ln_v2_rpb(rows, lpr, MAXB);                                                          \
-    const dim3 grid(ceil_div(rows, rpb));                                                                \
+    const dim3 grid(ceil_div(rows, rpb), NG);                                                            \
     hipStream_t s_ = (hipStream_t)stream;                                                                \
     if (lpr == 16 && vpl == 1) hipLaunchKernelGGL((KERNEL<16, 1>), grid, dim3(256), SMEM, s_, __VA_ARGS__, rpb); \
     else if (lpr == 32 && vpl == 1) hipLaunchKernelGGL((KERNEL<32, 1>), grid, dim3(256), SMEM, s_, __VA_ARGS__, rpb); \
@@ -286,7 +302,9 @@ extern "C" int micf_layernorm_fwd(const float* x1, const float* x2, int c1, cons
   if (rows == 0) return MICF_OK;
   int lpr, vpl;
   if (!x2 && ln_v2_shape(C, lpr, vpl) && aligned16(x1) && aligned16(y) && aligned16(gamma) && aligned16(beta)) {
-    MICF_LN_DISPATCH(ln_fwd_v2, 0, 2048, x1, gamma, beta, y, mean, rstd, rows, C, eps);
+    LnFwdSets p;
+    p.s[0] = p.s[1] = LnFwdSet{x1, gamma, beta, y, mean, rstd};
+    MICF_LN_DISPATCH(ln_fwd_v2, 0, 2048, 1, p, rows, C, eps);
     MICF_RETURN_LAUNCH();
   }
   const int rpb = ln_rows_per_block(rows);
@@ -336,7 +354,9 @@ extern "C" int micf_layernorm_bwd(const float* dy, const float* x1, const float*
   int lpr, vpl;
   if (!x2 && ln_v2_shape(C, lpr, vpl) && aligned16(x1) && aligned16(dy) && aligned16(dx1) && aligned16(gamma) &&
       (!add || aligned16(add))) {
-    MICF_LN_DISPATCH(ln_bwd_v2, 2 * C * sizeof(float), 512, dy, x1, mean, rstd, gamma, dx1, dgamma, dbeta, rows, C, add, partials);
+    LnBwdSets p;
+    p.s[0] = p.s[1] = LnBwdSet{dy, x1, mean, rstd, gamma, dx1, dgamma, dbeta, add, partials};
+    MICF_LN_DISPATCH(ln_bwd_v2, 2 * C * sizeof(float), 512, 1, p, rows, C);
     MICF_RETURN_LAUNCH();
   }
   if (partials) return MICF_EUNSUPPORTED;          // the partial form exists for the vector kernel only (see ..._partial_rows)
@@ -344,5 +364,55 @@ extern "C" int micf_layernorm_bwd(const float* dy, const float* x1, const float*
   const int blocks = ceil_div(rows, rpb);
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 2 * C * sizeof(float), (hipStream_t)stream, dy, x1,
                      x2 ? x2 : x1, c1, mean, rstd, gamma, dx1, dx2 ? dx2 : dx1, dgamma, dbeta, rows, C, add, rpb);
+  MICF_RETURN_LAUNCH();
+}
+
+// ---- two LayerNorms of the same shape in ONE launch (the two modalities of a cross pair: LN1 forward / backward of both blocks)
+extern "C" int micf_layernorm_fwd_pair(const micf_ln_pair_item* items, int n, int64_t rows, int C, float eps, micf_stream_t stream) {
+  if (!items || n < 1 || n > 2 || rows < 0 || C <= 0) return MICF_EINVAL;
+  if (rows == 0) return MICF_OK;
+  int lpr, vpl;
+  bool ok = ln_v2_shape(C, lpr, vpl);
+  LnFwdSets p;
+  for (int i = 0; i < 2; ++i) {
+    const micf_ln_pair_item& it = items[i < n ? i : 0];
+    if (!it.x || !it.gamma || !it.beta || !it.y) return MICF_EINVAL;
+    ok = ok && aligned16(it.x) && aligned16(it.y) && aligned16(it.gamma) && aligned16(it.beta);
+    p.s[i] = LnFwdSet{it.x, it.gamma, it.beta, it.y, it.mean, it.rstd};
+  }
+  if (!ok) {
+    for (int i = 0; i < n; ++i) {
+      const int rc = micf_layernorm_fwd(items[i].x, nullptr, C, items[i].gamma, items[i].beta, items[i].y, items[i].mean, items[i].rstd, rows, C, eps, stream);
+      if (rc != MICF_OK) return rc;
+    }
+    return MICF_OK;
+  }
+  MICF_LN_DISPATCH(ln_fwd_v2, 0, 2048, n, p, rows, C, eps);
+  MICF_RETURN_LAUNCH();
+}
+
+extern "C" int micf_layernorm_bwd_pair(const micf_ln_bwd_pair_item* items, int n, int64_t rows, int C, micf_stream_t stream) {
+  if (!items || n < 1 || n > 2 || rows < 0 || C <= 0) return MICF_EINVAL;
+  if (C > kLnMaxC) return MICF_EUNSUPPORTED;
+  if (rows == 0) return MICF_OK;
+  int lpr, vpl;
+  bool ok = ln_v2_shape(C, lpr, vpl);
+  LnBwdSets p;
+  for (int i = 0; i < 2; ++i) {
+    const micf_ln_bwd_pair_item& it = items[i < n ? i : 0];
+    if (!it.dy || !it.x || !it.mean || !it.rstd || !it.gamma || !it.dx) return MICF_EINVAL;
+    ok = ok && aligned16(it.x) && aligned16(it.dy) && aligned16(it.dx) && aligned16(it.gamma) && (!it.add || aligned16(it.add));
+    p.s[i] = LnBwdSet{it.dy, it.x, it.mean, it.rstd, it.gamma, it.dx, it.dgamma, it.dbeta, it.add, it.partials};
+  }
+  if (!ok) {
+    for (int i = 0; i < n; ++i) {
+      const micf_ln_bwd_pair_item& it = items[i];
+      const int rc = micf_layernorm_bwd(it.dy, it.x, nullptr, C, it.mean, it.rstd, it.gamma, it.dx, nullptr, it.dgamma, it.dbeta, rows, C, it.add,
+                                        it.partials, stream);
+      if (rc != MICF_OK) return rc;
+    }
+    return MICF_OK;
+  }
+  MICF_LN_DISPATCH(ln_bwd_v2, 2 * C * sizeof(float), 512, n, p, rows, C);
   MICF_RETURN_LAUNCH();
 }

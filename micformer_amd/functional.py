@@ -704,7 +704,7 @@ class CrossPairFn(torch.autograd.Function):
         xs = [x.reshape(-1, C), xa.reshape(-1, C)]
         if GROUP_CROSS_HEADS:
             # both offset heads per launch (micf_offset_head_fwd): no fork / join inside the captured graph
-            lns = [ops.layernorm_fwd(xs[i], Ps[i]["norm1.weight"], Ps[i]["norm1.bias"], eps) for i in (0, 1)]
+            lns = ops.layernorm_fwd_pair(xs, [P["norm1.weight"] for P in Ps], [P["norm1.bias"] for P in Ps], eps)
             hid = None
             if ops.offset_head_needs_zero(dims, C):
                 hid = ops.zero_(torch.empty((2, xs[0].shape[0], 16), dtype=torch.float32, device=x.device))
@@ -776,10 +776,15 @@ class CrossPairFn(torch.autograd.Function):
                     _cross_head_adjoint(i, hds, bos, Ps, Gs, xs, acc, dims, eps, C, sides)
             if side is not None:
                 main.wait_stream(side)
-        for i in (0, 1):
-            xn, m1, r1 = hds[i][:3]
-            ops.layernorm_bwd(bos[i]["dx"], xs[i], m1, r1, Ps[i]["norm1.weight"], Gs[i]["norm1.weight"], Gs[i]["norm1.bias"],
-                              add=acc[i], defer=_ln_defer(sides[i]), out=acc[i])
+        if GROUP_CROSS_HEADS:
+            ops.layernorm_bwd_pair([{"dy": bos[i]["dx"], "x": xs[i], "mean": hds[i][1], "rstd": hds[i][2], "gamma": Ps[i]["norm1.weight"],
+                                     "dgamma": Gs[i]["norm1.weight"], "dbeta": Gs[i]["norm1.bias"], "add": acc[i], "out": acc[i]}
+                                    for i in (0, 1)], [_ln_defer(sides[i]) for i in (0, 1)])
+        else:
+            for i in (0, 1):
+                xn, m1, r1 = hds[i][:3]
+                ops.layernorm_bwd(bos[i]["dx"], xs[i], m1, r1, Ps[i]["norm1.weight"], Gs[i]["norm1.weight"], Gs[i]["norm1.bias"],
+                                  add=acc[i], defer=_ln_defer(sides[i]), out=acc[i])
         shape = dims + (C,)
         grads = tuple(_ret(t, G[k]) for G, tg in zip(Gs, tgs) for k, t in zip(CROSS_KEYS, tg))
         return (acc[0].reshape(shape), acc[1].reshape(shape), None, None, None, None, None, None) + grads

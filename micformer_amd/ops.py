@@ -83,6 +83,41 @@ def layernorm_bwd(dy, x1, mean, rstd, gamma, dgamma, dbeta, x2=None, add=None, d
     return (dx1, dx2) if x2 is not None else dx1
 
 
+def layernorm_fwd_pair(xs, gammas, betas, eps):
+    """Two LayerNorms of the same shape in ONE launch: xs / gammas / betas are 2-lists -> [(y, mean, rstd)] * 2."""
+    rows, C = xs[0].shape
+    arr = (_lib.LnPairItem * 2)()
+    outs = []
+    for it, x, g, b in zip(arr, xs, gammas, betas):
+        y, mean, rstd = _new(x, rows, C), _new(x, rows), _new(x, rows)
+        it.x, it.gamma, it.beta, it.y, it.mean, it.rstd = f32(x), f32(g), f32(b), f32(y), f32(mean), f32(rstd)
+        outs.append((y, mean, rstd))
+    call("micf_layernorm_fwd_pair", ctypes.cast(arr, ctypes.c_void_p), len(xs), rows, C, float(eps),
+         cost=_cost(8 * rows * C * len(xs), *xs, *[o[0] for o in outs]))
+    return outs
+
+
+def layernorm_bwd_pair(items, defers):
+    """items: 2-list of dicts {dy, x, mean, rstd, gamma, dgamma, dbeta, add, out}; defers: per item a list (queue the parameter
+    gradient partials for layernorm_bwd_finish) or None.  ONE launch; returns the two dx (= out when given)."""
+    rows, C = items[0]["x"].shape
+    arr = (_lib.LnBwdPairItem * 2)()
+    outs = []
+    nb = _lib.lib.micf_layernorm_bwd_partial_rows(rows, C, C)
+    for it, d, defer in zip(arr, items, defers):
+        dx = d.get("out") if d.get("out") is not None else _new(d["x"], rows, C)
+        partials = None
+        if defer is not None and nb > 0:
+            partials = _new(d["x"], nb, 2 * C)
+            defer.append((partials, nb, C, d["dgamma"], d["dbeta"]))
+        it.dy, it.x, it.mean, it.rstd, it.gamma = f32(d["dy"]), f32(d["x"]), f32(d["mean"]), f32(d["rstd"]), f32(d["gamma"])
+        it.dx, it.dgamma, it.dbeta, it.add, it.partials = f32(dx), f32(d["dgamma"]), f32(d["dbeta"]), f32(d.get("add")), f32(partials)
+        outs.append(dx)
+    call("micf_layernorm_bwd_pair", ctypes.cast(arr, ctypes.c_void_p), len(items), rows, C,
+         cost=_cost(12 * rows * C * len(items), *[d["dy"] for d in items], *[d["x"] for d in items], *outs, *[d.get("add") for d in items]))
+    return outs
+
+
 class LnFinishPlan:
     """ctypes item array of queued LayerNorm parameter-gradient partials (reusable while the tensors keep their addresses)."""
 

@@ -312,7 +312,9 @@ typedef struct micf_ln_bwd_pair_item {
   const float* add;           /* optional: dx = add + LN'(dy) */
   float* partials;            /* optional [micf_layernorm_bwd_partial_rows][2C] for micf_layernorm_bwd_finish */
 } micf_ln_bwd_pair_item;
-int micf_layernorm_fwd_pair(const micf_ln_pair_item* items, int n, int64_t rows, int C, float eps, micf_stream_t stream);
+/* zero / zero_floats: optional buffer the same launch clears (the offset conv's atomically accumulated output) */
+int micf_layernorm_fwd_pair(const micf_ln_pair_item* items, int n, int64_t rows, int C, float eps, float* zero,
+                            int64_t zero_floats, micf_stream_t stream);
 int micf_layernorm_bwd_pair(const micf_ln_bwd_pair_item* items, int n, int64_t rows, int C, micf_stream_t stream);
 
 /* ---- The offset head of a cross block for both modalities of a cross pair in one call (csrc/offset_head.hip; MS.py:354-384):

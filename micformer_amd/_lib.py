@@ -40,7 +40,7 @@ SIGNATURES = {
     "micf_conv3_fwd_workspace": "iii",
     "micf_conv3_bwd_data": "pippiipiiiiiiipliip",
     "micf_conv3_weight_prep_grouped": "pip",
-    "micf_layernorm_fwd_pair": "pilifp",
+    "micf_layernorm_fwd_pair": "pilifplp",
     "micf_layernorm_bwd_pair": "pilip",
     "micf_offset_head_needs_zero": "iiiii",
     "micf_offset_head_fwd": "piiiiiifiiip",

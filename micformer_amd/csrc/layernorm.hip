@@ -266,11 +266,13 @@ static int ln_v2_rpb(int64_t rows, int lpr, int max_blocks) {
 // launch form: up to two independent LayerNorms of the same shape per launch (blockIdx.y): the two modalities of a pair
 struct LnFwdSet { const float *x, *gamma, *beta; float *y, *mean, *rstd; };
 struct LnBwdSet { const float *dy, *x, *mean, *rstd, *gamma; float *dx, *dgamma, *dbeta; const float* add; float* partials; };
-struct LnFwdSets { LnFwdSet s[2]; };
+struct LnFwdSets { LnFwdSet s[2]; float4* zero; int64_t zero4; };   // zero: optional side job (clears zero4 float4s)
 struct LnBwdSets { LnBwdSet s[2]; };
 template <int LPR, int VPL>
 __global__ void __launch_bounds__(256) ln_fwd_v2(const LnFwdSets p, int64_t rows, int C, float eps, int rpb) {
   const LnFwdSet& q = p.s[blockIdx.y];
+  if (p.zero && blockIdx.y == 0)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < p.zero4; i += (int64_t)gridDim.x * 256) p.zero[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   ln_fwd_v2_body<LPR, VPL>(q.x, q.gamma, q.beta, q.y, q.mean, q.rstd, rows, C, eps, rpb);
 }
 template <int LPR, int VPL>
@@ -304,6 +306,7 @@ extern "C" int micf_layernorm_fwd(const float* x1, const float* x2, int c1, cons
   if (!x2 && ln_v2_shape(C, lpr, vpl) && aligned16(x1) && aligned16(y) && aligned16(gamma) && aligned16(beta)) {
     LnFwdSets p;
     p.s[0] = p.s[1] = LnFwdSet{x1, gamma, beta, y, mean, rstd};
+    p.zero = nullptr; p.zero4 = 0;
     MICF_LN_DISPATCH(ln_fwd_v2, 0, 2048, 1, p, rows, C, eps);
     MICF_RETURN_LAUNCH();
   }
@@ -368,9 +371,11 @@ extern "C" int micf_layernorm_bwd(const float* dy, const float* x1, const float*
 }
 
 // ---- two LayerNorms of the same shape in ONE launch (the two modalities of a cross pair: LN1 forward / backward of both blocks)
-extern "C" int micf_layernorm_fwd_pair(const micf_ln_pair_item* items, int n, int64_t rows, int C, float eps, micf_stream_t stream) {
-  if (!items || n < 1 || n > 2 || rows < 0 || C <= 0) return MICF_EINVAL;
-  if (rows == 0) return MICF_OK;
+extern "C" int micf_layernorm_fwd_pair(const micf_ln_pair_item* items, int n, int64_t rows, int C, float eps, float* zero,
+                                       int64_t zero_floats, micf_stream_t stream) {
+  if (!items || n < 1 || n > 2 || rows < 0 || C <= 0 || zero_floats < 0 || (zero_floats > 0 && !zero)) return MICF_EINVAL;
+  if (zero_floats > 0 && ((zero_floats & 3) || !aligned16(zero))) return MICF_EINVAL;
+  if (rows == 0) return zero_floats ? micf_zero(zero, zero_floats * 4, stream) : MICF_OK;
   int lpr, vpl;
   bool ok = ln_v2_shape(C, lpr, vpl);
   LnFwdSets p;
@@ -385,8 +390,9 @@ extern "C" int micf_layernorm_fwd_pair(const micf_ln_pair_item* items, int n, in
       const int rc = micf_layernorm_fwd(items[i].x, nullptr, C, items[i].gamma, items[i].beta, items[i].y, items[i].mean, items[i].rstd, rows, C, eps, stream);
       if (rc != MICF_OK) return rc;
     }
-    return MICF_OK;
+    return zero_floats ? micf_zero(zero, zero_floats * 4, stream) : MICF_OK;
   }
+  p.zero = reinterpret_cast<float4*>(zero); p.zero4 = zero_floats / 4;
   MICF_LN_DISPATCH(ln_fwd_v2, 0, 2048, n, p, rows, C, eps);
   MICF_RETURN_LAUNCH();
 }

@@ -704,10 +704,10 @@ class CrossPairFn(torch.autograd.Function):
         xs = [x.reshape(-1, C), xa.reshape(-1, C)]
         if GROUP_CROSS_HEADS:
             # both offset heads per launch (micf_offset_head_fwd): no fork / join inside the captured graph
-            lns = ops.layernorm_fwd_pair(xs, [P["norm1.weight"] for P in Ps], [P["norm1.bias"] for P in Ps], eps)
             hid = None
-            if ops.offset_head_needs_zero(dims, C):
-                hid = ops.zero_(torch.empty((2, xs[0].shape[0], 16), dtype=torch.float32, device=x.device))
+            if ops.offset_head_needs_zero(dims, C):     # (atomically accumulated conv output: cleared by the LayerNorm launch)
+                hid = torch.empty((2, xs[0].shape[0], 16), dtype=torch.float32, device=x.device)
+            lns = ops.layernorm_fwd_pair(xs, [P["norm1.weight"] for P in Ps], [P["norm1.bias"] for P in Ps], eps, zero=hid)
             outs = ops.offset_head_fwd([{"xn": lns[i][0], "xa": xs[1 - i], "P": Ps[i]} for i in (0, 1)], dims, eps, hid)
             heads_ = [lns[i] + outs[i] for i in (0, 1)]
         elif OVERLAP_CROSS_HEADS:

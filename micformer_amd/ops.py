@@ -83,8 +83,9 @@ def layernorm_bwd(dy, x1, mean, rstd, gamma, dgamma, dbeta, x2=None, add=None, d
     return (dx1, dx2) if x2 is not None else dx1
 
 
-def layernorm_fwd_pair(xs, gammas, betas, eps):
-    """Two LayerNorms of the same shape in ONE launch: xs / gammas / betas are 2-lists -> [(y, mean, rstd)] * 2."""
+def layernorm_fwd_pair(xs, gammas, betas, eps, zero=None):
+    """Two LayerNorms of the same shape in ONE launch: xs / gammas / betas are 2-lists -> [(y, mean, rstd)] * 2.
+    zero: optional fp32 tensor (numel % 4 == 0) cleared by the same launch."""
     rows, C = xs[0].shape
     arr = (_lib.LnPairItem * 2)()
     outs = []
@@ -92,7 +93,8 @@ def layernorm_fwd_pair(xs, gammas, betas, eps):
         y, mean, rstd = _new(x, rows, C), _new(x, rows), _new(x, rows)
         it.x, it.gamma, it.beta, it.y, it.mean, it.rstd = f32(x), f32(g), f32(b), f32(y), f32(mean), f32(rstd)
         outs.append((y, mean, rstd))
-    call("micf_layernorm_fwd_pair", ctypes.cast(arr, ctypes.c_void_p), len(xs), rows, C, float(eps),
+    call("micf_layernorm_fwd_pair", ctypes.cast(arr, ctypes.c_void_p), len(xs), rows, C, float(eps), f32(zero),
+         zero.numel() if zero is not None else 0,
          cost=_cost(8 * rows * C * len(xs), *xs, *[o[0] for o in outs]))
     return outs
 

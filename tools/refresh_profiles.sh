@@ -26,7 +26,13 @@ done
 KEY=$(python -c "import json;print(json.load(open('$OUT/${R}_bench.json'))['roofline']['kernel'])")
 CALLS=$(python -c "import json;print(json.load(open('$OUT/${R}_bench.json'))['roofline']['launches_per_step'])")
 echo "dominant kernel: $KEY ($CALLS calls per step)" > $OUT/${R}_pmc_summary.txt
-python tools/pmc_summary.py $OUT/pmc $OUT/${R}_pmc_hbm_by_kernel.csv --key "$KEY" --kernels "${PMC_KERNELS:-block_bwd_kernel<48}" --calls-per-step $CALLS \
+case "$KEY" in      # kernels launched by one call of the dominant entry point
+  micf_linear_bwd_weight_grouped*) KERN="wgrad_grouped_kernel,wgrad_grouped_reduce_kernel";;
+  micf_block_bwd*) KERN="block_bwd_kernel<48";;
+  micf_block_fwd*) KERN="block_fwd_kernel<48";;
+  *) KERN="${KEY%%|*}";;
+esac
+python tools/pmc_summary.py $OUT/pmc $OUT/${R}_pmc_hbm_by_kernel.csv --key "$KEY" --kernels "${PMC_KERNELS:-$KERN}" --calls-per-step $CALLS \
   --json $OUT/pmc_traffic.json >> $OUT/${R}_pmc_summary.txt
 # matrix-core utilisation per kernel (its own pass)
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma -o m -- \

@@ -23,7 +23,7 @@ from .loss.dice import MDiceLoss
 class TrainEngine:
     def __init__(self, model, base_lr=1e-4, t_max=150, eta_min=0.0, betas=(0.9, 0.999), eps=1e-8, criterion=None,
                  use_graph=False, process_group=None, grad_bucket_bytes=64 << 20, parallel_modalities=True,
-                 defer_wgrad=True, split_step=None, always_collective=False, flush_points=True):
+                 defer_wgrad=True, split_step=None, always_collective=False, flush_points=True, early_adam=True):
         self.model = model
         self.criterion = criterion if criterion is not None else MDiceLoss()
         self.base_lr, self.t_max, self.eta_min = base_lr, t_max, eta_min
@@ -39,6 +39,7 @@ class TrainEngine:
         self.parallel_modalities = bool(parallel_modalities)
         self.defer_wgrad = bool(defer_wgrad)     # linear weight gradients: queued in backward, one grouped flush
         self.flush_points = bool(flush_points)   # ... launched stage by stage on a side stream while backward continues
+        self.early_adam = bool(early_adam)       # Adam over the decoder + last-stage parameters starts under the encoder's backward
         # Data parallel (or split_step=True, a single-GPU test hook): the graph holds forward + backward only; the queued weight
         # gradients are then launched group by group and every gradient slice is all-reduced as soon as its last writer is
         # done, overlapping RCCL with the remaining weight-gradient launches (see _flush_and_reduce).
@@ -90,6 +91,22 @@ class TrainEngine:
                 p._micf_grad = p.grad       # backward kernels accumulate straight into the flat gradient buffer
         self.params, self.offsets, self.sizes = params, offs, sizes
         self.adam_state = ops.adam_state(dev)
+        # Early optimiser step: the backward visits the stages in reverse, so once it has left the LAST encoder stage every
+        # gradient of that stage, the whole decoder and the head is final.  If those parameters form the tail [cut, total) of
+        # the flat buffers (model order: patch embed, encoder stages, decoder, head), Adam runs over that tail on the side stream
+        # while the backward of the earlier encoder stages continues, and only [0, cut) is left for the end of the step.
+        self._early_cut, self._early_layer, self._adam_tail_done = None, None, False
+        stages = getattr(getattr(self.model, "swin", self.model), "layers", None)
+        if stages is not None and len(stages) >= 2:
+            pre = [n.split(".layers.")[0] for n in names if ".layers." in n]
+            root = pre[0] if pre else None
+            early = lambda n: root is not None and (n.startswith(root + ".patch_embed.") or any(
+                n.startswith(f"{root}.layers.{i}.") for i in range(len(stages) - 1)))
+            ends = [o + s for n, o, s in zip(names, offs, sizes) if early(n)]
+            if ends:
+                cut = (max(ends) + 3) // 4 * 4
+                if all(o >= cut for n, o in zip(names, offs) if not early(n)) and cut < total:
+                    self._early_cut, self._early_layer = cut, stages[len(stages) - 1]
         # What the fused kernels stream instead of the parameters themselves, all refreshed once per step (the weights only
         # change in Adam):
         #   * bf16 mode, forward: a bf16 mirror of the WHOLE flat parameter buffer, written by the Adam kernel in the pass that
@@ -182,6 +199,10 @@ class TrainEngine:
                     ops.zero_(self.flat_g)                          # optimizer.zero_grad()        train.py:183
                     bwd.launch()                                    # W^T shadows of the fused backward
             _fn.park_entry_hook(backward_prep, at=3)
+            _fn.BACKWARD_HOOKS.clear()
+            self._adam_tail_done = False
+            if flush and self.world == 1 and self._early_cut is not None and self.early_adam:
+                _fn.BACKWARD_HOOKS[id(self._early_layer)] = self._early_adam
             logits = self.model(x)                                  #                              train.py:185
             loss = self.criterion(logits, target)                   #                              train.py:187
             _fn.run_entry_hook(force=True)                          # (fewer than 3 stages: launched here)
@@ -192,9 +213,30 @@ class TrainEngine:
         return loss.detach()
 
     def _adam(self, grad_scale):
-        ops.adam_tick(self.adam_state, self.base_lr, self.eta_min, self.t_max)   # scheduler (per iteration) train.py:206-207
-        ops.adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.adam_state,
-                      self.betas[0], self.betas[1], self.eps, grad_scale=grad_scale, mirror=self._mirror())          # optimizer.step()   train.py:201
+        lo, hi = 0, self.flat_p.numel()
+        if self._adam_tail_done:                                    # [cut, total) was updated mid-backward (same tick)
+            hi, self._adam_tail_done = self._early_cut, False
+        else:
+            ops.adam_tick(self.adam_state, self.base_lr, self.eta_min, self.t_max)   # scheduler (per iteration) train.py:206-207
+        self._adam_range(lo, hi, grad_scale)
+
+    def _adam_range(self, lo, hi, grad_scale):
+        mirror = self._mirror()
+        ops.adam_step(self.flat_p[lo:hi], self.flat_g[lo:hi], self.flat_m[lo:hi], self.flat_v[lo:hi], self.adam_state,
+                      self.betas[0], self.betas[1], self.eps, grad_scale=grad_scale,
+                      mirror=mirror[lo:hi] if mirror is not None else None)                   # optimizer.step()   train.py:201
+
+    def _early_adam(self):
+        """Backward hook (the last encoder stage is done): Adam over the flat tail on the weight-gradient side stream."""
+        from . import functional as _fn
+        dev = self.flat_p.device
+        main, side = torch.cuda.current_stream(dev), _fn._wgrad_stream(dev)
+        side.wait_stream(main)                                      # (also orders the in-place gradient accumulations of main)
+        with torch.cuda.stream(side):
+            ops.adam_tick(self.adam_state, self.base_lr, self.eta_min, self.t_max)
+            self._adam_range(self._early_cut, self.flat_p.numel(), 1.0)
+        _fn._WSIDE_USED.add(dev)
+        self._adam_tail_done = True
 
     def _update(self):
         """Un-overlapped form (eager steps): all-reduce(sum) the whole flat gradient, then Adam reads it as g / world."""

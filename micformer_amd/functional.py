@@ -165,9 +165,14 @@ def run_entry_hook(force=False):
         hook()
 
 
+# backward side: callables the engine parks per stage (key = id of the stage module); run when the backward has left that stage
+BACKWARD_HOOKS = {}
+
+
 class FlushPointFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, xa):
+    def forward(ctx, x, xa, key=None):
+        ctx.key = key
         return x.view_as(x), xa.view_as(xa)
 
     @staticmethod
@@ -178,7 +183,10 @@ class FlushPointFn(torch.autograd.Function):
             flush_wgrad_side()
         elif DEFER_CALLS and DEFER_WGRAD:
             flush_wgrad_side(calls_only=True)
-        return dx, dxa
+        hook = BACKWARD_HOOKS.pop(ctx.key, None) if ctx.key is not None else None
+        if hook is not None:
+            hook()
+        return dx, dxa, None
 
 
 def flush_wgrad(calls_only=False):

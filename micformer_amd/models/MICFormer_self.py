@@ -424,7 +424,7 @@ class BasicLayer(nn.Module):
     def forward(self, x, xa):
         Fn.run_entry_hook()                            # (engine: side work parked for this point of the forward)
         if (Fn.FLUSH_POINTS or Fn.DEFER_CALLS) and x.requires_grad:
-            x, xa = Fn.FlushPointFn.apply(x, xa)       # backward: launch this stage's queued weight gradients on a side stream
+            x, xa = Fn.FlushPointFn.apply(x, xa, id(self))   # backward: launch this stage's queued weight gradients on a side stream
         if self._pair_fusable(x, xa):
             x, xa = self._forward_pairs(x, xa)
             resample = getattr(self, self._resample_attr)

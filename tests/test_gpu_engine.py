@@ -183,3 +183,28 @@ def test_label_values_outside_the_class_range_are_ignored():
     onehot = torch.stack([(ign == c) for c in range(8)], 1).float().cuda()
     ref, _ = ops.dice_bce_fwd(logits, onehot)
     assert abs(float(loss) - float(ref)) < 1e-6
+
+
+def test_early_adam_over_the_flat_tail_is_the_same_update(M):
+    """Adam over [cut, total) launched mid-backward (decoder + last encoder stage are final there) + Adam over [0, cut) at the end
+    == one Adam over the whole buffer: same step counter, same moments, and every parameter moved exactly once."""
+    from micformer_amd.engine import TrainEngine
+    x, t = _data(1)
+    engines = []
+    for early in (False, True):
+        e = TrainEngine(_head(M, train=False), base_lr=1e-3, t_max=10, use_graph=False, early_adam=early)
+        assert e._early_cut is not None and 0 < e._early_cut < e.flat_p.numel()
+        p0 = e.flat_p.clone()
+        for _ in range(2):
+            e.step(x, t)
+        torch.cuda.synchronize()
+        engines.append((e, p0))
+    (a, pa), (b, pb) = engines
+    _same_training_state(a, b, "early vs single Adam")
+    fin = torch.isfinite(a.flat_v) & torch.isfinite(b.flat_v)
+    assert float((a.flat_v - b.flat_v)[fin].abs().max()) <= 1e-3 * float(a.flat_v[fin].abs().max()) + 1e-12
+    # both halves of the buffer were updated (the 2-step displacement is ~2 lr wherever the gradient is not noise)
+    for lo, hi in ((0, b._early_cut), (b._early_cut, b.flat_p.numel())):
+        moved = (b.flat_p[lo:hi] - pb[lo:hi]).abs()
+        moved = moved[torch.isfinite(moved)]
+        assert float(moved.max()) > 1e-3 and float(moved.max()) < 2.5e-3

@@ -5,6 +5,7 @@
 // Orientation (gemm_core.h): the tile's I side is whatever is contiguous in the OUTPUT -- the 16 hidden channels for the
 // channels-last offset conv, the voxels for the NCDHW logits, the input channels for d(input).
 #include "common.h"
+#include "conv3_layout.h"
 
 namespace micf {
 
@@ -209,14 +210,11 @@ struct C3PrepArgs { const float* w[kC3PrepMax]; float* fwd[kC3PrepMax]; float* b
 __global__ void __launch_bounds__(256) conv3_weight_prep_kernel(const C3PrepArgs a) {
   const int k = blockIdx.y;
   const float* __restrict__ w = a.w[k];
-  const int N = a.N[k], Cin = a.Cin[k], chunks = (Cin + 15) / 16;
-  const int64_t nf = a.fwd[k] ? (int64_t)chunks * 27 * 256 : 0, nb = a.bwd[k] ? (int64_t)27 * Cin * 16 : 0;
+  const int N = a.N[k], Cin = a.Cin[k];
+  const int64_t nf = a.fwd[k] ? conv3_fwd_layout_items(Cin) : 0, nb = a.bwd[k] ? (int64_t)27 * Cin * 16 : 0;
   for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < nf + nb; id += (int64_t)gridDim.x * 256) {
     if (id < nf) {
-      const int c = (int)(id & 15), n = (int)((id >> 4) & 15);
-      const int tap = (int)((id >> 8) % 27), chunk = (int)((id >> 8) / 27);
-      const int cc = chunk * 16 + c;
-      a.fwd[k][id] = (n < N && cc < Cin) ? w[((int64_t)n * Cin + cc) * 27 + tap] : 0.f;
+      conv3_fwd_layout_write(w, a.fwd[k], N, Cin, id);
     } else {
       const int64_t j = id - nf;
       const int n = (int)(j & 15);
@@ -238,7 +236,7 @@ extern "C" int micf_conv3_weight_prep_grouped(const micf_conv3_prep_item* items,
       const micf_conv3_prep_item& it = items[first + k];
       if (!it.w || (!it.fwd && !it.bwd) || it.N <= 0 || it.N > 16 || it.Cin <= 0) return MICF_EINVAL;
       a.w[k] = it.w; a.fwd[k] = it.fwd; a.bwd[k] = it.bwd; a.N[k] = it.N; a.Cin[k] = it.Cin;
-      const int64_t tot = (int64_t)((it.Cin + 15) / 16) * 27 * 256 + (int64_t)27 * it.Cin * 16;
+      const int64_t tot = conv3_fwd_layout_items(it.Cin) + (int64_t)27 * it.Cin * 16;
       most = tot > most ? tot : most;
     }
     int bx = (int)((most + 255) / 256);

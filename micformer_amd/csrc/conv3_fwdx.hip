@@ -14,6 +14,7 @@
 //     into the pre-zeroed output.
 // The LDS-weights direct kernel this replaces (conv3_direct.hip) needed 129 us at the 32^3 x 2 stage (41 TFLOP/s).
 #include "common.h"
+#include "conv3_layout.h"
 #include "gemm_dma.h"
 
 namespace micf {
@@ -32,11 +33,7 @@ struct FwdxArgs {
 
 __global__ void __launch_bounds__(256) conv3_wtf_kernel(const float* __restrict__ w, float* __restrict__ wt, int N, int Cin, int chunks) {
   const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (id >= (int64_t)chunks * 27 * 256) return;
-  const int c = (int)(id & 15), n = (int)((id >> 4) & 15);
-  const int tap = (int)((id >> 8) % 27), chunk = (int)((id >> 8) / 27);
-  const int cc = chunk * 16 + c;
-  wt[id] = (n < N && cc < Cin) ? w[((int64_t)n * Cin + cc) * 27 + tap] : 0.f;
+  if (id < conv3_fwd_layout_items(Cin)) conv3_fwd_layout_write(w, wt, N, Cin, id);
 }
 
 template <int TW, bool BF16>
@@ -76,11 +73,19 @@ __global__ void __launch_bounds__(256) conv3_fwdx_kernel(FwdxArgs a) {
       }
     }
   };
+  // bf16 mode keeps the halo in LDS as bf16 (same index arithmetic, 2-byte elements): every element is rounded ONCE at the
+  // commit instead of once per tap at the fragment read -- the conversions were 39 VALU instructions per MFMA
+  uint16_t* Xh = reinterpret_cast<uint16_t*>(Xs);
   auto commit = [&](const float4 (&hv)[NH]) {
 #pragma unroll
     for (int it = 0; it < NH; ++it) {
       const int idx = tid + it * 256;
-      if (idx < HALO * 4) *reinterpret_cast<float4*>(&Xs[(idx >> 2) * fKS + 4 * (idx & 3)]) = hv[it];
+      if (idx < HALO * 4) {
+        if constexpr (BF16)
+          *reinterpret_cast<uint2*>(&Xh[(idx >> 2) * fKS + 4 * (idx & 3)]) = make_uint2(pack_bf16(hv[it].x, hv[it].y), pack_bf16(hv[it].z, hv[it].w));
+        else
+          *reinterpret_cast<float4*>(&Xs[(idx >> 2) * fKS + 4 * (idx & 3)]) = hv[it];
+      }
     }
   };
 
@@ -101,8 +106,41 @@ __global__ void __launch_bounds__(256) conv3_fwdx_kernel(FwdxArgs a) {
     __syncthreads();
     if (kc + 1 < kc_end) fetch(kc + 1, hv);                             // lands while the MFMAs below run
     const float* wp = a.wt + ((int64_t)kc * 27 * 16 + li) * 16 + 4 * lr;  // + tap * 256
+    if constexpr (BF16) {
+      // bf16: weights from the bf16 part of the layout (one 16-byte load = the A fragment of a tap pair, no conversion), halo as
+      // bf16 from LDS; k = 32 = (16 channels of this chunk) x (two taps), the unpaired 27th tap is zero-padded on both sides
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      const u32x4* wq = reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(a.wt + conv3_fwd_layout_f32(Cin)) +
+                                                       (((int64_t)kc * 14 * 16 + li) * 4 + lr) * 8);     // + pair * 64 (u32x4 units)
+      u32x4 ringq[fAhead + 1];
+#pragma unroll
+      for (int t = 0; t < fAhead; ++t) ringq[t] = wq[t * 64];
+#pragma unroll
+      for (int p = 0; p < 14; ++p) {
+        if (p + fAhead < 14) ringq[(p + fAhead) % (fAhead + 1)] = wq[(p + fAhead) * 64];
+        const u32x4 aq = ringq[p % (fAhead + 1)];
+        uint2 h[2][2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int tap = 2 * p + e;
+          if (tap < 27) {
+            const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+            const int off = ((kd * HH + kh) * HW + kw) * fKS;
+            h[e][0] = *reinterpret_cast<const uint2*>(&Xh[vbase[0] + off]);
+            h[e][1] = *reinterpret_cast<const uint2*>(&Xh[vbase[1] + off]);
+          } else {
+            h[e][0] = make_uint2(0u, 0u); h[e][1] = h[e][0];
+          }
+        }
+        const u32x4 q0 = {h[0][0].x, h[0][0].y, h[1][0].x, h[1][0].y}, q1 = {h[0][1].x, h[0][1].y, h[1][1].x, h[1][1].y};
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, aq), __builtin_bit_cast(bf16x8, q0), acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, aq), __builtin_bit_cast(bf16x8, q1), acc[1], 0, 0, 0);
+      }
+      continue;
+    }
     float4 ring[fAhead + 1];
-    float4 aprev = make_float4(0.f, 0.f, 0.f, 0.f), bprev0 = aprev, bprev1 = aprev;
+    float4 aprev = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint2 hprev0 = make_uint2(0u, 0u), hprev1 = hprev0;
 #pragma unroll
     for (int t = 0; t < fAhead; ++t) ring[t] = *reinterpret_cast<const float4*>(wp + t * 256);
 #pragma unroll
@@ -111,9 +149,9 @@ __global__ void __launch_bounds__(256) conv3_fwdx_kernel(FwdxArgs a) {
       const float4 av = ring[tap % (fAhead + 1)];
       const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
       const int off = ((kd * HH + kh) * HW + kw) * fKS;                 // source voxel = token + (k - 1), halo origin -1
-      const float4 b0 = *reinterpret_cast<const float4*>(&Xs[vbase[0] + off]);
-      const float4 b1 = *reinterpret_cast<const float4*>(&Xs[vbase[1] + off]);
       if constexpr (!BF16) {
+        const float4 b0 = *reinterpret_cast<const float4*>(&Xs[vbase[0] + off]);
+        const float4 b1 = *reinterpret_cast<const float4*>(&Xs[vbase[1] + off]);
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b0.x, acc[0], 0, 0, 0);
         acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b1.x, acc[1], 0, 0, 0);
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b0.y, acc[0], 0, 0, 0);
@@ -124,14 +162,19 @@ __global__ void __launch_bounds__(256) conv3_fwdx_kernel(FwdxArgs a) {
         acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b1.w, acc[1], 0, 0, 0);
       } else {
         // bf16: k = 32 = (16 channels of this chunk) x (two taps); the odd tap of a pair issues the MFMA, the last tap is padded
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const uint2 h0 = *reinterpret_cast<const uint2*>(&Xh[vbase[0] + off]);
+        const uint2 h1 = *reinterpret_cast<const uint2*>(&Xh[vbase[1] + off]);
         if ((tap & 1) || tap == 26) {
           const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
           const bool pair = tap & 1;
           const bf16x8 ba = pair ? to_bf16x8(aprev, av) : to_bf16x8(av, z);
-          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ba, pair ? to_bf16x8(bprev0, b0) : to_bf16x8(b0, z), acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ba, pair ? to_bf16x8(bprev1, b1) : to_bf16x8(b1, z), acc[1], 0, 0, 0);
+          const u32x4 q0 = pair ? u32x4{hprev0.x, hprev0.y, h0.x, h0.y} : u32x4{h0.x, h0.y, 0u, 0u};
+          const u32x4 q1 = pair ? u32x4{hprev1.x, hprev1.y, h1.x, h1.y} : u32x4{h1.x, h1.y, 0u, 0u};
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ba, __builtin_bit_cast(bf16x8, q0), acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ba, __builtin_bit_cast(bf16x8, q1), acc[1], 0, 0, 0);
         } else {
-          aprev = av; bprev0 = b0; bprev1 = b1;
+          aprev = av; hprev0 = h0; hprev1 = h1;
         }
       }
     }
@@ -164,7 +207,7 @@ __global__ void __launch_bounds__(256) conv3_fwdx_kernel(FwdxArgs a) {
 
 int64_t conv3_fwdx_workspace(int N, int c1, int c2) {
   if (N <= 0 || N > 16 || c1 + c2 <= 0) return 0;
-  return (int64_t)((c1 + c2 + 15) / 16) * 27 * 256;
+  return conv3_fwd_layout_floats(c1 + c2);
 }
 
 // MICF_EUNSUPPORTED when the shape is outside what this kernel covers (caller falls back).
@@ -192,7 +235,7 @@ int conv3_fwd_x_groups(const Conv3FwdSet* sets, int n, int c1, int c2, int B, in
   const float *x1 = sets[0].x1, *x2 = sets[0].x2, *w = sets[0].w, *bias = sets[0].bias;
   float *y = sets[0].y, *wt = sets[0].wt;
   const int Cin = c1 + c2, chunks = (Cin + 15) / 16;
-  const int64_t nw = (int64_t)chunks * 27 * 256;
+  const int64_t nw = conv3_fwd_layout_items(Cin);
   if (!prepared) {      // (prepared: wt already holds this layout, written once per step by micf_conv3_weight_prep_grouped)
     for (int i = 0; i < n; ++i) {
       hipLaunchKernelGGL(conv3_wtf_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, sets[i].w, sets[i].wt, N, Cin, chunks);

@@ -154,7 +154,9 @@ if __name__ == "__main__":
     ap.add_argument("case")
     ap.add_argument("args", nargs="*", type=int)
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--dtype", default="bf16", choices=("fp32", "bf16"))
     a = ap.parse_args()
+    ops.set_compute_dtype(a.dtype)
     if a.case == "all":
         for n, g in ALL:
             case(n, g, a.reps)

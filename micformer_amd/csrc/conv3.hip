@@ -211,16 +211,12 @@ __global__ void __launch_bounds__(256) conv3_weight_prep_kernel(const C3PrepArgs
   const int k = blockIdx.y;
   const float* __restrict__ w = a.w[k];
   const int N = a.N[k], Cin = a.Cin[k];
-  const int64_t nf = a.fwd[k] ? conv3_fwd_layout_items(Cin) : 0, nb = a.bwd[k] ? (int64_t)27 * Cin * 16 : 0;
+  const int64_t nf = a.fwd[k] ? conv3_fwd_layout_items(Cin) : 0, nb = a.bwd[k] ? conv3_bwd_layout_items(Cin) : 0;
   for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < nf + nb; id += (int64_t)gridDim.x * 256) {
     if (id < nf) {
       conv3_fwd_layout_write(w, a.fwd[k], N, Cin, id);
     } else {
-      const int64_t j = id - nf;
-      const int n = (int)(j & 15);
-      const int c = (int)((j >> 4) % Cin);
-      const int tap = (int)((j >> 4) / Cin);
-      a.bwd[k][j] = n < N ? w[((int64_t)n * Cin + c) * 27 + tap] : 0.f;
+      conv3_bwd_layout_write(w, a.bwd[k], N, Cin, id - nf);
     }
   }
 }
@@ -236,7 +232,7 @@ extern "C" int micf_conv3_weight_prep_grouped(const micf_conv3_prep_item* items,
       const micf_conv3_prep_item& it = items[first + k];
       if (!it.w || (!it.fwd && !it.bwd) || it.N <= 0 || it.N > 16 || it.Cin <= 0) return MICF_EINVAL;
       a.w[k] = it.w; a.fwd[k] = it.fwd; a.bwd[k] = it.bwd; a.N[k] = it.N; a.Cin[k] = it.Cin;
-      const int64_t tot = conv3_fwd_layout_items(it.Cin) + (int64_t)27 * it.Cin * 16;
+      const int64_t tot = conv3_fwd_layout_items(it.Cin) + conv3_bwd_layout_items(it.Cin);
       most = tot > most ? tot : most;
     }
     int bx = (int)((most + 255) / 256);
@@ -283,7 +279,7 @@ extern "C" int micf_conv3_fwd(const float* x1, int c1, const float* x2, int c2, 
 }
 
 extern "C" int64_t micf_conv3_bwd_data_workspace(int N, int c1, int c2) {
-  return (N > 0 && N <= 16 && c1 + c2 > 0) ? (int64_t)27 * (c1 + c2) * 16 : 0;
+  return (N > 0 && N <= 16 && c1 + c2 > 0) ? conv3_bwd_layout_floats(c1 + c2) : 0;
 }
 
 extern "C" int micf_conv3_bwd_data(const float* dy, int dy_layout, const float* w, float* dx1, int c1, int acc1,

@@ -13,6 +13,7 @@
 //   * every wave owns 2 token rows x NCT channel tiles (2*NCT accumulators); per tap: 2 LDS reads + NCT loads for 8*NCT MFMAs.
 // The implicit-GEMM path (conv3.hip) needed 360 us for the 32^3 x 2 stage (15 TFLOP/s); see DESIGN.md for this kernel's numbers.
 #include "common.h"
+#include "conv3_layout.h"
 #include "gemm_dma.h"
 
 namespace micf {
@@ -30,11 +31,7 @@ struct BwdxArgs {
 
 __global__ void __launch_bounds__(256) conv3_wt_kernel(const float* __restrict__ w, float* __restrict__ wt, int N, int Cin) {
   const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (id >= (int64_t)27 * Cin * 16) return;
-  const int n = (int)(id & 15);
-  const int c = (int)((id >> 4) % Cin);
-  const int tap = (int)((id >> 4) / Cin);
-  wt[id] = n < N ? w[((int64_t)n * Cin + c) * 27 + tap] : 0.f;
+  if (id < conv3_bwd_layout_items(Cin)) conv3_bwd_layout_write(w, wt, N, Cin, id);
 }
 
 // TW: tokens of a tile along w (16 or 8); a column tile is 16/TW h-rows x TW.  Tile = 2 (d) x 4*(16/TW) (h) x TW = 128 tokens.
@@ -73,7 +70,13 @@ __global__ void __launch_bounds__(256) conv3_bwdx_kernel(BwdxArgs a) {
 #pragma unroll
     for (int it = 0; it < NH; ++it) {
       const int idx = tid + it * 256;
-      if (idx < HALO * 4) *reinterpret_cast<float4*>(&Xs[(idx >> 2) * xKS + 4 * (idx & 3)]) = hv4[it];
+      if (idx < HALO * 4) {
+        if constexpr (BF16)      // bf16 mode: the dy halo is rounded once here, not once per tap at the fragment read
+          *reinterpret_cast<uint2*>(&reinterpret_cast<uint16_t*>(Xs)[(idx >> 2) * xKS + 4 * (idx & 3)]) =
+              make_uint2(pack_bf16(hv4[it].x, hv4[it].y), pack_bf16(hv4[it].z, hv4[it].w));
+        else
+          *reinterpret_cast<float4*>(&Xs[(idx >> 2) * xKS + 4 * (idx & 3)]) = hv4[it];
+      }
     }
   }
   // ---- this wave's two column tiles: ct = 2*wave + tj -> (ld, h group); lane li -> (lh, lw) inside it
@@ -90,12 +93,53 @@ __global__ void __launch_bounds__(256) conv3_bwdx_kernel(BwdxArgs a) {
   for (int t = 0; t < NCT; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   const float* wp = a.wt + ((int64_t)(ct0 * 16 + li)) * 16 + 4 * lr;      // + tap * O * 16 + t * 256
   const int64_t tap_stride = (int64_t)a.O * 16;
+  if constexpr (BF16) {
+    // bf16: one 16-byte load per (tap pair, channel tile) is the A fragment (bf16 part of the layout), the dy halo is bf16 in LDS
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const uint16_t* Xh = reinterpret_cast<const uint16_t*>(Xs);
+    const u32x4* wq = reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(a.wt + conv3_bwd_layout_f32(a.O)) +
+                                                     (((int64_t)(ct0 * 16 + li)) * 4 + lr) * 8);       // + pair * O * 4 + t * 64  (u32x4)
+    const int64_t pair_stride = (int64_t)a.O * 4;
+    const u32x4 zq = {0u, 0u, 0u, 0u};
+    u32x4 aq[NCT], anq[NCT];
+#pragma unroll
+    for (int t = 0; t < NCT; ++t) aq[t] = (t < nct) ? wq[t * 64] : zq;
+    __syncthreads();
+#pragma unroll 1
+    for (int p = 0; p < 14; ++p) {
+      if (p + 1 < 14) {
+#pragma unroll
+        for (int t = 0; t < NCT; ++t) anq[t] = (t < nct) ? wq[(p + 1) * pair_stride + t * 64] : zq;
+      }
+      u32x4 bq[2];
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj) {
+        uint2 h[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int tap = 2 * p + e;
+          const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+          const int zd = ld[tj] + 2 - kd, zh = lh[tj] + 2 - kh, zw = lw[tj] + 2 - kw;
+          const uint2 v = *reinterpret_cast<const uint2*>(&Xh[((zd * HH + zh) * HW + zw) * xKS + 4 * lr]);
+          h[e] = tap < 27 ? v : make_uint2(0u, 0u);
+        }
+        bq[tj] = u32x4{h[0].x, h[0].y, h[1].x, h[1].y};
+      }
+#pragma unroll
+      for (int t = 0; t < NCT; ++t) {
+        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, aq[t]), __builtin_bit_cast(bf16x8, bq[0]), acc[t][0], 0, 0, 0);
+        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, aq[t]), __builtin_bit_cast(bf16x8, bq[1]), acc[t][1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < NCT; ++t) aq[t] = anq[t];
+    }
+  }
   float4 av[NCT], an[NCT], aprev[NCT], bprev[2];
 #pragma unroll
-  for (int t = 0; t < NCT; ++t) av[t] = (t < nct) ? *reinterpret_cast<const float4*>(wp + t * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
-  __syncthreads();
+  for (int t = 0; t < NCT; ++t) av[t] = (t < nct && !BF16) ? *reinterpret_cast<const float4*>(wp + t * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (!BF16) __syncthreads();
 #pragma unroll 1
-  for (int tap = 0; tap < 27; ++tap) {
+  for (int tap = 0; tap < (BF16 ? 0 : 27); ++tap) {
     if (tap + 1 < 27) {
 #pragma unroll
       for (int t = 0; t < NCT; ++t)
@@ -198,7 +242,7 @@ int conv3_bwd_data_x_groups(const Conv3BwdSet* sets, int ng, int c1, int acc1, i
       return MICF_EUNSUPPORTED;
   const float *dy = sets[0].dy;
   float *wt = sets[0].wt, *dx1 = sets[0].dx1, *dx2 = sets[0].dx2;
-  const int64_t n = (int64_t)27 * O * 16;
+  const int64_t n = conv3_bwd_layout_items(O);
   if (!prepared) {
     for (int i = 0; i < ng; ++i) {
       hipLaunchKernelGGL(conv3_wt_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, sets[i].w, sets[i].wt, N, O);

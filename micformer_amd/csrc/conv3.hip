@@ -6,6 +6,7 @@
 // channels-last offset conv, the voxels for the NCDHW logits, the input channels for d(input).
 #include "common.h"
 #include "conv3_layout.h"
+#include "gemm_dma.h"
 
 namespace micf {
 
@@ -206,19 +207,57 @@ extern "C" int64_t micf_conv3_fwd_workspace(int N, int c1, int c2) { return conv
 // in Adam).  fwd = [chunk][tap][16 n][16 c] (conv3_fwdx.hip), bwd = [tap][c][16 n] (conv3_bwdx.hip).
 namespace micf {
 constexpr int kC3PrepMax = 64;
-struct C3PrepArgs { const float* w[kC3PrepMax]; float* fwd[kC3PrepMax]; float* bwd[kC3PrepMax]; int N[kC3PrepMax], Cin[kC3PrepMax]; };
+struct C3PrepArgs {
+  const float* w[kC3PrepMax]; float* fwd[kC3PrepMax]; float* bwd[kC3PrepMax];
+  int N[kC3PrepMax], Cin[kC3PrepMax], end[kC3PrepMax];          // end: running total of 16-channel chunks (= workgroups)
+  int n;
+};
+// Workgroup = (weight, 16-channel chunk).  For every output channel n the chunk's 16 x 27 weights are CONTIGUOUS in w
+// ([N][Cin][27]): they come in with coalesced loads, sit in LDS as [n][c][tap], and every element of the four layouts that
+// belongs to this chunk -- each a contiguous run of the destination -- is written from there (the per-element gather this
+// replaces read w with a stride of 27 floats once per layout: 0.43 ms per step).
 __global__ void __launch_bounds__(256) conv3_weight_prep_kernel(const C3PrepArgs a) {
-  const int k = blockIdx.y;
+  __shared__ float ws[16][16 * 27 + 1];
+  const int wgi = blockIdx.x;
+  int k = 0;
+  while (k < a.n - 1 && wgi >= a.end[k]) ++k;
+  const int chunk = wgi - (k ? a.end[k - 1] : 0);
   const float* __restrict__ w = a.w[k];
-  const int N = a.N[k], Cin = a.Cin[k];
-  const int64_t nf = a.fwd[k] ? conv3_fwd_layout_items(Cin) : 0, nb = a.bwd[k] ? conv3_bwd_layout_items(Cin) : 0;
-  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < nf + nb; id += (int64_t)gridDim.x * 256) {
-    if (id < nf) {
-      conv3_fwd_layout_write(w, a.fwd[k], N, Cin, id);
-    } else {
-      conv3_bwd_layout_write(w, a.bwd[k], N, Cin, id - nf);
+  const int N = a.N[k], Cin = a.Cin[k], chunks = (Cin + 15) / 16;
+  const int c0 = chunk * 16, nc = min(16, Cin - c0);
+  for (int i = threadIdx.x; i < 16 * 432; i += 256) {
+    const int n = i / 432, r = i % 432;                               // r = c * 27 + tap
+    ws[n][r] = (n < N && r < nc * 27) ? w[((int64_t)n * Cin + c0) * 27 + r] : 0.f;
+  }
+  __syncthreads();
+  auto bf = [](float v) { return (uint16_t)(pack_bf16(v, 0.f) & 0xFFFFu); };
+  if (float* fwd = a.fwd[k]) {
+    float* f32p = fwd + (int64_t)chunk * 27 * 256;                    // [tap][16 n][16 c]
+    for (int i = threadIdx.x; i < 27 * 256; i += 256) {
+      const int c = i & 15, n = (i >> 4) & 15, tap = i >> 8;
+      f32p[i] = ws[n][c * 27 + tap];
+    }
+    uint16_t* hp = reinterpret_cast<uint16_t*>(fwd + conv3_fwd_layout_f32(Cin)) + (int64_t)chunk * 14 * 512;   // [pair][16 n][4 lr][8]
+    for (int i = threadIdx.x; i < 14 * 512; i += 256) {
+      const int e = i & 7, lr = (i >> 3) & 3, n = (i >> 5) & 15, p = i >> 9;
+      const int tap = 2 * p + (e >> 2), c = 4 * lr + (e & 3);
+      hp[i] = bf(tap < 27 ? ws[n][c * 27 + tap] : 0.f);
     }
   }
+  if (float* bwd = a.bwd[k]) {
+    const int O = Cin;                                                 // (multiple of 16 for the direct kernel; tails are masked)
+    for (int i = threadIdx.x; i < 27 * 256; i += 256) {                // [tap][O][16 n]: this chunk's run of 16 c x 16 n per tap
+      const int n = i & 15, c = (i >> 4) & 15, tap = i >> 8;
+      if (c < nc) bwd[((int64_t)tap * O + c0 + c) * 16 + n] = ws[n][c * 27 + tap];
+    }
+    uint16_t* hb = reinterpret_cast<uint16_t*>(bwd + conv3_bwd_layout_f32(O));                                  // [pair][O][4 lr][8]
+    for (int i = threadIdx.x; i < 14 * 512; i += 256) {
+      const int e = i & 7, lr = (i >> 3) & 3, c = (i >> 5) & 15, p = i >> 9;
+      const int tap = 2 * p + (e >> 2), n = 4 * lr + (e & 3);
+      if (c < nc) hb[(((int64_t)p * O + c0 + c) * 4 + lr) * 8 + e] = bf(tap < 27 ? ws[n][c * 27 + tap] : 0.f);
+    }
+  }
+  (void)chunks;
 }
 }  // namespace micf
 
@@ -227,17 +266,16 @@ extern "C" int micf_conv3_weight_prep_grouped(const micf_conv3_prep_item* items,
   for (int first = 0; first < n; first += kC3PrepMax) {
     const int cnt = (n - first < kC3PrepMax) ? n - first : kC3PrepMax;
     C3PrepArgs a;
-    int64_t most = 0;
+    a.n = cnt;
+    int blocks = 0;
     for (int k = 0; k < cnt; ++k) {
       const micf_conv3_prep_item& it = items[first + k];
       if (!it.w || (!it.fwd && !it.bwd) || it.N <= 0 || it.N > 16 || it.Cin <= 0) return MICF_EINVAL;
       a.w[k] = it.w; a.fwd[k] = it.fwd; a.bwd[k] = it.bwd; a.N[k] = it.N; a.Cin[k] = it.Cin;
-      const int64_t tot = conv3_fwd_layout_items(it.Cin) + conv3_bwd_layout_items(it.Cin);
-      most = tot > most ? tot : most;
+      blocks += (it.Cin + 15) / 16;
+      a.end[k] = blocks;
     }
-    int bx = (int)((most + 255) / 256);
-    if (bx > 64) bx = 64;
-    hipLaunchKernelGGL(conv3_weight_prep_kernel, dim3(bx, cnt), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(conv3_weight_prep_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     if (hipGetLastError() != hipSuccess) return MICF_ELAUNCH;
   }
   return MICF_OK;

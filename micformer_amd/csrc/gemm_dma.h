@@ -32,10 +32,12 @@ namespace micf {
 // ---- bf16 mode: MFMA operands rounded to bf16 at the fragment read (fp32 in HBM / LDS, fp32 accumulate)
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {   // round-to-nearest-even, a in the low half
-  unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
-  ua += 0x7FFFu + ((ua >> 16) & 1u);
-  ub += 0x7FFFu + ((ub >> 16) & 1u);
-  return (ua >> 16) | (ub & 0xFFFF0000u);
+  // gfx950 has the conversion in hardware: v_cvt_pk_bf16_f32 (round-to-nearest-even), ONE instruction for the pair -- the
+  // integer emulation (add 0x7FFF + lsb, shift, merge) was ~7 VALU instructions per pair and the bound of every bf16 kernel
+  typedef __bf16 bf16x2_hw __attribute__((ext_vector_type(2)));
+  typedef float f32x2_hw __attribute__((ext_vector_type(2)));
+  const f32x2_hw f = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2_hw));
 }
 __device__ __forceinline__ bf16x8 to_bf16x8(const float4& lo, const float4& hi) {
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));

@@ -584,3 +584,31 @@ def test_offset_head_pair_matches_per_op_calls(dims, C):
         close(dxn_g[i], dxn_r[i], f"dxn {i}")
         for k in ("conv_offset.1.norm.weight", "conv_offset.1.norm.bias", "conv_offset.3.weight"):
             close(Gg[i][k], Gr[i][k], f"{k} {i}")
+
+
+@pytest.mark.parametrize("C", [48, 192])
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_conv3_prepared_layouts_give_the_same_result(C, mode):
+    """micf_conv3_weight_prep_grouped (all layouts of a weight in one launch, once per step) against the calls' own re-layout."""
+    from micformer_amd import ops
+    dims = (1, 4, 8, 8)
+    T = 4 * 8 * 8
+    g = torch.Generator().manual_seed(11)
+    rnd = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).cuda()
+    x1, x2, dy = rnd(T, C), rnd(T, C), rnd(T, 16)
+    w, b = rnd(16, 2 * C, 3, 3, 3, sc=(54 * C) ** -0.5), rnd(16, sc=0.1)
+    prev = ops.compute_dtype()
+    ops.set_compute_dtype(mode)
+    try:
+        y0 = ops.conv3_fwd(x1, w, b, dims, x2=x2)
+        d0 = ops.conv3_bwd_data(dy, w, dims, C, C)
+        wp = w.clone()
+        wp._micf_c3f, wp._micf_c3b = ops.conv3_prepared_like(wp)
+        ops.Conv3PrepPlan([(wp, wp._micf_c3f, wp._micf_c3b)]).launch()
+        y1 = ops.conv3_fwd(x1, wp, b, dims, x2=x2)
+        d1 = ops.conv3_bwd_data(dy, wp, dims, C, C)
+    finally:
+        ops.set_compute_dtype(prev)
+    tol = 0 if mode == "bf16" else 0            # same kernels, same operands: only the atomic accumulation order may differ
+    assert float((y1 - y0).abs().max()) <= 1e-5 * float(y0.abs().max())
+    assert torch.equal(d1[0], d0[0]) and torch.equal(d1[1], d0[1])

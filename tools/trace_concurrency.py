@@ -3,14 +3,14 @@
 and the kernels that run alone the longest.  usage: trace_concurrency.py trace.csv [marker_kernel=adam_step_kernel]"""
 import csv, sys, collections, re
 rows = list(csv.DictReader(open(sys.argv[1])))
-marker = sys.argv[2] if len(sys.argv) > 2 else "adam_step_kernel"
+marker = sys.argv[2] if len(sys.argv) > 2 else "drop_path_draw_kernel"
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows))
 marks = [i for i, e in enumerate(ev) if marker in e[2]]
 if len(marks) < 3:
     sys.exit("need >= 3 steps")
-a, b = marks[-2], marks[-1]          # kernels strictly after the second-to-last marker, up to and including the last
-step = ev[a + 1:b + 1]
-t0, t1 = ev[a][1], step[-1][1]
+a, b = marks[-2], marks[-1]          # one step = from one DropPath draw (first launch of the forward) to the next
+step = ev[a:b]
+t0, t1 = ev[a][0], max(e for _, e, _ in step)
 pts = []
 for s, e, n in step:
     pts.append((s, 1, n)); pts.append((e, -1, n))

@@ -2,16 +2,16 @@
 """Stage timeline of one replayed training step from a rocprofv3 kernel-trace CSV.  The fused block kernels carry the channel
 count in their template arguments, so the step is cut wherever that count changes (stage 3 / the heads run no fused kernel: the
 gaps between the C=192 encoder run and the C=192 decoder run, and around the loss).  Per segment: wall time, time covered by
-the fused block kernels, by any other kernel, and idle.   usage: trace_stages.py trace.csv [marker=adam_step_kernel]"""
+the fused block kernels, by any other kernel, and idle.   usage: trace_stages.py trace.csv [marker=drop_path_draw_kernel]"""
 import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-marker = sys.argv[2] if len(sys.argv) > 2 else "adam_step_kernel"
+marker = sys.argv[2] if len(sys.argv) > 2 else "drop_path_draw_kernel"
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows))
 marks = [i for i, e in enumerate(ev) if marker in e[2]]
 if len(marks) < 3:
     sys.exit("need >= 3 steps")
-step = ev[marks[-2] + 1:marks[-1] + 1]
-t0 = ev[marks[-2]][1]
+step = ev[marks[-2]:marks[-1]]          # one step = from one DropPath draw (first launch of the forward) to the next
+t0 = ev[marks[-2]][0]
 blk = [(s, e, re.search(r"block_(fwd|bwd)_kernel<(\d+)", n)) for s, e, n in step]
 blk = [(s, e, m.group(1), int(m.group(2))) for s, e, m in blk if m]
 # stages: maximal runs of fused launches with the same (direction, C), per-op kernels between them included

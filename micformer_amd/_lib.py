@@ -27,10 +27,10 @@ SIGNATURES = {
     "micf_linear_bwd_weight_workspace": "lii",
     "micf_linear_bwd_weight_grouped": "piplip",
     "micf_linear_bwd_weight_grouped_workspace": "pi",
-    "micf_head_tail_compose": "pppppiiiip",
+    "micf_head_tail_compose": "pppppiiiipp",
     "micf_head_tail_col2im": "pppiiiiiip",
     "micf_head_tail_im2col": "ppiiiiiip",
-    "micf_head_tail_decompose": "pppppppppiiiip",
+    "micf_head_tail_decompose": "pppppppppiiiipp",
     "micf_sw_window": "ppiiiiiiiiiip",
     "micf_sw_accumulate": "pppiiiiiiiiiip",
     "micf_sw_normalize": "ppilp",

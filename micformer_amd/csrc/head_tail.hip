@@ -20,7 +20,8 @@ namespace micf {
 // one thread per (f, o, k): k fastest.  k == Ci computes the bias composite Bf[f, o] (W_up row replaced by b_up).
 __global__ void __launch_bounds__(256) tail_compose_kernel(const float* __restrict__ w_up, const float* __restrict__ b_up,
                                                            const float* __restrict__ w_out, float* __restrict__ wb,
-                                                           float* __restrict__ bf, int Ci, int Cm, int Co, int P) {
+                                                           float* __restrict__ bf, int Ci, int Cm, int Co, int P,
+                                                           const float* __restrict__ w_up_t) {
   const int F = P + 2, P3 = P * P * P;
   const int64_t total = (int64_t)F * F * F * Co * (Ci + 1);
   const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -38,7 +39,8 @@ __global__ void __launch_bounds__(256) tail_compose_kernel(const float* __restri
         const int t = ((pd + 2 - fd) * 3 + (ph + 2 - fh)) * 3 + (pw + 2 - fw);
         const int p = (pd * P + ph) * P + pw;
         for (int c = 0; c < Cm; ++c) {
-          const float wu = (k < Ci) ? w_up[((int64_t)k * Cm + c) * P3 + p] : b_up[c];
+          // (w_up_t = w_up as [Cm * P^3][Ci]: the lanes of a wave are consecutive k -> one coalesced load instead of 64 lines)
+          const float wu = (k < Ci) ? (w_up_t ? w_up_t[((int64_t)c * P3 + p) * Ci + k] : w_up[((int64_t)k * Cm + c) * P3 + p]) : b_up[c];
           acc += w_out[((int64_t)o * Cm + c) * 27 + t] * wu;
         }
       }
@@ -138,9 +140,9 @@ __global__ void __launch_bounds__(256) tail_dwup_kernel(const float* __restrict_
   const int64_t total = (int64_t)(Ci + 1) * Cm * P3;
   const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (id >= total) return;
-  const int p = (int)(id % P3);
-  const int c = (int)((id / P3) % Cm);
-  const int k = (int)(id / ((int64_t)P3 * Cm));
+  const int k = (int)(id % (Ci + 1));            // k fastest: the dWb rows are read coalesced (the single store per thread is strided)
+  const int c = (int)((id / (Ci + 1)) % Cm);
+  const int p = (int)(id / ((int64_t)(Ci + 1) * Cm));
   const int pw = p % P, ph = (p / P) % P, pd = p / (P * P);
   float acc = 0.f;
   for (int t = 0; t < 27; ++t) {
@@ -160,7 +162,7 @@ __global__ void __launch_bounds__(256) tail_dwup_kernel(const float* __restrict_
 __global__ void __launch_bounds__(256) tail_dwout_kernel(const float* __restrict__ dwb, const float* __restrict__ dbf,
                                                          const float* __restrict__ w_up, const float* __restrict__ b_up,
                                                          float* __restrict__ dw_out, float* __restrict__ db_out, int Ci, int Cm,
-                                                         int Co, int P) {
+                                                         int Co, int P, const float* __restrict__ w_up_t) {
   const int F = P + 2, P3 = P * P * P;
   const int lane = threadIdx.x & 63;
   const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -174,7 +176,8 @@ __global__ void __launch_bounds__(256) tail_dwout_kernel(const float* __restrict
     for (int p = 0; p < P3; ++p) {
       const int pw = p % P, ph = (p / P) % P, pd = p / (P * P);
       const int64_t row = (((int64_t)(pd - td + 2) * F + (ph - th + 2)) * F + (pw - tw + 2)) * Co + o;
-      for (int k = lane; k < Ci; k += 64) acc += dwb[row * Ci + k] * w_up[((int64_t)k * Cm + c) * P3 + p];
+      for (int k = lane; k < Ci; k += 64)
+        acc += dwb[row * Ci + k] * (w_up_t ? w_up_t[((int64_t)c * P3 + p) * Ci + k] : w_up[((int64_t)k * Cm + c) * P3 + p]);
       if (lane == 0) acc += dbf[row] * b_up[c];
     }
     acc = wave_sum(acc);
@@ -198,13 +201,13 @@ static bool dims_ok(int Ci, int Cm, int Co, int P) { return Ci > 0 && Cm > 0 && 
 using namespace micf;
 
 extern "C" int micf_head_tail_compose(const float* w_up, const float* b_up, const float* w_out, float* wb, float* bf, int Ci,
-                                      int Cm, int Co, int P, micf_stream_t stream) {
+                                      int Cm, int Co, int P, const float* w_up_t, micf_stream_t stream) {
   if (!w_up || !b_up || !w_out || !wb || !bf) return MICF_EINVAL;
   if (!dims_ok(Ci, Cm, Co, P)) return MICF_EUNSUPPORTED;
   const int F = P + 2;
   const int64_t total = (int64_t)F * F * F * Co * (Ci + 1);
   hipLaunchKernelGGL(tail_compose_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_up, b_up,
-                     w_out, wb, bf, Ci, Cm, Co, P);
+                     w_out, wb, bf, Ci, Cm, Co, P, w_up_t);
   MICF_RETURN_LAUNCH();
 }
 
@@ -235,7 +238,7 @@ extern "C" int micf_head_tail_im2col(const float* dy, float* u, int B, int Dc, i
 
 extern "C" int micf_head_tail_decompose(const float* dwb, const float* dbf, const float* w_up, const float* b_up,
                                         const float* w_out, float* dw_up, float* db_up, float* dw_out, float* db_out, int Ci,
-                                        int Cm, int Co, int P, micf_stream_t stream) {
+                                        int Cm, int Co, int P, const float* w_up_t, micf_stream_t stream) {
   if (!dwb || !dbf || !w_up || !b_up || !w_out || !dw_up || !db_up || !dw_out || !db_out) return MICF_EINVAL;
   if (!dims_ok(Ci, Cm, Co, P)) return MICF_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
@@ -243,6 +246,6 @@ extern "C" int micf_head_tail_decompose(const float* dwb, const float* dbf, cons
   hipLaunchKernelGGL(tail_dwup_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, dwb, dbf, w_out, dw_up, db_up, Ci, Cm, Co, P);
   if (hipGetLastError() != hipSuccess) return MICF_ELAUNCH;
   const int64_t n2 = (int64_t)Co * Cm * 27 + Co;
-  hipLaunchKernelGGL(tail_dwout_kernel, dim3((unsigned)((n2 + 3) / 4)), dim3(256), 0, s, dwb, dbf, w_up, b_up, dw_out, db_out, Ci, Cm, Co, P);
+  hipLaunchKernelGGL(tail_dwout_kernel, dim3((unsigned)((n2 + 3) / 4)), dim3(256), 0, s, dwb, dbf, w_up, b_up, dw_out, db_out, Ci, Cm, Co, P, w_up_t);
   MICF_RETURN_LAUNCH();
 }

@@ -894,23 +894,24 @@ class HeadTailFn(torch.autograd.Function):
     feature x (B, Dc, Hc, Wc, 2E) -> NCDHW logits (B, classes, P*Dc, P*Hc, P*Wc).  The E/2-channel fine feature is never built."""
 
     @staticmethod
-    def forward(ctx, x, w_up, b_up, w_out, b_out, wb=None, bf=None):
+    def forward(ctx, x, w_up, b_up, w_out, b_out, wb=None, bf=None, w_up_t=None):
         x = _c(x)
         B, Dc, Hc, Wc, Ci = x.shape
         P = w_up.shape[2]
         if wb is None:                                  # (else: composed earlier, off the critical path)
-            wb, bf = ops.head_tail_compose(w_up, b_up, w_out)
+            w_up_t = ops.head_tail_transposed_up(w_up)
+            wb, bf = ops.head_tail_compose(w_up, b_up, w_out, w_up_t)
         xf = x.reshape(-1, Ci)
         t = ops.linear_fwd(xf, wb, bf)
         y = ops.head_tail_col2im(t, b_out, (B, Dc, Hc, Wc), P)
-        ctx.save_for_backward(xf, wb, w_up, b_up, w_out)
+        ctx.save_for_backward(xf, wb, w_up, b_up, w_out, w_up_t)
         ctx.dims = (B, Dc, Hc, Wc)
         ctx.tg = _targets((w_up, b_up, w_out, b_out))
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        xf, wb, w_up, b_up, w_out = ctx.saved_tensors
+        xf, wb, w_up, b_up, w_out, w_up_t = ctx.saved_tensors
         B, Dc, Hc, Wc = ctx.dims
         P = w_up.shape[2]
         u = ops.head_tail_im2col(_c(dy), ctx.dims, P)
@@ -920,10 +921,10 @@ class HeadTailFn(torch.autograd.Function):
         def weight_grads():       # composed-map gradient, then its decomposition into the two layers' parameters
             dwb, dbf = ops.zero_(torch.empty_like(wb)), ops.zero_(torch.empty(wb.shape[0], dtype=wb.dtype, device=wb.device))
             ops.linear_bwd_weight(u, xf, dwb, dbf)
-            ops.head_tail_decompose(dwb, dbf, w_up, b_up, w_out, *grads)
+            ops.head_tail_decompose(dwb, dbf, w_up, b_up, w_out, *grads, w_up_t=w_up_t)
 
         _defer(all(t is not None for t in ctx.tg), weight_grads, u, xf, wb)
-        return (dx.reshape(B, Dc, Hc, Wc, -1),) + tuple(_ret(t, g) for t, g in zip(ctx.tg, grads)) + (None, None)
+        return (dx.reshape(B, Dc, Hc, Wc, -1),) + tuple(_ret(t, g) for t, g in zip(ctx.tg, grads)) + (None, None, None)
 
 
 class ResizeTrilinearFn(torch.autograd.Function):

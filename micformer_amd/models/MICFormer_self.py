@@ -622,18 +622,19 @@ class Head(nn.Module):
         if FUSE_HEAD_TAIL and 2 <= rp.kernel_size[0] <= 8 and oc.out_channels <= 32:
             # ConvTranspose3d(k = s = P) and the 3^3 Conv3d have nothing between them: one composed linear map (head_tail.hip)
             # (the composition reads weights only: in engine mode it runs on the side stream under the first stage)
-            wb = bf = None
+            wb = bf = wut = None
             if PARALLEL_MODALITIES:
                 from .. import ops
                 main, side = torch.cuda.current_stream(), _side_stream(x.device)
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
-                    wb, bf = ops.head_tail_compose(rp.weight, rp.bias, oc.weight)
+                    wut = ops.head_tail_transposed_up(rp.weight)
+                    wb, bf = ops.head_tail_compose(rp.weight, rp.bias, oc.weight, wut)
             coarse = self.swin.coarse_features(x, 0, x, 1)
             if wb is not None:
                 main.wait_stream(side)
-                wb.record_stream(main)
-                bf.record_stream(main)
-            return Fn.HeadTailFn.apply(coarse, rp.weight, rp.bias, oc.weight, oc.bias, wb, bf)
+                for t in (wb, bf, wut):
+                    t.record_stream(main)
+            return Fn.HeadTailFn.apply(coarse, rp.weight, rp.bias, oc.weight, oc.bias, wb, bf, wut)
         feat = self.swin.features(x, 0, x, 1)
         return Fn.OutConvFn.apply(feat, oc.weight, oc.bias)

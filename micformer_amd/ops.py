@@ -521,12 +521,21 @@ def conv_up_fwd(x, w, bias, k):
 
 
 # ----------------------------------------------------------------------------- reverse_patch_embedding + out_conv, composed
-def head_tail_compose(w_up, b_up, w_out):
+def head_tail_transposed_up(w_up):
+    """w_up [Ci, Cm, P, P, P] as [Cm * P^3, Ci]: what the composition kernels read coalesced (one small launch)."""
+    Ci = w_up.shape[0]
+    src = w_up.reshape(Ci, -1)
+    dst = _new(w_up, src.shape[1], Ci)
+    WeightPrepPlan([(src, None, dst)]).launch()
+    return dst
+
+
+def head_tail_compose(w_up, b_up, w_out, w_up_t=None):
     Ci, Cm, P = w_up.shape[0], w_up.shape[1], w_up.shape[2]
     Co = w_out.shape[0]
     rows = (P + 2) ** 3 * Co
     wb, bf = _new(w_up, rows, Ci), _new(w_up, rows)
-    call("micf_head_tail_compose", f32(w_up), f32(b_up), f32(w_out), f32(wb), f32(bf), Ci, Cm, Co, P,
+    call("micf_head_tail_compose", f32(w_up), f32(b_up), f32(w_out), f32(wb), f32(bf), Ci, Cm, Co, P, f32(w_up_t),
          cost=_cost(2 * rows * (Ci + 1) * Cm * 4, w_up, w_out, wb))
     return wb, bf
 
@@ -547,11 +556,11 @@ def head_tail_im2col(dy, dims, P):
     return u
 
 
-def head_tail_decompose(dwb, dbf, w_up, b_up, w_out, dw_up, db_up, dw_out, db_out):
+def head_tail_decompose(dwb, dbf, w_up, b_up, w_out, dw_up, db_up, dw_out, db_out, w_up_t=None):
     Ci, Cm, P = w_up.shape[0], w_up.shape[1], w_up.shape[2]
     Co = w_out.shape[0]
     call("micf_head_tail_decompose", f32(dwb), f32(dbf), f32(w_up), f32(b_up), f32(w_out), f32(dw_up), f32(db_up),
-         f32(dw_out), f32(db_out), Ci, Cm, Co, P,
+         f32(dw_out), f32(db_out), Ci, Cm, Co, P, f32(w_up_t),
          cost=_cost(4 * dwb.numel() * Cm * 27 // (P + 2) ** 3 * P ** 3, dwb, w_up, w_out))
 
 

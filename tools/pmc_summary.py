@@ -8,7 +8,7 @@
 Units / corrections (MI355X_MICROARCH.md, "HBM"): rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB; on gfx950 FETCH_SIZE is
 TCC_EA0_RDREQ x 64 B, i.e. HALF the bytes of wide coalesced reads -> doubled here; WRITE_SIZE is taken as reported
 (uncalibrated).  Infinity-Cache hits are counted, so "traffic" is an upper bound of true HBM bytes.  Per-step values divide by
-the number of adam_step_kernel launches seen in the pass."""
+the number of adam_tick_kernel launches (one per step) seen in the pass."""
 import argparse, collections, csv, json, os, re
 
 ap = argparse.ArgumentParser()
@@ -27,7 +27,7 @@ def load(counter):
             n = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").replace("micf::", "")
             n = re.sub(r"^at::native::", "aten::", n)[:90]
             tot[n] += float(r["Counter_Value"]); calls[n] += 1
-            steps += n.startswith("adam_step_kernel")
+            steps += n.startswith("adam_tick_kernel")
     return tot, calls, max(steps, 1)
 
 

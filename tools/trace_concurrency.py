@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Concurrency of one replayed step from a rocprofv3 kernel-trace CSV: wall time, time with 0 / 1 / >=2 kernels in flight,
-and the kernels that run alone the longest.  usage: trace_concurrency.py trace.csv [marker_kernel=adam_step_kernel]"""
+and the kernels that run alone the longest.  usage: trace_concurrency.py trace.csv [marker_kernel=drop_path_draw_kernel]"""
 import csv, sys, collections, re
 rows = list(csv.DictReader(open(sys.argv[1])))
 marker = sys.argv[2] if len(sys.argv) > 2 else "drop_path_draw_kernel"

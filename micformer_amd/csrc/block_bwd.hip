@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 4 : 2)) bloc
     constexpr int X4 = hc >> 2;
     r_h[ch].commit(U, SU);
     lds_barrier();
-    gemm_phase<TJ, NSL, 1, C, NW, BF16>(w2t + (int64_t)c0 * C, hc, A1, nullptr, 0, nullptr, S, U, SU, EpiGeluGrad{sc2});
+    gemm_phase<TJ, NSL, 1, C, NW, BF16>(w2t + (int64_t)c0 * C, hc, A1, nullptr, 0, nullptr, S, U, SU, EpiGeluGrad<BF16>{sc2});
 #pragma unroll 1
     for (int pass = 0; pass < NPASS; ++pass) {
       const int row = pass * RPP + wave * 4 + rg;

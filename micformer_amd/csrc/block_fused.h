@@ -61,13 +61,14 @@ struct EpiAccScale {          // += rowscale[trow] * v
     *reinterpret_cast<float4*>(o) = make_float4(c.x + rs * v.x, c.y + rs * v.y, c.z + rs * v.z, c.w + rs * v.w);
   }
 };
+template <bool FAST>
 struct EpiGeluGrad {          // rowscale[trow] * v * GELU'(what the tile holds: the saved pre-activation)
   const float* rowscale;
   __device__ __forceinline__ void operator()(float* o, int, int trow, const float4& v) const {
     const float rs = rowscale[trow];
     const float4 c = *reinterpret_cast<const float4*>(o);
-    *reinterpret_cast<float4*>(o) = make_float4(rs * v.x * gelu_grad_f(c.x), rs * v.y * gelu_grad_f(c.y), rs * v.z * gelu_grad_f(c.z),
-                                                 rs * v.w * gelu_grad_f(c.w));
+    *reinterpret_cast<float4*>(o) = make_float4(rs * v.x * gelu_grad_t<FAST>(c.x), rs * v.y * gelu_grad_t<FAST>(c.y),
+                                                 rs * v.z * gelu_grad_t<FAST>(c.z), rs * v.w * gelu_grad_t<FAST>(c.w));
   }
 };
 

@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
       for (int c4 = l16; c4 < X4; c4 += 16) {
         float* up = U + row * SU + 4 * c4;
         const float4 v = *reinterpret_cast<const float4*>(up);
-        const float4 ge = do_gelu ? make_float4(gelu_f(v.x), gelu_f(v.y), gelu_f(v.z), gelu_f(v.w)) : v;
+        const float4 ge = do_gelu ? make_float4(gelu_t<BF16>(v.x), gelu_t<BF16>(v.y), gelu_t<BF16>(v.z), gelu_t<BF16>(v.w)) : v;
         *reinterpret_cast<float4*>(up) = ge;
         if (tk >= 0 && save) {
           st4g(g.h + (int64_t)tk * Hd + c0 + 4 * c4, v);

@@ -46,6 +46,8 @@ struct CellLists {               // workspace carved by the launcher (all int32)
   int* list;                     // [cells][kCellCap]
   int* ovf;                      // [T] tokens that did not fit their cell's list
   int cap;                       // list entries actually used (kCellCap; smaller only under MICF_CELL_CAP, a test hook)
+  float* w8;                     // [T][8] trilinear weight of every corner of a listed token (written with the list entry: the
+                                 // gather then costs one load per (voxel, token) instead of re-deriving the taps from the flow)
 };
 struct SampleFwdSet { const float *h, *ln_g, *ln_b, *w1, *xa; float *flow, *xs; };
 struct SampleBwdSet {

@@ -59,7 +59,7 @@ extern "C" int micf_offset_head_bwd(const micf_offset_head_bwd_group* groups, in
         !g.dln_b || !g.dw1)
       return MICF_EINVAL;
     ss[i] = SampleBwdSet{g.dxs, g.hid, g.ln_g, g.ln_b, g.w1, g.xa, g.flow, g.dxa, g.dhid, g.dln_g, g.dln_b, g.dw1,
-                         CellLists{nullptr, nullptr, nullptr, nullptr, 0}, nullptr};
+                         CellLists{nullptr, nullptr, nullptr, nullptr, 0, nullptr}, nullptr};
     cs[i] = Conv3BwdSet{g.dhid, g.conv_w, g.conv_ws, g.dxn, g.dxa};
   }
   int rc = offset_sample_bwd_groups(ss, ngroups, B, D, H, W, C, eps, workspace, workspace_floats, s);

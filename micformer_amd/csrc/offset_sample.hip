@@ -320,6 +320,12 @@ __device__ __forceinline__ void offset_sample_bwd4_body(
         else cl.ovf[atomicAdd(cl.ovf_count, 1)] = (int)t;
       }
     }
+    if (!SCATTER && live && k < 8 && cl.w8) {           // lane k < 8: the weight of corner k (dz, dy, dx = bits of k)
+      const float ux = (k & 1) ? tp.cx - tp.x0 : (tp.x0 + 1.f) - tp.cx;
+      const float uy = (k & 2) ? tp.cy - tp.y0 : (tp.y0 + 1.f) - tp.cy;
+      const float uz = (k & 4) ? tp.cz - tp.z0 : (tp.z0 + 1.f) - tp.cz;
+      cl.w8[t * 8 + k] = ux * uy * uz;
+    }
     gz = sum16(gz); gy = sum16(gy); gx = sum16(gx);
     // grid_sample: d/dn = d/dcoord * S/2 ; STN.py:24: d/dnew = 2 * d/dn / (S-1)      (S == 1 -> 0/0 = NaN, as the reference)
     float go3[3];
@@ -380,13 +386,18 @@ __device__ __forceinline__ void sample_gather_body(const float* __restrict__ dxs
     n = n < cl.cap ? n : cl.cap;
     for (int i = 0; i < n; ++i) {
       const int t = cl.list[(int64_t)cell * kCellCap + i];
-      int tb, td, th, tw; g.decode(t, tb, td, th, tw);
-      const float fl[3] = {flow[(int64_t)t * 3 + 0], flow[(int64_t)t * 3 + 1], flow[(int64_t)t * 3 + 2]};
-      const Taps tp = make_taps(td, th, tw, fl, g.D, g.H, g.W);
-      const float wx = dx ? tp.cx - tp.x0 : (tp.x0 + 1.f) - tp.cx;
-      const float wy = dy ? tp.cy - tp.y0 : (tp.y0 + 1.f) - tp.cy;
-      const float wz = dz ? tp.cz - tp.z0 : (tp.z0 + 1.f) - tp.cz;
-      const float wgt = wx * wy * wz;
+      float wgt;
+      if (cl.w8) {
+        wgt = cl.w8[(int64_t)t * 8 + q];
+      } else {
+        int tb, td, th, tw; g.decode(t, tb, td, th, tw);
+        const float fl[3] = {flow[(int64_t)t * 3 + 0], flow[(int64_t)t * 3 + 1], flow[(int64_t)t * 3 + 2]};
+        const Taps tp = make_taps(td, th, tw, fl, g.D, g.H, g.W);
+        const float wx = dx ? tp.cx - tp.x0 : (tp.x0 + 1.f) - tp.cx;
+        const float wy = dy ? tp.cy - tp.y0 : (tp.y0 + 1.f) - tp.cy;
+        const float wz = dz ? tp.cz - tp.z0 : (tp.z0 + 1.f) - tp.cz;
+        wgt = wx * wy * wz;
+      }
       const float4 go = *reinterpret_cast<const float4*>(dxs + (int64_t)t * C + c4);
       acc.x += wgt * go.x; acc.y += wgt * go.y; acc.z += wgt * go.z; acc.w += wgt * go.w;
     }
@@ -593,7 +604,7 @@ extern "C" int64_t micf_offset_sample_bwd_workspace(int B, int D, int H, int W) 
   int64_t need = partial_floats(T);
   if (use_cells(T)) {
     const int64_t nc = (cell_count(B, D, H, W) + 3) / 4 * 4;
-    need += nc + 4 + nc * kCellCap + T;
+    need += nc + 4 + nc * kCellCap + T + 8 * T;
   }
   return need;
 }
@@ -621,7 +632,7 @@ int micf::offset_sample_bwd_groups(SampleBwdSet* sets, int n, int B, int D, int 
   const int wpb = quad ? quad_waves_per_block(T) : 4;
   const int blocks = ceil_div(T, (quad ? 4 * wpb : 4) * tpw);
   const int nwaves = blocks * wpb;
-  const CellLists none{nullptr, nullptr, nullptr, nullptr, 0};
+  const CellLists none{nullptr, nullptr, nullptr, nullptr, 0, nullptr};
   const int64_t per = micf_offset_sample_bwd_workspace(B, D, H, W);
   const bool have_ws = workspace && workspace_floats >= per * n && aligned16(workspace);
   const bool cells = have_ws && use_cells(T) && quad && cell_count(B, D, H, W) * kCellCap < (1LL << 31);
@@ -644,7 +655,8 @@ int micf::offset_sample_bwd_groups(SampleBwdSet* sets, int n, int B, int D, int 
     if (cells) {
       int* cnt = counters + k * (nc + 4);
       int* ls = lists + k * (nc * kCellCap + T);
-      p.s[i].cl = CellLists{cnt, cnt + nc, ls, ls + nc * kCellCap, cap};
+      float* w8 = reinterpret_cast<float*>(lists + n * (nc * kCellCap + T)) + (int64_t)k * 8 * T;
+      p.s[i].cl = CellLists{cnt, cnt + nc, ls, ls + nc * kCellCap, cap, w8};
     }
   }
   if (cells && hipMemsetAsync(counters, 0, sizeof(int) * (size_t)(n * (nc + 4)), s) != hipSuccess) return MICF_ELAUNCH;
@@ -672,7 +684,7 @@ extern "C" int micf_offset_sample_bwd(const float* dxs, const float* h, const fl
                                       const float* w1, const float* xa, const float* flow, float* dxa, float* dh,
                                       float* dln_g, float* dln_b, float* dw1, int B, int D, int H, int W, int C, float eps,
                                       float* workspace, int64_t workspace_floats, micf_stream_t stream) {
-  SampleBwdSet one{dxs, h, ln_g, ln_b, w1, xa, flow, dxa, dh, dln_g, dln_b, dw1, CellLists{nullptr, nullptr, nullptr, nullptr, 0}, nullptr};
+  SampleBwdSet one{dxs, h, ln_g, ln_b, w1, xa, flow, dxa, dh, dln_g, dln_b, dw1, CellLists{nullptr, nullptr, nullptr, nullptr, 0, nullptr}, nullptr};
   return offset_sample_bwd_groups(&one, 1, B, D, H, W, C, eps, workspace, workspace_floats, (hipStream_t)stream);
 }
 

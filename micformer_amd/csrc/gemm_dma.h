@@ -24,6 +24,7 @@
 #include <stdint.h>
 
 #include <mutex>
+#include <type_traits>
 
 #include "gemm_core.h"
 
@@ -132,7 +133,9 @@ __device__ __forceinline__ void dma_tile_loop(const DmaOperand& P, const DmaOper
     }
   }
   float4 aprev[4], bprev = make_float4(0.f, 0.f, 0.f, 0.f);     // bf16 mode: the even slab of a pair
-  for (int it = 0; it < nslab; ++it) {
+  auto slab = [&](int it, auto phase) {
+    constexpr int PHASE = decltype(phase)::value;
+
     // slab `it` has landed when at most the (up to NS-2) younger slabs of THIS wave are still outstanding
     wait_younger((nslab - 1 - it < NS - 2) ? nslab - 1 - it : NS - 2);
     __builtin_amdgcn_s_barrier();                         // every wave's piece of slab `it` is in LDS; slab it-1 is free
@@ -157,8 +160,10 @@ __device__ __forceinline__ void dma_tile_loop(const DmaOperand& P, const DmaOper
       for (int t = 0; t < 4; ++t) pv[t] = *reinterpret_cast<const float4*>(Pb + (16 * t + li) * kDmaBR + 4 * lr);
     }
     if (QX) {
+      if constexpr (!BF16) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) qv[s] = *reinterpret_cast<const float4*>(Qb + (4 * lr + s) * 64 + 4 * li);
+        for (int s = 0; s < 4; ++s) qv[s] = *reinterpret_cast<const float4*>(Qb + (4 * lr + s) * 64 + 4 * li);
+      }
     } else {
       qv[0] = *reinterpret_cast<const float4*>(Qb + (16 * wave + li) * kDmaBR + 4 * lr);
     }
@@ -187,23 +192,35 @@ __device__ __forceinline__ void dma_tile_loop(const DmaOperand& P, const DmaOper
 #pragma unroll
       for (int t = 0; t < 4; ++t)
         a4[t] = PX ? make_float4(f4e(pv[0], t), f4e(pv[1], t), f4e(pv[2], t), f4e(pv[3], t)) : pv[t];
-      if (QX) b4 = make_float4(f4e(qv[0], wave), f4e(qv[1], wave), f4e(qv[2], wave), f4e(qv[3], wave));
+      if (QX) b4 = make_float4(Qb[(4 * lr) * 64 + 4 * li + wave], Qb[(4 * lr + 1) * 64 + 4 * li + wave],
+                               Qb[(4 * lr + 2) * 64 + 4 * li + wave], Qb[(4 * lr + 3) * 64 + 4 * li + wave]);   // (column 4 li + wave)
       else b4 = qv[0];
-      const bool odd = it & 1, last = it == nslab - 1;
-      if (odd || last) {
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        const bf16x8 bb = odd ? to_bf16x8(bprev, b4) : to_bf16x8(b4, z);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const bf16x8 ba = odd ? to_bf16x8(aprev[t], a4[t]) : to_bf16x8(a4[t], z);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ba, bb, acc[t], 0, 0, 0);
-        }
-      } else {
+      // PHASE 0: even slab of a pair (kept), 1: odd slab (issues the MFMAs), 2: unpaired last slab (zero-padded) -- compile-time,
+      // so neither the conversions nor the MFMAs sit behind per-lane selects
+      if constexpr (PHASE == 0) {
         bprev = b4;
 #pragma unroll
         for (int t = 0; t < 4; ++t) aprev[t] = a4[t];
+      } else {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bf16x8 bb = PHASE == 1 ? to_bf16x8(bprev, b4) : to_bf16x8(b4, z);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const bf16x8 ba = PHASE == 1 ? to_bf16x8(aprev[t], a4[t]) : to_bf16x8(a4[t], z);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ba, bb, acc[t], 0, 0, 0);
+        }
       }
     }
+  };
+  if constexpr (BF16) {
+    int it = 0;
+    for (; it + 1 < nslab; it += 2) {
+      slab(it, std::integral_constant<int, 0>{});
+      slab(it + 1, std::integral_constant<int, 1>{});
+    }
+    if (it < nslab) slab(it, std::integral_constant<int, 2>{});
+  } else {
+    for (int it = 0; it < nslab; ++it) slab(it, std::integral_constant<int, 0>{});
   }
 }
 

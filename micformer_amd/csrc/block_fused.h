@@ -239,7 +239,17 @@ __device__ __forceinline__ void gemm_phase_bf16w(const uint16_t* __restrict__ W0
     }
   };
 
-  if (nunits > 0) {
+  if (nunits > 0 && nunits <= 3) {
+    // few units per wave (16 waves at C = 192): request them ALL before the first MFMA -- one L2 round trip per phase instead of
+    // one per unit (a unit's 6-12 MFMAs are far too short to hide the next unit's loads behind them)
+    Frag fa, fb, fc;
+    load_unit(0, fa);
+    load_unit(1, fb);
+    load_unit(2, fc);
+    compute_unit(0, fa);
+    if (nunits > 1) compute_unit(1, fb);
+    if (nunits > 2) compute_unit(2, fc);
+  } else if (nunits > 0) {
     Frag fa, fb;
     load_unit(0, fa);
     for (int u = 0; u < nunits; u += 2) {
@@ -312,6 +322,11 @@ int block_fwd_wide(const micf_block_fwd_group* groups, int ngroups, int B, int D
 int block_bwd_wide(const micf_block_bwd_group* groups, int ngroups, int B, int D, int H, int W, int C, int heads, float scale, int dtype,
                    hipStream_t s);
 __device__ __forceinline__ float4 ld4g(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ void st4g(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+// Outputs are written once and read by LATER kernels only: non-temporal stores keep them from evicting the block's weights
+// (0.9 MB per XCD at C = 192, re-read by every workgroup) out of the 4 MB L2 while the kernel runs.
+__device__ __forceinline__ void st4g(float* p, const float4& v) {
+  typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store(f32x4_nt{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4_nt*>(p));
+}
 
 }  // namespace micf

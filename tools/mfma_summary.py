@@ -19,7 +19,8 @@ for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
             n[k] += 1
-rows = sorted(acc.items(), key=lambda kv: -kv[1]["GRBM_GUI_ACTIVE"])
+rows = sorted(((k, c) for k, c in acc.items() if not k.startswith("__amd_rocclr")),       # (runtime copy / fill helpers: eager warm-up steps)
+              key=lambda kv: -kv[1]["GRBM_GUI_ACTIVE"])
 tot = sum(c["GRBM_GUI_ACTIVE"] for _, c in rows) or 1
 print(f"{'kernel':82s} {'launches':>8s} {'share':>6s} {'MfmaUtil':>8s} {'waves/SIMD':>10s} {'MFMA instr/launch':>18s}")
 for k, c in rows[:top]:

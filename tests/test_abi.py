@@ -71,3 +71,33 @@ def test_invalid_arguments_return_error_codes_without_gpu():
     assert _lib.lib.micf_layernorm_fwd(None, None, 4, None, None, None, None, None, 8, 4, 1e-5, None) == -1
     assert _lib.lib.micf_adam_tick(None, 1e-4, 0.0, 10, None) == -1
     assert _lib.lib.micf_conv_up_fwd(None, None, None, None, 1, 2, 2, 2, 4, 4, 3, None) == -1
+
+
+def test_round2_entry_points_validate_arguments_without_gpu():
+    """The grouped / fused entry points added in round 2: NULL arrays, bad group counts, unknown dtypes and unsupported shapes
+    are rejected before any launch; the pure shape queries answer on a CPU-only box."""
+    import ctypes as C
+    from micformer_amd import _lib
+    L = _lib.lib
+    EINVAL, EUNSUP = -1, -2
+    assert L.micf_block_fwd(None, 2, 1, 4, 4, 4, 48, 3, 192, C.c_float(1e-5), C.c_float(0.25), 0, None) == EINVAL
+    assert L.micf_block_bwd(None, 1, 1, 4, 4, 4, 48, 3, 192, C.c_float(0.25), 0, None) == EINVAL
+    g = (_lib.BlockFwdGroup * 2)()
+    assert L.micf_block_fwd(C.cast(g, C.c_void_p), 3, 1, 4, 4, 4, 48, 3, 192, C.c_float(1e-5), C.c_float(0.25), 0, None) == EINVAL
+    assert L.micf_block_fwd(C.cast(g, C.c_void_p), 1, 1, 3, 4, 4, 48, 3, 192, C.c_float(1e-5), C.c_float(0.25), 0, None) == EUNSUP   # odd grid
+    assert L.micf_block_fwd(C.cast(g, C.c_void_p), 1, 1, 4, 4, 4, 48, 3, 192, C.c_float(1e-5), C.c_float(0.25), 7, None) == EINVAL   # dtype
+    assert L.micf_block_fwd(C.cast(g, C.c_void_p), 1, 1, 4, 4, 4, 48, 3, 192, C.c_float(1e-5), C.c_float(0.25), 0, None) == EINVAL   # NULL tensors
+    # shape queries
+    assert L.micf_block_tile_tokens(2, 32, 32, 32, 48, 3, 192, 0) == 32 and L.micf_block_tile_tokens(2, 4, 4, 4, 384, 24, 1536, 1) == 16
+    assert L.micf_block_tile_tokens(1, 3, 4, 4, 48, 3, 192, 0) == 0 and L.micf_block_tile_tokens(1, 4, 4, 4, 768, 24, 3072, 0) == 0
+    assert L.micf_offset_head_needs_zero(2, 8, 8, 8, 192) == 1 and L.micf_offset_head_needs_zero(2, 32, 32, 32, 48) == 0
+    assert L.micf_offset_head_bwd_workspace(2, 2, 32, 32, 32) == 2 * L.micf_offset_sample_bwd_workspace(2, 32, 32, 32)
+    assert L.micf_conv3_fwd_workspace(16, 48, 48) > 6 * 27 * 256      # fp32 + bf16 layouts
+    # grouped helpers
+    assert L.micf_offset_head_fwd(None, 2, 1, 4, 4, 4, 48, C.c_float(1e-5), 0, 0, 0, None) == EINVAL
+    assert L.micf_offset_head_bwd(None, 2, 1, 4, 4, 4, 48, C.c_float(1e-5), 0, None, 0, 0, None) == EINVAL
+    assert L.micf_layernorm_fwd_pair(None, 2, 8, 48, C.c_float(1e-5), None, 0, None) == EINVAL
+    assert L.micf_layernorm_bwd_pair(None, 2, 8, 48, None) == EINVAL
+    assert L.micf_weight_prep_grouped(None, 3, None) == EINVAL and L.micf_weight_prep_grouped(None, 0, None) == 0
+    assert L.micf_conv3_weight_prep_grouped(None, 1, None) == EINVAL
+    assert L.micf_adam_step(None, None, None, None, 8, None, C.c_float(0.9), C.c_float(0.999), C.c_float(1e-8), C.c_float(1.0), None, None) == EINVAL

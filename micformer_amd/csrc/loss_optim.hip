@@ -169,21 +169,31 @@ __global__ void __launch_bounds__(256) adam_step_kernel(float* __restrict__ p, c
   const float bc1 = (float)(1.0 - pow((double)beta1, step));
   const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, step));
   const float step_size = (float)(st->lr / (double)bc1);
-  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
-    if (i + 3 < n) {
-      float4 P = *reinterpret_cast<float4*>(p + i), M = *reinterpret_cast<float4*>(m + i), Vv = *reinterpret_cast<float4*>(v + i);
-      float4 G = *reinterpret_cast<const float4*>(g + i);
-      G.x *= gscale; G.y *= gscale; G.z *= gscale; G.w *= gscale;        // data parallel: sum over ranks -> mean (1 on one GPU)
-      float* pp = &P.x; float* mm = &M.x; float* vv = &Vv.x; const float* gg = &G.x;
+  // two float4 per thread and round trip: the loads of both are issued before the first store (the kernel is pure HBM streaming,
+  // 30 bytes per parameter; bytes in flight per CU are what bounds it)
+  const int64_t stride = (int64_t)gridDim.x * 1024;
+  for (int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i0 < n; i0 += 2 * stride) {
+    const int64_t i1 = i0 + stride;
+    const bool full0 = i0 + 3 < n, full1 = i1 + 3 < n;
+    float4 P[2], M[2], V[2], G[2];
+    if (full0) { P[0] = *reinterpret_cast<float4*>(p + i0); M[0] = *reinterpret_cast<float4*>(m + i0); V[0] = *reinterpret_cast<float4*>(v + i0); G[0] = *reinterpret_cast<const float4*>(g + i0); }
+    if (full1) { P[1] = *reinterpret_cast<float4*>(p + i1); M[1] = *reinterpret_cast<float4*>(m + i1); V[1] = *reinterpret_cast<float4*>(v + i1); G[1] = *reinterpret_cast<const float4*>(g + i1); }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int64_t i = h ? i1 : i0;
+      if (i >= n) continue;
+    if (h ? full1 : full0) {
+      float* pp = &P[h].x; float* mm = &M[h].x; float* vv = &V[h].x; float* gg = &G[h].x;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
+        gg[e] *= gscale;                                                  // data parallel: sum over ranks -> mean (1 on one GPU)
         mm[e] = mm[e] + (gg[e] - mm[e]) * (1.0f - beta1);                 // exp_avg.lerp_(grad, 1 - beta1)
         vv[e] = vv[e] * beta2 + (1.0f - beta2) * gg[e] * gg[e];           // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
         const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
         pp[e] = pp[e] - step_size * (mm[e] / denom);                      // param.addcdiv_(exp_avg, denom, -step_size)
       }
-      *reinterpret_cast<float4*>(p + i) = P; *reinterpret_cast<float4*>(m + i) = M; *reinterpret_cast<float4*>(v + i) = Vv;
-      if (p16) *reinterpret_cast<uint2*>(p16 + i) = make_uint2(bf16_pair(P.x, P.y), bf16_pair(P.z, P.w));   // bf16 mirror (RNE)
+      *reinterpret_cast<float4*>(p + i) = P[h]; *reinterpret_cast<float4*>(m + i) = M[h]; *reinterpret_cast<float4*>(v + i) = V[h];
+      if (p16) *reinterpret_cast<uint2*>(p16 + i) = make_uint2(bf16_pair(P[h].x, P[h].y), bf16_pair(P[h].z, P[h].w));   // bf16 mirror (RNE)
     } else {
       for (int64_t j = i; j < n; ++j) {
         const float gj = g[j] * gscale;
@@ -192,6 +202,7 @@ __global__ void __launch_bounds__(256) adam_step_kernel(float* __restrict__ p, c
         p[j] = p[j] - step_size * (m[j] / (sqrtf(v[j]) / bc2_sqrt + eps));
         if (p16) p16[j] = (uint16_t)(bf16_pair(p[j], 0.f) & 0xFFFFu);
       }
+    }
     }
   }
 }

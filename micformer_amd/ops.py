@@ -306,7 +306,7 @@ def conv3_fwd(x1, w, bias, dims, x2=None, ncdhw_out=False):
     N = w.shape[0]
     y = _new(x1, B, N, D, H, W) if ncdhw_out else _new(x1, B * D * H * W, N)
     need = 0 if ncdhw_out else _lib.lib.micf_conv3_fwd_workspace(N, c1, c2)
-    ws = getattr(w, "_micf_c3f", None) if need > 0 else None     # engine mode: re-laid-out copy, refreshed once per step
+    ws = _conv_layouts(w)[0] if need > 0 else None               # engine mode: re-laid-out copy, refreshed once per step
     prepared = 1 if ws is not None else 0
     if ws is None and need > 0:
         ws = scratch(x1.device, need)
@@ -325,7 +325,7 @@ def conv3_bwd_data(dy, w, dims, c1, c2=0, ncdhw=False, dx1=None, dx2=None, acc1=
     if dx2 is None and want2 and c2 > 0:
         dx2 = _new(dy, T, c2)
     need = 0 if ncdhw else _lib.lib.micf_conv3_bwd_data_workspace(N, c1, c2)
-    ws = getattr(w, "_micf_c3b", None) if need > 0 else None
+    ws = _conv_layouts(w)[1] if need > 0 else None
     prepared = 1 if ws is not None else 0
     if ws is None and need > 0:
         ws = scratch(dy.device, need)
@@ -391,7 +391,7 @@ def offset_head_fwd(groups, dims, eps, hid=None):
     for i, (it, gd) in enumerate(zip(arr, groups)):
         P = gd["P"]
         w = P["conv_offset.0.weight"]
-        ws = getattr(w, "_micf_c3f", None)
+        ws = _conv_layouts(w)[0]
         prepared = (ws is not None) if prepared is None else (prepared and ws is not None)
         if ws is None:
             need = _lib.lib.micf_conv3_fwd_workspace(16, C, C)
@@ -426,7 +426,7 @@ def offset_head_bwd(groups, dims, eps):
     for it, gd in zip(arr, groups):
         P, G = gd["P"], gd["G"]
         w = P["conv_offset.0.weight"]
-        ws = getattr(w, "_micf_c3b", None)
+        ws = _conv_layouts(w)[1]
         prepared = (ws is not None) if prepared is None else (prepared and ws is not None)
         keep.append(ws)
         dhid = _new(gd["xa"], T, 16)
@@ -760,6 +760,34 @@ def shadow_like(w, transposed, dtype):
     return torch.empty((w.shape[1], w.shape[0]) if transposed else tuple(w.shape), dtype=dtype, device=w.device)
 
 
+def _inference_cache(w, key, build):
+    """Shadow copies for forward passes WITHOUT an engine (validation, sliding-window inference under no_grad): built once per
+    weight and kept on the tensor until torch code writes it (version counter).  A captured predictor graph
+    (inference.GraphedPredictor) then replays without any per-window weight preparation.  None when autograd is recording."""
+    if torch.is_grad_enabled():
+        return None
+    cache = w.__dict__.setdefault("_micf_cache", {})
+    ent = cache.get(key)
+    if ent is None or ent[0] != w._version:
+        ent = cache[key] = (w._version, build())
+    return ent[1]
+
+
+def _conv_layouts(w):
+    """(fwd, bwd) prepared layouts of an offset-conv weight: the engine's (refreshed per step), the inference cache's, or None."""
+    f, b = getattr(w, "_micf_c3f", None), getattr(w, "_micf_c3b", None)
+    if f is None and b is None and w.dim() == 5 and w.shape[0] <= 16:
+        def build():
+            fb = conv3_prepared_like(w)
+            if fb[0] is not None or fb[1] is not None:
+                Conv3PrepPlan([(w, fb[0], fb[1])]).launch()
+            return fb
+        fb = _inference_cache(w, "conv3", build)
+        if fb is not None:
+            f, b = fb
+    return f, b
+
+
 def block_weights(P, attn, backward):
     """The five weight matrices a fused block kernel streams, in the layout of the current arithmetic mode.  Engine mode: the
     parameter carries the shadow copy (refreshed once per step); otherwise it is made here (one grouped launch)."""
@@ -772,6 +800,12 @@ def block_weights(P, attn, backward):
             out[field] = w
             continue
         sh = getattr(w, spec[0], None)
+        if sh is None:
+            def build(w=w):
+                t = shadow_like(w, spec[1], spec[2])
+                WeightPrepPlan([(w, None, t) if spec[1] else (w, t, None)]).launch()
+                return t
+            sh = _inference_cache(w, spec[0], build)
         if sh is None:
             sh = shadow_like(w, spec[1], spec[2])
             todo.append((w, None, sh) if spec[1] else (w, sh, None))

@@ -209,3 +209,25 @@ def test_weight_prep_outputs(ops, rows, cols):
     assert torch.equal(wc, w) and torch.equal(wt, w.t().contiguous())
     assert torch.equal(w16, w.to(torch.bfloat16))
     assert torch.equal(wt16, w.t().contiguous().to(torch.bfloat16)) and torch.equal(only_t, wt16)
+
+
+def test_inference_shadow_cache_follows_weight_updates(ops):
+    """Under no_grad (no engine) the bf16 shadow weights are cached on the parameter and rebuilt when torch code writes it."""
+    ops.set_compute_dtype("bf16")
+    try:
+        keys = ("self_attn.q.weight", "self_attn.kv.weight", "self_attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight")
+        P = {k: torch.randn(96, 48, device="cuda") for k in keys}
+        with torch.no_grad():
+            a = ops.block_weights(P, "self_attn", backward=False)
+            b = ops.block_weights(P, "self_attn", backward=False)
+            assert all(a[f].data_ptr() == b[f].data_ptr() for f in a)                  # cached, not re-made
+            assert torch.equal(a["wq"], P["self_attn.q.weight"].to(torch.bfloat16))
+            P["self_attn.q.weight"].mul_(2.0)                                          # in-place update: version counter moves
+            c = ops.block_weights(P, "self_attn", backward=False)
+            torch.cuda.synchronize()
+            assert torch.equal(c["wq"], P["self_attn.q.weight"].to(torch.bfloat16))
+            assert c["wkv"].data_ptr() == a["wkv"].data_ptr()                          # untouched weights keep their copies
+        g = ops.block_weights(P, "self_attn", backward=False)                          # autograd recording: fresh temporaries
+        assert g["wq"].data_ptr() != c["wq"].data_ptr()
+    finally:
+        ops.set_compute_dtype("fp32")

@@ -90,7 +90,7 @@ struct EpiGeluGrad {          // rowscale[trow] * v * GELU'(what the tile holds:
 // lane group lr supplies k = 4 lr + s in step s, both operands alike); a wave writes only its own x columns of the LDS output
 // tile Os.  Two accumulator chains per token group (even / odd k-steps) keep the fp32 MFMA pipe at its issue rate.
 // All 64 * NW threads call it together; on return Os is complete and visible to the workgroup.
-template <int TG, int NSL, int NK, int LD, int NW, bool BF16, class Epi>
+template <int TG, int NSL, int NK, int LD, int NW, class Epi>
 __device__ __forceinline__ void gemm_phase_f32w(const float* __restrict__ W0, int X0, const float* Bs0, const float* __restrict__ W1,
                                            int X1, const float* Bs1, int SB, float* Os, int SO, const Epi epi) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -118,39 +118,21 @@ __device__ __forceinline__ void gemm_phase_f32w(const float* __restrict__ W0, in
   auto compute_unit = [&](int u, const Frag& f) {
     const int tile = wave + NW * (NK == 1 ? u : u / NK), kc = NK == 1 ? 0 : u % NK;
     const float* brow = ((tile >= nt0) ? Bs1 : Bs0) + li * SB + kc * NSL * 16 + 4 * lr;
-    float4 qprev[TG], aprev = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int s = 0; s < NSL; ++s) {
       const float4 av = f.v[s];
       float4 qv[TG];
 #pragma unroll
       for (int g = 0; g < TG; ++g) qv[g] = *reinterpret_cast<const float4*>(brow + g * 16 * SB + 16 * s);
-      if constexpr (!BF16) {
 #pragma unroll
-        for (int g = 0; g < TG; ++g) {
-          acc0[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, qv[g].x, acc0[g], 0, 0, 0);
-          acc1[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, qv[g].y, acc1[g], 0, 0, 0);
-        }
+      for (int g = 0; g < TG; ++g) {
+        acc0[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, qv[g].x, acc0[g], 0, 0, 0);
+        acc1[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, qv[g].y, acc1[g], 0, 0, 0);
+      }
 #pragma unroll
-        for (int g = 0; g < TG; ++g) {
-          acc0[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, qv[g].z, acc0[g], 0, 0, 0);
-          acc1[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, qv[g].w, acc1[g], 0, 0, 0);
-        }
-      } else {
-        // k = 32 per MFMA: (even slab, odd slab) pairs; an unpaired last slab of the chunk is padded with zeros
-        if ((s & 1) || s == NSL - 1) {
-          const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-          const bf16x8 ba = (s & 1) ? to_bf16x8(aprev, av) : to_bf16x8(av, z);
-#pragma unroll
-          for (int g = 0; g < TG; ++g) {
-            const bf16x8 bq = (s & 1) ? to_bf16x8(qprev[g], qv[g]) : to_bf16x8(qv[g], z);
-            acc0[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ba, bq, acc0[g], 0, 0, 0);
-          }
-        } else {
-          aprev = av;
-#pragma unroll
-          for (int g = 0; g < TG; ++g) qprev[g] = qv[g];
-        }
+      for (int g = 0; g < TG; ++g) {
+        acc0[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, qv[g].z, acc0[g], 0, 0, 0);
+        acc1[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, qv[g].w, acc1[g], 0, 0, 0);
       }
     }
     if (kc == NK - 1) {                                 // tile complete: epilogue into the LDS output tile (own columns only)
@@ -266,7 +248,7 @@ __device__ __forceinline__ void gemm_phase_bf16w(const uint16_t* __restrict__ W0
 template <int TG, int NSL, int NK, int LD, int NW, bool BF16, class Epi>
 __device__ __forceinline__ void gemm_phase(const float* W0, int X0, const float* Bs0, const float* W1, int X1, const float* Bs1, int SB,
                                            float* Os, int SO, const Epi epi) {
-  gemm_phase_f32w<TG, NSL, NK, LD, NW, false, Epi>(W0, X0, Bs0, W1, X1, Bs1, SB, Os, SO, epi);
+  gemm_phase_f32w<TG, NSL, NK, LD, NW, Epi>(W0, X0, Bs0, W1, X1, Bs1, SB, Os, SO, epi);
 }
 template <int TG, int NSL, int NK, int LD, int NW, bool BF16, class Epi>
 __device__ __forceinline__ void gemm_phase(const uint16_t* W0, int X0, const float* Bs0, const uint16_t* W1, int X1, const float* Bs1,

@@ -226,6 +226,9 @@ class LayerNormProxy(nn.Module):
 
 # Run the two modalities' independent blocks on two HIP streams (engine / bench switch; off = the reference's serial order).
 PARALLEL_MODALITIES = False
+# backward flush points inside a stage: every SLOT_FLUSH_STRIDE-th depth slot (measured at base / 128^3: 1 -> 15.2 ms, 2 -> 15.3,
+# 3 -> 14.8, 4 -> 14.9, none -> 15.5: one flush in the middle of the six-slot stage, none inside the two-slot stages)
+SLOT_FLUSH_STRIDE = int(__import__("os").environ.get("MICF_SLOT_FLUSH_STRIDE", "3"))
 # Head: run reverse_patch_embedding + out_conv as their composition (off = the reference's two separate convolutions).
 FUSE_HEAD_TAIL = True
 # Both modalities' blocks of a depth slot in one fused launch (off: one fused launch per modality, on two streams when
@@ -409,8 +412,8 @@ class BasicLayer(nn.Module):
 
     def _forward_pairs(self, x, xa):
         for i in range(self.depth):
-            if i and (Fn.FLUSH_POINTS or Fn.DEFER_CALLS) and x.requires_grad:
-                x, xa = Fn.FlushPointFn.apply(x, xa)   # backward: the later slots' weight gradients start under this slot's chain
+            if i and i % SLOT_FLUSH_STRIDE == 0 and (Fn.FLUSH_POINTS or Fn.DEFER_CALLS) and x.requires_grad:
+                x, xa = Fn.FlushPointFn.apply(x, xa)   # backward: the later slots' weight gradients start under the earlier slots' chain
             a, b = self.self_blocks1[i], self.self_blocks2[i]
             sa, sb = _block_scales(a, x), _block_scales(b, xa)
             x, xa = Fn.SelfPairFn.apply(x, xa, sa[0], sa[1], sb[0], sb[1], a.num_heads, a.norm1.eps,

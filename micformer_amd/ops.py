@@ -840,7 +840,9 @@ def block_fwd(groups, dims, C, heads, eps, scale):
         for k, v in o.items():
             setattr(it, k, f32(v))
         outs.append(o)
-        nb += 4 * (T * C * (9 if o["xn"] is not None else 8) + 2 * T * hidden) + 12 * C * C * wt.element_size()
+        # algorithmic bytes: read x (+ kvsrc), write [xn,] q, kv (2), o, x1, xn2, y, h (4), g (4); the weights once
+        nb += 4 * (T * C * ((9 if o["xn"] is not None else 8) + (1 if gd.get("kvsrc") is not None else 0)) + 2 * T * hidden) \
+            + 12 * C * C * wt.element_size()
         fl += 2 * T * 12 * C * C + 4 * T * C * 8
     call("micf_block_fwd", ctypes.cast(arr, ctypes.c_void_p), len(groups), B, D, H, W, C, heads, hidden, float(eps), float(scale),
          _dt(), cost=(nb, fl, f"{len(groups)}x{T}x{C}") if _lib.PROFILE is not None and DETAIL else ((nb, fl) if _lib.PROFILE is not None else None))
@@ -877,7 +879,8 @@ def block_bwd(groups, dims, C, heads, scale):
             setattr(it, k, f32(v))
         o["tiles"] = tiles
         outs.append(o)
-        nb += 4 * (T * C * (11 if cross else 9) + 2 * T * hidden) + 12 * C * C * wt.element_size()
+        # algorithmic bytes: read dy, x1, q, kv (2), h (4) [+ x: self]; write dx, dx1, dq, dkv (2), dh (4) [+ dxs, dx1_copy: cross]
+        nb += 4 * (T * C * ((11 + (1 if gd.get("want_copy") else 0)) if cross else 11) + 2 * T * hidden) + 12 * C * C * wt.element_size()
         fl += 2 * T * 12 * C * C + 8 * T * C * 8
     call("micf_block_bwd", ctypes.cast(arr, ctypes.c_void_p), len(groups), B, D, H, W, C, heads, hidden, float(scale),
          _dt(), cost=(nb, fl, f"{len(groups)}x{T}x{C}") if _lib.PROFILE is not None and DETAIL else ((nb, fl) if _lib.PROFILE is not None else None))

@@ -169,7 +169,7 @@ __device__ __forceinline__ void ln_bwd_tile(const float* D, float* A, int S, con
 }
 
 template <int C, int HD, int TJ, int NW, bool BF16>
-__global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 4 : 2)) block_bwd_kernel(const BlkBwdArgs a) {
+__global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) block_bwd_kernel(const BlkBwdArgs a) {
   constexpr int TM = 16 * TJ, VPL = (C + 63) / 64, NSL = C / 16, NTHR = 64 * NW, RPP = 4 * NW, NPASS = (TM + RPP - 1) / RPP;
   extern __shared__ __attribute__((aligned(1024))) float lds[];
   constexpr int C4 = C >> 2, S = C + 4, SU = 3 * C + 4, Hd = 4 * C;
@@ -216,10 +216,10 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 4 : 2)) bloc
 #pragma unroll
   for (int ch = 0; ch < Hd / HC; ++ch) r_h[ch].load(tok, [&](int tk, int c4) { return g.h + (int64_t)tk * Hd + ch * HC + 4 * c4; });
   r_ln2.load(tok, g.x1, g.stats + 2 * T, g.stats + 3 * T, g.ln2_g);
+  if (!g.dxs) r_ln1.load(tok, g.x, g.stats, g.stats + T, g.ln1_g);
   r_qkv.load(tok, [&](int tk, int c4) {
     return c4 < C4 ? g.q + (int64_t)tk * C + 4 * c4 : g.kv + (int64_t)tk * 2 * C + 4 * (c4 - C4);
   });
-  if (!g.dxs) r_ln1.load(tok, g.x, g.stats, g.stats + T, g.ln1_g);
 
   // ---- dy rows -> A1
   r_dy.commit(A1, S);

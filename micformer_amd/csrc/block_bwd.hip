@@ -32,7 +32,7 @@ struct RowRegs {
   static constexpr int RPP = 4 * NW, NPASS = (TM + RPP - 1) / RPP, K = (X4 + 15) / 16;
   float4 v[NPASS][K];
   template <class Addr>
-  __device__ __forceinline__ void load(const int* tok, const Addr addr) {       // addr(token, float4 column) -> const float*
+  __device__ __forceinline__ void load(const int* tok, int tk0, const Addr addr) {   // addr(row offset, float4 column) -> const float*
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15, rg = lane >> 4;
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
@@ -42,7 +42,7 @@ struct RowRegs {
       for (int k = 0; k < K; ++k) {
         const int c4 = l16 + 16 * k;
         const bool ok = tk >= 0 && c4 < X4;       // (branch-free: out-of-range lanes read a valid address and drop the value)
-        const float4 t = ld4g(addr(tk >= 0 ? tk : 0, c4 < X4 ? c4 : X4 - 1));
+        const float4 t = ld4g(addr(tk >= 0 ? (uint32_t)(tk - tk0) : 0u, (uint32_t)(c4 < X4 ? c4 : X4 - 1)));
         v[pass][k] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
@@ -67,17 +67,49 @@ struct LnRegs {
   RowRegs<TM, NW, C / 4> x;
   float mu[RowRegs<TM, NW, C / 4>::NPASS], rs[RowRegs<TM, NW, C / 4>::NPASS];
   float4 gm[(C + 63) / 64];
-  __device__ __forceinline__ void load(const int* tok, const float* __restrict__ xsrc, const float* __restrict__ mean,
+  // xsrc / mean / rstd: already advanced to the tile's first token tk0
+  __device__ __forceinline__ void load(const int* tok, int tk0, const float* __restrict__ xsrc, const float* __restrict__ mean,
                                        const float* __restrict__ rstd, const float* __restrict__ gamma) {
     constexpr int RPP = 4 * NW, NPASS = RowRegs<TM, NW, C / 4>::NPASS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15, rg = lane >> 4;
-    x.load(tok, [&](int tk, int c4) { return xsrc + (int64_t)tk * C + 4 * c4; });
+    x.load(tok, tk0, [&](uint32_t rel, uint32_t c4) { return at32(xsrc, (rel * C + 4 * c4) * 4u); });
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
       const int row = pass * RPP + wave * 4 + rg;
       const int tk = row < TM ? tok[row] : -1;
-      const float m = mean[tk >= 0 ? tk : 0], r = rstd[tk >= 0 ? tk : 0];
+      const uint32_t rel = tk >= 0 ? (uint32_t)(tk - tk0) : 0u;
+      const float m = *at32(mean, rel * 4u), r = *at32(rstd, rel * 4u);
       mu[pass] = tk >= 0 ? m : 0.f; rs[pass] = tk >= 0 ? r : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < (C + 63) / 64; ++k) {
+      const int c4 = l16 + 16 * k;
+      const float4 t = ld4g(gamma + 4 * (c4 < C / 4 ? c4 : C / 4 - 1));
+      gm[k] = c4 < C / 4 ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  // Set the registers aside in LDS (`stash`: TM * C + 4 * 64 * NW floats, lane-private slots: no barrier needed) across a
+  // phase that needs the register file for itself, and take them back afterwards.
+  __device__ __forceinline__ void park(float* stash) const {
+    constexpr int NPASS = RowRegs<TM, NW, C / 4>::NPASS;
+    x.commit(stash, C);
+    float* mine = stash + TM * C + threadIdx.x;
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) { mine[(2 * pass) * 64 * NW] = mu[pass]; mine[(2 * pass + 1) * 64 * NW] = rs[pass]; }
+  }
+  __device__ __forceinline__ void unpark(const float* stash, const float* __restrict__ gamma) {
+    constexpr int RPP = 4 * NW, NPASS = RowRegs<TM, NW, C / 4>::NPASS, K = RowRegs<TM, NW, C / 4>::K;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15, rg = lane >> 4;
+    const float* mine = stash + TM * C + threadIdx.x;
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+      const int row = pass * RPP + wave * 4 + rg;
+      mu[pass] = mine[(2 * pass) * 64 * NW]; rs[pass] = mine[(2 * pass + 1) * 64 * NW];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const int c4 = l16 + 16 * k;
+        x.v[pass][k] = (row < TM && c4 < C / 4) ? *reinterpret_cast<const float4*>(stash + row * C + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
 #pragma unroll
     for (int k = 0; k < (C + 63) / 64; ++k) {
@@ -90,10 +122,10 @@ struct LnRegs {
 
 // LayerNorm backward of the rows held in LDS tile `D` (gradient w.r.t. the normalised output, pre-gain) against the preloaded
 // LayerNorm input rows `in`: out = addt + rs * (g d - mean(g d) - xh mean(g d xh)).  addt / out are LDS tile A (in place) and
-// HBM `hout`.  The per-tile column sums of d * xh and d go through `scratch` (LDS, >= 16 * 2C floats) to part[2C].
+// HBM `hout` / `hout2` (both advanced to the tile's first token tk0).  The per-tile column sums of d * xh and d go through `scratch` (LDS, >= 16 * 2C floats) to part[2C].
 template <int TJ, int VPL, int NW, int C>
 __device__ __forceinline__ void ln_bwd_tile(const float* D, float* A, int S, const LnRegs<16 * TJ, NW, C>& in, const int* tok,
-                                            float* __restrict__ hout, float* __restrict__ hout2, float* scratch,
+                                            int tk0, float* __restrict__ hout, float* __restrict__ hout2, float* scratch,
                                             float* __restrict__ part) {
   constexpr int TM = 16 * TJ, NTHR = 64 * NW, RPP = 4 * NW, NPASS = (TM + RPP - 1) / RPP, NPR = RPP < TM ? RPP : TM;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, rg = lane >> 4;
@@ -140,8 +172,9 @@ __device__ __forceinline__ void ln_bwd_tile(const float* D, float* A, int S, con
         if (tk < 0) o = make_float4(0.f, 0.f, 0.f, 0.f);
         *reinterpret_cast<float4*>(ap) = o;
         if (tk >= 0) {
-          st4g(hout + (int64_t)tk * C + 4 * c4, o);
-          if (hout2) st4g(hout2 + (int64_t)tk * C + 4 * c4, o);
+          const uint32_t off = ((uint32_t)(tk - tk0) * C + 4 * c4) * 4u;
+          st4g(at32(hout, off), o);
+          if (hout2) st4g(at32(hout2, off), o);
         }
       }
     }
@@ -171,6 +204,7 @@ __device__ __forceinline__ void ln_bwd_tile(const float* D, float* A, int S, con
 template <int C, int HD, int TJ, int NW, bool BF16>
 __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) block_bwd_kernel(const BlkBwdArgs a) {
   constexpr int TM = 16 * TJ, VPL = (C + 63) / 64, NSL = C / 16, NTHR = 64 * NW, RPP = 4 * NW, NPASS = (TM + RPP - 1) / RPP;
+  constexpr bool PARK = block_bwd_park_floats(TM, C, NTHR) != 0;
   extern __shared__ __attribute__((aligned(1024))) float lds[];
   constexpr int C4 = C >> 2, S = C + 4, SU = 3 * C + 4, Hd = 4 * C;
   float* ring = lds;
@@ -180,6 +214,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
   float* sc1 = U + TM * SU;
   float* sc2 = sc1 + TM;
   int* tok = reinterpret_cast<int*>(sc2 + TM);
+  float* stash = sc2 + 2 * TM;                          // (PARK only) LayerNorm-1 inputs across the attention backward
 
   int grp, tile;
   if (a.G == 2) { const int xcd = blockIdx.x & 7; grp = xcd >> 2; tile = (int)(blockIdx.x >> 3) * 4 + (xcd & 3); }
@@ -206,19 +241,32 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
   }
   lds_barrier();
 
+  // Row addresses are (scalar base advanced to the tile's first token) + (32-bit byte offset): one register per address and
+  // the `saddr` form of the global loads / stores.  tok[0] is the smallest token of the tile (windows are raster ordered).
+  const int tk0 = __builtin_amdgcn_readfirstlane(tok[0]);
+  const float* dy0 = g.dy + (int64_t)tk0 * C;
+  const float* h0 = g.h + (int64_t)tk0 * Hd;
+  const float* q0 = g.q + (int64_t)tk0 * C;
+  const float* kv0 = g.kv + (int64_t)tk0 * 2 * C;
+  float* dh0 = g.dh + (int64_t)tk0 * Hd;
+  float* dq0 = g.dq + (int64_t)tk0 * C;
+  float* dkv0 = g.dkv + (int64_t)tk0 * 2 * C;
+  float* dx0 = g.dx + (int64_t)tk0 * C;
+
   // ---- request every global input of the tile (see RowRegs)
   constexpr int HC = 2 * C;
   RowRegs<TM, NW, C4> r_dy;
   RowRegs<TM, NW, HC / 4> r_h[Hd / HC];
   RowRegs<TM, NW, 3 * C4> r_qkv;
   LnRegs<TM, NW, C> r_ln2, r_ln1;
-  r_dy.load(tok, [&](int tk, int c4) { return g.dy + (int64_t)tk * C + 4 * c4; });
+  r_dy.load(tok, tk0, [&](uint32_t rel, uint32_t c4) { return at32(dy0, (rel * C + 4 * c4) * 4u); });
 #pragma unroll
-  for (int ch = 0; ch < Hd / HC; ++ch) r_h[ch].load(tok, [&](int tk, int c4) { return g.h + (int64_t)tk * Hd + ch * HC + 4 * c4; });
-  r_ln2.load(tok, g.x1, g.stats + 2 * T, g.stats + 3 * T, g.ln2_g);
-  if (!g.dxs) r_ln1.load(tok, g.x, g.stats, g.stats + T, g.ln1_g);
-  r_qkv.load(tok, [&](int tk, int c4) {
-    return c4 < C4 ? g.q + (int64_t)tk * C + 4 * c4 : g.kv + (int64_t)tk * 2 * C + 4 * (c4 - C4);
+  for (int ch = 0; ch < Hd / HC; ++ch)
+    r_h[ch].load(tok, tk0, [&](uint32_t rel, uint32_t c4) { return at32(h0, (rel * Hd + ch * HC + 4 * c4) * 4u); });
+  r_ln2.load(tok, tk0, g.x1 + (int64_t)tk0 * C, g.stats + 2 * T + tk0, g.stats + 3 * T + tk0, g.ln2_g);
+  if (!g.dxs) r_ln1.load(tok, tk0, g.x + (int64_t)tk0 * C, g.stats + tk0, g.stats + T + tk0, g.ln1_g);
+  r_qkv.load(tok, tk0, [&](uint32_t rel, uint32_t c4) {
+    return c4 < C4 ? at32(q0, (rel * C + 4 * c4) * 4u) : at32(kv0, (rel * 2 * C + 4 * (c4 - C4)) * 4u);
   });
 
   // ---- dy rows -> A1
@@ -239,19 +287,22 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
       if (row >= TM) continue;
       const int tk = tok[row];
       if (tk < 0) continue;
+      const uint32_t rel = (uint32_t)(tk - tk0);
       for (int c4 = l16; c4 < X4; c4 += 16)
-        st4g(g.dh + (int64_t)tk * Hd + c0 + 4 * c4, *reinterpret_cast<const float4*>(U + row * SU + 4 * c4));
+        st4g(at32(dh0, (rel * Hd + c0 + 4 * c4) * 4u), *reinterpret_cast<const float4*>(U + row * SU + 4 * c4));
     }
     if (ch == 0) gemm_phase<TJ, NSL, 2, Hd, NW, BF16>(w1t + c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiStore{});
     else gemm_phase<TJ, NSL, 2, Hd, NW, BF16>(w1t + c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiAcc{});
   }
 
   // ---- dx1 = dy + LN2'(A2) -> A1 + HBM; LN2 gain / bias partials
-  ln_bwd_tile<TJ, VPL, NW, C>(A2, A1, S, r_ln2, tok, g.dx1, g.dx1_copy, U, g.ln2_part ? g.ln2_part + (int64_t)tile * 2 * C : nullptr);
+  ln_bwd_tile<TJ, VPL, NW, C>(A2, A1, S, r_ln2, tok, tk0, g.dx1 + (int64_t)tk0 * C, g.dx1_copy ? g.dx1_copy + (int64_t)tk0 * C : nullptr, U,
+                              g.ln2_part ? g.ln2_part + (int64_t)tile * 2 * C : nullptr);
 
   // ---- do = s1 dx1 Wp -> A2;  q | k | v rows -> U
   gemm_phase<TJ, NSL, 1, C, NW, BF16>(wpt, C, A1, nullptr, 0, nullptr, S, A2, S, EpiStoreScale{sc1});
   r_qkv.commit(U, SU);
+  if (PARK && !g.dxs) r_ln1.park(stash);
   lds_barrier();
 
   // ---- attention backward in place on U.  Thread = (window, row i, head); batches of whole windows.
@@ -354,18 +405,20 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
     if (row >= TM) continue;
     const int tk = tok[row];
     if (tk < 0) continue;
+    const uint32_t rel = (uint32_t)(tk - tk0);
     for (int c4 = l16; c4 < 3 * C4; c4 += 16) {
       const float4 v = *reinterpret_cast<const float4*>(U + row * SU + 4 * c4);
-      if (c4 < C4) st4g(g.dq + (int64_t)tk * C + 4 * c4, v);
-      else st4g(g.dkv + (int64_t)tk * 2 * C + 4 * (c4 - C4), v);
+      if (c4 < C4) st4g(at32(dq0, (rel * C + 4 * c4) * 4u), v);
+      else st4g(at32(dkv0, (rel * 2 * C + 4 * (c4 - C4)) * 4u), v);
     }
   }
 
   if (!g.dxs) {
     // ---- self: dxn = dq Wq + dkv Wkv -> A2;  dx = dx1 + LN1'(dxn) -> HBM; LN1 partials
+    if (PARK) r_ln1.unpark(stash, g.ln1_g);
     gemm_phase<TJ, NSL, 1, C, NW, BF16>(wqt, C, U, nullptr, 0, nullptr, SU, A2, S, EpiStore{});
     gemm_phase<TJ, NSL, 2, 2 * C, NW, BF16>(wkvt, C, U + C, nullptr, 0, nullptr, SU, A2, S, EpiAcc{});
-    ln_bwd_tile<TJ, VPL, NW, C>(A2, A1, S, r_ln1, tok, g.dx, nullptr, U, g.ln1_part ? g.ln1_part + (int64_t)tile * 2 * C : nullptr);
+    ln_bwd_tile<TJ, VPL, NW, C>(A2, A1, S, r_ln1, tok, tk0, dx0, nullptr, U, g.ln1_part ? g.ln1_part + (int64_t)tile * 2 * C : nullptr);
   } else {
     // ---- cross: the q path's pre-LayerNorm gradient and the sampled K/V source's gradient leave separately
     gemm_phase<TJ, NSL, 1, C, NW, BF16>(wqt, C, U, nullptr, 0, nullptr, SU, A2, S, EpiStore{});
@@ -375,7 +428,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
       if (row >= TM) continue;
       const int tk = tok[row];
       if (tk < 0) continue;
-      for (int c4 = l16; c4 < C4; c4 += 16) st4g(g.dx + (int64_t)tk * C + 4 * c4, *reinterpret_cast<const float4*>(A2 + row * S + 4 * c4));
+      for (int c4 = l16; c4 < C4; c4 += 16)
+        st4g(at32(dx0, ((uint32_t)(tk - tk0) * C + 4 * c4) * 4u), *reinterpret_cast<const float4*>(A2 + row * S + 4 * c4));
     }
     lds_barrier();
     gemm_phase<TJ, NSL, 2, 2 * C, NW, BF16>(wkvt, C, U + C, nullptr, 0, nullptr, SU, A2, S, EpiStore{});
@@ -385,7 +439,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
       if (row >= TM) continue;
       const int tk = tok[row];
       if (tk < 0) continue;
-      for (int c4 = l16; c4 < C4; c4 += 16) st4g(g.dxs + (int64_t)tk * C + 4 * c4, *reinterpret_cast<const float4*>(A2 + row * S + 4 * c4));
+      for (int c4 = l16; c4 < C4; c4 += 16)
+        st4g(at32(g.dxs + (int64_t)tk0 * C, ((uint32_t)(tk - tk0) * C + 4 * c4) * 4u), *reinterpret_cast<const float4*>(A2 + row * S + 4 * c4));
     }
   }
 }
@@ -393,7 +448,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
 template <int C, int HD, int TJ>
 static int launch_bwd(const BlkBwdArgs& a, int dtype, hipStream_t s) {
   constexpr int TM = 16 * TJ, NW = C >= 192 ? 8 : 4;
-  const size_t lds = block_lds_floats(TM, C, block_bwd_scratch_floats(TM, C / HD, 64 * NW), 0) * sizeof(float);
+  const size_t lds = block_lds_floats(TM, C, block_bwd_scratch_floats(TM, C / HD, 64 * NW), block_bwd_park_floats(TM, C, 64 * NW)) * sizeof(float);
   if (lds > 160 * 1024) return MICF_EUNSUPPORTED;
   const unsigned grid = a.G == 2 ? (unsigned)((a.tiles + 3) / 4 * 8) : (unsigned)a.tiles;
   static std::once_flag once;
@@ -434,6 +489,9 @@ extern "C" int micf_block_bwd(const micf_block_bwd_group* groups, int ngroups, i
   a.tiles = (a.geo.nwin + TM / 8 - 1) / (TM / 8);
   hipStream_t s = (hipStream_t)stream;
   const int hd = C / heads, tj = TM / 16;
+  // rows are addressed relative to the tile's first token with 32-bit byte offsets: a tile of TM / 8 consecutive windows spans
+  // fewer than 2 H W (TM / 8 + 1) tokens
+  if ((int64_t)2 * H * W * (TM / 8 + 1) * hidden * (int64_t)sizeof(float) >= (int64_t)1 << 32) return MICF_EUNSUPPORTED;
   if (block_wide_tile_tokens(C, hd)) return block_bwd_wide(groups, ngroups, B, D, H, W, C, heads, scale, dtype, s);
 #define MICF_BB(C_, HD_, TJ_) if (C == C_ && hd == HD_ && tj == TJ_) return launch_bwd<C_, HD_, TJ_>(a, dtype, s)
   MICF_BB(48, 16, 2); MICF_BB(48, 16, 1); MICF_BB(48, 16, 4); MICF_BB(96, 16, 1); MICF_BB(96, 16, 2); MICF_BB(192, 16, 1);

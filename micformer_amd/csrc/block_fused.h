@@ -285,6 +285,9 @@ inline TileGeo make_tile_geo(int B, int D, int H, int W) {
 // floats of the attention backward's P / dS exchange: 16 per thread that takes part (one per attention row and head, whole
 // windows per batch)
 constexpr int block_bwd_scratch_floats(int TM, int heads, int nthr) { return (TM * heads < nthr ? TM * heads : nthr) * 16; }
+// C = 48: the attention backward needs the whole register file (three workgroups per CU), so the LayerNorm-1 inputs requested
+// at the top of the kernel wait in LDS meanwhile: [TM][C] rows + mean / rstd slots per thread
+constexpr int block_bwd_park_floats(int TM, int C, int nthr) { return C <= 48 ? TM * C + 2 * ((TM + nthr / 16 - 1) / (nthr / 16)) * nthr : 0; }
 // LDS floats of a fused block kernel: scratch + A1, A2 [TM][C+4] + U [TM][3C+4] + row scales / token ids + `params` (the
 // forward stages its 9C + hidden bias / LayerNorm vectors; the backward keeps none)
 inline size_t block_lds_floats(int TM, int C, int scratch, int params) {
@@ -304,6 +307,12 @@ int block_fwd_wide(const micf_block_fwd_group* groups, int ngroups, int B, int D
 int block_bwd_wide(const micf_block_bwd_group* groups, int ngroups, int B, int D, int H, int W, int C, int heads, float scale, int dtype,
                    hipStream_t s);
 __device__ __forceinline__ float4 ld4g(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// (wave-uniform base) + (32-bit byte offset): the address costs one VGPR and the access takes the scalar-base form
+template <class T>
+__device__ __forceinline__ T* at32(T* base, uint32_t byte_off) {
+  using B = typename std::conditional<std::is_const<T>::value, const char, char>::type;
+  return reinterpret_cast<T*>(reinterpret_cast<B*>(base) + byte_off);
+}
 // Outputs are written once and read by LATER kernels only: non-temporal stores keep them from evicting the block's weights
 // (0.9 MB per XCD at C = 192, re-read by every workgroup) out of the 4 MB L2 while the kernel runs.
 __device__ __forceinline__ void st4g(float* p, const float4& v) {

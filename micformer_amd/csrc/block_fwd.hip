@@ -322,7 +322,7 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
 
 template <int C, int HD, int TJ>
 static int launch_fwd(const BlkFwdArgs& a, int dtype, hipStream_t s) {
-  constexpr int TM = 16 * TJ, NW = C >= 192 ? 16 : 4;
+  constexpr int TM = 16 * TJ, NW = C >= 192 ? (HD <= 16 ? 16 : 8) : 4;   // (head_dim 32 attention rows need > 128 registers: 8 waves there)
   const size_t lds = block_lds_floats(TM, C, 0, 9 * C + 4 * C) * sizeof(float);
   if (lds > 160 * 1024) return MICF_EUNSUPPORTED;
   const unsigned grid = a.G == 2 ? (unsigned)((a.tiles + 3) / 4 * 8) : (unsigned)a.tiles;

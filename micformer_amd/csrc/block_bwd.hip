@@ -305,22 +305,26 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
   if (PARK && !g.dxs) r_ln1.park(stash);
   lds_barrier();
 
-  // ---- attention backward in place on U.  Thread = (window, row i, head); batches of whole windows.
+  // ---- attention backward in place on U.  Thread = (window, row i, head, half of the head's channels); batches of whole
+  // windows.  Where a tile has fewer (row, head) pairs than half the workgroup (C = 48: 96 of 256 threads), 2 or 4 adjacent
+  // lanes share a pair: each owns HD / 2 or HD / 4 channels and the partial dot products meet in cross-lane adds.
   {
-    constexpr int heads = C / HD, per = 8 * heads, wpb = NTHR / per;
-    float* PS = ring;                                   // [256][16]: P row | dS row of every thread of the batch
+    constexpr int heads = C / HD, SP = (TM * heads * 4 <= NTHR && HD >= 16) ? 4 : (TM * heads * 2 <= NTHR) ? 2 : 1, HP = HD / SP, per = 8 * heads * SP, wpb = NTHR / per;
+    float* PS = ring;                                   // [(row, head) pair][16]: P row | dS row
     for (int w0 = 0; w0 < TM / 8; w0 += wpb) {
       const int wl = tid / per, rem = tid - wl * per;
       const bool active = wl < wpb && (w0 + wl) < TM / 8;
-      const int i = rem / heads, hh = rem - i * heads;
-      const int row = (w0 + wl) * 8 + i, r0 = row - i, hoff = hh * HD;
-      float dq[HD], dk[HD], dv[HD];
+      const int sub = rem & (SP - 1), pr = rem / SP;    // pr = i * heads + hh
+      const int i = pr / heads, hh = pr - i * heads;
+      const int row = (w0 + wl) * 8 + i, r0 = row - i, hoff = hh * HD + sub * HP;
+      const int pair = tid / SP;                        // = (wl * 8 + i) * heads + hh
+      float dq[HP], dk[HP], dv[HP];
       if (active) {
-        float qr[HD], dor[HD];
+        float qr[HP], dor[HP];
         const float* qp = U + row * SU + hoff;
         const float* dop = A2 + row * S + hoff;
 #pragma unroll
-        for (int d = 0; d < HD; d += 4) {
+        for (int d = 0; d < HP; d += 4) {
           const float4 t = *reinterpret_cast<const float4*>(qp + d);
           qr[d] = t.x * a.scale; qr[d + 1] = t.y * a.scale; qr[d + 2] = t.z * a.scale; qr[d + 3] = t.w * a.scale;
           const float4 u = *reinterpret_cast<const float4*>(dop + d);
@@ -333,12 +337,14 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
           const float* vp = U + (r0 + j) * SU + 2 * C + hoff;
           float sacc = 0.f, dacc = 0.f;
 #pragma unroll
-          for (int d = 0; d < HD; d += 4) {
+          for (int d = 0; d < HP; d += 4) {
             const float4 t = *reinterpret_cast<const float4*>(kp + d);
             sacc += qr[d] * t.x; sacc += qr[d + 1] * t.y; sacc += qr[d + 2] * t.z; sacc += qr[d + 3] * t.w;
             const float4 u = *reinterpret_cast<const float4*>(vp + d);
             dacc += dor[d] * u.x; dacc += dor[d + 1] * u.y; dacc += dor[d + 2] * u.z; dacc += dor[d + 3] * u.w;
           }
+          if (SP >= 2) { sacc += __shfl_xor(sacc, 1, 64); dacc += __shfl_xor(dacc, 1, 64); }
+          if (SP == 4) { sacc += __shfl_xor(sacc, 2, 64); dacc += __shfl_xor(dacc, 2, 64); }
           p[j] = sacc; dp[j] = dacc;
           mx = fmaxf(mx, sacc);
         }
@@ -350,16 +356,18 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
 #pragma unroll
         for (int j = 0; j < 8; ++j) { p[j] *= inv; dot += p[j] * dp[j]; }
 #pragma unroll
-        for (int d = 0; d < HD; ++d) dq[d] = 0.f;
+        for (int d = 0; d < HP; ++d) dq[d] = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float ds = p[j] * (dp[j] - dot);
-          PS[tid * 16 + j] = p[j];
-          PS[tid * 16 + 8 + j] = ds;
+          if (j / (8 / SP) == sub) {                      // (the lanes of a pair hold identical rows: each stores its share)
+            PS[pair * 16 + j] = p[j];
+            PS[pair * 16 + 8 + j] = ds;
+          }
           const float* kp = U + (r0 + j) * SU + C + hoff;
           const float dss = ds * a.scale;
 #pragma unroll
-          for (int d = 0; d < HD; d += 4) {
+          for (int d = 0; d < HP; d += 4) {
             const float4 t = *reinterpret_cast<const float4*>(kp + d);
             dq[d] += dss * t.x; dq[d + 1] += dss * t.y; dq[d + 2] += dss * t.z; dq[d + 3] += dss * t.w;
           }
@@ -368,8 +376,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
       lds_barrier();
       if (active) {                                     // now as key / value row j = i: gather column j of P and dS from the mates
 #pragma unroll
-        for (int d = 0; d < HD; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
-        const int base = tid - i * heads;               // thread of (window, row 0, head hh)
+        for (int d = 0; d < HP; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+        const int base = pair - i * heads;              // pair of (window, row 0, head hh)
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
           const float pm = PS[(base + m * heads) * 16 + i];
@@ -377,7 +385,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
           const float* qp = U + (r0 + m) * SU + hoff;
           const float* dop = A2 + (r0 + m) * S + hoff;
 #pragma unroll
-          for (int d = 0; d < HD; d += 4) {
+          for (int d = 0; d < HP; d += 4) {
             const float4 t = *reinterpret_cast<const float4*>(qp + d);
             dk[d] += dsm * t.x; dk[d + 1] += dsm * t.y; dk[d + 2] += dsm * t.z; dk[d + 3] += dsm * t.w;
             const float4 u = *reinterpret_cast<const float4*>(dop + d);
@@ -388,7 +396,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
       lds_barrier();                                  // every read of this batch's q / k / v rows is done: overwrite in place
       if (active) {
 #pragma unroll
-        for (int d = 0; d < HD; d += 4) {
+        for (int d = 0; d < HP; d += 4) {
           *reinterpret_cast<float4*>(U + row * SU + hoff + d) = make_float4(dq[d], dq[d + 1], dq[d + 2], dq[d + 3]);
           *reinterpret_cast<float4*>(U + row * SU + C + hoff + d) = make_float4(dk[d], dk[d + 1], dk[d + 2], dk[d + 3]);
           *reinterpret_cast<float4*>(U + row * SU + 2 * C + hoff + d) = make_float4(dv[d], dv[d + 1], dv[d + 2], dv[d + 3]);

@@ -166,16 +166,19 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
     }
   }
 
-  // ---- attention per (row, head): the 8x8 score row lives in registers; o -> A1 (xn is no longer needed) + HBM
+  // ---- attention per (row, head): the 8x8 score row lives in registers; o -> A1 (xn is no longer needed) + HBM.  Where a tile
+  // has fewer (row, head) pairs than half the workgroup, 2 or 4 adjacent lanes share a pair (HD / 2 or HD / 4 channels each; the
+  // partial scores meet in cross-lane adds).
   if (!(a.debug & 2)) {
-    constexpr int heads = C / HD;
-    for (int item = tid; item < TM * heads; item += NTHR) {
-      const int row = item / heads, hh = item - row * heads;
-      const int r0 = row & ~7, hoff = hh * HD;
-      float qr[HD];
+    constexpr int heads = C / HD, SP = (TM * heads * 4 <= NTHR && HD >= 16) ? 4 : (TM * heads * 2 <= NTHR) ? 2 : 1, HP = HD / SP;
+    for (int item = tid; item < TM * heads * SP; item += NTHR) {
+      const int sub = item & (SP - 1), pr = item / SP;
+      const int row = pr / heads, hh = pr - row * heads;
+      const int r0 = row & ~7, hoff = hh * HD + sub * HP;
+      float qr[HP];
       const float* qp = U + row * SU + hoff;
 #pragma unroll
-      for (int d = 0; d < HD; d += 4) {
+      for (int d = 0; d < HP; d += 4) {
         const float4 t = *reinterpret_cast<const float4*>(qp + d);
         qr[d] = t.x * a.scale; qr[d + 1] = t.y * a.scale; qr[d + 2] = t.z * a.scale; qr[d + 3] = t.w * a.scale;
       }
@@ -185,10 +188,12 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
         const float* kp = U + (r0 + j) * SU + C + hoff;
         float acc = 0.f;
 #pragma unroll
-        for (int d = 0; d < HD; d += 4) {
+        for (int d = 0; d < HP; d += 4) {
           const float4 t = *reinterpret_cast<const float4*>(kp + d);
           acc += qr[d] * t.x; acc += qr[d + 1] * t.y; acc += qr[d + 2] * t.z; acc += qr[d + 3] * t.w;
         }
+        if (SP >= 2) acc += __shfl_xor(acc, 1, 64);
+        if (SP == 4) acc += __shfl_xor(acc, 2, 64);
         sj[j] = acc;
         mx = fmaxf(mx, acc);
       }
@@ -196,22 +201,22 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
 #pragma unroll
       for (int j = 0; j < 8; ++j) { sj[j] = expf(sj[j] - mx); den += sj[j]; }
       const float inv = 1.0f / den;
-      float oa[HD];
+      float oa[HP];
 #pragma unroll
-      for (int d = 0; d < HD; ++d) oa[d] = 0.f;
+      for (int d = 0; d < HP; ++d) oa[d] = 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float* vp = U + (r0 + j) * SU + 2 * C + hoff;
         const float pj = sj[j] * inv;
 #pragma unroll
-        for (int d = 0; d < HD; d += 4) {
+        for (int d = 0; d < HP; d += 4) {
           const float4 t = *reinterpret_cast<const float4*>(vp + d);
           oa[d] += pj * t.x; oa[d + 1] += pj * t.y; oa[d + 2] += pj * t.z; oa[d + 3] += pj * t.w;
         }
       }
       const int tk = tok[row];
 #pragma unroll
-      for (int d = 0; d < HD; d += 4) {
+      for (int d = 0; d < HP; d += 4) {
         const float4 t = make_float4(oa[d], oa[d + 1], oa[d + 2], oa[d + 3]);
         *reinterpret_cast<float4*>(A1 + row * S + hoff + d) = t;
         if (tk >= 0 && save) st4g(g.o + (int64_t)tk * C + hoff + d, t);

@@ -60,12 +60,16 @@ template <int K, bool BF16> __device__ __forceinline__ void pack(const float4 (&
     for (int i = 0; i < K / 16; ++i) f.v[i] = r[i];
   }
 }
-// weight tile: row = W + (n0 + li) * LD + k0 (this lane's output feature), K columns from there
-template <int K, bool BF16> __device__ __forceinline__ void load_w(const typename WSel<BF16>::T* __restrict__ row, int lr, Frag<K, BF16>& f) {
+// weight tile: rows n .. n + 15 (n a multiple of 16; this lane's output feature is n + li) of W [*, LD], K columns from k0.
+// bf16 shadow weights are K16-blocked (block_fused.h): a wave's load instruction covers 1 KB of consecutive addresses.
+template <int K, bool BF16> __device__ __forceinline__ void load_w(const typename WSel<BF16>::T* __restrict__ W, int n, int LD, int k0,
+                                                                   int li, int lr, Frag<K, BF16>& f) {
   if constexpr (BF16) {
+    const uint16_t* p = W + (int64_t)n * LD + k0 * 16 + li * 16 + 8 * (lr & 1);
 #pragma unroll
-    for (int j = 0; j < K / 32; ++j) f.v[j] = *reinterpret_cast<const u32x4*>(row + 32 * j + 8 * lr);
+    for (int j = 0; j < K / 32; ++j) f.v[j] = *reinterpret_cast<const u32x4*>(p + (2 * j + (lr >> 1)) * 256);
   } else {
+    const float* row = W + (int64_t)(n + li) * LD + k0;
 #pragma unroll
     for (int i = 0; i < K / 16; ++i) f.v[i] = *reinterpret_cast<const float4*>(row + 16 * i + 4 * lr);
   }
@@ -205,12 +209,12 @@ __global__ void __launch_bounds__(256) f1_kernel(const FwdArgs a) {
   const Row row = tile_row(a.geo, tile, li);
   const WT* wq = static_cast<const WT*>(g.wq), *wkv = static_cast<const WT*>(g.wkv);
 
-  auto wrow = [&](int t) {                                            // weight row of tile t (q: 0..HT-1, k, v) for this lane
-    const int part = t / HT, n = (part == 2 ? C : 0) + head * HD + 16 * (t % HT) + li;
-    return (part == 0 ? wq : wkv) + (int64_t)n * C;
+  auto load_tile = [&](int t, Frag<C, BF16>& f) {                     // weight rows of tile t (q: 0..HT-1, k, v)
+    const int part = t / HT, n = (part == 2 ? C : 0) + head * HD + 16 * (t % HT);
+    load_w<C, BF16>(part == 0 ? wq : wkv, n, C, 0, li, lr, f);
   };
   Frag<C, BF16> fa[2];
-  load_w<C, BF16>(wrow(0), lr, fa[0]);                                // in flight during the LayerNorm
+  load_tile(0, fa[0]);                                                // in flight during the LayerNorm
 
   Frag<C, BF16> bq, bkv;
   {
@@ -235,7 +239,7 @@ __global__ void __launch_bounds__(256) f1_kernel(const FwdArgs a) {
   }
 #pragma unroll
   for (int t = 0; t < NTL; ++t) {
-    if (t + 1 < NTL) load_w<C, BF16>(wrow(t + 1), lr, fa[(t + 1) & 1]);
+    if (t + 1 < NTL) load_tile(t + 1, fa[(t + 1) & 1]);
     const int part = t / HT, hh = t % HT;
     const int n = (part == 2 ? C : 0) + head * HD + 16 * hh + 4 * lr;
     float4 v = mma<C, BF16>(fa[t & 1], part == 0 ? bq : bkv);
@@ -294,7 +298,7 @@ __global__ void __launch_bounds__(256) f2_kernel(const FwdArgs a) {
   const micf_block_fwd_group& g = a.g[grp];
   const Row row = tile_row(a.geo, tile, li);
   Frag<C, BF16> fa, b;
-  load_w<C, BF16>(static_cast<const WT*>(g.wp) + (int64_t)(n0 + li) * C, lr, fa);
+  load_w<C, BF16>(static_cast<const WT*>(g.wp), n0, C, 0, li, lr, fa);
   {
     float4 raw[NF];
     load_raw<C, BF16>(g.o + (int64_t)row.tk * C, lr, row.ok, raw);
@@ -325,7 +329,7 @@ __global__ void __launch_bounds__(256) f3_kernel(const FwdArgs a) {
   const Row row = tile_row(a.geo, tile, li);
   const WT* w1 = static_cast<const WT*>(g.w1);
   Frag<C, BF16> fa[2], b;
-  load_w<C, BF16>(w1 + (int64_t)(n0 + li) * C, lr, fa[0]);
+  load_w<C, BF16>(w1, n0, C, 0, li, lr, fa[0]);
   {
     float4 raw[NF];
     load_raw<C, BF16>(g.x1 + (int64_t)row.tk * C, lr, row.ok, raw);
@@ -340,7 +344,7 @@ __global__ void __launch_bounds__(256) f3_kernel(const FwdArgs a) {
   }
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    if (t + 1 < NT) load_w<C, BF16>(w1 + (int64_t)(n0 + 16 * (t + 1) + li) * C, lr, fa[(t + 1) & 1]);
+    if (t + 1 < NT) load_w<C, BF16>(w1, n0 + 16 * (t + 1), C, 0, li, lr, fa[(t + 1) & 1]);
     const float4 v = mma<C, BF16>(fa[t & 1], b);
     if (row.ok) {
       const int n = n0 + 16 * t + 4 * lr;
@@ -365,7 +369,7 @@ __global__ void __launch_bounds__(256) f4_kernel(const FwdArgs a) {
   const micf_block_fwd_group& g = a.g[grp];
   const Row row = tile_row(a.geo, tile, li);
   Frag<C, BF16> fa, b;
-  load_w<C, BF16>(static_cast<const WT*>(g.w2) + (int64_t)(n0 + li) * Hd + wave * C, lr, fa);
+  load_w<C, BF16>(static_cast<const WT*>(g.w2), n0, Hd, wave * C, li, lr, fa);
   {
     float4 raw[NF];
     load_raw<C, BF16>(g.g + (int64_t)row.tk * Hd + wave * C, lr, row.ok, raw);
@@ -400,7 +404,7 @@ __global__ void __launch_bounds__(256) b1_kernel(const BwdArgs a) {
   const Row row = tile_row(a.geo, tile, li);
   const WT* w2t = static_cast<const WT*>(g.w2t);
   Frag<C, BF16> fa[2], b;
-  load_w<C, BF16>(w2t + (int64_t)(n0 + li) * C, lr, fa[0]);
+  load_w<C, BF16>(w2t, n0, C, 0, li, lr, fa[0]);
   {
     float4 raw[NF];
     load_raw<C, BF16>(g.dy + (int64_t)row.tk * C, lr, row.ok, raw);
@@ -409,7 +413,7 @@ __global__ void __launch_bounds__(256) b1_kernel(const BwdArgs a) {
   const float s2 = row_scale(a.geo, g.s2, row);
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    if (t + 1 < NT) load_w<C, BF16>(w2t + (int64_t)(n0 + 16 * (t + 1) + li) * C, lr, fa[(t + 1) & 1]);
+    if (t + 1 < NT) load_w<C, BF16>(w2t, n0 + 16 * (t + 1), C, 0, li, lr, fa[(t + 1) & 1]);
     const float4 v = mma<C, BF16>(fa[t & 1], b);
     if (row.ok) {
       const int n = n0 + 16 * t + 4 * lr;
@@ -433,7 +437,7 @@ __global__ void __launch_bounds__(256) b2_kernel(const BwdArgs a) {
   const micf_block_bwd_group& g = a.g[grp];
   const Row row = tile_row(a.geo, tile, li);
   Frag<C, BF16> fa, b;
-  load_w<C, BF16>(static_cast<const WT*>(g.w1t) + (int64_t)(n0 + li) * Hd + wave * C, lr, fa);
+  load_w<C, BF16>(static_cast<const WT*>(g.w1t), n0, Hd, wave * C, li, lr, fa);
   {
     float4 raw[NF];
     load_raw<C, BF16>(g.dh + (int64_t)row.tk * Hd + wave * C, lr, row.ok, raw);
@@ -466,7 +470,7 @@ __global__ void __launch_bounds__(256) b3_kernel(const BwdArgs a) {
   const Row row = tile_row(a.geo, tile, li);
   const WT* wpt = static_cast<const WT*>(g.wpt);
   Frag<C, BF16> fa[2], b;
-  load_w<C, BF16>(wpt + (int64_t)(head * HD + li) * C, lr, fa[0]);
+  load_w<C, BF16>(wpt, head * HD, C, 0, li, lr, fa[0]);
   // the head's q | k | v rows -> LDS (also in flight during the LayerNorm backward)
 #pragma unroll
   for (int hh = 0; hh < HT; ++hh) {
@@ -499,7 +503,7 @@ __global__ void __launch_bounds__(256) b3_kernel(const BwdArgs a) {
   const float s1 = row_scale(a.geo, g.s1, row);
 #pragma unroll
   for (int hh = 0; hh < HT; ++hh) {
-    if (hh + 1 < HT) load_w<C, BF16>(wpt + (int64_t)(head * HD + 16 * (hh + 1) + li) * C, lr, fa[(hh + 1) & 1]);
+    if (hh + 1 < HT) load_w<C, BF16>(wpt, head * HD + 16 * (hh + 1), C, 0, li, lr, fa[(hh + 1) & 1]);
     const float4 v = mma<C, BF16>(fa[hh & 1], b);
     *reinterpret_cast<float4*>(&sm[wave][3][li][16 * hh + 4 * lr]) = make_float4(s1 * v.x, s1 * v.y, s1 * v.z, s1 * v.w);
   }
@@ -574,8 +578,8 @@ __global__ void __launch_bounds__(192) b4_kernel(const BwdArgs a) {
   const micf_block_bwd_group& g = a.g[grp];
   const Row row = tile_row(a.geo, tile, li);
   Frag<C, BF16> fa, b;
-  if (wave == 0) load_w<C, BF16>(static_cast<const WT*>(g.wqt) + (int64_t)(n0 + li) * C, lr, fa);
-  else load_w<C, BF16>(static_cast<const WT*>(g.wkvt) + (int64_t)(n0 + li) * 2 * C + (wave - 1) * C, lr, fa);
+  if (wave == 0) load_w<C, BF16>(static_cast<const WT*>(g.wqt), n0, C, 0, li, lr, fa);
+  else load_w<C, BF16>(static_cast<const WT*>(g.wkvt), n0, 2 * C, (wave - 1) * C, li, lr, fa);
   {
     float4 raw[NF];
     if (wave == 0) load_raw<C, BF16>(g.dq + (int64_t)row.tk * C, lr, row.ok, raw);

@@ -236,7 +236,11 @@ __global__ void __launch_bounds__(256) weight_prep_kernel(const PrepArgs a) {
   while (k < a.n - 1 && w >= a.end[k]) ++k;
   const int local = w - (k ? a.end[k - 1] : 0);
   const int rows = a.rows[k], cols = a.cols[k];
-  const bool bf = a.bf16[k] != 0;
+  const bool bf = a.bf16[k] != 0, blocked = a.bf16[k] == 2;
+  // K16-blocked destination index of element (r, c) of an [R, Cn] matrix (4 consecutive c stay consecutive)
+  auto at = [&](int r, int c, int Cn) {
+    return blocked ? ((int64_t)(r >> 4) * (Cn >> 4) + (c >> 4)) * 256 + (r & 15) * 16 + (c & 15) : (int64_t)r * Cn + c;
+  };
   const int tc = (cols + 63) >> 6;
   const int r0 = (local / tc) * 64, c0 = (local % tc) * 64;
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;       // 16 float4 columns x 16 rows per pass
@@ -253,7 +257,7 @@ __global__ void __launch_bounds__(256) weight_prep_kernel(const PrepArgs a) {
       for (int i = 0; i < valid; ++i) e[i] = src[(int64_t)r * cols + c + i];
       v = make_float4(e[0], e[1], e[2], e[3]);
     }
-    if (a.dst[k] && valid > 0) prep_store4(a.dst[k], (int64_t)r * cols + c, bf, valid == 4 && vc, valid, v);
+    if (a.dst[k] && valid > 0) prep_store4(a.dst[k], at(r, c, cols), bf, valid == 4 && vc, valid, v);
     t[ty + j][4 * tx] = v.x; t[ty + j][4 * tx + 1] = v.y; t[ty + j][4 * tx + 2] = v.z; t[ty + j][4 * tx + 3] = v.w;
   }
   if (!a.dst_t[k]) return;
@@ -264,7 +268,7 @@ __global__ void __launch_bounds__(256) weight_prep_kernel(const PrepArgs a) {
     const int valid = c < cols ? (rows - r < 4 ? rows - r : 4) : 0;
     if (valid <= 0) continue;
     const float4 v = make_float4(t[4 * tx][ty + j], t[4 * tx + 1][ty + j], t[4 * tx + 2][ty + j], t[4 * tx + 3][ty + j]);
-    prep_store4(a.dst_t[k], (int64_t)c * rows + r, bf, valid == 4 && vr, valid, v);
+    prep_store4(a.dst_t[k], at(c, r, rows), bf, valid == 4 && vr, valid, v);
   }
 }
 }  // namespace micf
@@ -279,6 +283,7 @@ extern "C" int micf_weight_prep_grouped(const micf_weight_prep_item* items, int 
     for (int k = 0; k < cnt; ++k) {
       const micf_weight_prep_item& it = items[first + k];
       const int align = it.bf16 ? 7 : 15;
+      if (it.bf16 < 0 || it.bf16 > 2 || (it.bf16 == 2 && ((it.rows | it.cols) & 15))) return MICF_EINVAL;
       if (!it.src || (!it.dst && !it.dst_t) || it.rows <= 0 || it.cols <= 0 || (reinterpret_cast<uintptr_t>(it.src) & 15) ||
           (reinterpret_cast<uintptr_t>(it.dst) & align) || (reinterpret_cast<uintptr_t>(it.dst_t) & align))
         return MICF_EINVAL;

@@ -109,9 +109,9 @@ class TrainEngine:
                     self._early_cut, self._early_layer = cut, stages[len(stages) - 1]
         # What the fused kernels stream instead of the parameters themselves, all refreshed once per step (the weights only
         # change in Adam):
-        #   * bf16 mode, forward: a bf16 mirror of the WHOLE flat parameter buffer, written by the Adam kernel in the pass that
-        #     updates the parameters (no launch; `_sync_mirror` re-derives it whenever torch code wrote the parameters);
-        #   * backward: transposed copies of the block linears' weights (W^T fp32, or bf16 in bf16 mode) -- one grouped launch
+        #   * bf16 mode, forward: bf16 copies of the block linears' weights in the K16-blocked order the kernels' matrix-core
+        #     fragments read (one grouped launch on a side stream in front of the forward, joined at the first stage);
+        #   * backward: transposed copies of the same weights (W^T fp32 row-major, or bf16 K16-blocked) -- one grouped launch
         #     on a side stream, issued when the forward reaches the small stages, next to the zero fill of the gradient buffer;
         #   * the re-laid-out offset-conv weights of the direct conv kernels: one small grouped launch in front of the forward.
         pick = lambda suffixes: [(n, p) for n, p in zip(names, params) if n.endswith(suffixes)]
@@ -120,36 +120,25 @@ class TrainEngine:
         self._conv_w = [(n, p) for n, p in pick(("conv_offset.0.weight",)) if p.dim() == 5 and p.shape[0] <= 16]
         self._offset_of = {id(p): o for p, o in zip(params, offs)}
         self._prep_plans, self._shadow_bufs = {}, {}
-        self.flat_p16, self._p_version = None, None
         self._prep_stream = torch.cuda.Stream(device=dev)
 
-    def _sync_mirror(self):
-        """bf16 mirror <- parameters (round-to-nearest-even, the rounding of the bf16 kernels); needed after anything but the
-        Adam kernel wrote the parameters: construction, load_state_dict, the restore after the capture warm-up."""
-        if self.flat_p16 is not None:
-            with torch.no_grad():
-                self.flat_p16.copy_(self.flat_p)
-        self._p_version = self.flat_p._version
-
-    def _mirror(self):
-        """The Adam kernel's mirror target in the current arithmetic mode (None in fp32 mode)."""
-        return self.flat_p16 if ops.compute_dtype() == "bf16" else None
-
     def _weight_prep(self):
-        """(backward, conv) launch plans of the current arithmetic mode; creates the shadow buffers on first use."""
+        """(forward | None, backward, conv) launch plans of the current arithmetic mode; creates the shadow buffers on first use.
+        The copies are rewritten by every step, so nothing else has to track who wrote the parameters."""
         mode = ops.compute_dtype()
         plans = self._prep_plans.get(mode)
         if plans is None:
             ws = [p for _, p in self._shadow_w]
-            spec = ops.shadow_spec(False)
-            if spec is not None and self.flat_p16 is None:            # bf16 forward: views of the mirror, same offsets as flat_p
-                self.flat_p16 = torch.empty(self.flat_p.numel(), dtype=spec[2], device=self.flat_p.device)
-                for p in ws:
-                    o = self._offset_of[id(p)]
-                    setattr(p, spec[0], self.flat_p16[o:o + p.numel()].view(p.shape))
-                self._p_version = None                                # -> synchronised by the caller
-            attr, transposed, dtype = ops.shadow_spec(True)
             offs, total = flatten_views(ws, align=8)
+            fwd, spec = None, ops.shadow_spec(False)
+            if spec is not None:                                      # bf16 forward
+                buf = self._shadow_bufs[spec[0]] = torch.empty(max(total, 8), dtype=spec[2], device=self.flat_p.device)
+                ftrip = []
+                for p, o in zip(ws, offs):
+                    setattr(p, spec[0], buf[o:o + p.numel()].view(p.shape))
+                    ftrip.append((p.data, getattr(p, spec[0]), None))
+                fwd = ops.WeightPrepPlan(ftrip, blocked=True)
+            attr, transposed, dtype = ops.shadow_spec(True)
             buf = self._shadow_bufs[attr] = torch.empty(max(total, 8), dtype=dtype, device=self.flat_p.device)
             trip = []
             for p, o in zip(ws, offs):
@@ -161,9 +150,7 @@ class TrainEngine:
                     p._micf_c3f, p._micf_c3b = ops.conv3_prepared_like(p)
                     ctrip.append((p.data, p._micf_c3f, p._micf_c3b))
                 self._shadow_bufs["conv"] = ops.Conv3PrepPlan(ctrip)
-            plans = self._prep_plans[mode] = (ops.WeightPrepPlan(trip), self._shadow_bufs["conv"])
-        if self._mirror() is not None and self._p_version != self.flat_p._version:
-            self._sync_mirror()
+            plans = self._prep_plans[mode] = (fwd, ops.WeightPrepPlan(trip, blocked=True), self._shadow_bufs["conv"])
         return plans
 
     # ------------------------------------------------------------------ one optimisation step
@@ -175,22 +162,29 @@ class TrainEngine:
 
         @contextlib.contextmanager
         def scope():
-            prev = (_ms.PARALLEL_MODALITIES, _fn.DEFER_WGRAD, _fn.FLUSH_POINTS, _fn.DEFER_CALLS)
+            prev = (_ms.PARALLEL_MODALITIES, _fn.DEFER_WGRAD, _fn.FLUSH_POINTS, _fn.DEFER_CALLS, ops.ENGINE_SHADOWS)
             _ms.PARALLEL_MODALITIES, _fn.DEFER_WGRAD = self.parallel_modalities, self.defer_wgrad
             _fn.FLUSH_POINTS = self.defer_wgrad and self.flush_points and not self.split_step
             _fn.DEFER_CALLS = self.defer_wgrad
+            ops.ENGINE_SHADOWS = True                               # the parameters' shadow copies are current in this scope only
             try:
                 yield
             finally:
-                _ms.PARALLEL_MODALITIES, _fn.DEFER_WGRAD, _fn.FLUSH_POINTS, _fn.DEFER_CALLS = prev
+                _ms.PARALLEL_MODALITIES, _fn.DEFER_WGRAD, _fn.FLUSH_POINTS, _fn.DEFER_CALLS, ops.ENGINE_SHADOWS = prev
         return scope()
 
     def _fwd_bwd(self, x, target, flush=True):
         from . import functional as _fn
         _fn.drop_deferred()                                         # nothing left over from a backward that raised
         with self._scoped_flags():
-            bwd, conv = self._weight_prep()
+            fwd, bwd, conv = self._weight_prep()
             main, side = torch.cuda.current_stream(), self._prep_stream
+            _fn.clear_entry_hooks()
+            if fwd is not None:                                     # bf16 block weights, next to the patch embedding
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    fwd.launch()
+                _fn.park_entry_hook(lambda: main.wait_stream(side), at=1)
             conv.launch()                                           # offset-conv weight layouts (one small launch)
 
             def backward_prep():                                    # under the latency-bound small stages of the forward
@@ -221,10 +215,8 @@ class TrainEngine:
         self._adam_range(lo, hi, grad_scale)
 
     def _adam_range(self, lo, hi, grad_scale):
-        mirror = self._mirror()
         ops.adam_step(self.flat_p[lo:hi], self.flat_g[lo:hi], self.flat_m[lo:hi], self.flat_v[lo:hi], self.adam_state,
-                      self.betas[0], self.betas[1], self.eps, grad_scale=grad_scale,
-                      mirror=mirror[lo:hi] if mirror is not None else None)                   # optimizer.step()   train.py:201
+                      self.betas[0], self.betas[1], self.eps, grad_scale=grad_scale)          # optimizer.step()   train.py:201
 
     def _early_adam(self):
         """Backward hook (the last encoder stage is done): Adam over the flat tail on the weight-gradient side stream."""
@@ -307,8 +299,6 @@ class TrainEngine:
         else:
             if self._graph is None:
                 self._capture(x, target)
-            if self._p_version != self.flat_p._version:             # torch code wrote the parameters (load_state_dict, ...)
-                self._sync_mirror()
             self._static[0].copy_(x, non_blocking=True)
             self._static[1].copy_(target, non_blocking=True)
             self._graph.replay()
@@ -342,7 +332,6 @@ class TrainEngine:
                 dst.copy_(src)
         torch.set_rng_state(rng_cpu)
         torch.cuda.set_rng_state(rng_dev, sx.device)
-        self._sync_mirror()                                         # the restore above is not the Adam kernel
         del keep
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):

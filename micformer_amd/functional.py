@@ -150,19 +150,26 @@ def join_wgrad_stream():
 # forward side of a stage entry: the engine may park a callable here that runs when the forward reaches its n-th stage (work
 # only the backward needs -- zeroing the gradient buffer, transposed shadow weights -- is launched on a side stream under the
 # latency-bound small stages instead of in front of the step)
-_ENTRY_HOOK = [None, 0, 0]          # callable, the stage entry it waits for, stage entries seen since it was parked
+_ENTRY_HOOKS = []                   # [callable, the stage entry it waits for]
+_ENTRY_SEEN = [0]                   # stage entries seen since clear_entry_hooks()
+
+
+def clear_entry_hooks():
+    _ENTRY_HOOKS.clear()
+    _ENTRY_SEEN[0] = 0
 
 
 def park_entry_hook(fn, at):
-    _ENTRY_HOOK[0], _ENTRY_HOOK[1], _ENTRY_HOOK[2] = fn, at, 0
+    _ENTRY_HOOKS.append([fn, at])
 
 
 def run_entry_hook(force=False):
-    """Called at every stage entry: runs the parked callable at its entry (or now, `force`)."""
-    _ENTRY_HOOK[2] += 1
-    if _ENTRY_HOOK[0] is not None and (force or _ENTRY_HOOK[2] >= _ENTRY_HOOK[1]):
-        hook, _ENTRY_HOOK[0] = _ENTRY_HOOK[0], None
-        hook()
+    """Called at every stage entry: runs the parked callables whose entry this is (or all of them now, `force`)."""
+    _ENTRY_SEEN[0] += 1
+    due = [h for h in _ENTRY_HOOKS if force or _ENTRY_SEEN[0] >= h[1]]
+    for h in due:
+        _ENTRY_HOOKS.remove(h)
+        h[0]()
 
 
 # backward side: callables the engine parks per stage (key = id of the stage module); run when the backward has left that stage

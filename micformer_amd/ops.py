@@ -700,11 +700,19 @@ def block_tile_tokens(dims, C, heads, hidden, backward=False):
     return int(_lib.lib.micf_block_tile_tokens(B, D, H, W, C, heads, hidden, 1 if backward else 0))
 
 
+def blocked16(w):
+    """The K16-blocked order of a [R, Cn] matrix (R, Cn multiples of 16) in which the block kernels stream their bf16 shadow
+    weights: [R/16][Cn/16][16][16], returned with w's shape (torch restatement of micf_weight_prep_grouped's bf16 = 2 layout)."""
+    R, Cn = w.shape
+    return w.reshape(R // 16, 16, Cn // 16, 16).permute(0, 2, 1, 3).contiguous().reshape(R, Cn)
+
+
 class WeightPrepPlan:
     """ctypes item array of (src [r, c] fp32, dst [r, c] | None, dst_t [c, r] | None) triples for micf_weight_prep_grouped (the
-    outputs of one item are both fp32 or both bfloat16); reusable while the tensors keep their addresses."""
+    outputs of one item are both fp32 or both bfloat16); reusable while the tensors keep their addresses.  blocked: bfloat16
+    outputs are written K16-blocked (the block kernels' shadow weights) instead of row-major."""
 
-    def __init__(self, triples):
+    def __init__(self, triples, blocked=False):
         self.triples = list(triples)
         self.n = len(self.triples)
         self.arr = (_lib.WeightPrepItem * max(self.n, 1))()
@@ -713,7 +721,7 @@ class WeightPrepPlan:
             outs = [t for t in (dst, dst_t) if t is not None]
             assert outs and len({t.dtype for t in outs}) == 1 and outs[0].dtype in (torch.float32, torch.bfloat16)
             it.src, it.dst, it.dst_t, it.rows, it.cols = f32(src), ptr(dst), ptr(dst_t), src.shape[0], src.shape[1]
-            it.bf16 = 1 if outs[0].dtype == torch.bfloat16 else 0
+            it.bf16 = (2 if blocked else 1) if outs[0].dtype == torch.bfloat16 else 0
             self.nbytes += src.numel() * (4 + sum(t.element_size() for t in outs))
 
     def launch(self):
@@ -748,6 +756,9 @@ def conv3_prepared_like(w):
 # parameter attribute holding an engine-maintained shadow copy, per (arithmetic mode, direction): (name, transposed, dtype)
 _SHADOW = {("fp32", True): ("_micf_wt", True, torch.float32), ("bf16", False): ("_micf_w16", False, torch.bfloat16),
            ("bf16", True): ("_micf_wt16", True, torch.bfloat16)}
+
+
+ENGINE_SHADOWS = False      # set by the engine around its step: the shadow copies parked on the parameters are current
 
 
 def shadow_spec(backward):
@@ -799,11 +810,11 @@ def block_weights(P, attn, backward):
         if spec is None:
             out[field] = w
             continue
-        sh = getattr(w, spec[0], None)
+        sh = getattr(w, spec[0], None) if ENGINE_SHADOWS else None
         if sh is None:
             def build(w=w):
                 t = shadow_like(w, spec[1], spec[2])
-                WeightPrepPlan([(w, None, t) if spec[1] else (w, t, None)]).launch()
+                WeightPrepPlan([(w, None, t) if spec[1] else (w, t, None)], blocked=True).launch()
                 return t
             sh = _inference_cache(w, spec[0], build)
         if sh is None:
@@ -811,7 +822,7 @@ def block_weights(P, attn, backward):
             todo.append((w, None, sh) if spec[1] else (w, sh, None))
         out[field] = sh
     if todo:
-        WeightPrepPlan(todo).launch()
+        WeightPrepPlan(todo, blocked=True).launch()
     return out
 
 

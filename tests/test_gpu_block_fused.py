@@ -211,6 +211,21 @@ def test_weight_prep_outputs(ops, rows, cols):
     assert torch.equal(wt16, w.t().contiguous().to(torch.bfloat16)) and torch.equal(only_t, wt16)
 
 
+@pytest.mark.parametrize("rows,cols", [(48, 48), (96, 48), (192, 768), (768, 384)])
+def test_weight_prep_blocked_outputs(ops, rows, cols):
+    """bf16 = 2: the same bf16 values in the K16-blocked order the block kernels stream ([R/16][C/16][16][16]); shapes that are
+    not multiples of 16 are refused."""
+    w = torch.randn(rows, cols, device="cuda")
+    w16, wt16 = ops.shadow_like(w, False, torch.bfloat16), ops.shadow_like(w, True, torch.bfloat16)
+    ops.WeightPrepPlan([(w, w16, wt16)], blocked=True).launch()
+    torch.cuda.synchronize()
+    assert torch.equal(w16, ops.blocked16(w.to(torch.bfloat16)))
+    assert torch.equal(wt16, ops.blocked16(w.t().contiguous().to(torch.bfloat16)))
+    bad = torch.randn(40, 48, device="cuda")
+    with pytest.raises(RuntimeError):
+        ops.WeightPrepPlan([(bad, ops.shadow_like(bad, False, torch.bfloat16), None)], blocked=True).launch()
+
+
 def test_inference_shadow_cache_follows_weight_updates(ops):
     """Under no_grad (no engine) the bf16 shadow weights are cached on the parameter and rebuilt when torch code writes it."""
     ops.set_compute_dtype("bf16")
@@ -221,11 +236,11 @@ def test_inference_shadow_cache_follows_weight_updates(ops):
             a = ops.block_weights(P, "self_attn", backward=False)
             b = ops.block_weights(P, "self_attn", backward=False)
             assert all(a[f].data_ptr() == b[f].data_ptr() for f in a)                  # cached, not re-made
-            assert torch.equal(a["wq"], P["self_attn.q.weight"].to(torch.bfloat16))
+            assert torch.equal(a["wq"], ops.blocked16(P["self_attn.q.weight"].to(torch.bfloat16)))
             P["self_attn.q.weight"].mul_(2.0)                                          # in-place update: version counter moves
             c = ops.block_weights(P, "self_attn", backward=False)
             torch.cuda.synchronize()
-            assert torch.equal(c["wq"], P["self_attn.q.weight"].to(torch.bfloat16))
+            assert torch.equal(c["wq"], ops.blocked16(P["self_attn.q.weight"].to(torch.bfloat16)))
             assert c["wkv"].data_ptr() == a["wkv"].data_ptr()                          # untouched weights keep their copies
         g = ops.block_weights(P, "self_attn", backward=False)                          # autograd recording: fresh temporaries
         assert g["wq"].data_ptr() != c["wq"].data_ptr()

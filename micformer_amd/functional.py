@@ -61,6 +61,7 @@ _DEFERRED_CALLS = []                # (callable, tensors it reads, queued from i
 def _defer(ok, fn, *tensors):
     """Run `fn` now, or -- engine mode, every destination a view of the flat gradient buffer (`ok`) -- at the next flush."""
     if ok and DEFER_CALLS and DEFER_WGRAD:
+        launch_pending_flush()
         _DEFERRED_CALLS.append((fn, tuple(t for t in tensors if t is not None), _lib.BLOCK_DEPTH > 0))
     else:
         fn()
@@ -69,6 +70,7 @@ def _defer(ok, fn, *tensors):
 def _lin_wgrad(defer, dy, a, dw, db, dp_scale=None, rows_per_sample=0):
     if defer and DEFER_WGRAD and dy.shape[0] <= DEFER_MAX_TOKENS and ops.wgrad_groupable(dy, a, dp_scale, rows_per_sample) \
             and dw.data_ptr() not in _QUEUED_DW:          # (a layer applied twice in one step launches its second use at once)
+        launch_pending_flush()
         _QUEUED_DW.add(dw.data_ptr())
         _DEFERRED.append((dy, a, dw, db, dp_scale, rows_per_sample))
     else:
@@ -77,6 +79,7 @@ def _lin_wgrad(defer, dy, a, dw, db, dp_scale=None, rows_per_sample=0):
 
 def take_deferred():
     """Hand the queued (not yet launched) weight gradients and LayerNorm partials to the caller (TrainEngine's data-parallel step)."""
+    launch_pending_flush()
     if _DEFERRED_CALLS:
         raise RuntimeError("deferred gradient closures are a single-GPU engine feature (DEFER_CALLS) and cannot be planned")
     items, ln = list(_DEFERRED), list(_DEFERRED_LN)
@@ -93,6 +96,7 @@ def drop_deferred():
     _DEFERRED_LN.clear()
     _DEFERRED_CALLS.clear()
     _QUEUED_DW.clear()
+    _PENDING_FLUSH.clear()
 
 
 def _ln_defer(on):
@@ -116,15 +120,56 @@ def _wgrad_stream(device):
     return st
 
 
-def flush_wgrad_side(calls_only=False):
+# A flush point forks the side stream off the main chain.  Captured into a HIP graph with the side branch created first, the
+# main chain's next kernel moved to another hardware queue and started 130-190 us late (rocprofv3 kernel trace of the 8^3
+# stage's backward).  So the flush is launched lazily: the point only records an event on the main stream and sets the batch
+# aside; the batch goes to the side stream (waiting for that event) once the main chain has launched its next kernel -- i.e.
+# when the next entry is queued.  Measured 13.9 -> 13.4 ms per step (MICF_LAZY_FLUSH=0 restores the eager order).
+LAZY_FLUSH = __import__("os").environ.get("MICF_LAZY_FLUSH", "1") != "0"
+_PENDING_FLUSH = []                 # (event, device, linear items, LayerNorm items, closures)
+
+
+def launch_pending_flush():
+    while _PENDING_FLUSH:
+        ev, dev, items, ln, calls = _PENDING_FLUSH.pop(0)
+        side = _wgrad_stream(dev)
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            _launch_batch(items, ln, calls)
+        _WSIDE_USED.add(dev)
+
+
+def flush_wgrad_side(calls_only=False, lazy=False):
     """Launch everything queued so far on the weight-gradient side stream (ordered after the current stream's work).
     calls_only: just the deferred closures (data-parallel mode: the grouped linear weight gradients stay queued for the
-    engine, which interleaves them with the gradient all-reduce after the replay)."""
+    engine, which interleaves them with the gradient all-reduce after the replay).  lazy: see LAZY_FLUSH."""
+    launch_pending_flush()
     if not ((not calls_only and (_DEFERRED or _DEFERRED_LN)) or _DEFERRED_CALLS):
         return
     first = _DEFERRED_CALLS[0][1][0] if _DEFERRED_CALLS else (_DEFERRED[0][0] if _DEFERRED else _DEFERRED_LN[0][0])
     dev = first.device
     main, side = torch.cuda.current_stream(dev), _wgrad_stream(dev)
+    if lazy and LAZY_FLUSH:
+        ev = torch.cuda.Event()
+        ev.record(main)
+        items, ln = ([], []) if calls_only else (list(_DEFERRED), list(_DEFERRED_LN))
+        calls = list(_DEFERRED_CALLS)
+        for it in items:
+            for t in (it[0], it[1], it[4]):
+                if t is not None:
+                    t.record_stream(side)
+        for it in ln:
+            it[0].record_stream(side)
+        for _, tensors, _blk in calls:
+            for t in tensors:
+                t.record_stream(side)
+        if not calls_only:
+            _DEFERRED.clear()
+            _DEFERRED_LN.clear()
+            _QUEUED_DW.clear()
+        _DEFERRED_CALLS.clear()
+        _PENDING_FLUSH.append((ev, dev, items, ln, calls))
+        return
     side.wait_stream(main)
     if not calls_only:
         for it in _DEFERRED:                # the queue's references die at the flush: tell the allocator who still reads them
@@ -142,6 +187,7 @@ def flush_wgrad_side(calls_only=False):
 
 
 def join_wgrad_stream():
+    launch_pending_flush()
     for dev in list(_WSIDE_USED):
         torch.cuda.current_stream(dev).wait_stream(_wgrad_stream(dev))
     _WSIDE_USED.clear()
@@ -187,38 +233,41 @@ class FlushPointFn(torch.autograd.Function):
         # (a token cap exists for experiments: restricting the flushes to the latency-bound small stages was measured slower --
         # the weight gradients of the big stages then pile up in the tail)
         if FLUSH_POINTS and DEFER_WGRAD and dx.numel() // dx.shape[-1] <= FLUSH_MAX_TOKENS:
-            flush_wgrad_side()
+            flush_wgrad_side(lazy=True)
         elif DEFER_CALLS and DEFER_WGRAD:
-            flush_wgrad_side(calls_only=True)
+            flush_wgrad_side(calls_only=True, lazy=True)
         hook = BACKWARD_HOOKS.pop(ctx.key, None) if ctx.key is not None else None
         if hook is not None:
             hook()
         return dx, dxa, None
 
 
+def _launch_batch(items, ln, calls):
+    with block_region():
+        if ln:
+            ops.layernorm_bwd_finish(ln)
+        if items:
+            ops.linear_bwd_weight_grouped(items)
+    for fn, _, blk in calls:
+        if blk:
+            with block_region():
+                fn()
+        else:
+            fn()
+
+
 def flush_wgrad(calls_only=False):
     """Launch every queued weight gradient on the current stream (which must be ordered after their producers)."""
-    with block_region():
-        if calls_only:
-            pass
-        elif _DEFERRED_LN:
-            ln = list(_DEFERRED_LN)
-            _DEFERRED_LN.clear()
-            ops.layernorm_bwd_finish(ln)
-        if _DEFERRED and not calls_only:
-            items = list(_DEFERRED)
-            _DEFERRED.clear()
-            _QUEUED_DW.clear()
-            ops.linear_bwd_weight_grouped(items)
-    if _DEFERRED_CALLS:
-        calls = list(_DEFERRED_CALLS)
-        _DEFERRED_CALLS.clear()
-        for fn, _, blk in calls:
-            if blk:
-                with block_region():
-                    fn()
-            else:
-                fn()
+    launch_pending_flush()
+    items, ln = [], []
+    if not calls_only:
+        items, ln = list(_DEFERRED), list(_DEFERRED_LN)
+        _DEFERRED.clear()
+        _DEFERRED_LN.clear()
+        _QUEUED_DW.clear()
+    calls = list(_DEFERRED_CALLS)
+    _DEFERRED_CALLS.clear()
+    _launch_batch(items, ln, calls)
 
 
 def _targets(params):

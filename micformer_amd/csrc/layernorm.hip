@@ -91,10 +91,12 @@ __device__ __forceinline__ float group_sum(float v) {
 }
 
 template <int LPR, int VPL>
-__device__ __forceinline__ void ln_fwd_v2_body(const float* __restrict__ x, const float* __restrict__ gamma,
+__device__ __forceinline__ void ln_fwd_v2_body(const float* __restrict__ x, const float* __restrict__ x2, int c1,
+                                                 const float* __restrict__ gamma,
                                                  const float* __restrict__ beta, float* __restrict__ y,
                                                  float* __restrict__ mean, float* __restrict__ rstd, int64_t rows, int C,
                                                  float eps, int rpb) {
+  // (x2: the row is cat[x (c1 columns), x2 (C - c1 columns)], both multiples of 4 -- MS.py:1033-1034; otherwise c1 = C)
   constexpr int RPW = 64 / LPR;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane % LPR, rg = lane / LPR;
   const int64_t r_end = ((int64_t)(blockIdx.x + 1) * rpb < rows) ? (int64_t)(blockIdx.x + 1) * rpb : rows;
@@ -112,7 +114,7 @@ __device__ __forceinline__ void ln_fwd_v2_body(const float* __restrict__ x, cons
 #pragma unroll
     for (int k = 0; k < VPL; ++k) {
       const int c = (sub + k * LPR) * 4;
-      v[k] = c < C ? ldg4(x + row * C + c) : make_float4(0, 0, 0, 0);
+      v[k] = c < C ? ldg4(c < c1 ? x + row * c1 + c : x2 + row * (C - c1) + (c - c1)) : make_float4(0, 0, 0, 0);
       s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
     }
     const float mu = group_sum<LPR>(s) * invC;
@@ -136,8 +138,9 @@ __device__ __forceinline__ void ln_fwd_v2_body(const float* __restrict__ x, cons
 }
 
 template <int LPR, int VPL>
-__device__ __forceinline__ void ln_bwd_v2_body(const float* dy, const float* __restrict__ x, const float* __restrict__ mean,
-                                                 const float* __restrict__ rstd, const float* __restrict__ gamma, float* dx,
+__device__ __forceinline__ void ln_bwd_v2_body(const float* dy, const float* __restrict__ x, const float* __restrict__ x2, int c1,
+                                                 const float* __restrict__ mean,
+                                                 const float* __restrict__ rstd, const float* __restrict__ gamma, float* dx, float* dx2,
                                                  float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int C,
                                                  const float* add, float* __restrict__ partials, int rpb) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // [2][C]
@@ -163,7 +166,7 @@ __device__ __forceinline__ void ln_bwd_v2_body(const float* dy, const float* __r
     for (int k = 0; k < VPL; ++k) {
       const int c = (sub + k * LPR) * 4;
       if (c < C) {
-        const float4 v = ldg4(x + row * C + c);
+        const float4 v = ldg4(c < c1 ? x + row * c1 + c : x2 + row * (C - c1) + (c - c1));
         d[k] = ldg4(dy + row * C + c);
         xh[k] = make_float4((v.x - mu) * rs, (v.y - mu) * rs, (v.z - mu) * rs, (v.w - mu) * rs);
         const float g0 = g[k].x * d[k].x, g1 = g[k].y * d[k].y, g2 = g[k].z * d[k].z, g3 = g[k].w * d[k].w;
@@ -181,7 +184,7 @@ __device__ __forceinline__ void ln_bwd_v2_body(const float* dy, const float* __r
         float4 o = make_float4(rs * (g[k].x * d[k].x - A - xh[k].x * Bv), rs * (g[k].y * d[k].y - A - xh[k].y * Bv),
                                rs * (g[k].z * d[k].z - A - xh[k].z * Bv), rs * (g[k].w * d[k].w - A - xh[k].w * Bv));
         if (add) { const float4 a = ldg4(add + row * C + c); o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w; }
-        *reinterpret_cast<float4*>(dx + row * C + c) = o;
+        *reinterpret_cast<float4*>(c < c1 ? dx + row * c1 + c : dx2 + row * (C - c1) + (c - c1)) = o;
       }
     }
   }
@@ -264,8 +267,9 @@ static int ln_v2_rpb(int64_t rows, int lpr, int max_blocks) {
 }
 
 // launch form: up to two independent LayerNorms of the same shape per launch (blockIdx.y): the two modalities of a pair
-struct LnFwdSet { const float *x, *gamma, *beta; float *y, *mean, *rstd; };
-struct LnBwdSet { const float *dy, *x, *mean, *rstd, *gamma; float *dx, *dgamma, *dbeta; const float* add; float* partials; };
+struct LnFwdSet { const float *x, *gamma, *beta; float *y, *mean, *rstd; const float* x2; int c1; };      // c1 = C: no x2
+struct LnBwdSet { const float *dy, *x, *mean, *rstd, *gamma; float *dx, *dgamma, *dbeta; const float* add; float* partials;
+                  const float* x2; float* dx2; int c1; };
 struct LnFwdSets { LnFwdSet s[2]; float4* zero; int64_t zero4; };   // zero: optional side job (clears zero4 float4s)
 struct LnBwdSets { LnBwdSet s[2]; };
 template <int LPR, int VPL>
@@ -273,12 +277,12 @@ __global__ void __launch_bounds__(256) ln_fwd_v2(const LnFwdSets p, int64_t rows
   const LnFwdSet& q = p.s[blockIdx.y];
   if (p.zero && blockIdx.y == 0)
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < p.zero4; i += (int64_t)gridDim.x * 256) p.zero[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  ln_fwd_v2_body<LPR, VPL>(q.x, q.gamma, q.beta, q.y, q.mean, q.rstd, rows, C, eps, rpb);
+  ln_fwd_v2_body<LPR, VPL>(q.x, q.x2, q.c1, q.gamma, q.beta, q.y, q.mean, q.rstd, rows, C, eps, rpb);
 }
 template <int LPR, int VPL>
 __global__ void __launch_bounds__(256) ln_bwd_v2(const LnBwdSets p, int64_t rows, int C, int rpb) {
   const LnBwdSet& q = p.s[blockIdx.y];
-  ln_bwd_v2_body<LPR, VPL>(q.dy, q.x, q.mean, q.rstd, q.gamma, q.dx, q.dgamma, q.dbeta, rows, C, q.add, q.partials, rpb);
+  ln_bwd_v2_body<LPR, VPL>(q.dy, q.x, q.x2, q.c1, q.mean, q.rstd, q.gamma, q.dx, q.dx2, q.dgamma, q.dbeta, rows, C, q.add, q.partials, rpb);
 }
 
 #define MICF_LN_DISPATCH(KERNEL, SMEM, MAXB, NG, ...)                                                    \
@@ -303,9 +307,10 @@ extern "C" int micf_layernorm_fwd(const float* x1, const float* x2, int c1, cons
   if (!x1 || !gamma || !beta || !y || rows < 0 || C <= 0 || c1 <= 0 || c1 > C || (c1 < C && !x2)) return MICF_EINVAL;
   if (rows == 0) return MICF_OK;
   int lpr, vpl;
-  if (!x2 && ln_v2_shape(C, lpr, vpl) && aligned16(x1) && aligned16(y) && aligned16(gamma) && aligned16(beta)) {
+  const bool cat_ok = c1 == C || (x2 && !(c1 & 3) && !((C - c1) & 3) && aligned16(x2));
+  if (cat_ok && ln_v2_shape(C, lpr, vpl) && aligned16(x1) && aligned16(y) && aligned16(gamma) && aligned16(beta)) {
     LnFwdSets p;
-    p.s[0] = p.s[1] = LnFwdSet{x1, gamma, beta, y, mean, rstd};
+    p.s[0] = p.s[1] = LnFwdSet{x1, gamma, beta, y, mean, rstd, c1 == C ? x1 : x2, c1};
     p.zero = nullptr; p.zero4 = 0;
     MICF_LN_DISPATCH(ln_fwd_v2, 0, 2048, 1, p, rows, C, eps);
     MICF_RETURN_LAUNCH();
@@ -319,7 +324,7 @@ extern "C" int micf_layernorm_fwd(const float* x1, const float* x2, int c1, cons
 
 extern "C" int micf_layernorm_bwd_partial_rows(int64_t rows, int C, int c1) {
   int lpr, vpl;
-  if (rows <= 0 || C <= 0 || c1 != C || C > kLnMaxC || !ln_v2_shape(C, lpr, vpl)) return 0;
+  if (rows <= 0 || C <= 0 || c1 <= 0 || c1 > C || (c1 & 3) || ((C - c1) & 3) || C > kLnMaxC || !ln_v2_shape(C, lpr, vpl)) return 0;
   return ceil_div(rows, ln_v2_rpb(rows, lpr, 512));
 }
 
@@ -355,10 +360,11 @@ extern "C" int micf_layernorm_bwd(const float* dy, const float* x1, const float*
   if (C > kLnMaxC) return MICF_EUNSUPPORTED;
   if (rows == 0) return MICF_OK;
   int lpr, vpl;
-  if (!x2 && ln_v2_shape(C, lpr, vpl) && aligned16(x1) && aligned16(dy) && aligned16(dx1) && aligned16(gamma) &&
+  const bool cat_ok = c1 == C || (x2 && dx2 && !(c1 & 3) && !((C - c1) & 3) && aligned16(x2) && aligned16(dx2));
+  if (cat_ok && ln_v2_shape(C, lpr, vpl) && aligned16(x1) && aligned16(dy) && aligned16(dx1) && aligned16(gamma) &&
       (!add || aligned16(add))) {
     LnBwdSets p;
-    p.s[0] = p.s[1] = LnBwdSet{dy, x1, mean, rstd, gamma, dx1, dgamma, dbeta, add, partials};
+    p.s[0] = p.s[1] = LnBwdSet{dy, x1, mean, rstd, gamma, dx1, dgamma, dbeta, add, partials, c1 == C ? x1 : x2, c1 == C ? dx1 : dx2, c1};
     MICF_LN_DISPATCH(ln_bwd_v2, 2 * C * sizeof(float), 512, 1, p, rows, C);
     MICF_RETURN_LAUNCH();
   }
@@ -383,7 +389,7 @@ extern "C" int micf_layernorm_fwd_pair(const micf_ln_pair_item* items, int n, in
     const micf_ln_pair_item& it = items[i < n ? i : 0];
     if (!it.x || !it.gamma || !it.beta || !it.y) return MICF_EINVAL;
     ok = ok && aligned16(it.x) && aligned16(it.y) && aligned16(it.gamma) && aligned16(it.beta);
-    p.s[i] = LnFwdSet{it.x, it.gamma, it.beta, it.y, it.mean, it.rstd};
+    p.s[i] = LnFwdSet{it.x, it.gamma, it.beta, it.y, it.mean, it.rstd, it.x, C};
   }
   if (!ok) {
     for (int i = 0; i < n; ++i) {
@@ -408,7 +414,7 @@ extern "C" int micf_layernorm_bwd_pair(const micf_ln_bwd_pair_item* items, int n
     const micf_ln_bwd_pair_item& it = items[i < n ? i : 0];
     if (!it.dy || !it.x || !it.mean || !it.rstd || !it.gamma || !it.dx) return MICF_EINVAL;
     ok = ok && aligned16(it.x) && aligned16(it.dy) && aligned16(it.dx) && aligned16(it.gamma) && (!it.add || aligned16(it.add));
-    p.s[i] = LnBwdSet{it.dy, it.x, it.mean, it.rstd, it.gamma, it.dx, it.dgamma, it.dbeta, it.add, it.partials};
+    p.s[i] = LnBwdSet{it.dy, it.x, it.mean, it.rstd, it.gamma, it.dx, it.dgamma, it.dbeta, it.add, it.partials, it.x, it.dx, C};
   }
   if (!ok) {
     for (int i = 0; i < n; ++i) {

@@ -218,6 +218,20 @@ int micf_conv_down_bwd_data(const float* dy, const float* w, float* dx, int B, i
                             micf_stream_t stream);
 int micf_conv_down_bwd_weight(const float* dy, const float* x, float* dw, float* dbias, int B, int D, int H, int W,
                               int C, int N, micf_stream_t stream);
+/* The same k = s convolutions as plain GEMMs (what the autograd Functions launch): micf_space_to_depth gathers the k^3 voxels
+ * of every patch of a channels-last x [B,D,H,W,C] (voxel stride C, sample stride batch_stride elements, 0 = D*H*W*C; a
+ * single-channel NCDHW volume is C = 1 with batch_stride = nmod*D*H*W and x advanced to the modality) into one row of
+ * a [B*ceil(D/k)*ceil(H/k)*ceil(W/k), C*k^3]; column = c*k^3 + (tz*k + ty)*k + tx, i.e. the flattening of the Conv3d weight
+ * [N, C, k,k,k] (zeros beyond odd dims).  Then conv_down = micf_linear_fwd(a, w as [N, C k^3], bias); its weight gradient
+ * is the linear one on the same a; its data gradient micf_linear_bwd_data followed by micf_depth_to_space (the inverse
+ * scatter, + bias[c] when given, cropping what lies beyond D, H, W).  ConvTranspose3d [C, N, k,k,k]: y = depth_to_space(
+ * micf_linear_bwd_data(x, w as [C, N k^3]), bias[N]); dx = micf_linear_fwd(space_to_depth(dy), w as [C, N k^3]);
+ * dw = linear weight gradient of (dy := x, a := space_to_depth(dy)); dbias = micf_colsum(dy as [voxels, N]) (accumulated). */
+int micf_space_to_depth(const float* x, float* a, int B, int D, int H, int W, int C, int k, int64_t batch_stride,
+                        micf_stream_t stream);
+int micf_depth_to_space(const float* a, const float* bias, float* y, int B, int D, int H, int W, int C, int k,
+                        micf_stream_t stream);
+int micf_colsum(const float* x, float* out, int64_t M, int N, micf_stream_t stream);
 /* conv_up: ConvTranspose3d(C->N, k=s in {2,4}) on channels-last x [B,D,H,W,C] -> y [B,kD,kH,kW,N] channels-last
  * (PatchExpand MS.py:575-577; reverse_patch_embedding MS.py:990,1037). */
 int micf_conv_up_fwd(const float* x, const float* w, const float* bias, float* y, int B, int D, int H, int W, int C,

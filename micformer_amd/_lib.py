@@ -62,6 +62,9 @@ SIGNATURES = {
     "micf_conv_up_fwd": "ppppiiiiiiip",
     "micf_conv_up_bwd_data": "pppiiiiiiip",
     "micf_conv_up_bwd_weight": "ppppiiiiiiip",
+    "micf_space_to_depth": "ppiiiiiilp",
+    "micf_depth_to_space": "pppiiiiiip",
+    "micf_colsum": "pplip",
     "micf_pad3d": "ppiiiiiiiip",
     "micf_crop3d": "ppiiiiiiiiip",
     "micf_resize_trilinear_fwd": "ppiiiiiiiip",

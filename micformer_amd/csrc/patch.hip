@@ -287,3 +287,78 @@ extern "C" int micf_conv_up_bwd_weight(const float* dy, const float* x, float* d
   if (dbias) return colsum_atomic(dy, nullptr, 1, dbias, Tc * K3, N, S_(stream));
   return MICF_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Space-to-depth / depth-to-space: a convolution whose stride equals its kernel (patch embedding k = 4, PatchMerging k = 2,
+// PatchExpand's transposed conv k = 2) is a plain GEMM once the k^3 voxels of every patch sit in one row.  Column order is
+// (channel, tap), tap = (tz * k + ty) * k + tx -- the flattening of a Conv3d weight [N, C, k, k, k] -> [N, C k^3] and of a
+// ConvTranspose3d weight [C, N, k, k, k] -> [C, N k^3], so the parameters and their gradients are used in place and the
+// GEMMs are micf_linear_fwd / _bwd_data / the grouped weight gradient.  (The element-gather GEMMs above stay as the
+// reference form of the entry points; at 6 TFLOP/s they were 0.9 ms of the critical chain of the base step.)
+namespace micf {
+struct S2dGeo {
+  int B, D, H, W, C, k, K3;        // fine grid, channels, patch edge
+  int Dc, Hc, Wc;                  // coarse grid = ceil(fine / k): out-of-range voxels read as zero / are not written
+  int64_t batch_stride;            // elements between the samples of the FINE tensor (voxel stride = C)
+};
+template <bool TO_DEPTH>
+__global__ void __launch_bounds__(256) s2d_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                  const float* __restrict__ bias, S2dGeo g, int64_t total4) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const int q4 = g.K3 >> 2;
+  const int t4 = (int)(i % q4);
+  int64_t r = i / q4;
+  const int c = (int)(r % g.C); r /= g.C;
+  const int xc = (int)(r % g.Wc); int64_t r2 = r / g.Wc;
+  const int yc = (int)(r2 % g.Hc); r2 /= g.Hc;
+  const int zc = (int)(r2 % g.Dc); const int b = (int)(r2 / g.Dc);
+  float* mat = (TO_DEPTH ? dst : const_cast<float*>(src)) + (r * g.C + c) * g.K3 + 4 * t4;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (!TO_DEPTH) { const float4 t = *reinterpret_cast<const float4*>(mat); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+  const float bs = (!TO_DEPTH && bias) ? bias[c] : 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int tap = 4 * t4 + j;
+    const int tz = tap / (g.k * g.k), ty = (tap / g.k) % g.k, tx = tap % g.k;
+    const int z = zc * g.k + tz, y = yc * g.k + ty, x = xc * g.k + tx;
+    if (z >= g.D || y >= g.H || x >= g.W) continue;
+    const int64_t a = (int64_t)b * g.batch_stride + (((int64_t)z * g.H + y) * g.W + x) * g.C + c;
+    if (TO_DEPTH) v[j] = src[a];
+    else dst[a] = v[j] + bs;
+  }
+  if (TO_DEPTH) *reinterpret_cast<float4*>(mat) = make_float4(v[0], v[1], v[2], v[3]);
+}
+static bool s2d_geo(S2dGeo& g, int B, int D, int H, int W, int C, int k, int64_t batch_stride) {
+  if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || (k != 2 && k != 4)) return false;
+  g.B = B; g.D = D; g.H = H; g.W = W; g.C = C; g.k = k; g.K3 = k * k * k;
+  g.Dc = (D + k - 1) / k; g.Hc = (H + k - 1) / k; g.Wc = (W + k - 1) / k;
+  g.batch_stride = batch_stride > 0 ? batch_stride : (int64_t)D * H * W * C;
+  return true;
+}
+}  // namespace micf
+
+extern "C" int micf_space_to_depth(const float* x, float* a, int B, int D, int H, int W, int C, int k, int64_t batch_stride,
+                                   micf_stream_t stream) {
+  S2dGeo g;
+  if (!x || !a || !s2d_geo(g, B, D, H, W, C, k, batch_stride) || !aligned16(a)) return MICF_EINVAL;
+  const int64_t total4 = (int64_t)B * g.Dc * g.Hc * g.Wc * C * (g.K3 / 4);
+  hipLaunchKernelGGL(s2d_kernel<true>, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, S_(stream), x, a, nullptr, g, total4);
+  MICF_RETURN_LAUNCH();
+}
+
+extern "C" int micf_depth_to_space(const float* a, const float* bias, float* y, int B, int D, int H, int W, int C, int k,
+                                   micf_stream_t stream) {
+  S2dGeo g;
+  if (!a || !y || !s2d_geo(g, B, D, H, W, C, k, 0) || !aligned16(a)) return MICF_EINVAL;
+  const int64_t total4 = (int64_t)B * g.Dc * g.Hc * g.Wc * C * (g.K3 / 4);
+  hipLaunchKernelGGL(s2d_kernel<false>, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, S_(stream), a, y, bias, g, total4);
+  MICF_RETURN_LAUNCH();
+}
+
+extern "C" int micf_colsum(const float* x, float* out, int64_t M, int N, micf_stream_t stream) {
+  if (!x || !out || M < 0 || N <= 0) return MICF_EINVAL;
+  if (M == 0) return MICF_OK;
+  return colsum_atomic(x, nullptr, 1, out, M, N, S_(stream));
+}

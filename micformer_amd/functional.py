@@ -855,26 +855,39 @@ class CrossPairFn(torch.autograd.Function):
 
 
 # ============================================================================= patch embed / merging / expand / head
+PATCH_GEMM = __import__("os").environ.get("MICF_PATCH_GEMM", "1") != "0"
 class PatchEmbedFn(torch.autograd.Function):
     """PatchEmbed3D (MS.py:860-878) on modality `mod` of vol [B, nmod, D, H, W] -> (B, D', H', W', E) channels-last."""
 
+    # The k = s convolutions run as space-to-depth + the linear GEMMs (ops.space_to_depth; weights and gradients in place)
+    # when PATCH_GEMM is on; off = the element-gather GEMM entry points (micf_patch_embed_* / micf_conv_down_* / micf_conv_up_*).
     @staticmethod
     def forward(ctx, vol, mod, w, b, p):
         vol = _c(vol)
-        y = ops.patch_embed_fwd(vol, mod, w, b, p)
-        ctx.save_for_backward(vol, w)
-        ctx.meta = (mod, p)
+        B, nmod, D, H, W = vol.shape
+        E = w.shape[0]
+        if PATCH_GEMM and w.shape[1] == 1 and p in (2, 4):
+            a = ops.space_to_depth(vol, (B, D, H, W), 1, p, batch_stride=nmod * D * H * W, offset=mod * D * H * W)
+            y = ops.linear_fwd(a, w.reshape(E, p ** 3), b).reshape(B, -(-D // p), -(-H // p), -(-W // p), E)
+            ctx.save_for_backward(a, w)
+        else:
+            y = ops.patch_embed_fwd(vol, mod, w, b, p)
+            ctx.save_for_backward(vol, w)
+        ctx.meta = (mod, p, PATCH_GEMM and w.shape[1] == 1 and p in (2, 4))
         ctx.tg = _targets((w, b))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         vol, w = ctx.saved_tensors
-        mod, p = ctx.meta
+        mod, p, gemm = ctx.meta
         dw = _grad_buf(ctx.tg[0], w)
         db = ctx.tg[1] if ctx.tg[1] is not None else torch.zeros(w.shape[0], dtype=w.dtype, device=w.device)
         dy = _c(dy)
-        _defer(ctx.tg[0] is not None and ctx.tg[1] is not None, lambda: ops.patch_embed_bwd_weight(dy, vol, mod, dw, db, p), dy, vol)
+        if gemm:
+            _lin_wgrad(ctx.tg[0] is not None and ctx.tg[1] is not None, dy.reshape(-1, w.shape[0]), vol, dw.view(w.shape[0], -1), db)
+        else:
+            _defer(ctx.tg[0] is not None and ctx.tg[1] is not None, lambda: ops.patch_embed_bwd_weight(dy, vol, mod, dw, db, p), dy, vol)
         return None, None, _ret(ctx.tg[0], dw), _ret(ctx.tg[1], db), None   # the input volume is data: no gradient (train.py:177-185)
 
 
@@ -884,8 +897,16 @@ class ConvDownFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b):
         x = _c(x)
-        ctx.save_for_backward(x, w)
         ctx.tg = _targets((w, b))
+        ctx.xshape = tuple(x.shape)
+        ctx.gemm = PATCH_GEMM and tuple(w.shape[2:]) == (2, 2, 2)
+        if ctx.gemm:
+            B, D, H, W, C = x.shape
+            N = w.shape[0]
+            a = ops.space_to_depth(x, (B, D, H, W), C, 2)
+            ctx.save_for_backward(a, w)
+            return ops.linear_fwd(a, w.reshape(N, 8 * C), b).reshape(B, -(-D // 2), -(-H // 2), -(-W // 2), N)
+        ctx.save_for_backward(x, w)
         return ops.conv_down_fwd(x, w, b)
 
     @staticmethod
@@ -894,8 +915,15 @@ class ConvDownFn(torch.autograd.Function):
         dy = _c(dy)
         dw = _grad_buf(ctx.tg[0], w)
         db = ctx.tg[1] if ctx.tg[1] is not None else torch.zeros(w.shape[0], dtype=w.dtype, device=w.device)
+        if ctx.gemm:
+            B, D, H, W, C = ctx.xshape
+            N = w.shape[0]
+            dy2 = dy.reshape(-1, N)
+            _lin_wgrad(ctx.tg[0] is not None and ctx.tg[1] is not None, dy2, x, dw.view(N, 8 * C), db)
+            da = ops.linear_bwd_data(dy2, w.reshape(N, 8 * C))
+            return ops.depth_to_space(da, (B, D, H, W), C, 2), _ret(ctx.tg[0], dw), _ret(ctx.tg[1], db)
         _defer(ctx.tg[0] is not None and ctx.tg[1] is not None, lambda: ops.conv_down_bwd_weight(dy, x, dw, db), dy, x)
-        return ops.conv_down_bwd_data(dy, w, tuple(x.shape)), _ret(ctx.tg[0], dw), _ret(ctx.tg[1], db)
+        return ops.conv_down_bwd_data(dy, w, ctx.xshape), _ret(ctx.tg[0], dw), _ret(ctx.tg[1], db)
 
 
 class ConvUpFn(torch.autograd.Function):
@@ -907,6 +935,12 @@ class ConvUpFn(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.k = k
         ctx.tg = _targets((w, b))
+        ctx.gemm = PATCH_GEMM and k in (2, 4) and (w.shape[1] * k ** 3) % 4 == 0
+        if ctx.gemm:
+            B, D, H, W, C = x.shape
+            N = w.shape[1]
+            ya = ops.linear_bwd_data(x.reshape(-1, C), w.reshape(C, N * k ** 3))      # [coarse voxels, (n, tap)]
+            return ops.depth_to_space(ya, (B, D * k, H * k, W * k), N, k, bias=b)
         return ops.conv_up_fwd(x, w, b, k)
 
     @staticmethod
@@ -916,6 +950,15 @@ class ConvUpFn(torch.autograd.Function):
         dw = _grad_buf(ctx.tg[0], w)
         db = ctx.tg[1] if ctx.tg[1] is not None else torch.zeros(w.shape[1], dtype=w.dtype, device=w.device)
         k = ctx.k
+        if ctx.gemm:
+            B, D, H, W, C = x.shape
+            N = w.shape[1]
+            dya = ops.space_to_depth(dy, (B, D * k, H * k, W * k), N, k)             # [coarse voxels, (n, tap)]
+            ok = ctx.tg[0] is not None and ctx.tg[1] is not None
+            _lin_wgrad(ok, x.reshape(-1, C), dya, dw.view(C, N * k ** 3), None)
+            _defer(ok, lambda: ops.colsum_(dy.reshape(-1, N), db), dy)
+            dx = ops.linear_fwd(dya, w.reshape(C, N * k ** 3), None).reshape(x.shape)
+            return dx, _ret(ctx.tg[0], dw), _ret(ctx.tg[1], db), None
         _defer(ctx.tg[0] is not None and ctx.tg[1] is not None, lambda: ops.conv_up_bwd_weight(dy, x, dw, db, k), dy, x)
         return ops.conv_up_bwd_data(dy, w, tuple(x.shape), ctx.k), _ret(ctx.tg[0], dw), _ret(ctx.tg[1], db), None
 

@@ -580,6 +580,30 @@ def conv_up_bwd_weight(dy, x, dw, dbias, k):
          cost=_cost(2 * dy.numel() * C, dy, x, dw))
 
 
+def space_to_depth(x, dims, C, k, batch_stride=0, offset=0):
+    """Fine channels-last tensor (voxel stride C; `x` may be any contiguous fp32 buffer: `offset` elements to its first voxel,
+    `batch_stride` elements between samples, 0 = dense) -> [B * ceil(D/k) * ceil(H/k) * ceil(W/k), C * k^3] patch rows."""
+    B, D, H, W = dims
+    rows = B * (-(-D // k)) * (-(-H // k)) * (-(-W // k))
+    a = _new(x, rows, C * k ** 3)
+    call("micf_space_to_depth", ctypes.c_void_p(x.data_ptr() + 4 * offset), f32(a), B, D, H, W, C, k, batch_stride,
+         cost=_cost(0, a, a))
+    return a
+
+
+def depth_to_space(a, dims, C, k, bias=None):
+    """Inverse scatter of space_to_depth: [rows, C * k^3] -> channels-last [B, D, H, W, C] (+ bias[C]); every voxel is written."""
+    B, D, H, W = dims
+    y = _new(a, B, D, H, W, C)
+    call("micf_depth_to_space", f32(a), f32(bias), f32(y), B, D, H, W, C, k, cost=_cost(0, a, y))
+    return y
+
+
+def colsum_(x2d, out):
+    """out[N] += column sums of x2d [M, N]."""
+    call("micf_colsum", f32(x2d), f32(out), x2d.shape[0], x2d.shape[1], cost=_cost(0, x2d))
+
+
 # ----------------------------------------------------------------------------- pad / crop / resize
 def pad3d(x, dims, pdims):
     B, D, H, W = dims

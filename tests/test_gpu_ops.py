@@ -381,6 +381,75 @@ def test_conv_down(ops, shape):
     close(db, gb, rtol=2e-4, what="down db")
 
 
+@pytest.mark.parametrize("dims,C,k", [((2, 8, 6, 10), 12, 2), ((1, 5, 7, 9), 4, 2), ((2, 8, 8, 8), 1, 4), ((1, 6, 10, 7), 3, 4)])
+def test_space_to_depth_and_back(ops, dims, C, k):
+    """micf_space_to_depth: rows of k^3-voxel patches, column = c * k^3 + tap (zeros beyond odd dims); micf_depth_to_space
+    inverts it (+ bias), cropping the padding.  Both are pure data movement: bit-exact."""
+    B, D, H, W = dims
+    x = dev(rnd(B, D, H, W, C, seed=1))
+    a = ops.space_to_depth(x, dims, C, k)
+    Dp, Hp, Wp = [-(-v // k) * k for v in (D, H, W)]
+    xp = torch.zeros(B, Dp, Hp, Wp, C, device="cuda")
+    xp[:, :D, :H, :W] = x
+    ref = xp.view(B, Dp // k, k, Hp // k, k, Wp // k, k, C).permute(0, 1, 3, 5, 7, 2, 4, 6).reshape(-1, C * k ** 3)
+    assert torch.equal(a, ref)
+    assert torch.equal(ops.depth_to_space(a, dims, C, k), x)
+    bias = dev(rnd(C, seed=2))
+    assert torch.equal(ops.depth_to_space(a, dims, C, k, bias=bias), x + bias)
+    out = torch.zeros(C * k ** 3, device="cuda")
+    ops.colsum_(a, out)
+    close(out, a.sum(0), rtol=1e-5, what="colsum")
+
+
+@pytest.mark.parametrize("gemm", [True, False])
+def test_patch_conv_functions_match_torch(ops, gemm):
+    """PatchEmbedFn / ConvDownFn / ConvUpFn (both forms: space-to-depth + linear GEMMs, element-gather GEMMs) against
+    F.conv3d / F.conv_transpose3d, forward and all gradients, odd dims included."""
+    from micformer_amd import functional as Fn
+    prev = Fn.PATCH_GEMM
+    Fn.PATCH_GEMM = gemm
+    try:
+        # patch embedding, k = 4, modality 1 of 2
+        vol = rnd(1, 2, 9, 8, 10, seed=1)
+        w = (rnd(24, 1, 4, 4, 4, seed=2) / 8).requires_grad_(True)
+        b = (0.1 * rnd(24, seed=3)).requires_grad_(True)
+        y = F.conv3d(F.pad(vol[:, 1:2], (0, 2, 0, 0, 0, 3)), w, b, stride=4).permute(0, 2, 3, 4, 1)
+        dy = rnd(*y.shape, seed=4)
+        gw, gb = torch.autograd.grad((y * dy).sum(), [w, b])
+        wd, bd = dev(w.detach()).requires_grad_(True), dev(b.detach()).requires_grad_(True)
+        yy = Fn.PatchEmbedFn.apply(dev(vol), 1, wd, bd, 4)
+        close(yy, y, what="embed y")
+        g = torch.autograd.grad((yy * dev(dy)).sum(), [wd, bd])
+        close(g[0], gw, rtol=2e-4, what="embed dw"); close(g[1], gb, rtol=2e-4, what="embed db")
+        # PatchMerging conv, k = 2, odd dims
+        x = rnd(1, 5, 3, 6, 24, seed=5).requires_grad_(True)
+        w = (rnd(48, 24, 2, 2, 2, seed=6) / math.sqrt(192)).requires_grad_(True)
+        b = (0.1 * rnd(48, seed=7)).requires_grad_(True)
+        y = F.conv3d(F.pad(x.permute(0, 4, 1, 2, 3), (0, 0, 0, 1, 0, 1)), w, b, stride=2).permute(0, 2, 3, 4, 1)
+        dy = rnd(*y.shape, seed=8)
+        ref = torch.autograd.grad((y * dy).sum(), [x, w, b])
+        xd, wd, bd = (dev(t.detach()).requires_grad_(True) for t in (x, w, b))
+        yy = Fn.ConvDownFn.apply(xd, wd, bd)
+        close(yy, y, what="down y")
+        for got, want, tag in zip(torch.autograd.grad((yy * dev(dy)).sum(), [xd, wd, bd]), ref, ("dx", "dw", "db")):
+            close(got, want, rtol=2e-4, what="down " + tag)
+        # PatchExpand transposed conv, k = 2 and the reverse patch embedding, k = 4
+        for k, N in ((2, 24), (4, 12)):
+            x = rnd(2, 2, 3, 2, 48, seed=9).requires_grad_(True)
+            w = (rnd(48, N, k, k, k, seed=10) / math.sqrt(48)).requires_grad_(True)
+            b = (0.1 * rnd(N, seed=11)).requires_grad_(True)
+            y = F.conv_transpose3d(x.permute(0, 4, 1, 2, 3), w, b, stride=k).permute(0, 2, 3, 4, 1)
+            dy = rnd(*y.shape, seed=12)
+            ref = torch.autograd.grad((y * dy).sum(), [x, w, b])
+            xd, wd, bd = (dev(t.detach()).requires_grad_(True) for t in (x, w, b))
+            yy = Fn.ConvUpFn.apply(xd, wd, bd, k)
+            close(yy, y, what=f"up{k} y")
+            for got, want, tag in zip(torch.autograd.grad((yy * dev(dy)).sum(), [xd, wd, bd]), ref, ("dx", "dw", "db")):
+                close(got, want, rtol=2e-4, what=f"up{k} " + tag)
+    finally:
+        Fn.PATCH_GEMM = prev
+
+
 @pytest.mark.parametrize("shape,N,k", [((2, 2, 3, 2, 48), 24, 2), ((1, 4, 4, 4, 96), 48, 2), ((1, 3, 2, 4, 48), 12, 4),
                                         ((2, 2, 2, 2, 96), 24, 4)])
 def test_conv_up(ops, shape, N, k):

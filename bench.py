@@ -54,8 +54,10 @@ def pmc_traffic(kernel_key):
     except (OSError, ValueError):
         return None
     rec = table.get(kernel_key)
-    if rec is None:          # same entry point, different shape tag (e.g. the number of queued layers changed): still the same kernels
-        base = kernel_key.split("|")[0]
+    base = kernel_key.split("|")[0]
+    if rec is None and base == "micf_linear_bwd_weight_grouped":
+        # the tag of the grouped weight gradient is the number of queued layers: another count is still the same kernels
+        # (any other entry point's tag is a shape -- a different shape is a different kernel and has no row here)
         rec = next((v for k, v in table.items() if k.split("|")[0] == base), None)
     return int(rec["hbm_bytes_per_launch"]) if rec else None
 

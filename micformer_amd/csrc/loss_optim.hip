@@ -18,13 +18,22 @@ __global__ void __launch_bounds__(256) dice_bce_partial_kernel(const float* __re
   const float* tp = static_cast<const float*>(tv) + (int64_t)plane * V;
   const uint8_t* lp8 = static_cast<const uint8_t*>(tv) + (int64_t)(plane / K) * V;
   float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
-  for (int64_t i = v0 + threadIdx.x; i < v1; i += 256) {
-    const float p = 1.0f / (1.0f + expf(-zp[i]));          // torch.sigmoid
-    const float tt = LABEL ? (lp8[i] == ch ? 1.f : 0.f) : tp[i];
+  auto term = [&](float z1, float tt) {
+    const float p = 1.0f / (1.0f + expf(-z1));            // torch.sigmoid
     a += p * tt; b += p * p; c += tt * tt;
     // nn.BCELoss on the sigmoid output: log clamped at -100
     const float lp = fmaxf(logf(p), -100.f), lq = fmaxf(logf(1.0f - p), -100.f);
     d -= tt * lp + (1.0f - tt) * lq;
+  };
+  // 16-byte accesses where the plane and the chunk allow it (V and the chunk length multiples of 4: every training shape)
+  const bool vec = !LABEL && (V & 3) == 0 && (per & 3) == 0 && ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(tv)) & 15) == 0;
+  if (vec) {
+    for (int64_t i = v0 + 4 * threadIdx.x; i < v1; i += 1024) {
+      const float4 z4 = *reinterpret_cast<const float4*>(zp + i), t4 = *reinterpret_cast<const float4*>(tp + i);
+      term(z4.x, t4.x); term(z4.y, t4.y); term(z4.z, t4.z); term(z4.w, t4.w);
+    }
+  } else {
+    for (int64_t i = v0 + threadIdx.x; i < v1; i += 256) term(zp[i], LABEL ? (lp8[i] == ch ? 1.f : 0.f) : tp[i]);
   }
   a = wave_sum(a); b = wave_sum(b); c = wave_sum(c); d = wave_sum(d);
   __shared__ float part[4][4];

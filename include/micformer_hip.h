@@ -381,12 +381,15 @@ typedef struct micf_block_fwd_group {
   float* y;            /* [T, C] block output */
   /* saved for backward / the deferred weight gradients, natural token order: */
   float *xn, *q, *kv, *o, *x1, *xn2; /* LN1(x) [T,C] (may be NULL: not written); q [T,C]; k|v [T,2C]; attention out [T,C]; x + s1*attn [T,C]; LN2(x1) [T,C] */
-  float *h, *g;        /* fc1 pre-activation and GELU(h), [T, hidden] */
+  void* h;             /* fc1 pre-activation [T, hidden]: float for MICF_DTYPE_F32, bf16 (uint16_t, round-to-nearest-even)
+                          for MICF_DTYPE_BF16 -- only micf_block_bwd reads it (GELU'), so the bf16 mode stores it at half width */
+  float* g;            /* GELU(h) [T, hidden] (operand of the fc2 weight gradient) */
   float* stats;        /* [4, T]: mean1, rstd1, mean2, rstd2 */
 } micf_block_fwd_group;
 typedef struct micf_block_bwd_group {
   const float* dy;     /* [T, C] gradient w.r.t. the block output (also fc2's output gradient for the weight-gradient GEMM) */
-  const float *x, *x1, *stats, *q, *kv, *h; /* as saved by micf_block_fwd (x and ln1_g may be NULL for a cross block) */
+  const float *x, *x1, *stats, *q, *kv; /* as saved by micf_block_fwd (x and ln1_g may be NULL for a cross block) */
+  const void* h;       /* ... float or bf16 by dtype, as micf_block_fwd wrote it */
   const float *ln1_g, *ln2_g;
   const void *wqt, *wkvt, *wpt, *w1t, *w2t;  /* TRANSPOSED weights: q^T [C,C], kv^T [C,2C], proj^T [C,C], fc1^T [C,hidden],
                                                 fc2^T [hidden,C] from micf_weight_prep_grouped (dst_t): float for MICF_DTYPE_F32,

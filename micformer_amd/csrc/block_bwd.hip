@@ -61,6 +61,46 @@ struct RowRegs {
     }
   }
 };
+// Rows of the saved fc1 pre-activation: fp32, or bf16 at half the registers (bf16 mode).  base: the tensor advanced to the tile's
+// first token and the chunk's first column; ld: its row length in elements.
+template <int TM, int NW, int X4, bool BF16>
+struct HRegs {
+  static constexpr int RPP = 4 * NW, NPASS = (TM + RPP - 1) / RPP, K = (X4 + 15) / 16, ES = BF16 ? 2 : 4;
+  using V = typename std::conditional<BF16, uint2, float4>::type;
+  V v[NPASS][K];
+  __device__ __forceinline__ void load(const int* tok, int tk0, const char* base, uint32_t ld) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15, rg = lane >> 4;
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+      const int row = pass * RPP + wave * 4 + rg;
+      const int tk = row < TM ? tok[row] : -1;
+      const uint32_t rel = tk >= 0 ? (uint32_t)(tk - tk0) : 0u;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const int c4 = l16 + 16 * k;
+        const bool ok = tk >= 0 && c4 < X4;
+        const V t = *reinterpret_cast<const V*>(base + (rel * ld + 4u * (uint32_t)(c4 < X4 ? c4 : X4 - 1)) * (uint32_t)ES);
+        v[pass][k] = ok ? t : V{};
+      }
+    }
+  }
+  __device__ __forceinline__ void commit(float* dst, int stride) const {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15, rg = lane >> 4;
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+      const int row = pass * RPP + wave * 4 + rg;
+      if (row >= TM) continue;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const int c4 = l16 + 16 * k;
+        if (c4 >= X4) continue;
+        float4 f;
+        if constexpr (BF16) f = unpack4_bf16(v[pass][k]); else f = v[pass][k];
+        *reinterpret_cast<float4*>(dst + row * stride + 4 * c4) = f;
+      }
+    }
+  }
+};
 // ... plus the LayerNorm statistics of the rows and the gain vector: what a LayerNorm backward over the tile reads from HBM
 template <int TM, int NW, int C>
 struct LnRegs {
@@ -245,7 +285,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
   // the `saddr` form of the global loads / stores.  tok[0] is the smallest token of the tile (windows are raster ordered).
   const int tk0 = __builtin_amdgcn_readfirstlane(tok[0]);
   const float* dy0 = g.dy + (int64_t)tk0 * C;
-  const float* h0 = g.h + (int64_t)tk0 * Hd;
+  const char* h0 = static_cast<const char*>(g.h) + (int64_t)tk0 * Hd * (BF16 ? 2 : 4);
   const float* q0 = g.q + (int64_t)tk0 * C;
   const float* kv0 = g.kv + (int64_t)tk0 * 2 * C;
   float* dh0 = g.dh + (int64_t)tk0 * Hd;
@@ -256,13 +296,13 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
   // ---- request every global input of the tile (see RowRegs)
   constexpr int HC = 2 * C;
   RowRegs<TM, NW, C4> r_dy;
-  RowRegs<TM, NW, HC / 4> r_h[Hd / HC];
+  HRegs<TM, NW, HC / 4, BF16> r_h[Hd / HC];
   RowRegs<TM, NW, 3 * C4> r_qkv;
   LnRegs<TM, NW, C> r_ln2, r_ln1;
   r_dy.load(tok, tk0, [&](uint32_t rel, uint32_t c4) { return at32(dy0, (rel * C + 4 * c4) * 4u); });
 #pragma unroll
   for (int ch = 0; ch < Hd / HC; ++ch)
-    r_h[ch].load(tok, tk0, [&](uint32_t rel, uint32_t c4) { return at32(h0, (rel * Hd + ch * HC + 4 * c4) * 4u); });
+    r_h[ch].load(tok, tk0, h0 + ch * HC * (BF16 ? 2 : 4), (uint32_t)Hd);
   r_ln2.load(tok, tk0, g.x1 + (int64_t)tk0 * C, g.stats + 2 * T + tk0, g.stats + 3 * T + tk0, g.ln2_g);
   if (!g.dxs) r_ln1.load(tok, tk0, g.x + (int64_t)tk0 * C, g.stats + tk0, g.stats + T + tk0, g.ln1_g);
   r_qkv.load(tok, tk0, [&](uint32_t rel, uint32_t c4) {

@@ -198,22 +198,37 @@ __device__ __forceinline__ void gemm_phase_bf16w(const uint16_t* __restrict__ W0
   f32x4 acc[TG];
 #pragma unroll
   for (int g = 0; g < TG; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // The activation fragments of a (source, k chunk) are read from LDS and rounded to bf16 ONCE per wave and phase and reused
+  // by every unit of that chunk (they were re-read per unit: two ds_read_b128 + four conversions per MFMA).
+  bf16x8 actf[NF][TG];
+  const float* act_src = nullptr;
+  int act_kc = -1;
   auto compute_unit = [&](int u, const Frag& f) {
     const int tile = wave + NW * (NK == 1 ? u : u / NK), kc = NK == 1 ? 0 : u % NK;
-    const float* brow = ((tile >= nt0) ? Bs1 : Bs0) + li * SB + kc * NSL * 16;
+    const float* src = (tile >= nt0) ? Bs1 : Bs0;
+    if (src != act_src || kc != act_kc) {               // (wave-uniform)
+      act_src = src; act_kc = kc;
+      const float* brow = src + li * SB + kc * NSL * 16;
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        const bool half = REM && j == N32;
+        const int koff = 32 * j + 8 * (half ? lrh : lr);
+#pragma unroll
+        for (int g = 0; g < TG; ++g) {
+          const float* bp = brow + g * 16 * SB + koff;
+          float4 lo = *reinterpret_cast<const float4*>(bp), hi = *reinterpret_cast<const float4*>(bp + 4);
+          if (half && lr >= 2) { lo = make_float4(0.f, 0.f, 0.f, 0.f); hi = lo; }
+          actf[j][g] = to_bf16x8(lo, hi);
+        }
+      }
+    }
 #pragma unroll
     for (int j = 0; j < NF; ++j) {
       const bool half = REM && j == N32;
-      const int koff = 32 * j + 8 * (half ? lrh : lr);
       bf16x8 ba = __builtin_bit_cast(bf16x8, f.v[j]);
       if (half && lr >= 2) ba = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
 #pragma unroll
-      for (int g = 0; g < TG; ++g) {
-        const float* bp = brow + g * 16 * SB + koff;
-        float4 lo = *reinterpret_cast<const float4*>(bp), hi = *reinterpret_cast<const float4*>(bp + 4);
-        if (half && lr >= 2) { lo = make_float4(0.f, 0.f, 0.f, 0.f); hi = lo; }
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ba, to_bf16x8(lo, hi), acc[g], 0, 0, 0);
-      }
+      for (int g = 0; g < TG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ba, actf[j][g], acc[g], 0, 0, 0);
     }
     if (kc == NK - 1) {
       const int x = tile * 16 + 4 * lr;
@@ -323,6 +338,25 @@ __device__ __forceinline__ T* at32(T* base, uint32_t byte_off) {
 __device__ __forceinline__ void st4g(float* p, const float4& v) {
   typedef float f32x4_nt __attribute__((ext_vector_type(4)));
   __builtin_nontemporal_store(f32x4_nt{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4_nt*>(p));
+}
+// four values as bf16 (round-to-nearest-even) in 8 bytes and back: the saved fc1 pre-activation of the bf16 mode
+__device__ __forceinline__ uint2 pack4_bf16(const float4& v) { return make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w)); }
+__device__ __forceinline__ float4 unpack4_bf16(const uint2& u) {
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16),
+                     __uint_as_float(u.y & 0xFFFF0000u));
+}
+__device__ __forceinline__ void st2g(void* p, const uint2& v) {          // non-temporal, like st4g
+  typedef unsigned u32x2_nt __attribute__((ext_vector_type(2)));
+  __builtin_nontemporal_store(u32x2_nt{v.x, v.y}, reinterpret_cast<u32x2_nt*>(p));
+}
+// store / load 4 consecutive elements of the saved pre-activation at element offset `e` (multiple of 4)
+template <bool BF16> __device__ __forceinline__ void st_h4(void* h, int64_t e, const float4& v) {
+  if constexpr (BF16) st2g(static_cast<uint16_t*>(h) + e, pack4_bf16(v));
+  else st4g(static_cast<float*>(h) + e, v);
+}
+template <bool BF16> __device__ __forceinline__ float4 ld_h4(const void* h, int64_t e) {
+  if constexpr (BF16) return unpack4_bf16(*reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(h) + e));
+  else return ld4g(static_cast<const float*>(h) + e);
 }
 
 }  // namespace micf

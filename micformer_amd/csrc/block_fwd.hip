@@ -299,7 +299,7 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
         const float4 ge = do_gelu ? make_float4(gelu_t<BF16>(v.x), gelu_t<BF16>(v.y), gelu_t<BF16>(v.z), gelu_t<BF16>(v.w)) : v;
         *reinterpret_cast<float4*>(up) = ge;
         if (tk >= 0 && save) {
-          st4g(g.h + (int64_t)tk * Hd + c0 + 4 * c4, v);
+          st_h4<BF16>(g.h, (int64_t)tk * Hd + c0 + 4 * c4, v);
           st4g(g.g + (int64_t)tk * Hd + c0 + 4 * c4, ge);
         }
       }

@@ -350,7 +350,7 @@ __global__ void __launch_bounds__(256) f3_kernel(const FwdArgs a) {
       const int n = n0 + 16 * t + 4 * lr;
       const float4 b1 = ld4g(g.b1 + n);
       const float4 h = make_float4(v.x + b1.x, v.y + b1.y, v.z + b1.z, v.w + b1.w);
-      st4g(g.h + (int64_t)row.tk * Hd + n, h);
+      st_h4<BF16>(g.h, (int64_t)row.tk * Hd + n, h);
       st4g(g.g + (int64_t)row.tk * Hd + n, make_float4(gelu_t<BF16>(h.x), gelu_t<BF16>(h.y), gelu_t<BF16>(h.z), gelu_t<BF16>(h.w)));
     }
   }
@@ -417,7 +417,7 @@ __global__ void __launch_bounds__(256) b1_kernel(const BwdArgs a) {
     const float4 v = mma<C, BF16>(fa[t & 1], b);
     if (row.ok) {
       const int n = n0 + 16 * t + 4 * lr;
-      const float4 h = ld4g(g.h + (int64_t)row.tk * Hd + n);
+      const float4 h = ld_h4<BF16>(g.h, (int64_t)row.tk * Hd + n);
       st4g(g.dh + (int64_t)row.tk * Hd + n, make_float4(s2 * v.x * gelu_grad_t<BF16>(h.x), s2 * v.y * gelu_grad_t<BF16>(h.y),
                                                         s2 * v.z * gelu_grad_t<BF16>(h.z), s2 * v.w * gelu_grad_t<BF16>(h.w)));
     }

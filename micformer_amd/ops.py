@@ -858,12 +858,13 @@ def block_fwd(groups, dims, C, heads, eps, scale):
     hidden = groups[0]["P"]["mlp.fc1.weight"].shape[0]
     arr = (_lib.BlockFwdGroup * 2)()
     outs = []
+    h_dtype = torch.bfloat16 if _dt() else torch.float32       # the saved fc1 pre-activation: half width in bf16 mode
     keep = []            # temporary shadow weights must outlive the launch: the next group's outputs must not reuse them
     nb = fl = 0
     for it, gd in zip(arr, groups):
         x, P, a = gd["x"], gd["P"], gd["attn"]
         o = {"y": _new(x, T, C), "q": _new(x, T, C), "kv": _new(x, T, 2 * C), "o": _new(x, T, C), "x1": _new(x, T, C),
-             "xn2": _new(x, T, C), "h": _new(x, T, hidden), "g": _new(x, T, hidden), "stats": _new(x, 4, T),
+             "xn2": _new(x, T, C), "h": _new(x, T, hidden, dtype=h_dtype), "g": _new(x, T, hidden), "stats": _new(x, 4, T),
              "xn": _new(x, T, C) if gd.get("want_xn", True) else None}
         it.x, it.kvsrc, it.s1, it.s2 = f32(x), f32(gd.get("kvsrc")), f32(gd.get("s1")), f32(gd.get("s2"))
         for field, key in FWD_W:
@@ -873,11 +874,11 @@ def block_fwd(groups, dims, C, heads, eps, scale):
         for field, wt in wts.items():
             setattr(it, field, ptr(wt))
         for k, v in o.items():
-            setattr(it, k, f32(v))
+            setattr(it, k, ptr(v) if k == "h" else f32(v))
         outs.append(o)
         # algorithmic bytes: read x (+ kvsrc), write [xn,] q, kv (2), o, x1, xn2, y, h (4), g (4); the weights once
-        nb += 4 * (T * C * ((9 if o["xn"] is not None else 8) + (1 if gd.get("kvsrc") is not None else 0)) + 2 * T * hidden) \
-            + 12 * C * C * wt.element_size()
+        nb += 4 * (T * C * ((9 if o["xn"] is not None else 8) + (1 if gd.get("kvsrc") is not None else 0)) + T * hidden) \
+            + T * hidden * o["h"].element_size() + 12 * C * C * wt.element_size()
         fl += 2 * T * 12 * C * C + 4 * T * C * 8
     call("micf_block_fwd", ctypes.cast(arr, ctypes.c_void_p), len(groups), B, D, H, W, C, heads, hidden, float(eps), float(scale),
          _dt(), cost=(nb, fl, f"{len(groups)}x{T}x{C}") if _lib.PROFILE is not None and DETAIL else ((nb, fl) if _lib.PROFILE is not None else None))
@@ -902,8 +903,11 @@ def block_bwd(groups, dims, C, heads, scale):
              "dq": _new(dy, T, C), "dkv": _new(dy, T, 2 * C), "ln2_part": _new(dy, tiles, 2 * C),
              "ln1_part": None if cross else _new(dy, tiles, 2 * C),
              "dx1_copy": _new(dy, T, C) if gd.get("want_copy") else None}
-        for k in ("dy", "x", "x1", "stats", "q", "kv", "h", "s1", "s2"):
+        for k in ("dy", "x", "x1", "stats", "q", "kv", "s1", "s2"):
             setattr(it, k, f32(gd.get(k)))
+        if gd["h"].dtype != (torch.bfloat16 if _dt() else torch.float32):
+            raise _lib.MicfError("block_bwd: the saved pre-activation was written in another arithmetic mode")
+        it.h = ptr(gd["h"])
         for field, key in BWD_W:
             setattr(it, field, f32(P[key.format(a=a)]))
         wts = block_weights(P, a, backward=True)
@@ -915,7 +919,8 @@ def block_bwd(groups, dims, C, heads, scale):
         o["tiles"] = tiles
         outs.append(o)
         # algorithmic bytes: read dy, x1, q, kv (2), h (4) [+ x: self]; write dx, dx1, dq, dkv (2), dh (4) [+ dxs, dx1_copy: cross]
-        nb += 4 * (T * C * ((11 + (1 if gd.get("want_copy") else 0)) if cross else 11) + 2 * T * hidden) + 12 * C * C * wt.element_size()
+        nb += 4 * (T * C * ((11 + (1 if gd.get("want_copy") else 0)) if cross else 11) + T * hidden) + T * hidden * gd["h"].element_size() \
+            + 12 * C * C * wt.element_size()
         fl += 2 * T * 12 * C * C + 8 * T * C * 8
     call("micf_block_bwd", ctypes.cast(arr, ctypes.c_void_p), len(groups), B, D, H, W, C, heads, hidden, float(scale),
          _dt(), cost=(nb, fl, f"{len(groups)}x{T}x{C}") if _lib.PROFILE is not None and DETAIL else ((nb, fl) if _lib.PROFILE is not None else None))

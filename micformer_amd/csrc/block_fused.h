@@ -93,7 +93,10 @@ struct EpiGeluGrad {          // rowscale[trow] * v * GELU'(what the tile holds:
 template <int TG, int NSL, int NK, int LD, int NW, class Epi>
 __device__ __forceinline__ void gemm_phase_f32w(const float* __restrict__ W0, int X0, const float* Bs0, const float* __restrict__ W1,
                                            int X1, const float* Bs1, int SB, float* Os, int SO, const Epi epi) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // The units of a phase are dealt to waves 0, 1, ...: with few units per phase the low waves always get the extra one, and
+  // wave w of every workgroup on a CU sits on SIMD w.  Rotating the deal by a per-workgroup offset spreads that over the SIMDs.
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = (__builtin_amdgcn_readfirstlane(tid >> 6) + (int)((blockIdx.x * 2654435761u) >> 20)) & (NW - 1);
   const int li = lane & 15, lr = lane >> 4;
   const int nt0 = X0 >> 4, ntiles = nt0 + (X1 >> 4);
   const int mytiles = (ntiles - wave + NW - 1) / NW;       // tiles wave, wave + NW, ...
@@ -174,7 +177,10 @@ __device__ __forceinline__ void gemm_phase_bf16w(const uint16_t* __restrict__ W0
                                                  int X1, const float* Bs1, int SB, float* Os, int SO, const Epi epi) {
   constexpr int N32 = NSL / 2, REM = NSL & 1, NF = N32 + REM;
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // The units of a phase are dealt to waves 0, 1, ...: with few units per phase the low waves always get the extra one, and
+  // wave w of every workgroup on a CU sits on SIMD w.  Rotating the deal by a per-workgroup offset spreads that over the SIMDs.
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = (__builtin_amdgcn_readfirstlane(tid >> 6) + (int)((blockIdx.x * 2654435761u) >> 20)) & (NW - 1);
   const int li = lane & 15, lr = lane >> 4;
   const int nt0 = X0 >> 4, ntiles = nt0 + (X1 >> 4);
   const int mytiles = (ntiles - wave + NW - 1) / NW;

@@ -351,13 +351,15 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
   {
     constexpr int heads = C / HD, SP = (TM * heads * 4 <= NTHR && HD >= 16) ? 4 : (TM * heads * 2 <= NTHR) ? 2 : 1, HP = HD / SP, per = 8 * heads * SP, wpb = NTHR / per;
     float* PS = ring;                                   // [(row, head) pair][16]: P row | dS row
+    // (whole waves rotated per workgroup like the GEMM units: with fewer pairs than threads the last waves = SIMDs stay idle)
+    const int vt = (tid + 64 * (int)((blockIdx.x * 2654435761u) >> 20)) & (NTHR - 1);
     for (int w0 = 0; w0 < TM / 8; w0 += wpb) {
-      const int wl = tid / per, rem = tid - wl * per;
+      const int wl = vt / per, rem = vt - wl * per;
       const bool active = wl < wpb && (w0 + wl) < TM / 8;
       const int sub = rem & (SP - 1), pr = rem / SP;    // pr = i * heads + hh
       const int i = pr / heads, hh = pr - i * heads;
       const int row = (w0 + wl) * 8 + i, r0 = row - i, hoff = hh * HD + sub * HP;
-      const int pair = tid / SP;                        // = (wl * 8 + i) * heads + hh
+      const int pair = vt / SP;                         // = (wl * 8 + i) * heads + hh
       float dq[HP], dk[HP], dv[HP];
       if (active) {
         float qr[HP], dor[HP];

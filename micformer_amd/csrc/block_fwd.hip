@@ -171,7 +171,9 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
   // partial scores meet in cross-lane adds).
   if (!(a.debug & 2)) {
     constexpr int heads = C / HD, SP = (TM * heads * 4 <= NTHR && HD >= 16) ? 4 : (TM * heads * 2 <= NTHR) ? 2 : 1, HP = HD / SP;
-    for (int item = tid; item < TM * heads * SP; item += NTHR) {
+    // (whole waves rotated per workgroup like the GEMM units: with fewer items than threads the last waves = SIMDs stay idle)
+    const int vt = (tid + 64 * (int)((blockIdx.x * 2654435761u) >> 20)) & (NTHR - 1);
+    for (int item = vt; item < TM * heads * SP; item += NTHR) {
       const int sub = item & (SP - 1), pr = item / SP;
       const int row = pr / heads, hh = pr - row * heads;
       const int r0 = row & ~7, hoff = hh * HD + sub * HP;

@@ -374,9 +374,9 @@ typedef struct micf_block_fwd_group {
   const float* x;      /* [T, C] block input (residual stream), T = B*D*H*W tokens in natural order */
   const float* kvsrc;  /* cross: [T, C] deformably sampled raw other modality (K/V source, never normed); NULL = self attention */
   const float *ln1_g, *ln1_b, *bq, *bkv, *bp, *ln2_g, *ln2_b, *b1, *b2; /* state_dict layout */
-  const void *wq, *wkv, *wp, *w1, *w2; /* the five weight matrices, state_dict layout [out, in]: float for MICF_DTYPE_F32; bf16
-                                          (uint16_t) K16-blocked shadow copies made by micf_weight_prep_grouped (bf16 = 2)
-                                          for MICF_DTYPE_BF16 */
+  const void *wq, *wkv, *wp, *w1, *w2; /* the five weight matrices, state_dict layout [out, in]: K16-blocked shadow copies made by
+                                          micf_weight_prep_grouped: float (bf16 = 3) for MICF_DTYPE_F32, bf16 (uint16_t,
+                                          bf16 = 2) for MICF_DTYPE_BF16 */
   const float *s1, *s2; /* DropPath scales [B] of the two residual branches (NULL = 1) */
   float* y;            /* [T, C] block output */
   /* saved for backward / the deferred weight gradients, natural token order: */
@@ -392,8 +392,8 @@ typedef struct micf_block_bwd_group {
   const void* h;       /* ... float or bf16 by dtype, as micf_block_fwd wrote it */
   const float *ln1_g, *ln2_g;
   const void *wqt, *wkvt, *wpt, *w1t, *w2t;  /* TRANSPOSED weights: q^T [C,C], kv^T [C,2C], proj^T [C,C], fc1^T [C,hidden],
-                                                fc2^T [hidden,C] from micf_weight_prep_grouped (dst_t): float for MICF_DTYPE_F32,
-                                                K16-blocked bf16 (bf16 = 2) for MICF_DTYPE_BF16 */
+                                                fc2^T [hidden,C] from micf_weight_prep_grouped (dst_t), K16-blocked:
+                                                float (bf16 = 3) for MICF_DTYPE_F32, bf16 (bf16 = 2) for MICF_DTYPE_BF16 */
   const float *s1, *s2;
   float* dx;           /* self: [T, C] gradient w.r.t. the block input.  cross: the q path's PRE-LayerNorm gradient dq Wq (the
                           caller adds the offset-conv path and applies LN1 backward with add = dx1) */
@@ -407,16 +407,16 @@ typedef struct micf_block_bwd_group {
 int micf_block_tile_tokens(int B, int D, int H, int W, int C, int heads, int hidden, int backward);
 /* Per-step weight preparation for the fused block kernels: for each row-major fp32 matrix of a list (one launch per 64 items,
  * one read of the source) write dst = src and / or dst_t = src^T, as float (bf16 = 0), as row-major bf16 bit patterns in
- * uint16_t, round-to-nearest-even (bf16 = 1), or as the same bf16 values K16-BLOCKED (bf16 = 2; rows and cols multiples of
- * 16): element (r, c) of an [R, Cn] output at ((r / 16) * (Cn / 16) + c / 16) * 256 + (r % 16) * 16 + c % 16, the order in
+ * uint16_t, round-to-nearest-even (bf16 = 1), or K16-BLOCKED as bf16 (bf16 = 2) or as float (bf16 = 3; rows and cols multiples
+ * of 16): element (r, c) of an [R, Cn] output at ((r / 16) * (Cn / 16) + c / 16) * 256 + (r % 16) * 16 + c % 16, the order in
  * which the block kernels' matrix-core fragments read them (one load instruction = 1 KB of consecutive addresses).
- * fp32 mode needs dst_t only (micf_block_bwd streams W^T, row-major); bf16 mode needs both, BLOCKED (micf_block_fwd streams
- * bf16 W, micf_block_bwd bf16 W^T).  `items` is HOST memory, read during the call only. */
+ * Both block kernels stream BLOCKED copies: micf_block_fwd W (bf16 = 3 for MICF_DTYPE_F32, 2 for MICF_DTYPE_BF16),
+ * micf_block_bwd W^T likewise.  `items` is HOST memory, read during the call only. */
 typedef struct micf_weight_prep_item {
   const float* src; /* [rows, cols] */
   void* dst;        /* [rows, cols] or NULL */
   void* dst_t;      /* [cols, rows] or NULL */
-  int32_t rows, cols, bf16 /* 0 | 1 | 2, see above */, reserved;
+  int32_t rows, cols, bf16 /* 0 | 1 | 2 | 3, see above */, reserved;
 } micf_weight_prep_item;
 int micf_weight_prep_grouped(const micf_weight_prep_item* items, int n, micf_stream_t stream);
 /* `groups` is HOST memory, read during the call only. */

@@ -331,8 +331,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
       for (int c4 = l16; c4 < X4; c4 += 16)
         st4g(at32(dh0, (rel * Hd + c0 + 4 * c4) * 4u), *reinterpret_cast<const float4*>(U + row * SU + 4 * c4));
     }
-    if (ch == 0) gemm_phase<TJ, NSL, 2, Hd, NW, BF16>(w1t + (BF16 ? 16 : 1) * c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiStore{});
-    else gemm_phase<TJ, NSL, 2, Hd, NW, BF16>(w1t + (BF16 ? 16 : 1) * c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiAcc{});
+    if (ch == 0) gemm_phase<TJ, NSL, 2, Hd, NW, BF16>(w1t + 16 * c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiStore{});
+    else gemm_phase<TJ, NSL, 2, Hd, NW, BF16>(w1t + 16 * c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiAcc{});
   }
 
   // ---- dx1 = dy + LN2'(A2) -> A1 + HBM; LN2 gain / bias partials

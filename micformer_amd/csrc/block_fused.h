@@ -110,9 +110,10 @@ __device__ __forceinline__ void gemm_phase_f32w(const float* __restrict__ W0, in
     const bool seg1 = tile >= nt0;
     const float* Wb = seg1 ? W1 : W0;
     const int xt = (seg1 ? tile - nt0 : tile) * 16;
-    const float* p = Wb + (int64_t)(xt + li) * LD + kc * NSL * 16 + 4 * lr;
+    // K16-blocked like the bf16 copies (see gemm_phase_bf16w): one load instruction = 16 rows x 16 k = 1 KB of consecutive addresses
+    const float* p = Wb + (int64_t)xt * LD + kc * NSL * 256 + li * 16 + 4 * lr;
 #pragma unroll
-    for (int s = 0; s < NSL; ++s) f.v[s] = *reinterpret_cast<const float4*>(p + 16 * s);
+    for (int s = 0; s < NSL; ++s) f.v[s] = *reinterpret_cast<const float4*>(p + 256 * s);
   };
 
   f32x4 acc0[TG], acc1[TG];

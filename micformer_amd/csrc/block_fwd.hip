@@ -307,7 +307,7 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
       }
     }
     lds_barrier();
-    if (!(a.debug & 4)) gemm_phase<TJ, NSL, 2, Hd, NW, BF16>(w2 + (BF16 ? 16 : 1) * c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiAccScale{sc2});
+    if (!(a.debug & 4)) gemm_phase<TJ, NSL, 2, Hd, NW, BF16>(w2 + 16 * c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiAccScale{sc2});
   }
 
   // ---- y = x1 + s2 * (fc2 + b2)

@@ -69,9 +69,9 @@ template <int K, bool BF16> __device__ __forceinline__ void load_w(const typenam
 #pragma unroll
     for (int j = 0; j < K / 32; ++j) f.v[j] = *reinterpret_cast<const u32x4*>(p + (2 * j + (lr >> 1)) * 256);
   } else {
-    const float* row = W + (int64_t)(n + li) * LD + k0;
+    const float* p = W + (int64_t)n * LD + k0 * 16 + li * 16 + 4 * lr;
 #pragma unroll
-    for (int i = 0; i < K / 16; ++i) f.v[i] = *reinterpret_cast<const float4*>(row + 16 * i + 4 * lr);
+    for (int i = 0; i < K / 16; ++i) f.v[i] = *reinterpret_cast<const float4*>(p + 256 * i);
   }
 }
 // D[feature 4 lr + r][token li] = sum_k A[feature][k] B[token][k]: the lane ends up with 4 consecutive features of token li

@@ -236,7 +236,7 @@ __global__ void __launch_bounds__(256) weight_prep_kernel(const PrepArgs a) {
   while (k < a.n - 1 && w >= a.end[k]) ++k;
   const int local = w - (k ? a.end[k - 1] : 0);
   const int rows = a.rows[k], cols = a.cols[k];
-  const bool bf = a.bf16[k] != 0, blocked = a.bf16[k] == 2;
+  const bool bf = a.bf16[k] == 1 || a.bf16[k] == 2, blocked = a.bf16[k] >= 2;
   // K16-blocked destination index of element (r, c) of an [R, Cn] matrix (4 consecutive c stay consecutive)
   auto at = [&](int r, int c, int Cn) {
     return blocked ? ((int64_t)(r >> 4) * (Cn >> 4) + (c >> 4)) * 256 + (r & 15) * 16 + (c & 15) : (int64_t)r * Cn + c;
@@ -282,8 +282,8 @@ extern "C" int micf_weight_prep_grouped(const micf_weight_prep_item* items, int 
     int blocks = 0;
     for (int k = 0; k < cnt; ++k) {
       const micf_weight_prep_item& it = items[first + k];
-      const int align = it.bf16 ? 7 : 15;
-      if (it.bf16 < 0 || it.bf16 > 2 || (it.bf16 == 2 && ((it.rows | it.cols) & 15))) return MICF_EINVAL;
+      const int align = (it.bf16 == 1 || it.bf16 == 2) ? 7 : 15;
+      if (it.bf16 < 0 || it.bf16 > 3 || (it.bf16 >= 2 && ((it.rows | it.cols) & 15))) return MICF_EINVAL;
       if (!it.src || (!it.dst && !it.dst_t) || it.rows <= 0 || it.cols <= 0 || (reinterpret_cast<uintptr_t>(it.src) & 15) ||
           (reinterpret_cast<uintptr_t>(it.dst) & align) || (reinterpret_cast<uintptr_t>(it.dst_t) & align))
         return MICF_EINVAL;

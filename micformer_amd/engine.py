@@ -118,7 +118,8 @@ class TrainEngine:
         #   * the re-laid-out offset-conv weights of the direct conv kernels: one small grouped launch in front of the forward.
         pick = lambda suffixes: [(n, p) for n, p in zip(names, params) if n.endswith(suffixes)]
         self._shadow_w = [(n, p) for n, p in pick(("attn.q.weight", "attn.kv.weight", "attn.proj.weight", "mlp.fc1.weight",
-                                                   "mlp.fc2.weight")) if p.dim() == 2 and min(p.shape) <= 384]
+                                                   "mlp.fc2.weight"))
+                          if p.dim() == 2 and min(p.shape) <= 384 and not ((p.shape[0] | p.shape[1]) & 15)]   # (fusable widths)
         self._conv_w = [(n, p) for n, p in pick(("conv_offset.0.weight",)) if p.dim() == 5 and p.shape[0] <= 16]
         self._offset_of = {id(p): o for p, o in zip(params, offs)}
         self._prep_plans, self._shadow_bufs = {}, {}

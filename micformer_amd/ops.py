@@ -733,8 +733,8 @@ def blocked16(w):
 
 class WeightPrepPlan:
     """ctypes item array of (src [r, c] fp32, dst [r, c] | None, dst_t [c, r] | None) triples for micf_weight_prep_grouped (the
-    outputs of one item are both fp32 or both bfloat16); reusable while the tensors keep their addresses.  blocked: bfloat16
-    outputs are written K16-blocked (the block kernels' shadow weights) instead of row-major."""
+    outputs of one item are both fp32 or both bfloat16); reusable while the tensors keep their addresses.  blocked: the
+    outputs are written K16-blocked (the block kernels' shadow weights; rows and cols multiples of 16) instead of row-major."""
 
     def __init__(self, triples, blocked=False):
         self.triples = list(triples)
@@ -745,7 +745,7 @@ class WeightPrepPlan:
             outs = [t for t in (dst, dst_t) if t is not None]
             assert outs and len({t.dtype for t in outs}) == 1 and outs[0].dtype in (torch.float32, torch.bfloat16)
             it.src, it.dst, it.dst_t, it.rows, it.cols = f32(src), ptr(dst), ptr(dst_t), src.shape[0], src.shape[1]
-            it.bf16 = (2 if blocked else 1) if outs[0].dtype == torch.bfloat16 else 0
+            it.bf16 = (2 if blocked else 1) if outs[0].dtype == torch.bfloat16 else (3 if blocked else 0)
             self.nbytes += src.numel() * (4 + sum(t.element_size() for t in outs))
 
     def launch(self):
@@ -778,7 +778,8 @@ def conv3_prepared_like(w):
 
 
 # parameter attribute holding an engine-maintained shadow copy, per (arithmetic mode, direction): (name, transposed, dtype)
-_SHADOW = {("fp32", True): ("_micf_wt", True, torch.float32), ("bf16", False): ("_micf_w16", False, torch.bfloat16),
+_SHADOW = {("fp32", False): ("_micf_w32", False, torch.float32), ("fp32", True): ("_micf_wt", True, torch.float32),
+           ("bf16", False): ("_micf_w16", False, torch.bfloat16),
            ("bf16", True): ("_micf_wt16", True, torch.bfloat16)}
 
 
@@ -786,8 +787,7 @@ ENGINE_SHADOWS = False      # set by the engine around its step: the shadow copi
 
 
 def shadow_spec(backward):
-    """(attribute name, transposed, dtype) of the weight copy the fused kernels stream in the current arithmetic mode, or None
-    when they read the parameter itself (fp32 forward)."""
+    """(attribute name, transposed, dtype) of the K16-blocked weight copy the fused kernels stream in the current arithmetic mode."""
     return _SHADOW.get((compute_dtype(), bool(backward)))
 
 

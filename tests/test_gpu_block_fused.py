@@ -221,6 +221,10 @@ def test_weight_prep_blocked_outputs(ops, rows, cols):
     torch.cuda.synchronize()
     assert torch.equal(w16, ops.blocked16(w.to(torch.bfloat16)))
     assert torch.equal(wt16, ops.blocked16(w.t().contiguous().to(torch.bfloat16)))
+    w32, wt32 = ops.shadow_like(w, False, torch.float32), ops.shadow_like(w, True, torch.float32)
+    ops.WeightPrepPlan([(w, w32, wt32)], blocked=True).launch()                  # bf16 = 3: the fp32 mode's blocked copies
+    torch.cuda.synchronize()
+    assert torch.equal(w32, ops.blocked16(w)) and torch.equal(wt32, ops.blocked16(w.t().contiguous()))
     bad = torch.randn(40, 48, device="cuda")
     with pytest.raises(RuntimeError):
         ops.WeightPrepPlan([(bad, ops.shadow_like(bad, False, torch.bfloat16), None)], blocked=True).launch()

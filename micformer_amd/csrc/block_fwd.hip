@@ -79,7 +79,9 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
       // (branch-free: out-of-range lanes read a valid address and drop the value, so all loads of the pass are in flight together)
       const bool ok = tk >= 0 && c4 < C4;
       const int64_t off = (int64_t)(tk >= 0 ? tk : 0) * C + 4 * (c4 < C4 ? c4 : C4 - 1);
-      const float4 xv = ld4g(g.x + off), kv4 = ld4g((g.kvsrc ? g.kvsrc : g.x) + off);
+      const float4 xv = ld4g(g.x + off);
+      float4 kv4 = xv;
+      if (g.kvsrc) kv4 = ld4g(g.kvsrc + off);           // (workgroup-uniform: a self block reads its rows once)
       xr[pass][k] = ok ? xv : make_float4(0.f, 0.f, 0.f, 0.f);
       kvv[pass][k] = ok ? kv4 : make_float4(0.f, 0.f, 0.f, 0.f);
     }

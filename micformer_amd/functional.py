@@ -108,6 +108,8 @@ def _ln_defer(on):
 # gradients queued so far on a side stream, so they run under the rest of the backward chain (which is latency-bound, not
 # throughput-bound, since the blocks were fused) instead of in a tail after it.  join_wgrad_stream() re-joins before Adam.
 FLUSH_POINTS = False
+FLUSH_BUDGET = [1 << 30]            # flush points that may still launch the queued linear weight gradients (the data-parallel step
+                                    # allows the first few only: the rest stays queued for the launches that overlap the all-reduce)
 FLUSH_MAX_TOKENS = int(__import__("os").environ.get("MICF_FLUSH_MAX_TOKENS", 1 << 30))   # (measured: flushing at every point wins, 19.6 vs 20.2 ms small stages only)
 _WSIDE = {}
 _WSIDE_USED = set()
@@ -232,7 +234,8 @@ class FlushPointFn(torch.autograd.Function):
     def backward(ctx, dx, dxa):
         # (a token cap exists for experiments: restricting the flushes to the latency-bound small stages was measured slower --
         # the weight gradients of the big stages then pile up in the tail)
-        if FLUSH_POINTS and DEFER_WGRAD and dx.numel() // dx.shape[-1] <= FLUSH_MAX_TOKENS:
+        if FLUSH_POINTS and DEFER_WGRAD and dx.numel() // dx.shape[-1] <= FLUSH_MAX_TOKENS and FLUSH_BUDGET[0] > 0:
+            FLUSH_BUDGET[0] -= 1
             flush_wgrad_side(lazy=True)
         elif DEFER_CALLS and DEFER_WGRAD:
             flush_wgrad_side(calls_only=True, lazy=True)

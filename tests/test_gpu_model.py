@@ -357,7 +357,8 @@ def test_two_train_steps_against_reference(M):
         close(sub(sd[n]), g["w2." + n], atol=2e-6, rtol=0, what="w2." + n)
 
 
-def test_split_step_matches_fused_step(M):
+@pytest.mark.parametrize("graph_flushes", [0, 6])
+def test_split_step_matches_fused_step(M, graph_flushes):
     """The data-parallel step layout (graph = forward + backward; queued weight gradients launched group by group with the
     per-stage gradient slices all-reduced as they complete; Adam with grad_scale) on ONE rank against the fused single-graph
     step: same parameters after 3 steps.  (The collective itself is a no-op on one rank; its bucket plan is unit-tested on
@@ -369,10 +370,13 @@ def test_split_step_matches_fused_step(M):
     # layout could get wrong is a dropped, stale or doubly-counted weight gradient of a QUEUED layer: an O(1) relative error on
     # that layer's dW / dbias.  Accumulation-order noise is ~1e-4 of a weight gradient's scale (LayerNorm gains with heavy
     # cancellation are noisier, but they are not queued), so 2 % per queued tensor separates the two cleanly.
-    engines = [TrainEngine(build_head(M, 24, (1, 1, 1, 1)), base_lr=1e-9, t_max=9, use_graph=True, split_step=s) for s in (False, True)]
+    # graph_flushes: how many flush points of the backward launch their weight gradients inside the graph (engine default 6);
+    # the rest is queued for the grouped launches after the replay
+    engines = [TrainEngine(build_head(M, 24, (1, 1, 1, 1)), base_lr=1e-9, t_max=9, use_graph=True, split_step=s,
+                           dp_graph_flushes=graph_flushes) for s in (False, True)]
     losses = [e.step(x, t) for e in engines]
     plan = engines[1]._wplan
-    assert plan is not None and plan.n > 50
+    assert plan is not None and plan.n > (50 if graph_flushes == 0 else 10)
     assert min(engines[1]._bucket_last) >= -1 and max(engines[1]._bucket_last) >= 0
     assert sorted(set(engines[1]._bucket_last) - {-1}) == sorted(set(l for l in engines[1]._bucket_last if l >= 0))
     close(losses[1], losses[0], atol=1e-5, what="loss of the replayed step")

@@ -342,6 +342,7 @@ class TrainEngine:
                 self._flush_and_reduce(then_update=True)
             loss = self._static[2]
         self.steps_done += 1
+        ops.PARAM_EPOCH[0] += 1                                     # (copies cached for engine-less forwards are stale now)
         return loss
 
     def _matches_static(self, x, target):

@@ -36,7 +36,11 @@ class GraphedPredictor:
 
     def __call__(self, x):
         from . import ops
-        key = (tuple(x.shape), x.dtype, ops.compute_dtype())     # the arithmetic mode is baked into a captured graph
+        # the arithmetic mode and the cached weight copies are baked into a captured graph: an engine step (PARAM_EPOCH) retires it
+        if getattr(self, "_epoch", None) != ops.PARAM_EPOCH[0]:
+            self.graphs.clear()
+            self._epoch = ops.PARAM_EPOCH[0]
+        key = (tuple(x.shape), x.dtype, ops.compute_dtype())
         entry = self.graphs.get(key)
         if entry is None:
             static_in = x.clone()

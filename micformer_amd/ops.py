@@ -795,22 +795,28 @@ def shadow_like(w, transposed, dtype):
     return torch.empty((w.shape[1], w.shape[0]) if transposed else tuple(w.shape), dtype=dtype, device=w.device)
 
 
+PARAM_EPOCH = [0]           # bumped by TrainEngine after every optimiser step: its Adam kernel writes the parameters without
+                            # touching torch's version counters, so the caches below would otherwise serve pre-step copies
+
+
 def _inference_cache(w, key, build):
     """Shadow copies for forward passes WITHOUT an engine (validation, sliding-window inference under no_grad): built once per
-    weight and kept on the tensor until torch code writes it (version counter).  A captured predictor graph
-    (inference.GraphedPredictor) then replays without any per-window weight preparation.  None when autograd is recording."""
+    weight and kept on the tensor until torch code (version counter) or an engine step (PARAM_EPOCH) writes it.  A captured
+    predictor graph (inference.GraphedPredictor) then replays without any per-window weight preparation.  None when autograd
+    is recording."""
     if torch.is_grad_enabled():
         return None
     cache = w.__dict__.setdefault("_micf_cache", {})
     ent = cache.get(key)
-    if ent is None or ent[0] != w._version:
-        ent = cache[key] = (w._version, build())
+    stamp = (w._version, PARAM_EPOCH[0])
+    if ent is None or ent[0] != stamp:
+        ent = cache[key] = (stamp, build())
     return ent[1]
 
 
 def _conv_layouts(w):
     """(fwd, bwd) prepared layouts of an offset-conv weight: the engine's (refreshed per step), the inference cache's, or None."""
-    f, b = getattr(w, "_micf_c3f", None), getattr(w, "_micf_c3b", None)
+    f, b = (getattr(w, "_micf_c3f", None), getattr(w, "_micf_c3b", None)) if ENGINE_SHADOWS else (None, None)
     if f is None and b is None and w.dim() == 5 and w.shape[0] <= 16:
         def build():
             fb = conv3_prepared_like(w)

@@ -208,3 +208,36 @@ def test_early_adam_over_the_flat_tail_is_the_same_update(M):
         moved = (b.flat_p[lo:hi] - pb[lo:hi]).abs()
         moved = moved[torch.isfinite(moved)]
         assert float(moved.max()) > 1e-3 and float(moved.max()) < 2.5e-3
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_forward_after_engine_steps_uses_the_updated_weights(M, dtype):
+    """The engine's Adam kernel writes the parameters behind torch's back (no version-counter bump).  An engine-less forward
+    after training (validation) must not serve weight copies cached or parked before the update: it has to equal the forward
+    of a fresh model that loaded the trained state_dict."""
+    from micformer_amd import ops
+    from micformer_amd.engine import TrainEngine
+    ops.set_compute_dtype(dtype)
+    try:
+        x, t = _data(2)
+        model = M.Head(embed_dim=48, num_classes=8, depths=(1, 1, 1, 1)).cuda()     # widths the fused kernels take
+        with torch.no_grad():
+            model.eval()
+            before = model(x).clone()                                               # fills the inference caches
+            model.train()
+        eng = TrainEngine(model, base_lr=3e-3, t_max=9, use_graph=True)
+        for _ in range(3):
+            eng.step(x, t)
+        fresh = M.Head(embed_dim=48, num_classes=8, depths=(1, 1, 1, 1)).cuda()
+        fresh.load_state_dict(model.state_dict())
+        with torch.no_grad():
+            model.eval(); fresh.eval()
+            got, want = model(x), fresh(x)
+        assert torch.isfinite(want).all()
+        # fp32: the two forwards are the same arithmetic (atomics order aside); bf16 mode amplifies that noise to ~1e-3 through
+        # rounding flips.  Three Adam steps at lr 3e-3 move the logits by far more than either tolerance (checked).
+        tol = (1e-5 if dtype == "fp32" else 1e-2) * max(1.0, float(want.abs().max()))
+        assert float((want - before).abs().max()) > 20 * tol, "the test needs the training steps to change the output"
+        assert float((got - want).abs().max()) <= tol, "stale weight copies in the forward"
+    finally:
+        ops.set_compute_dtype("fp32")

@@ -1,6 +1,7 @@
 """GPU tests of the step engine's contract with the reference's loop (train.py:183-207): one optimiser update and one
 scheduler tick per batch also on the HIP-graph path (the capture warm-up must not train), ragged last batches, the LR written
 into checkpoints, process-global launch switches scoped to the engine's own step, the HIP DropPath draw, label range guards."""
+import os
 import math
 
 import pytest
@@ -241,3 +242,17 @@ def test_forward_after_engine_steps_uses_the_updated_weights(M, dtype):
         assert float((got - want).abs().max()) <= tol, "stale weight copies in the forward"
     finally:
         ops.set_compute_dtype("fp32")
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_training_script_in_miniature(dtype):
+    """tools/train_synthetic.py end to end on the fused kernels' widths (embed 48): train with the graph engine, validate by
+    sliding-window inference + argmax meandice, save / resume a checkpoint.  Its own assertions: the validation loss falls and
+    the resumed model validates exactly like the trained one (this is what caught stale weight copies after engine steps)."""
+    import json, subprocess, sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "train_synthetic.py")
+    r = subprocess.run([sys.executable, tool, "--dtype", dtype, "--embed-dim", "48", "--vol", "64", "--steps", "60",
+                        "--out", f"/tmp/micf_test_{dtype}.pth.tar"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["val_loss"][1] < out["val_loss"][0] and abs(out["resumed_val_meandice"] - out["val_meandice"][1]) < 1e-3

@@ -399,6 +399,43 @@ def test_split_step_matches_fused_step(M, graph_flushes):
         assert torch.isfinite(sc_[k]).all() and float((sa[k] - sc_[k]).abs().max()) < 1e-7, k
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_step_layouts_agree_at_fused_widths(M, dtype):
+    """embed 48 (every transformer block runs on the fused kernels; K16-blocked shadow weights, lazy flush points, the side-stream
+    anchor, early Adam, in-graph flushes of the data-parallel layout): the eager engine, the single-graph engine, the graph engine
+    without early Adam and the data-parallel layout must compute the same step -- same loss and the same flat gradient buffer
+    from the same weights and data (a vanishing learning rate keeps the weights equal over the 3 steps; a dropped, stale or
+    doubly-launched group of weight gradients is an O(1) error on its slice, accumulation-order noise ~1e-4 of the scale)."""
+    from micformer_amd import ops
+    from micformer_amd.engine import TrainEngine
+    ops.set_compute_dtype(dtype)
+    try:
+        x = fill.make_volume(2, 64, 64, 64).cuda()
+        t = fill.one_hot(fill.make_label_map(2, 64, 64, 64)).cuda()
+        cfgs = [dict(use_graph=False), dict(use_graph=True), dict(use_graph=True, split_step=True),
+                dict(use_graph=True, early_adam=False)]
+        engines = [TrainEngine(build_head(M, 48, (1, 1, 1, 1)), base_lr=1e-9, t_max=9, **c) for c in cfgs]
+        for _ in range(3):
+            losses = [float(e.step(x, t)) for e in engines]
+        torch.cuda.synchronize()
+        g0 = engines[0].flat_g
+        scale = float(g0.abs().max())
+        assert math.isfinite(scale) and scale > 0
+        tol = 2e-2 if dtype == "fp32" else 6e-2
+        for e, c, l in zip(engines[1:], cfgs[1:], losses[1:]):
+            assert abs(l - losses[0]) <= (1e-5 if dtype == "fp32" else 2e-3), f"{c}: loss {l} vs {losses[0]}"
+            assert torch.isfinite(e.flat_g).all()
+            # per parameter tensor, against that tensor's own gradient scale
+            for o, n in zip(e.offsets, e.sizes):
+                ref, got = g0[o:o + n], e.flat_g[o:o + n]
+                sc = float(ref.abs().max())
+                floor = (1e-6 if dtype == "fp32" else 5e-5) * scale      # (tensors whose whole gradient is rounding-level small)
+                assert float((ref - got).abs().max()) <= tol * sc + floor, f"{c}: gradient slice at {o} (+{n})"
+            assert int(e.adam_state[0].item()) == 3
+    finally:
+        ops.set_compute_dtype("fp32")
+
+
 def test_split_step_with_rccl_on_one_rank(M):
     """The overlapped data-parallel step with REAL RCCL calls: a one-rank `nccl` process group, collectives forced on
     (`always_collective`), so the async all-reduces of the gradient slices, their stream ordering against the grouped

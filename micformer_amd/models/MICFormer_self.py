@@ -226,8 +226,9 @@ class LayerNormProxy(nn.Module):
 
 # Run the two modalities' independent blocks on two HIP streams (engine / bench switch; off = the reference's serial order).
 PARALLEL_MODALITIES = False
-# backward flush points inside a stage: every SLOT_FLUSH_STRIDE-th depth slot (measured at base / 128^3: 1 -> 15.2 ms, 2 -> 15.3,
-# 3 -> 14.8, 4 -> 14.9, none -> 15.5: one flush in the middle of the six-slot stage, none inside the two-slot stages)
+# backward flush points inside a stage: every SLOT_FLUSH_STRIDE-th depth slot (measured at base / 128^3 at the end of round 2:
+# 1 -> 15.8 ms (the captured graph then replays side and main work serially), 2 -> 12.6, 3 -> 12.6, 4 -> 12.7, none -> 14.0:
+# one flush in the middle of the six-slot stage, none inside the two-slot stages)
 SLOT_FLUSH_STRIDE = int(__import__("os").environ.get("MICF_SLOT_FLUSH_STRIDE", "3"))
 # Head: run reverse_patch_embedding + out_conv as their composition (off = the reference's two separate convolutions).
 FUSE_HEAD_TAIL = True

@@ -131,6 +131,46 @@ __global__ void __launch_bounds__(256) tail_im2col_kernel(const float* __restric
   }
 }
 
+// The same for 8 classes, patch 4 and rows of TW = 8 coarse voxels along W: the fine region the 8 patches cover
+// ([8 classes][6][6][34] floats = 38 KB) goes through LDS, so dy is read in 34-float runs instead of the 6-float runs of the
+// per-(q, f) gather, and U is written as one contiguous 54 KB block.
+constexpr int kImTW = 8, kImP = 4, kImF = kImP + 2, kImCO = 8, kImX = kImTW * kImP + 2;
+__global__ void __launch_bounds__(256) tail_im2col_rows_kernel(const float* __restrict__ dy, float* __restrict__ U, int B, int Dc,
+                                                               int Hc, int Wc) {
+  __shared__ float s[kImCO * kImF * kImF * kImX];
+  const int Df = Dc * kImP, Hf = Hc * kImP, Wf = Wc * kImP;
+  const int64_t plane = (int64_t)Df * Hf * Wf;
+  const int wt = Wc / kImTW;
+  int r = blockIdx.x;
+  const int qw0 = (r % wt) * kImTW; r /= wt;
+  const int qh = r % Hc; r /= Hc;
+  const int qd = r % Dc;
+  const int b = r / Dc;
+  const float* src = dy + (int64_t)b * kImCO * plane;
+  for (int i = threadIdx.x; i < kImCO * kImF * kImF * kImX; i += 256) {
+    const int x = i % kImX;
+    int t = i / kImX;
+    const int fh = t % kImF; t /= kImF;
+    const int fd = t % kImF;
+    const int o = t / kImF;
+    const int ud = qd * kImP - 1 + fd, uh = qh * kImP - 1 + fh, uw = qw0 * kImP - 1 + x;
+    const bool in = ud >= 0 && ud < Df && uh >= 0 && uh < Hf && uw >= 0 && uw < Wf;
+    s[i] = in ? src[(int64_t)o * plane + ((int64_t)ud * Hf + uh) * Wf + uw] : 0.f;
+  }
+  __syncthreads();
+  constexpr int F3 = kImF * kImF * kImF;
+  const int64_t q0 = (((int64_t)b * Dc + qd) * Hc + qh) * Wc + qw0;
+  float* dst = U + q0 * F3 * kImCO;
+  for (int i = threadIdx.x; i < kImTW * F3 * (kImCO / 4); i += 256) {       // one float4 (4 classes) per item, contiguous in U
+    const int oh = i & 1;
+    const int f = (i >> 1) % F3, tq = (i >> 1) / F3;
+    const int fw = f % kImF, fh = (f / kImF) % kImF, fd = f / (kImF * kImF);
+    const float* p = s + ((4 * oh * kImF + fd) * kImF + fh) * kImX + tq * kImP + fw;
+    constexpr int OS = kImF * kImF * kImX;
+    *reinterpret_cast<float4*>(dst + 4 * (int64_t)i) = make_float4(p[0], p[OS], p[2 * OS], p[3 * OS]);
+  }
+}
+
 // dW_up[k, c, p] += sum_{t, o} dWb[f(p,t), o, k] W_out[o, c, t]      (k == Ci: db_up[c] += sum_p of the same with dBf)
 // one thread per (k, c, p), p fastest
 __global__ void __launch_bounds__(256) tail_dwup_kernel(const float* __restrict__ dwb, const float* __restrict__ dbf,
@@ -231,7 +271,9 @@ extern "C" int micf_head_tail_im2col(const float* dy, float* u, int B, int Dc, i
   const int64_t total = (int64_t)B * Dc * Hc * Wc * F * F * F;
   const unsigned blocks = (unsigned)((total + 255) / 256);
   hipStream_t s = (hipStream_t)stream;
-  if (Co == 8 && aligned16(u)) hipLaunchKernelGGL(tail_im2col_kernel<8>, dim3(blocks), dim3(256), 0, s, dy, u, B, Dc, Hc, Wc, Co, P);
+  if (Co == kImCO && P == kImP && Wc % kImTW == 0 && aligned16(u))
+    hipLaunchKernelGGL(tail_im2col_rows_kernel, dim3((unsigned)((int64_t)B * Dc * Hc * (Wc / kImTW))), dim3(256), 0, s, dy, u, B, Dc, Hc, Wc);
+  else if (Co == 8 && aligned16(u)) hipLaunchKernelGGL(tail_im2col_kernel<8>, dim3(blocks), dim3(256), 0, s, dy, u, B, Dc, Hc, Wc, Co, P);
   else hipLaunchKernelGGL(tail_im2col_kernel<0>, dim3(blocks), dim3(256), 0, s, dy, u, B, Dc, Hc, Wc, Co, P);
   MICF_RETURN_LAUNCH();
 }

@@ -181,7 +181,8 @@ def test_linear_bwd_weight_grouped(ops):
 
 
 @pytest.mark.parametrize("dims,Ci,Cm,Co,P", [((2, 3, 2, 4), 96, 24, 8, 4), ((1, 1, 1, 1), 48, 12, 8, 4), ((1, 2, 3, 1), 48, 12, 14, 4),
-                                             ((1, 3, 3, 3), 32, 8, 5, 2), ((1, 4, 4, 4), 96, 24, 8, 4)])
+                                             ((1, 3, 3, 3), 32, 8, 5, 2), ((1, 4, 4, 4), 96, 24, 8, 4),
+                                             ((1, 2, 3, 8), 48, 12, 8, 4), ((2, 2, 2, 16), 96, 24, 8, 4)])   # (W % 8 == 0: im2col via LDS)
 def test_head_tail_composed(dims, Ci, Cm, Co, P):
     """HeadTailFn (ConvTranspose3d(k=s=P) + Conv3d(3, pad 1) composed, csrc/head_tail.hip) against the two torch convolutions:
     logits and all five gradients."""

@@ -33,7 +33,12 @@ struct LinFwdEpi {
         const float4 r = ld4(resid + o);
         v[0] = r.x + s * v[0]; v[1] = r.y + s * v[1]; v[2] = r.z + s * v[2]; v[3] = r.w + s * v[3];
       }
-      st4(y + o, v[0], v[1], v[2], v[3]);
+      if (vec == 2) {          // output larger than the 256 MB MALL (the composed head's patch matrix): stream it past the caches
+        typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(f32x4_nt{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4_nt*>(y + o));
+      } else {
+        st4(y + o, v[0], v[1], v[2], v[3]);
+      }
     } else {
       MICF_FOR_N(n, e) {
         float t = v[e] + (bias ? bias[i + e] : 0.f);
@@ -199,7 +204,8 @@ extern "C" int micf_linear_fwd(const float* a1, const float* a2, int k1, const f
     if (!a2 && N >= 48 && M >= 64 && dma_ok(P, false, Q, false, K, K)) {
       if (act) return RC((launch_gemm_dma<false, false>(P, Q, LinFwdEpi<1, 0>{bias, nullptr, nullptr, rps, y, pre_act, N, evec}, N, M, K, 1, s, nullptr, dtype)));
       if (resid) return RC((launch_gemm_dma<false, false>(P, Q, LinFwdEpi<0, 1>{bias, resid, dp_scale, rps, y, nullptr, N, evec}, N, M, K, 1, s, nullptr, dtype)));
-      return RC((launch_gemm_dma<false, false>(P, Q, LinFwdEpi<0, 0>{bias, nullptr, nullptr, rps, y, nullptr, N, evec}, N, M, K, 1, s, nullptr, dtype)));
+      const int big = (evec && (int64_t)M * N * (int64_t)sizeof(float) > ((int64_t)256 << 20)) ? 2 : evec;
+      return RC((launch_gemm_dma<false, false>(P, Q, LinFwdEpi<0, 0>{bias, nullptr, nullptr, rps, y, nullptr, N, big}, N, M, K, 1, s, nullptr, dtype)));
     }
   }
   if (act) return RC(launch_gemm(pa, qa, LinFwdEpi<1, 0>{bias, nullptr, nullptr, rps, y, pre_act, N, evec}, N, M, K, 1, s));

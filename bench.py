@@ -75,34 +75,77 @@ def path_bytes(embed_dim, depths, vol, batch, elem_bytes, block_param_count):
     return 26 * sigma * elem_bytes * batch + 2 * block_param_count * elem_bytes, sigma
 
 
-def cpu_baseline(vol, threads):
-    """The CPU restatement (oracle/, 'port') timed on the host cores: ONE real train step (fwd + MDiceLoss + bwd + Adam) of
-    the base model on ONE full-size CT+MR pair (B = 1) -- the same workload unit the GPU number counts -- after one small
-    warm-up step (thread pools, allocator).  Bounded: a single step is ~20-30 s on the GPU box's cores."""
+def host_cpu():
+    """(model name, physical cores, logical cpus) of the host from /proc/cpuinfo."""
+    model, cores, logical = "unknown", set(), 0
+    try:
+        phys = core = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                k, _, v = line.partition(":")
+                k, v = k.strip(), v.strip()
+                if k == "processor":
+                    logical += 1
+                elif k == "model name":
+                    model = v
+                elif k == "physical id":
+                    phys = v
+                elif k == "core id":
+                    core = v
+                elif not k and phys is not None:
+                    cores.add((phys, core))
+                    phys = core = None
+            if phys is not None:
+                cores.add((phys, core))
+    except OSError:
+        pass
+    logical = logical or (os.cpu_count() or 1)
+    return model, (len(cores) or logical), logical
+
+
+def cpu_baseline(vol, timed=3, budget_s=240.0, batches=(1, 2)):
+    """the CPU restatement (oracle/, kind 'port') timed on ALL PHYSICAL host cores: the identical train
+    step (fwd + MDiceLoss + bwd + Adam, fp32) of the base model on full-size CT+MR pairs at B = 1 and B = 2, one untimed
+    full-size warm-up step, then `timed` steps each, median.  `value` is the better of the two batch sizes in pairs/s (the unit
+    the GPU value counts).  Bounded: timing stops early (and says so) once `budget_s` of CPU work is spent."""
+    import statistics
     import torch
     from oracle import micformer_ref as R
     from oracle.shapes import filled_params
-    threads = max(1, min(threads, 64))          # torch CPU ops stop scaling (and oversubscribe SMT siblings) beyond this
+    model, phys, logical = host_cpu()
+    threads = max(1, phys)
     torch.set_num_threads(threads)
     cfg = R.Cfg()
-    P = filled_params(cfg)
     g = torch.Generator().manual_seed(1234)
 
-    def batch(v):
-        x = torch.randn((1, 2) + v, generator=g)
-        lab = torch.randint(0, 8, (1,) + v, generator=g)
+    def batch(b, v):
+        x = torch.randn((b, 2) + v, generator=g)
+        lab = torch.randint(0, 8, (b,) + v, generator=g)
         return x, torch.nn.functional.one_hot(lab, 8).permute(0, 4, 1, 2, 3).float().contiguous()
 
-    R.train_step(P, {}, *batch((64, 64, 64)), cfg, step=1)           # warm-up, untimed (thread pools, allocator)
+    t_start = time.perf_counter()
     P = filled_params(cfg)
-    x, tgt = batch(vol)
-    t0 = time.perf_counter()
-    R.train_step(P, {}, x, tgt, cfg, step=1)
-    dt = time.perf_counter() - t0
-    return {"value": round(1.0 / dt, 4), "unit": "pairs/s", "cores": threads, "kind": "port",
-            "sample": f"1 full fp32 train step (fwd+loss+bwd+Adam) of MicFormer base on one {vol[0]}^3 CT+MR pair (B=1, the "
-                      f"unit the GPU value counts), oracle/ torch CPU ops, {threads} threads, after one untimed 64^3 warm-up "
-                      f"step: {dt:.2f} s"}
+    R.train_step(P, {}, *batch(1, vol), cfg, step=1)                 # warm-up at full size, untimed (thread pools, allocator)
+    per_batch, notes = {}, []
+    for b in batches:
+        x, tgt = batch(b, vol)
+        P, state, times = filled_params(cfg), {}, []
+        for k in range(timed):
+            if times and time.perf_counter() - t_start > budget_s:
+                notes.append(f"B={b}: stopped after {len(times)} timed steps (CPU budget {budget_s:.0f} s)")
+                break
+            t0 = time.perf_counter()
+            R.train_step(P, state, x, tgt, cfg, step=k + 1)
+            times.append(time.perf_counter() - t0)
+        per_batch[b] = {"median_s_per_step": round(statistics.median(times), 3), "timed_steps": len(times),
+                        "pairs_per_s": round(b / statistics.median(times), 4)}
+    best = max(v["pairs_per_s"] for v in per_batch.values())
+    return {"value": best, "unit": "pairs/s", "cores": threads, "kind": "port", "cpu_model": model,
+            "physical_cores": phys, "logical_cpus": logical, "by_batch": {f"B={b}": v for b, v in per_batch.items()},
+            "sample": f"full fp32 train steps (fwd+loss+bwd+Adam, lr 1e-4, cosine per iteration) of MicFormer base on {vol[0]}^3 CT+MR "
+                      f"pairs, oracle/ torch CPU ops on {threads} threads (= physical cores of {model}); 1 untimed full-size "
+                      f"warm-up step, then median of {timed} timed steps at B=1 and at B=2; value = the better pairs/s"
+                      + ("; " + "; ".join(notes) if notes else "")}
 
 
 class _StubEngine:
@@ -140,6 +183,8 @@ def main(argv=None):
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-baseline steps per batch size (median is reported)")
+    ap.add_argument("--cpu-budget-s", type=float, default=240.0, help="stop timing further CPU steps once this much CPU time is spent")
     ap.add_argument("--serial-modalities", action="store_true", help="do not overlap the CT / MR branches on two streams")
     ap.add_argument("--detail", action="store_true", help="roofline leg: key kernels by shape too (diagnostic)")
     ap.add_argument("--eval-mode", action="store_true", help="DropPath off (default: train mode, DropPath active)")
@@ -257,29 +302,43 @@ def main(argv=None):
         gbs = top["bytes"] / sec / 1e9
         tfl = top["flops"] / sec / 1e12
         frac_hbm, frac_mfma = gbs / HBM_PEAK_GBS, tfl / mfma_peak
-        # the bound that applies is the one the kernel's arithmetic intensity puts it under
-        ai = top["flops"] / max(top["bytes"], 1)
+        # The fraction reported is SURVEY.md 8(d)'s: ALGORITHMIC bytes of the launch (for a transformer-block launch the ideal-
+        # fusion activation passes + the block's weights at the element size of the arithmetic mode, ops._block_cost; for any
+        # other launch every tensor once) over the measured launch time, against the HBM peak.  What the kernel itself moves
+        # (it also writes what its backward / the weight gradients re-read, in the element sizes actually stored) is reported
+        # as `own_traffic_bytes_per_launch` / `hbm_util`; `traffic` is the PMC-measured HBM bytes per launch.
+        s8d = top.get("s8d_bytes", 0)
+        algo = s8d if s8d > 0 else top["bytes"]
+        algo_gbs = algo / sec / 1e9
+        ai = top["flops"] / max(algo, 1)
         ridge = mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9)
         if ai > ridge:
             roof = {"bound": "mfma", "achieved": round(tfl, 3), "peak": mfma_peak, "unit": "TFLOP/s", "frac": round(frac_mfma, 4)}
         else:
-            roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(frac_hbm, 4)}
-        roof.update({"traffic": pmc_traffic(name), "kernel": name, "launches_per_step": per // nprof,
+            roof = {"bound": "hbm", "achieved": round(algo_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(algo_gbs / HBM_PEAK_GBS, 4)}
+        traffic = pmc_traffic(name)
+        roof.update({"traffic": traffic, "kernel": name, "launches_per_step": per // nprof,
                      "avg_launch_us": round(1e3 * top["ms"] / per, 2),
                      "share_of_kernel_time": round(top["ms"] / total_ms, 4),
-                     "algorithmic_bytes_per_launch": top["bytes"] // per, "flops_per_launch": top["flops"] // per,
-                     "hbm_frac": round(frac_hbm, 4), "mfma_frac": round(frac_mfma, 4)})
+                     "algorithmic_bytes_per_launch": algo // per,
+                     "algorithmic_rule": ("SURVEY 8(d): self block 2 fwd / 3 bwd, cross block 3 fwd / 5 bwd passes of T*C*e per "
+                                          "modality + block weights once, e = %d B" % e) if s8d > 0 else "every tensor of the launch once",
+                     "own_traffic_bytes_per_launch": top["bytes"] // per, "flops_per_launch": top["flops"] // per,
+                     "hbm_util": round(frac_hbm, 4), "mfma_frac": round(frac_mfma, 4),
+                     "traffic_over_algorithmic": round(traffic / (algo / per), 2) if traffic else None})
         # whole-step view: entry points (all shapes merged), algorithmic bytes / flops over the sum of their event times
         merged = {}
         for k, v in prof.items():
-            m = merged.setdefault(k.split("|")[0], dict(calls=0, ms=0.0, bytes=0, flops=0))
-            for f in ("calls", "ms", "bytes", "flops"):
-                m[f] += v[f]
+            m = merged.setdefault(k.split("|")[0], dict(calls=0, ms=0.0, bytes=0, flops=0, s8d_bytes=0))
+            for f in ("calls", "ms", "bytes", "flops", "s8d_bytes"):
+                m[f] += v.get(f, 0)
         fam_name, fam = max(merged.items(), key=lambda kv: kv[1]["ms"])
         roof["family"] = {"kernel": fam_name, "ms_per_step": round(fam["ms"] / nprof, 3), "calls_per_step": fam["calls"] // nprof,
                           "GB/s": round(fam["bytes"] / max(fam["ms"], 1e-9) / 1e6, 1),
                           "TFLOP/s": round(fam["flops"] / max(fam["ms"], 1e-9) / 1e9, 2),
-                          "hbm_frac": round(fam["bytes"] / max(fam["ms"], 1e-9) / 1e6 / HBM_PEAK_GBS, 4),
+                          "hbm_util": round(fam["bytes"] / max(fam["ms"], 1e-9) / 1e6 / HBM_PEAK_GBS, 4),
+                          "frac_8d": round(fam.get("s8d_bytes", 0) / max(fam["ms"], 1e-9) / 1e6 / HBM_PEAK_GBS, 4),
                           "share_of_kernel_time": round(fam["ms"] / total_ms, 4)}
         # SURVEY.md 8(d) "attention path's HBM roofline": ideal-fusion bytes of the transformer blocks over the time the step
         # spends in them = replayed step wall minus the event time of everything that is NOT a block kernel (patch embed /
@@ -312,7 +371,7 @@ def main(argv=None):
 
     if rank == 0:
         if not args.no_cpu_baseline and world == 1 and not stub:
-            out["cpu_baseline"] = cpu_baseline(vol, os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(vol, timed=args.cpu_steps, budget_s=args.cpu_budget_s)
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

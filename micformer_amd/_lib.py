@@ -224,7 +224,9 @@ class block_region:
 
 
 def call(name, *args, cost=None):
-    """Launch one C-ABI entry point on torch's current stream.  cost = (algorithmic bytes, flops) for the profiler."""
+    """Launch one C-ABI entry point on torch's current stream.  cost = (bytes the launch itself moves with every tensor touched
+    once, flops[, shape tag[, SURVEY 8(d) bytes]]) for the profiler; the 8(d) bytes are the ideal-fusion activation passes + block
+    weights of a transformer-block launch (None for everything that is not one)."""
     if PROFILE is None:
         rc = getattr(lib, name)(*args, stream())
     else:
@@ -232,12 +234,14 @@ def call(name, *args, cost=None):
         e0.record()
         rc = getattr(lib, name)(*args, stream())
         e1.record()
-        key = name if (cost is None or len(cost) < 3) else f"{name}|{cost[2]}"
-        rec = PROFILE.setdefault(key, [[], 0, 0])
+        key = name if (cost is None or len(cost) < 3 or cost[2] is None) else f"{name}|{cost[2]}"
+        rec = PROFILE.setdefault(key, [[], 0, 0, 0])
         rec[0].append((e0, e1, BLOCK_DEPTH > 0))
         if cost is not None:
             rec[1] += cost[0]
             rec[2] += cost[1]
+            if len(cost) > 3 and cost[3] is not None:
+                rec[3] += cost[3]
     if rc != 0:
         raise MicfError(f"{name} failed: {lib.micf_strerror(rc).decode()} (code {rc})")
 
@@ -253,9 +257,10 @@ def profile_stop():
     prof, PROFILE = PROFILE, None
     torch.cuda.synchronize()
     out = {}
-    for name, (evs, nbytes, flops) in (prof or {}).items():
+    for name, (evs, nbytes, flops, s8d) in (prof or {}).items():
         ms = [(a.elapsed_time(b), blk) for a, b, blk in evs]
-        out[name] = dict(calls=len(evs), ms=sum(m for m, _ in ms), bytes=nbytes, flops=flops, block_ms=sum(m for m, blk in ms if blk))
+        out[name] = dict(calls=len(evs), ms=sum(m for m, _ in ms), bytes=nbytes, flops=flops, block_ms=sum(m for m, blk in ms if blk),
+                         s8d_bytes=s8d)
     return out
 
 

@@ -24,7 +24,7 @@ class TrainEngine:
     def __init__(self, model, base_lr=1e-4, t_max=150, eta_min=0.0, betas=(0.9, 0.999), eps=1e-8, criterion=None,
                  use_graph=False, process_group=None, grad_bucket_bytes=64 << 20, parallel_modalities=True,
                  defer_wgrad=True, split_step=None, always_collective=False, flush_points=True, early_adam=True,
-                 dp_graph_flushes=6):
+                 dp_graph_flushes=6, grad_bf16=False):
         self.model = model
         self.criterion = criterion if criterion is not None else MDiceLoss()
         self.base_lr, self.t_max, self.eta_min = base_lr, t_max, eta_min
@@ -51,10 +51,15 @@ class TrainEngine:
         # (encoder) weight-gradient groups that are launched after the replay.  Measured on one GPU (data-parallel layout):
         # 0 -> 13.3 ms, 4 -> 12.9, 6 -> 12.8, all -> 12.7 (but then nothing is left to hide RCCL behind).
         self.dp_graph_flushes = int(__import__("os").environ.get("MICF_DP_GRAPH_FLUSHES", dp_graph_flushes))
+        # Optional bf16 wire format of the gradient exchange (123 MB instead of 247 MB per step at base): each slice is rounded
+        # to bf16, sum-reduced, widened back; Adam still reads fp32.  Off by default (the fp32 exchange is exact).
+        self.grad_bf16 = bool(grad_bf16)
+        self._wire = torch.empty(self.flat_g.numel(), dtype=torch.bfloat16, device=self.flat_g.device) if self.grad_bf16 else None
         self._wplan = None
         self.use_graph = use_graph
         self._graph = None
         self._static = None
+        self._static_mode = None
         self.steps_done = 0
 
     # ------------------------------------------------------------------ flat parameter / gradient storage
@@ -118,7 +123,7 @@ class TrainEngine:
                     self._early_cut, self._early_layer = cut, stages[len(stages) - 1]
         # What the fused kernels stream instead of the parameters themselves, all refreshed once per step (the weights only
         # change in Adam):
-        #   * bf16 mode, forward: bf16 copies of the block linears' weights in the K16-blocked order the kernels' matrix-core
+        #   * forward: copies of the block linears' weights (bf16 in bf16 mode, fp32 otherwise) in the K16-blocked order the kernels' matrix-core
         #     fragments read (one grouped launch on a side stream in front of the forward, joined at the first stage);
         #   * backward: transposed copies of the same weights (W^T fp32 row-major, or bf16 K16-blocked) -- one grouped launch
         #     on a side stream, issued when the forward reaches the small stages, next to the zero fill of the gradient buffer;
@@ -140,8 +145,10 @@ class TrainEngine:
         if plans is None:
             ws = [p for _, p in self._shadow_w]
             offs, total = flatten_views(ws, align=8)
+            # Forward copies: the fused kernels only stream K16-blocked operands, so BOTH modes have one (bf16 mode: bf16, half the
+            # parameter bytes; fp32 mode: a second full fp32 copy of the block weights, 4 B / parameter, rewritten every step).
             fwd, spec = None, ops.shadow_spec(False)
-            if spec is not None:                                      # bf16 forward
+            if spec is not None:
                 buf = self._shadow_bufs[spec[0]] = torch.empty(max(total, 8), dtype=spec[2], device=self.flat_p.device)
                 ftrip = []
                 for p, o in zip(ws, offs):
@@ -173,6 +180,7 @@ class TrainEngine:
         @contextlib.contextmanager
         def scope():
             prev = (_ms.PARALLEL_MODALITIES, _fn.DEFER_WGRAD, _fn.FLUSH_POINTS, _fn.DEFER_CALLS, ops.ENGINE_SHADOWS)
+            prev_budget = _fn.FLUSH_BUDGET[0]
             _ms.PARALLEL_MODALITIES, _fn.DEFER_WGRAD = self.parallel_modalities, self.defer_wgrad
             _fn.FLUSH_POINTS = self.defer_wgrad and self.flush_points and (not self.split_step or self.dp_graph_flushes > 0)
             _fn.FLUSH_BUDGET[0] = self.dp_graph_flushes if self.split_step else 1 << 30
@@ -182,6 +190,7 @@ class TrainEngine:
                 yield
             finally:
                 _ms.PARALLEL_MODALITIES, _fn.DEFER_WGRAD, _fn.FLUSH_POINTS, _fn.DEFER_CALLS, ops.ENGINE_SHADOWS = prev
+                _fn.FLUSH_BUDGET[0] = prev_budget
         return scope()
 
     def _fwd_bwd(self, x, target, flush=True):
@@ -192,7 +201,7 @@ class TrainEngine:
             main, side = torch.cuda.current_stream(), self._prep_stream
             _fn.clear_entry_hooks()
             conv.launch()                                           # offset-conv weight layouts (one small launch)
-            if fwd is not None:                                     # bf16 block weights, next to the patch embedding
+            if fwd is not None:                                     # K16-blocked block weights, next to the patch embedding
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     fwd.launch()
@@ -206,7 +215,11 @@ class TrainEngine:
             _fn.park_entry_hook(backward_prep, at=3)
             _fn.BACKWARD_HOOKS.clear()
             self._adam_tail_done = False
-            if flush and self.world == 1 and self._early_cut is not None and self.early_adam:
+            # Early Adam reads the tail of the flat gradient mid-backward: only valid when the flush point that fires it has
+            # launched EVERY weight gradient queued so far (flush points on, unbounded budget, no token cap) -- otherwise the
+            # linear / LayerNorm gradients of the tail would still sit in the queue and be applied one step late, never.
+            full_flush = _fn.FLUSH_POINTS and _fn.FLUSH_BUDGET[0] >= (1 << 30) and _fn.FLUSH_MAX_TOKENS >= (1 << 30)
+            if flush and self.world == 1 and self._early_cut is not None and self.early_adam and full_flush:
                 _fn.BACKWARD_HOOKS[id(self._early_layer)] = self._early_adam
             elif self._anchor_layer is not None:
                 _fn.BACKWARD_HOOKS[id(self._anchor_layer)] = self._side_anchor
@@ -288,7 +301,7 @@ class TrainEngine:
                 if t is not None:
                     writes.append((k // ops.GROUP_ITEMS, (t.data_ptr() - base) // 4, t.numel()))
         self._bucket_last = last_writer_per_bucket(self._buckets, writes)
-        self._overlap = OverlappedGradReduce(self.sync, self.flat_g, self._buckets, self._bucket_last)
+        self._overlap = OverlappedGradReduce(self.sync, self.flat_g, self._buckets, self._bucket_last, wire=self._wire)
 
     def _flush_and_reduce(self, then_update=False):
         """Launch the queued weight gradients group by group; all-reduce every slice of the flat gradient right after the
@@ -318,11 +331,17 @@ class TrainEngine:
 
     def _allreduce_grads(self):
         """Gradient all-reduce(sum) over RCCL/xGMI in a few large buckets of the flat buffer (the 1/world goes into Adam)."""
-        works = [self.sync.allreduce_sum_async(self.flat_g[s:s + self.sync.bucket_elems])
-                 for s in range(0, self.flat_g.numel(), self.sync.bucket_elems)]
+        buf = self.flat_g
+        if self._wire is not None:
+            self._wire.copy_(self.flat_g)
+            buf = self._wire
+        works = [self.sync.allreduce_sum_async(buf[s:s + self.sync.bucket_elems])
+                 for s in range(0, buf.numel(), self.sync.bucket_elems)]
         for w in works:
             if w is not None:
                 w.wait()
+        if self._wire is not None:
+            self.flat_g.copy_(self._wire)
 
     def step(self, x, target):
         """Run one training step; returns the (device) loss of this rank's batch."""
@@ -347,7 +366,15 @@ class TrainEngine:
 
     def _matches_static(self, x, target):
         sx, st = self._static[0], self._static[1]
-        return x.shape == sx.shape and target.shape == st.shape and x.dtype == sx.dtype and target.dtype == st.dtype
+        ok = x.shape == sx.shape and target.shape == st.shape and x.dtype == sx.dtype and target.dtype == st.dtype \
+            and self._static_mode == ops.compute_dtype()            # (the arithmetic mode is baked into the captured launches)
+        if self.world > 1:
+            # Data parallel: the replayed step and the eager step cut the gradient exchange differently (per-stage slices vs
+            # whole-buffer buckets), so every rank must take the same path: ONE small all-reduce(MIN) of the flag per step.
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=x.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.sync.pg)
+            ok = bool(flag.item())
+        return ok
 
     def _capture(self, x, target):
         """Warm up eagerly on a side stream, then capture ONE step into a HIP graph.  The warm-up runs real kernels (it sizes the
@@ -356,6 +383,10 @@ class TrainEngine:
         (the reference does one optimizer.step() + scheduler.step() per batch, train.py:200-207)."""
         sx, st = x.clone(), target.clone()
         keep = [t.clone() for t in (self.flat_p, self.flat_m, self.flat_v, self.adam_state)]
+        # (the DropPath stream lives on the device -- seed + counter, created on first use from torch's CPU generator: create it
+        # BEFORE the snapshot so the warm-up neither draws its seed nor advances its counter for good)
+        dp_rng = self._drop_path_rng_tensors(sx)
+        dp_keep = [t.clone() for t in dp_rng]
         rng_cpu, rng_dev = torch.get_rng_state(), torch.cuda.get_rng_state(sx.device)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -366,6 +397,8 @@ class TrainEngine:
         torch.cuda.synchronize()
         with torch.no_grad():
             for dst, src in zip((self.flat_p, self.flat_m, self.flat_v, self.adam_state), keep):
+                dst.copy_(src)
+            for dst, src in zip(dp_rng, dp_keep):
                 dst.copy_(src)
         torch.set_rng_state(rng_cpu)
         torch.cuda.set_rng_state(rng_dev, sx.device)
@@ -378,7 +411,25 @@ class TrainEngine:
         if self.split_step:
             from . import functional as _fn
             self._plan_split(*_fn.take_deferred())                  # (capture records, it does not run: step() replays next)
-        self._graph, self._static = g, (sx, st, sl)
+        self._graph, self._static, self._static_mode = g, (sx, st, sl), ops.compute_dtype()
+
+    def _drop_path_rng_tensors(self, x):
+        """The device-side DropPath RNG states ({seed, counter}) of the model, created now if the model is in train mode and has
+        not drawn yet."""
+        out = []
+        for m in self.model.modules():
+            pre = getattr(m, "_predraw_drop_path", None)
+            if pre is None:
+                continue
+            if m.training and not m.__dict__.get("_dp_keep_cache", {}).get(x.device):
+                pre(x.shape[0], x.device)                           # creates the entry (one draw; restored below)
+                ent = m.__dict__.get("_dp_keep_cache", {}).get(x.device)
+                if ent is not None:
+                    ent[1][1] = 0                                   # counter back to the fresh state
+            ent = m.__dict__.get("_dp_keep_cache", {}).get(x.device)
+            if ent is not None:
+                out.append(ent[1])
+        return out
 
     # ------------------------------------------------------------------ checkpoints (utils.py:57-65, 108-138)
     def optimizer_state_dict(self):
@@ -437,6 +488,7 @@ class TrainEngine:
                 raise KeyError(f"state_dict keys differ: {sorted(missing)[:5]} ...")
             for k, v in ckpt["state_dict"].items():
                 own[k].copy_(v)
+        ops.PARAM_EPOCH[0] += 1                                     # weight copies cached for engine-less forwards are stale
         if "optimizer" in ckpt:
             self.load_optimizer_state_dict(ckpt["optimizer"])
         if "scheduler" in ckpt:

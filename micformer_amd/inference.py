@@ -34,12 +34,21 @@ class GraphedPredictor:
     def __init__(self, predictor, warmup=2):
         self.predictor, self.warmup, self.graphs = predictor, warmup, {}
 
+    def _param_versions(self):
+        params = getattr(self.predictor, "parameters", None)
+        if params is None:
+            return 0
+        return sum(p._version for p in params())
+
     def __call__(self, x):
         from . import ops
-        # the arithmetic mode and the cached weight copies are baked into a captured graph: an engine step (PARAM_EPOCH) retires it
-        if getattr(self, "_epoch", None) != ops.PARAM_EPOCH[0]:
+        # The arithmetic mode and the cached K16-blocked / re-laid-out weight copies are baked into a captured graph (biases,
+        # LayerNorm parameters and head weights are read live): ANY parameter write retires it -- an engine step or checkpoint
+        # load (PARAM_EPOCH), or torch code such as load_state_dict / an optimizer step (the tensors' version counters).
+        stamp = (ops.PARAM_EPOCH[0], self._param_versions())
+        if getattr(self, "_epoch", None) != stamp:
             self.graphs.clear()
-            self._epoch = ops.PARAM_EPOCH[0]
+            self._epoch = stamp
         key = (tuple(x.shape), x.dtype, ops.compute_dtype())
         entry = self.graphs.get(key)
         if entry is None:

@@ -856,6 +856,21 @@ def block_weights(P, attn, backward):
     return out
 
 
+def _block_cost(nb, fl, groups, T, C, hidden, self_passes, cross_passes):
+    """Profiler cost of one fused block launch.  The 4th field is SURVEY.md 8(d)'s figure for it: with ideal whole-block fusion a
+    self block moves its activation 2 times forward (R x, W x') and 3 times backward (R x, R dy, W dx), a cross block 3 / 5 times
+    (+ R xa; + R xa, W dxa), each pass T * C * e bytes with e the element size of the arithmetic mode (bf16 = 2), plus the block's
+    weights (3 C^2 + C^2 + 2 C hidden elements) once."""
+    if _lib.PROFILE is None:
+        return None
+    e = 2 if _dt() else 4
+    s8d = 0
+    for gd in groups:
+        cross = gd.get("cross", gd.get("kvsrc") is not None)
+        s8d += (cross_passes if cross else self_passes) * T * C * e + (4 * C * C + 2 * C * hidden) * e
+    return (nb, fl, f"{len(groups)}x{T}x{C}" if DETAIL else None, s8d)
+
+
 def block_fwd(groups, dims, C, heads, eps, scale):
     """groups: 1 or 2 dicts {x [T,C], kvsrc [T,C] | None, P {state_dict-style name: tensor}, attn 'self_attn' | 'cross_attn',
     s1, s2 [B] | None, want_xn bool}.  ONE launch.  Returns per group a dict of the tensors saved for backward (+ 'y')."""
@@ -887,7 +902,7 @@ def block_fwd(groups, dims, C, heads, eps, scale):
             + T * hidden * o["h"].element_size() + 12 * C * C * wt.element_size()
         fl += 2 * T * 12 * C * C + 4 * T * C * 8
     call("micf_block_fwd", ctypes.cast(arr, ctypes.c_void_p), len(groups), B, D, H, W, C, heads, hidden, float(eps), float(scale),
-         _dt(), cost=(nb, fl, f"{len(groups)}x{T}x{C}") if _lib.PROFILE is not None and DETAIL else ((nb, fl) if _lib.PROFILE is not None else None))
+         _dt(), cost=_block_cost(nb, fl, groups, T, C, hidden, 2, 3))
     return outs
 
 
@@ -929,7 +944,7 @@ def block_bwd(groups, dims, C, heads, scale):
             + 12 * C * C * wt.element_size()
         fl += 2 * T * 12 * C * C + 8 * T * C * 8
     call("micf_block_bwd", ctypes.cast(arr, ctypes.c_void_p), len(groups), B, D, H, W, C, heads, hidden, float(scale),
-         _dt(), cost=(nb, fl, f"{len(groups)}x{T}x{C}") if _lib.PROFILE is not None and DETAIL else ((nb, fl) if _lib.PROFILE is not None else None))
+         _dt(), cost=_block_cost(nb, fl, groups, T, C, hidden, 3, 5))
     del keep
     return outs
 

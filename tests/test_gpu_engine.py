@@ -211,6 +211,50 @@ def test_early_adam_over_the_flat_tail_is_the_same_update(M):
         assert float(moved.max()) > 1e-3 and float(moved.max()) < 2.5e-3
 
 
+def test_early_adam_is_not_armed_without_full_flush_points(M):
+    """flush_points=False leaves the linear / LayerNorm weight gradients queued until the end of backward: early Adam over the
+    flat tail would then run on incomplete gradients (and the late ones would never be applied).  The engine must fall back to
+    one Adam at the end: same training state as early_adam=False, and the same as the default layout."""
+    from micformer_amd.engine import TrainEngine
+    x, t = _data(1)
+    engines = []
+    for kw in (dict(early_adam=False, flush_points=False), dict(early_adam=True, flush_points=False), dict()):
+        e = TrainEngine(_head(M, train=False), base_lr=1e-3, t_max=10, use_graph=False, **kw)
+        for _ in range(2):
+            e.step(x, t)
+        torch.cuda.synchronize()
+        engines.append(e)
+    _same_training_state(engines[0], engines[1], "early Adam requested without flush points")
+    _same_training_state(engines[0], engines[2], "default layout")
+
+
+def test_graphed_predictor_retires_on_any_parameter_write(M):
+    """A captured predictor graph bakes in cached copies of the block weights: load_state_dict (torch version counters) and
+    engine.load_checkpoint (PARAM_EPOCH) must retire it -- the next call has to equal a fresh model with the new weights."""
+    from micformer_amd.inference import GraphedPredictor
+
+    def head48():                                                # embed 48: the fused block kernels and their cached K16-blocked weights
+        h = M.Head(embed_dim=48, num_classes=8, depths=(1, 1, 1, 1))
+        with torch.no_grad():
+            for name, t in h.state_dict().items():
+                t.copy_(fill.fill_tensor(name, t))
+        return h.cuda().eval()
+
+    h = head48()
+    x = _data(1)[0]
+    gp = GraphedPredictor(h)
+    with torch.no_grad():
+        y0 = gp(x).clone()
+        sd = {k: (v * 1.25 if v.dim() >= 2 else v.clone()) for k, v in h.state_dict().items()}   # linear AND conv weights change
+        h.load_state_dict(sd)
+        y1 = gp(x).clone()
+        fresh = head48()
+        fresh.load_state_dict(sd)
+        want = fresh(x)
+    assert float((y1 - y0).abs().max()) > 1e-4
+    assert float((y1 - want).abs().max()) <= 1e-5, float((y1 - want).abs().max())
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_forward_after_engine_steps_uses_the_updated_weights(M, dtype):
     """The engine's Adam kernel writes the parameters behind torch's back (no version-counter bump).  An engine-less forward

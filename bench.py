@@ -20,6 +20,10 @@ import os
 import sys
 import time
 
+# the segmented step capture needs the HIP runtime's graph packet capture off, and the runtime reads the flag when it initialises
+# (micformer_amd/_lib.py explains; set here as well so that it is in place before anything imports torch)
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -181,6 +185,8 @@ def main(argv=None):
                     help="matrix-core arithmetic: bf16 (BASELINE config 2; bf16 MFMA operands, fp32 accumulate / storage, passes the "
                          "SURVEY 8(c) gates of tests/test_gpu_bf16.py) or fp32 (exact, the parity mode)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured HIP graph")
+    ap.add_argument("--single-graph", action="store_true", help="capture the step as ONE HIP graph (round-2 layout) instead of the "
+                    "sequence of graphs replayed on two streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-baseline steps per batch size (median is reported)")
@@ -233,7 +239,8 @@ def main(argv=None):
         torch.manual_seed(1234 + rank)                              # rank-distinct DropPath stream and data
         x, tgt = synthetic_batch(args.batch, vol, 8, dev, 1234 + rank)
         eng = TrainEngine(model, base_lr=1e-4, t_max=150, use_graph=not args.no_graph,
-                          parallel_modalities=not args.serial_modalities, flush_points=not args.no_flush_points)
+                          parallel_modalities=not args.serial_modalities, flush_points=not args.no_flush_points,
+                          segmented=not args.single_graph)
 
     def barrier():
         if world > 1:
@@ -268,7 +275,9 @@ def main(argv=None):
                                f"8 classes) full train step (fwd + MDiceLoss + bwd + Adam/cosine) on {args.vol}^3 CT+MR pairs, "
                                f"{'DropPath on' if not args.eval_mode else 'eval mode'}",
                    "local_batch": args.batch, "global_batch": world * args.batch, "parallelism": f"dp{world}",
-                   "launch": "eager" if args.no_graph else "hipGraph replay"},
+                   "launch": "eager" if args.no_graph else ("hipGraph replay (one graph)" if (stub or not eng.segmented) else
+                                                            f"hipGraph replay ({len(eng._graph.segments)} segments: main chain / "
+                                                            "parameter-gradient batches as separate graphs on two streams)")},
         "final_loss": round(loss_val, 6),
     }
 

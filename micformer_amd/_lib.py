@@ -6,7 +6,20 @@ raises on non-CUDA tensors -- the product path is the HIP path or nothing.
 import ctypes
 import os
 
-import torch
+# ROCm 7.2's HIP runtime replays a captured graph from AQL packets it records at the first launch ("graph packet capture").  With
+# MORE THAN ONE instantiated graph of this step's size launched alternately, the second launch of a graph after another graph
+# ran faults (memory access fault in the replayed kernels; found by bisection on MI355X: [forward | backward] as two graphs works
+# once and faults at the next step, and works with the optimisation off; a single graph is not affected, its step time does not
+# change either way).  The segmented step capture (functional.StepSegmenter) therefore needs the flag OFF, and the runtime reads
+# it when it initialises -- i.e. before the first HIP call of the process.  GRAPH_SEGMENTS_OK records whether that was achieved;
+# TrainEngine falls back to the one-graph layout otherwise.
+_PKT = "DEBUG_CLR_GRAPH_PACKET_CAPTURE"
+_pkt_before = os.environ.get(_PKT)
+os.environ.setdefault(_PKT, "0")
+
+import torch  # noqa: E402
+
+GRAPH_SEGMENTS_OK = os.environ.get(_PKT) == "0" and (_pkt_before == "0" or not torch.cuda.is_initialized())
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmicformer_hip.so")
@@ -223,10 +236,14 @@ class block_region:
         return False
 
 
+LAUNCHES = [0]           # C-ABI calls issued so far (functional.StepSegmenter: is the segment being captured empty?)
+
+
 def call(name, *args, cost=None):
     """Launch one C-ABI entry point on torch's current stream.  cost = (bytes the launch itself moves with every tensor touched
     once, flops[, shape tag[, SURVEY 8(d) bytes]]) for the profiler; the 8(d) bytes are the ideal-fusion activation passes + block
     weights of a transformer-block launch (None for everything that is not one)."""
+    LAUNCHES[0] += 1
     if PROFILE is None:
         rc = getattr(lib, name)(*args, stream())
     else:

@@ -24,7 +24,7 @@ class TrainEngine:
     def __init__(self, model, base_lr=1e-4, t_max=150, eta_min=0.0, betas=(0.9, 0.999), eps=1e-8, criterion=None,
                  use_graph=False, process_group=None, grad_bucket_bytes=64 << 20, parallel_modalities=True,
                  defer_wgrad=True, split_step=None, always_collective=False, flush_points=True, early_adam=True,
-                 dp_graph_flushes=6, grad_bf16=False):
+                 dp_graph_flushes=6, grad_bf16=False, segmented=None):
         self.model = model
         self.criterion = criterion if criterion is not None else MDiceLoss()
         self.base_lr, self.t_max, self.eta_min = base_lr, t_max, eta_min
@@ -55,6 +55,14 @@ class TrainEngine:
         # to bf16, sum-reduced, widened back; Adam still reads fp32.  Off by default (the fp32 exchange is exact).
         self.grad_bf16 = bool(grad_bf16)
         self._wire = torch.empty(self.flat_g.numel(), dtype=torch.bfloat16, device=self.flat_g.device) if self.grad_bf16 else None
+        # Graph layout of a captured step: ONE HIP graph (round 2; where its side branch runs is the graph executor's choice) or
+        # a sequence of graphs replayed on two streams with explicit events (functional.StepSegmenter; the default).
+        # (needs the runtime's graph packet capture off, see _lib.GRAPH_SEGMENTS_OK: one graph otherwise)
+        self.segmented = (__import__("os").environ.get("MICF_SEGMENTED", "1") != "0") if segmented is None else bool(segmented)
+        # ... and single-process only: with an initialised NCCL (= RCCL) process group hipGraphLaunch of a segment crashed in the
+        # host runtime (tests/test_gpu_model.py::test_split_step_with_rccl_on_one_rank, ROCm 7.2), so data-parallel jobs keep the
+        # one-graph layout that the round-2 RCCL tests ran on.
+        self.segmented = self.segmented and _lib.GRAPH_SEGMENTS_OK and not (dist.is_available() and dist.is_initialized())
         self._wplan = None
         self.use_graph = use_graph
         self._graph = None
@@ -180,6 +188,8 @@ class TrainEngine:
         @contextlib.contextmanager
         def scope():
             prev = (_ms.PARALLEL_MODALITIES, _fn.DEFER_WGRAD, _fn.FLUSH_POINTS, _fn.DEFER_CALLS, ops.ENGINE_SHADOWS)
+            prev_fork = _ms.FORK_AUTOGRAD_STREAMS
+            _ms.FORK_AUTOGRAD_STREAMS = not (self.segmented and self.use_graph)
             prev_budget = _fn.FLUSH_BUDGET[0]
             _ms.PARALLEL_MODALITIES, _fn.DEFER_WGRAD = self.parallel_modalities, self.defer_wgrad
             _fn.FLUSH_POINTS = self.defer_wgrad and self.flush_points and (not self.split_step or self.dp_graph_flushes > 0)
@@ -191,6 +201,7 @@ class TrainEngine:
             finally:
                 _ms.PARALLEL_MODALITIES, _fn.DEFER_WGRAD, _fn.FLUSH_POINTS, _fn.DEFER_CALLS, ops.ENGINE_SHADOWS = prev
                 _fn.FLUSH_BUDGET[0] = prev_budget
+                _ms.FORK_AUTOGRAD_STREAMS = prev_fork
         return scope()
 
     def _fwd_bwd(self, x, target, flush=True):
@@ -220,14 +231,20 @@ class TrainEngine:
             # linear / LayerNorm gradients of the tail would still sit in the queue and be applied one step late, never.
             full_flush = _fn.FLUSH_POINTS and _fn.FLUSH_BUDGET[0] >= (1 << 30) and _fn.FLUSH_MAX_TOKENS >= (1 << 30)
             if flush and self.world == 1 and self._early_cut is not None and self.early_adam and full_flush:
-                _fn.BACKWARD_HOOKS[id(self._early_layer)] = self._early_adam
-            elif self._anchor_layer is not None:
+                _fn.BACKWARD_HOOKS[id(self._early_layer)] = self._early_adam_segment if _fn.SEGMENTER is not None else self._early_adam
+            elif self._anchor_layer is not None and _fn.SEGMENTER is None:
                 _fn.BACKWARD_HOOKS[id(self._anchor_layer)] = self._side_anchor
             logits = self.model(x)                                  #                              train.py:185
             loss = self.criterion(logits, target)                   #                              train.py:187
             _fn.run_entry_hook(force=True)                          # (fewer than 3 stages: launched here)
             main.wait_stream(side)
-            loss.backward()                                         #                              train.py:200
+            if _fn.SEGMENTER is not None:
+                # segmented capture: the flush points end / begin stream captures from inside backward; keep autograd on the
+                # calling thread so every hipStreamBeginCapture / EndCapture of this step is issued by ONE host thread
+                with torch.autograd.set_multithreading_enabled(False):
+                    loss.backward()
+            else:
+                loss.backward()                                     #                              train.py:200
             _fn.flush_wgrad(calls_only=not flush)                   # what is still queued: grouped linear weight gradients (left
             _fn.join_wgrad_stream()                                 # to the data-parallel tail when flush=False), closures
         return loss.detach()
@@ -260,6 +277,13 @@ class TrainEngine:
         with torch.cuda.stream(side):
             tail()
         _fn._WSIDE_USED.add(dev)
+        self._adam_tail_done = True
+
+    def _early_adam_segment(self):
+        """The same inside a segmented capture: called while the side segment of this flush point is being captured (the current
+        stream IS the side stream, ordered after the main chain by the replay's events)."""
+        ops.adam_tick(self.adam_state, self.base_lr, self.eta_min, self.t_max)
+        self._adam_range(self._early_cut, self.flat_p.numel(), 1.0)
         self._adam_tail_done = True
 
     def _side_anchor(self):
@@ -403,11 +427,28 @@ class TrainEngine:
         torch.set_rng_state(rng_cpu)
         torch.cuda.set_rng_state(rng_dev, sx.device)
         del keep
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            # single GPU: the whole step; data parallel: forward + backward only (weight-gradient groups, collective and Adam
-            # are issued eagerly after the replay)
-            sl = self._fwd_bwd(sx, st, flush=False) if self.split_step else self._step_impl(sx, st)
+        # single GPU: the whole step; data parallel: forward + backward only (weight-gradient groups, collective and Adam
+        # are issued eagerly after the replay)
+        body = (lambda: self._fwd_bwd(sx, st, flush=False)) if self.split_step else (lambda: self._step_impl(sx, st))
+        if self.segmented:
+            from . import functional as _fn
+            torch.cuda.empty_cache()
+            g = _fn.StepSegmenter(_fn._wgrad_stream(sx.device))
+            cs = torch.cuda.Stream(device=sx.device)
+            cs.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(cs):
+                _fn.SEGMENTER = g
+                try:
+                    g.begin()
+                    sl = body()
+                    g.finish()
+                finally:
+                    _fn.SEGMENTER = None
+            torch.cuda.current_stream().wait_stream(cs)
+        else:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                sl = body()
         if self.split_step:
             from . import functional as _fn
             self._plan_split(*_fn.take_deferred())                  # (capture records, it does not run: step() replays next)

@@ -131,6 +131,76 @@ LAZY_FLUSH = __import__("os").environ.get("MICF_LAZY_FLUSH", "1") != "0"
 _PENDING_FLUSH = []                 # (event, device, linear items, LayerNorm items, closures)
 
 
+# Segmented capture (TrainEngine(segmented=True)): instead of ONE HIP graph whose executor decides on which hardware queue the
+# side branch runs (round 2: 12.5 ms when it happens to overlap, 15.8 ms when it serialises, and the deciding factor was node
+# creation order), the step is captured as a SEQUENCE of graphs -- the main chain is cut at every flush point, every side batch
+# is its own graph -- and replayed on two streams with explicit events: main segments back to back on the launch stream, side
+# batch k on the weight-gradient stream after main segment k.  Each graph is a plain chain (plus short fork / joins), so nothing
+# is left for the executor to place.  Memory: main segments share one private pool, side segments another (graphs of one pool
+# replay in capture order on one stream); tensors a side batch reads were allocated by main segments and are kept referenced
+# until the capture is complete, so no later main segment can be handed their blocks.
+SEGMENTER = None
+SEG_SERIAL = __import__("os").environ.get("MICF_SEG_SERIAL", "0") == "1"      # debug: side segments on the main stream too
+
+
+class StepSegmenter:
+    def __init__(self, side_stream):
+        self.side = side_stream
+        self.pool_m, self.pool_s = torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle()
+        self.segments = []              # ("main" | "side", CUDAGraph) | ("join", None)
+        self.keep = []
+        self.cur = None
+
+    def begin(self):
+        """Start the next main segment on the CURRENT stream (relaxed mode: autograd ends / begins captures from its own thread)."""
+        self.cur = torch.cuda.CUDAGraph()
+        self.cur.capture_begin(pool=self.pool_m, capture_error_mode="relaxed")
+        self._mark = _lib.LAUNCHES[0]
+
+    def _end_main(self):
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")         # ("The CUDA Graph is empty": two cuts with nothing between them)
+            self.cur.capture_end()
+        if _lib.LAUNCHES[0] != self._mark:          # (an empty segment is dropped, not replayed)
+            self.segments.append(("main", self.cur))
+        self.cur = None
+
+    def run_side(self, work, keep=None):
+        """Cut the main chain here; capture `work` (callables) as one graph on the side stream; resume the main chain."""
+        self._end_main()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(self.side):
+            g.capture_begin(pool=self.pool_s, capture_error_mode="relaxed")
+            for w in work:
+                w()
+            g.capture_end()
+        self.segments.append(("side", g))
+        self.keep.append(keep)
+        self.begin()
+
+    def join(self):
+        self._end_main()
+        self.segments.append(("join", None))
+        self.begin()
+
+    def finish(self):
+        self._end_main()
+        self.keep.clear()               # (the pools keep every block a captured graph uses; the Python references can go)
+
+    def replay(self):
+        main = torch.cuda.current_stream()
+        for kind, g in self.segments:
+            if kind == "main" or (kind == "side" and SEG_SERIAL):
+                g.replay()
+            elif kind == "side":
+                self.side.wait_stream(main)
+                with torch.cuda.stream(self.side):
+                    g.replay()
+            else:
+                main.wait_stream(self.side)
+
+
 def launch_pending_flush():
     while _PENDING_FLUSH:
         ev, dev, items, ln, calls = _PENDING_FLUSH.pop(0)
@@ -141,10 +211,24 @@ def launch_pending_flush():
         _WSIDE_USED.add(dev)
 
 
-def flush_wgrad_side(calls_only=False, lazy=False):
+def flush_wgrad_side(calls_only=False, lazy=False, extra=None):
     """Launch everything queued so far on the weight-gradient side stream (ordered after the current stream's work).
     calls_only: just the deferred closures (data-parallel mode: the grouped linear weight gradients stay queued for the
-    engine, which interleaves them with the gradient all-reduce after the replay).  lazy: see LAZY_FLUSH."""
+    engine, which interleaves them with the gradient all-reduce after the replay).  lazy: see LAZY_FLUSH.
+    extra: callables launched behind the batch on the same stream (segmented capture: the early optimiser step)."""
+    if SEGMENTER is not None:
+        items, ln = ([], []) if calls_only else (list(_DEFERRED), list(_DEFERRED_LN))
+        calls = list(_DEFERRED_CALLS)
+        if not calls_only:
+            _DEFERRED.clear()
+            _DEFERRED_LN.clear()
+            _QUEUED_DW.clear()
+        _DEFERRED_CALLS.clear()
+        work = [lambda: _launch_batch(items, ln, calls)] if (items or ln or calls) else []
+        work += list(extra or [])
+        if work:
+            SEGMENTER.run_side(work, keep=(items, ln, calls))
+        return
     launch_pending_flush()
     if not ((not calls_only and (_DEFERRED or _DEFERRED_LN)) or _DEFERRED_CALLS):
         return
@@ -189,6 +273,9 @@ def flush_wgrad_side(calls_only=False, lazy=False):
 
 
 def join_wgrad_stream():
+    if SEGMENTER is not None:
+        SEGMENTER.join()
+        return
     launch_pending_flush()
     for dev in list(_WSIDE_USED):
         torch.cuda.current_stream(dev).wait_stream(_wgrad_stream(dev))
@@ -234,12 +321,19 @@ class FlushPointFn(torch.autograd.Function):
     def backward(ctx, dx, dxa):
         # (a token cap exists for experiments: restricting the flushes to the latency-bound small stages was measured slower --
         # the weight gradients of the big stages then pile up in the tail)
-        if FLUSH_POINTS and DEFER_WGRAD and dx.numel() // dx.shape[-1] <= FLUSH_MAX_TOKENS and FLUSH_BUDGET[0] > 0:
+        full = FLUSH_POINTS and DEFER_WGRAD and dx.numel() // dx.shape[-1] <= FLUSH_MAX_TOKENS and FLUSH_BUDGET[0] > 0
+        hook = BACKWARD_HOOKS.pop(ctx.key, None) if ctx.key is not None else None
+        if SEGMENTER is not None:                       # the hook (early Adam) rides in the same side segment as the batch
+            if full or (DEFER_CALLS and DEFER_WGRAD) or hook is not None:
+                if full:
+                    FLUSH_BUDGET[0] -= 1
+                flush_wgrad_side(calls_only=not full, extra=[hook] if hook is not None else None)
+            return dx, dxa, None
+        if full:
             FLUSH_BUDGET[0] -= 1
             flush_wgrad_side(lazy=True)
         elif DEFER_CALLS and DEFER_WGRAD:
             flush_wgrad_side(calls_only=True, lazy=True)
-        hook = BACKWARD_HOOKS.pop(ctx.key, None) if ctx.key is not None else None
         if hook is not None:
             hook()
         return dx, dxa, None
@@ -261,6 +355,9 @@ def _launch_batch(items, ln, calls):
 
 def flush_wgrad(calls_only=False):
     """Launch every queued weight gradient on the current stream (which must be ordered after their producers)."""
+    if SEGMENTER is not None:                           # segmented capture: one more side segment (join_wgrad_stream follows)
+        flush_wgrad_side(calls_only)
+        return
     launch_pending_flush()
     items, ln = [], []
     if not calls_only:

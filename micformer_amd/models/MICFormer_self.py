@@ -226,6 +226,12 @@ class LayerNormProxy(nn.Module):
 
 # Run the two modalities' independent blocks on two HIP streams (engine / bench switch; off = the reference's serial order).
 PARALLEL_MODALITIES = False
+# ... and whether AUTOGRAD-tracked work may be put on the second stream (the two modalities' resampling convs, the per-op block
+# path).  A segmented step capture (functional.StepSegmenter) turns it off: autograd replays an op's backward on its forward
+# stream and orders it with events, and a gradient produced on the second stream in one captured segment but consumed in a later
+# one (the skip connections) would be an event edge between two different graphs.  Forward-only side work (the head composition,
+# weight preparation) is not affected.
+FORK_AUTOGRAD_STREAMS = True
 # backward flush points inside a stage: every SLOT_FLUSH_STRIDE-th depth slot (measured at base / 128^3 at the end of round 2:
 # 1 -> 15.8 ms (the captured graph then replays side and main work serially), 2 -> 12.6, 3 -> 12.6, 4 -> 12.7, none -> 14.0:
 # one flush in the middle of the six-slot stage, none inside the two-slot stages)
@@ -360,7 +366,7 @@ class PatchExpand(nn.Module):
 def _both(fn, a, b):
     """(fn(a), fn(b)) for the two modalities -- the second call on the side stream when they may overlap (the resampling
     convs between the stages are 40-75 us launches each: a fork / join costs less than running them back to back)."""
-    if not (PARALLEL_MODALITIES and (a[0] if isinstance(a, tuple) else a).is_cuda):
+    if not (PARALLEL_MODALITIES and FORK_AUTOGRAD_STREAMS and (a[0] if isinstance(a, tuple) else a).is_cuda):
         return fn(a), fn(b)
     main, side = torch.cuda.current_stream(), _side_stream((a[0] if isinstance(a, tuple) else a).device)
     side.wait_stream(main)
@@ -435,7 +441,7 @@ class BasicLayer(nn.Module):
             if resample is not None:
                 return (x, xa) + _both(resample, x, xa)
             return x, xa, x, xa
-        side = _side_stream(x.device) if (PARALLEL_MODALITIES and x.is_cuda) else None
+        side = _side_stream(x.device) if (PARALLEL_MODALITIES and FORK_AUTOGRAD_STREAMS and x.is_cuda) else None
         if side is None:
             for i in range(self.depth):
                 x, xa = self.self_blocks1[i](x), self.self_blocks2[i](xa)

@@ -170,6 +170,7 @@ def linear_bwd_data(dy, w, dp_scale=None, rows_per_sample=0, pre_act=None, k1=No
 
 
 _SCRATCH = {}
+_SCRATCH_RETIRED = []
 
 
 def scratch(device, nfloats):
@@ -178,6 +179,10 @@ def scratch(device, nfloats):
     key = (device, torch.cuda.current_stream(device).cuda_stream)      # one scratch per stream: launches on different
     buf = _SCRATCH.get(key)                                            # streams may run concurrently
     if buf is None or buf.numel() < nfloats:
+        if buf is not None:
+            # a captured HIP graph may have baked the old buffer's address into its kernels (also a graph captured EARLIER in a
+            # sequence of graphs of the same step): it is retired, never freed
+            _SCRATCH_RETIRED.append(buf)
         buf = torch.empty(max(int(nfloats), 1 << 22), dtype=torch.float32, device=device)
         _SCRATCH[key] = buf
     return buf

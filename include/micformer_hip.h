@@ -101,8 +101,8 @@ int64_t micf_linear_bwd_weight_workspace(int64_t M, int N, int K);
  * dp_scale: rows_per_sample % 16 == 0 and M % rows_per_sample == 0.  `items` is HOST memory (read during the call only);
  * the buffers it points to are device memory and must stay valid until the stream has run the launches. */
 typedef struct micf_wgrad_item {
-  const float* a;          /* [M, K] layer input */
-  const float* dy;         /* [M, N] gradient of the layer output */
+  const float* a;          /* [M, K] layer input (bfloat16 elements when operand_dtype == MICF_DTYPE_BF16) */
+  const float* dy;         /* [M, N] gradient of the layer output (likewise) */
   const float* dp_scale;   /* [M / rows_per_sample] DropPath scale per sample, or NULL */
   float* dw;               /* [N, K] */
   float* dbias;            /* [N] or NULL */
@@ -110,6 +110,9 @@ typedef struct micf_wgrad_item {
   int64_t rows_per_sample;
   int32_t N;
   int32_t K;
+  int32_t operand_dtype;   /* MICF_DTYPE_F32: a / dy are fp32; MICF_DTYPE_BF16: both were STORED as bfloat16 (what the fused block
+                              kernels leave in bf16 mode); then M % 32 == 0, N % 8 == 0, K % 8 == 0, rows_per_sample % 32 == 0 */
+  int32_t reserved;
 } micf_wgrad_item;
 int micf_linear_bwd_weight_grouped(const micf_wgrad_item* items, int n, float* workspace, int64_t workspace_floats,
                                    int dtype, micf_stream_t stream);
@@ -385,7 +388,16 @@ typedef struct micf_block_fwd_group {
                           for MICF_DTYPE_BF16 -- only micf_block_bwd reads it (GELU'), so the bf16 mode stores it at half width */
   float* g;            /* GELU(h) [T, hidden] (operand of the fc2 weight gradient) */
   float* stats;        /* [4, T]: mean1, rstd1, mean2, rstd2 */
+  void* kvs16;         /* cross, bf16 storage only (micf_block_saves_bf16): [T, C] bf16 copy of kvsrc, the operand of the kv
+                          weight gradient; NULL otherwise */
 } micf_block_fwd_group;
+/* STORAGE of the saved tensors.  micf_block_saves_bf16(C, heads, dtype) != 0 (MICF_DTYPE_BF16 on the tile-per-workgroup kernels,
+ * C <= 192): xn, q, kv, o, xn2, g (forward) and dq, dkv, dh, dx1 (backward) are bfloat16 arrays of the documented shapes (the
+ * struct fields keep their float* type for the fp32 case), and kvs16 / dy16 receive bf16 copies of a cross block's K/V source and
+ * of dy, so that every operand pair of the five nn.Linear weight gradients of a block is stored as bf16
+ * (micf_wgrad_item.operand_dtype = MICF_DTYPE_BF16).  x1, y, stats, dx, dxs, dx1_copy and the LayerNorm partials are always
+ * fp32.  Otherwise (MICF_DTYPE_F32, or the few-token decomposition at C = 384) everything is fp32 except h. */
+int micf_block_saves_bf16(int C, int heads, int dtype);
 typedef struct micf_block_bwd_group {
   const float* dy;     /* [T, C] gradient w.r.t. the block output (also fc2's output gradient for the weight-gradient GEMM) */
   const float *x, *x1, *stats, *q, *kv; /* as saved by micf_block_fwd (x and ln1_g may be NULL for a cross block) */
@@ -402,7 +414,8 @@ typedef struct micf_block_bwd_group {
   float *ln1_part, *ln2_part; /* [tiles, 2C] per-tile partial dgamma | dbeta for micf_layernorm_bwd_finish (NULL = skip;
                                  tiles = ceil(T / micf_block_tile_tokens)) */
   float* dx1_copy;     /* optional second copy of dx1 [T, C]: the buffer a cross PAIR then accumulates the other block's
-                          K/V-source gradient and its own LN1 backward into (no zero fill, no separate add) */
+                          K/V-source gradient and its own LN1 backward into (no zero fill, no separate add); always fp32 */
+  void* dy16;          /* bf16 storage only: [T, C] bf16 copy of dy (operand of the fc2 weight gradient); NULL otherwise */
 } micf_block_bwd_group;
 int micf_block_tile_tokens(int B, int D, int H, int W, int C, int heads, int hidden, int backward);
 /* Per-step weight preparation for the fused block kernels: for each row-major fp32 matrix of a list (one launch per 64 items,

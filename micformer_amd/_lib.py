@@ -90,6 +90,7 @@ SIGNATURES = {
     "micf_adam_tick": "pddlp",
     "micf_adam_step": "pppplpffffpp",
     "micf_block_tile_tokens": "iiiiiiii",
+    "micf_block_saves_bf16": "iii",
     "micf_weight_prep_grouped": "pip",
     "micf_block_fwd": "piiiiiiiiffip",
     "micf_block_bwd": "piiiiiiiifip",
@@ -107,7 +108,7 @@ class WgradItem(ctypes.Structure):
     """struct micf_wgrad_item (include/micformer_hip.h)."""
     _fields_ = [("a", ctypes.c_void_p), ("dy", ctypes.c_void_p), ("dp_scale", ctypes.c_void_p), ("dw", ctypes.c_void_p),
                 ("dbias", ctypes.c_void_p), ("M", ctypes.c_int64), ("rows_per_sample", ctypes.c_int64),
-                ("N", ctypes.c_int32), ("K", ctypes.c_int32)]
+                ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("operand_dtype", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class LnFinishItem(ctypes.Structure):
@@ -122,14 +123,14 @@ _VP = ctypes.c_void_p
 class BlockFwdGroup(ctypes.Structure):
     """struct micf_block_fwd_group (include/micformer_hip.h)."""
     FIELDS = ("x", "kvsrc", "ln1_g", "ln1_b", "bq", "bkv", "bp", "ln2_g", "ln2_b", "b1", "b2", "wq", "wkv", "wp", "w1", "w2",
-              "s1", "s2", "y", "xn", "q", "kv", "o", "x1", "xn2", "h", "g", "stats")
+              "s1", "s2", "y", "xn", "q", "kv", "o", "x1", "xn2", "h", "g", "stats", "kvs16")
     _fields_ = [(n, _VP) for n in FIELDS]
 
 
 class BlockBwdGroup(ctypes.Structure):
     """struct micf_block_bwd_group (include/micformer_hip.h)."""
     FIELDS = ("dy", "x", "x1", "stats", "q", "kv", "h", "ln1_g", "ln2_g", "wqt", "wkvt", "wpt", "w1t", "w2t", "s1", "s2",
-              "dx", "dxs", "dx1", "dh", "dq", "dkv", "ln1_part", "ln2_part", "dx1_copy")
+              "dx", "dxs", "dx1", "dh", "dq", "dkv", "ln1_part", "ln2_part", "dx1_copy", "dy16")
     _fields_ = [(n, _VP) for n in FIELDS]
 
 
@@ -190,6 +191,7 @@ def _load():
     lib.micf_conv3_fwd_workspace.restype = _L
     lib.micf_offset_head_bwd_workspace.restype = _L
     lib.micf_block_tile_tokens.argtypes = [_I] * 8          # (no stream argument: a pure shape query)
+    lib.micf_block_saves_bf16.argtypes = [_I] * 3
     lib.micf_strerror.argtypes = [_I]
     lib.micf_strerror.restype = ctypes.c_char_p
     lib.micf_abi_version.argtypes = []

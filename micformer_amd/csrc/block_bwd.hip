@@ -60,6 +60,21 @@ struct RowRegs {
       }
     }
   }
+  // a bf16 copy of the rows (row length 4 * X4) at `base`, advanced to the tile's first token
+  __device__ __forceinline__ void store_b16(const int* tok, int tk0, void* base) const {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15, rg = lane >> 4;
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+      const int row = pass * RPP + wave * 4 + rg;
+      const int tk = row < TM ? tok[row] : -1;
+      if (tk < 0) continue;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const int c4 = l16 + 16 * k;
+        if (c4 < X4) st_h4_32<true>(base, (uint32_t)(tk - tk0) * (4 * X4) + 4 * c4, v[pass][k]);
+      }
+    }
+  }
 };
 // Rows of the saved fc1 pre-activation: fp32, or bf16 at half the registers (bf16 mode).  base: the tensor advanced to the tile's
 // first token and the chunk's first column; ld: its row length in elements.
@@ -163,9 +178,9 @@ struct LnRegs {
 // LayerNorm backward of the rows held in LDS tile `D` (gradient w.r.t. the normalised output, pre-gain) against the preloaded
 // LayerNorm input rows `in`: out = addt + rs * (g d - mean(g d) - xh mean(g d xh)).  addt / out are LDS tile A (in place) and
 // HBM `hout` / `hout2` (both advanced to the tile's first token tk0).  The per-tile column sums of d * xh and d go through `scratch` (LDS, >= 16 * 2C floats) to part[2C].
-template <int TJ, int VPL, int NW, int C>
+template <int TJ, int VPL, int NW, int C, bool H16 = false>
 __device__ __forceinline__ void ln_bwd_tile(const float* D, float* A, int S, const LnRegs<16 * TJ, NW, C>& in, const int* tok,
-                                            int tk0, float* __restrict__ hout, float* __restrict__ hout2, float* scratch,
+                                            int tk0, void* __restrict__ hout, float* __restrict__ hout2, float* scratch,
                                             float* __restrict__ part) {
   constexpr int TM = 16 * TJ, NTHR = 64 * NW, RPP = 4 * NW, NPASS = (TM + RPP - 1) / RPP, NPR = RPP < TM ? RPP : TM;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, rg = lane >> 4;
@@ -212,9 +227,9 @@ __device__ __forceinline__ void ln_bwd_tile(const float* D, float* A, int S, con
         if (tk < 0) o = make_float4(0.f, 0.f, 0.f, 0.f);
         *reinterpret_cast<float4*>(ap) = o;
         if (tk >= 0) {
-          const uint32_t off = ((uint32_t)(tk - tk0) * C + 4 * c4) * 4u;
-          st4g(at32(hout, off), o);
-          if (hout2) st4g(at32(hout2, off), o);
+          const uint32_t eoff = (uint32_t)(tk - tk0) * C + 4 * c4;
+          st_h4_32<H16>(hout, eoff, o);                     // (H16: the weight-gradient operand copy, bf16)
+          if (hout2) st4g(at32(hout2, eoff * 4u), o);
         }
       }
     }
@@ -286,18 +301,20 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
   const int tk0 = __builtin_amdgcn_readfirstlane(tok[0]);
   const float* dy0 = g.dy + (int64_t)tk0 * C;
   const char* h0 = static_cast<const char*>(g.h) + (int64_t)tk0 * Hd * (BF16 ? 2 : 4);
-  const float* q0 = g.q + (int64_t)tk0 * C;
-  const float* kv0 = g.kv + (int64_t)tk0 * 2 * C;
-  float* dh0 = g.dh + (int64_t)tk0 * Hd;
-  float* dq0 = g.dq + (int64_t)tk0 * C;
-  float* dkv0 = g.dkv + (int64_t)tk0 * 2 * C;
+  constexpr int ES = BF16 ? 2 : 4;                      // element size of the tensors the bf16 mode stores as bf16
+  const char* q0 = reinterpret_cast<const char*>(g.q) + (int64_t)tk0 * C * ES;
+  const char* kv0 = reinterpret_cast<const char*>(g.kv) + (int64_t)tk0 * 2 * C * ES;
+  char* dh0 = reinterpret_cast<char*>(g.dh) + (int64_t)tk0 * Hd * ES;
+  char* dq0 = reinterpret_cast<char*>(g.dq) + (int64_t)tk0 * C * ES;
+  char* dkv0 = reinterpret_cast<char*>(g.dkv) + (int64_t)tk0 * 2 * C * ES;
   float* dx0 = g.dx + (int64_t)tk0 * C;
 
   // ---- request every global input of the tile (see RowRegs)
   constexpr int HC = 2 * C;
   RowRegs<TM, NW, C4> r_dy;
   HRegs<TM, NW, HC / 4, BF16> r_h[Hd / HC];
-  RowRegs<TM, NW, 3 * C4> r_qkv;
+  HRegs<TM, NW, C4, BF16> r_q;
+  HRegs<TM, NW, 2 * C4, BF16> r_kv;
   LnRegs<TM, NW, C> r_ln2, r_ln1;
   r_dy.load(tok, tk0, [&](uint32_t rel, uint32_t c4) { return at32(dy0, (rel * C + 4 * c4) * 4u); });
 #pragma unroll
@@ -305,12 +322,12 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
     r_h[ch].load(tok, tk0, h0 + ch * HC * (BF16 ? 2 : 4), (uint32_t)Hd);
   r_ln2.load(tok, tk0, g.x1 + (int64_t)tk0 * C, g.stats + 2 * T + tk0, g.stats + 3 * T + tk0, g.ln2_g);
   if (!g.dxs) r_ln1.load(tok, tk0, g.x + (int64_t)tk0 * C, g.stats + tk0, g.stats + T + tk0, g.ln1_g);
-  r_qkv.load(tok, tk0, [&](uint32_t rel, uint32_t c4) {
-    return c4 < C4 ? at32(q0, (rel * C + 4 * c4) * 4u) : at32(kv0, (rel * 2 * C + 4 * (c4 - C4)) * 4u);
-  });
+  r_q.load(tok, tk0, q0, (uint32_t)C);
+  r_kv.load(tok, tk0, kv0, (uint32_t)(2 * C));
 
-  // ---- dy rows -> A1
+  // ---- dy rows -> A1 (+ the bf16 copy fc2's weight gradient reads)
   r_dy.commit(A1, S);
+  if (BF16 && g.dy16) r_dy.store_b16(tok, tk0, reinterpret_cast<char*>(g.dy16) + (int64_t)tk0 * C * 2);
 
   // ---- MLP backward in hidden chunks: h chunk -> U;  U <- s2 (dy W2) GELU'(h) = dh (saved);  A2 (+)= dh W1
 #pragma unroll
@@ -329,19 +346,21 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
       if (tk < 0) continue;
       const uint32_t rel = (uint32_t)(tk - tk0);
       for (int c4 = l16; c4 < X4; c4 += 16)
-        st4g(at32(dh0, (rel * Hd + c0 + 4 * c4) * 4u), *reinterpret_cast<const float4*>(U + row * SU + 4 * c4));
+        st_h4_32<BF16>(dh0, rel * Hd + c0 + 4 * c4, *reinterpret_cast<const float4*>(U + row * SU + 4 * c4));
     }
     if (ch == 0) gemm_phase<TJ, NSL, 2, Hd, NW, BF16>(w1t + 16 * c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiStore{});
     else gemm_phase<TJ, NSL, 2, Hd, NW, BF16>(w1t + 16 * c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiAcc{});
   }
 
   // ---- dx1 = dy + LN2'(A2) -> A1 + HBM; LN2 gain / bias partials
-  ln_bwd_tile<TJ, VPL, NW, C>(A2, A1, S, r_ln2, tok, tk0, g.dx1 + (int64_t)tk0 * C, g.dx1_copy ? g.dx1_copy + (int64_t)tk0 * C : nullptr, U,
-                              g.ln2_part ? g.ln2_part + (int64_t)tile * 2 * C : nullptr);
+  ln_bwd_tile<TJ, VPL, NW, C, BF16>(A2, A1, S, r_ln2, tok, tk0, reinterpret_cast<char*>(g.dx1) + (int64_t)tk0 * C * ES,
+                                    g.dx1_copy ? g.dx1_copy + (int64_t)tk0 * C : nullptr, U,
+                                    g.ln2_part ? g.ln2_part + (int64_t)tile * 2 * C : nullptr);
 
   // ---- do = s1 dx1 Wp -> A2;  q | k | v rows -> U
   gemm_phase<TJ, NSL, 1, C, NW, BF16>(wpt, C, A1, nullptr, 0, nullptr, S, A2, S, EpiStoreScale{sc1});
-  r_qkv.commit(U, SU);
+  r_q.commit(U, SU);
+  r_kv.commit(U + C, SU);
   if (PARK && !g.dxs) r_ln1.park(stash);
   lds_barrier();
 
@@ -458,8 +477,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
     const uint32_t rel = (uint32_t)(tk - tk0);
     for (int c4 = l16; c4 < 3 * C4; c4 += 16) {
       const float4 v = *reinterpret_cast<const float4*>(U + row * SU + 4 * c4);
-      if (c4 < C4) st4g(at32(dq0, (rel * C + 4 * c4) * 4u), v);
-      else st4g(at32(dkv0, (rel * 2 * C + 4 * (c4 - C4)) * 4u), v);
+      if (c4 < C4) st_h4_32<BF16>(dq0, rel * C + 4 * c4, v);
+      else st_h4_32<BF16>(dkv0, rel * 2 * C + 4 * (c4 - C4), v);
     }
   }
 
@@ -528,7 +547,7 @@ extern "C" int micf_block_bwd(const micf_block_bwd_group* groups, int ngroups, i
     for (const void* p : need)
       if (!p || (reinterpret_cast<uintptr_t>(p) & 15)) return MICF_EINVAL;
     if (!g.dxs && (!g.x || !g.ln1_g)) return MICF_EINVAL;          // self: LayerNorm-1 backward runs in the kernel
-    const void* opt[] = {g.x, g.ln1_g, g.dxs, g.ln1_part, g.ln2_part, g.dx1_copy};
+    const void* opt[] = {g.x, g.ln1_g, g.dxs, g.ln1_part, g.ln2_part, g.dx1_copy, g.dy16};
     for (const void* p : opt)
       if (p && (reinterpret_cast<uintptr_t>(p) & 15)) return MICF_EINVAL;
     a.g[i] = g;

@@ -329,6 +329,13 @@ __device__ __forceinline__ float sum16(float v) {      // sum over the 16-lane g
 }
 // block_wide.hip: the few-token decomposition of the same two entry points (several launches, GEMMs split over features)
 int block_wide_tile_tokens(int C, int hd);
+// Storage of what the fused kernels save for the backward / leave for the weight gradients.  MICF_DTYPE_BF16 on the
+// tile-per-workgroup kernels (this file's users: C <= 192) stores every tensor that is only ever consumed as a matrix-core operand or
+// by the attention backward as bf16 -- xn, q, kv, o, xn2, g (+ kvs16, a bf16 copy of a cross block's K/V source) in the forward,
+// dq, dkv, dh, dx1 (+ dy16, a bf16 copy of dy) in the backward; the residual stream (x1, y, dx, dxs, dx1_copy), the LayerNorm
+// statistics and partial sums stay fp32.  The few-token decomposition (block_wide.hip, C = 384) re-reads its own intermediates
+// between launches and keeps fp32 everywhere.
+inline bool block_saves_bf16(int C, int hd, int dtype) { return dtype == MICF_DTYPE_BF16 && !block_wide_tile_tokens(C, hd); }
 int block_fwd_wide(const micf_block_fwd_group* groups, int ngroups, int B, int D, int H, int W, int C, int heads, float eps, float scale,
                    int dtype, hipStream_t s);
 int block_bwd_wide(const micf_block_bwd_group* groups, int ngroups, int B, int D, int H, int W, int C, int heads, float scale, int dtype,
@@ -360,6 +367,11 @@ __device__ __forceinline__ void st2g(void* p, const uint2& v) {          // non-
 template <bool BF16> __device__ __forceinline__ void st_h4(void* h, int64_t e, const float4& v) {
   if constexpr (BF16) st2g(static_cast<uint16_t*>(h) + e, pack4_bf16(v));
   else st4g(static_cast<float*>(h) + e, v);
+}
+// ... the same with a (wave-uniform base, 32-bit element offset) address: one offset register, scalar-base store
+template <bool BF16> __device__ __forceinline__ void st_h4_32(void* base, uint32_t e, const float4& v) {
+  if constexpr (BF16) st2g(at32(static_cast<char*>(base), e * 2u), pack4_bf16(v));
+  else st4g(at32(static_cast<float*>(base), e * 4u), v);
 }
 template <bool BF16> __device__ __forceinline__ float4 ld_h4(const void* h, int64_t e) {
   if constexpr (BF16) return unpack4_bf16(*reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(h) + e));

@@ -140,7 +140,8 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
           if (tk < 0) y = make_float4(0.f, 0.f, 0.f, 0.f);
           *reinterpret_cast<float4*>(A1 + row * S + 4 * c4) = y;
           if (g.kvsrc) *reinterpret_cast<float4*>(A2 + row * S + 4 * c4) = kvv[pass][k];
-          if (tk >= 0 && g.xn && save) st4g(g.xn + (int64_t)tk * C + 4 * c4, y);
+          if (tk >= 0 && g.xn && save) st_h4<BF16>(g.xn, (int64_t)tk * C + 4 * c4, y);
+          if (BF16 && tk >= 0 && g.kvsrc && g.kvs16 && save) st_h4<true>(g.kvs16, (int64_t)tk * C + 4 * c4, kvv[pass][k]);
         }
       }
       if (l16 == 0 && tk >= 0) { g.stats[tk] = mu; g.stats[T + tk] = rs; }
@@ -162,8 +163,8 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
       if (tk < 0) continue;
       for (int c4 = l16; c4 < 3 * C4; c4 += 16) {
         const float4 v = *reinterpret_cast<const float4*>(U + row * SU + 4 * c4);
-        if (c4 < C4) st4g(g.q + (int64_t)tk * C + 4 * c4, v);
-        else st4g(g.kv + (int64_t)tk * 2 * C + 4 * (c4 - C4), v);
+        if (c4 < C4) st_h4<BF16>(g.q, (int64_t)tk * C + 4 * c4, v);
+        else st_h4<BF16>(g.kv, (int64_t)tk * 2 * C + 4 * (c4 - C4), v);
       }
     }
   }
@@ -223,7 +224,7 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
       for (int d = 0; d < HP; d += 4) {
         const float4 t = make_float4(oa[d], oa[d + 1], oa[d + 2], oa[d + 3]);
         *reinterpret_cast<float4*>(A1 + row * S + hoff + d) = t;
-        if (tk >= 0 && save) st4g(g.o + (int64_t)tk * C + hoff + d, t);
+        if (tk >= 0 && save) st_h4<BF16>(g.o, (int64_t)tk * C + hoff + d, t);
       }
     }
   }
@@ -277,7 +278,7 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
                                  (v[pass][k].z - mu) * rs * gm.z + bt.z, (v[pass][k].w - mu) * rs * gm.w + bt.w);
           if (tk < 0) y = make_float4(0.f, 0.f, 0.f, 0.f);
           *reinterpret_cast<float4*>(A1 + row * S + 4 * c4) = y;
-          if (tk >= 0 && save) st4g(g.xn2 + (int64_t)tk * C + 4 * c4, y);
+          if (tk >= 0 && save) st_h4<BF16>(g.xn2, (int64_t)tk * C + 4 * c4, y);
         }
       }
       if (l16 == 0 && tk >= 0) { g.stats[2 * T + tk] = mu; g.stats[3 * T + tk] = rs; }
@@ -304,7 +305,7 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
         *reinterpret_cast<float4*>(up) = ge;
         if (tk >= 0 && save) {
           st_h4<BF16>(g.h, (int64_t)tk * Hd + c0 + 4 * c4, v);
-          st4g(g.g + (int64_t)tk * Hd + c0 + 4 * c4, ge);
+          st_h4<BF16>(g.g, (int64_t)tk * Hd + c0 + 4 * c4, ge);
         }
       }
     }
@@ -374,6 +375,11 @@ extern "C" int micf_block_tile_tokens(int B, int D, int H, int W, int C, int hea
   return 16 * tj;
 }
 
+extern "C" int micf_block_saves_bf16(int C, int heads, int dtype) {
+  if (C <= 0 || heads <= 0 || C % heads) return 0;
+  return block_saves_bf16(C, C / heads, dtype) ? 1 : 0;
+}
+
 extern "C" int micf_block_fwd(const micf_block_fwd_group* groups, int ngroups, int B, int D, int H, int W, int C, int heads,
                               int hidden, float eps, float scale, int dtype, micf_stream_t stream) {
   if (!groups || ngroups < 1 || ngroups > 2) return MICF_EINVAL;
@@ -387,7 +393,8 @@ extern "C" int micf_block_fwd(const micf_block_fwd_group* groups, int ngroups, i
                           g.y, g.q, g.kv, g.o, g.x1, g.xn2, g.h, g.g, g.stats};
     for (const void* p : need)
       if (!p || (reinterpret_cast<uintptr_t>(p) & 15)) return MICF_EINVAL;
-    if ((g.kvsrc && (reinterpret_cast<uintptr_t>(g.kvsrc) & 15)) || (g.xn && (reinterpret_cast<uintptr_t>(g.xn) & 15))) return MICF_EINVAL;
+    if ((g.kvsrc && (reinterpret_cast<uintptr_t>(g.kvsrc) & 15)) || (g.xn && (reinterpret_cast<uintptr_t>(g.xn) & 15)) ||
+        (g.kvs16 && (reinterpret_cast<uintptr_t>(g.kvs16) & 15))) return MICF_EINVAL;
     a.g[i] = g;
   }
   if (ngroups == 1) a.g[1] = a.g[0];

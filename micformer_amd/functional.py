@@ -68,6 +68,14 @@ def _defer(ok, fn, *tensors):
 
 
 def _lin_wgrad(defer, dy, a, dw, db, dp_scale=None, rows_per_sample=0):
+    if dy.dtype == torch.bfloat16 or a.dtype == torch.bfloat16:
+        # operands the fused block kernels stored as bf16: only the grouped entry point reads them (shapes it does not take -- fewer
+        # than 32 tokens -- are widened and go the fp32 way)
+        if dy.dtype != a.dtype or not ops.wgrad_groupable(dy, a, dp_scale, rows_per_sample):
+            dy, a = dy.float(), a.float()
+        elif not (defer and DEFER_WGRAD and dw.data_ptr() not in _QUEUED_DW):
+            ops.linear_bwd_weight_grouped([(dy, a, dw, db, dp_scale, rows_per_sample)])
+            return
     if defer and DEFER_WGRAD and dy.shape[0] <= DEFER_MAX_TOKENS and ops.wgrad_groupable(dy, a, dp_scale, rows_per_sample) \
             and dw.data_ptr() not in _QUEUED_DW:          # (a layer applied twice in one step launches its second use at once)
         launch_pending_flush()
@@ -648,13 +656,13 @@ class CrossBlockFn(torch.autograd.Function):
             side = all(t is not None for t in ctx.tg)
             dyf = _c(dy).reshape(-1, C)
             bo = ops.block_bwd([{"dy": dyf, "x": None, "x1": svd["x1"], "stats": svd["stats"], "q": svd["q"], "kv": svd["kv"],
-                                 "h": svd["h"], "P": P, "attn": "cross_attn", "s1": s1, "s2": s2, "cross": True}], dims, C, heads,
-                               (C // heads) ** -0.5)[0]
+                                 "h": svd["h"], "P": P, "attn": "cross_attn", "s1": s1, "s2": s2, "cross": True,
+                                 "want_copy": True}], dims, C, heads, (C // heads) ** -0.5)[0]
             xn, m1, r1, hid, flow, xsamp = hd
             _queue_block_wgrads(side, P, G, "cross_attn", svd, bo, dyf, xn, xsamp, s1, s2, rps)
             _ln_partials(side, bo["ln2_part"], bo["tiles"], C, G["norm2.weight"], G["norm2.bias"])
             dxa = ops.zero_(torch.empty_like(xaf))                  # scatter target of the sampler (one memset node)
-            dx = _cross_head_bwd(side, P, G, dims, eps, xf, xaf, xn, m1, r1, hid, flow, bo["dx"], bo["dxs"], dxa, bo["dx1"])
+            dx = _cross_head_bwd(side, P, G, dims, eps, xf, xaf, xn, m1, r1, hid, flow, bo["dx"], bo["dxs"], dxa, bo["dx1_copy"])
             shape = dims + (C,)
             return (dx.reshape(shape), dxa.reshape(shape), None, None, None, None, None) + \
                 tuple(_ret(t, G[k]) for k, t in zip(CROSS_KEYS, ctx.tg))
@@ -711,6 +719,9 @@ FUSE_BLOCKS = _os.environ.get("MICF_FUSE_BLOCKS", "1") != "0"   # off = the roun
 
 def _queue_block_wgrads(side, P, G, attn, sv, bo, dy, xn, kv_in, s1, s2, rps):
     """The five nn.Linear weight gradients of a block from the operands the fused kernels left in HBM (deferred in engine mode)."""
+    if bo.get("dy16") is not None:          # bf16 storage: every operand pair was left as bf16 (block_fused.h block_saves_bf16)
+        dy, xn = bo["dy16"], sv["xn"]
+        kv_in = sv["kvs16"] if sv.get("kvs16") is not None else sv["xn"]
     _lin_wgrad(side, dy, sv["g"], G["mlp.fc2.weight"], G["mlp.fc2.bias"], s2, rps)
     _lin_wgrad(side, bo["dh"], sv["xn2"], G["mlp.fc1.weight"], G["mlp.fc1.bias"])
     _lin_wgrad(side, bo["dx1"], sv["o"], G[f"{attn}.proj.weight"], G[f"{attn}.proj.bias"], s1, rps)
@@ -817,7 +828,7 @@ def _cross_head_bwd(side, P, G, dims, eps, xf, xaf, xn, m1, r1, hid, flow, dxq, 
                              out=out)
 
 
-_CSV_KEYS = ("q", "kv", "o", "x1", "xn2", "h", "g", "stats")
+_CSV_KEYS = ("q", "kv", "o", "x1", "xn2", "h", "g", "stats", "xn", "kvs16")      # (xn / kvs16: bf16 storage only, else None)
 
 # The two offset heads of a cross pair (LN1 -> 3^3 conv -> sampling, and their adjoints) are independent per-op launch chains:
 # the second one runs on a side stream (a fork / join in the captured graph), as round 1 did for whole blocks.

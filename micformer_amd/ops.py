@@ -204,6 +204,11 @@ def wgrad_groupable(dy, a1, dp_scale=None, rows_per_sample=0):
     """Shape / alignment gate of micf_linear_bwd_weight_grouped for one layer."""
     M, N = dy.shape
     K = a1.shape[1]
+    if dy.dtype != a1.dtype:
+        return False
+    if dy.dtype == torch.bfloat16:          # operands stored as bf16 (the fused block kernels' outputs in bf16 mode)
+        if M % 32 or N % 8 or K % 8 or (dy.data_ptr() | a1.data_ptr()) & 15 or (dp_scale is not None and rows_per_sample % 32):
+            return False
     if M % 16 or N % 4 or K % 4 or (dy.data_ptr() | a1.data_ptr()) & 15:
         return False
     if dp_scale is not None and (rows_per_sample <= 0 or rows_per_sample % 16 or M % rows_per_sample):
@@ -227,10 +232,13 @@ class GroupedWgradPlan:
         for k, (it, (dy, a, dw, db, sc, rps)) in enumerate(zip(self.arr, self.items)):
             M, N = dy.shape
             K = a.shape[1]
-            it.a, it.dy, it.dp_scale, it.dw, it.dbias = f32(a), f32(dy), f32(sc), f32(dw), f32(db)
+            if dy.dtype != a.dtype or dy.dtype not in (torch.float32, torch.bfloat16):
+                raise _lib.MicfError("grouped weight gradient: both operands must be float32 or both bfloat16")
+            it.a, it.dy, it.dp_scale, it.dw, it.dbias = ptr(a), ptr(dy), f32(sc), f32(dw), f32(db)
             it.M, it.rows_per_sample, it.N, it.K = M, int(rps) if sc is not None else 0, N, K
+            it.operand_dtype = 1 if dy.dtype == torch.bfloat16 else 0
             self.flops[k] = 2 * M * N * K
-            self.nbytes[k] = 4 * (dy.numel() + a.numel() + 2 * dw.numel())
+            self.nbytes[k] = dy.element_size() * (dy.numel() + a.numel()) + 8 * dw.numel()
         self.device = self.items[0][0].device if n else None
         self.item_bytes = ctypes.sizeof(_lib.WgradItem)
 
@@ -876,6 +884,12 @@ def _block_cost(nb, fl, groups, T, C, hidden, self_passes, cross_passes):
     return (nb, fl, f"{len(groups)}x{T}x{C}" if DETAIL else None, s8d)
 
 
+def block_saves_bf16(C, heads):
+    """True when the fused block kernels store their saved tensors / weight-gradient operands as bf16 for this shape in the current
+    arithmetic mode (include/micformer_hip.h micf_block_saves_bf16)."""
+    return bool(_lib.lib.micf_block_saves_bf16(C, heads, _dt()))
+
+
 def block_fwd(groups, dims, C, heads, eps, scale):
     """groups: 1 or 2 dicts {x [T,C], kvsrc [T,C] | None, P {state_dict-style name: tensor}, attn 'self_attn' | 'cross_attn',
     s1, s2 [B] | None, want_xn bool}.  ONE launch.  Returns per group a dict of the tensors saved for backward (+ 'y')."""
@@ -885,13 +899,19 @@ def block_fwd(groups, dims, C, heads, eps, scale):
     arr = (_lib.BlockFwdGroup * 2)()
     outs = []
     h_dtype = torch.bfloat16 if _dt() else torch.float32       # the saved fc1 pre-activation: half width in bf16 mode
+    st16 = block_saves_bf16(C, heads)                          # ... and everything only matrix cores / the attention backward re-read
+    sd = torch.bfloat16 if st16 else torch.float32
     keep = []            # temporary shadow weights must outlive the launch: the next group's outputs must not reuse them
     nb = fl = 0
     for it, gd in zip(arr, groups):
         x, P, a = gd["x"], gd["P"], gd["attn"]
-        o = {"y": _new(x, T, C), "q": _new(x, T, C), "kv": _new(x, T, 2 * C), "o": _new(x, T, C), "x1": _new(x, T, C),
-             "xn2": _new(x, T, C), "h": _new(x, T, hidden, dtype=h_dtype), "g": _new(x, T, hidden), "stats": _new(x, 4, T),
-             "xn": _new(x, T, C) if gd.get("want_xn", True) else None}
+        cross = gd.get("kvsrc") is not None
+        o = {"y": _new(x, T, C), "q": _new(x, T, C, dtype=sd), "kv": _new(x, T, 2 * C, dtype=sd), "o": _new(x, T, C, dtype=sd),
+             "x1": _new(x, T, C), "xn2": _new(x, T, C, dtype=sd), "h": _new(x, T, hidden, dtype=h_dtype),
+             "g": _new(x, T, hidden, dtype=sd), "stats": _new(x, 4, T),
+             # (bf16 storage: the q weight gradient pairs a bf16 dq with a bf16 xn, so the kernel always writes its own copy)
+             "xn": _new(x, T, C, dtype=sd) if (gd.get("want_xn", True) or st16) else None,
+             "kvs16": _new(x, T, C, dtype=sd) if (st16 and cross) else None}
         it.x, it.kvsrc, it.s1, it.s2 = f32(x), f32(gd.get("kvsrc")), f32(gd.get("s1")), f32(gd.get("s2"))
         for field, key in FWD_W:
             setattr(it, field, f32(P[key.format(a=a)]))
@@ -900,11 +920,11 @@ def block_fwd(groups, dims, C, heads, eps, scale):
         for field, wt in wts.items():
             setattr(it, field, ptr(wt))
         for k, v in o.items():
-            setattr(it, k, ptr(v) if k == "h" else f32(v))
+            setattr(it, k, ptr(v))
         outs.append(o)
-        # algorithmic bytes: read x (+ kvsrc), write [xn,] q, kv (2), o, x1, xn2, y, h (4), g (4); the weights once
-        nb += 4 * (T * C * ((9 if o["xn"] is not None else 8) + (1 if gd.get("kvsrc") is not None else 0)) + T * hidden) \
-            + T * hidden * o["h"].element_size() + 12 * C * C * wt.element_size()
+        # bytes the launch moves: read x (+ kvsrc), write everything in `o`; the weights once
+        nb += 4 * T * C * (2 if cross else 1) + sum(v.numel() * v.element_size() for v in o.values() if v is not None) \
+            + 12 * C * C * wt.element_size()
         fl += 2 * T * 12 * C * C + 4 * T * C * 8
     call("micf_block_fwd", ctypes.cast(arr, ctypes.c_void_p), len(groups), B, D, H, W, C, heads, hidden, float(eps), float(scale),
          _dt(), cost=_block_cost(nb, fl, groups, T, C, hidden, 2, 3))
@@ -923,17 +943,20 @@ def block_bwd(groups, dims, C, heads, scale):
     outs = []
     keep = []            # temporaries (transposed weights) must outlive the launch: the next group's outputs must not reuse them
     nb = fl = 0
+    st16 = block_saves_bf16(C, heads)
+    sd = torch.bfloat16 if st16 else torch.float32
     for it, gd in zip(arr, groups):
         dy, P, a, cross = gd["dy"], gd["P"], gd["attn"], gd["cross"]
-        o = {"dx": _new(dy, T, C), "dxs": _new(dy, T, C) if cross else None, "dx1": _new(dy, T, C), "dh": _new(dy, T, hidden),
-             "dq": _new(dy, T, C), "dkv": _new(dy, T, 2 * C), "ln2_part": _new(dy, tiles, 2 * C),
-             "ln1_part": None if cross else _new(dy, tiles, 2 * C),
-             "dx1_copy": _new(dy, T, C) if gd.get("want_copy") else None}
-        for k in ("dy", "x", "x1", "stats", "q", "kv", "s1", "s2"):
+        o = {"dx": _new(dy, T, C), "dxs": _new(dy, T, C) if cross else None, "dx1": _new(dy, T, C, dtype=sd),
+             "dh": _new(dy, T, hidden, dtype=sd), "dq": _new(dy, T, C, dtype=sd), "dkv": _new(dy, T, 2 * C, dtype=sd),
+             "ln2_part": _new(dy, tiles, 2 * C), "ln1_part": None if cross else _new(dy, tiles, 2 * C),
+             "dx1_copy": _new(dy, T, C) if gd.get("want_copy") else None,
+             "dy16": _new(dy, T, C, dtype=sd) if st16 else None}
+        for k in ("dy", "x", "x1", "stats", "s1", "s2"):
             setattr(it, k, f32(gd.get(k)))
-        if gd["h"].dtype != (torch.bfloat16 if _dt() else torch.float32):
-            raise _lib.MicfError("block_bwd: the saved pre-activation was written in another arithmetic mode")
-        it.h = ptr(gd["h"])
+        if gd["h"].dtype != (torch.bfloat16 if _dt() else torch.float32) or gd["q"].dtype != sd or gd["kv"].dtype != sd:
+            raise _lib.MicfError("block_bwd: the saved tensors were written in another arithmetic mode")
+        it.h, it.q, it.kv = ptr(gd["h"]), ptr(gd["q"]), ptr(gd["kv"])
         for field, key in BWD_W:
             setattr(it, field, f32(P[key.format(a=a)]))
         wts = block_weights(P, a, backward=True)
@@ -941,12 +964,12 @@ def block_bwd(groups, dims, C, heads, scale):
         for field, wt in wts.items():
             setattr(it, field, ptr(wt))
         for k, v in o.items():
-            setattr(it, k, f32(v))
+            setattr(it, k, ptr(v))
+        # bytes the launch moves: read dy, x1, q, kv, h [+ x: self]; write everything in `o`; the weights once
+        nb += 4 * T * C * (2 if cross else 3) + sum(gd[k].numel() * gd[k].element_size() for k in ("q", "kv", "h")) \
+            + sum(v.numel() * v.element_size() for v in o.values() if v is not None) + 12 * C * C * wt.element_size()
         o["tiles"] = tiles
         outs.append(o)
-        # algorithmic bytes: read dy, x1, q, kv (2), h (4) [+ x: self]; write dx, dx1, dq, dkv (2), dh (4) [+ dxs, dx1_copy: cross]
-        nb += 4 * (T * C * ((11 + (1 if gd.get("want_copy") else 0)) if cross else 11) + T * hidden) + T * hidden * gd["h"].element_size() \
-            + 12 * C * C * wt.element_size()
         fl += 2 * T * 12 * C * C + 8 * T * C * 8
     call("micf_block_bwd", ctypes.cast(arr, ctypes.c_void_p), len(groups), B, D, H, W, C, heads, hidden, float(scale),
          _dt(), cost=_block_cost(nb, fl, groups, T, C, hidden, 3, 5))

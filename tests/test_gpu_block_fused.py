@@ -195,6 +195,47 @@ def test_fused_block_bf16_mode_is_close(ops, case):
         check(f"bf16 bwd {k}", b[k], rb[k], 3e-2, errs)
     assert float((o["y"] - ref["y"]).abs().max()) > 0                      # it really is a different arithmetic
     assert not errs, "\n".join(errs)
+    # storage: the tile-per-workgroup kernels (C <= 192) leave what only matrix cores / the attention backward re-read as bf16
+    st16 = C <= 192
+    for k in ("xn", "q", "kv", "o", "xn2", "g"):
+        assert (o[k].dtype == torch.bfloat16) == st16, k
+    for k in ("dq", "dkv", "dh", "dx1"):
+        assert (b[k].dtype == torch.bfloat16) == st16, k
+    assert o["x1"].dtype == o["y"].dtype == b["dx"].dtype == torch.float32
+    if st16:
+        assert torch.equal(b["dy16"], dy.bfloat16())                        # the bf16 copy of dy is its RNE rounding
+    else:
+        assert b["dy16"] is None
+
+
+def test_bf16_storage_cross_block_operand_copies(ops):
+    """bf16 storage of a cross block: kvs16 is the RNE rounding of the K/V source, xn is written although the caller did not ask
+    for it (the q weight gradient pairs two bf16 operands), and the five weight gradients from the stored operands equal the
+    fp32-operand weight gradients of the same (rounded) values."""
+    B, D, H, W, C, heads = 2, 4, 4, 4, 96, 6
+    dims, T, attn = (B, D, H, W), 128, "cross_attn"
+    P = make_params(C, 4 * C, attn, 11)
+    x, kvsrc, dy = rnd((T, C), 12), rnd((T, C), 13), rnd((T, C), 14)
+    eps, scale = 1e-5, (C // heads) ** -0.5
+    ops.set_compute_dtype("bf16")
+    try:
+        o = ops.block_fwd([{"x": x, "kvsrc": kvsrc, "P": P, "attn": attn, "s1": None, "s2": None, "want_xn": False}], dims, C, heads, eps,
+                          scale)[0]
+        b = ops.block_bwd([{"dy": dy, "x": None, "x1": o["x1"], "stats": o["stats"], "q": o["q"], "kv": o["kv"], "h": o["h"], "P": P,
+                            "attn": attn, "s1": None, "s2": None, "cross": True, "want_copy": True}], dims, C, heads, scale)[0]
+        assert torch.equal(o["kvs16"], kvsrc.bfloat16()) and o["xn"] is not None and o["xn"].dtype == torch.bfloat16
+        assert b["dx1_copy"].dtype == torch.float32 and float((b["dx1_copy"] - b["dx1"].float()).abs().max()) <= 2 ** -8 * float(b["dx1_copy"].abs().max())
+        errs = []
+        for dyo, a, name in ((b["dy16"], o["g"], "fc2"), (b["dh"], o["xn2"], "fc1"), (b["dx1"], o["o"], "proj"), (b["dq"], o["xn"], "q"),
+                             (b["dkv"], o["kvs16"], "kv")):
+            N, K = dyo.shape[1], a.shape[1]
+            w16, w32 = torch.zeros(N, K, device="cuda"), torch.zeros(N, K, device="cuda")
+            ops.linear_bwd_weight_grouped([(dyo, a, w16, None, None, 0)])
+            ops.linear_bwd_weight_grouped([(dyo.float(), a.float(), w32, None, None, 0)])
+            check(f"wgrad {name}", w16, w32, 1e-5, errs)
+        assert not errs, "\n".join(errs)
+    finally:
+        ops.set_compute_dtype("fp32")
 
 
 @pytest.mark.parametrize("rows,cols", [(48, 48), (96, 48), (192, 768), (33, 70), (130, 4)])

@@ -20,9 +20,11 @@ import os
 import sys
 import time
 
-# the segmented step capture needs the HIP runtime's graph packet capture off, and the runtime reads the flag when it initialises
-# (micformer_amd/_lib.py explains; set here as well so that it is in place before anything imports torch)
-os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+# --segmented: the step as a sequence of HIP graphs on two streams.  It needs the HIP runtime's graph packet capture off, and
+# the runtime reads that flag when it initialises (micformer_amd/_lib.py explains): set before anything imports torch.
+if "--segmented" in sys.argv:
+    os.environ["MICF_SEGMENTED"] = "1"
+    os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -185,8 +187,8 @@ def main(argv=None):
                     help="matrix-core arithmetic: bf16 (BASELINE config 2; bf16 MFMA operands, fp32 accumulate / storage, passes the "
                          "SURVEY 8(c) gates of tests/test_gpu_bf16.py) or fp32 (exact, the parity mode)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured HIP graph")
-    ap.add_argument("--single-graph", action="store_true", help="capture the step as ONE HIP graph (round-2 layout) instead of the "
-                    "sequence of graphs replayed on two streams")
+    ap.add_argument("--segmented", action="store_true", help="capture the step as a sequence of HIP graphs replayed on two streams "
+                    "with explicit events (main chain / parameter-gradient batches) instead of ONE graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-baseline steps per batch size (median is reported)")
@@ -240,7 +242,7 @@ def main(argv=None):
         x, tgt = synthetic_batch(args.batch, vol, 8, dev, 1234 + rank)
         eng = TrainEngine(model, base_lr=1e-4, t_max=150, use_graph=not args.no_graph,
                           parallel_modalities=not args.serial_modalities, flush_points=not args.no_flush_points,
-                          segmented=not args.single_graph)
+                          segmented=args.segmented)
 
     def barrier():
         if world > 1:

@@ -361,6 +361,8 @@ typedef struct micf_offset_head_bwd_group {
 } micf_offset_head_bwd_group;
 /* 1 = the conv accumulates atomically at this shape: hid must be zero when it starts (the call clears it unless hid_zeroed) */
 int micf_offset_head_needs_zero(int B, int D, int H, int W, int C);
+/* flow == NULL and xs == NULL in every group: the 3^3 conv only (the sampling then runs inside micf_block_fwd, see
+ * micf_block_fwd_group.hid). */
 int micf_offset_head_fwd(const micf_offset_head_group* groups, int ngroups, int B, int D, int H, int W, int C, float eps,
                          int prepared, int hid_zeroed, int dtype, micf_stream_t stream);
 int64_t micf_offset_head_bwd_workspace(int ngroups, int B, int D, int H, int W);
@@ -388,9 +390,18 @@ typedef struct micf_block_fwd_group {
                           for MICF_DTYPE_BF16 -- only micf_block_bwd reads it (GELU'), so the bf16 mode stores it at half width */
   float* g;            /* GELU(h) [T, hidden] (operand of the fc2 weight gradient) */
   float* stats;        /* [4, T]: mean1, rstd1, mean2, rstd2 */
-  void* kvs16;         /* cross, bf16 storage only (micf_block_saves_bf16): [T, C] bf16 copy of kvsrc, the operand of the kv
+  void* kvs16;         /* cross, bf16 storage only (micf_block_saves_bf16): [T, C] bf16 copy of the K/V source, the operand of the kv
                           weight gradient; NULL otherwise */
+  /* Cross block with the deformable sampling FUSED IN (micf_block_fuses_sampler(C, heads) != 0; then kvsrc must be NULL): the
+   * launch itself runs LayerNorm(16) -> GELU -> 1^3 conv on the offset conv's output rows, adds the reference points and
+   * gathers the trilinear taps of the raw other modality (what micf_offset_sample_fwd does as its own launch). */
+  const float* hid;        /* [T, 16] output of conv_offset.0 (micf_offset_head_fwd with flow = xs = NULL), or NULL */
+  const float* samp_src;   /* [T, C] raw other modality */
+  const float *ln16_g, *ln16_b, *w1c; /* conv_offset.1.norm.{weight,bias} [16], conv_offset.3.weight [3, 16] */
+  float* flow;             /* out [T, 3]: offsets + reference points (the sampler's backward reads them) */
+  float* xs32;             /* out, optional, fp32 storage only: [T, C] the sampled rows (operand of the kv weight gradient) */
 } micf_block_fwd_group;
+int micf_block_fuses_sampler(int C, int heads);
 /* STORAGE of the saved tensors.  micf_block_saves_bf16(C, heads, dtype) != 0 (MICF_DTYPE_BF16 on the tile-per-workgroup kernels,
  * C <= 192): xn, q, kv, o, xn2, g (forward) and dq, dkv, dh, dx1 (backward) are bfloat16 arrays of the documented shapes (the
  * struct fields keep their float* type for the fp32 case), and kvs16 / dy16 receive bf16 copies of a cross block's K/V source and

@@ -12,10 +12,14 @@ import os
 # once and faults at the next step, and works with the optimisation off; a single graph is not affected, its step time does not
 # change either way).  The segmented step capture (functional.StepSegmenter) therefore needs the flag OFF, and the runtime reads
 # it when it initialises -- i.e. before the first HIP call of the process.  GRAPH_SEGMENTS_OK records whether that was achieved;
-# TrainEngine falls back to the one-graph layout otherwise.
+# TrainEngine falls back to the one-graph layout otherwise.  The segmented layout is OPT-IN (MICF_SEGMENTED=1 / TrainEngine(
+# segmented=True)): it measures the same step time as the best one-graph placement (the main chain alone replays in the step's
+# time: the side work is fully hidden either way), and a suite that keeps several segmented engines alive in one process was
+# seen to abort intermittently on this runtime.
 _PKT = "DEBUG_CLR_GRAPH_PACKET_CAPTURE"
 _pkt_before = os.environ.get(_PKT)
-os.environ.setdefault(_PKT, "0")
+if os.environ.get("MICF_SEGMENTED", "0") == "1":        # opt-in (bench.py --segmented sets both)
+    os.environ.setdefault(_PKT, "0")
 
 import torch  # noqa: E402
 
@@ -91,6 +95,7 @@ SIGNATURES = {
     "micf_adam_step": "pppplpffffpp",
     "micf_block_tile_tokens": "iiiiiiii",
     "micf_block_saves_bf16": "iii",
+    "micf_block_fuses_sampler": "ii",
     "micf_weight_prep_grouped": "pip",
     "micf_block_fwd": "piiiiiiiiffip",
     "micf_block_bwd": "piiiiiiiifip",
@@ -123,7 +128,7 @@ _VP = ctypes.c_void_p
 class BlockFwdGroup(ctypes.Structure):
     """struct micf_block_fwd_group (include/micformer_hip.h)."""
     FIELDS = ("x", "kvsrc", "ln1_g", "ln1_b", "bq", "bkv", "bp", "ln2_g", "ln2_b", "b1", "b2", "wq", "wkv", "wp", "w1", "w2",
-              "s1", "s2", "y", "xn", "q", "kv", "o", "x1", "xn2", "h", "g", "stats", "kvs16")
+              "s1", "s2", "y", "xn", "q", "kv", "o", "x1", "xn2", "h", "g", "stats", "kvs16", "hid", "samp_src", "ln16_g", "ln16_b", "w1c", "flow", "xs32")
     _fields_ = [(n, _VP) for n in FIELDS]
 
 
@@ -192,6 +197,7 @@ def _load():
     lib.micf_offset_head_bwd_workspace.restype = _L
     lib.micf_block_tile_tokens.argtypes = [_I] * 8          # (no stream argument: a pure shape query)
     lib.micf_block_saves_bf16.argtypes = [_I] * 3
+    lib.micf_block_fuses_sampler.argtypes = [_I] * 2
     lib.micf_strerror.argtypes = [_I]
     lib.micf_strerror.restype = ctypes.c_char_p
     lib.micf_abi_version.argtypes = []

@@ -18,6 +18,7 @@
 
 #include "common.h"
 #include "gemm_dma.h"
+#include "sampler_common.h"
 
 namespace micf {
 
@@ -298,6 +299,13 @@ struct TileGeo {
     const int b = (int)q;
     return ((b * D + 2 * (int)xd + (i >> 2)) * H + 2 * (int)xh + ((i >> 1) & 1)) * W + 2 * (int)xw + (i & 1);
   }
+  __device__ __forceinline__ void coords(int win, int i, int& b, int& d, int& h, int& w) const {
+    uint32_t q, xw, xh, xd;
+    f_nww.divmod((uint32_t)win, q, xw);
+    f_nwh.divmod(q, q, xh);
+    f_nwd.divmod(q, q, xd);
+    b = (int)q; d = 2 * (int)xd + (i >> 2); h = 2 * (int)xh + ((i >> 1) & 1); w = 2 * (int)xw + (i & 1);
+  }
 };
 inline TileGeo make_tile_geo(int B, int D, int H, int W) {
   TileGeo g;
@@ -323,10 +331,7 @@ inline size_t block_lds_floats(int TM, int C, int scratch, int params) {
 // waves per workgroup: 8 where a launch has too few tiles to fill the chip and every tile streams megabytes of weights
 // (C = 192: 128 tiles of 16 tokens at the base model's 8^3 stage) -- the x tiles of a phase are then dealt to 8 waves
 inline int block_waves(int C) { return C >= 192 ? 8 : 4; }
-__device__ __forceinline__ float sum16(float v) {      // sum over the 16-lane group (rows are handled by 16 lanes each)
-  v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
-  return v;
-}
+// (sum16: sum over the 16-lane group that handles a row -- sampler_common.h)
 // block_wide.hip: the few-token decomposition of the same two entry points (several launches, GEMMs split over features)
 int block_wide_tile_tokens(int C, int hd);
 // Storage of what the fused kernels save for the backward / leave for the weight gradients.  MICF_DTYPE_BF16 on the

@@ -67,6 +67,7 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
     tok[tid] = tk; sc1[tid] = v1; sc2[tid] = v2;
   }
   // ---- the tile's input rows are requested first (they stay in flight under the parameter staging; x is kept for the residual)
+  const bool cross = g.kvsrc != nullptr || g.hid != nullptr;
   float4 xr[NPASS][VPL], kvv[NPASS][VPL];
 #pragma unroll
   for (int pass = 0; pass < NPASS; ++pass) {
@@ -84,6 +85,54 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
       if (g.kvsrc) kv4 = ld4g(g.kvsrc + off);           // (workgroup-uniform: a self block reads its rows once)
       xr[pass][k] = ok ? xv : make_float4(0.f, 0.f, 0.f, 0.f);
       kvv[pass][k] = ok ? kv4 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  if (g.hid) {
+    // ---- cross block with the deformable sampling fused in (MS.py:360-384, STN.py:9-32; the stand-alone form is
+    // offset_sample.hip): the 16-lane group that owns a row runs the offset head of its token -- LayerNorm(16) -> GELU -> 1^3 conv
+    // on the offset conv's output row, + reference point -- and gathers the 8 trilinear taps of the raw other modality straight
+    // into the K/V source registers: no sampler launch and no [T, C] round trip of the sampled rows through HBM.
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+      const int rowl = pass * RPP + wave * 4 + rg;
+      const int winl = tile * (TM / 8) + (rowl >> 3);
+      const bool live = rowl < TM && winl < a.geo.nwin;
+      int b = 0, d = 0, hh = 0, w = 0;
+      a.geo.coords(live ? winl : 0, rowl & 7, b, d, hh, w);
+      const int tk = ((b * a.geo.D + d) * a.geo.H + hh) * a.geo.W + w;
+      float xh, rs, ln, gl, off3[3];
+      head_fwd(g.hid + (int64_t)tk * kHid, g.ln16_g, g.ln16_b, g.w1c, a.eps, l16, xh, rs, ln, gl, off3);
+      float fl[3];
+      fl[0] = off3[0] + (((float)d + 0.5f) / (float)a.geo.H * 2.f - 1.f);      // MS.py:335  ref[...,0] /= H_key
+      fl[1] = off3[1] + (((float)hh + 0.5f) / (float)a.geo.W * 2.f - 1.f);     // MS.py:334  ref[...,1] /= W_key
+      fl[2] = off3[2] + (((float)w + 0.5f) / (float)a.geo.D * 2.f - 1.f);      // MS.py:333  ref[...,2] /= D_key
+      if (live && l16 < 3 && save) g.flow[(int64_t)tk * 3 + l16] = l16 == 0 ? fl[0] : (l16 == 1 ? fl[1] : fl[2]);
+      const Taps tp = make_taps(d, hh, w, fl, a.geo.D, a.geo.H, a.geo.W);
+      const float* base = g.samp_src + (int64_t)b * a.geo.D * a.geo.H * a.geo.W * C;
+      int lin[8]; float wgt[8]; bool okq[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int dz = q >> 2, dy = (q >> 1) & 1, dx = q & 1;
+        lin[q] = 0;
+        okq[q] = live && tp.finite && corner(tp, dz, dy, dx, a.geo.D, a.geo.H, a.geo.W, lin[q]);
+        const float wx = dx ? tp.cx - tp.x0 : (tp.x0 + 1.f) - tp.cx;
+        const float wy = dy ? tp.cy - tp.y0 : (tp.y0 + 1.f) - tp.cy;
+        const float wz = dz ? tp.cz - tp.z0 : (tp.z0 + 1.f) - tp.cz;
+        wgt[q] = okq[q] ? wx * wy * wz : 0.f;            // (an invalid tap reads token 0 of the sample with weight 0)
+      }
+#pragma unroll
+      for (int k = 0; k < VPL; ++k) {
+        const int c4 = l16 + 16 * k;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 tv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) tv[q] = ld4g(base + (int64_t)lin[q] * C + 4 * (c4 < C4 ? c4 : C4 - 1));
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {                    // (tap order 0..7 with ok-skips, as the stand-alone kernel)
+          if (okq[q]) { acc.x += tv[q].x * wgt[q]; acc.y += tv[q].y * wgt[q]; acc.z += tv[q].z * wgt[q]; acc.w += tv[q].w * wgt[q]; }
+        }
+        kvv[pass][k] = (live && c4 < C4) ? acc : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
   }
   {
@@ -139,9 +188,10 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
                                  (v[pass][k].z - mu) * rs * gm.z + bt.z, (v[pass][k].w - mu) * rs * gm.w + bt.w);
           if (tk < 0) y = make_float4(0.f, 0.f, 0.f, 0.f);
           *reinterpret_cast<float4*>(A1 + row * S + 4 * c4) = y;
-          if (g.kvsrc) *reinterpret_cast<float4*>(A2 + row * S + 4 * c4) = kvv[pass][k];
+          if (cross) *reinterpret_cast<float4*>(A2 + row * S + 4 * c4) = kvv[pass][k];
           if (tk >= 0 && g.xn && save) st_h4<BF16>(g.xn, (int64_t)tk * C + 4 * c4, y);
-          if (BF16 && tk >= 0 && g.kvsrc && g.kvs16 && save) st_h4<true>(g.kvs16, (int64_t)tk * C + 4 * c4, kvv[pass][k]);
+          if (BF16 && tk >= 0 && cross && g.kvs16 && save) st_h4<true>(g.kvs16, (int64_t)tk * C + 4 * c4, kvv[pass][k]);
+          if (!BF16 && tk >= 0 && g.hid && g.xs32 && save) st4g(g.xs32 + (int64_t)tk * C + 4 * c4, kvv[pass][k]);
         }
       }
       if (l16 == 0 && tk >= 0) { g.stats[tk] = mu; g.stats[T + tk] = rs; }
@@ -152,7 +202,7 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
   // ---- q | k | v (+ bias) -> U, then out to HBM
   if (!(a.debug & 4)) {
     // q | k | v in ONE phase (two weight segments; the biases bq | bkv are contiguous in PV)
-    gemm_phase<TJ, NSL, 1, C, NW, BF16>(wq, C, A1, wkv, 2 * C, g.kvsrc ? A2 : A1, S, U, SU, EpiBias{p_bq});
+    gemm_phase<TJ, NSL, 1, C, NW, BF16>(wq, C, A1, wkv, 2 * C, cross ? A2 : A1, S, U, SU, EpiBias{p_bq});
   }
   if (save) {
 #pragma unroll 1
@@ -375,6 +425,11 @@ extern "C" int micf_block_tile_tokens(int B, int D, int H, int W, int C, int hea
   return 16 * tj;
 }
 
+extern "C" int micf_block_fuses_sampler(int C, int heads) {
+  if (C <= 0 || heads <= 0 || C % heads) return 0;
+  return block_wide_tile_tokens(C, C / heads) ? 0 : 1;
+}
+
 extern "C" int micf_block_saves_bf16(int C, int heads, int dtype) {
   if (C <= 0 || heads <= 0 || C % heads) return 0;
   return block_saves_bf16(C, C / heads, dtype) ? 1 : 0;
@@ -395,6 +450,11 @@ extern "C" int micf_block_fwd(const micf_block_fwd_group* groups, int ngroups, i
       if (!p || (reinterpret_cast<uintptr_t>(p) & 15)) return MICF_EINVAL;
     if ((g.kvsrc && (reinterpret_cast<uintptr_t>(g.kvsrc) & 15)) || (g.xn && (reinterpret_cast<uintptr_t>(g.xn) & 15)) ||
         (g.kvs16 && (reinterpret_cast<uintptr_t>(g.kvs16) & 15))) return MICF_EINVAL;
+    if (g.hid) {      // fused sampling: the offset head's parameters, the raw source and the flow output come with it
+      if (g.kvsrc || !g.samp_src || !g.ln16_g || !g.ln16_b || !g.w1c || !g.flow || (reinterpret_cast<uintptr_t>(g.samp_src) & 15) ||
+          (g.xs32 && (reinterpret_cast<uintptr_t>(g.xs32) & 15)) || block_wide_tile_tokens(C, C / heads))
+        return MICF_EINVAL;
+    }
     a.g[i] = g;
   }
   if (ngroups == 1) a.g[1] = a.g[0];

@@ -22,9 +22,12 @@ extern "C" int micf_offset_head_fwd(const micf_offset_head_group* groups, int ng
   hipStream_t s = (hipStream_t)stream;
   Conv3FwdSet cs[2];
   SampleFwdSet ss[2];
+  bool conv_only = true;               // no flow / xs outputs: the caller samples inside micf_block_fwd
   for (int i = 0; i < ngroups; ++i) {
     const micf_offset_head_group& g = groups[i];
-    if (!g.xn || !g.xa || !g.conv_w || !g.ln_g || !g.ln_b || !g.w1 || !g.hid || !g.flow || !g.xs) return MICF_EINVAL;
+    if (!g.xn || !g.xa || !g.conv_w || !g.hid) return MICF_EINVAL;
+    conv_only = conv_only && !g.flow && !g.xs;
+    if (!conv_only && (!g.ln_g || !g.ln_b || !g.w1 || !g.flow || !g.xs)) return MICF_EINVAL;
     cs[i] = Conv3FwdSet{g.xn, g.xa, g.conv_w, g.conv_b, g.hid, g.conv_ws};
     ss[i] = SampleFwdSet{g.hid, g.ln_g, g.ln_b, g.w1, g.xa, g.flow, g.xs};
   }
@@ -37,7 +40,7 @@ extern "C" int micf_offset_head_fwd(const micf_offset_head_group* groups, int ng
       if (rc != MICF_OK) return rc;
     }
   }
-  if (rc != MICF_OK) return rc;
+  if (rc != MICF_OK || conv_only) return rc;
   return offset_sample_fwd_groups(ss, ngroups, B, D, H, W, C, eps, s);
 }
 

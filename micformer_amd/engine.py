@@ -56,9 +56,9 @@ class TrainEngine:
         self.grad_bf16 = bool(grad_bf16)
         self._wire = torch.empty(self.flat_g.numel(), dtype=torch.bfloat16, device=self.flat_g.device) if self.grad_bf16 else None
         # Graph layout of a captured step: ONE HIP graph (round 2; where its side branch runs is the graph executor's choice) or
-        # a sequence of graphs replayed on two streams with explicit events (functional.StepSegmenter; the default).
+        # a sequence of graphs replayed on two streams with explicit events (functional.StepSegmenter; opt-in, see _lib.py).
         # (needs the runtime's graph packet capture off, see _lib.GRAPH_SEGMENTS_OK: one graph otherwise)
-        self.segmented = (__import__("os").environ.get("MICF_SEGMENTED", "1") != "0") if segmented is None else bool(segmented)
+        self.segmented = (__import__("os").environ.get("MICF_SEGMENTED", "0") == "1") if segmented is None else bool(segmented)
         # ... and single-process only: with an initialised NCCL (= RCCL) process group hipGraphLaunch of a segment crashed in the
         # host runtime (tests/test_gpu_model.py::test_split_step_with_rccl_on_one_rank, ROCm 7.2), so data-parallel jobs keep the
         # one-graph layout that the round-2 RCCL tests ran on.

@@ -149,6 +149,7 @@ _PENDING_FLUSH = []                 # (event, device, linear items, LayerNorm it
 # until the capture is complete, so no later main segment can be handed their blocks.
 SEGMENTER = None
 SEG_SERIAL = __import__("os").environ.get("MICF_SEG_SERIAL", "0") == "1"      # debug: side segments on the main stream too
+SEG_SKIP_SIDE = __import__("os").environ.get("MICF_SEG_SKIP_SIDE", "0") == "1"  # measurement: the main chain alone (WRONG results)
 
 
 class StepSegmenter:
@@ -199,6 +200,8 @@ class StepSegmenter:
     def replay(self):
         main = torch.cuda.current_stream()
         for kind, g in self.segments:
+            if kind == "side" and SEG_SKIP_SIDE:
+                continue
             if kind == "main" or (kind == "side" and SEG_SERIAL):
                 g.replay()
             elif kind == "side":
@@ -835,6 +838,9 @@ _CSV_KEYS = ("q", "kv", "o", "x1", "xn2", "h", "g", "stats", "xn", "kvs16")     
 OVERLAP_CROSS_HEADS = True
 # ... superseded by the grouped entry points: both heads of a pair in every launch (micf_offset_head_fwd / _bwd)
 GROUP_CROSS_HEADS = _os.environ.get("MICF_GROUP_HEADS", "1") != "0"
+# ... and the sampling half of the head (LayerNorm-16 / GELU / 1^3 conv / reference points / trilinear gather) inside the cross
+# pair's block_fwd launch: one launch and one [T, C] round trip less per cross pair
+FUSE_SAMPLER = _os.environ.get("MICF_FUSE_SAMPLER", "1") != "0"
 
 
 def _conv_offset_wgrad(side, dhid, xn, xa, G, dims):
@@ -877,13 +883,16 @@ class CrossPairFn(torch.autograd.Function):
         B, D, H, W, C = x.shape
         dims = (B, D, H, W)
         xs = [x.reshape(-1, C), xa.reshape(-1, C)]
+        fuse_sampler = GROUP_CROSS_HEADS and FUSE_SAMPLER and ops.block_fuses_sampler(C, heads)
         if GROUP_CROSS_HEADS:
             # both offset heads per launch (micf_offset_head_fwd): no fork / join inside the captured graph
             hid = None
             if ops.offset_head_needs_zero(dims, C):     # (atomically accumulated conv output: cleared by the LayerNorm launch)
                 hid = torch.empty((2, xs[0].shape[0], 16), dtype=torch.float32, device=x.device)
             lns = ops.layernorm_fwd_pair(xs, [P["norm1.weight"] for P in Ps], [P["norm1.bias"] for P in Ps], eps, zero=hid)
-            outs = ops.offset_head_fwd([{"xn": lns[i][0], "xa": xs[1 - i], "P": Ps[i]} for i in (0, 1)], dims, eps, hid)
+            # (fuse_sampler: the 3^3 conv only -- LayerNorm(16) / GELU / 1^3 conv / sampling run inside the block launch below)
+            outs = ops.offset_head_fwd([{"xn": lns[i][0], "xa": xs[1 - i], "P": Ps[i]} for i in (0, 1)], dims, eps, hid,
+                                       sample=not fuse_sampler)
             heads_ = [lns[i] + outs[i] for i in (0, 1)]
         elif OVERLAP_CROSS_HEADS:
             main, side = torch.cuda.current_stream(), _side_stream(x.device)
@@ -900,7 +909,12 @@ class CrossPairFn(torch.autograd.Function):
         scales = [(sa1, sa2), (sb1, sb2)]
         groups = [{"x": xs[i], "kvsrc": heads_[i][5], "P": Ps[i], "attn": "cross_attn", "s1": scales[i][0], "s2": scales[i][1],
                    "want_xn": False} for i in (0, 1)]
+        if fuse_sampler:
+            for i in (0, 1):
+                groups[i].update(kvsrc=None, hid=heads_[i][3], samp_src=xs[1 - i])
         svs = ops.block_fwd(groups, dims, C, heads, eps, (C // heads) ** -0.5)
+        if fuse_sampler:                                 # (flow: saved for the sampler's adjoint; xs32: fp32 storage's kv-gradient operand)
+            heads_ = [heads_[i][:4] + (svs[i]["flow"], svs[i]["xs32"]) for i in (0, 1)]
         ctx.save_for_backward(*xs, *[t for hd in heads_ for t in hd], *[sv[k] for sv in svs for k in _CSV_KEYS], sa1, sa2, sb1, sb2,
                               *params)
         ctx.meta = (dims, heads, eps)

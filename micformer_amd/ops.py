@@ -390,9 +390,10 @@ def offset_head_needs_zero(dims, C):
     return bool(_lib.lib.micf_offset_head_needs_zero(B, D, H, W, C))
 
 
-def offset_head_fwd(groups, dims, eps, hid=None):
+def offset_head_fwd(groups, dims, eps, hid=None, sample=True):
     """groups: 1 or 2 dicts {xn [T,C], xa [T,C], P {conv_offset.* parameters}}.  The whole head(s) in one call (2-3 launches).
-    hid: optional pre-zeroed [n, T, 16] buffer (see offset_head_needs_zero).  Returns per group (hid, flow, xs)."""
+    hid: optional pre-zeroed [n, T, 16] buffer (see offset_head_needs_zero).  Returns per group (hid, flow, xs).
+    sample=False: the 3^3 conv only -- (hid, None, None); the sampling then runs inside block_fwd (its `hid` group field)."""
     B, D, H, W = dims
     T, C = groups[0]["xn"].shape
     n = len(groups)
@@ -410,7 +411,7 @@ def offset_head_fwd(groups, dims, eps, hid=None):
             need = _lib.lib.micf_conv3_fwd_workspace(16, C, C)
             ws = _new(w, need) if need > 0 else None
         keep.append(ws)
-        flow, xs = _new(gd["xn"], T, 3), _new(gd["xn"], T, C)
+        flow, xs = (_new(gd["xn"], T, 3), _new(gd["xn"], T, C)) if sample else (None, None)
         it.xn, it.xa, it.conv_w, it.conv_b, it.conv_ws = f32(gd["xn"]), f32(gd["xa"]), f32(w), f32(P["conv_offset.0.bias"]), f32(ws)
         it.ln_g, it.ln_b, it.w1 = f32(P["conv_offset.1.norm.weight"]), f32(P["conv_offset.1.norm.bias"]), f32(P["conv_offset.3.weight"])
         it.hid, it.flow, it.xs = f32(hid[i]), f32(flow), f32(xs)
@@ -422,8 +423,8 @@ def offset_head_fwd(groups, dims, eps, hid=None):
             keep.append(ws)
             it.conv_ws = f32(ws)
     call("micf_offset_head_fwd", ctypes.cast(arr, ctypes.c_void_p), n, B, D, H, W, C, float(eps), 1 if prepared else 0,
-         1 if zeroed else 0, _dt(), cost=_cost(n * (2 * T * 27 * 2 * C * 16 + T * (20 * C + 400)), *[g["xn"] for g in groups],
-                                                *[g["xa"] for g in groups], *[o[2] for o in outs]))
+         1 if zeroed else 0, _dt(), cost=_cost(n * (2 * T * 27 * 2 * C * 16 + (T * (20 * C + 400) if sample else 0)), *[g["xn"] for g in groups],
+                                                *[g["xa"] for g in groups], *[o[2] for o in outs], *[o[0] for o in outs]))
     del keep
     return outs
 
@@ -879,9 +880,14 @@ def _block_cost(nb, fl, groups, T, C, hidden, self_passes, cross_passes):
     e = 2 if _dt() else 4
     s8d = 0
     for gd in groups:
-        cross = gd.get("cross", gd.get("kvsrc") is not None)
+        cross = gd.get("cross", gd.get("kvsrc") is not None or gd.get("hid") is not None)
         s8d += (cross_passes if cross else self_passes) * T * C * e + (4 * C * C + 2 * C * hidden) * e
     return (nb, fl, f"{len(groups)}x{T}x{C}" if DETAIL else None, s8d)
+
+
+def block_fuses_sampler(C, heads):
+    """True when block_fwd can run a cross block's deformable sampling itself for this shape (group field `hid`)."""
+    return bool(_lib.lib.micf_block_fuses_sampler(C, heads))
 
 
 def block_saves_bf16(C, heads):
@@ -905,14 +911,20 @@ def block_fwd(groups, dims, C, heads, eps, scale):
     nb = fl = 0
     for it, gd in zip(arr, groups):
         x, P, a = gd["x"], gd["P"], gd["attn"]
-        cross = gd.get("kvsrc") is not None
+        fused_sampler = gd.get("hid") is not None       # cross block that samples its K/V source itself: {hid, samp_src} given
+        cross = gd.get("kvsrc") is not None or fused_sampler
         o = {"y": _new(x, T, C), "q": _new(x, T, C, dtype=sd), "kv": _new(x, T, 2 * C, dtype=sd), "o": _new(x, T, C, dtype=sd),
              "x1": _new(x, T, C), "xn2": _new(x, T, C, dtype=sd), "h": _new(x, T, hidden, dtype=h_dtype),
              "g": _new(x, T, hidden, dtype=sd), "stats": _new(x, 4, T),
              # (bf16 storage: the q weight gradient pairs a bf16 dq with a bf16 xn, so the kernel always writes its own copy)
              "xn": _new(x, T, C, dtype=sd) if (gd.get("want_xn", True) or st16) else None,
-             "kvs16": _new(x, T, C, dtype=sd) if (st16 and cross) else None}
+             "kvs16": _new(x, T, C, dtype=sd) if (st16 and cross) else None,
+             "flow": _new(x, T, 3) if fused_sampler else None,
+             "xs32": _new(x, T, C) if (fused_sampler and not st16) else None}
         it.x, it.kvsrc, it.s1, it.s2 = f32(x), f32(gd.get("kvsrc")), f32(gd.get("s1")), f32(gd.get("s2"))
+        if fused_sampler:
+            it.hid, it.samp_src = f32(gd["hid"]), f32(gd["samp_src"])
+            it.ln16_g, it.ln16_b, it.w1c = (f32(P[k]) for k in ("conv_offset.1.norm.weight", "conv_offset.1.norm.bias", "conv_offset.3.weight"))
         for field, key in FWD_W:
             setattr(it, field, f32(P[key.format(a=a)]))
         wts = block_weights(P, a, backward=False)
@@ -923,7 +935,8 @@ def block_fwd(groups, dims, C, heads, eps, scale):
             setattr(it, k, ptr(v))
         outs.append(o)
         # bytes the launch moves: read x (+ kvsrc), write everything in `o`; the weights once
-        nb += 4 * T * C * (2 if cross else 1) + sum(v.numel() * v.element_size() for v in o.values() if v is not None) \
+        nb += 4 * T * C * (2 if cross else 1) + (64 * T if fused_sampler else 0) \
+            + sum(v.numel() * v.element_size() for v in o.values() if v is not None) \
             + 12 * C * C * wt.element_size()
         fl += 2 * T * 12 * C * C + 4 * T * C * 8
     call("micf_block_fwd", ctypes.cast(arr, ctypes.c_void_p), len(groups), B, D, H, W, C, heads, hidden, float(eps), float(scale),

@@ -3,8 +3,6 @@ import sys
 
 import pytest
 
-os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")     # (micformer_amd/_lib.py: before the HIP runtime initialises)
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -1,5 +1,6 @@
 """Debug driver for the segmented step capture: small and base configurations, segmented vs eager."""
 import os, sys, math
+os.environ["MICF_SEGMENTED"] = "1"          # (before micformer_amd / the HIP runtime: _lib.py turns the graph packet capture off)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch

@@ -41,7 +41,9 @@ bad = 0
 names = [n for n, _ in ref.model.named_parameters()]
 for nm, o, m in zip(names, ref.offsets, ref.sizes):
     a, b = g0[o:o + m], g1[o:o + m]
-    if float((a - b).abs().max()) > 0.02 * float(a.abs().max()) + 1e-6 * sc:
+    # (bf16: tensors whose whole gradient is rounding-level small are run-to-run noise -- the gates of test_step_layouts_agree)
+    rel_tol, floor = (0.06, 3e-4) if os.environ.get("DT", "fp32") == "bf16" else (0.02, 1e-6)
+    if float((a - b).abs().max()) > rel_tol * float(a.abs().max()) + floor * sc:
         bad += 1
         print("   off:", nm, float(a.abs().max()), float(b.abs().max()), float((a - b).abs().max()))
 print("gradient slices off:", bad, "of", len(ref.sizes), flush=True)

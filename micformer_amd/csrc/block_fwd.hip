@@ -27,7 +27,9 @@ struct BlkFwdArgs {
 
 // rows of a [TM][X] tile are handled by 16-lane groups: pass p, wave w, lane group rg -> row p*16 + 4*w + rg; lane l16 covers
 // the float4 columns l16, l16 + 16, ...
-template <int C, int HD, int TJ, int NW, bool BF16>
+// SAMP: the variant whose cross blocks sample their K/V source themselves (micf_block_fwd_group.hid).  Its own instantiation: the
+// sampling prologue costs registers (8 taps in flight per row), and the self blocks -- half of all launches -- must not pay for it.
+template <int C, int HD, int TJ, int NW, bool BF16, bool SAMP>
 __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) {
   constexpr int TM = 16 * TJ, VPL = (C + 63) / 64, NSL = C / 16, NTHR = 64 * NW, RPP = 4 * NW, NPASS = (TM + RPP - 1) / RPP;
   extern __shared__ __attribute__((aligned(1024))) float lds[];
@@ -67,7 +69,7 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
     tok[tid] = tk; sc1[tid] = v1; sc2[tid] = v2;
   }
   // ---- the tile's input rows are requested first (they stay in flight under the parameter staging; x is kept for the residual)
-  const bool cross = g.kvsrc != nullptr || g.hid != nullptr;
+  const bool cross = g.kvsrc != nullptr || (SAMP && g.hid != nullptr);
   float4 xr[NPASS][VPL], kvv[NPASS][VPL];
 #pragma unroll
   for (int pass = 0; pass < NPASS; ++pass) {
@@ -87,7 +89,7 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
       kvv[pass][k] = ok ? kv4 : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
-  if (g.hid) {
+  if (SAMP && g.hid) {
     // ---- cross block with the deformable sampling fused in (MS.py:360-384, STN.py:9-32; the stand-alone form is
     // offset_sample.hip): the 16-lane group that owns a row runs the offset head of its token -- LayerNorm(16) -> GELU -> 1^3 conv
     // on the offset conv's output row, + reference point -- and gathers the 8 trilinear taps of the raw other modality straight
@@ -191,7 +193,7 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
           if (cross) *reinterpret_cast<float4*>(A2 + row * S + 4 * c4) = kvv[pass][k];
           if (tk >= 0 && g.xn && save) st_h4<BF16>(g.xn, (int64_t)tk * C + 4 * c4, y);
           if (BF16 && tk >= 0 && cross && g.kvs16 && save) st_h4<true>(g.kvs16, (int64_t)tk * C + 4 * c4, kvv[pass][k]);
-          if (!BF16 && tk >= 0 && g.hid && g.xs32 && save) st4g(g.xs32 + (int64_t)tk * C + 4 * c4, kvv[pass][k]);
+          if (SAMP && !BF16 && tk >= 0 && g.hid && g.xs32 && save) st4g(g.xs32 + (int64_t)tk * C + 4 * c4, kvv[pass][k]);
         }
       }
       if (l16 == 0 && tk >= 0) { g.stats[tk] = mu; g.stats[T + tk] = rs; }
@@ -388,11 +390,19 @@ static int launch_fwd(const BlkFwdArgs& a, int dtype, hipStream_t s) {
   const unsigned grid = a.G == 2 ? (unsigned)((a.tiles + 3) / 4 * 8) : (unsigned)a.tiles;
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_fwd_kernel<C, HD, TJ, NW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_fwd_kernel<C, HD, TJ, NW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_fwd_kernel<C, HD, TJ, NW, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_fwd_kernel<C, HD, TJ, NW, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_fwd_kernel<C, HD, TJ, NW, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_fwd_kernel<C, HD, TJ, NW, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
-  if (dtype == MICF_DTYPE_BF16) hipLaunchKernelGGL((block_fwd_kernel<C, HD, TJ, NW, true>), dim3(grid), dim3(64 * NW), lds, s, a);
-  else hipLaunchKernelGGL((block_fwd_kernel<C, HD, TJ, NW, false>), dim3(grid), dim3(64 * NW), lds, s, a);
+  const bool samp = a.g[0].hid != nullptr || a.g[1].hid != nullptr;
+  if (dtype == MICF_DTYPE_BF16) {
+    if (samp) hipLaunchKernelGGL((block_fwd_kernel<C, HD, TJ, NW, true, true>), dim3(grid), dim3(64 * NW), lds, s, a);
+    else hipLaunchKernelGGL((block_fwd_kernel<C, HD, TJ, NW, true, false>), dim3(grid), dim3(64 * NW), lds, s, a);
+  } else {
+    if (samp) hipLaunchKernelGGL((block_fwd_kernel<C, HD, TJ, NW, false, true>), dim3(grid), dim3(64 * NW), lds, s, a);
+    else hipLaunchKernelGGL((block_fwd_kernel<C, HD, TJ, NW, false, false>), dim3(grid), dim3(64 * NW), lds, s, a);
+  }
   MICF_RETURN_LAUNCH();
 }
 

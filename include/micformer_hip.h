@@ -134,6 +134,12 @@ int micf_head_tail_compose(const float* w_up, const float* b_up, const float* w_
                            int Co, int P, const float* w_up_t, micf_stream_t stream);
 int micf_head_tail_col2im(const float* t, const float* b_out, float* y, int B, int Dc, int Hc, int Wc, int Co, int P,
                           micf_stream_t stream);
+/* The same gather-sum for SLIDING-WINDOW INFERENCE (utils.py:226-234): T holds n windows; window i's logits are ADDED into the fp32
+ * volume accumulator out [VB, Co, VD, VH, VW] at coords[4 i ..] = {volume sample, z0, y0, x0} and count [VB, VD, VH, VW] += 1
+ * there -- the inferer's accumulate / count epilogue fused into the logits store (no [n, Co, roi] prediction tensor, no separate
+ * accumulate launch).  coords is DEVICE memory (int32): a captured predictor graph is replayed with new origins. */
+int micf_head_tail_col2im_sw(const float* t, const float* b_out, float* out, float* count, const int32_t* coords, int n, int Dc,
+                             int Hc, int Wc, int Co, int P, int VB, int VD, int VH, int VW, micf_stream_t stream);
 int micf_head_tail_im2col(const float* dy, float* u, int B, int Dc, int Hc, int Wc, int Co, int P, micf_stream_t stream);
 int micf_head_tail_decompose(const float* dwb, const float* dbf, const float* w_up, const float* b_up, const float* w_out,
                              float* dw_up, float* db_up, float* dw_out, float* db_out, int Ci, int Cm, int Co, int P,
@@ -270,6 +276,13 @@ int micf_sw_accumulate_batch(const float* pred, float* out, float* count, const 
  * params [B,5] = {flip D, flip H, flip W (0/1), f, o} on the device, or NULL (validation: normalise only).
  * (Normalising before or after the flips is the same: the statistics are permutation-invariant.) */
 int micf_intensity_stats(const void* vol, int is_half, double* sums, int B, int Cm, int64_t V, micf_stream_t stream);
+/* The same tail fused into PATCH EMBEDDING's gather (MS.py:860-878): rows0 / rows1 [B * ceil(D/k) * ceil(H/k) * ceil(W/k), k^3] =
+ * the patch-row matrices of modality 0 / 1 (the operand of the k = s convolution as a GEMM: micf_space_to_depth's layout) computed
+ * from the RAW volume with the flips as index arithmetic and normalise / scale / shift as one affine map per (sample, channel);
+ * the prepared float32 volume is never written.  Cm <= 2; rows1 NULL for one modality.  micf_input_prepare with out == NULL then
+ * only flips the label map. */
+int micf_patch_rows_prepared(const void* vol, int is_half, const double* sums, const float* params, float* rows0, float* rows1, int B,
+                             int Cm, int D, int H, int W, int k, micf_stream_t stream);
 int micf_input_prepare(const void* vol, int is_half, const double* sums, const float* params, float* out, const uint8_t* label_in,
                        uint8_t* label_out, int B, int Cm, int D, int H, int W, micf_stream_t stream);
 

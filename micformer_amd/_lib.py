@@ -47,6 +47,7 @@ SIGNATURES = {
     "micf_head_tail_compose": "pppppiiiipp",
     "micf_head_tail_col2im": "pppiiiiiip",
     "micf_head_tail_im2col": "ppiiiiiip",
+    "micf_head_tail_col2im_sw": "pppppiiiiiiiiiip",
     "micf_head_tail_decompose": "pppppppppiiiipp",
     "micf_sw_window": "ppiiiiiiiiiip",
     "micf_sw_accumulate": "pppiiiiiiiiiip",
@@ -104,6 +105,7 @@ SIGNATURES = {
     "micf_sw_accumulate_batch": "ppppiiiiiiiiip",
     "micf_intensity_stats": "pipiilp",
     "micf_input_prepare": "pipppppiiiiip",
+    "micf_patch_rows_prepared": "pippppiiiiiip",
     "micf_zero": "plp",
     "micf_drop_path_draw": "pppiip",
 }

@@ -50,9 +50,15 @@ __global__ void __launch_bounds__(256) tail_compose_kernel(const float* __restri
 }
 
 // y[b, o, u] = b_out[o] + sum of T over the coarse voxels whose (P+2)^3 patch covers u.  One thread per fine voxel.
+// sw != nullptr: sliding-window inference (utils.py:226-234) -- batch entry b is WINDOW b of a volume: its logits are ADDED into the
+// fp32 volume accumulator y [VB, Co, VD, VH, VW] at the window's origin sw[4 b ..] = {volume sample, z0, y0, x0} (device
+// memory, so a captured predictor graph can be replayed with new coordinates) and the visit count of the voxel is bumped: the
+// accumulate / count epilogue of the reference's inferer fused into the logits store (windows of one batch may overlap: fp32 atomics).
 template <int CO>
 __global__ void __launch_bounds__(256) tail_col2im_kernel(const float* __restrict__ T, const float* __restrict__ b_out,
-                                                          float* __restrict__ y, int B, int Dc, int Hc, int Wc, int Co_rt, int P) {
+                                                          float* __restrict__ y, int B, int Dc, int Hc, int Wc, int Co_rt, int P,
+                                                          const int32_t* __restrict__ sw, float* __restrict__ count, int VD, int VH,
+                                                          int VW) {
   const int Co = CO ? CO : Co_rt;
   const int F = P + 2, Df = Dc * P, Hf = Hc * P, Wf = Wc * P;
   const int64_t plane = (int64_t)Df * Hf * Wf;
@@ -92,6 +98,15 @@ __global__ void __launch_bounds__(256) tail_col2im_kernel(const float* __restric
           for (int o = 0; o < MAXCO; ++o) if (o < Co) acc[o] += src[o];
         }
       }
+  if (sw) {
+    const int vb = sw[4 * b], z = sw[4 * b + 1] + ud, yy = sw[4 * b + 2] + uh, x = sw[4 * b + 3] + uw;
+    const int64_t vplane = (int64_t)VD * VH * VW, v = ((int64_t)z * VH + yy) * VW + x;
+    float* dst = y + (int64_t)vb * Co * vplane + v;
+#pragma unroll
+    for (int o = 0; o < MAXCO; ++o) if (o < Co) atomicAdd(dst + (int64_t)o * vplane, acc[o]);
+    atomicAdd(count + (int64_t)vb * vplane + v, 1.f);
+    return;
+  }
   float* dst = y + (int64_t)b * Co * plane + ((int64_t)ud * Hf + uh) * Wf + uw;
 #pragma unroll
   for (int o = 0; o < MAXCO; ++o) if (o < Co) dst[(int64_t)o * plane] = acc[o];
@@ -259,8 +274,21 @@ extern "C" int micf_head_tail_col2im(const float* t, const float* b_out, float* 
   const int64_t total = (int64_t)B * Dc * Hc * Wc * P * P * P;
   const unsigned blocks = (unsigned)((total + 255) / 256);
   hipStream_t s = (hipStream_t)stream;
-  if (Co == 8 && aligned16(t)) hipLaunchKernelGGL(tail_col2im_kernel<8>, dim3(blocks), dim3(256), 0, s, t, b_out, y, B, Dc, Hc, Wc, Co, P);
-  else hipLaunchKernelGGL(tail_col2im_kernel<0>, dim3(blocks), dim3(256), 0, s, t, b_out, y, B, Dc, Hc, Wc, Co, P);
+  if (Co == 8 && aligned16(t)) hipLaunchKernelGGL(tail_col2im_kernel<8>, dim3(blocks), dim3(256), 0, s, t, b_out, y, B, Dc, Hc, Wc, Co, P, nullptr, nullptr, 0, 0, 0);
+  else hipLaunchKernelGGL(tail_col2im_kernel<0>, dim3(blocks), dim3(256), 0, s, t, b_out, y, B, Dc, Hc, Wc, Co, P, nullptr, nullptr, 0, 0, 0);
+  MICF_RETURN_LAUNCH();
+}
+
+extern "C" int micf_head_tail_col2im_sw(const float* t, const float* b_out, float* out, float* count, const int32_t* coords, int n,
+                                        int Dc, int Hc, int Wc, int Co, int P, int VB, int VD, int VH, int VW, micf_stream_t stream) {
+  if (!t || !b_out || !out || !count || !coords || n <= 0 || Dc <= 0 || Hc <= 0 || Wc <= 0 || VB <= 0) return MICF_EINVAL;
+  if (Dc * P > VD || Hc * P > VH || Wc * P > VW) return MICF_EINVAL;      // (the window must fit the volume; origins are the caller's)
+  if (!dims_ok(1, 1, Co, P)) return MICF_EUNSUPPORTED;
+  const int64_t total = (int64_t)n * Dc * Hc * Wc * P * P * P;
+  const unsigned blocks = (unsigned)((total + 255) / 256);
+  hipStream_t s = (hipStream_t)stream;
+  if (Co == 8 && aligned16(t)) hipLaunchKernelGGL(tail_col2im_kernel<8>, dim3(blocks), dim3(256), 0, s, t, b_out, out, n, Dc, Hc, Wc, Co, P, coords, count, VD, VH, VW);
+  else hipLaunchKernelGGL(tail_col2im_kernel<0>, dim3(blocks), dim3(256), 0, s, t, b_out, out, n, Dc, Hc, Wc, Co, P, coords, count, VD, VH, VW);
   MICF_RETURN_LAUNCH();
 }
 

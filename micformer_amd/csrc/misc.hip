@@ -406,7 +406,7 @@ __global__ void __launch_bounds__(256) input_prepare_kernel(const T* __restrict_
     const int w = (int)(i % W); int64_t r = i / W;
     const int h = (int)(r % H); const int d = (int)(r / H);
     const int64_t src = ((int64_t)(fd ? D - 1 - d : d) * H + (fh ? H - 1 - h : h)) * W + (fw ? W - 1 - w : w);
-    for (int m = 0; m < Cm; ++m) {
+    for (int m = 0; m < (out ? Cm : 0); ++m) {
       const double* sp = sums + ((int64_t)b * Cm + m) * 3;
       const double n = sp[2];
       const double mean = n > 0 ? sp[0] / n : 0.0;
@@ -421,7 +421,66 @@ __global__ void __launch_bounds__(256) input_prepare_kernel(const T* __restrict_
     if (lab_in) lab_out[(int64_t)b * V + i] = lab_in[(int64_t)b * V + src];
   }
 }
+// The same arithmetic fused into patch embedding's gather (SURVEY 8(f) row 3 as written): rows[m][r, tap] of modality m =
+// prepared value of the fine voxel (k zc + tz, k yc + ty, k xc + tx), r = ((b Dc + zc) Hc + yc) Wc + xc -- the [tokens, k^3] matrix
+// the patch-embedding GEMM reads (patch.hip's space-to-depth layout), straight from the RAW volume: the flips are index
+// arithmetic, normalise / scale / shift one affine map per (sample, channel); the float32 volume is never written.
+// Voxels beyond the volume (right padding to a multiple of k, MS.py:866-872) are zero, as F.pad leaves them.
+template <class T>
+__global__ void __launch_bounds__(256) patch_rows_prepared_kernel(const T* __restrict__ vol, const double* __restrict__ sums,
+                                                                  const float* __restrict__ params, float* __restrict__ rows0,
+                                                                  float* __restrict__ rows1, int B, int Cm, int D, int H, int W, int k,
+                                                                  int Dc, int Hc, int Wc, int64_t total4) {
+  const int m = blockIdx.y;
+  float* rows = m == 0 ? rows0 : rows1;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4 || !rows) return;
+  const int K3 = k * k * k, q4 = K3 >> 2;
+  const int t4 = (int)(i % q4);
+  int64_t r = i / q4;
+  const int xc = (int)(r % Wc); int64_t r2 = r / Wc;
+  const int yc = (int)(r2 % Hc); r2 /= Hc;
+  const int zc = (int)(r2 % Dc); const int b = (int)(r2 / Dc);
+  int fd = 0, fh = 0, fw = 0;
+  float f = 0.f, o = 0.f;
+  if (params) { fd = params[b * 5] != 0.f; fh = params[b * 5 + 1] != 0.f; fw = params[b * 5 + 2] != 0.f; f = params[b * 5 + 3]; o = params[b * 5 + 4]; }
+  const double* sp = sums + ((int64_t)b * Cm + m) * 3;
+  const double n = sp[2];
+  const double mean = n > 0 ? sp[0] / n : 0.0;
+  double var = n > 0 ? sp[1] / n - mean * mean : 0.0;
+  if (var < 0) var = 0;
+  double sd = sqrt(var);
+  if (sd == 0.0) sd = 1.0;
+  const int64_t V = (int64_t)D * H * W;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int tap = 4 * t4 + j;
+    const int tz = tap / (k * k), ty = (tap / k) % k, tx = tap % k;
+    const int z = zc * k + tz, y = yc * k + ty, x = xc * k + tx;
+    if (z >= D || y >= H || x >= W) continue;
+    const int64_t src = ((int64_t)(fd ? D - 1 - z : z) * H + (fh ? H - 1 - y : y)) * W + (fw ? W - 1 - x : x);
+    const float raw = ldv<T>(vol, ((int64_t)b * Cm + m) * V + src);
+    const float yv = raw != 0.f ? (float)(((double)raw - mean) / sd) : 0.f;
+    v[j] = yv * (1.f + f) + o;
+  }
+  *reinterpret_cast<float4*>(rows + r * K3 + 4 * t4) = make_float4(v[0], v[1], v[2], v[3]);
+}
 }  // namespace micf
+
+extern "C" int micf_patch_rows_prepared(const void* vol, int is_half, const double* sums, const float* params, float* rows0,
+                                        float* rows1, int B, int Cm, int D, int H, int W, int k, micf_stream_t stream) {
+  if (!vol || !sums || (!rows0 && !rows1) || B <= 0 || Cm < 1 || Cm > 2 || (Cm == 1 && rows1) || D <= 0 || H <= 0 || W <= 0 ||
+      (k != 2 && k != 4))
+    return MICF_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(rows0) | reinterpret_cast<uintptr_t>(rows1)) & 15) return MICF_EINVAL;
+  const int Dc = (D + k - 1) / k, Hc = (H + k - 1) / k, Wc = (W + k - 1) / k;
+  const int64_t total4 = (int64_t)B * Dc * Hc * Wc * (k * k * k / 4);
+  const dim3 grid((unsigned)((total4 + 255) / 256), Cm);
+  if (is_half) hipLaunchKernelGGL(micf::patch_rows_prepared_kernel<__half>, grid, dim3(256), 0, (hipStream_t)stream, static_cast<const __half*>(vol), sums, params, rows0, rows1, B, Cm, D, H, W, k, Dc, Hc, Wc, total4);
+  else hipLaunchKernelGGL(micf::patch_rows_prepared_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, static_cast<const float*>(vol), sums, params, rows0, rows1, B, Cm, D, H, W, k, Dc, Hc, Wc, total4);
+  MICF_RETURN_LAUNCH();
+}
 
 extern "C" int micf_intensity_stats(const void* vol, int is_half, double* sums, int B, int Cm, int64_t V, micf_stream_t stream) {
   if (!vol || !sums || B <= 0 || Cm <= 0 || V <= 0) return MICF_EINVAL;
@@ -435,7 +494,8 @@ extern "C" int micf_intensity_stats(const void* vol, int is_half, double* sums, 
 }
 extern "C" int micf_input_prepare(const void* vol, int is_half, const double* sums, const float* params, float* out,
                                   const uint8_t* label_in, uint8_t* label_out, int B, int Cm, int D, int H, int W, micf_stream_t stream) {
-  if (!vol || !sums || !out || B <= 0 || Cm <= 0 || D <= 0 || H <= 0 || W <= 0 || (label_in && !label_out)) return MICF_EINVAL;
+  // (out == NULL with a label map: flip the labels only -- the image then goes through micf_patch_rows_prepared)
+  if (!vol || !sums || (!out && !label_in) || B <= 0 || Cm <= 0 || D <= 0 || H <= 0 || W <= 0 || (label_in && !label_out)) return MICF_EINVAL;
   const int64_t V = (int64_t)D * H * W;
   const dim3 grid(grid_for(V) > 1024 ? 1024 : grid_for(V), B);
   if (is_half) hipLaunchKernelGGL(micf::input_prepare_kernel<__half>, grid, dim3(256), 0, (hipStream_t)stream, static_cast<const __half*>(vol), sums, params, out, label_in, label_out, Cm, D, H, W);

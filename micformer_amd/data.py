@@ -34,3 +34,47 @@ def prepare_batch(image, label_map=None, params=None):
     """image [B, 2, D, H, W] float16 / float32 raw intensities on the GPU, label_map [B, D, H, W] uint8 (or None), params from
     draw_augmentation (None = the validation transform: normalise only, train.py:126-130).  -> (x float32 for Head, label map)."""
     return ops.input_prepare(image.contiguous(), None if label_map is None else label_map.contiguous(), params)
+
+
+class RawBatch:
+    """The raw image batch with its augmentation draws, for a Head whose patch embedding applies the input tail itself (flips as
+    index arithmetic, normalise / scale / shift as one affine map per (sample, channel) inside the patch gather,
+    micf_patch_rows_prepared): `model(RawBatch(image, params))` equals `model(prepare_batch(image, None, params)[0])` without the
+    float32 volume ever being written.  Quacks like the (B, 2, D, H, W) tensor where Head / TrainEngine look at it."""
+
+    def __init__(self, image, params=None, sums=None):
+        if image.dim() != 5 or image.shape[1] != 2 or image.dtype not in (torch.float16, torch.float32) or not image.is_cuda:
+            raise ValueError("RawBatch expects a (B, 2, D, H, W) float16 / float32 CUDA volume")
+        self.image = image.contiguous()
+        self.params = None if params is None else params.to(image.device, torch.float32).contiguous()
+        self.sums = sums                                  # per-channel non-zero statistics (computed on first use)
+
+    shape = property(lambda self: self.image.shape)
+    dtype = property(lambda self: self.image.dtype)
+    device = property(lambda self: self.image.device)
+    is_cuda = True
+
+    def dim(self):
+        return 5
+
+    def clone(self):
+        return RawBatch(self.image.clone(), None if self.params is None else self.params.clone())
+
+    def copy_(self, other, non_blocking=False):
+        """In-place refresh of a captured step's static input (TrainEngine): the statistics are recomputed by the replay."""
+        self.image.copy_(other.image, non_blocking=non_blocking)
+        if self.params is not None:
+            self.params.copy_(other.params, non_blocking=non_blocking)
+        return self
+
+    def patch_rows(self, k):
+        """-> ([rows of modality 0, rows of modality 1], (B, D', H', W')): two launches (statistics, gather)."""
+        B, _, D, H, W = self.image.shape
+        sums = ops.intensity_stats(self.image)            # (inside a captured step: part of the graph, fresh per replay)
+        return ops.patch_rows_prepared(self.image, sums, self.params, k), (B, -(-D // k), -(-H // k), -(-W // k))
+
+
+def prepare_raw_batch(image, label_map=None, params=None):
+    """The fused counterpart of prepare_batch: -> (RawBatch for Head, flipped uint8 label map)."""
+    lab = None if label_map is None else ops.flip_labels(label_map.contiguous(), None if params is None else params.to(image.device))
+    return RawBatch(image, params), lab

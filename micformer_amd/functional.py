@@ -1016,6 +1016,26 @@ class PatchEmbedFn(torch.autograd.Function):
         return None, None, _ret(ctx.tg[0], dw), _ret(ctx.tg[1], db), None   # the input volume is data: no gradient (train.py:177-185)
 
 
+class PatchRowsEmbedFn(torch.autograd.Function):
+    """PatchEmbed3D on an already gathered [tokens, k^3] patch-row matrix (ops.patch_rows_prepared: the input tail fused into the
+    gather) -> tokens [rows, E].  The rows are data: no gradient."""
+
+    @staticmethod
+    def forward(ctx, a, w, b):
+        E = w.shape[0]
+        ctx.save_for_backward(a, w)
+        ctx.tg = _targets((w, b))
+        return ops.linear_fwd(a, w.reshape(E, -1), b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, w = ctx.saved_tensors
+        dw = _grad_buf(ctx.tg[0], w)
+        db = ctx.tg[1] if ctx.tg[1] is not None else torch.zeros(w.shape[0], dtype=w.dtype, device=w.device)
+        _lin_wgrad(ctx.tg[0] is not None and ctx.tg[1] is not None, _c(dy).reshape(-1, w.shape[0]), a, dw.view(w.shape[0], -1), db)
+        return None, _ret(ctx.tg[0], dw), _ret(ctx.tg[1], db)
+
+
 class ConvDownFn(torch.autograd.Function):
     """Conv3d(C->N, k=s=2) of PatchMerging on channels-last x (MS.py:548-557)."""
 

@@ -18,6 +18,9 @@ from . import _lib
 from ._lib import call, f32
 
 
+FUSE_ACCUMULATE = __import__("os").environ.get("MICF_SW_FUSE", "1") != "0"
+
+
 def sliding_window_starts(L, roi, overlap=0.5):
     if L <= roi:
         return [0]
@@ -68,6 +71,48 @@ class GraphedPredictor:
         graph.replay()
         return static_out
 
+    def accumulators(self, shape, device):
+        """Persistent (out, count) volume accumulators per volume shape: the captured accumulate graphs bake their addresses in,
+        so re-using them across volumes avoids a re-capture per volume.  sliding_window_inference returns a copy of `out`."""
+        acc = self.__dict__.setdefault("_acc", {})
+        key = (tuple(shape), str(device))
+        if key not in acc:
+            B, K, D, H, W = shape
+            acc[key] = (torch.empty(shape, dtype=torch.float32, device=device), torch.empty((B, D, H, W), dtype=torch.float32, device=device))
+        return acc[key]
+
+    def accumulate(self, x, out, count, coords):
+        """The predictor's `forward_accumulate` (windows -> ADDED into the volume accumulator at `coords`, see
+        MICFormer_self.Head.forward_accumulate) replayed from one HIP graph per (window batch shape, accumulator): the accumulator
+        addresses are baked in, the coordinates are a static device tensor refreshed before every replay."""
+        from . import ops
+        stamp = (ops.PARAM_EPOCH[0], self._param_versions())
+        if getattr(self, "_epoch", None) != stamp:
+            self.graphs.clear()
+            self._epoch = stamp
+        key = ("acc", tuple(x.shape), x.dtype, ops.compute_dtype(), out.data_ptr(), count.data_ptr())
+        entry = self.graphs.get(key)
+        if entry is None:
+            static_in, static_c = x.clone(), coords.clone()
+            keep_out, keep_cnt = out.clone(), count.clone()             # the eager warm-up runs accumulate for real: undone below
+            side = torch.cuda.Stream(device=x.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(self.warmup):
+                    self.predictor.forward_accumulate(static_in, out, count, static_c)
+            torch.cuda.current_stream().wait_stream(side)
+            out.copy_(keep_out)
+            count.copy_(keep_cnt)
+            del keep_out, keep_cnt
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph), torch.no_grad():
+                self.predictor.forward_accumulate(static_in, out, count, static_c)
+            entry = self.graphs[key] = (graph, static_in, static_c)
+        graph, static_in, static_c = entry
+        static_in.copy_(x)
+        static_c.copy_(coords)
+        graph.replay()
+
 
 def sliding_window_inference(inputs, roi_size, sw_batch_size, predictor, overlap=0.5, mode="constant", *, graph=False,
                              autocast=False):
@@ -96,7 +141,37 @@ def sliding_window_inference(inputs, roi_size, sw_batch_size, predictor, overlap
     sw = min(max(int(sw_batch_size), 1), 64)
     out = count = None
     from . import ops
+    # Fused epilogue: a predictor that offers `forward_accumulate` (MICFormer_self.Head with the composed head)
+    # adds its logits straight into the volume accumulator at the window origins and bumps the visit counts in its last launch --
+    # no [n, K, roi] prediction tensor, no accumulate launch.  Needs roi dims that the patch size divides (else the model pads).
+    base = predictor.predictor if isinstance(predictor, GraphedPredictor) else predictor
+    fused = FUSE_ACCUMULATE and hasattr(base, "forward_accumulate") and hasattr(base, "out_conv") and not (rd % 4 or rh % 4 or rw % 4)
     with torch.no_grad():
+        if fused:
+            K = base.out_conv.out_channels
+            cached = isinstance(predictor, GraphedPredictor)
+            if cached:
+                out, count = predictor.accumulators((B, K, Dp, Hp, Wp), x.device)
+            else:
+                out = torch.empty((B, K, Dp, Hp, Wp), dtype=torch.float32, device=x.device)
+                count = torch.empty((B, Dp, Hp, Wp), dtype=torch.float32, device=x.device)
+            ops.zero_(out)
+            ops.zero_(count)
+            prev = ops.compute_dtype()
+            if autocast:
+                ops.set_compute_dtype("bf16")
+            try:
+                for i in range(0, len(slices), sw):
+                    chunk = slices[i:i + sw]
+                    win = ops.sw_window_batch(x, chunk, (rd, rh, rw))
+                    coords = torch.tensor(chunk, dtype=torch.int32).to(x.device, non_blocking=True)
+                    if isinstance(predictor, GraphedPredictor):
+                        predictor.accumulate(win, out, count, coords)
+                    else:
+                        base.forward_accumulate(win, out, count, coords)
+            finally:
+                ops.set_compute_dtype(prev)
+            slices = []
         for i in range(0, len(slices), sw):
             chunk = slices[i:i + sw]
             win = ops.sw_window_batch(x, chunk, (rd, rh, rw))                 # ONE launch crops the whole batch of windows
@@ -118,6 +193,8 @@ def sliding_window_inference(inputs, roi_size, sw_batch_size, predictor, overlap
             ops.sw_accumulate_batch(pred, out, count, chunk)                  # ONE launch adds it into the volume accumulator
         for b in range(B):
             call("micf_sw_normalize", f32(out[b]), f32(count[b]), K, V)
+        if fused and cached:
+            out = out.clone()                             # (the accumulator itself stays with the predictor's graphs)
     if pd or ph or pw:
         out = out[:, :, pd // 2:pd // 2 + D, ph // 2:ph // 2 + H, pw // 2:pw // 2 + W].contiguous()
     return out

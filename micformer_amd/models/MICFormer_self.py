@@ -506,6 +506,13 @@ class PatchEmbed3D(nn.Module):
             y = Fn.LayerNormFn.apply(y, None, self.norm.weight, self.norm.bias, self.norm.eps)
         return y
 
+    def tokens_from_rows(self, rows, grid):
+        """rows [B * D' * H' * W', k^3] (the patch-row matrix of one modality, ops.patch_rows_prepared), grid (B, D', H', W')."""
+        y = Fn.PatchRowsEmbedFn.apply(rows, self.proj.weight, self.proj.bias).reshape(tuple(grid) + (self.embed_dim,))
+        if self.norm is not None:
+            y = Fn.LayerNormFn.apply(y, None, self.norm.weight, self.norm.bias, self.norm.eps)
+        return y
+
     def forward(self, x):
         return self.tokens(x, 0).permute(0, 4, 1, 2, 3)
 
@@ -585,8 +592,17 @@ class MicFormer(nn.Module):
     def coarse_features(self, vol_m, mod_m, vol_f, mod_f):
         """Channels-last (B, D/P, H/P, W/P, 2E) tokens after norm2, the input of reverse_patch_embedding (MS.py:1033-1036)."""
         self._predraw_drop_path(vol_m.shape[0], vol_m.device)
-        m = self.patch_embed.tokens(vol_m, mod_m)
-        f = self.patch_embed.tokens(vol_f, mod_f)
+        if hasattr(vol_m, "patch_rows"):        # data.RawBatch: the input tail runs inside the patch gather (SURVEY 8(f) row 3)
+            P = self.patch_size[0]
+            rows, grid = vol_m.patch_rows(P)
+            m = self.patch_embed.tokens_from_rows(rows[0], grid)
+            f = self.patch_embed.tokens_from_rows(rows[1], grid)
+        else:
+            m = self.patch_embed.tokens(vol_m, mod_m)
+            f = self.patch_embed.tokens(vol_f, mod_f)
+        return self._coarse_from_tokens(m, f)
+
+    def _coarse_from_tokens(self, m, f):
         skips = []
         for layer in self.layers:
             m_out, f_out, m, f = layer(m, f)
@@ -627,7 +643,8 @@ class Head(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("micformer_amd.Head runs on the MI355X HIP kernels only (no CPU path): move the model "
                                "and the input to cuda")
-        x = x.float().contiguous()
+        if not hasattr(x, "patch_rows"):        # (a data.RawBatch keeps its raw float16 / float32 volume: prepared in the patch gather)
+            x = x.float().contiguous()
         rp, oc = self.swin.reverse_patch_embedding, self.out_conv
         if FUSE_HEAD_TAIL and 2 <= rp.kernel_size[0] <= 8 and oc.out_channels <= 32:
             # ConvTranspose3d(k = s = P) and the 3^3 Conv3d have nothing between them: one composed linear map (head_tail.hip)
@@ -648,3 +665,21 @@ class Head(nn.Module):
             return Fn.HeadTailFn.apply(coarse, rp.weight, rp.bias, oc.weight, oc.bias, wb, bf, wut)
         feat = self.swin.features(x, 0, x, 1)
         return Fn.OutConvFn.apply(feat, oc.weight, oc.bias)
+
+    def forward_accumulate(self, x, out, count, coords):
+        """Sliding-window inference (utils.py:226-234) with the accumulate / count epilogue fused into the logits store: x holds n
+        windows (n, 2, rd, rh, rw); window i's logits are ADDED into the fp32 volume accumulator `out` (VB, classes, D, H, W) at
+        coords[i] = (sample, z0, y0, x0) (int32 device tensor [n, 4]) and `count` (VB, D, H, W) += 1 there.  No gradient; the
+        prediction tensor is never materialised.  Returns None."""
+        from .. import ops
+        rp, oc = self.swin.reverse_patch_embedding, self.out_conv
+        if not (FUSE_HEAD_TAIL and 2 <= rp.kernel_size[0] <= 8 and oc.out_channels <= 32) or torch.is_grad_enabled():
+            raise RuntimeError("forward_accumulate needs the composed head and torch.no_grad()")
+        x = x.float().contiguous()
+        P = rp.kernel_size[0]
+        wut = ops.head_tail_transposed_up(rp.weight)
+        wb, bf = ops.head_tail_compose(rp.weight, rp.bias, oc.weight, wut)
+        coarse = self.swin.coarse_features(x, 0, x, 1)
+        n, Dc, Hc, Wc, Ci = coarse.shape
+        t = ops.linear_fwd(coarse.reshape(-1, Ci), wb, bf)
+        ops.head_tail_col2im_sw(t, oc.bias, out, count, coords, (n, Dc, Hc, Wc), P)

@@ -562,6 +562,17 @@ def head_tail_col2im(t, b_out, dims, P):
     return y
 
 
+def head_tail_col2im_sw(t, b_out, out, count, coords, dims, P):
+    """Sliding-window form of head_tail_col2im: t holds len(coords) windows; their logits are ADDED into the volume accumulator `out`
+    [VB, Co, VD, VH, VW] at coords [n, 4] int32 (device: {sample, z0, y0, x0}) and `count` [VB, VD, VH, VW] += 1 there.  ONE launch."""
+    n, Dc, Hc, Wc = dims
+    VB, Co, VD, VH, VW = out.shape
+    if coords.dtype != torch.int32 or coords.shape != (n, 4):
+        raise TypeError("coords must be an int32 [n, 4] device tensor")
+    call("micf_head_tail_col2im_sw", f32(t), f32(b_out), f32(out), f32(count), ptr(coords), n, Dc, Hc, Wc, Co, P, VB, VD, VH, VW,
+         cost=_cost(t.numel(), t))
+
+
 def head_tail_im2col(dy, dims, P):
     B, Dc, Hc, Wc = dims
     Co = dy.shape[1]
@@ -1015,6 +1026,38 @@ def sw_accumulate_batch(pred, out, count, chunk):
     arr = _coords(chunk)
     call("micf_sw_accumulate_batch", f32(pred), f32(out), f32(count), ctypes.cast(arr, ctypes.c_void_p), len(chunk), B, K, D, H, W,
          rd, rh, rw)
+
+
+def intensity_stats(vol):
+    """{sum, sum of squares, count} of the non-zero voxels per (sample, channel): [B * Cm * 3] float64."""
+    B, Cm = vol.shape[:2]
+    if vol.dtype not in (torch.float16, torch.float32):
+        raise TypeError("raw volume must be float16 or float32")
+    sums = torch.empty(B * Cm * 3, dtype=torch.float64, device=vol.device)
+    call("micf_intensity_stats", ptr(vol), 1 if vol.dtype == torch.float16 else 0, ptr(sums), B, Cm, vol[0, 0].numel())
+    return sums
+
+
+def patch_rows_prepared(vol, sums, params, k):
+    """Raw volume [B, Cm <= 2, D, H, W] (fp16 / fp32) -> the [tokens, k^3] patch-row matrices of its modalities with the input
+    tail (flips, non-zero normalisation, scale / shift) applied on the fly.  ONE launch."""
+    B, Cm, D, H, W = vol.shape
+    rows = B * (-(-D // k)) * (-(-H // k)) * (-(-W // k))
+    outs = [torch.empty((rows, k ** 3), dtype=torch.float32, device=vol.device) for _ in range(Cm)]
+    call("micf_patch_rows_prepared", ptr(vol), 1 if vol.dtype == torch.float16 else 0, ptr(sums), f32(params), f32(outs[0]),
+         f32(outs[1]) if Cm > 1 else None, B, Cm, D, H, W, k, cost=_cost(0, vol, *outs))
+    return outs
+
+
+def flip_labels(label_map, params):
+    """label_out = label_in[flips of params] (uint8 [B, D, H, W]); params None: the map itself."""
+    if params is None:
+        return label_map
+    B, D, H, W = label_map.shape
+    out = torch.empty_like(label_map)
+    dummy = torch.zeros(3 * B, dtype=torch.float64, device=label_map.device)
+    call("micf_input_prepare", ptr(label_map), 0, ptr(dummy), f32(params), None, ptr(label_map), ptr(out), B, 1, D, H, W)
+    return out
 
 
 def input_prepare(vol, label_map=None, params=None):

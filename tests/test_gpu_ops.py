@@ -605,6 +605,57 @@ def test_input_pipeline_tail_kernel(ops, half):
     assert float((xv.cpu() - wv).abs().max()) < (2e-3 if half else 2e-5)
 
 
+@pytest.mark.parametrize("half", [True, False])
+def test_input_tail_fused_into_patch_embedding(ops, half):
+    """SURVEY 8(f) row 3 as written: micf_patch_rows_prepared (flips as index arithmetic, normalise / scale / shift as one affine map
+    inside the patch gather) -- the patch-row matrices equal space-to-depth of the prepared volume bit for bit; Head(RawBatch) equals
+    Head(prepared volume) incl. a non-multiple-of-4 volume (right padding), labels are flipped alike, and the patch-embedding weight
+    gradient agrees; one TrainEngine graph step on a RawBatch equals the step on the prepared tensor."""
+    import micformer_amd.models.MICFormer_self as M
+    from micformer_amd import data
+    from micformer_amd.engine import TrainEngine
+    g = torch.Generator().manual_seed(21)
+    B, D, H, W = 2, 30, 32, 34
+    img = torch.randn(B, 2, D, H, W, generator=g) * 40 + 100
+    img[:, :, :3] = 0
+    img = (img.half() if half else img).cuda()
+    lab = torch.randint(0, 8, (B, D, H, W), generator=g, dtype=torch.uint8).cuda()
+    params = torch.tensor([[1, 0, 1, 0.07, -0.03], [0, 1, 1, -0.05, 0.09]], dtype=torch.float32).cuda()
+    x, l = data.prepare_batch(img, lab, params)
+    raw, l2 = data.prepare_raw_batch(img, lab, params)
+    assert torch.equal(l, l2)
+    rows, grid = raw.patch_rows(4)
+    for m in (0, 1):
+        want = ops.space_to_depth(x, (B, D, H, W), 1, 4, batch_stride=2 * D * H * W, offset=m * D * H * W)
+        assert torch.equal(rows[m], want)
+    head = M.Head(embed_dim=24, num_classes=8, depths=(1, 1, 1, 1))
+    with torch.no_grad():
+        for name, t in head.state_dict().items():
+            t.copy_(fill.fill_tensor(name, t))
+    head = head.cuda().eval()
+    ya, yb = head(x), head(raw)
+    assert torch.equal(ya, yb)
+    ga = torch.autograd.grad(ya.square().mean(), head.swin.patch_embed.proj.weight)[0]
+    gb = torch.autograd.grad(yb.square().mean(), head.swin.patch_embed.proj.weight)[0]
+    assert float((ga - gb).abs().max()) <= 1e-6 * float(ga.abs().max())
+    # validation transform (no augmentation draws) and the engine's captured step
+    xv, _ = data.prepare_batch(img, None, None)
+    assert torch.equal(head(xv), head(data.RawBatch(img)))
+    x64 = img[:, :, :28, :32, :32].contiguous()
+    xp, lp = data.prepare_batch(x64, lab[:, :28, :32, :32].contiguous(), params)
+    rp, _ = data.prepare_raw_batch(x64, None, params)
+    losses = []
+    for inp in (xp, rp):
+        torch.manual_seed(3)
+        h2 = M.Head(embed_dim=24, num_classes=8, depths=(1, 1, 1, 1))
+        with torch.no_grad():
+            for name, t in h2.state_dict().items():
+                t.copy_(fill.fill_tensor(name, t))
+        e = TrainEngine(h2.cuda().eval(), base_lr=1e-4, t_max=10, use_graph=True)
+        losses.append([float(e.step(inp, lp)) for _ in range(2)])
+    assert losses[0] == losses[1], losses
+
+
 @pytest.mark.parametrize("dims,C", [((1, 4, 8, 8), 96), ((2, 8, 8, 16), 48), ((1, 4, 4, 4), 384)])
 def test_offset_head_pair_matches_per_op_calls(dims, C):
     """micf_offset_head_fwd / _bwd (both heads of a cross pair per launch) against the per-modality entry points they replace."""

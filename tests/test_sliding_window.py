@@ -81,3 +81,68 @@ def test_tiny_head_as_predictor_matches_oracle():
     assert float((got.cpu() - want).abs().max()) <= 1e-4
     assert torch.equal(got.argmax(1).cpu(), want.argmax(1)) or \
         float((got.argmax(1).cpu() != want.argmax(1)).float().mean()) < 1e-3
+
+
+def _head(E, depths):
+    from oracle import fill
+    import micformer_amd.models.MICFormer_self as M
+    head = M.Head(embed_dim=E, num_classes=8, depths=depths)
+    with torch.no_grad():
+        for name, t in head.state_dict().items():
+            t.copy_(fill.fill_tensor(name, t))
+    return head.cuda().eval()
+
+
+@pytest.mark.gpu
+def test_fused_accumulate_epilogue_matches_the_separate_launches():
+    """SURVEY 8(f) row 1 as written: the accumulate / count epilogue inside the head's logits store (Head.forward_accumulate ->
+    micf_head_tail_col2im_sw, window origins as a device argument) against the unfused path (prediction tensor + batched accumulate
+    launch), eager and graph-replayed, fp32."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import fill
+    from micformer_amd import inference as I
+    head = _head(48, (1, 1, 1, 1))
+    x = fill.make_volume(2, 96, 64, 80, "SW.fused").cuda()
+    with torch.no_grad():
+        fused = I.sliding_window_inference(x, (64, 64, 64), 3, head, overlap=0.5)
+        fused_g = I.sliding_window_inference(x, (64, 64, 64), 2, head, overlap=0.5, graph=True)
+        I.FUSE_ACCUMULATE = False
+        try:
+            plain = I.sliding_window_inference(x, (64, 64, 64), 3, head, overlap=0.5)
+        finally:
+            I.FUSE_ACCUMULATE = True
+    scale = float(plain.abs().max())
+    # (the same fp32 terms summed in another order -- atomics, and the head's patch sum folded into the accumulation)
+    assert float((fused - plain).abs().max()) <= 1e-5 * max(1.0, scale)
+    assert float((fused_g - plain).abs().max()) <= 1e-5 * max(1.0, scale)
+
+
+@pytest.mark.gpu
+def test_config5_whole_heart_volume_full_size():
+    """BASELINE config 5 at full size: base Head on a 512 x 512 x 256 two-modality volume, roi 128^3, overlap 0.5 -> 147 windows,
+    HIP-graph replayed predictor with the fused accumulate epilogue.  Size-independent properties: any sw_batch_size gives the
+    same volume (the network is batch-independent; fp32: to accumulation-order rounding), every voxel is finite, the region only
+    ONE window covers (the first 64 voxels of every axis) equals the direct prediction of that window, and the bf16 predictor (the
+    reference wraps its predictor in autocast, utils.py:236-238) stays within the bf16 logits gate of the fp32 one."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from micformer_amd import inference as I
+    head = _head(48, (2, 2, 6, 2))
+    g = torch.Generator(device="cuda").manual_seed(99)
+    x = torch.randn((1, 2, 512, 512, 256), generator=g, device="cuda")
+    starts = [I.sliding_window_starts(n, 128) for n in (512, 512, 256)]
+    assert len(starts[0]) * len(starts[1]) * len(starts[2]) == 147
+    gp = I.GraphedPredictor(head)
+    with torch.no_grad():
+        y7 = I.sliding_window_inference(x, 128, 7, gp, overlap=0.5)
+        y1 = I.sliding_window_inference(x, 128, 1, gp, overlap=0.5)
+        assert y7.shape == (1, 8, 512, 512, 256) and bool(torch.isfinite(y7).all())
+        scale = max(1.0, float(y7.abs().max()))
+        assert float((y7 - y1).abs().max()) <= 1e-5 * scale
+        direct = head(x[:, :, :128, :128, :128].contiguous())
+        assert float((y7[:, :, :64, :64, :64] - direct[:, :, :64, :64, :64]).abs().max()) <= 1e-5 * scale
+        del y1, direct
+        y16 = I.sliding_window_inference(x, 128, 7, gp, overlap=0.5, autocast=True)
+        err = float((y16 - y7).abs().max())
+        assert 0 < err <= 2e-2, err

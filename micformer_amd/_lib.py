@@ -63,7 +63,9 @@ SIGNATURES = {
     "micf_offset_head_needs_zero": "iiiii",
     "micf_offset_head_fwd": "piiiiiifiiip",
     "micf_offset_head_bwd_workspace": "iiiii",
-    "micf_offset_head_bwd": "piiiiiifiplip",
+    "micf_offset_head_bwd": "piiiiiifipliip",
+    "micf_offset_head_finish_deferrable": "iiii",
+    "micf_offset_head_bwd_finish": "piiiiiiplp",
     "micf_conv3_bwd_data_workspace": "iii",
     "micf_conv3_bwd_weight": "pipipippiiiiiplip",
     "micf_conv3_bwd_weight_workspace": "iiiiiii",
@@ -199,6 +201,7 @@ def _load():
     lib.micf_offset_head_bwd_workspace.restype = _L
     lib.micf_block_tile_tokens.argtypes = [_I] * 8          # (no stream argument: a pure shape query)
     lib.micf_block_saves_bf16.argtypes = [_I] * 3
+    lib.micf_offset_head_finish_deferrable.argtypes = [_I] * 4
     lib.micf_block_fuses_sampler.argtypes = [_I] * 2
     lib.micf_strerror.argtypes = [_I]
     lib.micf_strerror.restype = ctypes.c_char_p

@@ -48,9 +48,30 @@ extern "C" int64_t micf_offset_head_bwd_workspace(int ngroups, int B, int D, int
   return ngroups > 0 ? ngroups * micf_offset_sample_bwd_workspace(B, D, H, W) : 0;
 }
 
+static int head_bwd_sets(const micf_offset_head_bwd_group* groups, int ngroups, SampleBwdSet* ss) {
+  for (int i = 0; i < ngroups; ++i) {
+    const micf_offset_head_bwd_group& g = groups[i];
+    if (!g.dxs || !g.hid || !g.flow || !g.xa || !g.ln_g || !g.ln_b || !g.w1 || !g.conv_w || !g.dxa || !g.dxn || !g.dhid || !g.dln_g ||
+        !g.dln_b || !g.dw1)
+      return MICF_EINVAL;
+    ss[i] = SampleBwdSet{g.dxs, g.hid, g.ln_g, g.ln_b, g.w1, g.xa, g.flow, g.dxa, g.dhid, g.dln_g, g.dln_b, g.dw1,
+                         CellLists{nullptr, nullptr, nullptr, nullptr, 0, nullptr}, nullptr};
+  }
+  return MICF_OK;
+}
+
+extern "C" int micf_offset_head_bwd_finish(const micf_offset_head_bwd_group* groups, int ngroups, int B, int D, int H, int W, int C,
+                                           float* workspace, int64_t workspace_floats, micf_stream_t stream) {
+  if (!groups || ngroups < 1 || ngroups > 2 || !micf_offset_head_finish_deferrable(B, D, H, W)) return MICF_EINVAL;
+  SampleBwdSet ss[2];
+  const int rc = head_bwd_sets(groups, ngroups, ss);
+  if (rc != MICF_OK) return rc;
+  return offset_sample_bwd_groups(ss, ngroups, B, D, H, W, C, 0.f, workspace, workspace_floats, (hipStream_t)stream, 2);
+}
+
 extern "C" int micf_offset_head_bwd(const micf_offset_head_bwd_group* groups, int ngroups, int B, int D, int H, int W, int C,
                                     float eps, int prepared, float* workspace, int64_t workspace_floats, int dtype,
-                                    micf_stream_t stream) {
+                                    int defer_finish, micf_stream_t stream) {
   if (!groups || ngroups < 1 || ngroups > 2 || B <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0) return MICF_EINVAL;
   if (dtype != MICF_DTYPE_F32 && dtype != MICF_DTYPE_BF16) return MICF_EINVAL;
   hipStream_t s = (hipStream_t)stream;
@@ -65,7 +86,7 @@ extern "C" int micf_offset_head_bwd(const micf_offset_head_bwd_group* groups, in
                          CellLists{nullptr, nullptr, nullptr, nullptr, 0, nullptr}, nullptr};
     cs[i] = Conv3BwdSet{g.dhid, g.conv_w, g.conv_ws, g.dxn, g.dxa};
   }
-  int rc = offset_sample_bwd_groups(ss, ngroups, B, D, H, W, C, eps, workspace, workspace_floats, s);
+  int rc = offset_sample_bwd_groups(ss, ngroups, B, D, H, W, C, eps, workspace, workspace_floats, s, defer_finish ? 1 : 0);
   if (rc != MICF_OK) return rc;
   rc = MICF_EUNSUPPORTED;
   if (groups[0].conv_ws && (ngroups == 1 || groups[1].conv_ws))

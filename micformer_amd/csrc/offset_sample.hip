@@ -563,8 +563,10 @@ extern "C" int64_t micf_offset_sample_bwd_workspace(int B, int D, int H, int W) 
 // workspace: n * micf_offset_sample_bwd_workspace floats (or NULL: atomic scatter, atomic parameter gradients).  The
 // parameter-gradient partial sums are finished by the last launch; with `defer_finish` (allowed when no cell lists are in
 // use, i.e. small grids) that launch is left to the caller: offset_sample_bwd_finish_groups with the same arguments.
+// phase: 0 = everything; 1 = leave the finishing launch (head-parameter partial sums) to a later call when no cell lists are in
+// use (small grids: nothing on the data path waits for it); 2 = that finishing launch only (same workspace, same arguments).
 int micf::offset_sample_bwd_groups(SampleBwdSet* sets, int n, int B, int D, int H, int W, int C, float eps, float* workspace,
-                             int64_t workspace_floats, hipStream_t s) {
+                             int64_t workspace_floats, hipStream_t s, int phase) {
   if (!sets || n < 1 || n > 2 || B <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0) return MICF_EINVAL;
   const Geo g{B, D, H, W};
   const int64_t T = g.tokens();
@@ -609,6 +611,11 @@ int micf::offset_sample_bwd_groups(SampleBwdSet* sets, int n, int B, int D, int 
       p.s[i].cl = CellLists{cnt, cnt + nc, ls, ls + nc * kCellCap, cap, w8};
     }
   }
+  if (phase == 2) {
+    if (!have_ws || cells) return MICF_EINVAL;
+    hipLaunchKernelGGL(sample_finish_kernel, dim3(5 * kHid, n), dim3(256), 0, s, p, g, C, nwaves);
+    MICF_RETURN_LAUNCH();
+  }
   if (cells && hipMemsetAsync(counters, 0, sizeof(int) * (size_t)(n * (nc + 4)), s) != hipSuccess) return MICF_ELAUNCH;
   const bool scatter = !cells;
   const dim3 grid(blocks, n), blk(64 * wpb);
@@ -626,8 +633,16 @@ int micf::offset_sample_bwd_groups(SampleBwdSet* sets, int n, int B, int D, int 
     hipLaunchKernelGGL(sample_gather_kernel, dim3((unsigned)((threads + 255) / 256), n), dim3(256), 0, s, p, g, C);
     if (hipGetLastError() != hipSuccess) return MICF_ELAUNCH;
   }
+  if (phase == 1 && !cells) return MICF_OK;          // the caller finishes later (micf_offset_head_bwd_finish)
   hipLaunchKernelGGL(sample_finish_kernel, dim3(5 * kHid, n), dim3(256), 0, s, p, g, C, nwaves);
   MICF_RETURN_LAUNCH();
+}
+
+// 1 when a sampler backward at this grid leaves only head-parameter partial sums to its finishing launch (no cell lists, no
+// overflow pass): that launch may then run anywhere later on a stream ordered after the call, given the same workspace
+extern "C" int micf_offset_head_finish_deferrable(int B, int D, int H, int W) {
+  if (B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+  return use_cells((int64_t)B * D * H * W) ? 0 : 1;
 }
 
 extern "C" int micf_offset_sample_bwd(const float* dxs, const float* h, const float* ln_g, const float* ln_b,

@@ -951,8 +951,16 @@ class CrossPairFn(torch.autograd.Function):
             _ln_partials(sides[i], bos[i]["ln2_part"], bos[i]["tiles"], C, Gs[i]["norm2.weight"], Gs[i]["norm2.bias"])
         if GROUP_CROSS_HEADS:
             # block i's raw-xa gradient goes to the OTHER input's buffer; its own LN1 backward lands in acc[i] (in place)
-            dhids = ops.offset_head_bwd([{"dxs": bos[i]["dxs"], "hid": hds[i][3], "flow": hds[i][4], "xa": xs[1 - i], "P": Ps[i],
-                                          "G": Gs[i], "dxa": acc[1 - i], "dxn": bos[i]["dx"]} for i in (0, 1)], dims, eps)
+            hgroups = [{"dxs": bos[i]["dxs"], "hid": hds[i][3], "flow": hds[i][4], "xa": xs[1 - i], "P": Ps[i],
+                        "G": Gs[i], "dxa": acc[1 - i], "dxn": bos[i]["dx"]} for i in (0, 1)]
+            # small grids: the sampler's finishing launch only sums head-parameter partials -- off the data-gradient chain with
+            # the other parameter gradients (its partial table then lives in a workspace of its own until the flush)
+            defer_ws = None
+            if all(sides) and DEFER_CALLS and DEFER_WGRAD and ops.offset_head_finish_deferrable(dims):
+                defer_ws = torch.empty(ops.offset_head_bwd_workspace(2, dims), dtype=torch.float32, device=xs[0].device)
+            dhids = ops.offset_head_bwd(hgroups, dims, eps, defer_ws=defer_ws)
+            if defer_ws is not None:
+                _defer(True, lambda: ops.offset_head_bwd_finish(hgroups, dhids, dims, defer_ws), defer_ws, *dhids)
             for i in (0, 1):
                 _conv_offset_wgrad(sides[i], dhids[i], hds[i][0], xs[1 - i], Gs[i], dims)
         else:

@@ -385,6 +385,10 @@ def offset_sample_bwd(dxs, h, ln_g, ln_b, w1, xa, flow, dxa, dln_g, dln_b, dw1, 
     return dh
 
 
+def offset_head_bwd_workspace(n, dims):
+    return int(_lib.lib.micf_offset_head_bwd_workspace(n, *dims))
+
+
 def offset_head_needs_zero(dims, C):
     B, D, H, W = dims
     return bool(_lib.lib.micf_offset_head_needs_zero(B, D, H, W, C))
@@ -429,9 +433,35 @@ def offset_head_fwd(groups, dims, eps, hid=None, sample=True):
     return outs
 
 
-def offset_head_bwd(groups, dims, eps):
+def offset_head_finish_deferrable(dims):
+    return bool(_lib.lib.micf_offset_head_finish_deferrable(*dims))
+
+
+def _head_bwd_array(groups, dhids):
+    arr = (_lib.OffsetHeadBwdGroup * 2)()
+    for it, gd, dhid in zip(arr, groups, dhids):
+        P, G = gd["P"], gd["G"]
+        it.dxs, it.hid, it.flow, it.xa = f32(gd["dxs"]), f32(gd["hid"]), f32(gd["flow"]), f32(gd["xa"])
+        it.ln_g, it.ln_b, it.w1 = f32(P["conv_offset.1.norm.weight"]), f32(P["conv_offset.1.norm.bias"]), f32(P["conv_offset.3.weight"])
+        it.conv_w = f32(P["conv_offset.0.weight"])
+        it.dxa, it.dxn, it.dhid = f32(gd["dxa"]), f32(gd["dxn"]), f32(dhid)
+        it.dln_g, it.dln_b, it.dw1 = f32(G["conv_offset.1.norm.weight"]), f32(G["conv_offset.1.norm.bias"]), f32(G["conv_offset.3.weight"])
+    return arr
+
+
+def offset_head_bwd_finish(groups, dhids, dims, ws):
+    """The finishing launch a deferring offset_head_bwd left out (head-parameter partial sums -> dw1 / dln_g / dln_b)."""
+    B, D, H, W = dims
+    C = groups[0]["xa"].shape[1]
+    arr = _head_bwd_array(groups, dhids)
+    call("micf_offset_head_bwd_finish", ctypes.cast(arr, ctypes.c_void_p), len(groups), B, D, H, W, C, f32(ws), ws.numel())
+
+
+def offset_head_bwd(groups, dims, eps, defer_ws=None):
     """groups: 1 or 2 dicts {dxs, hid, flow, xa, P, G, dxa (accumulated), dxn (accumulated)}.  Sampler adjoint(s) + conv data
-    gradient(s) in one call; returns the dhid [T,16] of every group (operand of the conv weight gradient)."""
+    gradient(s) in one call; returns the dhid [T,16] of every group (operand of the conv weight gradient).
+    defer_ws: a dedicated workspace tensor (offset_head_finish_deferrable grids only) -- the finishing launch is then left to a later
+    offset_head_bwd_finish(groups, dhids, dims, defer_ws)."""
     B, D, H, W = dims
     T, C = groups[0]["xa"].shape
     n = len(groups)
@@ -457,9 +487,9 @@ def offset_head_bwd(groups, dims, eps):
             keep.append(ws)
             it.conv_ws = f32(ws)
     need = _lib.lib.micf_offset_head_bwd_workspace(n, B, D, H, W)
-    ws = scratch(groups[0]["xa"].device, need) if need > 0 else None
+    ws = defer_ws if defer_ws is not None else (scratch(groups[0]["xa"].device, need) if need > 0 else None)
     call("micf_offset_head_bwd", ctypes.cast(arr, ctypes.c_void_p), n, B, D, H, W, C, float(eps), 1 if prepared else 0, f32(ws),
-         ws.numel() if ws is not None else 0, _dt(),
+         ws.numel() if ws is not None else 0, _dt(), 1 if defer_ws is not None else 0,
          cost=_cost(n * (2 * T * 27 * 2 * C * 16 + T * (40 * C + 800)), *[g["dxs"] for g in groups], *[g["xa"] for g in groups],
                     *[g["dxa"] for g in groups], *[g["dxa"] for g in groups], *[g["dxn"] for g in groups]))
     del keep

@@ -34,13 +34,13 @@ def parse_header():
 
 def test_header_declares_expected_entry_points():
     d = parse_header()
-    assert len(d) == 76, sorted(d)
+    assert len(d) == 78, sorted(d)
     assert all(sig.endswith("p") for n, sig in d.items()
                if n not in ("micf_abi_version", "micf_strerror", "micf_linear_bwd_weight_workspace",
                             "micf_linear_bwd_weight_grouped_workspace", "micf_conv3_bwd_data_workspace",
                             "micf_offset_sample_bwd_workspace", "micf_conv3_bwd_weight_workspace",
                             "micf_conv3_fwd_workspace", "micf_layernorm_bwd_partial_rows", "micf_block_tile_tokens",
-                            "micf_offset_head_needs_zero", "micf_offset_head_bwd_workspace", "micf_block_saves_bf16", "micf_block_fuses_sampler"))
+                            "micf_offset_head_needs_zero", "micf_offset_head_bwd_workspace", "micf_block_saves_bf16", "micf_block_fuses_sampler", "micf_offset_head_finish_deferrable"))
 
 
 def test_library_exports_every_declared_symbol():
@@ -95,7 +95,7 @@ def test_round2_entry_points_validate_arguments_without_gpu():
     assert L.micf_conv3_fwd_workspace(16, 48, 48) > 6 * 27 * 256      # fp32 + bf16 layouts
     # grouped helpers
     assert L.micf_offset_head_fwd(None, 2, 1, 4, 4, 4, 48, C.c_float(1e-5), 0, 0, 0, None) == EINVAL
-    assert L.micf_offset_head_bwd(None, 2, 1, 4, 4, 4, 48, C.c_float(1e-5), 0, None, 0, 0, None) == EINVAL
+    assert L.micf_offset_head_bwd(None, 2, 1, 4, 4, 4, 48, C.c_float(1e-5), 0, None, 0, 0, 0, None) == EINVAL
     assert L.micf_layernorm_fwd_pair(None, 2, 8, 48, C.c_float(1e-5), None, 0, None) == EINVAL
     assert L.micf_layernorm_bwd_pair(None, 2, 8, 48, None) == EINVAL
     assert L.micf_weight_prep_grouped(None, 3, None) == EINVAL and L.micf_weight_prep_grouped(None, 0, None) == 0

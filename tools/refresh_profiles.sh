@@ -1,12 +1,27 @@
 #!/bin/bash
 # Run ON THE GPU BOX (through gpurun) from the repo root: regenerates the evidence kept under profiles/ into gpurun_out/$R/.
-#   gpurun --timeout 1800 -- 'bash tools/refresh_profiles.sh r02'   then   cp gpurun_out/r02/* profiles/
+#   gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh r03'   then   cp gpurun_out/r03/r03_* gpurun_out/r03/pmc_traffic.json profiles/
 set -u
-R=${1:-r02}
+R=${1:-r03}
 OUT=gpurun_out/$R
 mkdir -p $OUT
 python bench.py > $OUT/${R}_bench.json 2> $OUT/bench.err
 python bench.py --dtype fp32 --no-cpu-baseline > $OUT/${R}_bench_fp32.json 2>> $OUT/bench.err
+# the step as a sequence of graphs on two streams (opt-in layout), its main chain alone and everything serial: how much of the
+# parameter-gradient side work is hidden (functional.StepSegmenter; MICF_SEG_SKIP_SIDE computes WRONG updates: a timing probe only)
+{
+  echo "# ms per step, base / 128^3 / batch 2 / bf16, one MI355X (python bench.py --segmented --no-roofline --no-cpu-baseline --steps 30)"
+  for v in "" "MICF_SEG_SKIP_SIDE=1" "MICF_SEG_SERIAL=1"; do
+    ms=$(env $v python bench.py --segmented --no-cpu-baseline --no-roofline --steps 30 2>>$OUT/bench.err | python -c "import json,sys; print(json.loads(sys.stdin.read())['ms_per_step'])")
+    echo "segmented ${v:-(main chain + side batches on two streams)}: $ms"
+  done
+  ms=$(python bench.py --no-cpu-baseline --no-roofline --steps 30 2>>$OUT/bench.err | python -c "import json,sys; print(json.loads(sys.stdin.read())['ms_per_step'])")
+  echo "one graph (default): $ms"
+} > $OUT/${R}_graph_layouts.txt
+python tools/run_large.py 1 bf16 2>>$OUT/bench.err | tail -1 > $OUT/${R}_large160.jsonl
+python tools/run_large.py 2 bf16 2>>$OUT/bench.err | tail -1 >> $OUT/${R}_large160.jsonl
+python tools/bench_infer.py 2>>$OUT/bench.err | tail -1 > $OUT/${R}_infer512.jsonl
+python tools/bench_infer.py --autocast 2>>$OUT/bench.err | tail -1 >> $OUT/${R}_infer512.jsonl
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 # kernel trace + stats of the bench command (graph replay); the trace itself is large: keep the derived tables only
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tmp -o b -- python bench.py --steps 10 --warmup 0 --no-cpu-baseline --no-roofline \

@@ -395,6 +395,46 @@ def _ret(target, buf):
     return None if target is not None else buf
 
 
+# ============================================================================= both modalities as ONE tensor
+# The modules between the stages (patch merging / expand, their LayerNorms, the skip linears, the final norm) are shared by the two
+# modalities and per token: run once on [2B, ...] they are half the launches and need no second stream.  The pair kernels write
+# the two modalities' outputs (and input gradients) as the halves of one buffer, so joining and splitting are views, not copies.
+def _adjacent(a, b):
+    return a.is_contiguous() and b.is_contiguous() and a.shape == b.shape and a.dtype == b.dtype and \
+        a.data_ptr() + a.numel() * a.element_size() == b.data_ptr() and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+
+
+def _joined(a, b):
+    """[2B, ...] over the memory of two adjacent halves (no copy), else their concatenation."""
+    if _adjacent(a, b):
+        return a.new_empty(0).set_(a.untyped_storage(), a.storage_offset(), (2 * a.shape[0],) + tuple(a.shape[1:]))
+    return torch.cat([a, b], 0)
+
+
+class JoinFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.B = a.shape[0]
+        return _joined(_c(a.detach()), _c(b.detach()))
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        return g[:ctx.B], g[ctx.B:]
+
+
+class SplitFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ab):
+        ab = _c(ab.detach())
+        B = ab.shape[0] // 2
+        return ab[:B], ab[B:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        return _joined(_c(ga), _c(gb))
+
+
 # ============================================================================= LayerNorm
 class LayerNormFn(torch.autograd.Function):
     """nn.LayerNorm over the last dim of [..., C] (optionally over cat[x, x2], MS.py:1033-1034)."""

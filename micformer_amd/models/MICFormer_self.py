@@ -363,6 +363,13 @@ class PatchExpand(nn.Module):
         return Fn.LayerNormFn.apply(y, None, self.norm.weight, self.norm.bias, self.norm.eps)
 
 
+JOINT_MODALITIES = _os.environ.get("MICF_JOINT", "1") != "0"   # the shared per-token modules between the stages on [2B, ...] tensors
+
+
+def _joint_ok(a, b):
+    return JOINT_MODALITIES and torch.is_tensor(a) and torch.is_tensor(b) and a.is_cuda and a.shape == b.shape and a.dtype == b.dtype
+
+
 def _both(fn, a, b):
     """(fn(a), fn(b)) for the two modalities -- the second call on the side stream when they may overlap (the resampling
     convs between the stages are 40-75 us launches each: a fork / join costs less than running them back to back)."""
@@ -439,6 +446,8 @@ class BasicLayer(nn.Module):
             x, xa = self._forward_pairs(x, xa)
             resample = getattr(self, self._resample_attr)
             if resample is not None:
+                if _joint_ok(x, xa):     # both modalities through the shared module in ONE pass (the pair kernels wrote them adjacent)
+                    return (x, xa) + tuple(Fn.SplitFn.apply(resample(Fn.JoinFn.apply(x, xa))))
                 return (x, xa) + _both(resample, x, xa)
             return x, xa, x, xa
         side = _side_stream(x.device) if (PARALLEL_MODALITIES and FORK_AUTOGRAD_STREAMS and x.is_cuda) else None
@@ -608,8 +617,11 @@ class MicFormer(nn.Module):
             m_out, f_out, m, f = layer(m, f)
             skips.append((m_out, f_out))
         ln = self.norm
-        m = Fn.LayerNormFn.apply(m, None, ln.weight, ln.bias, ln.eps)
-        f = Fn.LayerNormFn.apply(f, None, ln.weight, ln.bias, ln.eps)
+        if _joint_ok(m, f):
+            m, f = Fn.SplitFn.apply(Fn.LayerNormFn.apply(Fn.JoinFn.apply(m, f), None, ln.weight, ln.bias, ln.eps))
+        else:
+            m = Fn.LayerNormFn.apply(m, None, ln.weight, ln.bias, ln.eps)
+            f = Fn.LayerNormFn.apply(f, None, ln.weight, ln.bias, ln.eps)
         last = self.num_layers - 1
         for inx, up in enumerate(self.up_layers):
             if inx > 0:
@@ -618,7 +630,10 @@ class MicFormer(nn.Module):
                     m = Fn.ResizeTrilinearFn.apply(m, tuple(sm.shape[1:4]))
                     f = Fn.ResizeTrilinearFn.apply(f, tuple(sf.shape[1:4]))
                 lin = self.concat_back_dim[inx]
-                m, f = _both(lambda t: Fn.LinearFn.apply(t[0], t[1], lin.weight, lin.bias), (m, sm), (f, sf))
+                if _joint_ok(m, f) and _joint_ok(sm, sf):
+                    m, f = Fn.SplitFn.apply(Fn.LinearFn.apply(Fn.JoinFn.apply(m, f), Fn.JoinFn.apply(sm, sf), lin.weight, lin.bias))
+                else:
+                    m, f = _both(lambda t: Fn.LinearFn.apply(t[0], t[1], lin.weight, lin.bias), (m, sm), (f, sf))
             _, _, m, f = up(m, f)
         return Fn.LayerNormFn.apply(m, f, self.norm2.weight, self.norm2.bias, self.norm2.eps)
 

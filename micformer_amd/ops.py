@@ -635,12 +635,12 @@ def conv_up_bwd_weight(dy, x, dw, dbias, k):
          cost=_cost(2 * dy.numel() * C, dy, x, dw))
 
 
-def space_to_depth(x, dims, C, k, batch_stride=0, offset=0):
+def space_to_depth(x, dims, C, k, batch_stride=0, offset=0, out=None):
     """Fine channels-last tensor (voxel stride C; `x` may be any contiguous fp32 buffer: `offset` elements to its first voxel,
     `batch_stride` elements between samples, 0 = dense) -> [B * ceil(D/k) * ceil(H/k) * ceil(W/k), C * k^3] patch rows."""
     B, D, H, W = dims
     rows = B * (-(-D // k)) * (-(-H // k)) * (-(-W // k))
-    a = _new(x, rows, C * k ** 3)
+    a = out if out is not None else _new(x, rows, C * k ** 3)
     call("micf_space_to_depth", ctypes.c_void_p(x.data_ptr() + 4 * offset), f32(a), B, D, H, W, C, k, batch_stride,
          cost=_cost(0, a, a))
     return a
@@ -950,11 +950,12 @@ def block_fwd(groups, dims, C, heads, eps, scale):
     sd = torch.bfloat16 if st16 else torch.float32
     keep = []            # temporary shadow weights must outlive the launch: the next group's outputs must not reuse them
     nb = fl = 0
-    for it, gd in zip(arr, groups):
+    y_all = _new(groups[0]["x"], len(groups) * T, C)    # the groups' outputs are the halves of ONE buffer (functional.JoinFn: no copy)
+    for gi, (it, gd) in enumerate(zip(arr, groups)):
         x, P, a = gd["x"], gd["P"], gd["attn"]
         fused_sampler = gd.get("hid") is not None       # cross block that samples its K/V source itself: {hid, samp_src} given
         cross = gd.get("kvsrc") is not None or fused_sampler
-        o = {"y": _new(x, T, C), "q": _new(x, T, C, dtype=sd), "kv": _new(x, T, 2 * C, dtype=sd), "o": _new(x, T, C, dtype=sd),
+        o = {"y": y_all[gi * T:(gi + 1) * T], "q": _new(x, T, C, dtype=sd), "kv": _new(x, T, 2 * C, dtype=sd), "o": _new(x, T, C, dtype=sd),
              "x1": _new(x, T, C), "xn2": _new(x, T, C, dtype=sd), "h": _new(x, T, hidden, dtype=h_dtype),
              "g": _new(x, T, hidden, dtype=sd), "stats": _new(x, 4, T),
              # (bf16 storage: the q weight gradient pairs a bf16 dq with a bf16 xn, so the kernel always writes its own copy)
@@ -999,12 +1000,14 @@ def block_bwd(groups, dims, C, heads, scale):
     nb = fl = 0
     st16 = block_saves_bf16(C, heads)
     sd = torch.bfloat16 if st16 else torch.float32
-    for it, gd in zip(arr, groups):
+    dx_all = _new(groups[0]["dy"], len(groups) * T, C)          # halves of one buffer: the input gradients join without a copy
+    copy_all = _new(groups[0]["dy"], len(groups) * T, C) if all(gd.get("want_copy") for gd in groups) else None
+    for gi, (it, gd) in enumerate(zip(arr, groups)):
         dy, P, a, cross = gd["dy"], gd["P"], gd["attn"], gd["cross"]
-        o = {"dx": _new(dy, T, C), "dxs": _new(dy, T, C) if cross else None, "dx1": _new(dy, T, C, dtype=sd),
+        o = {"dx": dx_all[gi * T:(gi + 1) * T], "dxs": _new(dy, T, C) if cross else None, "dx1": _new(dy, T, C, dtype=sd),
              "dh": _new(dy, T, hidden, dtype=sd), "dq": _new(dy, T, C, dtype=sd), "dkv": _new(dy, T, 2 * C, dtype=sd),
              "ln2_part": _new(dy, tiles, 2 * C), "ln1_part": None if cross else _new(dy, tiles, 2 * C),
-             "dx1_copy": _new(dy, T, C) if gd.get("want_copy") else None,
+             "dx1_copy": (copy_all[gi * T:(gi + 1) * T] if copy_all is not None else _new(dy, T, C)) if gd.get("want_copy") else None,
              "dy16": _new(dy, T, C, dtype=sd) if st16 else None}
         for k in ("dy", "x", "x1", "stats", "s1", "s2"):
             setattr(it, k, f32(gd.get(k)))

@@ -1084,6 +1084,32 @@ class PatchRowsEmbedFn(torch.autograd.Function):
         return None, _ret(ctx.tg[0], dw), _ret(ctx.tg[1], db)
 
 
+class PatchEmbedPairFn(torch.autograd.Function):
+    """PatchEmbed3D (shared weights, MS.py:1003-1004) on BOTH modalities of vol [B, 2, D, H, W] in one GEMM:
+    -> [2B, D', H', W', E] (modality-major: the first B samples are modality 0)."""
+
+    @staticmethod
+    def forward(ctx, vol, w, b, p):
+        vol = _c(vol)
+        B, nmod, D, H, W = vol.shape
+        E = w.shape[0]
+        rows = B * (-(-D // p)) * (-(-H // p)) * (-(-W // p))
+        a = torch.empty((2 * rows, p ** 3), dtype=torch.float32, device=vol.device)
+        for m in (0, 1):
+            ops.space_to_depth(vol, (B, D, H, W), 1, p, batch_stride=nmod * D * H * W, offset=m * D * H * W, out=a[m * rows:(m + 1) * rows])
+        ctx.save_for_backward(a, w)
+        ctx.tg = _targets((w, b))
+        return ops.linear_fwd(a, w.reshape(E, p ** 3), b).reshape(2 * B, -(-D // p), -(-H // p), -(-W // p), E)
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, w = ctx.saved_tensors
+        dw = _grad_buf(ctx.tg[0], w)
+        db = ctx.tg[1] if ctx.tg[1] is not None else torch.zeros(w.shape[0], dtype=w.dtype, device=w.device)
+        _lin_wgrad(ctx.tg[0] is not None and ctx.tg[1] is not None, _c(dy).reshape(-1, w.shape[0]), a, dw.view(w.shape[0], -1), db)
+        return None, _ret(ctx.tg[0], dw), _ret(ctx.tg[1], db), None
+
+
 class ConvDownFn(torch.autograd.Function):
     """Conv3d(C->N, k=s=2) of PatchMerging on channels-last x (MS.py:548-557)."""
 

@@ -604,8 +604,15 @@ class MicFormer(nn.Module):
         if hasattr(vol_m, "patch_rows"):        # data.RawBatch: the input tail runs inside the patch gather
             P = self.patch_size[0]
             rows, grid = vol_m.patch_rows(P)
-            m = self.patch_embed.tokens_from_rows(rows[0], grid)
-            f = self.patch_embed.tokens_from_rows(rows[1], grid)
+            if JOINT_MODALITIES and Fn._adjacent(rows[0], rows[1]):
+                m, f = Fn.SplitFn.apply(self.patch_embed.tokens_from_rows(Fn._joined(rows[0], rows[1]), (2 * grid[0],) + tuple(grid[1:])))
+            else:
+                m = self.patch_embed.tokens_from_rows(rows[0], grid)
+                f = self.patch_embed.tokens_from_rows(rows[1], grid)
+        elif (JOINT_MODALITIES and vol_m is vol_f and (mod_m, mod_f) == (0, 1) and vol_m.is_cuda and vol_m.shape[1] == 2
+              and Fn.PATCH_GEMM and self.patch_embed.norm is None and self.patch_size[0] in (2, 4)):
+            pe = self.patch_embed                    # both modalities of the input in one GEMM (shared weights)
+            m, f = Fn.SplitFn.apply(Fn.PatchEmbedPairFn.apply(vol_m, pe.proj.weight, pe.proj.bias, self.patch_size[0]))
         else:
             m = self.patch_embed.tokens(vol_m, mod_m)
             f = self.patch_embed.tokens(vol_f, mod_f)

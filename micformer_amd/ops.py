@@ -1076,7 +1076,8 @@ def patch_rows_prepared(vol, sums, params, k):
     tail (flips, non-zero normalisation, scale / shift) applied on the fly.  ONE launch."""
     B, Cm, D, H, W = vol.shape
     rows = B * (-(-D // k)) * (-(-H // k)) * (-(-W // k))
-    outs = [torch.empty((rows, k ** 3), dtype=torch.float32, device=vol.device) for _ in range(Cm)]
+    both = torch.empty((Cm * rows, k ** 3), dtype=torch.float32, device=vol.device)      # (halves of one buffer: one GEMM for both)
+    outs = [both[m * rows:(m + 1) * rows] for m in range(Cm)]
     call("micf_patch_rows_prepared", ptr(vol), 1 if vol.dtype == torch.float16 else 0, ptr(sums), f32(params), f32(outs[0]),
          f32(outs[1]) if Cm > 1 else None, B, Cm, D, H, W, k, cost=_cost(0, vol, *outs))
     return outs

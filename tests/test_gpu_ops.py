@@ -634,13 +634,14 @@ def test_input_tail_fused_into_patch_embedding(ops, half):
             t.copy_(fill.fill_tensor(name, t))
     head = head.cuda().eval()
     ya, yb = head(x), head(raw)
-    assert torch.equal(ya, yb)
+    # (the patch-row matrices are bit-equal; downstream the small grids accumulate the offset conv with fp32 atomics: run-to-run rounding)
+    assert float((ya - yb).abs().max()) <= 1e-5
     ga = torch.autograd.grad(ya.square().mean(), head.swin.patch_embed.proj.weight)[0]
     gb = torch.autograd.grad(yb.square().mean(), head.swin.patch_embed.proj.weight)[0]
     assert float((ga - gb).abs().max()) <= 1e-6 * float(ga.abs().max())
     # validation transform (no augmentation draws) and the engine's captured step
     xv, _ = data.prepare_batch(img, None, None)
-    assert torch.equal(head(xv), head(data.RawBatch(img)))
+    assert float((head(xv) - head(data.RawBatch(img))).abs().max()) <= 1e-5
     x64 = img[:, :, :28, :32, :32].contiguous()
     xp, lp = data.prepare_batch(x64, lab[:, :28, :32, :32].contiguous(), params)
     rp, _ = data.prepare_raw_batch(x64, None, params)
@@ -653,7 +654,7 @@ def test_input_tail_fused_into_patch_embedding(ops, half):
                 t.copy_(fill.fill_tensor(name, t))
         e = TrainEngine(h2.cuda().eval(), base_lr=1e-4, t_max=10, use_graph=True)
         losses.append([float(e.step(inp, lp)) for _ in range(2)])
-    assert losses[0] == losses[1], losses
+    assert all(abs(a - b) <= 1e-5 for a, b in zip(*losses)), losses
 
 
 @pytest.mark.parametrize("dims,C", [((1, 4, 8, 8), 96), ((2, 8, 8, 16), 48), ((1, 4, 4, 4), 384)])

@@ -188,6 +188,20 @@ int micf_conv3_bwd_weight(const float* dy, int dy_layout, const float* x1, int c
                           float* dbias, int B, int D, int H, int W, int N, float* workspace, int64_t workspace_floats,
                           int dtype, micf_stream_t stream);
 int64_t micf_conv3_bwd_weight_workspace(int B, int D, int H, int W, int N, int c1, int c2);
+/* n layers of ONE shape (channels-last dy; e.g. the offset convs of both modalities of every cross pair of a stage) as one MFMA
+ * launch + one reduce (<= 12 layers per launch; more are chunked); dw / dbias are ACCUMULATED.  Shapes the MFMA kernel does not
+ * take (N != 16, W < 4, channel counts not multiples of 4) run layer by layer as micf_conv3_bwd_weight does.  `items` is HOST
+ * memory read during the call only.  workspace: micf_conv3_bwd_weight_grouped_workspace floats (0 = none needed). */
+typedef struct micf_conv3_wgrad_item {
+  const float* dy;   /* [T, N] */
+  const float* x1;   /* [T, c1] */
+  const float* x2;   /* [T, c2] or NULL when c2 == 0 */
+  float* dw;         /* [N, c1 + c2, 3, 3, 3] */
+  float* dbias;      /* [N] or NULL */
+} micf_conv3_wgrad_item;
+int micf_conv3_bwd_weight_grouped(const micf_conv3_wgrad_item* items, int n, int c1, int c2, int B, int D, int H, int W, int N,
+                                  float* workspace, int64_t workspace_floats, int dtype, micf_stream_t stream);
+int64_t micf_conv3_bwd_weight_grouped_workspace(int n, int B, int D, int H, int W, int N, int c1, int c2);
 
 /* ---- deformable re-sampling of the key/value modality (MS.py:313-318 tail, 326-337, 360-384; STN.py:9-32):
  *   off = W1 @ GELU(LN16(h))           h [T,16] = conv_offset.0 output, W1 [3,16] (no bias)

@@ -69,6 +69,8 @@ SIGNATURES = {
     "micf_conv3_bwd_data_workspace": "iii",
     "micf_conv3_bwd_weight": "pipipippiiiiiplip",
     "micf_conv3_bwd_weight_workspace": "iiiiiii",
+    "micf_conv3_bwd_weight_grouped": "piiiiiiiiplip",
+    "micf_conv3_bwd_weight_grouped_workspace": "iiiiiiii",
     "micf_offset_sample_fwd": "pppppppiiiiifp",
     "micf_offset_sample_bwd": "ppppppppppppiiiiifplp",
     "micf_offset_sample_bwd_workspace": "iiii",
@@ -118,6 +120,12 @@ class WgradItem(ctypes.Structure):
     _fields_ = [("a", ctypes.c_void_p), ("dy", ctypes.c_void_p), ("dp_scale", ctypes.c_void_p), ("dw", ctypes.c_void_p),
                 ("dbias", ctypes.c_void_p), ("M", ctypes.c_int64), ("rows_per_sample", ctypes.c_int64),
                 ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("operand_dtype", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class Conv3WgradItem(ctypes.Structure):
+    """struct micf_conv3_wgrad_item (include/micformer_hip.h)."""
+    _fields_ = [("dy", ctypes.c_void_p), ("x1", ctypes.c_void_p), ("x2", ctypes.c_void_p), ("dw", ctypes.c_void_p),
+                ("dbias", ctypes.c_void_p)]
 
 
 class LnFinishItem(ctypes.Structure):
@@ -197,6 +205,7 @@ def _load():
     lib.micf_conv3_bwd_data_workspace.restype = _L
     lib.micf_offset_sample_bwd_workspace.restype = _L
     lib.micf_conv3_bwd_weight_workspace.restype = _L
+    lib.micf_conv3_bwd_weight_grouped_workspace.restype = _L
     lib.micf_conv3_fwd_workspace.restype = _L
     lib.micf_offset_head_bwd_workspace.restype = _L
     lib.micf_block_tile_tokens.argtypes = [_I] * 8          # (no stream argument: a pure shape query)

@@ -78,7 +78,10 @@ int64_t conv3_fwdx_workspace(int N, int c1, int c2);
 int conv3_fwd_x(const float* x1, int c1, const float* x2, int c2, const float* w, const float* bias, float* y, float* wt, int B, int D,
                 int H, int W, int N, hipStream_t stream, int dtype = 0, int prepared = 0);
 // MFMA weight gradient for 16 channels-last dy channels (conv3_wgradx.hip)
-int64_t conv3_wgradx_workspace(int B, int D, int H, int W, int N, int c1, int c2);
+int64_t conv3_wgradx_workspace(int B, int D, int H, int W, int N, int c1, int c2, int items = 1);
+int conv3_wgradx_items(const float* const* dy, const float* const* x1, const float* const* x2, float* const* dw, float* const* dbias,
+                       int n, int c1, int c2, int B, int D, int H, int W, int N, float* ws, int64_t ws_floats, hipStream_t stream,
+                       int dtype);
 int conv3_wgradx(const float* dy, const float* x1, int c1, const float* x2, int c2, float* dw, float* dbias, int B, int D, int H,
                  int W, int N, float* ws, int64_t ws_floats, hipStream_t stream, int dtype = 0);
 

@@ -342,6 +342,15 @@ extern "C" int micf_conv3_bwd_data(const float* dy, int dy_layout, const float* 
   return RC(launch_gemm(pa, make_elem<false>(gat, (int)T), epi, Cin, T, 27 * N, 1, s));                      // voxels contiguous
 }
 
+// Several offset-conv layers of ONE shape (the two modalities' heads of every cross pair a flush hands over) in one launch + one
+// reduce; shapes the MFMA kernel does not take run item by item through micf_conv3_bwd_weight with the same workspace.
+extern "C" int64_t micf_conv3_bwd_weight_grouped_workspace(int n, int B, int D, int H, int W, int N, int c1, int c2) {
+  if (n <= 0 || B <= 0 || D <= 0 || H <= 0 || W <= 0 || c1 < 0 || c2 < 0) return 0;
+  const int64_t one = conv3_wgradx_workspace(B, D, H, W, N, c1, c2);
+  const int64_t all = conv3_wgradx_workspace(B, D, H, W, N, c1, c2, n);
+  return all > one ? all : one;
+}
+
 extern "C" int64_t micf_conv3_bwd_weight_workspace(int B, int D, int H, int W, int N, int c1, int c2) {
   if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || c1 < 0 || c2 < 0) return 0;
   return conv3_wgradx_workspace(B, D, H, W, N, c1, c2);
@@ -378,4 +387,34 @@ extern "C" int micf_conv3_bwd_weight(const float* dy, int dy_layout, const float
   e = launch_gemm(pa, make_elem<true>(Conv3DyPlanes{dy, N, DHW, FastDiv((uint32_t)DHW)}, N), epi, 27 * Cin, N, (int)T, splits, s,
                   dbias, dbias ? 2 : 0);
   return RC(e);
+}
+
+extern "C" int micf_conv3_bwd_weight_grouped(const micf_conv3_wgrad_item* items, int n, int c1, int c2, int B, int D, int H, int W,
+                                             int N, float* workspace, int64_t workspace_floats, int dtype, micf_stream_t stream) {
+  if (!items || n <= 0 || !conv3_args_ok(B, D, H, W, N, c1, c2)) return MICF_EINVAL;
+  for (int i = 0; i < n; ++i)
+    if (!items[i].dy || !items[i].x1 || !items[i].dw || (c2 > 0 && !items[i].x2)) return MICF_EINVAL;
+  constexpr int kMax = 12;
+  if (workspace && n > 1) {
+    bool all_ok = true;
+    for (int base = 0; base < n && all_ok; base += kMax) {
+      const int m = n - base < kMax ? n - base : kMax;
+      const float* dy[kMax]; const float* x1[kMax]; const float* x2[kMax]; float* dw[kMax]; float* db[kMax];
+      for (int i = 0; i < m; ++i) {
+        const micf_conv3_wgrad_item& it = items[base + i];
+        dy[i] = it.dy; x1[i] = it.x1; x2[i] = c2 > 0 ? it.x2 : nullptr; dw[i] = it.dw; db[i] = it.dbias;
+      }
+      const int rc = conv3_wgradx_items(dy, x1, x2, dw, db, m, c1, c2, B, D, H, W, N, workspace, workspace_floats,
+                                        (hipStream_t)stream, dtype);
+      if (rc == MICF_EUNSUPPORTED && base == 0) { all_ok = false; break; }    // (nothing launched yet: item by item below)
+      if (rc != MICF_OK) return rc;
+    }
+    if (all_ok) return MICF_OK;
+  }
+  for (int i = 0; i < n; ++i) {
+    const int rc = micf_conv3_bwd_weight(items[i].dy, 0, items[i].x1, c1, items[i].x2, c2, items[i].dw, items[i].dbias, B, D, H, W, N,
+                                         workspace, workspace_floats, dtype, stream);
+    if (rc != MICF_OK) return rc;
+  }
+  return MICF_OK;
 }

@@ -23,12 +23,15 @@ constexpr int wPairs = 27 * (wCS / 16); // 81 (tap, channel tile) pairs per slab
 constexpr int wTPW = (wPairs + 3) / 4;  // 21 accumulator tiles per wave
 constexpr int wSlabFloats = 4 * wTPW * 256;   // partial slab of one workgroup in the workspace (21.5 K floats)
 
+constexpr int kWgxItems = 12;           // layers of one shape per launch (blockIdx.z): the two modalities' offset convs of every
+                                        // depth slot a flush hands over (6 items at the six-slot stages)
 struct WgxArgs {
-  const float* dy;                      // channels-last [T, 16]
-  const float* x1; const float* x2; int c1, c2;
-  float* ws;                            // [slabs][groups][wSlabFloats]
-  float* bias_ws;                       // [groups][16]  (slab 0 only) or nullptr
-  int B, D, H, W, tiles_d, tiles_h, tiles_w, tiles_per_group, groups;
+  const float* dy[kWgxItems];           // channels-last [T, 16]
+  const float* x1[kWgxItems]; const float* x2[kWgxItems];
+  int c1, c2;
+  float* ws;                            // [item][slabs][groups][wSlabFloats]
+  float* bias_ws;                       // [item][groups][16]  (slab 0 only) or nullptr
+  int B, D, H, W, tiles_d, tiles_h, tiles_w, tiles_per_group, groups, slabs;
 };
 
 // TW: tile extent along w (16 or 8).  Tile = 1 (d) x 64/TW (h) x TW (w) = 64 tokens; a token group is 16/TW h-rows x TW.
@@ -38,7 +41,10 @@ __global__ void __launch_bounds__(256) conv3_wgradx_kernel(WgxArgs a) {
   constexpr int HH = TH + 2, HW = TW + 2, HALO = 3 * HH * HW;
   extern __shared__ __attribute__((aligned(16))) float Xs[];           // [HALO][wXS]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lr = lane >> 4;
-  const int slab = blockIdx.x, group = blockIdx.y;
+  const int slab = blockIdx.x, group = blockIdx.y, item = blockIdx.z;
+  const float* __restrict__ a_dy = a.dy[item];
+  const float* __restrict__ a_x1 = a.x1[item];
+  const float* __restrict__ a_x2 = a.x2[item];
   const int Cin = a.c1 + a.c2;
   const int cbase = slab * wCS;
   const int64_t DHW = (int64_t)a.D * a.H * a.W;
@@ -82,8 +88,8 @@ __global__ void __launch_bounds__(256) conv3_wgradx_kernel(WgxArgs a) {
           const int c = cbase + 4 * g;
           if ((unsigned)dd < (unsigned)a.D && (unsigned)yy < (unsigned)a.H && (unsigned)ww < (unsigned)a.W && c < Cin) {
             const int64_t tok = (int64_t)b * DHW + ((int64_t)dd * a.H + yy) * a.W + ww;
-            v[u] = c < a.c1 ? *reinterpret_cast<const float4*>(a.x1 + tok * a.c1 + c)
-                            : *reinterpret_cast<const float4*>(a.x2 + tok * a.c2 + (c - a.c1));
+            v[u] = c < a.c1 ? *reinterpret_cast<const float4*>(a_x1 + tok * a.c1 + c)
+                            : *reinterpret_cast<const float4*>(a_x2 + tok * a.c2 + (c - a.c1));
           }
         }
       }
@@ -101,7 +107,7 @@ __global__ void __launch_bounds__(256) conv3_wgradx_kernel(WgxArgs a) {
         const int j = 4 * lr + s;
         const int yy = h0 + g * CH + j / TW, ww = w0 + j % TW;
         bv[s] = 0.f;
-        if (g < 4 && yy < a.H && ww < a.W) bv[s] = a.dy[((int64_t)b * DHW + ((int64_t)d0 * a.H + yy) * a.W + ww) * 16 + li];
+        if (g < 4 && yy < a.H && ww < a.W) bv[s] = a_dy[((int64_t)b * DHW + ((int64_t)d0 * a.H + yy) * a.W + ww) * 16 + li];
       }
     };
     float bv[4], bn[4];
@@ -160,23 +166,28 @@ __global__ void __launch_bounds__(256) conv3_wgradx_kernel(WgxArgs a) {
     }
   }
   // ---- partial slab -> workspace: [(wave*TPW + p)][lane][4], 16-byte stores
-  float* out = a.ws + ((int64_t)slab * a.groups + group) * wSlabFloats;
+  float* out = a.ws + (((int64_t)item * a.slabs + slab) * a.groups + group) * wSlabFloats;
 #pragma unroll
   for (int p = 0; p < wTPW; ++p)
     *reinterpret_cast<float4*>(out + ((wave * wTPW + p) * 64 + lane) * 4) = make_float4(acc[p][0], acc[p][1], acc[p][2], acc[p][3]);
   if (a.bias_ws && slab == 0 && wave == 0) {
     bsum += __shfl_xor(bsum, 16, 64);
     bsum += __shfl_xor(bsum, 32, 64);
-    if (lane < 16) a.bias_ws[group * 16 + lane] = bsum;
+    if (lane < 16) a.bias_ws[((int64_t)item * a.groups + group) * 16 + lane] = bsum;
   }
 }
 
 // dw[n][c][tap] += sum over the groups' partial slabs;  dbias[n] += sum of the groups' column sums.
 // Block = 64 slab elements x 4 slices of the group range (independent loads, unrolled), combined through LDS.
-__global__ void __launch_bounds__(256) conv3_wgradx_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ bias_ws,
-                                                                  float* __restrict__ dw, float* __restrict__ dbias, int Cin,
-                                                                  int slabs, int groups) {
+struct WgxOut { float* dw[kWgxItems]; float* dbias[kWgxItems]; };
+__global__ void __launch_bounds__(256) conv3_wgradx_reduce_kernel(const float* __restrict__ ws_all, const float* __restrict__ bias_all,
+                                                                  WgxOut o, int Cin, int slabs, int groups) {
   __shared__ float red[256];
+  const int item = blockIdx.y;
+  const float* __restrict__ ws = ws_all + (int64_t)item * slabs * groups * wSlabFloats;
+  const float* __restrict__ bias_ws = bias_all ? bias_all + (int64_t)item * groups * 16 : nullptr;
+  float* __restrict__ dw = o.dw[item];
+  float* __restrict__ dbias = o.dbias[item];
   const int el = threadIdx.x & 63, slice = threadIdx.x >> 6;
   const int64_t id = (int64_t)blockIdx.x * 64 + el;
   const int64_t per_slab = (int64_t)wPairs * 256;
@@ -217,13 +228,14 @@ __global__ void __launch_bounds__(256) conv3_wgradx_reduce_kernel(const float* _
 
 struct WgxPlan { int slabs, groups, tiles_per_group, tw; int64_t floats; };
 
-static WgxPlan wgx_plan(int B, int D, int H, int W, int Cin) {
+static WgxPlan wgx_plan(int B, int D, int H, int W, int Cin, int items = 1) {
   WgxPlan p;
   p.tw = W >= 12 ? 16 : 8;
   const int th = 64 / p.tw;
   const int ntiles = B * D * ((H + th - 1) / th) * ((W + p.tw - 1) / p.tw);
   p.slabs = (Cin + wCS - 1) / wCS;
-  int groups = (256 + p.slabs - 1) / p.slabs;                 // ~one workgroup per CU (100+ KiB of LDS each)
+  int groups = (256 + p.slabs * items - 1) / (p.slabs * items);   // ~one workgroup per CU over all items (100+ KiB of LDS each)
+  if (groups < 4) groups = 4 < ntiles ? 4 : ntiles;
   if (groups > ntiles) groups = ntiles;
   p.tiles_per_group = (ntiles + groups - 1) / groups;
   p.groups = (ntiles + p.tiles_per_group - 1) / p.tiles_per_group;
@@ -231,25 +243,34 @@ static WgxPlan wgx_plan(int B, int D, int H, int W, int Cin) {
   return p;
 }
 
-int64_t conv3_wgradx_workspace(int B, int D, int H, int W, int N, int c1, int c2) {
-  if (N != 16 || W < 8 || (c1 & 3) || (c2 & 3)) return 0;
-  return wgx_plan(B, D, H, W, c1 + c2).floats;
+int64_t conv3_wgradx_workspace(int B, int D, int H, int W, int N, int c1, int c2, int items) {
+  if (N != 16 || W < 4 || (c1 & 3) || (c2 & 3) || items < 1 || items > kWgxItems) return 0;   // (W = 4: masked 8-wide tiles)
+  return wgx_plan(B, D, H, W, c1 + c2, items).floats * items;
 }
 
 // MICF_EUNSUPPORTED when the shape / workspace is outside what this kernel covers (caller falls back).
-int conv3_wgradx(const float* dy, const float* x1, int c1, const float* x2, int c2, float* dw, float* dbias, int B, int D, int H,
-                 int W, int N, float* ws, int64_t ws_floats, hipStream_t stream, int dtype) {
-  const int64_t need = conv3_wgradx_workspace(B, D, H, W, N, c1, c2);
-  if (need == 0 || !ws || ws_floats < need || !aligned16(ws) || !aligned16(dy) || !aligned16(x1) || (x2 && !aligned16(x2)))
-    return MICF_EUNSUPPORTED;
-  const WgxPlan p = wgx_plan(B, D, H, W, c1 + c2);
+// n items of ONE shape per launch (blockIdx.z): dy / x1 / x2 / dw / dbias per item.
+int conv3_wgradx_items(const float* const* dy, const float* const* x1, const float* const* x2, float* const* dw, float* const* dbias,
+                       int n, int c1, int c2, int B, int D, int H, int W, int N, float* ws, int64_t ws_floats, hipStream_t stream,
+                       int dtype) {
+  const int64_t need = conv3_wgradx_workspace(B, D, H, W, N, c1, c2, n);
+  if (need == 0 || !ws || ws_floats < need || !aligned16(ws)) return MICF_EUNSUPPORTED;
+  const WgxPlan p = wgx_plan(B, D, H, W, c1 + c2, n);
   WgxArgs a{};
-  a.dy = dy; a.x1 = x1; a.x2 = x2 ? x2 : x1; a.c1 = c1; a.c2 = c2;
-  a.ws = ws; a.bias_ws = dbias ? ws + (int64_t)p.slabs * p.groups * wSlabFloats : nullptr;
+  WgxOut o{};
+  bool any_bias = false;
+  for (int i = 0; i < n; ++i) {
+    if (!dy[i] || !x1[i] || !dw[i] || !aligned16(dy[i]) || !aligned16(x1[i]) || (x2 && x2[i] && !aligned16(x2[i]))) return MICF_EUNSUPPORTED;
+    a.dy[i] = dy[i]; a.x1[i] = x1[i]; a.x2[i] = (x2 && x2[i]) ? x2[i] : x1[i];
+    o.dw[i] = dw[i]; o.dbias[i] = dbias ? dbias[i] : nullptr;
+    any_bias = any_bias || o.dbias[i];
+  }
+  a.c1 = c1; a.c2 = c2;
+  a.ws = ws; a.bias_ws = any_bias ? ws + (int64_t)n * p.slabs * p.groups * wSlabFloats : nullptr;
   a.B = B; a.D = D; a.H = H; a.W = W;
   const int th = 64 / p.tw;
   a.tiles_d = D; a.tiles_h = (H + th - 1) / th; a.tiles_w = (W + p.tw - 1) / p.tw;
-  a.tiles_per_group = p.tiles_per_group; a.groups = p.groups;
+  a.tiles_per_group = p.tiles_per_group; a.groups = p.groups; a.slabs = p.slabs;
   static std::once_flag attr_once;       // > 64 KiB of dynamic LDS needs the opt-in once per process
   std::call_once(attr_once, [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgradx_kernel<16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
@@ -257,7 +278,7 @@ int conv3_wgradx(const float* dy, const float* x1, int c1, const float* x2, int 
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgradx_kernel<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgradx_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   });
-  const dim3 grid(p.slabs, p.groups);
+  const dim3 grid(p.slabs, p.groups, n);
   if (p.tw == 16) {
     constexpr int HALO = 3 * (4 + 2) * (16 + 2);
     if (dtype == MICF_DTYPE_BF16) hipLaunchKernelGGL((conv3_wgradx_kernel<16, true>), grid, dim3(256), sizeof(float) * HALO * wXS, stream, a);
@@ -268,10 +289,15 @@ int conv3_wgradx(const float* dy, const float* x1, int c1, const float* x2, int 
     else hipLaunchKernelGGL((conv3_wgradx_kernel<8, false>), grid, dim3(256), sizeof(float) * HALO * wXS, stream, a);
   }
   if (hipGetLastError() != hipSuccess) return MICF_ELAUNCH;
-  const int64_t n = (int64_t)wPairs * 256 * p.slabs + 16;
-  hipLaunchKernelGGL(conv3_wgradx_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, stream, ws, a.bias_ws, dw, dbias,
+  const int64_t ne = (int64_t)wPairs * 256 * p.slabs + 16;
+  hipLaunchKernelGGL(conv3_wgradx_reduce_kernel, dim3((unsigned)((ne + 63) / 64), n), dim3(256), 0, stream, ws, a.bias_ws, o,
                      c1 + c2, p.slabs, p.groups);
   return hipGetLastError() == hipSuccess ? MICF_OK : MICF_ELAUNCH;
+}
+
+int conv3_wgradx(const float* dy, const float* x1, int c1, const float* x2, int c2, float* dw, float* dbias, int B, int D, int H,
+                 int W, int N, float* ws, int64_t ws_floats, hipStream_t stream, int dtype) {
+  return conv3_wgradx_items(&dy, &x1, &x2, &dw, &dbias, 1, c1, c2, B, D, H, W, N, ws, ws_floats, stream, dtype);
 }
 
 }  // namespace micf

@@ -350,18 +350,41 @@ class FlushPointFn(torch.autograd.Function):
         return dx, dxa, None
 
 
+GROUP_CONV_WGRAD = __import__("os").environ.get("MICF_GROUP_CONV_WGRAD", "1") != "0"
+
+
+def _defer_conv_wgrad(ok, dhid, xn, xa, dw, db, dims):
+    """Offset-conv weight gradient: now, or queued like _defer -- the flush then launches all queued layers of one shape (both
+    modalities of every cross pair since the last flush) as ONE micf_conv3_bwd_weight_grouped call."""
+    def fn():
+        ops.conv3_bwd_weight(dhid, xn, dw, db, dims, x2=xa)
+    fn.conv = (dhid, xn, xa, dw, db, tuple(dims))
+    _defer(ok, fn, dhid, xn, xa)
+
+
 def _launch_batch(items, ln, calls):
     with block_region():
         if ln:
             ops.layernorm_bwd_finish(ln)
         if items:
             ops.linear_bwd_weight_grouped(items)
+    convs = {}
     for fn, _, blk in calls:
+        cv = getattr(fn, "conv", None) if GROUP_CONV_WGRAD else None
+        if cv is not None:
+            key = (cv[5], cv[1].shape, None if cv[2] is None else cv[2].shape, cv[3].shape, cv[4] is None)
+            grp = convs.setdefault(key, [])
+            if all(g[3].data_ptr() != cv[3].data_ptr() for g in grp):       # (a layer applied twice: its second use runs alone)
+                grp.append(cv)
+                continue
         if blk:
             with block_region():
                 fn()
         else:
             fn()
+    for grp in convs.values():
+        with block_region():
+            ops.conv3_bwd_weight_grouped([(dy, x1, x2, dw, db) for dy, x1, x2, dw, db, _ in grp], grp[0][5])
 
 
 def flush_wgrad(calls_only=False):
@@ -735,8 +758,7 @@ class CrossBlockFn(torch.autograd.Function):
         dhid = ops.offset_sample_bwd(dxs, hid, P["conv_offset.1.norm.weight"], P["conv_offset.1.norm.bias"],
                                      P["conv_offset.3.weight"], xap, flow, dxap, G["conv_offset.1.norm.weight"],
                                      G["conv_offset.1.norm.bias"], G["conv_offset.3.weight"], pdims, eps)
-        _defer(side, lambda: ops.conv3_bwd_weight(dhid, xnp, G["conv_offset.0.weight"], G["conv_offset.0.bias"], pdims, x2=xap),
-               dhid, xnp, xap)
+        _defer_conv_wgrad(side, dhid, xnp, xap, G["conv_offset.0.weight"], G["conv_offset.0.bias"], pdims)
         ops.conv3_bwd_data(dhid, P["conv_offset.0.weight"], pdims, C, C, dx1=dxnp, dx2=dxap, acc1=True, acc2=True)
         if padded:
             dxn = ops.crop3d(dxnp, dims, pd)
@@ -864,8 +886,7 @@ def _cross_head_bwd(side, P, G, dims, eps, xf, xaf, xn, m1, r1, hid, flow, dxq, 
     dhid = ops.offset_sample_bwd(dxs, hid, P["conv_offset.1.norm.weight"], P["conv_offset.1.norm.bias"], P["conv_offset.3.weight"],
                                  xaf, flow, dxa_acc, G["conv_offset.1.norm.weight"], G["conv_offset.1.norm.bias"],
                                  G["conv_offset.3.weight"], dims, eps)
-    _defer(side, lambda: ops.conv3_bwd_weight(dhid, xn, G["conv_offset.0.weight"], G["conv_offset.0.bias"], dims, x2=xaf),
-           dhid, xn, xaf)
+    _defer_conv_wgrad(side, dhid, xn, xaf, G["conv_offset.0.weight"], G["conv_offset.0.bias"], dims)
     ops.conv3_bwd_data(dhid, P["conv_offset.0.weight"], dims, C, C, dx1=dxq, dx2=dxa_acc, acc1=True, acc2=True)
     return ops.layernorm_bwd(dxq, xf, m1, r1, P["norm1.weight"], G["norm1.weight"], G["norm1.bias"], add=add, defer=_ln_defer(side),
                              out=out)
@@ -884,7 +905,7 @@ FUSE_SAMPLER = _os.environ.get("MICF_FUSE_SAMPLER", "1") != "0"
 
 
 def _conv_offset_wgrad(side, dhid, xn, xa, G, dims):
-    _defer(side, lambda: ops.conv3_bwd_weight(dhid, xn, G["conv_offset.0.weight"], G["conv_offset.0.bias"], dims, x2=xa), dhid, xn, xa)
+    _defer_conv_wgrad(side, dhid, xn, xa, G["conv_offset.0.weight"], G["conv_offset.0.bias"], dims)
 _SIDE = {}
 
 
@@ -902,8 +923,7 @@ def _cross_head_adjoint(i, hds, bos, Ps, Gs, xs, acc, dims, eps, C, sides):
     dhid = ops.offset_sample_bwd(bos[i]["dxs"], hid, Ps[i]["conv_offset.1.norm.weight"], Ps[i]["conv_offset.1.norm.bias"],
                                  Ps[i]["conv_offset.3.weight"], xs[1 - i], flow, acc[1 - i], Gs[i]["conv_offset.1.norm.weight"],
                                  Gs[i]["conv_offset.1.norm.bias"], Gs[i]["conv_offset.3.weight"], dims, eps)
-    _defer(sides[i], lambda: ops.conv3_bwd_weight(dhid, xn, Gs[i]["conv_offset.0.weight"], Gs[i]["conv_offset.0.bias"], dims,
-                                                  x2=xs[1 - i]), dhid, xn, xs[1 - i])
+    _defer_conv_wgrad(sides[i], dhid, xn, xs[1 - i], Gs[i]["conv_offset.0.weight"], Gs[i]["conv_offset.0.bias"], dims)
     ops.conv3_bwd_data(dhid, Ps[i]["conv_offset.0.weight"], dims, C, C, dx1=bos[i]["dx"], dx2=acc[1 - i], acc1=True, acc2=True)
 
 

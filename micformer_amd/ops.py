@@ -360,6 +360,30 @@ def conv3_bwd_weight(dy, x1, dw, dbias, dims, x2=None, ncdhw=False):
          cost=_cost(2 * B * D * H * W * 27 * (c1 + c2) * N, dy, x1, x2, dw))
 
 
+def conv3_bwd_weight_grouped(items, dims):
+    """items: [(dy [T,N], x1 [T,c1], x2 [T,c2] | None, dw, dbias | None)] of ONE shape (channels-last): one launch + one reduce."""
+    if len(items) == 1:
+        dy, x1, x2, dw, db = items[0]
+        return conv3_bwd_weight(dy, x1, dw, db, dims, x2=x2)
+    B, D, H, W = dims
+    dy0, x10, x20, dw0, _ = items[0]
+    c1 = x10.shape[-1]
+    c2 = x20.shape[-1] if x20 is not None else 0
+    N = dw0.shape[0]
+    n = len(items)
+    arr = (_lib.Conv3WgradItem * n)()
+    for k, (dy, x1, x2, dw, db) in enumerate(items):
+        assert dy.shape == dy0.shape and x1.shape == x10.shape and dw.shape == dw0.shape
+        arr[k].dy, arr[k].x1, arr[k].x2 = f32(dy), f32(x1), f32(x2)
+        arr[k].dw, arr[k].dbias = f32(dw), f32(db)
+    need = _lib.lib.micf_conv3_bwd_weight_grouped_workspace(n, B, D, H, W, N, c1, c2)
+    ws = scratch(dy0.device, need) if need > 0 else None
+    flat = [t for it in items for t in it if t is not None]
+    call("micf_conv3_bwd_weight_grouped", ctypes.addressof(arr), n, c1, c2, B, D, H, W, N, f32(ws),
+         ws.numel() if ws is not None else 0, _dt(),
+         cost=_cost(2 * n * B * D * H * W * 27 * (c1 + c2) * N, *flat))
+
+
 # ----------------------------------------------------------------------------- offset head + deformable sampling
 def offset_sample_fwd(h, ln_g, ln_b, w1, xa, dims, eps):
     B, D, H, W = dims

@@ -145,6 +145,21 @@ int micf_head_tail_decompose(const float* dwb, const float* dbf, const float* w_
                              float* dw_up, float* db_up, float* dw_out, float* db_out, int Ci, int Cm, int Co, int P,
                              const float* w_up_t, micf_stream_t stream);
 
+/* ---- the same map WITHOUT the patch matrices T / U (MICF_DTYPE_BF16, Co == 8, P == 4, Ci in {96, 192}, Wc % 16 == 0, Hc % 4 == 0;
+ * micf_head_tail_fused_supported says so): the overlap-add is index arithmetic inside the GEMMs (head_tail_fused.hip).
+ * pack: wb / bf (micf_head_tail_compose) and b_out -> the bf16 operand packs of the two kernels (micf_head_tail_pack_bytes(Ci, 0)
+ * and (Ci, 1) bytes, 16-byte aligned), once per optimizer step.  fwd: x [B*Dc*Hc*Wc, Ci] -> NCDHW logits y [B, 8, 4Dc, 4Hc, 4Wc]
+ * (bias terms included).  bwd_data: dy (NCDHW) -> dx [B*Dc*Hc*Wc, Ci] (overwritten).  The weight gradient keeps
+ * micf_head_tail_im2col + micf_linear_bwd_weight + micf_head_tail_decompose. */
+int micf_head_tail_fused_supported(int Dc, int Hc, int Wc, int Ci, int Co, int P, int dtype);
+int64_t micf_head_tail_pack_bytes(int Ci, int which);
+int micf_head_tail_pack(const float* wb, const float* bf, const float* b_out, void* pack_fwd, void* pack_bwd, int Ci, int Co,
+                        int P, micf_stream_t stream);
+int micf_head_tail_fwd_fused(const float* x, const void* pack_fwd, float* y, int B, int Dc, int Hc, int Wc, int Ci, int Co,
+                             int P, micf_stream_t stream);
+int micf_head_tail_bwd_data_fused(const float* dy, const void* pack_bwd, float* dx, int B, int Dc, int Hc, int Wc, int Ci,
+                                  int Co, int P, micf_stream_t stream);
+
 /* ---- (Cross)WindowAttention3D core on channels-last token grids, windows by index math (never materialised):
  * softmax((q*scale) k^T) v per head and per non-overlapping (wd,wh,ww) window (MS.py:193-200, 251-258;
  * window_partition/reverse MS.py:37-50,117-132).  q [T,ldq], k/v [T,ldkv] (k = kv, v = kv + C), o [T,ldo].

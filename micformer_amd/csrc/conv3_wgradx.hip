@@ -10,6 +10,7 @@
 // and every MFMA then costs exactly one 4-byte LDS read.  Partial slabs go to a workspace with coalesced 16-byte stores
 // and a second kernel sums them over the workgroups and scatters into the [N][Cin][27] layout (+=).
 // The LDS-tiled VALU kernel this replaces (conv3_wgrad.hip) reached 28 TFLOP/s at the 32^3 x 2 stage.
+#include <cstdlib>
 #include <mutex>
 
 #include "common.h"
@@ -31,7 +32,7 @@ struct WgxArgs {
   int c1, c2;
   float* ws;                            // [item][slabs][groups][wSlabFloats]
   float* bias_ws;                       // [item][groups][16]  (slab 0 only) or nullptr
-  int B, D, H, W, tiles_d, tiles_h, tiles_w, tiles_per_group, groups, slabs;
+  int B, D, H, W, tiles_d, tiles_h, tiles_w, tiles_per_group, groups, slabs, xcd_order;
 };
 
 // TW: tile extent along w (16 or 8).  Tile = 1 (d) x 64/TW (h) x TW (w) = 64 tokens; a token group is 16/TW h-rows x TW.
@@ -41,7 +42,17 @@ __global__ void __launch_bounds__(256) conv3_wgradx_kernel(WgxArgs a) {
   constexpr int HH = TH + 2, HW = TW + 2, HALO = 3 * HH * HW;
   extern __shared__ __attribute__((aligned(16))) float Xs[];           // [HALO][wXS]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lr = lane >> 4;
-  const int slab = blockIdx.x, group = blockIdx.y, item = blockIdx.z;
+  // XCD-aware order: workgroups are dealt to the 8 XCDs round-robin by linear id; the tile ranges (consecutive d planes, whose
+  // halos overlap) handed to one XCD are made contiguous so the planes a workgroup shares with its neighbours hit that XCD's L2
+  int slab = blockIdx.x, group = blockIdx.y;
+  const int item = blockIdx.z;
+  if (a.xcd_order) {
+    const int L = gridDim.x * gridDim.y;
+    const int lin = slab + gridDim.x * group;
+    const int logical = (lin % 8) * (L / 8) + lin / 8;
+    slab = logical % gridDim.x;
+    group = logical / gridDim.x;
+  }
   const float* __restrict__ a_dy = a.dy[item];
   const float* __restrict__ a_x1 = a.x1[item];
   const float* __restrict__ a_x2 = a.x2[item];
@@ -271,6 +282,8 @@ int conv3_wgradx_items(const float* const* dy, const float* const* x1, const flo
   const int th = 64 / p.tw;
   a.tiles_d = D; a.tiles_h = (H + th - 1) / th; a.tiles_w = (W + p.tw - 1) / p.tw;
   a.tiles_per_group = p.tiles_per_group; a.groups = p.groups; a.slabs = p.slabs;
+  static const bool xcd_env = [] { const char* e = getenv("MICF_WGX_XCD"); return !e || e[0] != '0'; }();
+  a.xcd_order = (xcd_env && (p.slabs * p.groups) % 8 == 0) ? 1 : 0;
   static std::once_flag attr_once;       // > 64 KiB of dynamic LDS needs the opt-in once per process
   std::call_once(attr_once, [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgradx_kernel<16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);

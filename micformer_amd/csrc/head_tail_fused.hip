@@ -1,0 +1,470 @@
+// head_tail_fused.hip -- the composed head tail (head_tail.hip: reverse_patch_embedding, MS.py:1037, followed by Head.out_conv,
+// MS.py:1053, as one linear map on the coarse grid) WITHOUT its patch matrices: bf16 mode, 8 classes, patch 4.
+//
+// head_tail.hip runs the map as  T = x Wb^T  (GEMM, [tokens, 6^3 * 8] = 453 MB at 128^3 / batch 2) + col2im gather, and backward as
+// im2col (U, another 453 MB) + two GEMMs: 1.8 GB of HBM traffic for 67 MB of logits, 0.75 ms of the step's critical chain.  Here
+// the overlap-add is folded into the GEMM's index arithmetic instead.  With fine voxel u = 4 q + r (r in [0,4)^3):
+//   y[u, o] = sum over d in {-1,0,1}^3 of  Wc[d][(r, o), :] . x[q + d, :]          Wc[d][(r, o)] = Wb[(r - 4 d + 1, o)] where that
+//   index lies in [0,6)^3 (d = 0: every r; d = -1 along an axis: r = 0 there; d = +1: r = 3), else no term.
+// Forward: a workgroup owns 1 x 4 x 16 coarse voxels; their 3 x 6 x 18 halo of x rows sits in LDS as bf16 (out-of-volume rows zero);
+// MFMA operand A = a prepacked 16-row slab of Wc[d] (rows = 4 rw x 4 classes, read from L2), operand B = 16 x rows shifted by d;
+// the accumulator quad of a lane is then the 4 consecutive fine voxels (rw = 0..3) of ONE class at one coarse voxel and the 16 lanes
+// of a row group hold 16 consecutive coarse voxels: every store instruction writes 256-byte runs of the NCDHW logits.  The
+// composite bias Bf (which depends on which neighbours are inside the volume) rides in the GEMM: x rows carry a 1.0 column that
+// is 0 for out-of-volume rows, Wc a matching column (Bf as a hi + lo bf16 pair: exact to 2^-17), b_out folded into d = 0.
+// Backward data: dx[q, :] = sum_{f, o} dy[o, 4 q - 1 + f] Wb[(f, o), :].  The fine region of dy a workgroup's 1 x 2 x 16 coarse
+// voxels touch (6 x 10 x 66 voxels x 8 classes) sits in LDS as bf16, class-fastest, so the MFMA operand of a coarse voxel and a
+// tap f is ONE 16-byte LDS read (4 taps x 8 classes per k-step); U is never written.
+// fp32 (parity) mode keeps head_tail.hip's path.
+#include "common.h"
+#include "gemm_dma.h"
+
+namespace micf {
+
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+
+constexpr int kFSlots = 27 * 32;        // (d + 1 per axis: 27) x rd (4) x rh (4) x class group (2)
+constexpr int kXPad = 24;               // bf16 columns after the Ci channels of an LDS x row: [1.0, 1.0, 0 x 14 | 8 unused]
+                                        // (row stride (Ci + 24) * 2 bytes = 60 dwords mod 64 for Ci = 96: 16-byte reads of 16 rows hit 16 disjoint bank quads)
+constexpr int kBK = 54;                 // backward k-steps: fd (6) x fh pair (3) x fw pair (3); lane group lr = (fh & 1) * 2 + (fw & 1)
+constexpr int kDW = 83;                 // LDS slots per fine (d, h) row of dy: w + (w >> 2), w < 66 (a pad slot after every 4 voxels:
+                                        // the 16 coarse voxels of an operand read are then 80 bytes apart = disjoint bank quads)
+
+__device__ __forceinline__ uint16_t bf16_bits(float v) { return (uint16_t)(pack_bf16(v, 0.f) & 0xFFFFu); }
+__device__ __forceinline__ float bf16_val(uint16_t b) { return __uint_as_float((unsigned)b << 16); }
+
+// ---- weight packs (once per step, off the critical path)
+// forward:  wpf[slot][ks][lane][8]   slot = ((((dd*3 + dh)*3 + dw)*4 + rd)*4 + rh)*2 + og,  lane = (li, lr): row li <-> rw = li & 3,
+//           class o = 4 og + (li >> 2); k = 32 ks + 8 lr + j;   then the bias slabs wpb[slot][lane][4] = {hi, lo, 0, 0} for lr == 0
+// backward: wq[ks][jt][lane][8]      lane (li, lr): channel 16 jt + li, tap f(ks, lr), j = class
+__global__ void __launch_bounds__(256) tail_pack_kernel(const float* __restrict__ wb, const float* __restrict__ bf,
+                                                        const float* __restrict__ b_out, uint16_t* __restrict__ wpf,
+                                                        uint16_t* __restrict__ wq, int Ci) {
+  const int KS = Ci / 32, NJ = Ci / 16;
+  const int64_t n_f = (int64_t)kFSlots * KS * 64, n_b = (int64_t)kFSlots * 64, n_q = (int64_t)kBK * NJ * 64;
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (id < n_f + n_b) {
+    const bool bias = id >= n_f;
+    const int64_t e = bias ? id - n_f : id;
+    const int lane = (int)(e & 63);
+    const int ks = bias ? 0 : (int)((e >> 6) % KS);
+    int slot = bias ? (int)(e >> 6) : (int)((e >> 6) / KS);
+    const int li = lane & 15, lr = lane >> 4;
+    const int og = slot & 1; slot >>= 1;
+    const int rh = slot & 3; slot >>= 2;
+    const int rd = slot & 3; slot >>= 2;
+    const int dw = slot % 3, dh = (slot / 3) % 3, dd = slot / 9;
+    const int rw = li & 3, o = 4 * og + (li >> 2);
+    const int fd = rd - 4 * (dd - 1) + 1, fh = rh - 4 * (dh - 1) + 1, fw = rw - 4 * (dw - 1) + 1;
+    const bool ok = fd >= 0 && fd < 6 && fh >= 0 && fh < 6 && fw >= 0 && fw < 6;
+    const int64_t row = (((int64_t)fd * 6 + fh) * 6 + fw) * 8 + o;
+    if (bias) {
+      uint16_t* dst = wpf + n_f * 8 + e * 4;
+      float v = (ok && lr == 0) ? bf[row] + ((dd == 1 && dh == 1 && dw == 1) ? b_out[o] : 0.f) : 0.f;
+      const uint16_t hi = bf16_bits(v);
+      const uint16_t lo = bf16_bits(v - bf16_val(hi));
+      dst[0] = hi; dst[1] = lo; dst[2] = 0; dst[3] = 0;
+    } else {
+      uint16_t* dst = wpf + e * 8;
+      const float* src = wb + row * Ci + 32 * ks + 8 * lr;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dst[j] = ok ? bf16_bits(src[j]) : (uint16_t)0;
+    }
+    return;
+  }
+  const int64_t e = id - n_f - n_b;
+  if (e == n_q) {                                                      // the zero block behind the forward pack
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wpf[n_f * 8 + n_b * 4 + j] = 0;
+    return;
+  }
+  if (e > n_q) return;
+  const int lane = (int)(e & 63), li = lane & 15, lr = lane >> 4;
+  const int jt = (int)((e >> 6) % NJ), ks = (int)((e >> 6) / NJ);
+  const int fd = ks / 9, fh = 2 * ((ks / 3) % 3) + (lr >> 1), fw = 2 * (ks % 3) + (lr & 1);
+  const int64_t row0 = (((int64_t)fd * 6 + fh) * 6 + fw) * 8;
+  uint16_t* dst = wq + e * 8;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) dst[j] = bf16_bits(wb[(row0 + j) * Ci + 16 * jt + li]);
+}
+
+// ---- forward
+// Per class group (2 passes) the MFMA stream of a wave is 27 weight slabs x (Ci / 32 + 1) k-steps, each slab fragment (16 bytes per lane, from L2) feeding the
+// 4 MFMAs of the wave's 4 coarse h rows.  The fragments go through a ring of 16 registers quads issued 16 units ahead (L2
+// latency ~ 12 units of MFMA time); the x fragments (LDS) one k-step group ahead.  Everything is indexed at compile time.
+constexpr int kRing = 16;
+struct FwdUnit { int sd, sh, dw, ks, rdi, rhi, group, first; };
+constexpr FwdUnit fwd_unit(int u, int KS1) {
+  int g = 0;
+  for (int sd = 0; sd < 2; ++sd)
+    for (int sh = 0; sh < 2; ++sh) {
+      const int nrh = sh ? 1 : 2, nt = (sd ? 1 : 2) * nrh;
+      for (int dw = 0; dw < 3; ++dw)
+        for (int ks = 0; ks < KS1; ++ks) {
+          if (u < nt) return FwdUnit{sd, sh, dw, ks, u / nrh, u % nrh, g, u == 0};
+          u -= nt;
+          ++g;
+        }
+    }
+  return FwdUnit{0, 0, 0, 0, 0, 0, 0, 0};
+}
+template <int CI>
+struct FwdState {
+  static constexpr int KS = CI / 32, KS1 = KS + 1, NU = 27 * KS1, NG = 12 * KS1, RS = CI + kXPad;
+  f32x4 acc[2][2][4];                   // [rd idx][rh idx][coarse h row] of the class group in flight
+  int og;
+  bf16x8 ring[kRing];
+  bf16x8 bx[2][4];
+  int rd_of[2], rh_of[2], dd_out, dh_out, lane, li, lr;
+  const uint16_t* Xs;
+  const uint16_t* wl;                   // forward pack + 8 * lane
+  const uint16_t* wbl;                  // bias slabs + 4 * lane
+  const uint16_t* zero;                 // 16 zero bytes (lanes whose slab row is structurally zero all read these)
+};
+template <int CI, int U>
+__device__ __forceinline__ void fwd_issue(FwdState<CI>& st) {          // weight fragment of unit U -> ring
+  if constexpr (U < FwdState<CI>::NU) {
+    constexpr FwdUnit un = fwd_unit(U, FwdState<CI>::KS1);
+    constexpr int KS = FwdState<CI>::KS;
+    const int dd = un.sd ? st.dd_out : 1, dh = un.sh ? st.dh_out : 1;
+    const int slot = ((((dd * 3 + dh) * 3 + un.dw) * 4 + st.rd_of[un.rdi]) * 4 + st.rh_of[un.rhi]) * 2 + st.og;
+    const bool a_on = un.dw == 1 || (st.li & 3) == (un.dw == 0 ? 0 : 3);
+    if constexpr (un.ks < KS) {
+      const uint16_t* p = st.wl + (int64_t)(slot * KS + un.ks) * 512;
+      st.ring[U % kRing] = *reinterpret_cast<const bf16x8*>(a_on ? p : st.zero);
+    } else {
+      const uint16_t* p = st.wbl + (int64_t)slot * 256;
+      const bf16x4 v = *reinterpret_cast<const bf16x4*>((a_on && st.lr == 0) ? p : st.zero);
+      st.ring[U % kRing] = bf16x8{v[0], v[1], v[2], v[3], 0, 0, 0, 0};
+    }
+  }
+}
+template <int CI, int G>
+__device__ __forceinline__ void fwd_issue_b(FwdState<CI>& st) {        // x fragments of k-step group G -> bx[G & 1]
+  if constexpr (G < FwdState<CI>::NG) {
+    constexpr int KS1 = FwdState<CI>::KS1, KS = FwdState<CI>::KS, RS = FwdState<CI>::RS;
+    constexpr int ks = G % KS1, dw = (G / KS1) % 3, sh = (G / (3 * KS1)) % 2, sd = G / (6 * KS1);
+    const int dd = sd ? st.dd_out : 1, dh = sh ? st.dh_out : 1;
+    // x rows of coarse h row m shifted by d: LDS row ((dd * 6 + m + dh) * 18 + li + dw)
+    const uint16_t* xrow = st.Xs + ((dd * 6 + dh) * 18 + st.li + dw) * RS;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      if constexpr (ks < KS) st.bx[G & 1][m] = *reinterpret_cast<const bf16x8*>(xrow + m * 18 * RS + 32 * ks + 8 * st.lr);
+      else {
+        const bf16x4 v = *reinterpret_cast<const bf16x4*>(xrow + m * 18 * RS + CI + 4 * st.lr);
+        st.bx[G & 1][m] = bf16x8{v[0], v[1], v[2], v[3], 0, 0, 0, 0};
+      }
+    }
+  }
+}
+template <int CI, int U>
+__device__ __forceinline__ void fwd_prologue(FwdState<CI>& st) {
+  if constexpr (U < kRing) {
+    fwd_issue<CI, U>(st);
+    fwd_prologue<CI, U + 1>(st);
+  }
+}
+template <int CI, int U>
+__device__ __forceinline__ void fwd_step(FwdState<CI>& st) {
+  if constexpr (U < FwdState<CI>::NU) {
+    constexpr FwdUnit un = fwd_unit(U, FwdState<CI>::KS1);
+    if constexpr (un.first) fwd_issue_b<CI, un.group + 1>(st);
+    const bf16x8 a = st.ring[U % kRing];
+    fwd_issue<CI, U + kRing>(st);
+    __builtin_amdgcn_sched_barrier(0);                                  // (the scheduler otherwise hoists every load of the pass: 500+ spills)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      f32x4& c = st.acc[un.rdi][un.rhi][m];
+      const bf16x8 bv = st.bx[un.group & 1][m];
+      if constexpr (un.ks < FwdState<CI>::KS) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bv, c, 0, 0, 0);
+      else c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bf16x4{a[0], a[1], a[2], a[3]}, bf16x4{bv[0], bv[1], bv[2], bv[3]}, c, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    fwd_step<CI, U + 1>(st);
+  }
+}
+
+template <int CI>
+__global__ void __launch_bounds__(256, (CI <= 96 ? 2 : 1)) tail_fwd_fused_kernel(const float* __restrict__ x, const uint16_t* __restrict__ wpf,
+                                                             float* __restrict__ y, int B, int Dc, int Hc, int Wc) {
+  constexpr int KS = CI / 32, RS = CI + kXPad, V4 = CI / 4, ROWS = 3 * 6 * 18;
+  extern __shared__ __attribute__((aligned(16))) uint16_t Xs[];       // [3][6][18][RS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lr = lane >> 4;
+  // XCD-aware order: workgroups go to the 8 XCDs round-robin by id; each XCD gets a CONTIGUOUS eighth of the tiles, so the halo
+  // rows neighbouring tiles share are fetched into that XCD's L2 once (round-robin order: every XCD fetched its own copy, 3-5x the bytes)
+  int r = blockIdx.x;
+  if (gridDim.x % 8 == 0) r = (r % 8) * (gridDim.x / 8) + r / 8;
+  const int qw0 = (r % (Wc / 16)) * 16; r /= (Wc / 16);
+  const int qh0 = (r % (Hc / 4)) * 4; r /= (Hc / 4);
+  const int qd = r % Dc;
+  const int b = r / Dc;
+
+  // ---- wave = quadrant of (rd, rh): index 0 = the border residue (a neighbour along that axis contributes), 1 = the inner one
+  FwdState<CI> st;
+  st.lane = lane; st.li = li; st.lr = lr;
+  const int qa = wave >> 1, qc = wave & 1;
+  st.rd_of[0] = qa ? 3 : 0; st.rd_of[1] = qa ? 2 : 1; st.rh_of[0] = qc ? 3 : 0; st.rh_of[1] = qc ? 2 : 1;
+  st.dd_out = qa ? 2 : 0; st.dh_out = qc ? 2 : 0;                       // (d + 1 of the neighbour)
+  st.Xs = Xs; st.wl = wpf + lane * 8; st.wbl = wpf + (int64_t)kFSlots * KS * 512 + lane * 4;
+  st.zero = wpf + (int64_t)kFSlots * KS * 512 + (int64_t)kFSlots * 256;   // 16 zero bytes behind the packs
+  st.og = 0;
+  fwd_prologue<CI, 0>(st);                                              // (weights only: in flight while the x halo is staged)
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- the halo of x rows -> LDS (bf16), 16 float4 loads in flight per thread
+  for (int base = 0; base < ROWS * V4; base += 256 * 16) {
+    float4 v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int idx = base + u * 256 + tid;
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < ROWS * V4) {
+        const int hv = idx / V4, g = idx % V4;
+        const int zd = qd + hv / 108 - 1, zh = qh0 + (hv / 18) % 6 - 1, zw = qw0 + hv % 18 - 1;
+        if ((unsigned)zd < (unsigned)Dc && (unsigned)zh < (unsigned)Hc && (unsigned)zw < (unsigned)Wc)
+          v[u] = *reinterpret_cast<const float4*>(x + ((((int64_t)b * Dc + zd) * Hc + zh) * Wc + zw) * CI + 4 * g);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int idx = base + u * 256 + tid;
+      if (idx < ROWS * V4)
+        *reinterpret_cast<u32x2v*>(&Xs[(idx / V4) * RS + 4 * (idx % V4)]) = u32x2v{pack_bf16(v[u].x, v[u].y), pack_bf16(v[u].z, v[u].w)};
+    }
+  }
+  for (int hv = tid; hv < ROWS; hv += 256) {                           // the bias columns
+    const int zd = qd + hv / 108 - 1, zh = qh0 + (hv / 18) % 6 - 1, zw = qw0 + hv % 18 - 1;
+    const bool in = (unsigned)zd < (unsigned)Dc && (unsigned)zh < (unsigned)Hc && (unsigned)zw < (unsigned)Wc;
+    u32x4v* p = reinterpret_cast<u32x4v*>(&Xs[hv * RS + CI]);
+    p[0] = u32x4v{in ? 0x3F803F80u : 0u, 0u, 0u, 0u};
+    p[1] = u32x4v{0u, 0u, 0u, 0u};
+    p[2] = u32x4v{0u, 0u, 0u, 0u};
+  }
+  __syncthreads();
+
+  const int Df = 4 * Dc, Hf = 4 * Hc, Wf = 4 * Wc;
+#pragma nounroll
+  for (int og = 0; og < 2; ++og) {
+    if (og) {
+      st.og = og;
+      fwd_prologue<CI, 0>(st);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) st.acc[i][j][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    fwd_issue_b<CI, 0>(st);
+    fwd_step<CI, 0>(st);
+    // ---- logits: lane (li, lr) holds, per tile, the 4 fine voxels w = 4 (qw0 + li) .. + 3 of class 4 og + lr
+#pragma unroll
+    for (int rdi = 0; rdi < 2; ++rdi)
+#pragma unroll
+      for (int rhi = 0; rhi < 2; ++rhi)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int o = 4 * og + lr, ud = 4 * qd + st.rd_of[rdi], uh = 4 * (qh0 + m) + st.rh_of[rhi];
+          float* dst = y + ((((int64_t)b * 8 + o) * Df + ud) * Hf + uh) * Wf + 4 * (qw0 + li);
+          const f32x4 v = st.acc[rdi][rhi][m];
+          *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+  }
+}
+
+// ---- backward data
+// A wave's MFMA stream: 54 k-steps (4 taps x 8 classes each), per k-step its CI/96 weight fragments (L2) and 2 dy fragments (LDS).
+// Same ring discipline as the forward: weight fragments issued kBRing k-steps ahead (the first ones before the dy region is staged).
+template <int CI>
+struct BwdState {
+  static constexpr int NJ = CI / 16, JPW = NJ / 6, R = JPW == 1 ? 12 : 6;
+  f32x4 acc[JPW][2];
+  bf16x8 ring[R][JPW];
+  bf16x8 bx[2][2];
+  const u32x4v* dlane;
+  const uint16_t* wlane;
+};
+template <int CI, int U>
+__device__ __forceinline__ void bwd_issue(BwdState<CI>& st) {
+  if constexpr (U < kBK) {
+#pragma unroll
+    for (int j = 0; j < BwdState<CI>::JPW; ++j)
+      st.ring[U % BwdState<CI>::R][j] = *reinterpret_cast<const bf16x8*>(st.wlane + ((int64_t)U * BwdState<CI>::NJ + j) * 512);
+  }
+}
+template <int CI, int U>
+__device__ __forceinline__ void bwd_issue_b(BwdState<CI>& st) {
+  if constexpr (U < kBK) {
+    constexpr int HR = 10;
+    constexpr int fd = U / 9, fh2 = (U / 3) % 3, fw2 = U % 3;
+    constexpr int off = (fd * HR + 2 * fh2) * kDW + 2 * fw2 + (fw2 == 2 ? 1 : 0);
+    st.bx[U & 1][0] = __builtin_bit_cast(bf16x8, st.dlane[off]);
+    st.bx[U & 1][1] = __builtin_bit_cast(bf16x8, st.dlane[off + 4 * kDW]);
+  }
+}
+template <int CI, int U>
+__device__ __forceinline__ void bwd_prologue(BwdState<CI>& st) {
+  if constexpr (U < BwdState<CI>::R) {
+    bwd_issue<CI, U>(st);
+    bwd_prologue<CI, U + 1>(st);
+  }
+}
+template <int CI, int U>
+__device__ __forceinline__ void bwd_step(BwdState<CI>& st) {
+  if constexpr (U < kBK) {
+    constexpr int JPW = BwdState<CI>::JPW;
+    bwd_issue_b<CI, U + 1>(st);
+    bf16x8 a[JPW];
+#pragma unroll
+    for (int j = 0; j < JPW; ++j) a[j] = st.ring[U % BwdState<CI>::R][j];
+    bwd_issue<CI, U + BwdState<CI>::R>(st);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < JPW; ++j) {
+      st.acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], st.bx[U & 1][0], st.acc[j][0], 0, 0, 0);
+      st.acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], st.bx[U & 1][1], st.acc[j][1], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    bwd_step<CI, U + 1>(st);
+  }
+}
+
+template <int CI>
+__global__ void __launch_bounds__(384) tail_bwd_data_fused_kernel(const float* __restrict__ dy, const uint16_t* __restrict__ wq,
+                                                                  float* __restrict__ dx, int B, int Dc, int Hc, int Wc) {
+  constexpr int NJ = CI / 16, JPW = NJ / 6, HR = 10;
+  extern __shared__ __attribute__((aligned(16))) u32x4v Ds[];          // [6][HR][kDW] fine voxels x 8 classes (bf16)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lr = lane >> 4;
+  // XCD-aware order: workgroups go to the 8 XCDs round-robin by id; each XCD gets a CONTIGUOUS eighth of the tiles, so the halo
+  // rows neighbouring tiles share are fetched into that XCD's L2 once (round-robin order: every XCD fetched its own copy, 3-5x the bytes)
+  int r = blockIdx.x;
+  if (gridDim.x % 8 == 0) r = (r % 8) * (gridDim.x / 8) + r / 8;
+  const int qw0 = (r % (Wc / 16)) * 16; r /= (Wc / 16);
+  const int qh0 = (r % (Hc / 2)) * 2; r /= (Hc / 2);
+  const int qd = r % Dc;
+  const int b = r / Dc;
+  const int Df = 4 * Dc, Hf = 4 * Hc, Wf = 4 * Wc;
+  const int64_t plane = (int64_t)Df * Hf * Wf;
+  const float* src = dy + (int64_t)b * 8 * plane;
+
+  BwdState<CI> st;
+  st.wlane = wq + ((int64_t)wave * JPW * 64 + lane) * 8;
+  bwd_prologue<CI, 0>(st);                                             // (weights only: in flight while the dy region is staged)
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- the fine region of dy -> LDS.  Item = (class pair, fine (d, h) row, aligned 4-voxel chunk along w): two 16-byte loads, four
+  // packed class pairs to LDS; 6 items (12 loads) in flight per thread.  Chunk c covers region voxels w = 4 c - 3 .. 4 c (region
+  // w = fine w - (4 qw0 - 1)), so chunks 0 and 17 contribute one voxel each.
+  constexpr int NI = 4 * 6 * HR * 18, NBI = 6;
+  for (int base = 0; base < NI; base += 384 * NBI) {
+    float4 v[NBI][2];
+#pragma unroll
+    for (int u = 0; u < NBI; ++u) {
+      const int p = base + u * 384 + tid;
+      const int c = p % 18, h = (p / 18) % HR, d = (p / (18 * HR)) % 6, op = p / (18 * HR * 6);
+      const int ud = 4 * qd - 1 + d, uh = 4 * qh0 - 1 + h, uw = 4 * qw0 - 4 + 4 * c;
+      const bool in = p < NI && (unsigned)ud < (unsigned)Df && (unsigned)uh < (unsigned)Hf && (unsigned)uw < (unsigned)Wf;
+      const float* s = src + (int64_t)(2 * op) * plane + ((int64_t)ud * Hf + uh) * Wf + uw;
+      v[u][0] = in ? *reinterpret_cast<const float4*>(s) : make_float4(0.f, 0.f, 0.f, 0.f);
+      v[u][1] = in ? *reinterpret_cast<const float4*>(s + plane) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < NBI; ++u) {
+      const int p = base + u * 384 + tid;
+      if (p < NI) {
+        const int c = p % 18, h = (p / 18) % HR, d = (p / (18 * HR)) % 6, op = p / (18 * HR * 6);
+        unsigned* row = reinterpret_cast<unsigned*>(Ds + (d * HR + h) * kDW) + op;      // (4 dwords per voxel slot: class pair op)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int w = 4 * c - 3 + e;
+          if (w >= 0 && w < 66) row[(w + (w >> 2)) * 4] = pack_bf16(f4e(v[u][0], e), f4e(v[u][1], e));
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+#pragma unroll
+  for (int j = 0; j < JPW; ++j) st.acc[j][0] = st.acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // coarse voxel (m, li), tap (fd, fh, fw): fine (fd, 4 m + fh, 4 li + fw) -> slot (fd * HR + 4 m + fh) * kDW + 5 li + fw + (fw >> 2)
+  st.dlane = Ds + (lr >> 1) * kDW + (lr & 1) + 5 * li;
+  bwd_issue_b<CI, 0>(st);
+  bwd_step<CI, 0>(st);
+  auto& acc = st.acc;
+#pragma unroll
+  for (int j = 0; j < JPW; ++j)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int64_t q = (((int64_t)b * Dc + qd) * Hc + qh0 + m) * Wc + qw0 + li;
+      const f32x4 v = acc[j][m];
+      *reinterpret_cast<float4*>(dx + q * CI + 16 * (wave * JPW + j) + 4 * lr) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+static bool fused_ok(int Dc, int Hc, int Wc, int Ci, int Co, int P) {
+  return Co == 8 && P == 4 && (Ci == 96 || Ci == 192) && Dc > 0 && Hc > 0 && Wc > 0 && Wc % 16 == 0 && Hc % 4 == 0;
+}
+
+template <typename K>
+static void allow_lds(K kernel, int bytes) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); }
+
+}  // namespace micf
+
+using namespace micf;
+
+extern "C" int micf_head_tail_fused_supported(int Dc, int Hc, int Wc, int Ci, int Co, int P, int dtype) {
+  return (dtype == MICF_DTYPE_BF16 && fused_ok(Dc, Hc, Wc, Ci, Co, P)) ? 1 : 0;
+}
+
+// bytes of the two weight packs (forward incl. its bias slabs; backward data)
+extern "C" int64_t micf_head_tail_pack_bytes(int Ci, int which) {
+  if (Ci <= 0 || Ci % 32) return 0;
+  if (which == 0) return ((int64_t)kFSlots * (Ci / 32) * 512 + (int64_t)kFSlots * 256 + 8) * 2;
+  return (int64_t)kBK * (Ci / 16) * 512 * 2;
+}
+
+extern "C" int micf_head_tail_pack(const float* wb, const float* bf, const float* b_out, void* pack_fwd, void* pack_bwd, int Ci,
+                                   int Co, int P, micf_stream_t stream) {
+  if (!wb || !bf || !b_out || !pack_fwd || !pack_bwd) return MICF_EINVAL;
+  if (Co != 8 || P != 4 || Ci <= 0 || Ci % 32) return MICF_EUNSUPPORTED;
+  const int64_t n = (int64_t)kFSlots * (Ci / 32) * 64 + (int64_t)kFSlots * 64 + (int64_t)kBK * (Ci / 16) * 64 + 1;
+  hipLaunchKernelGGL(tail_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wb, bf, b_out,
+                     reinterpret_cast<uint16_t*>(pack_fwd), reinterpret_cast<uint16_t*>(pack_bwd), Ci);
+  MICF_RETURN_LAUNCH();
+}
+
+extern "C" int micf_head_tail_fwd_fused(const float* x, const void* pack_fwd, float* y, int B, int Dc, int Hc, int Wc, int Ci,
+                                        int Co, int P, micf_stream_t stream) {
+  if (!x || !pack_fwd || !y || B <= 0) return MICF_EINVAL;
+  if (!fused_ok(Dc, Hc, Wc, Ci, Co, P) || !aligned16(x) || !aligned16(y) || !aligned16(pack_fwd)) return MICF_EUNSUPPORTED;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    allow_lds(&tail_fwd_fused_kernel<96>, 324 * (96 + kXPad) * 2);
+    allow_lds(&tail_fwd_fused_kernel<192>, 324 * (192 + kXPad) * 2);
+  });
+  const dim3 grid((unsigned)((int64_t)B * Dc * (Hc / 4) * (Wc / 16)));
+  const uint16_t* wp = reinterpret_cast<const uint16_t*>(pack_fwd);
+  hipStream_t s = (hipStream_t)stream;
+  if (Ci == 96) hipLaunchKernelGGL(tail_fwd_fused_kernel<96>, grid, dim3(256), 324 * (96 + kXPad) * 2, s, x, wp, y, B, Dc, Hc, Wc);
+  else hipLaunchKernelGGL(tail_fwd_fused_kernel<192>, grid, dim3(256), 324 * (192 + kXPad) * 2, s, x, wp, y, B, Dc, Hc, Wc);
+  MICF_RETURN_LAUNCH();
+}
+
+extern "C" int micf_head_tail_bwd_data_fused(const float* dy, const void* pack_bwd, float* dx, int B, int Dc, int Hc, int Wc,
+                                             int Ci, int Co, int P, micf_stream_t stream) {
+  if (!dy || !pack_bwd || !dx || B <= 0) return MICF_EINVAL;
+  if (!fused_ok(Dc, Hc, Wc, Ci, Co, P) || !aligned16(dx) || !aligned16(dy) || !aligned16(pack_bwd)) return MICF_EUNSUPPORTED;
+  constexpr int lds = 6 * 10 * kDW * 16;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    allow_lds(&tail_bwd_data_fused_kernel<96>, lds);
+    allow_lds(&tail_bwd_data_fused_kernel<192>, lds);
+  });
+  const dim3 grid((unsigned)((int64_t)B * Dc * (Hc / 2) * (Wc / 16)));
+  const uint16_t* wq = reinterpret_cast<const uint16_t*>(pack_bwd);
+  hipStream_t s = (hipStream_t)stream;
+  if (Ci == 96) hipLaunchKernelGGL(tail_bwd_data_fused_kernel<96>, grid, dim3(384), lds, s, dy, wq, dx, B, Dc, Hc, Wc);
+  else hipLaunchKernelGGL(tail_bwd_data_fused_kernel<192>, grid, dim3(384), lds, s, dy, wq, dx, B, Dc, Hc, Wc);
+  MICF_RETURN_LAUNCH();
+}

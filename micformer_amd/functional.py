@@ -1226,13 +1226,16 @@ class OutConvFn(torch.autograd.Function):
         return dx.reshape(feat.shape), _ret(ctx.tg[0], dw), _ret(ctx.tg[1], db)
 
 
+FUSE_TAIL_PATCHES = _os.environ.get("MICF_FUSE_TAIL", "1") != "0"
+
+
 class HeadTailFn(torch.autograd.Function):
     """reverse_patch_embedding (ConvTranspose3d 2E -> E/2, k = s = P; MS.py:1037) + Head.out_conv (Conv3d E/2 -> classes, 3,
     padding=1; MS.py:1053) composed into one linear map on the coarse grid (csrc/head_tail.hip): channels-last coarse
     feature x (B, Dc, Hc, Wc, 2E) -> NCDHW logits (B, classes, P*Dc, P*Hc, P*Wc).  The E/2-channel fine feature is never built."""
 
     @staticmethod
-    def forward(ctx, x, w_up, b_up, w_out, b_out, wb=None, bf=None, w_up_t=None):
+    def forward(ctx, x, w_up, b_up, w_out, b_out, wb=None, bf=None, w_up_t=None, packs=None):
         x = _c(x)
         B, Dc, Hc, Wc, Ci = x.shape
         P = w_up.shape[2]
@@ -1240,29 +1243,42 @@ class HeadTailFn(torch.autograd.Function):
             w_up_t = ops.head_tail_transposed_up(w_up)
             wb, bf = ops.head_tail_compose(w_up, b_up, w_out, w_up_t)
         xf = x.reshape(-1, Ci)
-        t = ops.linear_fwd(xf, wb, bf)
-        y = ops.head_tail_col2im(t, b_out, (B, Dc, Hc, Wc), P)
-        ctx.save_for_backward(xf, wb, w_up, b_up, w_out, w_up_t)
+        fused = FUSE_TAIL_PATCHES and ops.head_tail_fused_supported((B, Dc, Hc, Wc), Ci, b_out.shape[0], P)
+        if fused:                                       # bf16 mode: no T / U patch matrices (head_tail_fused.hip)
+            if packs is None:
+                packs = ops.head_tail_pack(wb, bf, b_out, P)
+            y = ops.head_tail_fwd_fused(xf, packs[0], (B, Dc, Hc, Wc), b_out.shape[0], P)
+        else:
+            packs = (None, None)
+            t = ops.linear_fwd(xf, wb, bf)
+            y = ops.head_tail_col2im(t, b_out, (B, Dc, Hc, Wc), P)
+        ctx.save_for_backward(xf, wb, w_up, b_up, w_out, w_up_t, packs[1])
         ctx.dims = (B, Dc, Hc, Wc)
         ctx.tg = _targets((w_up, b_up, w_out, b_out))
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        xf, wb, w_up, b_up, w_out, w_up_t = ctx.saved_tensors
+        xf, wb, w_up, b_up, w_out, w_up_t, pack_bwd = ctx.saved_tensors
         B, Dc, Hc, Wc = ctx.dims
         P = w_up.shape[2]
-        u = ops.head_tail_im2col(_c(dy), ctx.dims, P)
-        dx = ops.linear_bwd_data(u, wb)
+        dy = _c(dy)
         grads = [_grad_buf(t, p) for t, p in zip(ctx.tg, (w_up, b_up, w_out, w_out.new_empty(w_out.shape[0])))]
+        if pack_bwd is not None:
+            dx = ops.head_tail_bwd_data_fused(dy, pack_bwd, ctx.dims, xf.shape[1], P)
+            u = None
+        else:
+            u = ops.head_tail_im2col(dy, ctx.dims, P)
+            dx = ops.linear_bwd_data(u, wb)
 
         def weight_grads():       # composed-map gradient, then its decomposition into the two layers' parameters
+            uu = u if u is not None else ops.head_tail_im2col(dy, ctx.dims, P)
             dwb, dbf = ops.zero_(torch.empty_like(wb)), ops.zero_(torch.empty(wb.shape[0], dtype=wb.dtype, device=wb.device))
-            ops.linear_bwd_weight(u, xf, dwb, dbf)
+            ops.linear_bwd_weight(uu, xf, dwb, dbf)
             ops.head_tail_decompose(dwb, dbf, w_up, b_up, w_out, *grads, w_up_t=w_up_t)
 
-        _defer(all(t is not None for t in ctx.tg), weight_grads, u, xf, wb)
-        return (dx.reshape(B, Dc, Hc, Wc, -1),) + tuple(_ret(t, g) for t, g in zip(ctx.tg, grads)) + (None, None, None)
+        _defer(all(t is not None for t in ctx.tg), weight_grads, u if u is not None else dy, xf, wb)
+        return (dx.reshape(B, Dc, Hc, Wc, -1),) + tuple(_ret(t, g) for t, g in zip(ctx.tg, grads)) + (None, None, None, None)
 
 
 class ResizeTrilinearFn(torch.autograd.Function):

@@ -671,7 +671,7 @@ class Head(nn.Module):
         if FUSE_HEAD_TAIL and 2 <= rp.kernel_size[0] <= 8 and oc.out_channels <= 32:
             # ConvTranspose3d(k = s = P) and the 3^3 Conv3d have nothing between them: one composed linear map (head_tail.hip)
             # (the composition reads weights only: in engine mode it runs on the side stream under the first stage)
-            wb = bf = wut = None
+            wb = bf = wut = packs = None
             if PARALLEL_MODALITIES:
                 from .. import ops
                 main, side = torch.cuda.current_stream(), _side_stream(x.device)
@@ -679,12 +679,16 @@ class Head(nn.Module):
                 with torch.cuda.stream(side):
                     wut = ops.head_tail_transposed_up(rp.weight)
                     wb, bf = ops.head_tail_compose(rp.weight, rp.bias, oc.weight, wut)
+                    if Fn.FUSE_TAIL_PATCHES and ops.head_tail_fused_supported(
+                            (x.shape[0],) + tuple(s // rp.kernel_size[0] for s in x.shape[2:]), rp.in_channels, oc.out_channels,
+                            rp.kernel_size[0]) and all(s % rp.kernel_size[0] == 0 for s in x.shape[2:]):
+                        packs = ops.head_tail_pack(wb, bf, oc.bias, rp.kernel_size[0])
             coarse = self.swin.coarse_features(x, 0, x, 1)
             if wb is not None:
                 main.wait_stream(side)
-                for t in (wb, bf, wut):
+                for t in (wb, bf, wut) + (tuple(packs) if packs is not None else ()):
                     t.record_stream(main)
-            return Fn.HeadTailFn.apply(coarse, rp.weight, rp.bias, oc.weight, oc.bias, wb, bf, wut)
+            return Fn.HeadTailFn.apply(coarse, rp.weight, rp.bias, oc.weight, oc.bias, wb, bf, wut, packs)
         feat = self.swin.features(x, 0, x, 1)
         return Fn.OutConvFn.apply(feat, oc.weight, oc.bias)
 

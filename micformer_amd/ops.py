@@ -608,6 +608,40 @@ def head_tail_compose(w_up, b_up, w_out, w_up_t=None):
     return wb, bf
 
 
+def head_tail_fused_supported(dims, Ci, Co, P):
+    """The patch-matrix-free head tail (head_tail_fused.hip) covers this grid / mode?"""
+    _, Dc, Hc, Wc = dims
+    return bool(_lib.lib.micf_head_tail_fused_supported(Dc, Hc, Wc, Ci, Co, P, _dt()))
+
+
+def head_tail_pack(wb, bf, b_out, P):
+    """The bf16 operand packs of micf_head_tail_fwd_fused / _bwd_data_fused from the composed map (once per step)."""
+    Ci = wb.shape[1]
+    Co = b_out.shape[0]
+    pf = torch.empty(_lib.lib.micf_head_tail_pack_bytes(Ci, 0) // 2, dtype=torch.bfloat16, device=wb.device)
+    pq = torch.empty(_lib.lib.micf_head_tail_pack_bytes(Ci, 1) // 2, dtype=torch.bfloat16, device=wb.device)
+    call("micf_head_tail_pack", f32(wb), f32(bf), f32(b_out), ptr(pf), ptr(pq), Ci, Co, P, cost=_cost(0, wb, pf, pq))
+    return pf, pq
+
+
+def head_tail_fwd_fused(x, pack_fwd, dims, Co, P):
+    B, Dc, Hc, Wc = dims
+    Ci = x.shape[-1]
+    y = _new(x, B, Co, Dc * P, Hc * P, Wc * P)
+    call("micf_head_tail_fwd_fused", f32(x), ptr(pack_fwd), f32(y), B, Dc, Hc, Wc, Ci, Co, P,
+         cost=_cost(2 * x.shape[0] * (P + 2) ** 3 * Co * Ci, x, y, tag=f"{x.shape[0]}x{Ci}"))
+    return y
+
+
+def head_tail_bwd_data_fused(dy, pack_bwd, dims, Ci, P):
+    B, Dc, Hc, Wc = dims
+    Co = dy.shape[1]
+    dx = _new(dy, B * Dc * Hc * Wc, Ci)
+    call("micf_head_tail_bwd_data_fused", f32(dy), ptr(pack_bwd), f32(dx), B, Dc, Hc, Wc, Ci, Co, P,
+         cost=_cost(2 * dx.shape[0] * (P + 2) ** 3 * Co * Ci, dy, dx, tag=f"{dx.shape[0]}x{Ci}"))
+    return dx
+
+
 def head_tail_col2im(t, b_out, dims, P):
     B, Dc, Hc, Wc = dims
     Co = b_out.shape[0]

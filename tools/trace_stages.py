@@ -2,10 +2,13 @@
 """Stage timeline of one replayed training step from a rocprofv3 kernel-trace CSV.  The fused block kernels carry the channel
 count in their template arguments, so the step is cut wherever that count changes (stage 3 / the heads run no fused kernel: the
 gaps between the C=192 encoder run and the C=192 decoder run, and around the loss).  Per segment: wall time, time covered by
-the fused block kernels, by any other kernel, and idle.   usage: trace_stages.py trace.csv [marker=drop_path_draw_kernel]"""
+the fused block kernels, by any other kernel, and idle.   usage: trace_stages.py trace.csv [marker=drop_path_draw_kernel] [--detail]
+(--detail: per segment, the kernels by total time: count x mean us)"""
 import csv, re, sys
-rows = list(csv.DictReader(open(sys.argv[1])))
-marker = sys.argv[2] if len(sys.argv) > 2 else "drop_path_draw_kernel"
+detail = "--detail" in sys.argv
+argv = [a for a in sys.argv if a != "--detail"]
+rows = list(csv.DictReader(open(argv[1])))
+marker = argv[2] if len(argv) > 2 else "drop_path_draw_kernel"
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows))
 marks = [i for i, e in enumerate(ev) if marker in e[2]]
 if len(marks) < 3:
@@ -49,3 +52,13 @@ for name, lo, hi in segs:
     al = covered(lo, hi, lambda n: True)
     nk = sum(1 for s, e, n in step if lo <= s < hi)
     print(f"{name:22s} {(hi - lo) / 1e6:8.3f} {fz / 1e6:8.3f} {(al - fz) / 1e6:8.3f} {(hi - lo - al) / 1e6:8.3f} {nk:8d}")
+    if detail:
+        agg = {}
+        for s, e, n in step:
+            if lo <= s < hi:
+                k = re.sub(r"\(.*", "", n)[:70]
+                a = agg.setdefault(k, [0, 0])
+                a[0] += 1
+                a[1] += e - s
+        for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]:
+            print(f"      {t / 1e3:8.1f} us  {c:3d} x {t / c / 1e3:6.1f}  {k}")

@@ -149,8 +149,7 @@ int micf_head_tail_decompose(const float* dwb, const float* dbf, const float* w_
  * micf_head_tail_fused_supported says so): the overlap-add is index arithmetic inside the GEMMs (head_tail_fused.hip).
  * pack: wb / bf (micf_head_tail_compose) and b_out -> the bf16 operand packs of the two kernels (micf_head_tail_pack_bytes(Ci, 0)
  * and (Ci, 1) bytes, 16-byte aligned), once per optimizer step.  fwd: x [B*Dc*Hc*Wc, Ci] -> NCDHW logits y [B, 8, 4Dc, 4Hc, 4Wc]
- * (bias terms included).  bwd_data: dy (NCDHW) -> dx [B*Dc*Hc*Wc, Ci] (overwritten).  The weight gradient keeps
- * micf_head_tail_im2col + micf_linear_bwd_weight + micf_head_tail_decompose. */
+ * (bias terms included).  bwd_data: dy (NCDHW) -> dx [B*Dc*Hc*Wc, Ci] (overwritten). */
 int micf_head_tail_fused_supported(int Dc, int Hc, int Wc, int Ci, int Co, int P, int dtype);
 int64_t micf_head_tail_pack_bytes(int Ci, int which);
 int micf_head_tail_pack(const float* wb, const float* bf, const float* b_out, void* pack_fwd, void* pack_bwd, int Ci, int Co,
@@ -159,6 +158,13 @@ int micf_head_tail_fwd_fused(const float* x, const void* pack_fwd, float* y, int
                              int P, micf_stream_t stream);
 int micf_head_tail_bwd_data_fused(const float* dy, const void* pack_bwd, float* dx, int B, int Dc, int Hc, int Wc, int Ci,
                                   int Co, int P, micf_stream_t stream);
+/* dwb [216 * 8, Ci] / dbf [216 * 8] = the composed map's parameter gradient (OVERWRITTEN; feed micf_head_tail_decompose), reduced
+ * over the coarse voxels with dy gathered on the fly -- additionally Wc % 32 == 0; workspace: ..._workspace floats (0 = this grid is
+ * not covered: use micf_head_tail_im2col + micf_linear_bwd_weight). */
+int micf_head_tail_bwd_weight_fused(const float* dy, const float* x, float* dwb, float* dbf, float* workspace,
+                                    int64_t workspace_floats, int B, int Dc, int Hc, int Wc, int Ci, int Co, int P,
+                                    micf_stream_t stream);
+int64_t micf_head_tail_bwd_weight_fused_workspace(int B, int Dc, int Hc, int Wc, int Ci);
 
 /* ---- (Cross)WindowAttention3D core on channels-last token grids, windows by index math (never materialised):
  * softmax((q*scale) k^T) v per head and per non-overlapping (wd,wh,ww) window (MS.py:193-200, 251-258;

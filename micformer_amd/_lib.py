@@ -54,6 +54,8 @@ SIGNATURES = {
     "micf_head_tail_pack": "pppppiiip",
     "micf_head_tail_fwd_fused": "pppiiiiiiip",
     "micf_head_tail_bwd_data_fused": "pppiiiiiiip",
+    "micf_head_tail_bwd_weight_fused": "pppppliiiiiiip",
+    "micf_head_tail_bwd_weight_fused_workspace": "iiiii",
     "micf_sw_window": "ppiiiiiiiiiip",
     "micf_sw_accumulate": "pppiiiiiiiiiip",
     "micf_sw_normalize": "ppilp",
@@ -212,6 +214,7 @@ def _load():
     lib.micf_conv3_bwd_weight_workspace.restype = _L
     lib.micf_conv3_bwd_weight_grouped_workspace.restype = _L
     lib.micf_head_tail_pack_bytes.restype = _L
+    lib.micf_head_tail_bwd_weight_fused_workspace.restype = _L
     lib.micf_conv3_fwd_workspace.restype = _L
     lib.micf_offset_head_bwd_workspace.restype = _L
     lib.micf_block_tile_tokens.argtypes = [_I] * 8          # (no stream argument: a pure shape query)

@@ -402,6 +402,158 @@ __global__ void __launch_bounds__(384) tail_bwd_data_fused_kernel(const float* _
     }
 }
 
+// ---- backward weights: dWb[(f, o), k] = sum_q dy[o, 4 q - 1 + f] x[q, k],  dBf[(f, o)] = sum_q dy[o, 4 q - 1 + f]
+// The reduction runs over coarse voxels, 32 (one stretch of a coarse w row) per MFMA k-step.  A workgroup owns one fd (6 workgroup
+// kinds) and a range of coarse (b, d, h, w-stretch) steps; its 6 waves own one fh each: 6 fw x 8 classes = 48 rows of Wb = 3 row
+// tiles x Ci / 16 column tiles of accumulators per wave.  Per step a
+// wave de-interleaves ITS fine row of dy (d = 4 qd - 1 + fd, h = 4 qh - 1 + fh, 130 voxels x 8 classes) into LDS as
+// S[class][fw][q] = dy[4 q - 1 + fw], so an operand fragment (8 consecutive q of one (fw, class)) is one 16-byte read; the x rows of
+// the step are shared by the 6 waves (bf16, row-major) and read transposed with ds_read_b64_tr_b16.  Loads of step s + 1 are in
+// flight under the MFMAs of step s.  dBf is a plain fp32 sum of the values a lane de-interleaves (its fw residue is fixed: lane & 3),
+// exact like the bias gradient of the patch-matrix path.  Partial slabs go to a workspace; tail_wgrad_reduce_kernel sums them
+// into dWb / dBf (=).
+constexpr int kWS = 40;                 // bf16 elements per S row (32 + 8: 80 bytes -- the 16 rows of a fragment read hit disjoint bank quads)
+typedef short s16x4w __attribute__((ext_vector_type(4)));
+
+template <int CI>
+__global__ void __launch_bounds__(384) tail_bwd_weight_fused_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                    float* __restrict__ ws, int B, int Dc, int Hc, int Wc,
+                                                                    int steps_per_group) {
+  constexpr int NJ = CI / 16, XS = CI + 20, V4 = CI / 4, XL = (32 * V4) / 384;
+  static_assert((32 * V4) % 384 == 0, "x stretch divides over the workgroup");
+  extern __shared__ __attribute__((aligned(16))) uint16_t wsm[];          // Xs[2][32 * XS] | Ss[2][6][48 * kWS]
+  uint16_t (*Xs)[32 * XS] = reinterpret_cast<uint16_t (*)[32 * XS]>(wsm);
+  uint16_t (*Ss)[6][48 * kWS] = reinterpret_cast<uint16_t (*)[6][48 * kWS]>(wsm + 2 * 32 * XS);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lr = lane >> 4;
+  const int fd = blockIdx.x, grp = blockIdx.y;
+  const int Df = 4 * Dc, Hf = 4 * Hc, Wf = 4 * Wc, wst = Wc / 32;
+  const int64_t plane = (int64_t)Df * Hf * Wf;
+  const int total = B * Dc * Hc * wst;
+  const int s_begin = grp * steps_per_group, s_end = min(total, s_begin + steps_per_group);
+
+  f32x4 acc[3][NJ];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bs_main[8], bs_alt[8];                                         // dBf partials: fw = lane & 3, and fw + 4 (lanes with fw < 2)
+#pragma unroll
+  for (int o = 0; o < 8; ++o) bs_main[o] = bs_alt[o] = 0.f;
+
+  float dyr[8][3];
+  float4 xr[XL];
+  auto fetch = [&](int s) {
+    int r = s;
+    const int qw0 = (r % wst) * 32; r /= wst;
+    const int qh = r % Hc; r /= Hc;
+    const int qd = r % Dc;
+    const int b = r / Dc;
+    const int ud = 4 * qd - 1 + fd, uh = 4 * qh - 1 + wave;
+    const bool row_in = (unsigned)ud < (unsigned)Df && (unsigned)uh < (unsigned)Hf;
+    const float* src = dy + (int64_t)b * 8 * plane + ((int64_t)ud * Hf + uh) * Wf;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int t = lane + 64 * j, uw = 4 * qw0 - 1 + t;
+      const bool in = row_in && t < 130 && (unsigned)uw < (unsigned)Wf;
+#pragma unroll
+      for (int o = 0; o < 8; ++o) dyr[o][j] = in ? src[o * plane + uw] : 0.f;
+    }
+    const float* xs = x + ((((int64_t)b * Dc + qd) * Hc + qh) * Wc + qw0) * CI;
+#pragma unroll
+    for (int u = 0; u < XL; ++u) xr[u] = *reinterpret_cast<const float4*>(xs + 4 * (tid + 384 * u));
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < XL; ++u) {
+      const int idx = tid + 384 * u;
+      *reinterpret_cast<u32x2v*>(&Xs[buf][(idx / V4) * XS + 4 * (idx % V4)]) = u32x2v{pack_bf16(xr[u].x, xr[u].y), pack_bf16(xr[u].z, xr[u].w)};
+    }
+    uint16_t* S = Ss[buf][wave];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int t = lane + 64 * j, q = t >> 2, fwl = t & 3;            // fine voxel t of the row = 4 q + fwl
+      if (t < 130) {
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+          const uint16_t v = bf16_bits(dyr[o][j]);
+          if (q < 32) { S[(o * 6 + fwl) * kWS + q] = v; bs_main[o] += dyr[o][j]; }
+          if (fwl < 2 && q >= 1) { S[(o * 6 + fwl + 4) * kWS + q - 1] = v; bs_alt[o] += dyr[o][j]; }
+        }
+      }
+    }
+  };
+
+  if (s_begin < s_end) fetch(s_begin);
+  int buf = 0;
+  for (int s = s_begin; s < s_end; ++s, buf ^= 1) {
+    commit(buf);
+    __syncthreads();
+    if (s + 1 < s_end) fetch(s + 1);
+    const uint16_t* S = Ss[buf][wave];
+    bf16x8 a[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+      a[t] = *reinterpret_cast<const bf16x8*>(S + ((li & 7) * 6 + 2 * t + (li >> 3)) * kWS + 8 * lr);
+    // transposed x fragments: lanes 4 j .. 4 j + 3 of a 16-lane group address row j (8 bytes each), lane i receives column i
+    const unsigned xb = (unsigned)(uintptr_t)(&Xs[buf][0]) + (unsigned)(((8 * lr + (li >> 2)) * XS + 4 * (li & 3)) * 2);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const s16x4w lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4w*)(uintptr_t)(xb + 32 * j));
+      const s16x4w hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4w*)(uintptr_t)(xb + 32 * j + 4 * XS * 2));
+      const bf16x8 bb = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+      for (int t = 0; t < 3; ++t) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], bb, acc[t][j], 0, 0, 0);
+    }
+  }
+  float* out = ws + ((((int64_t)grp * 6 + fd) * 6 + wave) * (3 * NJ) * 64 + lane) * 4;
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+      *reinterpret_cast<float4*>(out + (int64_t)(t * NJ + j) * 256) = make_float4(acc[t][j][0], acc[t][j][1], acc[t][j][2], acc[t][j][3]);
+  // dBf partials: sum over the lanes of one residue (lane & 3), then [group][slab][fw][class] behind the slabs
+  float* bout = ws + (int64_t)gridDim.y * 36 * (3 * NJ) * 256 + (((int64_t)grp * 6 + fd) * 6 + wave) * 48;
+#pragma unroll
+  for (int o = 0; o < 8; ++o) {
+    float m = bs_main[o], al = bs_alt[o];
+#pragma unroll
+    for (int d = 4; d < 64; d <<= 1) { m += __shfl_xor(m, d, 64); al += __shfl_xor(al, d, 64); }
+    if (lane < 4) bout[lane * 8 + o] = m;
+    if (lane < 2) bout[(lane + 4) * 8 + o] = al;
+  }
+}
+
+// dWb[(fd, fh, fw, o), ch] = sum over the groups' partial slabs (one thread per (slab tile, lane)); dBf likewise from its partials.
+__global__ void __launch_bounds__(256) tail_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dwb,
+                                                                float* __restrict__ dbf, int Ci, int groups) {
+  const int NJ = Ci / 16;
+  const int per_slab = 3 * NJ * 64;
+  const int id = blockIdx.x * 256 + threadIdx.x;
+  if (id >= 36 * per_slab) {                                           // dBf: [group][slab][fw][class] behind the slabs
+    const int e = id - 36 * per_slab;
+    if (e >= 36 * 48) return;
+    const float* b = ws + (int64_t)groups * 36 * per_slab * 4;
+    float sum = 0.f;
+    for (int g = 0; g < groups; ++g) sum += b[(int64_t)g * 36 * 48 + e];
+    dbf[e] = sum;                                                      // (slab * 6 + fw) * 8 + o == e
+    return;
+  }
+  const int slab = id / per_slab, e = id % per_slab;
+  const int lane = e & 63, tile = e >> 6, t = tile / NJ, j = tile % NJ, li = lane & 15, lr = lane >> 4;
+  float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int g = 0; g < groups; ++g) {
+    const float4 v = *reinterpret_cast<const float4*>(ws + (((int64_t)g * 36 + slab) * per_slab + e) * 4);
+    sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+  }
+  const float vals[4] = {sum.x, sum.y, sum.z, sum.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ra = 4 * lr + i, fw = 2 * t + (ra >> 3), o = ra & 7;
+    const int row = (slab * 6 + fw) * 8 + o;                             // slab = fd * 6 + fh
+    dwb[(int64_t)row * Ci + 16 * j + li] = vals[i];
+  }
+}
+
 static bool fused_ok(int Dc, int Hc, int Wc, int Ci, int Co, int P) {
   return Co == 8 && P == 4 && (Ci == 96 || Ci == 192) && Dc > 0 && Hc > 0 && Wc > 0 && Wc % 16 == 0 && Hc % 4 == 0;
 }
@@ -466,5 +618,41 @@ extern "C" int micf_head_tail_bwd_data_fused(const float* dy, const void* pack_b
   hipStream_t s = (hipStream_t)stream;
   if (Ci == 96) hipLaunchKernelGGL(tail_bwd_data_fused_kernel<96>, grid, dim3(384), lds, s, dy, wq, dx, B, Dc, Hc, Wc);
   else hipLaunchKernelGGL(tail_bwd_data_fused_kernel<192>, grid, dim3(384), lds, s, dy, wq, dx, B, Dc, Hc, Wc);
+  MICF_RETURN_LAUNCH();
+}
+
+static int wgrad_groups(int total) {
+  int g = 256 / 6;                                   // ~one workgroup per CU over the 6 fd kinds
+  return g < total ? g : total;
+}
+
+extern "C" int64_t micf_head_tail_bwd_weight_fused_workspace(int B, int Dc, int Hc, int Wc, int Ci) {
+  if (B <= 0 || Dc <= 0 || Hc <= 0 || Wc <= 0 || Wc % 32 || (Ci != 96 && Ci != 192)) return 0;
+  const int total = B * Dc * Hc * (Wc / 32);
+  return (int64_t)wgrad_groups(total) * 36 * (3 * (Ci / 16) * 256 + 48);
+}
+
+extern "C" int micf_head_tail_bwd_weight_fused(const float* dy, const float* x, float* dwb, float* dbf, float* workspace,
+                                               int64_t workspace_floats, int B, int Dc, int Hc, int Wc, int Ci, int Co, int P,
+                                               micf_stream_t stream) {
+  if (!dy || !x || !dwb || !dbf || !workspace || B <= 0) return MICF_EINVAL;
+  const int64_t need = micf_head_tail_bwd_weight_fused_workspace(B, Dc, Hc, Wc, Ci);
+  if (!fused_ok(Dc, Hc, Wc, Ci, Co, P) || need == 0 || workspace_floats < need || !aligned16(x) || !aligned16(workspace))
+    return MICF_EUNSUPPORTED;
+  const int total = B * Dc * Hc * (Wc / 32);
+  const int groups = wgrad_groups(total);
+  const int spg = (total + groups - 1) / groups;
+  hipStream_t s = (hipStream_t)stream;
+  const int lds = (2 * 32 * (Ci + 20) + 2 * 6 * 48 * kWS) * 2;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    allow_lds(&tail_bwd_weight_fused_kernel<96>, (2 * 32 * (96 + 20) + 2 * 6 * 48 * kWS) * 2);
+    allow_lds(&tail_bwd_weight_fused_kernel<192>, (2 * 32 * (192 + 20) + 2 * 6 * 48 * kWS) * 2);
+  });
+  if (Ci == 96) hipLaunchKernelGGL(tail_bwd_weight_fused_kernel<96>, dim3(6, groups), dim3(384), lds, s, dy, x, workspace, B, Dc, Hc, Wc, spg);
+  else hipLaunchKernelGGL(tail_bwd_weight_fused_kernel<192>, dim3(6, groups), dim3(384), lds, s, dy, x, workspace, B, Dc, Hc, Wc, spg);
+  if (hipGetLastError() != hipSuccess) return MICF_ELAUNCH;
+  const int n = 36 * 3 * (Ci / 16) * 64 + 36 * 48;
+  hipLaunchKernelGGL(tail_wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, workspace, dwb, dbf, Ci, groups);
   MICF_RETURN_LAUNCH();
 }

@@ -1272,9 +1272,13 @@ class HeadTailFn(torch.autograd.Function):
             dx = ops.linear_bwd_data(u, wb)
 
         def weight_grads():       # composed-map gradient, then its decomposition into the two layers' parameters
-            uu = u if u is not None else ops.head_tail_im2col(dy, ctx.dims, P)
-            dwb, dbf = ops.zero_(torch.empty_like(wb)), ops.zero_(torch.empty(wb.shape[0], dtype=wb.dtype, device=wb.device))
-            ops.linear_bwd_weight(uu, xf, dwb, dbf)
+            got = ops.head_tail_bwd_weight_fused(dy, xf, ctx.dims, P) if u is None else None
+            if got is not None:
+                dwb, dbf = got
+            else:
+                uu = u if u is not None else ops.head_tail_im2col(dy, ctx.dims, P)
+                dwb, dbf = ops.zero_(torch.empty_like(wb)), ops.zero_(torch.empty(wb.shape[0], dtype=wb.dtype, device=wb.device))
+                ops.linear_bwd_weight(uu, xf, dwb, dbf)
             ops.head_tail_decompose(dwb, dbf, w_up, b_up, w_out, *grads, w_up_t=w_up_t)
 
         _defer(all(t is not None for t in ctx.tg), weight_grads, u if u is not None else dy, xf, wb)

@@ -642,6 +642,21 @@ def head_tail_bwd_data_fused(dy, pack_bwd, dims, Ci, P):
     return dx
 
 
+def head_tail_bwd_weight_fused(dy, x, dims, P):
+    """(dwb, dbf) of the composed map with dy gathered on the fly (no U), or None when this grid is not covered."""
+    B, Dc, Hc, Wc = dims
+    Ci, Co = x.shape[-1], dy.shape[1]
+    need = _lib.lib.micf_head_tail_bwd_weight_fused_workspace(B, Dc, Hc, Wc, Ci)
+    if need == 0 or not head_tail_fused_supported(dims, Ci, Co, P):
+        return None
+    rows = (P + 2) ** 3 * Co
+    dwb, dbf = _new(x, rows, Ci), _new(x, rows)
+    ws = scratch(x.device, need)
+    call("micf_head_tail_bwd_weight_fused", f32(dy), f32(x), f32(dwb), f32(dbf), f32(ws), ws.numel(), B, Dc, Hc, Wc, Ci, Co, P,
+         cost=_cost(2 * x.shape[0] * rows * Ci, dy, x, dwb, tag=f"{x.shape[0]}x{Ci}"))
+    return dwb, dbf
+
+
 def head_tail_col2im(t, b_out, dims, P):
     B, Dc, Hc, Wc = dims
     Co = b_out.shape[0]

@@ -19,6 +19,7 @@
 namespace micf {
 
 constexpr int wCS = 48;                 // channels per slab (3 channel tiles): 67 KB of LDS, so a workgroup of the other stream fits beside it
+constexpr int wDS = 20;                 // LDS stride of a dy row (floats): the four lane groups' tokens are 80 floats = 16 banks apart
 constexpr int wXS = 52;                 // LDS voxel stride (floats): 4 * 52 = 208 = 16 (mod 64) -> the four k lanes hit disjoint banks
 constexpr int wPairs = 27 * (wCS / 16); // 81 (tap, channel tile) pairs per slab
 constexpr int wTPW = (wPairs + 3) / 4;  // 21 accumulator tiles per wave
@@ -76,54 +77,63 @@ __global__ void __launch_bounds__(256) conv3_wgradx_kernel(WgxArgs a) {
   const int ntiles = a.B * a.tiles_d * a.tiles_h * a.tiles_w;
   const int t_begin = group * a.tiles_per_group;
   const int t_end = min(ntiles, t_begin + a.tiles_per_group);
-  for (int tile = t_begin; tile < t_end; ++tile) {
+  // The halo and the dy rows of the NEXT tile are fetched into registers under the MFMAs of the current one (one workgroup per
+  // CU: nothing else hides the load latency) and committed to LDS after the barrier that ends the current tile.  The MFMA phase
+  // itself issues no global load (dy fragments come from LDS): loads return in order, one issued there would wait for the prefetch.
+  constexpr int NQ = HALO * (wCS / 4);
+  constexpr int NB = 16;
+  static_assert(NQ <= 256 * NB, "one batch per tile");
+  float* Dys = Xs + HALO * wXS;                                        // [64 tokens][wDS] dy of the tile
+  float4 v[NB], vdy;
+  auto fetch = [&](int tile) {
     int q = tile;
     const int tw = q % a.tiles_w; q /= a.tiles_w;
     const int th = q % a.tiles_h; q /= a.tiles_h;
     const int d0 = q % a.tiles_d; const int b = q / a.tiles_d;
     const int h0 = th * TH, w0 = tw * TW;
-    __syncthreads();                                                   // previous tile fully consumed
-    // ---- stage the halo: HALO voxels x 24 float4 (channels cbase .. cbase+95 of [x1 | x2]), loads batched 16 deep
-    constexpr int NQ = HALO * (wCS / 4);
-    constexpr int NB = 16;
-    for (int base = 0; base < NQ; base += 256 * NB) {
-      float4 v[NB];
 #pragma unroll
-      for (int u = 0; u < NB; ++u) {
-        const int idx = base + u * 256 + tid;
-        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (idx < NQ) {
-          const int hv = idx / (wCS / 4), g = idx % (wCS / 4);
-          const int hw = hv % HW, hh = (hv / HW) % HH, hd = hv / (HW * HH);
-          const int dd = d0 + hd - 1, yy = h0 + hh - 1, ww = w0 + hw - 1;
-          const int c = cbase + 4 * g;
-          if ((unsigned)dd < (unsigned)a.D && (unsigned)yy < (unsigned)a.H && (unsigned)ww < (unsigned)a.W && c < Cin) {
-            const int64_t tok = (int64_t)b * DHW + ((int64_t)dd * a.H + yy) * a.W + ww;
-            v[u] = c < a.c1 ? *reinterpret_cast<const float4*>(a_x1 + tok * a.c1 + c)
-                            : *reinterpret_cast<const float4*>(a_x2 + tok * a.c2 + (c - a.c1));
-          }
+    for (int u = 0; u < NB; ++u) {
+      const int idx = u * 256 + tid;
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < NQ) {
+        const int hv = idx / (wCS / 4), g = idx % (wCS / 4);
+        const int hw = hv % HW, hh = (hv / HW) % HH, hd = hv / (HW * HH);
+        const int dd = d0 + hd - 1, yy = h0 + hh - 1, ww = w0 + hw - 1;
+        const int c = cbase + 4 * g;
+        if ((unsigned)dd < (unsigned)a.D && (unsigned)yy < (unsigned)a.H && (unsigned)ww < (unsigned)a.W && c < Cin) {
+          const int64_t tok = (int64_t)b * DHW + ((int64_t)dd * a.H + yy) * a.W + ww;
+          v[u] = c < a.c1 ? *reinterpret_cast<const float4*>(a_x1 + tok * a.c1 + c)
+                          : *reinterpret_cast<const float4*>(a_x2 + tok * a.c2 + (c - a.c1));
         }
       }
-#pragma unroll
-      for (int u = 0; u < NB; ++u) {
-        const int idx = base + u * 256 + tid;
-        if (idx < NQ) *reinterpret_cast<float4*>(&Xs[(idx / (wCS / 4)) * wXS + 4 * (idx % (wCS / 4))]) = v[u];
-      }
     }
-    // dy fragment of a 16-token group (k-permutation: in step s lane group lr supplies token j = 4*lr + s of the group);
-    // the fragment of group g+1 is fetched under the MFMAs of group g, the first one before the barrier
+    {
+      const int tk = tid >> 2, yy = h0 + tk / TW, ww = w0 + tk % TW;    // tile-local token tk = lh * TW + lw
+      vdy = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (yy < a.H && ww < a.W)
+        vdy = *reinterpret_cast<const float4*>(a_dy + ((int64_t)b * DHW + ((int64_t)d0 * a.H + yy) * a.W + ww) * 16 + 4 * (tid & 3));
+    }
+  };
+  if (t_begin < t_end) fetch(t_begin);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    __syncthreads();                                                   // previous tile fully consumed
+    // ---- commit: HALO voxels x 12 float4 (channels cbase .. cbase+47 of [x1 | x2]) and the 64 x 16 dy rows
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int idx = u * 256 + tid;
+      if (idx < NQ) *reinterpret_cast<float4*>(&Xs[(idx / (wCS / 4)) * wXS + 4 * (idx % (wCS / 4))]) = v[u];
+    }
+    *reinterpret_cast<float4*>(&Dys[(tid >> 2) * wDS + 4 * (tid & 3)]) = vdy;
+    // dy fragment of a 16-token group (k-permutation: in step s lane group lr supplies token j = 4*lr + s of the group)
     auto load_dy = [&](int g, float (&bv)[4]) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int j = 4 * lr + s;
-        const int yy = h0 + g * CH + j / TW, ww = w0 + j % TW;
-        bv[s] = 0.f;
-        if (g < 4 && yy < a.H && ww < a.W) bv[s] = a_dy[((int64_t)b * DHW + ((int64_t)d0 * a.H + yy) * a.W + ww) * 16 + li];
-      }
+      for (int s = 0; s < 4; ++s) bv[s] = g < 4 ? Dys[(g * 16 + 4 * lr + s) * wDS + li] : 0.f;
     };
+    __syncthreads();
+    if (tile + 1 < t_end) fetch(tile + 1);
     float bv[4], bn[4];
     load_dy(0, bv);
-    __syncthreads();
+
     if constexpr (!BF16) {
     // ---- 4 token groups of 16 tokens
 #pragma unroll 1
@@ -294,12 +304,12 @@ int conv3_wgradx_items(const float* const* dy, const float* const* x1, const flo
   const dim3 grid(p.slabs, p.groups, n);
   if (p.tw == 16) {
     constexpr int HALO = 3 * (4 + 2) * (16 + 2);
-    if (dtype == MICF_DTYPE_BF16) hipLaunchKernelGGL((conv3_wgradx_kernel<16, true>), grid, dim3(256), sizeof(float) * HALO * wXS, stream, a);
-    else hipLaunchKernelGGL((conv3_wgradx_kernel<16, false>), grid, dim3(256), sizeof(float) * HALO * wXS, stream, a);
+    if (dtype == MICF_DTYPE_BF16) hipLaunchKernelGGL((conv3_wgradx_kernel<16, true>), grid, dim3(256), sizeof(float) * (HALO * wXS + 64 * wDS), stream, a);
+    else hipLaunchKernelGGL((conv3_wgradx_kernel<16, false>), grid, dim3(256), sizeof(float) * (HALO * wXS + 64 * wDS), stream, a);
   } else {
     constexpr int HALO = 3 * (8 + 2) * (8 + 2);
-    if (dtype == MICF_DTYPE_BF16) hipLaunchKernelGGL((conv3_wgradx_kernel<8, true>), grid, dim3(256), sizeof(float) * HALO * wXS, stream, a);
-    else hipLaunchKernelGGL((conv3_wgradx_kernel<8, false>), grid, dim3(256), sizeof(float) * HALO * wXS, stream, a);
+    if (dtype == MICF_DTYPE_BF16) hipLaunchKernelGGL((conv3_wgradx_kernel<8, true>), grid, dim3(256), sizeof(float) * (HALO * wXS + 64 * wDS), stream, a);
+    else hipLaunchKernelGGL((conv3_wgradx_kernel<8, false>), grid, dim3(256), sizeof(float) * (HALO * wXS + 64 * wDS), stream, a);
   }
   if (hipGetLastError() != hipSuccess) return MICF_ELAUNCH;
   const int64_t ne = (int64_t)wPairs * 256 * p.slabs + 16;

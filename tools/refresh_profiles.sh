@@ -29,6 +29,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tmp -o b -- python 
 cp $OUT/tmp/b_kernel_stats.csv $OUT/${R}_bench_kernel_stats.csv
 python tools/trace_concurrency.py $OUT/tmp/b_kernel_trace.csv > $OUT/${R}_concurrency.txt
 python tools/trace_stages.py $OUT/tmp/b_kernel_trace.csv > $OUT/${R}_stages.txt
+python tools/trace_stages.py $OUT/tmp/b_kernel_trace.csv --detail > $OUT/${R}_stages_detail.txt
 # by (kernel, grid) from an eager run (graph replays keep the grid too, but eager separates the warm-up cleanly)
 rocprofv3 --kernel-trace --output-format csv -d $OUT/tmp -o e -- python bench.py --steps 4 --warmup 0 --no-cpu-baseline --no-roofline --no-graph \
   > /dev/null 2>> $OUT/rocprof.err

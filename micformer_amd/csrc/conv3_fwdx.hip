@@ -45,6 +45,9 @@ __global__ void __launch_bounds__(256) conv3_fwdx_kernel(FwdxArgs a) {
   if (blockIdx.z) { a.x1 = a.x1b; a.x2 = a.x2b; a.wt = a.wtb; a.bias = a.biasb; a.y = a.yb; }   // the other modality's head
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lr = lane >> 4;
   int q = blockIdx.x;
+  // XCD-contiguous tile order (gridDim.x % 8 == 0: the XCD of a workgroup is blockIdx.x % 8 whatever y / z): the halo planes
+  // neighbouring tiles share are fetched into ONE XCD's L2
+  if (gridDim.x >= 64 && (gridDim.x & 7) == 0) q = (q & 7) * (gridDim.x >> 3) + (q >> 3);
   const int tw = q % a.tiles_w; q /= a.tiles_w;
   const int th = q % a.tiles_h; q /= a.tiles_h;
   const int td = q % a.tiles_d; const int b = q / a.tiles_d;

@@ -275,6 +275,10 @@ int micf_space_to_depth(const float* x, float* a, int B, int D, int H, int W, in
                         micf_stream_t stream);
 int micf_depth_to_space(const float* a, const float* bias, float* y, int B, int D, int H, int W, int C, int k,
                         micf_stream_t stream);
+/* ... the same with y = scatter(a) + bias + add, add [B, D, H, W, C] (may alias y): where a tensor has a second gradient -- the
+ * skip connection of an encoder stage -- it is summed here instead of by a separate elementwise launch. */
+int micf_depth_to_space_add(const float* a, const float* bias, const float* add, float* y, int B, int D, int H, int W, int C,
+                            int k, micf_stream_t stream);
 int micf_colsum(const float* x, float* out, int64_t M, int N, micf_stream_t stream);
 /* conv_up: ConvTranspose3d(C->N, k=s in {2,4}) on channels-last x [B,D,H,W,C] -> y [B,kD,kH,kW,N] channels-last
  * (PatchExpand MS.py:575-577; reverse_patch_embedding MS.py:990,1037). */

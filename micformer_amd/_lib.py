@@ -93,6 +93,7 @@ SIGNATURES = {
     "micf_conv_up_bwd_weight": "ppppiiiiiiip",
     "micf_space_to_depth": "ppiiiiiilp",
     "micf_depth_to_space": "pppiiiiiip",
+    "micf_depth_to_space_add": "ppppiiiiiip",
     "micf_colsum": "pplip",
     "micf_pad3d": "ppiiiiiiiip",
     "micf_crop3d": "ppiiiiiiiiip",

@@ -304,7 +304,8 @@ struct S2dGeo {
 };
 template <bool TO_DEPTH>
 __global__ void __launch_bounds__(256) s2d_kernel(const float* __restrict__ src, float* __restrict__ dst,
-                                                  const float* __restrict__ bias, S2dGeo g, int64_t total4) {
+                                                  const float* __restrict__ bias, S2dGeo g, int64_t total4,
+                                                  const float* addp = nullptr) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total4) return;
   const int q4 = g.K3 >> 2;
@@ -326,7 +327,7 @@ __global__ void __launch_bounds__(256) s2d_kernel(const float* __restrict__ src,
     if (z >= g.D || y >= g.H || x >= g.W) continue;
     const int64_t a = (int64_t)b * g.batch_stride + (((int64_t)z * g.H + y) * g.W + x) * g.C + c;
     if (TO_DEPTH) v[j] = src[a];
-    else dst[a] = v[j] + bs;
+    else dst[a] = v[j] + bs + (addp ? addp[a] : 0.f);
   }
   if (TO_DEPTH) *reinterpret_cast<float4*>(mat) = make_float4(v[0], v[1], v[2], v[3]);
 }
@@ -354,6 +355,16 @@ extern "C" int micf_depth_to_space(const float* a, const float* bias, float* y, 
   if (!a || !y || !s2d_geo(g, B, D, H, W, C, k, 0) || !aligned16(a)) return MICF_EINVAL;
   const int64_t total4 = (int64_t)B * g.Dc * g.Hc * g.Wc * C * (g.K3 / 4);
   hipLaunchKernelGGL(s2d_kernel<false>, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, S_(stream), a, y, bias, g, total4);
+  MICF_RETURN_LAUNCH();
+}
+
+// ... + add[voxel, c]: a second gradient of the same tensor (the skip connection's) summed in the scatter, add may alias y
+extern "C" int micf_depth_to_space_add(const float* a, const float* bias, const float* add, float* y, int B, int D, int H, int W,
+                                       int C, int k, micf_stream_t stream) {
+  S2dGeo g;
+  if (!a || !y || !add || !s2d_geo(g, B, D, H, W, C, k, 0) || !aligned16(a)) return MICF_EINVAL;
+  const int64_t total4 = (int64_t)B * g.Dc * g.Hc * g.Wc * C * (g.K3 / 4);
+  hipLaunchKernelGGL(s2d_kernel<false>, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, S_(stream), a, y, bias, g, total4, add);
   MICF_RETURN_LAUNCH();
 }
 

@@ -1130,6 +1130,44 @@ class PatchEmbedPairFn(torch.autograd.Function):
         return None, _ret(ctx.tg[0], dw), _ret(ctx.tg[1], db), None
 
 
+# The output of an encoder stage has two consumers: PatchMerging (next stage) and the decoder's skip concat.  autograd sums their
+# gradients with an ATen elementwise launch per tensor.  Instead the skip gradient is handed over Python-side: ConvDownFn.forward
+# registers a token under its input's address; the decoder passes the skip through SkipMailFn (created late in the forward, so
+# its backward runs as soon as the concat linear's backward has produced the skip gradient -- long before this stage's
+# PatchMerging backward, which depends on it through the whole deeper network), whose backward parks the gradient in the token
+# and returns None (no second gradient path for autograd to sum); ConvDownFn.backward adds it inside its depth-to-space scatter.
+SKIP_MAIL = _os.environ.get("MICF_SKIP_MAIL", "1") != "0"
+_SKIP_TOKENS = {}                   # data_ptr of a ConvDownFn input of THIS forward -> token
+
+
+class _SkipToken:
+    __slots__ = ("grad",)
+
+    def __init__(self):
+        self.grad = None
+
+
+def clear_skip_tokens():
+    _SKIP_TOKENS.clear()
+
+
+def skip_token(t):
+    """The token of the PatchMerging launch that consumed exactly this tensor in the current forward, or None."""
+    return _SKIP_TOKENS.get(t.data_ptr()) if SKIP_MAIL else None
+
+
+class SkipMailFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, token):
+        ctx.token = token
+        return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.token.grad = g if ctx.token.grad is None else ctx.token.grad + g
+        return None, None
+
+
 class ConvDownFn(torch.autograd.Function):
     """Conv3d(C->N, k=s=2) of PatchMerging on channels-last x (MS.py:548-557)."""
 
@@ -1139,6 +1177,9 @@ class ConvDownFn(torch.autograd.Function):
         ctx.tg = _targets((w, b))
         ctx.xshape = tuple(x.shape)
         ctx.gemm = PATCH_GEMM and tuple(w.shape[2:]) == (2, 2, 2)
+        ctx.token = None
+        if ctx.gemm and SKIP_MAIL and x.requires_grad:
+            ctx.token = _SKIP_TOKENS[x.data_ptr()] = _SkipToken()
         if ctx.gemm:
             B, D, H, W, C = x.shape
             N = w.shape[0]
@@ -1160,7 +1201,11 @@ class ConvDownFn(torch.autograd.Function):
             dy2 = dy.reshape(-1, N)
             _lin_wgrad(ctx.tg[0] is not None and ctx.tg[1] is not None, dy2, x, dw.view(N, 8 * C), db)
             da = ops.linear_bwd_data(dy2, w.reshape(N, 8 * C))
-            return ops.depth_to_space(da, (B, D, H, W), C, 2), _ret(ctx.tg[0], dw), _ret(ctx.tg[1], db)
+            skip = ctx.token.grad if ctx.token is not None else None      # the skip connection's gradient of x (SkipMailFn)
+            if skip is not None:
+                ctx.token.grad = None
+                skip = _c(skip)
+            return ops.depth_to_space(da, (B, D, H, W), C, 2, add=skip), _ret(ctx.tg[0], dw), _ret(ctx.tg[1], db)
         _defer(ctx.tg[0] is not None and ctx.tg[1] is not None, lambda: ops.conv_down_bwd_weight(dy, x, dw, db), dy, x)
         return ops.conv_down_bwd_data(dy, w, ctx.xshape), _ret(ctx.tg[0], dw), _ret(ctx.tg[1], db)
 

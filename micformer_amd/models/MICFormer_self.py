@@ -619,6 +619,7 @@ class MicFormer(nn.Module):
         return self._coarse_from_tokens(m, f)
 
     def _coarse_from_tokens(self, m, f):
+        Fn.clear_skip_tokens()
         skips = []
         for layer in self.layers:
             m_out, f_out, m, f = layer(m, f)
@@ -638,7 +639,11 @@ class MicFormer(nn.Module):
                     f = Fn.ResizeTrilinearFn.apply(f, tuple(sf.shape[1:4]))
                 lin = self.concat_back_dim[inx]
                 if _joint_ok(m, f) and _joint_ok(sm, sf):
-                    m, f = Fn.SplitFn.apply(Fn.LinearFn.apply(Fn.JoinFn.apply(m, f), Fn.JoinFn.apply(sm, sf), lin.weight, lin.bias))
+                    skip = Fn.JoinFn.apply(sm, sf)
+                    tok = Fn.skip_token(skip) if skip.requires_grad else None
+                    if tok is not None:                   # its gradient joins the stage output's other gradient inside PatchMerging's backward
+                        skip = Fn.SkipMailFn.apply(skip, tok)
+                    m, f = Fn.SplitFn.apply(Fn.LinearFn.apply(Fn.JoinFn.apply(m, f), skip, lin.weight, lin.bias))
                 else:
                     m, f = _both(lambda t: Fn.LinearFn.apply(t[0], t[1], lin.weight, lin.bias), (m, sm), (f, sf))
             _, _, m, f = up(m, f)

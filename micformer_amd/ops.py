@@ -719,10 +719,15 @@ def space_to_depth(x, dims, C, k, batch_stride=0, offset=0, out=None):
     return a
 
 
-def depth_to_space(a, dims, C, k, bias=None):
-    """Inverse scatter of space_to_depth: [rows, C * k^3] -> channels-last [B, D, H, W, C] (+ bias[C]); every voxel is written."""
+def depth_to_space(a, dims, C, k, bias=None, add=None):
+    """Inverse scatter of space_to_depth: [rows, C * k^3] -> channels-last [B, D, H, W, C] (+ bias[C]); every voxel is written.
+    add: a [B, D, H, W, C] tensor summed in (a second gradient of the same tensor: the skip connection's)."""
     B, D, H, W = dims
     y = _new(a, B, D, H, W, C)
+    if add is not None:
+        assert add.numel() == y.numel() and add.is_contiguous()
+        call("micf_depth_to_space_add", f32(a), f32(bias), f32(add), f32(y), B, D, H, W, C, k, cost=_cost(0, a, add, y))
+        return y
     call("micf_depth_to_space", f32(a), f32(bias), f32(y), B, D, H, W, C, k, cost=_cost(0, a, y))
     return y
 

@@ -438,10 +438,13 @@ class JoinFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):
         ctx.B = a.shape[0]
+        ctx.set_materialize_grads(False)        # (SkipMailFn hands its gradient over out of band: no zero tensor, no sum)
         return _joined(_c(a.detach()), _c(b.detach()))
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return None, None
         g = _c(g)
         return g[:ctx.B], g[ctx.B:]
 

@@ -54,5 +54,12 @@ python tools/pmc_summary.py $OUT/pmc $OUT/${R}_pmc_hbm_by_kernel.csv --key "$KEY
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma -o m -- \
   python bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-roofline > /dev/null 2>> $OUT/rocprof.err
 python tools/mfma_summary.py $OUT/mfma 30 > $OUT/${R}_mfma_util.txt
-rm -rf $OUT/tmp $OUT/pmc $OUT/mfma
+# where the waves of the block kernels spend their cycles (two SQ passes of 8 counters; quad-cycle units, see tools/pmc_sq_summary.py)
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_LDS \
+  --kernel-trace --output-format csv -d $OUT/sq -o s -- python bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-roofline --no-graph > /dev/null 2>> $OUT/rocprof.err
+python tools/pmc_sq_summary.py $OUT/sq > $OUT/${R}_sq_wave_time.txt
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAVES SQ_BUSY_CYCLES SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM \
+  --kernel-trace --output-format csv -d $OUT/sq2 -o s -- python bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-roofline --no-graph > /dev/null 2>> $OUT/rocprof.err
+python tools/pmc_sq_summary.py $OUT/sq2 >> $OUT/${R}_sq_wave_time.txt
+rm -rf $OUT/tmp $OUT/pmc $OUT/mfma $OUT/sq $OUT/sq2
 tail -3 $OUT/${R}_pmc_summary.txt; head -12 $OUT/${R}_mfma_util.txt; head -c 400 $OUT/${R}_bench.json

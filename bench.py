@@ -265,7 +265,8 @@ def main(argv=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss_val = float(loss)
-    assert loss_val == loss_val, "loss is NaN"
+    probe = os.environ.get("MICF_SEG_SKIP_SIDE") == "1"             # timing probe: main chain alone, parameter gradients skipped
+    assert probe or loss_val == loss_val, "loss is NaN"
     ms_step = 1000.0 * dt / args.steps
 
     out = {
@@ -282,6 +283,8 @@ def main(argv=None):
                                                             "parameter-gradient batches as separate graphs on two streams)")},
         "final_loss": round(loss_val, 6),
     }
+    if probe:
+        out["probe"] = "MICF_SEG_SKIP_SIDE=1: the main (data-gradient) chain alone, parameter-gradient batches skipped -- a timing probe, NOT a training step"
 
     # ---- roofline leg: HIP events around every C-ABI launch of 2 eager steps on the launch stream(s), keyed by (entry point,
     # shape).  EVERY rank runs it (the eager steps contain the gradient all-reduce); rank 0 reports its own numbers.

@@ -198,6 +198,146 @@ __global__ void __launch_bounds__(256) conv3_wgradx_kernel(WgxArgs a) {
   }
 }
 
+// ---- bf16 mode, round 3: the halo and the dy rows sit in LDS as bf16, token-major (no transposing staging), and the MFMA fragments
+// -- 8 tokens of one channel per lane -- are read with the transposing LDS read ds_read_b64_tr_b16: lanes 4 j .. 4 j + 3 of a 16-lane
+// group address token row j (8 bytes = 4 channels each), lane i receives column i.  The 4 rows of a read are ARBITRARY addresses,
+// so a tap is just a byte offset on every row address (whole voxel rows: no sub-row misalignment), and one (tap, channel tile)
+// costs 2 reads + 2 adds per MFMA where the fp32-staged kernel above pays 8 reads + 8 adds + 4 conversions (SQ counters put
+// that kernel at 58 % issue-busy on its one wave per SIMD: instruction-bound).  34 KB of LDS instead of 72: a workgroup of the
+// main chain fits beside it.  Same accumulator / workspace layout as above, same reduce kernel.
+constexpr int wRSB = 104;               // bytes per halo voxel row: 48 bf16 + 8 pad (26 dwords: the 4 token rows of a read are bank-disjoint)
+constexpr int wDYB = 40;                // bytes per dy token row: 16 bf16 + 8 pad
+typedef short s16x4x __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x8 tr_pair(unsigned a0, unsigned a1) {
+  const s16x4x lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4x*)(uintptr_t)a0);
+  const s16x4x hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4x*)(uintptr_t)a1);
+  return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+template <int TW>
+__global__ void __launch_bounds__(256) conv3_wgradx_b16_kernel(WgxArgs a) {
+  constexpr int TH = 64 / TW;
+  constexpr int HH = TH + 2, HW = TW + 2, HALO = 3 * HH * HW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];          // Xh [HALO][wRSB] | Dy [64][wDYB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lr = lane >> 4;
+  int slab = blockIdx.x, group = blockIdx.y;
+  const int item = blockIdx.z;
+  if (a.xcd_order) {
+    const int L = gridDim.x * gridDim.y;
+    const int lin = slab + gridDim.x * group;
+    const int logical = (lin % 8) * (L / 8) + lin / 8;
+    slab = logical % gridDim.x;
+    group = logical / gridDim.x;
+  }
+  const float* __restrict__ a_dy = a.dy[item];
+  const float* __restrict__ a_x1 = a.x1[item];
+  const float* __restrict__ a_x2 = a.x2[item];
+  const int Cin = a.c1 + a.c2;
+  const int cbase = slab * wCS;
+  const int64_t DHW = (int64_t)a.D * a.H * a.W;
+  const unsigned xh = (unsigned)(uintptr_t)smem, dyl = xh + HALO * wRSB;
+
+  f32x4 acc[wTPW];
+#pragma unroll
+  for (int p = 0; p < wTPW; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int offs[wTPW];                                                      // byte offset of (tap, channel tile) p of this wave
+#pragma unroll
+  for (int p = 0; p < wTPW; ++p) {
+    const int pair = min(wave * wTPW + p, wPairs - 1);
+    const int tap = pair / (wCS / 16), ct = pair % (wCS / 16);
+    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+    offs[p] = (((kd - 1) * HH + (kh - 1)) * HW + (kw - 1)) * wRSB + ct * 32;
+  }
+  // token t = 8 lr + 4 r + (li >> 2) of k-step ks (32 tokens = 32 / TW tile rows): its centre voxel row in the halo / its dy row
+  unsigned abase[2][2], bbase[2][2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int t = 8 * lr + 4 * r + (li >> 2);
+      const int lh = ks * (32 / TW) + t / TW, lw = t % TW;
+      abase[ks][r] = xh + (unsigned)(((1 * HH + lh + 1) * HW + lw + 1) * wRSB + 8 * (li & 3));
+      bbase[ks][r] = dyl + (unsigned)((32 * ks + t) * wDYB + 8 * (li & 3));
+    }
+  float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);                         // column sums of dy (channels 4 (tid & 3) ..) over this thread's tokens
+
+  const int ntiles = a.B * a.tiles_d * a.tiles_h * a.tiles_w;
+  const int t_begin = group * a.tiles_per_group;
+  const int t_end = min(ntiles, t_begin + a.tiles_per_group);
+  constexpr int NQ = HALO * (wCS / 4);
+  constexpr int NB = 16;
+  static_assert(NQ <= 256 * NB, "one batch per tile");
+  float4 v[NB], vdy;
+  auto fetch = [&](int tile) {
+    int q = tile;
+    const int tw = q % a.tiles_w; q /= a.tiles_w;
+    const int th = q % a.tiles_h; q /= a.tiles_h;
+    const int d0 = q % a.tiles_d; const int b = q / a.tiles_d;
+    const int h0 = th * TH, w0 = tw * TW;
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int idx = u * 256 + tid;
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < NQ) {
+        const int hv = idx / (wCS / 4), g = idx % (wCS / 4);
+        const int hw = hv % HW, hh = (hv / HW) % HH, hd = hv / (HW * HH);
+        const int dd = d0 + hd - 1, yy = h0 + hh - 1, ww = w0 + hw - 1;
+        const int c = cbase + 4 * g;
+        if ((unsigned)dd < (unsigned)a.D && (unsigned)yy < (unsigned)a.H && (unsigned)ww < (unsigned)a.W && c < Cin) {
+          const int64_t tok = (int64_t)b * DHW + ((int64_t)dd * a.H + yy) * a.W + ww;
+          v[u] = c < a.c1 ? *reinterpret_cast<const float4*>(a_x1 + tok * a.c1 + c)
+                          : *reinterpret_cast<const float4*>(a_x2 + tok * a.c2 + (c - a.c1));
+        }
+      }
+    }
+    const int tk = tid >> 2, yy = h0 + tk / TW, ww = w0 + tk % TW;      // tile-local token tk = lh * TW + lw
+    vdy = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (yy < a.H && ww < a.W)
+      vdy = *reinterpret_cast<const float4*>(a_dy + ((int64_t)b * DHW + ((int64_t)d0 * a.H + yy) * a.W + ww) * 16 + 4 * (tid & 3));
+  };
+  typedef unsigned u32x2w __attribute__((ext_vector_type(2)));
+  if (t_begin < t_end) fetch(t_begin);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    __syncthreads();                                                   // previous tile fully consumed
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int idx = u * 256 + tid;
+      if (idx < NQ)
+        *reinterpret_cast<u32x2w*>(smem + (idx / (wCS / 4)) * wRSB + 8 * (idx % (wCS / 4))) = u32x2w{pack_bf16(v[u].x, v[u].y), pack_bf16(v[u].z, v[u].w)};
+    }
+    *reinterpret_cast<u32x2w*>(smem + HALO * wRSB + (tid >> 2) * wDYB + 8 * (tid & 3)) = u32x2w{pack_bf16(vdy.x, vdy.y), pack_bf16(vdy.z, vdy.w)};
+    bs.x += vdy.x; bs.y += vdy.y; bs.z += vdy.z; bs.w += vdy.w;
+    __syncthreads();
+    if (tile + 1 < t_end) fetch(tile + 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8 bb = tr_pair(bbase[ks][0], bbase[ks][1]);
+#pragma unroll
+      for (int p = 0; p < wTPW; ++p) {
+        const bf16x8 ba = tr_pair(abase[ks][0] + offs[p], abase[ks][1] + offs[p]);
+        acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ba, bb, acc[p], 0, 0, 0);
+      }
+    }
+  }
+  // ---- partial slab -> workspace: [(wave*TPW + p)][lane][4], 16-byte stores
+  float* out = a.ws + (((int64_t)item * a.slabs + slab) * a.groups + group) * wSlabFloats;
+#pragma unroll
+  for (int p = 0; p < wTPW; ++p)
+    *reinterpret_cast<float4*>(out + ((wave * wTPW + p) * 64 + lane) * 4) = make_float4(acc[p][0], acc[p][1], acc[p][2], acc[p][3]);
+  if (a.bias_ws && slab == 0) {                                        // column sums of dy: over the lanes of one channel quad, then the waves
+#pragma unroll
+    for (int d = 4; d < 64; d <<= 1) {
+      bs.x += __shfl_xor(bs.x, d, 64); bs.y += __shfl_xor(bs.y, d, 64); bs.z += __shfl_xor(bs.z, d, 64); bs.w += __shfl_xor(bs.w, d, 64);
+    }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+    if (lane < 4) *reinterpret_cast<float4*>(red + (wave * 4 + lane) * 4) = bs;
+    __syncthreads();
+    if (tid < 16) a.bias_ws[((int64_t)item * a.groups + group) * 16 + tid] = red[tid] + red[16 + tid] + red[32 + tid] + red[48 + tid];
+  }
+}
+
 // dw[n][c][tap] += sum over the groups' partial slabs;  dbias[n] += sum of the groups' column sums.
 // Block = 64 slab elements x 4 slices of the group range (independent loads, unrolled), combined through LDS.
 struct WgxOut { float* dw[kWgxItems]; float* dbias[kWgxItems]; };
@@ -300,15 +440,21 @@ int conv3_wgradx_items(const float* const* dy, const float* const* x1, const flo
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgradx_kernel<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgradx_kernel<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgradx_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgradx_b16_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgradx_b16_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
   });
   const dim3 grid(p.slabs, p.groups, n);
   if (p.tw == 16) {
     constexpr int HALO = 3 * (4 + 2) * (16 + 2);
-    if (dtype == MICF_DTYPE_BF16) hipLaunchKernelGGL((conv3_wgradx_kernel<16, true>), grid, dim3(256), sizeof(float) * (HALO * wXS + 64 * wDS), stream, a);
+    static const bool old_b16 = [] { const char* e = getenv("MICF_WGX_OLD"); return e && e[0] == '1'; }();
+    if (dtype == MICF_DTYPE_BF16 && !old_b16) hipLaunchKernelGGL((conv3_wgradx_b16_kernel<16>), grid, dim3(256), HALO * wRSB + 64 * wDYB, stream, a);
+    else if (dtype == MICF_DTYPE_BF16) hipLaunchKernelGGL((conv3_wgradx_kernel<16, true>), grid, dim3(256), sizeof(float) * (HALO * wXS + 64 * wDS), stream, a);
     else hipLaunchKernelGGL((conv3_wgradx_kernel<16, false>), grid, dim3(256), sizeof(float) * (HALO * wXS + 64 * wDS), stream, a);
   } else {
     constexpr int HALO = 3 * (8 + 2) * (8 + 2);
-    if (dtype == MICF_DTYPE_BF16) hipLaunchKernelGGL((conv3_wgradx_kernel<8, true>), grid, dim3(256), sizeof(float) * (HALO * wXS + 64 * wDS), stream, a);
+    static const bool old_b16 = [] { const char* e = getenv("MICF_WGX_OLD"); return e && e[0] == '1'; }();
+    if (dtype == MICF_DTYPE_BF16 && !old_b16) hipLaunchKernelGGL((conv3_wgradx_b16_kernel<8>), grid, dim3(256), HALO * wRSB + 64 * wDYB, stream, a);
+    else if (dtype == MICF_DTYPE_BF16) hipLaunchKernelGGL((conv3_wgradx_kernel<8, true>), grid, dim3(256), sizeof(float) * (HALO * wXS + 64 * wDS), stream, a);
     else hipLaunchKernelGGL((conv3_wgradx_kernel<8, false>), grid, dim3(256), sizeof(float) * (HALO * wXS + 64 * wDS), stream, a);
   }
   if (hipGetLastError() != hipSuccess) return MICF_ELAUNCH;

@@ -11,7 +11,7 @@ python bench.py --dtype fp32 --no-cpu-baseline > $OUT/${R}_bench_fp32.json 2>> $
 # parameter-gradient side work is hidden (functional.StepSegmenter; MICF_SEG_SKIP_SIDE computes WRONG updates: a timing probe only)
 {
   echo "# ms per step, base / 128^3 / batch 2 / bf16, one MI355X (python bench.py --segmented --no-roofline --no-cpu-baseline --steps 30)"
-  for v in "" "MICF_SEG_SERIAL=1"; do
+  for v in "" "MICF_SEG_SERIAL=1" "MICF_SEG_SKIP_SIDE=1"; do
     ms=$(env $v python bench.py --segmented --no-cpu-baseline --no-roofline --steps 30 2>>$OUT/bench.err | python -c "import json,sys; print(json.loads(sys.stdin.read())['ms_per_step'])")
     echo "segmented ${v:-(main chain + side batches on two streams)}: $ms"
   done

@@ -38,6 +38,7 @@ __global__ void __launch_bounds__(256) tail_compose_kernel(const float* __restri
       for (int pw = max(fw - 2, 0); pw <= min(fw, P - 1); ++pw) {
         const int t = ((pd + 2 - fd) * 3 + (ph + 2 - fh)) * 3 + (pw + 2 - fw);
         const int p = (pd * P + ph) * P + pw;
+#pragma unroll 8
         for (int c = 0; c < Cm; ++c) {
           // (w_up_t = w_up as [Cm * P^3][Ci]: the lanes of a wave are consecutive k -> one coalesced load instead of 64 lines)
           const float wu = (k < Ci) ? (w_up_t ? w_up_t[((int64_t)c * P3 + p) * Ci + k] : w_up[((int64_t)k * Cm + c) * P3 + p]) : b_up[c];
@@ -201,6 +202,18 @@ __global__ void __launch_bounds__(256) tail_dwup_kernel(const float* __restrict_
   const int p = (int)(id / ((int64_t)(Ci + 1) * Cm));
   const int pw = p % P, ph = (p / P) % P, pd = p / (P * P);
   float acc = 0.f;
+  if (Co == 8) {                                  // (the model's head: 8 independent loads per tap in flight, three taps unrolled)
+#pragma unroll 3
+    for (int t = 0; t < 27; ++t) {
+      const int tw = t % 3, th = (t / 3) % 3, td = t / 9;
+      const int64_t row0 = (((int64_t)(pd - td + 2) * F + (ph - th + 2)) * F + (pw - tw + 2)) * 8;
+      float g[8];
+#pragma unroll
+      for (int o = 0; o < 8; ++o) g[o] = (k < Ci) ? dwb[(row0 + o) * Ci + k] : dbf[row0 + o];
+#pragma unroll
+      for (int o = 0; o < 8; ++o) acc += g[o] * w_out[((int64_t)o * Cm + c) * 27 + t];
+    }
+  } else
   for (int t = 0; t < 27; ++t) {
     const int tw = t % 3, th = (t / 3) % 3, td = t / 9;
     const int64_t row0 = (((int64_t)(pd - td + 2) * F + (ph - th + 2)) * F + (pw - tw + 2)) * Co;
@@ -248,6 +261,60 @@ __global__ void __launch_bounds__(256) tail_dwout_kernel(const float* __restrict
     acc = wave_sum(acc);
     if (lane == 0) db_out[o] += acc;
   }
+}
+
+// The same as a split-K GEMM: dW_out[(o, t), c] = sum over (p, k) of A[(o, t), (p, k)] B[(p, k), c], A = dWb gathered, B = W_up (k == Ci:
+// the dBf / b_up column).  Block = (patch voxel p, 32-wide k chunk): its 27 Co x 32 slice of A and Cm x 32 slice of B go through LDS
+// (each read from L2 ONCE per block: the wave-per-output form above re-reads them 24 / 216 times, 255 MB of 4-byte loads), every
+// thread accumulates ~20 of the 27 Co Cm outputs and adds them atomically.  db_out rides in the k-chunk-0 blocks.
+constexpr int kDwoK = 32, kDwoP = 8;
+__global__ void __launch_bounds__(256) tail_dwout_gemm_kernel(const float* __restrict__ dwb, const float* __restrict__ dbf,
+                                                              const float* __restrict__ w_up, const float* __restrict__ b_up,
+                                                              float* __restrict__ dw_out, float* __restrict__ db_out, int Ci,
+                                                              int Cm, int Co, int P, const float* __restrict__ w_up_t) {
+  // block = (group of kDwoP patch voxels, k chunk, class o): A = 27 rows (taps) x 32, B = Cm x 32 per patch voxel; a thread owns
+  // up to 3 of the 27 Cm outputs of its class across the group's voxels and adds them atomically once (32-way contention, not 256)
+  __shared__ float As[27 * (kDwoK + 1)];
+  __shared__ float Bs[64 * (kDwoK + 1)];
+  const int F = P + 2, P3 = P * P * P;
+  const int kc = blockIdx.y, k0 = kc * kDwoK, o = blockIdx.z;
+  float acc[3] = {0.f, 0.f, 0.f};
+  float bsum = 0.f;
+  for (int p = blockIdx.x * kDwoP; p < min(P3, (int)(blockIdx.x + 1) * kDwoP); ++p) {
+    const int pw = p % P, ph = (p / P) % P, pd = p / (P * P);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 27 * kDwoK; i += 256) {
+      const int t = i / kDwoK, kk = i % kDwoK, k = k0 + kk;
+      const int tw = t % 3, th = (t / 3) % 3, td = t / 9;
+      const int64_t row = (((int64_t)(pd - td + 2) * F + (ph - th + 2)) * F + (pw - tw + 2)) * Co + o;
+      As[t * (kDwoK + 1) + kk] = k < Ci ? dwb[row * Ci + k] : (k == Ci ? dbf[row] : 0.f);
+    }
+    for (int i = threadIdx.x; i < Cm * kDwoK; i += 256) {
+      const int c = i / kDwoK, kk = i % kDwoK, k = k0 + kk;
+      Bs[c * (kDwoK + 1) + kk] = k < Ci ? (w_up_t ? w_up_t[((int64_t)c * P3 + p) * Ci + k] : w_up[((int64_t)k * Cm + c) * P3 + p])
+                                        : (k == Ci ? b_up[c] : 0.f);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int j = threadIdx.x + 256 * u;
+      if (j < 27 * Cm) {
+        const float* ap = As + (j / Cm) * (kDwoK + 1);
+        const float* bp = Bs + (j % Cm) * (kDwoK + 1);
+        float a = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < kDwoK; ++kk) a += ap[kk] * bp[kk];
+        acc[u] += a;
+      }
+    }
+    if (kc == 0 && threadIdx.x == 0) bsum += dbf[((((int64_t)(pd + 1) * F + (ph + 1)) * F + (pw + 1))) * Co + o];
+  }
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    const int j = threadIdx.x + 256 * u;
+    if (j < 27 * Cm) atomicAdd(dw_out + ((int64_t)o * Cm + j % Cm) * 27 + j / Cm, acc[u]);
+  }
+  if (kc == 0 && threadIdx.x == 0) atomicAdd(db_out + o, bsum);
 }
 
 static bool dims_ok(int Ci, int Cm, int Co, int P) { return Ci > 0 && Cm > 0 && Co > 0 && Co <= 32 && P >= 2 && P <= 8; }
@@ -316,6 +383,11 @@ extern "C" int micf_head_tail_decompose(const float* dwb, const float* dbf, cons
   const int64_t n1 = (int64_t)(Ci + 1) * Cm * P * P * P;
   hipLaunchKernelGGL(tail_dwup_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, dwb, dbf, w_out, dw_up, db_up, Ci, Cm, Co, P);
   if (hipGetLastError() != hipSuccess) return MICF_ELAUNCH;
+  if (Cm <= 64 && 27 * Cm <= 3 * 256) {
+    hipLaunchKernelGGL(tail_dwout_gemm_kernel, dim3((P * P * P + kDwoP - 1) / kDwoP, (Ci + 1 + kDwoK - 1) / kDwoK, Co), dim3(256), 0, s,
+                       dwb, dbf, w_up, b_up, dw_out, db_out, Ci, Cm, Co, P, w_up_t);
+    MICF_RETURN_LAUNCH();
+  }
   const int64_t n2 = (int64_t)Co * Cm * 27 + Co;
   hipLaunchKernelGGL(tail_dwout_kernel, dim3((unsigned)((n2 + 3) / 4)), dim3(256), 0, s, dwb, dbf, w_up, b_up, dw_out, db_out, Ci, Cm, Co, P, w_up_t);
   MICF_RETURN_LAUNCH();

@@ -23,12 +23,15 @@ for graphed in (False, True):
     for sw in (1, 3, 7):
         pred = GraphedPredictor(model) if graphed else model
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
-            sliding_window_inference(x[:, :, :256, :256, :128], (128, 128, 128), sw, pred, autocast=AUTOCAST)   # warm-up (and graph capture)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            out = sliding_window_inference(x, (128, 128, 128), sw, pred, overlap=0.5, autocast=AUTOCAST)
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
+            # warm-up on the SAME volume and overlap (graph capture incl. the volume accumulators it bakes in), then the better of two runs
+            sliding_window_inference(x, (128, 128, 128), sw, pred, overlap=0.5, autocast=AUTOCAST)
+            dt = 1e9
+            for _ in range(2):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                out = sliding_window_inference(x, (128, 128, 128), sw, pred, overlap=0.5, autocast=AUTOCAST)
+                torch.cuda.synchronize()
+                dt = min(dt, time.perf_counter() - t0)
         res[f"{'graph' if graphed else 'eager'}_sw_batch_{sw}"] = {"s_per_volume": round(dt, 3), "windows_per_s": round(nwin / dt, 1)}
 print(json.dumps({"workload": f"sliding-window inference, MicFormer base, volume {dims}, roi 128^3, overlap 0.5, {nwin} windows, {'bf16 mode' if AUTOCAST else 'fp32 kernels'}",
                   "results": res, "checksum": float(out.double().mean())}))

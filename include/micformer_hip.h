@@ -112,7 +112,8 @@ typedef struct micf_wgrad_item {
   int32_t K;
   int32_t operand_dtype;   /* MICF_DTYPE_F32: a / dy are fp32; MICF_DTYPE_BF16: both were STORED as bfloat16 (what the fused block
                               kernels leave in bf16 mode); then M % 32 == 0, N % 8 == 0, K % 8 == 0, rows_per_sample % 32 == 0 */
-  int32_t reserved;
+  int32_t ldw;             /* row stride of dw in floats when dw is a column block of a wider matrix (a layer applied to a
+                              concatenation [a1 | a2]: one item per part); 0 = K.  ldw >= K, ldw % 4 == 0 */
 } micf_wgrad_item;
 int micf_linear_bwd_weight_grouped(const micf_wgrad_item* items, int n, float* workspace, int64_t workspace_floats,
                                    int dtype, micf_stream_t stream);

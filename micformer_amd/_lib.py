@@ -127,7 +127,7 @@ class WgradItem(ctypes.Structure):
     """struct micf_wgrad_item (include/micformer_hip.h)."""
     _fields_ = [("a", ctypes.c_void_p), ("dy", ctypes.c_void_p), ("dp_scale", ctypes.c_void_p), ("dw", ctypes.c_void_p),
                 ("dbias", ctypes.c_void_p), ("M", ctypes.c_int64), ("rows_per_sample", ctypes.c_int64),
-                ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("operand_dtype", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("operand_dtype", ctypes.c_int32), ("ldw", ctypes.c_int32)]
 
 
 class Conv3WgradItem(ctypes.Structure):

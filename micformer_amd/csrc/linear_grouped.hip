@@ -20,6 +20,7 @@ struct GItem {
   const float* a; const float* dy; const float* scale; float* out; float* dbias; float* dw;     // (a / dy: bf16 in the *_b16 kernel)
   int M, N, K, rps;
   int tiles_i, tiles, splits, direct;
+  int ldw, pad_;                       // row stride of dw in floats (>= K: a column block of a wider weight matrix)
   int64_t split_stride;
 };
 struct GArgs {
@@ -79,11 +80,12 @@ __global__ void __launch_bounds__(256) wgrad_grouped_kernel(const GArgs g) {
   const int j = j0 + 4 * li + wave;
   if (j >= it.N) return;
   float* base = it.direct ? it.dw : it.out + (int64_t)split * it.split_stride;
+  const int ld = it.direct ? it.ldw : it.K;
 #pragma unroll
   for (int v = 0; v < 4; ++v) {
     const int i = i0 + 16 * lr + 4 * v;
     if (i >= it.K) continue;
-    float* p = base + (int64_t)j * it.K + i;
+    float* p = base + (int64_t)j * ld + i;
     float4 o = make_float4(tot[0][v], tot[1][v], tot[2][v], tot[3][v]);
     if (i + 4 <= it.K) {
       if (it.direct) { const float4 old = *reinterpret_cast<const float4*>(p); o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
@@ -216,11 +218,12 @@ __global__ void __launch_bounds__(256) wgrad_grouped_b16_kernel(const GArgs g) {
   }
   if (j >= it.N) return;
   float* base = it.direct ? it.dw : it.out + (int64_t)split * it.split_stride;
+  const int ld = it.direct ? it.ldw : it.K;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int i = i0 + 16 * q + 4 * lr;
     if (i >= it.K) continue;
-    float* p = base + (int64_t)j * it.K + i;          // (K % 8 == 0: whole float4)
+    float* p = base + (int64_t)j * ld + i;            // (K % 8 == 0: whole float4)
     float4 o = make_float4(tot[q][0], tot[q][1], tot[q][2], tot[q][3]);
     if (it.direct) { const float4 old = *reinterpret_cast<const float4*>(p); o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
     *reinterpret_cast<float4*>(p) = o;
@@ -237,7 +240,8 @@ __global__ void __launch_bounds__(256) wgrad_grouped_reduce_kernel(const GArgs g
   const int64_t n4 = (int64_t)it.N * it.K / 4;
   const int64_t e = (int64_t)local * 256 + threadIdx.x;
   if (e >= n4) return;
-  float4 acc = *reinterpret_cast<const float4*>(it.dw + 4 * e);
+  float* dst = it.dw + ((4 * e) / it.K) * (int64_t)it.ldw + (4 * e) % it.K;      // (K % 4 == 0: a float4 never straddles rows)
+  float4 acc = *reinterpret_cast<const float4*>(dst);
   int s = 0;
   for (; s + 4 <= it.splits; s += 4) {
     float4 v[4];
@@ -250,7 +254,7 @@ __global__ void __launch_bounds__(256) wgrad_grouped_reduce_kernel(const GArgs g
     const float4 v = *reinterpret_cast<const float4*>(it.out + s * it.split_stride + 4 * e);
     acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
   }
-  *reinterpret_cast<float4*>(it.dw + 4 * e) = acc;
+  *reinterpret_cast<float4*>(dst) = acc;
 }
 
 static bool item_ok(const micf_wgrad_item& x) {
@@ -260,6 +264,7 @@ static bool item_ok(const micf_wgrad_item& x) {
     if (x.dp_scale && x.rows_per_sample % 32) return false;
   }
   if (!x.a || !x.dy || !x.dw || x.M <= 0 || x.N < 4 || x.K < 4) return false;
+  if (x.ldw != 0 && (x.ldw < x.K || x.ldw % 4)) return false;
   if (x.M % kDmaBR || x.M >= (1LL << 30) || x.N % 4 || x.K % 4) return false;
   if ((reinterpret_cast<uintptr_t>(x.a) | reinterpret_cast<uintptr_t>(x.dy) | reinterpret_cast<uintptr_t>(x.dw)) & 15) return false;
   if (x.dp_scale && (x.rows_per_sample <= 0 || x.rows_per_sample % kDmaBR || x.M % x.rows_per_sample)) return false;
@@ -307,6 +312,7 @@ extern "C" int micf_linear_bwd_weight_grouped(const micf_wgrad_item* items, int 
         GItem& d = g.it[q];
         d.a = x.a; d.dy = x.dy; d.scale = x.dp_scale; d.dbias = x.dbias; d.dw = x.dw;
         d.M = (int)x.M; d.N = x.N; d.K = x.K; d.rps = x.dp_scale ? (int)x.rows_per_sample : (int)x.M;
+        d.ldw = x.ldw > 0 ? x.ldw : x.K; d.pad_ = 0;
         d.tiles_i = ceil_div(x.K, 64);
         d.tiles = d.tiles_i * ceil_div(x.N, 64);
         d.splits = item_splits(x);

@@ -512,8 +512,15 @@ class LinearFn(torch.autograd.Function):
         a2f = a2.reshape(-1, a2.shape[-1]) if a2 is not None else None
         dw = _grad_buf(ctx.tg[0], w)
         db = (ctx.tg[1] if ctx.tg[1] is not None else torch.zeros(w.shape[0], dtype=w.dtype, device=w.device)) if ctx.has_bias else None
-        _defer(ctx.tg[0] is not None and (ctx.tg[1] is not None or not ctx.has_bias),
-               lambda: ops.linear_bwd_weight(dy, af, dw, db, a2f), dy, af, a2f)
+        engine = ctx.tg[0] is not None and (ctx.tg[1] is not None or not ctx.has_bias)
+        if a2f is not None and engine and DEFER_WGRAD and k1 % 4 == 0 and a2f.shape[1] % 4 == 0 and (k1 * 4) % 16 == 0 \
+                and dy.shape[0] <= DEFER_MAX_TOKENS and ops.wgrad_groupable(dy, af) and ops.wgrad_groupable(dy, a2f) \
+                and dw.data_ptr() not in _QUEUED_DW:
+            # a layer on a concatenation [a | a2]: two items of the grouped launch, each a column block of dw (row stride K)
+            _lin_wgrad(True, dy, af, dw[:, :k1], db)
+            _lin_wgrad(True, dy, a2f, dw[:, k1:], None)
+        else:
+            _defer(engine, lambda: ops.linear_bwd_weight(dy, af, dw, db, a2f), dy, af, a2f)
         r = ops.linear_bwd_data(dy, w, k1=k1)
         rdw, rdb = _ret(ctx.tg[0], dw), _ret(ctx.tg[1], db)     # (new names: the deferred closure above still reads dw / db)
         if a2 is None:

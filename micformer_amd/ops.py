@@ -234,9 +234,14 @@ class GroupedWgradPlan:
             K = a.shape[1]
             if dy.dtype != a.dtype or dy.dtype not in (torch.float32, torch.bfloat16):
                 raise _lib.MicfError("grouped weight gradient: both operands must be float32 or both bfloat16")
-            it.a, it.dy, it.dp_scale, it.dw, it.dbias = ptr(a), ptr(dy), f32(sc), f32(dw), f32(db)
+            if dw.dtype != torch.float32 or not dw.is_cuda:
+                raise _lib.MicfError("grouped weight gradient: dw must be a float32 device tensor")
+            it.a, it.dy, it.dp_scale, it.dw, it.dbias = ptr(a), ptr(dy), f32(sc), dw.data_ptr(), f32(db)
             it.M, it.rows_per_sample, it.N, it.K = M, int(rps) if sc is not None else 0, N, K
             it.operand_dtype = 1 if dy.dtype == torch.bfloat16 else 0
+            if dw.dim() != 2 or dw.stride(1) != 1 or dw.shape != (N, K):
+                raise _lib.MicfError("grouped weight gradient: dw must be an [N, K] (column block of a) row-major matrix")
+            it.ldw = 0 if dw.stride(0) == K else dw.stride(0)
             self.flops[k] = 2 * M * N * K
             self.nbytes[k] = dy.element_size() * (dy.numel() + a.numel()) + 8 * dw.numel()
         self.device = self.items[0][0].device if n else None

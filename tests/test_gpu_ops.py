@@ -767,3 +767,18 @@ def test_conv3_prepared_layouts_give_the_same_result(C, mode):
     tol = 0 if mode == "bf16" else 0            # same kernels, same operands: only the atomic accumulation order may differ
     assert float((y1 - y0).abs().max()) <= 1e-5 * float(y0.abs().max())
     assert torch.equal(d1[0], d0[0]) and torch.equal(d1[1], d0[1])
+
+
+def test_grouped_wgrad_column_blocks(ops):
+    """micf_wgrad_item.ldw: a layer on a concatenation [a1 | a2] as two grouped items, each a column block of one dw (long layers:
+    split + reduce through the workspace; short ones: direct) == the two-input micf_linear_bwd_weight, accumulated."""
+    for M in (4096, 512):
+        N, k1, k2 = 48, 96, 32
+        dy, a1, a2 = dev(rnd(M, N, seed=1)), dev(rnd(M, k1, seed=2)), dev(rnd(M, k2, seed=3))
+        w0, b0 = rnd(N, k1 + k2, seed=4), rnd(N, seed=5)
+        dw_ref, db_ref = dev(w0.clone()), dev(b0.clone())
+        ops.linear_bwd_weight(dy, a1, dw_ref, db_ref, a2)
+        dw, db = dev(w0.clone()), dev(b0.clone())
+        ops.linear_bwd_weight_grouped([(dy, a1, dw[:, :k1], db, None, 0), (dy, a2, dw[:, k1:], None, None, 0)])
+        close(dw, dw_ref.cpu(), rtol=2e-5, what=f"column-block dw M={M}")
+        close(db, db_ref.cpu(), rtol=2e-5, what=f"column-block db M={M}")

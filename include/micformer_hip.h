@@ -427,6 +427,15 @@ int micf_offset_head_bwd(const micf_offset_head_bwd_group* groups, int ngroups, 
 int micf_offset_head_finish_deferrable(int B, int D, int H, int W);
 int micf_offset_head_bwd_finish(const micf_offset_head_bwd_group* groups, int ngroups, int B, int D, int H, int W, int C,
                                 float* workspace, int64_t workspace_floats, micf_stream_t stream);
+/* ... of up to 16 deferring calls (any mix of grids and layers) as ONE launch; `calls` and the group arrays it points to are HOST
+ * memory read during the call only. */
+typedef struct micf_offset_head_finish_call {
+  const micf_offset_head_bwd_group* groups;   /* as passed to the deferring micf_offset_head_bwd */
+  int32_t ngroups, B, D, H, W, C;
+  float* workspace;                            /* the workspace of that call */
+  int64_t workspace_floats;
+} micf_offset_head_finish_call;
+int micf_offset_head_bwd_finish_grouped(const micf_offset_head_finish_call* calls, int ncalls, micf_stream_t stream);
 
 /* ---- Fused window-local transformer block (csrc/block_fwd.hip, block_bwd.hip): everything of a TransformerBlock3D
  * (MS.py:430-524), and everything of a CrossTransformerBlock3D (MS.py:277-426) downstream of the deformable sampling, in ONE

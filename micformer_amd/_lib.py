@@ -73,6 +73,7 @@ SIGNATURES = {
     "micf_offset_head_bwd": "piiiiiifipliip",
     "micf_offset_head_finish_deferrable": "iiii",
     "micf_offset_head_bwd_finish": "piiiiiiplp",
+    "micf_offset_head_bwd_finish_grouped": "pip",
     "micf_conv3_bwd_data_workspace": "iii",
     "micf_conv3_bwd_weight": "pipipippiiiiiplip",
     "micf_conv3_bwd_weight_workspace": "iiiiiii",
@@ -187,6 +188,12 @@ class OffsetHeadBwdGroup(ctypes.Structure):
     """struct micf_offset_head_bwd_group (include/micformer_hip.h)."""
     FIELDS = ("dxs", "hid", "flow", "xa", "ln_g", "ln_b", "w1", "conv_w", "conv_ws", "dxa", "dxn", "dhid", "dln_g", "dln_b", "dw1")
     _fields_ = [(n, _VP) for n in FIELDS]
+
+
+class OffsetHeadFinishCall(ctypes.Structure):
+    """struct micf_offset_head_finish_call (include/micformer_hip.h)."""
+    _fields_ = [("groups", _VP), ("ngroups", ctypes.c_int32), ("B", ctypes.c_int32), ("D", ctypes.c_int32), ("H", ctypes.c_int32),
+                ("W", ctypes.c_int32), ("C", ctypes.c_int32), ("workspace", _VP), ("workspace_floats", ctypes.c_int64)]
 
 
 class Conv3PrepItem(ctypes.Structure):

@@ -59,6 +59,8 @@ struct SampleBwdSet {
 int offset_sample_fwd_groups(const SampleFwdSet* sets, int n, int B, int D, int H, int W, int C, float eps, hipStream_t stream);
 int offset_sample_bwd_groups(SampleBwdSet* sets, int n, int B, int D, int H, int W, int C, float eps, float* workspace,
                              int64_t workspace_floats, hipStream_t s, int phase = 0);
+struct SampleFinishCall { const SampleBwdSet* sets; int n, B, D, H, W, C; float* workspace; int64_t workspace_floats; };
+int offset_sample_finish_many(const SampleFinishCall* calls, int ncalls, hipStream_t s);
 
 // pointer sets of the grouped (two modalities per launch) forms
 struct Conv3FwdSet { const float* x1; const float* x2; const float* w; const float* bias; float* y; float* wt; };

@@ -69,6 +69,22 @@ extern "C" int micf_offset_head_bwd_finish(const micf_offset_head_bwd_group* gro
   return offset_sample_bwd_groups(ss, ngroups, B, D, H, W, C, 0.f, workspace, workspace_floats, (hipStream_t)stream, 2);
 }
 
+// The finishing launches of several deferring micf_offset_head_bwd calls (any mix of grids) as ONE launch.
+extern "C" int micf_offset_head_bwd_finish_grouped(const micf_offset_head_finish_call* calls, int ncalls, micf_stream_t stream) {
+  constexpr int kMax = 16;
+  if (!calls || ncalls < 1 || ncalls > kMax) return MICF_EINVAL;
+  SampleBwdSet ss[kMax][2];
+  SampleFinishCall fc[kMax];
+  for (int c = 0; c < ncalls; ++c) {
+    const micf_offset_head_finish_call& q = calls[c];
+    if (!q.groups || q.ngroups < 1 || q.ngroups > 2 || !micf_offset_head_finish_deferrable(q.B, q.D, q.H, q.W)) return MICF_EINVAL;
+    const int rc = head_bwd_sets(q.groups, q.ngroups, ss[c]);
+    if (rc != MICF_OK) return rc;
+    fc[c] = SampleFinishCall{ss[c], q.ngroups, q.B, q.D, q.H, q.W, q.C, q.workspace, q.workspace_floats};
+  }
+  return offset_sample_finish_many(fc, ncalls, (hipStream_t)stream);
+}
+
 extern "C" int micf_offset_head_bwd(const micf_offset_head_bwd_group* groups, int ngroups, int B, int D, int H, int W, int C,
                                     float eps, int prepared, float* workspace, int64_t workspace_floats, int dtype,
                                     int defer_finish, micf_stream_t stream) {

@@ -435,6 +435,15 @@ __global__ void __launch_bounds__(256) sample_finish_kernel(const SampleBwdSets 
   sample_finish_body(q.dxs, q.flow, q.dxa, g, C, q.cl, q.partials, nwaves, q.dw1, q.dln_g, q.dln_b);
 }
 
+// The finishing sums of SEVERAL deferred backward calls (different grids / layers) in ONE launch: blockIdx.y = set.
+constexpr int kFinishMany = 32;
+struct FinishSets { const float* partials[kFinishMany]; float* dw1[kFinishMany]; float* dln_g[kFinishMany]; float* dln_b[kFinishMany]; int nwaves[kFinishMany]; };
+__global__ void __launch_bounds__(256) sample_finish_many_kernel(const FinishSets f, const Geo unit) {
+  const int k = blockIdx.y;
+  const CellLists none{nullptr, nullptr, nullptr, nullptr, 0, nullptr};
+  sample_finish_body(nullptr, nullptr, nullptr, unit, 0, none, f.partials[k], f.nwaves[k], f.dw1[k], f.dln_g[k], f.dln_b[k]);
+}
+
 // ---- standalone SpatialTransformer (STN.py:9-32) on channels-last src with a GIVEN flow [T,3] (voxel units, z,y,x)
 __global__ void __launch_bounds__(256) stn_fwd_kernel(const float* __restrict__ src, const float* __restrict__ flow,
                                                       float* __restrict__ out, Geo g, int C) {
@@ -669,5 +678,39 @@ extern "C" int micf_stn_bwd(const float* dout, const float* src, const float* fl
   if (g.tokens() >= (1LL << 31)) return MICF_EUNSUPPORTED;
   hipLaunchKernelGGL(stn_bwd_kernel, dim3(ceil_div(g.tokens(), 4)), dim3(256), 0, (hipStream_t)stream, dout, src, flow, dsrc,
                      dflow, g, C);
+  MICF_RETURN_LAUNCH();
+}
+
+// calls[i]: the (sets, n, grid, workspace) of a backward call that ran with phase 1; everything of phase 2 in one launch
+int micf::offset_sample_finish_many(const SampleFinishCall* calls, int ncalls, hipStream_t s) {
+  if (!calls || ncalls < 1) return MICF_EINVAL;
+  FinishSets f;
+  int total = 0;
+  for (int c = 0; c < ncalls; ++c) {
+    const SampleFinishCall& q = calls[c];
+    if (!q.sets || q.n < 1 || q.n > 2 || q.B <= 0 || q.D <= 0 || q.H <= 0 || q.W <= 0) return MICF_EINVAL;
+    const Geo g{q.B, q.D, q.H, q.W};
+    const int64_t T = g.tokens();
+    const int64_t per = micf_offset_sample_bwd_workspace(q.B, q.D, q.H, q.W);
+    if (!q.workspace || q.workspace_floats < per * q.n || !aligned16(q.workspace) || use_cells(T)) return MICF_EINVAL;
+    bool al = true;
+    for (int i = 0; i < q.n; ++i) al = al && aligned16(q.sets[i].dxs) && aligned16(q.sets[i].xa) && aligned16(q.sets[i].dxa);
+    const bool quad = T >= 4096 && (q.C % 4 == 0) && al;         // (the launch shape of the phase-1 call: same formula)
+    const int tpw = quad ? quads_per_wave(T) : tok_per_wave(T);
+    const int wpb = quad ? quad_waves_per_block(T) : 4;
+    const int blocks = ceil_div(T, (quad ? 4 * wpb : 4) * tpw);
+    for (int i = 0; i < q.n; ++i) {
+      if (total == kFinishMany) {
+        hipLaunchKernelGGL(sample_finish_many_kernel, dim3(5 * kHid, total), dim3(256), 0, s, f, Geo{1, 1, 1, 1});
+        if (hipGetLastError() != hipSuccess) return MICF_ELAUNCH;
+        total = 0;
+      }
+      f.partials[total] = q.workspace + i * partial_floats(T);
+      f.dw1[total] = q.sets[i].dw1; f.dln_g[total] = q.sets[i].dln_g; f.dln_b[total] = q.sets[i].dln_b;
+      f.nwaves[total] = blocks * wpb;
+      ++total;
+    }
+  }
+  hipLaunchKernelGGL(sample_finish_many_kernel, dim3(5 * kHid, total), dim3(256), 0, s, f, Geo{1, 1, 1, 1});
   MICF_RETURN_LAUNCH();
 }

@@ -368,8 +368,12 @@ def _launch_batch(items, ln, calls):
             ops.layernorm_bwd_finish(ln)
         if items:
             ops.linear_bwd_weight_grouped(items)
-    convs = {}
+    convs, finishes = {}, []
     for fn, _, blk in calls:
+        fz = getattr(fn, "finish", None) if GROUP_CONV_WGRAD else None
+        if fz is not None:
+            finishes.append(fz)
+            continue
         cv = getattr(fn, "conv", None) if GROUP_CONV_WGRAD else None
         if cv is not None:
             key = (cv[5], cv[1].shape, None if cv[2] is None else cv[2].shape, cv[3].shape, cv[4] is None)
@@ -382,6 +386,9 @@ def _launch_batch(items, ln, calls):
                 fn()
         else:
             fn()
+    if finishes:
+        with block_region():
+            ops.offset_head_bwd_finish_grouped(finishes)
     for grp in convs.values():
         with block_region():
             ops.conv3_bwd_weight_grouped([(dy, x1, x2, dw, db) for dy, x1, x2, dw, db, _ in grp], grp[0][5])
@@ -1030,7 +1037,10 @@ class CrossPairFn(torch.autograd.Function):
                 defer_ws = torch.empty(ops.offset_head_bwd_workspace(2, dims), dtype=torch.float32, device=xs[0].device)
             dhids = ops.offset_head_bwd(hgroups, dims, eps, defer_ws=defer_ws)
             if defer_ws is not None:
-                _defer(True, lambda: ops.offset_head_bwd_finish(hgroups, dhids, dims, defer_ws), defer_ws, *dhids)
+                def fin():
+                    ops.offset_head_bwd_finish(hgroups, dhids, dims, defer_ws)
+                fin.finish = (hgroups, dhids, tuple(dims), defer_ws)        # (the flush groups these into one launch)
+                _defer(True, fin, defer_ws, *dhids)
             for i in (0, 1):
                 _conv_offset_wgrad(sides[i], dhids[i], hds[i][0], xs[1 - i], Gs[i], dims)
         else:

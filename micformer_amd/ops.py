@@ -486,6 +486,23 @@ def offset_head_bwd_finish(groups, dhids, dims, ws):
     call("micf_offset_head_bwd_finish", ctypes.cast(arr, ctypes.c_void_p), len(groups), B, D, H, W, C, f32(ws), ws.numel())
 
 
+def offset_head_bwd_finish_grouped(calls):
+    """calls: [(groups, dhids, dims, ws)] of deferring offset_head_bwd calls (any mix of grids): their finishing launches as one."""
+    for first in range(0, len(calls), 16):
+        part = calls[first:first + 16]
+        arr = (_lib.OffsetHeadFinishCall * len(part))()
+        keep = []
+        for it, (groups, dhids, dims, ws) in zip(arr, part):
+            ga = _head_bwd_array(groups, dhids)
+            keep.append(ga)
+            it.groups = ctypes.cast(ga, ctypes.c_void_p)
+            it.ngroups = len(groups)
+            it.B, it.D, it.H, it.W = dims
+            it.C = groups[0]["xa"].shape[1]
+            it.workspace, it.workspace_floats = f32(ws), ws.numel()
+        call("micf_offset_head_bwd_finish_grouped", ctypes.addressof(arr), len(part))
+
+
 def offset_head_bwd(groups, dims, eps, defer_ws=None):
     """groups: 1 or 2 dicts {dxs, hid, flow, xa, P, G, dxa (accumulated), dxn (accumulated)}.  Sampler adjoint(s) + conv data
     gradient(s) in one call; returns the dhid [T,16] of every group (operand of the conv weight gradient).

@@ -419,7 +419,8 @@ int micf_offset_head_needs_zero(int B, int D, int H, int W, int C);
 int micf_offset_head_fwd(const micf_offset_head_group* groups, int ngroups, int B, int D, int H, int W, int C, float eps,
                          int prepared, int hid_zeroed, int dtype, micf_stream_t stream);
 int64_t micf_offset_head_bwd_workspace(int ngroups, int B, int D, int H, int W);
-/* defer_finish != 0 on a grid where micf_offset_head_finish_deferrable(...) != 0 (small grids: no cell lists): the launch that
+/* defer_finish != 0 on a grid where micf_offset_head_finish_deferrable(...) != 0 (every grid since the backward kernel scatters
+ * cell-list overflow itself; the predicate stays in the ABI): the launch that
  * sums the head-parameter partials into dw1 / dln_g / dln_b is left out -- nothing on the data path waits for it -- and the
  * caller issues it later with micf_offset_head_bwd_finish on the SAME workspace (which must stay untouched until then). */
 int micf_offset_head_bwd(const micf_offset_head_bwd_group* groups, int ngroups, int B, int D, int H, int W, int C, float eps,

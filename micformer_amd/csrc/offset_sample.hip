@@ -262,12 +262,31 @@ __device__ __forceinline__ void offset_sample_bwd4_body(
         gz += (dz ? val : -val) * wx[q] * wy[q];
       }
     }
-    if (!SCATTER && live && k == 0) {
-      const int cell = cell_of(tp, b, g.D, g.H, g.W);
-      if (cell >= 0) {
-        const int slot = atomicAdd(cl.count + cell, 1);
-        if (slot < cl.cap) cl.list[(int64_t)cell * kCellCap + slot] = (int)t;
-        else cl.ovf[atomicAdd(cl.ovf_count, 1)] = (int)t;
+    if (!SCATTER) {
+      // a token whose cell list is full (normally none) scatters its d(xa) contributions atomically right here -- before the gather
+      // launch reads / writes d(xa), so the finishing launch has no overflow pass left and only sums head-parameter partials
+      int ovf = 0;
+      if (live && k == 0) {
+        const int cell = cell_of(tp, b, g.D, g.H, g.W);
+        if (cell >= 0) {
+          const int slot = atomicAdd(cl.count + cell, 1);
+          if (slot < cl.cap) cl.list[(int64_t)cell * kCellCap + slot] = (int)t;
+          else ovf = 1;
+        }
+      }
+      ovf = __shfl(ovf, lane & 48, 64);
+      if (ovf) {
+        for (int c = 4 * k; c < C; c += 64) {
+          const float4 go = ld4(dxs + t * C + c);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            if (!ok[q]) continue;
+            const int64_t a = boff + (int64_t)lin[q] * C + c;
+            const float wq = wx[q] * wy[q] * wz[q];
+            atomicAdd(dxa + a, wq * go.x); atomicAdd(dxa + a + 1, wq * go.y);
+            atomicAdd(dxa + a + 2, wq * go.z); atomicAdd(dxa + a + 3, wq * go.w);
+          }
+        }
       }
     }
     if (!SCATTER && live && k < 8 && cl.w8) {           // lane k < 8: the weight of corner k (dz, dy, dx = bits of k)
@@ -621,7 +640,7 @@ int micf::offset_sample_bwd_groups(SampleBwdSet* sets, int n, int B, int D, int 
     }
   }
   if (phase == 2) {
-    if (!have_ws || cells) return MICF_EINVAL;
+    if (!have_ws) return MICF_EINVAL;
     hipLaunchKernelGGL(sample_finish_kernel, dim3(5 * kHid, n), dim3(256), 0, s, p, g, C, nwaves);
     MICF_RETURN_LAUNCH();
   }
@@ -642,16 +661,16 @@ int micf::offset_sample_bwd_groups(SampleBwdSet* sets, int n, int B, int D, int 
     hipLaunchKernelGGL(sample_gather_kernel, dim3((unsigned)((threads + 255) / 256), n), dim3(256), 0, s, p, g, C);
     if (hipGetLastError() != hipSuccess) return MICF_ELAUNCH;
   }
-  if (phase == 1 && !cells) return MICF_OK;          // the caller finishes later (micf_offset_head_bwd_finish)
+  if (phase == 1) return MICF_OK;                    // the caller finishes later (micf_offset_head_bwd_finish[_grouped])
   hipLaunchKernelGGL(sample_finish_kernel, dim3(5 * kHid, n), dim3(256), 0, s, p, g, C, nwaves);
   MICF_RETURN_LAUNCH();
 }
 
-// 1 when a sampler backward at this grid leaves only head-parameter partial sums to its finishing launch (no cell lists, no
-// overflow pass): that launch may then run anywhere later on a stream ordered after the call, given the same workspace
+// 1 when a sampler backward at this grid leaves only head-parameter partial sums to its finishing launch: that launch may then run
+// anywhere later on a stream ordered after the call, given the same workspace.  (Every grid since cell-list overflow is scattered
+// by the backward kernel itself.)
 extern "C" int micf_offset_head_finish_deferrable(int B, int D, int H, int W) {
-  if (B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
-  return use_cells((int64_t)B * D * H * W) ? 0 : 1;
+  return (B <= 0 || D <= 0 || H <= 0 || W <= 0) ? 0 : 1;
 }
 
 extern "C" int micf_offset_sample_bwd(const float* dxs, const float* h, const float* ln_g, const float* ln_b,
@@ -692,7 +711,7 @@ int micf::offset_sample_finish_many(const SampleFinishCall* calls, int ncalls, h
     const Geo g{q.B, q.D, q.H, q.W};
     const int64_t T = g.tokens();
     const int64_t per = micf_offset_sample_bwd_workspace(q.B, q.D, q.H, q.W);
-    if (!q.workspace || q.workspace_floats < per * q.n || !aligned16(q.workspace) || use_cells(T)) return MICF_EINVAL;
+    if (!q.workspace || q.workspace_floats < per * q.n || !aligned16(q.workspace)) return MICF_EINVAL;
     bool al = true;
     for (int i = 0; i < q.n; ++i) al = al && aligned16(q.sets[i].dxs) && aligned16(q.sets[i].xa) && aligned16(q.sets[i].dxa);
     const bool quad = T >= 4096 && (q.C % 4 == 0) && al;         // (the launch shape of the phase-1 call: same formula)

@@ -197,6 +197,8 @@ def main(argv=None):
     ap.add_argument("--detail", action="store_true", help="roofline leg: key kernels by shape too (diagnostic)")
     ap.add_argument("--eval-mode", action="store_true", help="DropPath off (default: train mode, DropPath active)")
     ap.add_argument("--no-flush-points", action="store_true", help="launch all queued weight gradients after backward")
+    ap.add_argument("--split-step", action="store_true", help="single-GPU probe of the DATA-PARALLEL step layout (graph = forward + "
+                    "backward, grouped weight gradients + Adam outside it, no collective at world 1)")
     ap.add_argument("--cpu-stub", action="store_true", help="control-flow test on CPU/gloo with a stub engine (no kernels)")
     args = ap.parse_args(argv)
 
@@ -242,7 +244,7 @@ def main(argv=None):
         x, tgt = synthetic_batch(args.batch, vol, 8, dev, 1234 + rank)
         eng = TrainEngine(model, base_lr=1e-4, t_max=150, use_graph=not args.no_graph,
                           parallel_modalities=not args.serial_modalities, flush_points=not args.no_flush_points,
-                          segmented=args.segmented)
+                          segmented=args.segmented, **({"split_step": True} if args.split_step else {}))
 
     def barrier():
         if world > 1:

@@ -456,7 +456,9 @@ typedef struct micf_block_fwd_group {
   /* saved for backward / the deferred weight gradients, natural token order: */
   float *xn, *q, *kv, *o, *x1, *xn2; /* LN1(x) [T,C] (may be NULL: not written); q [T,C]; k|v [T,2C]; attention out [T,C]; x + s1*attn [T,C]; LN2(x1) [T,C] */
   void* h;             /* fc1 pre-activation [T, hidden]: float for MICF_DTYPE_F32, bf16 (uint16_t, round-to-nearest-even)
-                          for MICF_DTYPE_BF16 -- only micf_block_bwd reads it (GELU'), so the bf16 mode stores it at half width */
+                          for MICF_DTYPE_BF16 -- only micf_block_bwd reads it (GELU'), so the bf16 mode stores it at half width.
+                          NULL where micf_block_recomputes_h(C, heads) != 0: not written (8 of the 36 bytes a bf16 block writes per
+                          element of T*C); micf_block_bwd then rebuilds it from xn2 with one more GEMM phase */
   float* g;            /* GELU(h) [T, hidden] (operand of the fc2 weight gradient) */
   float* stats;        /* [4, T]: mean1, rstd1, mean2, rstd2 */
   void* kvs16;         /* cross, bf16 storage only (micf_block_saves_bf16): [T, C] bf16 copy of the K/V source, the operand of the kv
@@ -481,7 +483,8 @@ int micf_block_saves_bf16(int C, int heads, int dtype);
 typedef struct micf_block_bwd_group {
   const float* dy;     /* [T, C] gradient w.r.t. the block output (also fc2's output gradient for the weight-gradient GEMM) */
   const float *x, *x1, *stats, *q, *kv; /* as saved by micf_block_fwd (x and ln1_g may be NULL for a cross block) */
-  const void* h;       /* ... float or bf16 by dtype, as micf_block_fwd wrote it */
+  const void* h;       /* ... float or bf16 by dtype, as micf_block_fwd wrote it; NULL (micf_block_recomputes_h only) = rebuild it
+                          in the kernel as xn2 W1^T + b1 from the three fields at the end of this struct */
   const float *ln1_g, *ln2_g;
   const void *wqt, *wkvt, *wpt, *w1t, *w2t;  /* TRANSPOSED weights: q^T [C,C], kv^T [C,2C], proj^T [C,C], fc1^T [C,hidden],
                                                 fc2^T [hidden,C] from micf_weight_prep_grouped (dst_t), K16-blocked:
@@ -496,7 +499,14 @@ typedef struct micf_block_bwd_group {
   float* dx1_copy;     /* optional second copy of dx1 [T, C]: the buffer a cross PAIR then accumulates the other block's
                           K/V-source gradient and its own LN1 backward into (no zero fill, no separate add); always fp32 */
   void* dy16;          /* bf16 storage only: [T, C] bf16 copy of dy (operand of the fc2 weight gradient); NULL otherwise */
+  /* h == NULL: the fc1 pre-activation is recomputed (same MFMA order as the forward: bit-identical in fp32 mode) from */
+  const float* xn2;    /* LN2(x1) [T, C] as micf_block_fwd saved it (bf16 where micf_block_saves_bf16) */
+  const void* w1;      /* mlp.fc1.weight [hidden, C], the forward's K16-blocked shadow copy (micf_block_fwd_group.w1) */
+  const float* b1;     /* mlp.fc1.bias [hidden] */
 } micf_block_bwd_group;
+/* != 0: the tile-per-workgroup kernels (everything but the few-token decomposition at C = 384) accept h == NULL in both groups
+ * structs (see there).  MICF_BLOCK_SAVE_H=1 in the environment makes this return 0 (A/B switch: h stored and re-read). */
+int micf_block_recomputes_h(int C, int heads);
 int micf_block_tile_tokens(int B, int D, int H, int W, int C, int heads, int hidden, int backward);
 /* Per-step weight preparation for the fused block kernels: for each row-major fp32 matrix of a list (one launch per 64 items,
  * one read of the source) write dst = src and / or dst_t = src^T, as float (bf16 = 0), as row-major bf16 bit patterns in

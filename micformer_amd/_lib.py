@@ -110,6 +110,7 @@ SIGNATURES = {
     "micf_block_tile_tokens": "iiiiiiii",
     "micf_block_saves_bf16": "iii",
     "micf_block_fuses_sampler": "ii",
+    "micf_block_recomputes_h": "ii",
     "micf_weight_prep_grouped": "pip",
     "micf_block_fwd": "piiiiiiiiffip",
     "micf_block_bwd": "piiiiiiiifip",
@@ -156,7 +157,7 @@ class BlockFwdGroup(ctypes.Structure):
 class BlockBwdGroup(ctypes.Structure):
     """struct micf_block_bwd_group (include/micformer_hip.h)."""
     FIELDS = ("dy", "x", "x1", "stats", "q", "kv", "h", "ln1_g", "ln2_g", "wqt", "wkvt", "wpt", "w1t", "w2t", "s1", "s2",
-              "dx", "dxs", "dx1", "dh", "dq", "dkv", "ln1_part", "ln2_part", "dx1_copy", "dy16")
+              "dx", "dxs", "dx1", "dh", "dq", "dkv", "ln1_part", "ln2_part", "dx1_copy", "dy16", "xn2", "w1", "b1")
     _fields_ = [(n, _VP) for n in FIELDS]
 
 
@@ -229,6 +230,7 @@ def _load():
     lib.micf_block_saves_bf16.argtypes = [_I] * 3
     lib.micf_offset_head_finish_deferrable.argtypes = [_I] * 4
     lib.micf_block_fuses_sampler.argtypes = [_I] * 2
+    lib.micf_block_recomputes_h.argtypes = [_I] * 2
     lib.micf_strerror.argtypes = [_I]
     lib.micf_strerror.restype = ctypes.c_char_p
     lib.micf_abi_version.argtypes = []

@@ -2,6 +2,8 @@
 // modalities (the adjoint of block_fwd.hip; MS.py:277-524 through autograd in the reference):
 //
 //   dh  = (s2 dy W2) * GELU'(h)            -> HBM (fc1 weight gradient)          dy itself is fc2's output gradient
+//         (h = the saved fc1 pre-activation, or -- RECOMP, micf_block_recomputes_h -- rebuilt here as xn2 W1^T + b1 by the forward's
+//          own GEMM phase: the forward then never writes h, 8 of its 36 bytes per element, and this kernel reads 2 instead of 8)
 //   dx1 = dy + LN2'(dh W1)                 -> HBM (proj weight gradient; the cross block's LN1 backward adds it)
 //   do  = s1 dx1 Wp ;  (dq, dk, dv) = attention'(q, k, v, do)   -> HBM dq, dkv (q / kv weight gradients)
 //   self : dx  = dx1 + LN1'(dq Wq + dkv Wkv)                 (all "dY W" products read the TRANSPOSED weights W^T [K, N], which
@@ -256,7 +258,7 @@ __device__ __forceinline__ void ln_bwd_tile(const float* D, float* A, int S, con
   lds_barrier();
 }
 
-template <int C, int HD, int TJ, int NW, bool BF16>
+template <int C, int HD, int TJ, int NW, bool BF16, bool RECOMP>
 __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) block_bwd_kernel(const BlkBwdArgs a) {
   constexpr int TM = 16 * TJ, VPL = (C + 63) / 64, NSL = C / 16, NTHR = 64 * NW, RPP = 4 * NW, NPASS = (TM + RPP - 1) / RPP;
   constexpr bool PARK = block_bwd_park_floats(TM, C, NTHR) != 0;
@@ -270,6 +272,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
   float* sc2 = sc1 + TM;
   int* tok = reinterpret_cast<int*>(sc2 + TM);
   float* stash = sc2 + 2 * TM;                          // (PARK only) LayerNorm-1 inputs across the attention backward
+  float* pb1 = stash + block_bwd_park_floats(TM, C, NTHR);   // (RECOMP only) fc1 bias [4C]
 
   int grp, tile;
   if (a.G == 2) { const int xcd = blockIdx.x & 7; grp = xcd >> 2; tile = (int)(blockIdx.x >> 3) * 4 + (xcd & 3); }
@@ -280,7 +283,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
   const int64_t T = a.geo.T;
   using WT = typename std::conditional<BF16, uint16_t, float>::type;      // bf16 mode streams bf16 shadow weights
   const WT* wqt = static_cast<const WT*>(g.wqt), *wkvt = static_cast<const WT*>(g.wkvt), *wpt = static_cast<const WT*>(g.wpt),
-           *w1t = static_cast<const WT*>(g.w1t), *w2t = static_cast<const WT*>(g.w2t);
+           *w1t = static_cast<const WT*>(g.w1t), *w2t = static_cast<const WT*>(g.w2t), *w1f = static_cast<const WT*>(g.w1);
 
   if (tid < TM) {
     const int win = tile * (TM / 8) + (tid >> 3);
@@ -300,8 +303,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
   // the `saddr` form of the global loads / stores.  tok[0] is the smallest token of the tile (windows are raster ordered).
   const int tk0 = __builtin_amdgcn_readfirstlane(tok[0]);
   const float* dy0 = g.dy + (int64_t)tk0 * C;
-  const char* h0 = static_cast<const char*>(g.h) + (int64_t)tk0 * Hd * (BF16 ? 2 : 4);
   constexpr int ES = BF16 ? 2 : 4;                      // element size of the tensors the bf16 mode stores as bf16
+  const char* h0 = static_cast<const char*>(g.h) + (int64_t)tk0 * Hd * ES;
   const char* q0 = reinterpret_cast<const char*>(g.q) + (int64_t)tk0 * C * ES;
   const char* kv0 = reinterpret_cast<const char*>(g.kv) + (int64_t)tk0 * 2 * C * ES;
   char* dh0 = reinterpret_cast<char*>(g.dh) + (int64_t)tk0 * Hd * ES;
@@ -312,14 +315,26 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
   // ---- request every global input of the tile (see RowRegs)
   constexpr int HC = 2 * C;
   RowRegs<TM, NW, C4> r_dy;
-  HRegs<TM, NW, HC / 4, BF16> r_h[Hd / HC];
+  HRegs<TM, NW, HC / 4, BF16> r_h[RECOMP ? 1 : Hd / HC];
+  HRegs<TM, NW, C4, BF16> r_xn2;
+  float4 r_b1[(Hd / 4 + NTHR - 1) / NTHR];
   HRegs<TM, NW, C4, BF16> r_q;
   HRegs<TM, NW, 2 * C4, BF16> r_kv;
   LnRegs<TM, NW, C> r_ln2, r_ln1;
   r_dy.load(tok, tk0, [&](uint32_t rel, uint32_t c4) { return at32(dy0, (rel * C + 4 * c4) * 4u); });
+  if constexpr (RECOMP) {
+    // (requested right behind dy: loads return in order, and both are committed to LDS first)
 #pragma unroll
-  for (int ch = 0; ch < Hd / HC; ++ch)
-    r_h[ch].load(tok, tk0, h0 + ch * HC * (BF16 ? 2 : 4), (uint32_t)Hd);
+    for (int k = 0; k < (Hd / 4 + NTHR - 1) / NTHR; ++k) {
+      const int e4 = tid + k * NTHR;
+      r_b1[k] = ld4g(g.b1 + 4 * (e4 < Hd / 4 ? e4 : Hd / 4 - 1));
+    }
+    r_xn2.load(tok, tk0, reinterpret_cast<const char*>(g.xn2) + (int64_t)tk0 * C * ES, (uint32_t)C);
+  } else {
+#pragma unroll
+    for (int ch = 0; ch < Hd / HC; ++ch)
+      r_h[ch].load(tok, tk0, h0 + ch * HC * (BF16 ? 2 : 4), (uint32_t)Hd);
+  }
   r_ln2.load(tok, tk0, g.x1 + (int64_t)tk0 * C, g.stats + 2 * T + tk0, g.stats + 3 * T + tk0, g.ln2_g);
   if (!g.dxs) r_ln1.load(tok, tk0, g.x + (int64_t)tk0 * C, g.stats + tk0, g.stats + T + tk0, g.ln1_g);
   r_q.load(tok, tk0, q0, (uint32_t)C);
@@ -335,8 +350,23 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
     const int c0 = ch * HC;
     constexpr int hc = HC;
     constexpr int X4 = hc >> 2;
-    r_h[ch].commit(U, SU);
-    lds_barrier();
+    if constexpr (RECOMP) {
+      // h chunk = xn2 W1[c0 .. c0 + 2C)^T + b1 -> U[:, 0 .. 2C): the forward's phase (same units, same k order); the xn2 rows wait in
+      // the third (idle) column block of U
+      if (ch == 0) {
+        r_xn2.commit(U + 2 * C, SU);
+#pragma unroll
+        for (int k = 0; k < (Hd / 4 + NTHR - 1) / NTHR; ++k) {
+          const int e4 = tid + k * NTHR;
+          if (e4 < Hd / 4) *reinterpret_cast<float4*>(pb1 + 4 * e4) = r_b1[k];
+        }
+        lds_barrier();
+      }
+      gemm_phase<TJ, NSL, 1, C, NW, BF16>(w1f + (int64_t)c0 * C, hc, U + 2 * C, nullptr, 0, nullptr, SU, U, SU, EpiBias{pb1 + c0});
+    } else {
+      r_h[ch].commit(U, SU);
+      lds_barrier();
+    }
     gemm_phase<TJ, NSL, 1, C, NW, BF16>(w2t + (int64_t)c0 * C, hc, A1, nullptr, 0, nullptr, S, U, SU, EpiGeluGrad<BF16>{sc2});
 #pragma unroll 1
     for (int pass = 0; pass < NPASS; ++pass) {
@@ -517,16 +547,25 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
 template <int C, int HD, int TJ>
 static int launch_bwd(const BlkBwdArgs& a, int dtype, hipStream_t s) {
   constexpr int TM = 16 * TJ, NW = C >= 192 ? 8 : 4;
-  const size_t lds = block_lds_floats(TM, C, block_bwd_scratch_floats(TM, C / HD, 64 * NW), block_bwd_park_floats(TM, C, 64 * NW)) * sizeof(float);
+  const bool recomp = a.g[0].h == nullptr;              // (both groups alike: checked by the entry point)
+  const size_t lds = block_lds_floats(TM, C, block_bwd_scratch_floats(TM, C / HD, 64 * NW),
+                                      block_bwd_park_floats(TM, C, 64 * NW) + (recomp ? 4 * C : 0)) * sizeof(float);
   if (lds > 160 * 1024) return MICF_EUNSUPPORTED;
   const unsigned grid = a.G == 2 ? (unsigned)((a.tiles + 3) / 4 * 8) : (unsigned)a.tiles;
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_bwd_kernel<C, HD, TJ, NW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_bwd_kernel<C, HD, TJ, NW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_bwd_kernel<C, HD, TJ, NW, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_bwd_kernel<C, HD, TJ, NW, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_bwd_kernel<C, HD, TJ, NW, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_bwd_kernel<C, HD, TJ, NW, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
-  if (dtype == MICF_DTYPE_BF16) hipLaunchKernelGGL((block_bwd_kernel<C, HD, TJ, NW, true>), dim3(grid), dim3(64 * NW), lds, s, a);
-  else hipLaunchKernelGGL((block_bwd_kernel<C, HD, TJ, NW, false>), dim3(grid), dim3(64 * NW), lds, s, a);
+  if (dtype == MICF_DTYPE_BF16) {
+    if (recomp) hipLaunchKernelGGL((block_bwd_kernel<C, HD, TJ, NW, true, true>), dim3(grid), dim3(64 * NW), lds, s, a);
+    else hipLaunchKernelGGL((block_bwd_kernel<C, HD, TJ, NW, true, false>), dim3(grid), dim3(64 * NW), lds, s, a);
+  } else {
+    if (recomp) hipLaunchKernelGGL((block_bwd_kernel<C, HD, TJ, NW, false, true>), dim3(grid), dim3(64 * NW), lds, s, a);
+    else hipLaunchKernelGGL((block_bwd_kernel<C, HD, TJ, NW, false, false>), dim3(grid), dim3(64 * NW), lds, s, a);
+  }
   MICF_RETURN_LAUNCH();
 }
 
@@ -543,9 +582,18 @@ extern "C" int micf_block_bwd(const micf_block_bwd_group* groups, int ngroups, i
   BlkBwdArgs a;
   for (int i = 0; i < ngroups; ++i) {
     const micf_block_bwd_group& g = groups[i];
-    const void* need[] = {g.dy, g.x1, g.stats, g.q, g.kv, g.h, g.ln2_g, g.wqt, g.wkvt, g.wpt, g.w1t, g.w2t, g.dx, g.dx1, g.dh, g.dq, g.dkv};
+    const void* need[] = {g.dy, g.x1, g.stats, g.q, g.kv, g.ln2_g, g.wqt, g.wkvt, g.wpt, g.w1t, g.w2t, g.dx, g.dx1, g.dh, g.dq, g.dkv};
     for (const void* p : need)
       if (!p || (reinterpret_cast<uintptr_t>(p) & 15)) return MICF_EINVAL;
+    if (g.h) {                                          // the saved pre-activation ...
+      if (reinterpret_cast<uintptr_t>(g.h) & 15) return MICF_EINVAL;
+    } else {                                            // ... or what the kernel rebuilds it from (tile kernels only, both groups alike)
+      const void* re[] = {g.xn2, g.w1, g.b1};
+      for (const void* p : re)
+        if (!p || (reinterpret_cast<uintptr_t>(p) & 15)) return MICF_EINVAL;
+      if (!micf_block_recomputes_h(C, heads)) return MICF_EINVAL;
+    }
+    if (i > 0 && (g.h == nullptr) != (groups[0].h == nullptr)) return MICF_EINVAL;
     if (!g.dxs && (!g.x || !g.ln1_g)) return MICF_EINVAL;          // self: LayerNorm-1 backward runs in the kernel
     const void* opt[] = {g.x, g.ln1_g, g.dxs, g.ln1_part, g.ln2_part, g.dx1_copy, g.dy16};
     for (const void* p : opt)

@@ -356,7 +356,7 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
         const float4 ge = do_gelu ? make_float4(gelu_t<BF16>(v.x), gelu_t<BF16>(v.y), gelu_t<BF16>(v.z), gelu_t<BF16>(v.w)) : v;
         *reinterpret_cast<float4*>(up) = ge;
         if (tk >= 0 && save) {
-          st_h4<BF16>(g.h, (int64_t)tk * Hd + c0 + 4 * c4, v);
+          if (g.h) st_h4<BF16>(g.h, (int64_t)tk * Hd + c0 + 4 * c4, v);       // (workgroup-uniform; NULL: the backward recomputes it)
           st_h4<BF16>(g.g, (int64_t)tk * Hd + c0 + 4 * c4, ge);
         }
       }
@@ -440,6 +440,12 @@ extern "C" int micf_block_fuses_sampler(int C, int heads) {
   return block_wide_tile_tokens(C, C / heads) ? 0 : 1;
 }
 
+extern "C" int micf_block_recomputes_h(int C, int heads) {
+  if (C <= 0 || heads <= 0 || C % heads || block_wide_tile_tokens(C, C / heads)) return 0;
+  const char* e = getenv("MICF_BLOCK_SAVE_H");
+  return (e && atoi(e) != 0) ? 0 : 1;
+}
+
 extern "C" int micf_block_saves_bf16(int C, int heads, int dtype) {
   if (C <= 0 || heads <= 0 || C % heads) return 0;
   return block_saves_bf16(C, C / heads, dtype) ? 1 : 0;
@@ -455,9 +461,11 @@ extern "C" int micf_block_fwd(const micf_block_fwd_group* groups, int ngroups, i
   for (int i = 0; i < ngroups; ++i) {
     const micf_block_fwd_group& g = groups[i];
     const void* need[] = {g.x, g.ln1_g, g.ln1_b, g.wq, g.bq, g.wkv, g.bkv, g.wp, g.bp, g.ln2_g, g.ln2_b, g.w1, g.b1, g.w2, g.b2,
-                          g.y, g.q, g.kv, g.o, g.x1, g.xn2, g.h, g.g, g.stats};
+                          g.y, g.q, g.kv, g.o, g.x1, g.xn2, g.g, g.stats};
     for (const void* p : need)
       if (!p || (reinterpret_cast<uintptr_t>(p) & 15)) return MICF_EINVAL;
+    // h may be left out where the backward rebuilds it (micf_block_recomputes_h); the few-token decomposition always stores it
+    if (g.h ? (reinterpret_cast<uintptr_t>(g.h) & 15) != 0 : !micf_block_recomputes_h(C, heads)) return MICF_EINVAL;
     if ((g.kvsrc && (reinterpret_cast<uintptr_t>(g.kvsrc) & 15)) || (g.xn && (reinterpret_cast<uintptr_t>(g.xn) & 15)) ||
         (g.kvs16 && (reinterpret_cast<uintptr_t>(g.kvs16) & 15))) return MICF_EINVAL;
     if (g.hid) {      // fused sampling: the offset head's parameters, the raw source and the flow output come with it

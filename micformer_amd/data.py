@@ -62,6 +62,9 @@ class RawBatch:
 
     def copy_(self, other, non_blocking=False):
         """In-place refresh of a captured step's static input (TrainEngine): the statistics are recomputed by the replay."""
+        if not isinstance(other, RawBatch) or (self.params is None) != (other.params is None):
+            # (silently dropping the draws would leave the image un-flipped under labels prepare_raw_batch already flipped)
+            raise ValueError("RawBatch.copy_: source must be a RawBatch with the same augmentation state (params None / not None)")
         self.image.copy_(other.image, non_blocking=non_blocking)
         if self.params is not None:
             self.params.copy_(other.params, non_blocking=non_blocking)
@@ -76,5 +79,7 @@ class RawBatch:
 
 def prepare_raw_batch(image, label_map=None, params=None):
     """The fused counterpart of prepare_batch: -> (RawBatch for Head, flipped uint8 label map)."""
-    lab = None if label_map is None else ops.flip_labels(label_map.contiguous(), None if params is None else params.to(image.device))
+    if params is not None:
+        params = params.to(image.device, torch.float32).contiguous()      # (the C-ABI takes float32 draws only)
+    lab = None if label_map is None else ops.flip_labels(label_map.contiguous(), params)
     return RawBatch(image, params), lab

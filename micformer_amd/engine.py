@@ -392,6 +392,9 @@ class TrainEngine:
         sx, st = self._static[0], self._static[1]
         ok = x.shape == sx.shape and target.shape == st.shape and x.dtype == sx.dtype and target.dtype == st.dtype \
             and self._static_mode == ops.compute_dtype()            # (the arithmetic mode is baked into the captured launches)
+        # a plain tensor and a data.RawBatch (and a RawBatch with / without augmentation draws) take different launches in the
+        # patch embedding: the captured graph holds exactly one of them, anything else runs eagerly
+        ok = ok and type(x) is type(sx) and (getattr(x, "params", None) is None) == (getattr(sx, "params", None) is None)
         if self.world > 1:
             # Data parallel: the replayed step and the eager step cut the gradient exchange differently (per-stage slices vs
             # whole-buffer buckets), so every rank must take the same path: ONE small all-reduce(MIN) of the flag per step.

@@ -81,6 +81,10 @@ def _lin_wgrad(defer, dy, a, dw, db, dp_scale=None, rows_per_sample=0):
         launch_pending_flush()
         _QUEUED_DW.add(dw.data_ptr())
         _DEFERRED.append((dy, a, dw, db, dp_scale, rows_per_sample))
+    elif dy.dtype == torch.bfloat16:
+        # bf16 operands of a layer too long to queue (> DEFER_MAX_TOKENS rows: batch >= 5 at 128^3): the per-layer entry point is
+        # fp32 only, the grouped one reads bf16 pairs -- launch it now for this one layer
+        ops.linear_bwd_weight_grouped([(dy, a, dw, db, dp_scale, rows_per_sample)])
     else:
         ops.linear_bwd_weight(dy, a, dw, db, dp_scale=dp_scale, rows_per_sample=rows_per_sample)
 
@@ -739,7 +743,7 @@ class CrossBlockFn(torch.autograd.Function):
             side = all(t is not None for t in ctx.tg)
             dyf = _c(dy).reshape(-1, C)
             bo = ops.block_bwd([{"dy": dyf, "x": None, "x1": svd["x1"], "stats": svd["stats"], "q": svd["q"], "kv": svd["kv"],
-                                 "h": svd["h"], "P": P, "attn": "cross_attn", "s1": s1, "s2": s2, "cross": True,
+                                 "h": svd["h"], "xn2": svd["xn2"], "P": P, "attn": "cross_attn", "s1": s1, "s2": s2, "cross": True,
                                  "want_copy": True}], dims, C, heads, (C // heads) ** -0.5)[0]
             xn, m1, r1, hid, flow, xsamp = hd
             _queue_block_wgrads(side, P, G, "cross_attn", svd, bo, dyf, xn, xsamp, s1, s2, rps)
@@ -831,7 +835,7 @@ def _self_fwd_fused(xs, Ps, scales, dims, heads, eps):
 def _self_bwd_fused(dys, xs, svs, Ps, Gs, scales, dims, heads, sides):
     C = xs[0].shape[1]
     rps = dims[1] * dims[2] * dims[3]
-    groups = [{"dy": dy, "x": x, "x1": sv["x1"], "stats": sv["stats"], "q": sv["q"], "kv": sv["kv"], "h": sv["h"], "P": P,
+    groups = [{"dy": dy, "x": x, "x1": sv["x1"], "stats": sv["stats"], "q": sv["q"], "kv": sv["kv"], "h": sv["h"], "xn2": sv["xn2"], "P": P,
                "attn": "self_attn", "s1": s[0], "s2": s[1], "cross": False} for dy, x, sv, P, s in zip(dys, xs, svs, Ps, scales)]
     bos = ops.block_bwd(groups, dims, C, heads, (C // heads) ** -0.5)
     for dy, sv, bo, P, G, s, side in zip(dys, svs, bos, Ps, Gs, scales, sides):
@@ -1018,7 +1022,7 @@ class CrossPairFn(torch.autograd.Function):
         rps = dims[1] * dims[2] * dims[3]
         dys = [_c(dy).reshape(-1, C), _c(dya).reshape(-1, C)]
         groups = [{"dy": dys[i], "x": None, "x1": svs[i]["x1"], "stats": svs[i]["stats"], "q": svs[i]["q"], "kv": svs[i]["kv"],
-                   "h": svs[i]["h"], "P": Ps[i], "attn": "cross_attn", "s1": scales[i][0], "s2": scales[i][1], "cross": True,
+                   "h": svs[i]["h"], "xn2": svs[i]["xn2"], "P": Ps[i], "attn": "cross_attn", "s1": scales[i][0], "s2": scales[i][1], "cross": True,
                    "want_copy": True} for i in (0, 1)]
         bos = ops.block_bwd(groups, dims, C, heads, (C // heads) ** -0.5)
         acc = [bos[0]["dx1_copy"], bos[1]["dx1_copy"]]       # acc[i] becomes d(input i): starts as dx1 of block i
@@ -1161,10 +1165,13 @@ _SKIP_TOKENS = {}                   # data_ptr of a ConvDownFn input of THIS for
 
 
 class _SkipToken:
-    __slots__ = ("grad",)
+    # mailed / received: SkipMailFn forwards that took this token / backwards that delivered; consumed: ConvDownFn's backward ran
+    __slots__ = ("grad", "mailed", "received", "consumed")
 
     def __init__(self):
         self.grad = None
+        self.mailed = self.received = 0
+        self.consumed = False
 
 
 def clear_skip_tokens():
@@ -1173,18 +1180,26 @@ def clear_skip_tokens():
 
 def skip_token(t):
     """The token of the PatchMerging launch that consumed exactly this tensor in the current forward, or None."""
-    return _SKIP_TOKENS.get(t.data_ptr()) if SKIP_MAIL else None
+    return _SKIP_TOKENS.get((t.data_ptr(), tuple(t.shape))) if SKIP_MAIL else None
 
 
 class SkipMailFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, t, token):
         ctx.token = token
+        token.mailed += 1
         return t.view_as(t)
 
     @staticmethod
     def backward(ctx, g):
-        ctx.token.grad = g if ctx.token.grad is None else ctx.token.grad + g
+        tok = ctx.token
+        if tok.consumed:
+            # the hand-over relies on autograd reaching the skip consumer (decoder) before PatchMerging's backward (encoder); any
+            # other order (autograd.grad on a sub-graph, a second pass over a retained graph) would drop this gradient silently
+            raise RuntimeError("SkipMailFn.backward ran after the PatchMerging backward that should have added its gradient "
+                               "(set MICF_SKIP_MAIL=0 for backward passes in a non-standard order)")
+        tok.grad = g if tok.grad is None else tok.grad + g
+        tok.received += 1
         return None, None
 
 
@@ -1199,7 +1214,7 @@ class ConvDownFn(torch.autograd.Function):
         ctx.gemm = PATCH_GEMM and tuple(w.shape[2:]) == (2, 2, 2)
         ctx.token = None
         if ctx.gemm and SKIP_MAIL and x.requires_grad:
-            ctx.token = _SKIP_TOKENS[x.data_ptr()] = _SkipToken()
+            ctx.token = _SKIP_TOKENS[(x.data_ptr(), tuple(x.shape))] = _SkipToken()
         if ctx.gemm:
             B, D, H, W, C = x.shape
             N = w.shape[0]
@@ -1222,8 +1237,13 @@ class ConvDownFn(torch.autograd.Function):
             _lin_wgrad(ctx.tg[0] is not None and ctx.tg[1] is not None, dy2, x, dw.view(N, 8 * C), db)
             da = ops.linear_bwd_data(dy2, w.reshape(N, 8 * C))
             skip = ctx.token.grad if ctx.token is not None else None      # the skip connection's gradient of x (SkipMailFn)
-            if skip is not None:
+            if ctx.token is not None:
+                if ctx.token.received != ctx.token.mailed and not ctx.token.consumed:
+                    raise RuntimeError(f"PatchMerging backward reached before its skip connection's gradient arrived "
+                                       f"({ctx.token.received} of {ctx.token.mailed} mailed): MICF_SKIP_MAIL=0 for this pass order")
+                ctx.token.consumed = True
                 ctx.token.grad = None
+            if skip is not None:
                 skip = _c(skip)
             return ops.depth_to_space(da, (B, D, H, W), C, 2, add=skip), _ret(ctx.tg[0], dw), _ret(ctx.tg[1], db)
         _defer(ctx.tg[0] is not None and ctx.tg[1] is not None, lambda: ops.conv_down_bwd_weight(dy, x, dw, db), dy, x)

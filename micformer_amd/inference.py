@@ -77,6 +77,12 @@ class GraphedPredictor:
         acc = self.__dict__.setdefault("_acc", {})
         key = (tuple(shape), str(device))
         if key not in acc:
+            # ONE accumulator pair is kept (validation sets with varying volume sizes would otherwise grow device memory without
+            # bound: 2.4 GB per 512x512x256 shape at 8 classes); a new shape evicts the old pair and the graphs that baked it in
+            for old in list(acc):
+                o, c = acc.pop(old)
+                for k in [k for k in self.graphs if k[0] == "acc" and k[-2:] == (o.data_ptr(), c.data_ptr())]:
+                    del self.graphs[k]
             B, K, D, H, W = shape
             acc[key] = (torch.empty(shape, dtype=torch.float32, device=device), torch.empty((B, D, H, W), dtype=torch.float32, device=device))
         return acc[key]
@@ -145,7 +151,8 @@ def sliding_window_inference(inputs, roi_size, sw_batch_size, predictor, overlap
     # adds its logits straight into the volume accumulator at the window origins and bumps the visit counts in its last launch --
     # no [n, K, roi] prediction tensor, no accumulate launch.  Needs roi dims that the patch size divides (else the model pads).
     base = predictor.predictor if isinstance(predictor, GraphedPredictor) else predictor
-    fused = FUSE_ACCUMULATE and hasattr(base, "forward_accumulate") and hasattr(base, "out_conv") and not (rd % 4 or rh % 4 or rw % 4)
+    fused = FUSE_ACCUMULATE and hasattr(base, "forward_accumulate") and hasattr(base, "out_conv") \
+        and getattr(base, "can_accumulate", lambda roi: False)((rd, rh, rw))      # (else: the generic crop / predict / accumulate path)
     with torch.no_grad():
         if fused:
             K = base.out_conv.out_channels

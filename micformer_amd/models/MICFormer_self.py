@@ -697,6 +697,16 @@ class Head(nn.Module):
         feat = self.swin.features(x, 0, x, 1)
         return Fn.OutConvFn.apply(feat, oc.weight, oc.bias)
 
+    def can_accumulate(self, roi=None):
+        """True when forward_accumulate can take windows of spatial size `roi`: the composed head is on and supports this
+        patch size / class count, `roi` is a multiple of the patch size (else the model pads the coarse grid and the patches
+        would spill into the neighbouring accumulator regions), and forward() is Head's own (a subclass that post-processes its
+        logits must go through the generic prediction path)."""
+        rp, oc = self.swin.reverse_patch_embedding, self.out_conv
+        P = rp.kernel_size[0]
+        ok = FUSE_HEAD_TAIL and 2 <= P <= 8 and oc.out_channels <= 32 and type(self).forward is Head.forward
+        return bool(ok and (roi is None or all(int(r) % P == 0 for r in roi)))
+
     def forward_accumulate(self, x, out, count, coords):
         """Sliding-window inference (utils.py:226-234) with the accumulate / count epilogue fused into the logits store: x holds n
         windows (n, 2, rd, rh, rw); window i's logits are ADDED into the fp32 volume accumulator `out` (VB, classes, D, H, W) at
@@ -704,8 +714,8 @@ class Head(nn.Module):
         prediction tensor is never materialised.  Returns None."""
         from .. import ops
         rp, oc = self.swin.reverse_patch_embedding, self.out_conv
-        if not (FUSE_HEAD_TAIL and 2 <= rp.kernel_size[0] <= 8 and oc.out_channels <= 32) or torch.is_grad_enabled():
-            raise RuntimeError("forward_accumulate needs the composed head and torch.no_grad()")
+        if not self.can_accumulate(tuple(x.shape[2:])) or torch.is_grad_enabled():
+            raise RuntimeError("forward_accumulate needs the composed head, window dims the patch size divides and torch.no_grad()")
         x = x.float().contiguous()
         P = rp.kernel_size[0]
         wut = ops.head_tail_transposed_up(rp.weight)

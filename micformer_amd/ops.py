@@ -984,10 +984,13 @@ def _conv_layouts(w):
     return f, b
 
 
-def block_weights(P, attn, backward):
-    """The five weight matrices a fused block kernel streams, in the layout of the current arithmetic mode.  Engine mode: the
-    parameter carries the shadow copy (refreshed once per step); otherwise it is made here (one grouped launch)."""
+def block_weights(P, attn, backward, only=None):
+    """The five weight matrices a fused block kernel streams (or the fields named in `only`), in the layout of the current
+    arithmetic mode.  Engine mode: the parameter carries the shadow copy (refreshed once per step); otherwise it is made here
+    (one grouped launch)."""
     fields = BWD_WT if backward else FWD_WM
+    if only is not None:
+        fields = tuple(f for f in fields if f[0] in only)
     spec = shadow_spec(backward)
     out, todo = {}, []
     for field, key in fields:
@@ -1037,6 +1040,12 @@ def block_saves_bf16(C, heads):
     return bool(_lib.lib.micf_block_saves_bf16(C, heads, _dt()))
 
 
+def block_recomputes_h(C, heads):
+    """True when block_bwd rebuilds the fc1 pre-activation from xn2 for this shape: block_fwd then does not store it
+    (include/micformer_hip.h micf_block_recomputes_h; MICF_BLOCK_SAVE_H=1 restores the stored form)."""
+    return bool(_lib.lib.micf_block_recomputes_h(C, heads))
+
+
 def block_fwd(groups, dims, C, heads, eps, scale):
     """groups: 1 or 2 dicts {x [T,C], kvsrc [T,C] | None, P {state_dict-style name: tensor}, attn 'self_attn' | 'cross_attn',
     s1, s2 [B] | None, want_xn bool}.  ONE launch.  Returns per group a dict of the tensors saved for backward (+ 'y')."""
@@ -1048,6 +1057,7 @@ def block_fwd(groups, dims, C, heads, eps, scale):
     h_dtype = torch.bfloat16 if _dt() else torch.float32       # the saved fc1 pre-activation: half width in bf16 mode
     st16 = block_saves_bf16(C, heads)                          # ... and everything only matrix cores / the attention backward re-read
     sd = torch.bfloat16 if st16 else torch.float32
+    no_h = block_recomputes_h(C, heads)                        # the backward rebuilds h from xn2: not stored
     keep = []            # temporary shadow weights must outlive the launch: the next group's outputs must not reuse them
     nb = fl = 0
     y_all = _new(groups[0]["x"], len(groups) * T, C)    # the groups' outputs are the halves of ONE buffer (functional.JoinFn: no copy)
@@ -1056,7 +1066,7 @@ def block_fwd(groups, dims, C, heads, eps, scale):
         fused_sampler = gd.get("hid") is not None       # cross block that samples its K/V source itself: {hid, samp_src} given
         cross = gd.get("kvsrc") is not None or fused_sampler
         o = {"y": y_all[gi * T:(gi + 1) * T], "q": _new(x, T, C, dtype=sd), "kv": _new(x, T, 2 * C, dtype=sd), "o": _new(x, T, C, dtype=sd),
-             "x1": _new(x, T, C), "xn2": _new(x, T, C, dtype=sd), "h": _new(x, T, hidden, dtype=h_dtype),
+             "x1": _new(x, T, C), "xn2": _new(x, T, C, dtype=sd), "h": None if no_h else _new(x, T, hidden, dtype=h_dtype),
              "g": _new(x, T, hidden, dtype=sd), "stats": _new(x, 4, T),
              # (bf16 storage: the q weight gradient pairs a bf16 dq with a bf16 xn, so the kernel always writes its own copy)
              "xn": _new(x, T, C, dtype=sd) if (gd.get("want_xn", True) or st16) else None,
@@ -1111,9 +1121,15 @@ def block_bwd(groups, dims, C, heads, scale):
              "dy16": _new(dy, T, C, dtype=sd) if st16 else None}
         for k in ("dy", "x", "x1", "stats", "s1", "s2"):
             setattr(it, k, f32(gd.get(k)))
-        if gd["h"].dtype != (torch.bfloat16 if _dt() else torch.float32) or gd["q"].dtype != sd or gd["kv"].dtype != sd:
+        h = gd.get("h")
+        if (h is not None and h.dtype != (torch.bfloat16 if _dt() else torch.float32)) or gd["q"].dtype != sd or gd["kv"].dtype != sd \
+                or (h is None and gd["xn2"].dtype != sd):
             raise _lib.MicfError("block_bwd: the saved tensors were written in another arithmetic mode")
-        it.h, it.q, it.kv = ptr(gd["h"]), ptr(gd["q"]), ptr(gd["kv"])
+        it.h, it.q, it.kv = ptr(h), ptr(gd["q"]), ptr(gd["kv"])
+        if h is None:                                   # recompute: xn2, the FORWARD orientation of fc1's weight, its bias
+            w1 = block_weights(P, a, backward=False, only=("w1",))["w1"]
+            keep.append(w1)
+            it.xn2, it.w1, it.b1 = ptr(gd["xn2"]), ptr(w1), f32(P["mlp.fc1.bias"])
         for field, key in BWD_W:
             setattr(it, field, f32(P[key.format(a=a)]))
         wts = block_weights(P, a, backward=True)
@@ -1123,7 +1139,7 @@ def block_bwd(groups, dims, C, heads, scale):
         for k, v in o.items():
             setattr(it, k, ptr(v))
         # bytes the launch moves: read dy, x1, q, kv, h [+ x: self]; write everything in `o`; the weights once
-        nb += 4 * T * C * (2 if cross else 3) + sum(gd[k].numel() * gd[k].element_size() for k in ("q", "kv", "h")) \
+        nb += 4 * T * C * (2 if cross else 3) + sum(gd[k].numel() * gd[k].element_size() for k in ("q", "kv", "h" if h is not None else "xn2")) \
             + sum(v.numel() * v.element_size() for v in o.values() if v is not None) + 12 * C * C * wt.element_size()
         o["tiles"] = tiles
         outs.append(o)

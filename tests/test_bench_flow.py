@@ -39,6 +39,7 @@ def test_bench_two_ranks_complete_with_roofline_leg():
     assert out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
     assert "roofline" in out and "path" in out["roofline"] and "family" in out["roofline"]
     assert out["cpu_baseline"] is None                     # N > 1: the CPU leg is a rank-0, N = 1 item
+    assert out["rccl_ranks"] == 2 and out["dist_backend"].startswith("gloo")   # what the collective backend itself saw
 
 
 @pytest.mark.timeout(300)
@@ -49,3 +50,26 @@ def test_bench_single_process_stub_and_no_roofline():
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert out["n_gpus"] == 1 and "roofline" not in out and "cpu_baseline" not in out
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_real_engine_two_ranks_on_one_gpu():
+    """bench.py's REAL N > 1 path before the driver's 8-GPU run -- torchrun with 2 ranks, both on the box's one
+    MI355X, collectives over gloo on device tensors (`--dist-backend gloo`): process-group init, weight broadcast, the capture
+    under a live group, timed replays with the post-replay weight-gradient groups + per-slice all-reduces + Adam, the eager
+    roofline leg with its collectives, the MAX-over-ranks timing and rank 0's single JSON line.  BASELINE config 3's per-rank
+    workload (base, 128^3, local batch 2, bf16), 3 steps."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--dist-backend", "gloo", "--no-cpu-baseline"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=850, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["distinct_local_devices"] == 1
+    assert out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2" and out["dtype"] == "bf16"
+    assert out["final_loss"] == out["final_loss"] and 0.0 < out["final_loss"] < 2.0
+    assert out["value"] > 0 and "roofline" in out and out["roofline"]["kernel"].startswith("micf_")

@@ -300,3 +300,54 @@ def test_training_script_in_miniature(dtype):
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["val_loss"][1] < out["val_loss"][0] and abs(out["resumed_val_meandice"] - out["val_meandice"][1]) < 1e-3
+
+
+def test_captured_step_refuses_another_input_kind(M):
+    """a graph captured on RawBatch(params=None) replayed a later RawBatch WITH augmentation draws (its flips / scale /
+    shift silently dropped under labels that were already flipped), and a plain tensor against a captured RawBatch raised.  The
+    engine now replays only for the input kind it captured (same type, same params-is-None state) and steps eagerly otherwise;
+    RawBatch.copy_ itself refuses a mismatch."""
+    from micformer_amd import data
+    from micformer_amd.engine import TrainEngine
+    x, t = _data(2)
+    img = (x * 40 + 100).half()
+    lab = fill.make_label_map(2, 64, 64, 64).to(torch.uint8).cuda()
+    params = torch.tensor([[1, 0, 1, 0.07, -0.03], [0, 1, 1, -0.05, 0.09]], dtype=torch.float64).cuda()   # (float64 draws: cast inside)
+    raw_plain, _ = data.prepare_raw_batch(img, None, None)
+    raw_aug, lab_aug = data.prepare_raw_batch(img, lab, params)
+    with pytest.raises(ValueError):
+        raw_plain.clone().copy_(raw_aug)
+    with pytest.raises(ValueError):
+        raw_aug.clone().copy_(raw_plain)
+    a = TrainEngine(_head(M), base_lr=1e-3, t_max=5, use_graph=True)
+    b = TrainEngine(_head(M), base_lr=1e-3, t_max=5, use_graph=False)
+    for inp, tgt in ((raw_plain, lab), (raw_aug, lab_aug), (data.prepare_batch(img, None, None)[0], t), (raw_plain, lab)):
+        la, lb = a.step(inp, tgt), b.step(inp, tgt)       # graph engine: 1st captures, 2nd / 3rd fall back to eager, 4th replays
+        assert abs(float(la) - float(lb)) < 1e-4
+    assert int(a.adam_state[0].item()) == 4
+    _same_training_state(a, b, "after four input kinds")
+
+
+def test_bf16_weight_gradient_of_a_layer_too_long_to_queue():
+    """bf16-stored operands of a layer with more than DEFER_MAX_TOKENS rows (batch >= 5 at 128^3) fell through to the
+    fp32-only per-layer entry point and raised.  Such a layer now launches the grouped kernel at once."""
+    from micformer_amd import functional as Fn
+    from micformer_amd import ops
+    g = torch.Generator().manual_seed(9)
+    Mrows, N, K = (1 << 17) + 4096, 48, 192
+    dy = (torch.randn(Mrows, N, generator=g) * 0.1).cuda()
+    a = torch.randn(Mrows, K, generator=g).cuda()
+    dw, db = torch.zeros(N, K, device="cuda"), torch.zeros(N, device="cuda")
+    prev, prev_defer = ops.compute_dtype(), Fn.DEFER_WGRAD
+    ops.set_compute_dtype("bf16")
+    Fn.DEFER_WGRAD = True
+    try:
+        Fn._lin_wgrad(True, dy.bfloat16(), a.bfloat16(), dw, db)
+        assert not Fn._DEFERRED                                   # launched, not queued
+    finally:
+        Fn.DEFER_WGRAD = prev_defer
+        Fn.drop_deferred()
+        ops.set_compute_dtype(prev)
+    want = dy.bfloat16().float().t() @ a.bfloat16().float()
+    assert float((dw - want).abs().max()) <= 2e-3 * float(want.abs().max())
+    assert float((db - dy.bfloat16().float().sum(0)).abs().max()) <= 2e-3 * float(dy.sum(0).abs().max()) + 1e-3

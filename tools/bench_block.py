@@ -66,7 +66,7 @@ def main():
         outs = fus_f()
         ops.set_compute_dtype("fp32")
         refs = ref_f()
-        bg = [{"dy": tb.rnd((T, C), 9 + i), "x": g["x"], "x1": o["x1"], "stats": o["stats"], "q": o["q"], "kv": o["kv"], "h": o["h"],
+        bg = [{"dy": tb.rnd((T, C), 9 + i), "x": g["x"], "x1": o["x1"], "stats": o["stats"], "q": o["q"], "kv": o["kv"], "h": o["h"], "xn2": o["xn2"],
                "P": g["P"], "attn": attn, "s1": None, "s2": None, "cross": args.cross} for i, (g, o) in enumerate(zip(gs, outs))]
         ref_b = lambda: [tb.ref_bwd(ops, b["dy"], b["x"], r, b["P"], attn, None, None, dims, heads, scale, args.cross) for b, r in zip(bg, refs)]
         t_ref_b = 0.0 if args.fused_only else timeit(ref_b)

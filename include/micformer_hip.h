@@ -457,8 +457,8 @@ typedef struct micf_block_fwd_group {
   float *xn, *q, *kv, *o, *x1, *xn2; /* LN1(x) [T,C] (may be NULL: not written); q [T,C]; k|v [T,2C]; attention out [T,C]; x + s1*attn [T,C]; LN2(x1) [T,C] */
   void* h;             /* fc1 pre-activation [T, hidden]: float for MICF_DTYPE_F32, bf16 (uint16_t, round-to-nearest-even)
                           for MICF_DTYPE_BF16 -- only micf_block_bwd reads it (GELU'), so the bf16 mode stores it at half width.
-                          NULL where micf_block_recomputes_h(C, heads) != 0: not written (8 of the 36 bytes a bf16 block writes per
-                          element of T*C); micf_block_bwd then rebuilds it from xn2 with one more GEMM phase */
+                          May be NULL on the tile-per-workgroup kernels (C <= 192): not written (8 of the 36 bytes a bf16 block
+                          writes per element of T*C); micf_block_bwd then rebuilds it from xn2 with one more GEMM phase */
   float* g;            /* GELU(h) [T, hidden] (operand of the fc2 weight gradient) */
   float* stats;        /* [4, T]: mean1, rstd1, mean2, rstd2 */
   void* kvs16;         /* cross, bf16 storage only (micf_block_saves_bf16): [T, C] bf16 copy of the K/V source, the operand of the kv
@@ -504,8 +504,10 @@ typedef struct micf_block_bwd_group {
   const void* w1;      /* mlp.fc1.weight [hidden, C], the forward's K16-blocked shadow copy (micf_block_fwd_group.w1) */
   const float* b1;     /* mlp.fc1.bias [hidden] */
 } micf_block_bwd_group;
-/* != 0: the tile-per-workgroup kernels (everything but the few-token decomposition at C = 384) accept h == NULL in both groups
- * structs (see there).  MICF_BLOCK_SAVE_H=1 in the environment makes this return 0 (A/B switch: h stored and re-read). */
+/* != 0: the caller should pass h == NULL in both groups structs (see there).  Only with MICF_BLOCK_RECOMPUTE_H=1 in the
+ * environment and only for the tile-per-workgroup kernels (everything but the few-token decomposition at C = 384): a memory
+ * switch (8 of the 34 saved bytes per element), not a speed one -- the extra GEMM phase of the backward costs more time than the
+ * bytes save. */
 int micf_block_recomputes_h(int C, int heads);
 int micf_block_tile_tokens(int B, int D, int H, int W, int C, int heads, int hidden, int backward);
 /* Per-step weight preparation for the fused block kernels: for each row-major fp32 matrix of a list (one launch per 64 items,

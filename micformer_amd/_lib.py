@@ -26,7 +26,8 @@ import torch  # noqa: E402
 GRAPH_SEGMENTS_OK = os.environ.get(_PKT) == "0" and (_pkt_before == "0" or not torch.cuda.is_initialized())
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmicformer_hip.so")
+# (MICF_LIB: another build of the same library -- A/B runs of kernel variants on one box, tools/ab_build.sh)
+LIB_PATH = os.environ.get("MICF_LIB") or os.path.join(_HERE, "libmicformer_hip.so")
 
 _P, _I, _L, _F, _D = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double
 _T = {"p": _P, "i": _I, "l": _L, "f": _F, "d": _D}

@@ -263,7 +263,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
   constexpr int TM = 16 * TJ, VPL = (C + 63) / 64, NSL = C / 16, NTHR = 64 * NW, RPP = 4 * NW, NPASS = (TM + RPP - 1) / RPP;
   constexpr bool PARK = block_bwd_park_floats(TM, C, NTHR) != 0;
   extern __shared__ __attribute__((aligned(1024))) float lds[];
-  constexpr int C4 = C >> 2, S = C + 4, SU = 3 * C + 4, Hd = 4 * C;
+  constexpr int C4 = C >> 2, S = C + 4, SU = block_u_cols(C) + 4, Hd = 4 * C;
   float* ring = lds;
   float* A1 = ring + block_bwd_scratch_floats(TM, C / HD, NTHR);
   float* A2 = A1 + TM * S;
@@ -273,6 +273,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
   int* tok = reinterpret_cast<int*>(sc2 + TM);
   float* stash = sc2 + 2 * TM;                          // (PARK only) LayerNorm-1 inputs across the attention backward
   float* pb1 = stash + block_bwd_park_floats(TM, C, NTHR);   // (RECOMP only) fc1 bias [4C]
+  float* XN2 = block_hidden_chunk(C) == 4 * C ? A2 : U + 2 * C;      // (RECOMP only) where the xn2 rows wait, and their row stride
+  constexpr int SXN2 = block_hidden_chunk(C) == 4 * C ? S : SU;
 
   int grp, tile;
   if (a.G == 2) { const int xcd = blockIdx.x & 7; grp = xcd >> 2; tile = (int)(blockIdx.x >> 3) * 4 + (xcd & 3); }
@@ -313,7 +315,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
   float* dx0 = g.dx + (int64_t)tk0 * C;
 
   // ---- request every global input of the tile (see RowRegs)
-  constexpr int HC = 2 * C;
+  constexpr int HC = block_hidden_chunk(C);
   RowRegs<TM, NW, C4> r_dy;
   HRegs<TM, NW, HC / 4, BF16> r_h[RECOMP ? 1 : Hd / HC];
   HRegs<TM, NW, C4, BF16> r_xn2;
@@ -351,10 +353,10 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
     constexpr int hc = HC;
     constexpr int X4 = hc >> 2;
     if constexpr (RECOMP) {
-      // h chunk = xn2 W1[c0 .. c0 + 2C)^T + b1 -> U[:, 0 .. 2C): the forward's phase (same units, same k order); the xn2 rows wait in
-      // the third (idle) column block of U
+      // h chunk = xn2 W1[c0 .. c0 + HC)^T + b1 -> U[:, 0 .. HC): the forward's phase (same units, same k order); the xn2 rows wait in
+      // the third (idle) column block of U -- or, with a single chunk, in A2 (free until the chunk's dh W1 product overwrites it)
       if (ch == 0) {
-        r_xn2.commit(U + 2 * C, SU);
+        r_xn2.commit(XN2, SXN2);
 #pragma unroll
         for (int k = 0; k < (Hd / 4 + NTHR - 1) / NTHR; ++k) {
           const int e4 = tid + k * NTHR;
@@ -362,7 +364,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
         }
         lds_barrier();
       }
-      gemm_phase<TJ, NSL, 1, C, NW, BF16>(w1f + (int64_t)c0 * C, hc, U + 2 * C, nullptr, 0, nullptr, SU, U, SU, EpiBias{pb1 + c0});
+      gemm_phase<TJ, NSL, 1, C, NW, BF16>(w1f + (int64_t)c0 * C, hc, XN2, nullptr, 0, nullptr, SXN2, U, SU, EpiBias{pb1 + c0});
     } else {
       r_h[ch].commit(U, SU);
       lds_barrier();
@@ -378,8 +380,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
       for (int c4 = l16; c4 < X4; c4 += 16)
         st_h4_32<BF16>(dh0, rel * Hd + c0 + 4 * c4, *reinterpret_cast<const float4*>(U + row * SU + 4 * c4));
     }
-    if (ch == 0) gemm_phase<TJ, NSL, 2, Hd, NW, BF16>(w1t + 16 * c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiStore{});
-    else gemm_phase<TJ, NSL, 2, Hd, NW, BF16>(w1t + 16 * c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiAcc{});
+    if (ch == 0) gemm_phase<TJ, NSL, HC / C, Hd, NW, BF16>(w1t + 16 * c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiStore{});
+    else gemm_phase<TJ, NSL, HC / C, Hd, NW, BF16>(w1t + 16 * c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiAcc{});
   }
 
   // ---- dx1 = dy + LN2'(A2) -> A1 + HBM; LN2 gain / bias partials
@@ -398,7 +400,15 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
   // windows.  Where a tile has fewer (row, head) pairs than half the workgroup (C = 48: 96 of 256 threads), 2 or 4 adjacent
   // lanes share a pair: each owns HD / 2 or HD / 4 channels and the partial dot products meet in cross-lane adds.
   {
-    constexpr int heads = C / HD, SP = (TM * heads * 4 <= NTHR && HD >= 16) ? 4 : (TM * heads * 2 <= NTHR) ? 2 : 1, HP = HD / SP, per = 8 * heads * SP, wpb = NTHR / per;
+    // (C = 96 at 32 tokens: 192 pairs on 256 threads would run whole 16-channel head rows per lane -- 80 registers of dq / dk / dv /
+    //  q / do rows on top of the parked LayerNorm-1 inputs: 24 spilled.  Two lanes per pair in two batches of 2 windows instead.)
+#ifdef MICF_AB_SP1
+    constexpr bool kSplit96 = false;
+#else
+    constexpr bool kSplit96 = C == 96 && TM == 32 && HD == 16;
+#endif
+    constexpr int heads = C / HD, SP = (TM * heads * 4 <= NTHR && HD >= 16) ? 4 : (TM * heads * 2 <= NTHR || kSplit96) ? 2 : 1,
+                  HP = HD / SP, per = 8 * heads * SP, wpb = NTHR / per;
     float* PS = ring;                                   // [(row, head) pair][16]: P row | dS row
     // (whole waves rotated per workgroup like the GEMM units: with fewer pairs than threads the last waves = SIMDs stay idle)
     const int vt = (tid + 64 * (int)((blockIdx.x * 2654435761u) >> 20)) & (NTHR - 1);

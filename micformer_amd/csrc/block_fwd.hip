@@ -33,7 +33,7 @@ template <int C, int HD, int TJ, int NW, bool BF16, bool SAMP>
 __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) {
   constexpr int TM = 16 * TJ, VPL = (C + 63) / 64, NSL = C / 16, NTHR = 64 * NW, RPP = 4 * NW, NPASS = (TM + RPP - 1) / RPP;
   extern __shared__ __attribute__((aligned(1024))) float lds[];
-  constexpr int C4 = C >> 2, S = C + 4, SU = 3 * C + 4, Hd = 4 * C;
+  constexpr int C4 = C >> 2, S = C + 4, SU = block_u_cols(C) + 4, Hd = 4 * C;
   float* A1 = lds;
   float* A2 = A1 + TM * S;
   float* U = A2 + TM * S;
@@ -126,12 +126,18 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
       for (int k = 0; k < VPL; ++k) {
         const int c4 = l16 + 16 * k;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 tv[8];
+        // taps in flight per batch: all 8, or 4 + 4 where the workgroup has 16 waves (128 registers per lane: 8 float4 taps on top
+        // of the row registers spilled 20 of them); the accumulation order is 0..7 either way
+        constexpr int TB = NW >= 16 ? 4 : 8;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) tv[q] = ld4g(base + (int64_t)lin[q] * C + 4 * (c4 < C4 ? c4 : C4 - 1));
+        for (int q0 = 0; q0 < 8; q0 += TB) {
+          float4 tv[TB];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {                    // (tap order 0..7 with ok-skips, as the stand-alone kernel)
-          if (okq[q]) { acc.x += tv[q].x * wgt[q]; acc.y += tv[q].y * wgt[q]; acc.z += tv[q].z * wgt[q]; acc.w += tv[q].w * wgt[q]; }
+          for (int q = 0; q < TB; ++q) tv[q] = ld4g(base + (int64_t)lin[q0 + q] * C + 4 * (c4 < C4 ? c4 : C4 - 1));
+#pragma unroll
+          for (int q = 0; q < TB; ++q) {                 // (tap order 0..7 with ok-skips, as the stand-alone kernel)
+            if (okq[q0 + q]) { acc.x += tv[q].x * wgt[q0 + q]; acc.y += tv[q].y * wgt[q0 + q]; acc.z += tv[q].z * wgt[q0 + q]; acc.w += tv[q].w * wgt[q0 + q]; }
+          }
         }
         kvv[pass][k] = (live && c4 < C4) ? acc : make_float4(0.f, 0.f, 0.f, 0.f);
       }
@@ -340,7 +346,7 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
 
   // ---- MLP in hidden chunks of <= 2C (<= 3C fits U): fc1 chunk (+ b1) -> U; save h, GELU in place, save g; fc2 chunk
   // accumulates s2 * (g W2^T) into A2 (which holds x1)
-  constexpr int HC = 2 * C;
+  constexpr int HC = block_hidden_chunk(C);
   for (int c0 = 0; c0 < Hd; c0 += HC) {
     constexpr int hc = HC;
     if (!(a.debug & 4)) gemm_phase<TJ, NSL, 1, C, NW, BF16>(w1 + (int64_t)c0 * C, hc, A1, nullptr, 0, nullptr, S, U, SU, EpiBias{p_b1 + c0});
@@ -362,7 +368,7 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
       }
     }
     lds_barrier();
-    if (!(a.debug & 4)) gemm_phase<TJ, NSL, 2, Hd, NW, BF16>(w2 + 16 * c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiAccScale{sc2});
+    if (!(a.debug & 4)) gemm_phase<TJ, NSL, HC / C, Hd, NW, BF16>(w2 + 16 * c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiAccScale{sc2});
   }
 
   // ---- y = x1 + s2 * (fc2 + b2)
@@ -442,8 +448,11 @@ extern "C" int micf_block_fuses_sampler(int C, int heads) {
 
 extern "C" int micf_block_recomputes_h(int C, int heads) {
   if (C <= 0 || heads <= 0 || C % heads || block_wide_tile_tokens(C, C / heads)) return 0;
-  const char* e = getenv("MICF_BLOCK_SAVE_H");
-  return (e && atoi(e) != 0) ? 0 : 1;
+  // opt-in: measured on MI355X (base shapes, bf16, batch 2) the extra GEMM phase costs more than the bytes save -- block_bwd
+  // 123 -> 135 us at 32^3, 45 -> 52 at 16^3, 34 -> 42 at 8^3, forward unchanged (its stores are fire-and-forget), step 10.35 ->
+  // 10.44 ms -- so the default stores h.  What the switch buys is MEMORY: 8 of the 34 bytes saved per element of T * C.
+  const char* e = getenv("MICF_BLOCK_RECOMPUTE_H");
+  return (e && atoi(e) != 0) ? 1 : 0;
 }
 
 extern "C" int micf_block_saves_bf16(int C, int heads, int dtype) {

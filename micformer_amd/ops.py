@@ -1042,7 +1042,7 @@ def block_saves_bf16(C, heads):
 
 def block_recomputes_h(C, heads):
     """True when block_bwd rebuilds the fc1 pre-activation from xn2 for this shape: block_fwd then does not store it
-    (include/micformer_hip.h micf_block_recomputes_h; MICF_BLOCK_SAVE_H=1 restores the stored form)."""
+    (include/micformer_hip.h micf_block_recomputes_h: opt-in with MICF_BLOCK_RECOMPUTE_H=1, a memory switch)."""
     return bool(_lib.lib.micf_block_recomputes_h(C, heads))
 
 

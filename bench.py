@@ -315,6 +315,8 @@ def main(argv=None):
         out["dist_backend"] = dist.get_backend() + (" (= RCCL over xGMI)" if dist.get_backend() == "nccl" else
                                                     " (plumbing check: NOT the RCCL / xGMI path, ranks may share a GPU)")
         out["distinct_local_devices"] = len({int(g.item()) for g in gathered})
+        if not stub:
+            out["grad_wire"] = "bf16" if eng.grad_bf16 else "fp32"          # wire format of the gradient all-reduce
     else:
         out["rccl_ranks"] = 1
     if probe:

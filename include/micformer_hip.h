@@ -42,6 +42,12 @@ typedef void* micf_stream_t; /* hipStream_t */
 #define MICF_DTYPE_F32 0  /* v_mfma_f32_16x16x4_f32: exact fp32 (bitwise a k-ordered fmaf chain) -- the parity mode */
 #define MICF_DTYPE_BF16 1 /* v_mfma_f32_16x16x32_bf16: operands rounded to bf16 (RNE) at the fragment read, fp32 accumulate;
                              residual stream, LayerNorm, softmax, GELU, loss and everything stored stay fp32 */
+#define MICF_DTYPE_BF16_ATTN_FP8 2 /* BASELINE config 4's leg: MICF_DTYPE_BF16 everywhere, except that the two products of window
+                             attention (q k^T and P v, forward) take e4m3 operands -- on the tile-per-workgroup and few-token block
+                             kernels as v_mfma_f32_16x16x32_fp8_fp8 on two windows x one head per tile (csrc/attn_fp8.h), on the per-op
+                             entry point as the same rounding on the VALU.  Accepted by micf_block_fwd and micf_window_attn_fwd_fp8
+                             only; every other entry point of a step in this mode is called with MICF_DTYPE_BF16.  The backward
+                             is the bf16 one (straight-through). */
 
 int micf_abi_version(void);
 const char* micf_strerror(int code);
@@ -157,6 +163,15 @@ int micf_head_tail_pack(const float* wb, const float* bf, const float* b_out, vo
                         int P, micf_stream_t stream);
 int micf_head_tail_fwd_fused(const float* x, const void* pack_fwd, float* y, int B, int Dc, int Hc, int Wc, int Ci, int Co,
                              int P, micf_stream_t stream);
+/* ... with MDiceLoss's forward (dice.py:130-166) in the logits store: every lane folds the terms of the logits it writes (target:
+ * one-hot float planes [B, 8, 4Dc, 4Hc, 4Wc], or target_is_label != 0 the uint8 class map [B, 4Dc, 4Hc, 4Wc]) into
+ * part [micf_head_tail_loss_parts(...)][32] floats; a one-workgroup finishing launch of the same call writes sums [8][4] (double:
+ * sum p t, sum p^2, sum t^2, sum bce per class -- what micf_dice_bce_bwd reads) and the scalar loss.  Replaces
+ * micf_head_tail_fwd_fused + micf_dice_bce_fwd: the logits are not re-read. */
+int64_t micf_head_tail_loss_parts(int B, int Dc, int Hc, int Wc);
+int micf_head_tail_fwd_loss_fused(const float* x, const void* pack_fwd, float* y, const void* target, int target_is_label,
+                                  float* part, double* sums, float* loss, int B, int Dc, int Hc, int Wc, int Ci, int Co, int P,
+                                  micf_stream_t stream);
 int micf_head_tail_bwd_data_fused(const float* dy, const void* pack_bwd, float* dx, int B, int Dc, int Hc, int Wc, int Ci,
                                   int Co, int P, micf_stream_t stream);
 /* dwb [216 * 8, Ci] / dbf [216 * 8] = the composed map's parameter gradient (OVERWRITTEN; feed micf_head_tail_decompose), reduced
@@ -172,6 +187,10 @@ int64_t micf_head_tail_bwd_weight_fused_workspace(int B, int Dc, int Hc, int Wc,
  * window_partition/reverse MS.py:37-50,117-132).  q [T,ldq], k/v [T,ldkv] (k = kv, v = kv + C), o [T,ldo].
  * D,H,W must be multiples of the window (the host pads, MS.py:345-350); window tokens <= 8. */
 int micf_window_attn_fwd(const float* q, int ldq, const float* k, const float* v, int ldkv, float* o, int ldo, int B,
+                         int D, int H, int W, int C, int heads, int wd, int wh, int ww, float scale,
+                         micf_stream_t stream);
+/* The same with e4m3-rounded operands of both products (MICF_DTYPE_BF16_ATTN_FP8 on the shapes micf_block_fwd does not take). */
+int micf_window_attn_fwd_fp8(const float* q, int ldq, const float* k, const float* v, int ldkv, float* o, int ldo, int B,
                          int D, int H, int W, int C, int heads, int wd, int wh, int ww, float scale,
                          micf_stream_t stream);
 int micf_window_attn_bwd(const float* q, int ldq, const float* k, const float* v, int ldkv, const float* d_o, int ldo,

@@ -54,6 +54,8 @@ SIGNATURES = {
     "micf_head_tail_pack_bytes": "ii",
     "micf_head_tail_pack": "pppppiiip",
     "micf_head_tail_fwd_fused": "pppiiiiiiip",
+    "micf_head_tail_loss_parts": "iiii",
+    "micf_head_tail_fwd_loss_fused": "ppppipppiiiiiiip",
     "micf_head_tail_bwd_data_fused": "pppiiiiiiip",
     "micf_head_tail_bwd_weight_fused": "pppppliiiiiiip",
     "micf_head_tail_bwd_weight_fused_workspace": "iiiii",
@@ -61,6 +63,7 @@ SIGNATURES = {
     "micf_sw_accumulate": "pppiiiiiiiiiip",
     "micf_sw_normalize": "ppilp",
     "micf_window_attn_fwd": "pippipiiiiiiiiiifp",
+    "micf_window_attn_fwd_fp8": "pippipiiiiiiiiiifp",
     "micf_window_attn_bwd": "pippipipippiiiiiiiiiifp",
     "micf_conv3_fwd": "pipipppiiiiiipliip",
     "micf_conv3_fwd_workspace": "iii",
@@ -224,6 +227,8 @@ def _load():
     lib.micf_conv3_bwd_weight_workspace.restype = _L
     lib.micf_conv3_bwd_weight_grouped_workspace.restype = _L
     lib.micf_head_tail_pack_bytes.restype = _L
+    lib.micf_head_tail_loss_parts.restype = _L
+    lib.micf_head_tail_loss_parts.argtypes = [_I] * 4
     lib.micf_head_tail_bwd_weight_fused_workspace.restype = _L
     lib.micf_conv3_fwd_workspace.restype = _L
     lib.micf_offset_head_bwd_workspace.restype = _L

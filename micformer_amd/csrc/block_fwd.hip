@@ -15,6 +15,7 @@
 #include <cstdlib>
 
 #include "block_fused.h"
+#include "attn_fp8.h"
 
 namespace micf {
 
@@ -22,6 +23,7 @@ struct BlkFwdArgs {
   micf_block_fwd_group g[2];
   TileGeo geo;
   int G, tiles, C, heads, hidden, debug;
+  int att8;                 // MICF_DTYPE_BF16_ATTN_FP8: QK^T / AV on the matrix cores with e4m3 operands (attn_fp8.h)
   float eps, scale;
 };
 
@@ -230,7 +232,22 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
   // ---- attention per (row, head): the 8x8 score row lives in registers; o -> A1 (xn is no longer needed) + HBM.  Where a tile
   // has fewer (row, head) pairs than half the workgroup, 2 or 4 adjacent lanes share a pair (HD / 2 or HD / 4 channels each; the
   // partial scores meet in cross-lane adds).
-  if (!(a.debug & 2)) {
+  if (BF16 && a.att8) {
+    // fp8 attention: unit = (16-token group = 2 windows, head), dealt to the waves; every lane of a wave works on its unit
+    constexpr int heads = C / HD;
+    for (int unit = wave; unit < TJ * heads; unit += NW) {
+      const int gq = unit / heads, hh = unit - gq * heads, hoff = hh * HD;
+      const float* base = U + gq * 16 * SU + hoff;
+      float4 ov[HD / 16];
+      attn16_fp8<HD>(base, base + C, base + 2 * C, SU, a.scale, ov);
+      const int row = gq * 16 + l16, tk = tok[row];
+#pragma unroll
+      for (int cb = 0; cb < HD / 16; ++cb) {
+        *reinterpret_cast<float4*>(A1 + row * S + hoff + 16 * cb + 4 * rg) = ov[cb];
+        if (tk >= 0 && save) st_h4<BF16>(g.o, (int64_t)tk * C + hoff + 16 * cb + 4 * rg, ov[cb]);
+      }
+    }
+  } else if (!(a.debug & 2)) {
     constexpr int heads = C / HD, SP = (TM * heads * 4 <= NTHR && HD >= 16) ? 4 : (TM * heads * 2 <= NTHR) ? 2 : 1, HP = HD / SP;
     // (whole waves rotated per workgroup like the GEMM units: with fewer items than threads the last waves = SIMDs stay idle)
     const int vt = (tid + 64 * (int)((blockIdx.x * 2654435761u) >> 20)) & (NTHR - 1);
@@ -465,8 +482,11 @@ extern "C" int micf_block_fwd(const micf_block_fwd_group* groups, int ngroups, i
   if (!groups || ngroups < 1 || ngroups > 2) return MICF_EINVAL;
   const int TM = micf_block_tile_tokens(B, D, H, W, C, heads, hidden, 0);
   if (TM == 0) return MICF_EUNSUPPORTED;
+  const int att8 = dtype == MICF_DTYPE_BF16_ATTN_FP8;
+  if (att8) dtype = MICF_DTYPE_BF16;                     // everything but the two attention products is the bf16 mode
   if (dtype != MICF_DTYPE_F32 && dtype != MICF_DTYPE_BF16) return MICF_EINVAL;
   BlkFwdArgs a;
+  a.att8 = att8;
   for (int i = 0; i < ngroups; ++i) {
     const micf_block_fwd_group& g = groups[i];
     const void* need[] = {g.x, g.ln1_g, g.ln1_b, g.wq, g.bq, g.wkv, g.bkv, g.wp, g.bp, g.ln2_g, g.ln2_b, g.w1, g.b1, g.w2, g.b2,
@@ -492,7 +512,7 @@ extern "C" int micf_block_fwd(const micf_block_fwd_group* groups, int ngroups, i
   a.debug = dbg ? atoi(dbg) : 0;
   hipStream_t s = (hipStream_t)stream;
   const int hd = C / heads, tj = TM / 16;
-  if (block_wide_tile_tokens(C, hd)) return block_fwd_wide(groups, ngroups, B, D, H, W, C, heads, eps, scale, dtype, s);
+  if (block_wide_tile_tokens(C, hd)) return block_fwd_wide(groups, ngroups, B, D, H, W, C, heads, eps, scale, att8 ? MICF_DTYPE_BF16_ATTN_FP8 : dtype, s);
 #define MICF_BF(C_, HD_, TJ_) if (C == C_ && hd == HD_ && tj == TJ_) return launch_fwd<C_, HD_, TJ_>(a, dtype, s)
   MICF_BF(48, 16, 2); MICF_BF(48, 16, 1); MICF_BF(48, 16, 4); MICF_BF(96, 16, 1); MICF_BF(96, 16, 2); MICF_BF(192, 16, 1);
   MICF_BF(96, 32, 1); MICF_BF(192, 32, 1);

@@ -25,6 +25,7 @@
 #include <cstdlib>
 
 #include "block_fused.h"
+#include "attn_fp8.h"
 
 namespace micf {
 namespace wide {
@@ -189,7 +190,7 @@ template <int C, bool BF16> __device__ __forceinline__ void ln_partials(const fl
   }
 }
 
-struct FwdArgs { micf_block_fwd_group g[2]; TileGeo geo; int G, tiles; float eps, scale; };
+struct FwdArgs { micf_block_fwd_group g[2]; TileGeo geo; int G, tiles; float eps, scale; int att8; };   // att8: attn_fp8.h
 struct BwdArgs { micf_block_bwd_group g[2]; TileGeo geo; int G, tiles; float scale; };
 
 // ---------------------------------------------------------------------------------------------------------------- forward
@@ -252,7 +253,14 @@ __global__ void __launch_bounds__(256) f1_kernel(const FwdArgs a) {
     }
   }
   __syncthreads();
-  if (lane < 16 && row.ok) {                                          // attention row = lane (li == lane): 8 keys of its window
+  if (BF16 && a.att8) {                                               // e4m3 operands on the matrix cores: the wave's (tile, head) is one unit
+    float4 ov[HD / 16];
+    attn16_fp8<HD>(&sm[wave][0][0][0], &sm[wave][1][0][0], &sm[wave][2][0][0], QS, a.scale, ov);
+    if (row.ok) {
+#pragma unroll
+      for (int cb = 0; cb < HD / 16; ++cb) st4g(g.o + (int64_t)row.tk * C + head * HD + 16 * cb + 4 * lr, ov[cb]);
+    }
+  } else if (lane < 16 && row.ok) {                                   // attention row = lane (li == lane): 8 keys of its window
     const int r0 = lane & ~7;
     float qr[HD];
 #pragma unroll
@@ -675,8 +683,9 @@ int block_fwd_wide(const micf_block_fwd_group* groups, int ngroups, int B, int D
   a.geo = make_tile_geo(B, D, H, W);
   a.G = ngroups; a.eps = eps; a.scale = scale;
   a.tiles = (a.geo.nwin + 1) / 2;
+  a.att8 = dtype == MICF_DTYPE_BF16_ATTN_FP8;
   const int hd = C / heads;
-  const bool bf = dtype == MICF_DTYPE_BF16;
+  const bool bf = dtype == MICF_DTYPE_BF16 || a.att8;
   MICF_WIDE_DISPATCH(wide::launch_fwd, a, s);
   return MICF_EUNSUPPORTED;
 }

@@ -18,6 +18,7 @@
 // fp32 (parity) mode keeps head_tail.hip's path.
 #include "common.h"
 #include "gemm_dma.h"
+#include "loss_terms.h"
 
 namespace micf {
 
@@ -186,11 +187,15 @@ __device__ __forceinline__ void fwd_step(FwdState<CI>& st) {
   }
 }
 
-template <int CI>
+// LOSS: 0 = logits only; 1 = + partial loss sums against one-hot float planes [B, 8, Df, Hf, Wf]; 2 = against the uint8 class map
+// [B, Df, Hf, Wf].  part: [workgroups][8 classes][4] floats {sum p t, sum p^2, sum t^2, sum bce} (summed by dice_bce_finish_kernel).
+template <int CI, int LOSS>
 __global__ void __launch_bounds__(256, (CI <= 96 ? 2 : 1)) tail_fwd_fused_kernel(const float* __restrict__ x, const uint16_t* __restrict__ wpf,
-                                                             float* __restrict__ y, int B, int Dc, int Hc, int Wc) {
+                                                             float* __restrict__ y, int B, int Dc, int Hc, int Wc,
+                                                             const void* __restrict__ target, float* __restrict__ part) {
   constexpr int KS = CI / 32, RS = CI + kXPad, V4 = CI / 4, ROWS = 3 * 6 * 18;
   extern __shared__ __attribute__((aligned(16))) uint16_t Xs[];       // [3][6][18][RS]
+  __shared__ float loss_red[LOSS != 0 ? 4 : 1][8][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lr = lane >> 4;
   // XCD-aware order: workgroups go to the 8 XCDs round-robin by id; each XCD gets a CONTIGUOUS eighth of the tiles, so the halo
   // rows neighbouring tiles share are fetched into that XCD's L2 once (round-robin order: every XCD fetched its own copy, 3-5x the bytes)
@@ -259,17 +264,84 @@ __global__ void __launch_bounds__(256, (CI <= 96 ? 2 : 1)) tail_fwd_fused_kernel
     fwd_issue_b<CI, 0>(st);
     fwd_step<CI, 0>(st);
     // ---- logits: lane (li, lr) holds, per tile, the 4 fine voxels w = 4 (qw0 + li) .. + 3 of class 4 og + lr
+    const int o = 4 * og + lr;
+    LossAcc la{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int rdi = 0; rdi < 2; ++rdi)
+    for (int rdi = 0; rdi < 2; ++rdi) {
+      // (loss: the 8 target quads of this rd are requested together, then consumed store by store)
+      float4 tq[LOSS == 1 ? 2 : 1][LOSS == 1 ? 4 : 1];
+      unsigned lq[LOSS == 2 ? 2 : 1][LOSS == 2 ? 4 : 1];          // (class map: the 4 label bytes, expanded where they are used)
+      if constexpr (LOSS != 0) {
+#pragma unroll
+        for (int rhi = 0; rhi < 2; ++rhi)
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const int ud = 4 * qd + st.rd_of[rdi], uh = 4 * (qh0 + m) + st.rh_of[rhi];
+            if constexpr (LOSS == 1) {
+              tq[rhi][m] = *reinterpret_cast<const float4*>(static_cast<const float*>(target) +
+                                                            ((((int64_t)b * 8 + o) * Df + ud) * Hf + uh) * Wf + 4 * (qw0 + li));
+            } else {
+              lq[rhi][m] = *reinterpret_cast<const unsigned*>(static_cast<const uint8_t*>(target) +
+                                                              (((int64_t)b * Df + ud) * Hf + uh) * Wf + 4 * (qw0 + li));
+            }
+          }
+      }
 #pragma unroll
       for (int rhi = 0; rhi < 2; ++rhi)
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-          const int o = 4 * og + lr, ud = 4 * qd + st.rd_of[rdi], uh = 4 * (qh0 + m) + st.rh_of[rhi];
+          const int ud = 4 * qd + st.rd_of[rdi], uh = 4 * (qh0 + m) + st.rh_of[rhi];
           float* dst = y + ((((int64_t)b * 8 + o) * Df + ud) * Hf + uh) * Wf + 4 * (qw0 + li);
           const f32x4 v = st.acc[rdi][rhi][m];
           *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+          if constexpr (LOSS == 1) {
+            const float4 t = tq[rhi][m];
+            la.term(v[0], t.x); la.term(v[1], t.y); la.term(v[2], t.z); la.term(v[3], t.w);
+          } else if constexpr (LOSS == 2) {
+            const unsigned l4 = lq[rhi][m], oo = (unsigned)o;
+            la.term(v[0], (l4 & 255u) == oo ? 1.f : 0.f); la.term(v[1], ((l4 >> 8) & 255u) == oo ? 1.f : 0.f);
+            la.term(v[2], ((l4 >> 16) & 255u) == oo ? 1.f : 0.f); la.term(v[3], (l4 >> 24) == oo ? 1.f : 0.f);
+          }
         }
+    }
+    if constexpr (LOSS != 0) {
+      // the 16 lanes of a row group hold the same class: fold them, then lane li == 0 of each group leaves the wave's share in LDS
+#pragma unroll
+      for (int dlt = 1; dlt < 16; dlt <<= 1) {
+        la.a += __shfl_xor(la.a, dlt, 64); la.b += __shfl_xor(la.b, dlt, 64);
+        la.c += __shfl_xor(la.c, dlt, 64); la.d += __shfl_xor(la.d, dlt, 64);
+      }
+      if (li == 0) {
+        float* r = &loss_red[wave][o][0];
+        r[0] = la.a; r[1] = la.b; r[2] = la.c; r[3] = la.d;
+      }
+    }
+  }
+  if constexpr (LOSS != 0) {
+    __syncthreads();
+    if (tid < 32) part[(int64_t)blockIdx.x * 32 + tid] = (loss_red[0][tid >> 2][tid & 3] + loss_red[1][tid >> 2][tid & 3]) +
+                                                        (loss_red[2][tid >> 2][tid & 3] + loss_red[3][tid >> 2][tid & 3]);
+  }
+}
+
+// sums[class][4] (double) = sum over the workgroups' partial rows; loss = (0.7 sum_c dice_c + 0.3 sum_c bce_c / count) / K.
+// One workgroup of 256 threads: 8 threads per (class, quantity), double accumulation.
+__global__ void __launch_bounds__(256) dice_bce_finish_kernel(const float* __restrict__ part, int nparts, double* __restrict__ sums,
+                                                              float* __restrict__ loss, double count) {
+  __shared__ double acc[32];
+  const int e = threadIdx.x >> 3, sub = threadIdx.x & 7;
+  double s = 0.0;
+  for (int i = sub; i < nparts; i += 8) s += (double)part[(int64_t)i * 32 + e];
+  s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+  if (sub == 0) { acc[e] = s; sums[e] = s; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double dice = 0.0, ce = 0.0;
+    for (int i = 0; i < 8; ++i) {
+      dice += 1.0 - (2.0 * acc[i * 4 + 0] + 1.0) / (acc[i * 4 + 1] + acc[i * 4 + 2] + 1.0);
+      ce += acc[i * 4 + 3] / count;
+    }
+    *loss = (float)((0.7 * dice + 0.3 * ce) / 8.0);
   }
 }
 
@@ -586,20 +658,50 @@ extern "C" int micf_head_tail_pack(const float* wb, const float* bf, const float
   MICF_RETURN_LAUNCH();
 }
 
-extern "C" int micf_head_tail_fwd_fused(const float* x, const void* pack_fwd, float* y, int B, int Dc, int Hc, int Wc, int Ci,
-                                        int Co, int P, micf_stream_t stream) {
+template <int CI, int LOSS>
+static void launch_tail_fwd(dim3 grid, hipStream_t s, const float* x, const uint16_t* wp, float* y, int B, int Dc, int Hc, int Wc,
+                            const void* target, float* part) {
+  static std::once_flag once;
+  std::call_once(once, [] { allow_lds(&tail_fwd_fused_kernel<CI, LOSS>, 324 * (CI + kXPad) * 2); });
+  hipLaunchKernelGGL((tail_fwd_fused_kernel<CI, LOSS>), grid, dim3(256), 324 * (CI + kXPad) * 2, s, x, wp, y, B, Dc, Hc, Wc, target, part);
+}
+
+static int tail_fwd_any(const float* x, const void* pack_fwd, float* y, const void* target, int target_is_label, float* part, int B,
+                        int Dc, int Hc, int Wc, int Ci, int Co, int P, hipStream_t s) {
   if (!x || !pack_fwd || !y || B <= 0) return MICF_EINVAL;
   if (!fused_ok(Dc, Hc, Wc, Ci, Co, P) || !aligned16(x) || !aligned16(y) || !aligned16(pack_fwd)) return MICF_EUNSUPPORTED;
-  static std::once_flag once;
-  std::call_once(once, [] {
-    allow_lds(&tail_fwd_fused_kernel<96>, 324 * (96 + kXPad) * 2);
-    allow_lds(&tail_fwd_fused_kernel<192>, 324 * (192 + kXPad) * 2);
-  });
   const dim3 grid((unsigned)((int64_t)B * Dc * (Hc / 4) * (Wc / 16)));
   const uint16_t* wp = reinterpret_cast<const uint16_t*>(pack_fwd);
+  const int loss = target ? (target_is_label ? 2 : 1) : 0;
+#define MICF_TF(CI_) do { if (loss == 0) launch_tail_fwd<CI_, 0>(grid, s, x, wp, y, B, Dc, Hc, Wc, nullptr, nullptr); \
+                         else if (loss == 1) launch_tail_fwd<CI_, 1>(grid, s, x, wp, y, B, Dc, Hc, Wc, target, part); \
+                         else launch_tail_fwd<CI_, 2>(grid, s, x, wp, y, B, Dc, Hc, Wc, target, part); } while (0)
+  if (Ci == 96) MICF_TF(96); else MICF_TF(192);
+#undef MICF_TF
+  MICF_RETURN_LAUNCH();
+}
+
+extern "C" int micf_head_tail_fwd_fused(const float* x, const void* pack_fwd, float* y, int B, int Dc, int Hc, int Wc, int Ci,
+                                        int Co, int P, micf_stream_t stream) {
+  return tail_fwd_any(x, pack_fwd, y, nullptr, 0, nullptr, B, Dc, Hc, Wc, Ci, Co, P, (hipStream_t)stream);
+}
+
+extern "C" int64_t micf_head_tail_loss_parts(int B, int Dc, int Hc, int Wc) {
+  if (B <= 0 || Dc <= 0 || Hc <= 0 || Wc <= 0 || Hc % 4 || Wc % 16) return 0;
+  return (int64_t)B * Dc * (Hc / 4) * (Wc / 16);
+}
+
+extern "C" int micf_head_tail_fwd_loss_fused(const float* x, const void* pack_fwd, float* y, const void* target, int target_is_label,
+                                             float* part, double* sums, float* loss, int B, int Dc, int Hc, int Wc, int Ci, int Co,
+                                             int P, micf_stream_t stream) {
+  if (!target || !part || !sums || !loss) return MICF_EINVAL;
+  if (!aligned16(target) || !aligned16(part)) return MICF_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
-  if (Ci == 96) hipLaunchKernelGGL(tail_fwd_fused_kernel<96>, grid, dim3(256), 324 * (96 + kXPad) * 2, s, x, wp, y, B, Dc, Hc, Wc);
-  else hipLaunchKernelGGL(tail_fwd_fused_kernel<192>, grid, dim3(256), 324 * (192 + kXPad) * 2, s, x, wp, y, B, Dc, Hc, Wc);
+  const int rc = tail_fwd_any(x, pack_fwd, y, target, target_is_label, part, B, Dc, Hc, Wc, Ci, Co, P, s);
+  if (rc != MICF_OK) return rc;
+  const int nparts = (int)micf_head_tail_loss_parts(B, Dc, Hc, Wc);
+  const double count = (double)B * 64.0 * Dc * Hc * Wc;                 // elements of one class channel over the batch (P = 4)
+  hipLaunchKernelGGL(dice_bce_finish_kernel, dim3(1), dim3(256), 0, s, part, nparts, sums, loss, count);
   MICF_RETURN_LAUNCH();
 }
 

@@ -1,6 +1,7 @@
 // loss_optim.hip -- MDiceLoss forward/backward (dice.py:130-166), argmax + meandice (train.py:305, 392-407) and the
 // fused Adam + cosine-LR step (train.py:114, 148, 200-207) as HBM-streaming kernels.
 #include "common.h"
+#include "loss_terms.h"
 
 namespace micf {
 
@@ -17,24 +18,27 @@ __global__ void __launch_bounds__(256) dice_bce_partial_kernel(const float* __re
   const float* zp = z + (int64_t)plane * V;
   const float* tp = static_cast<const float*>(tv) + (int64_t)plane * V;
   const uint8_t* lp8 = static_cast<const uint8_t*>(tv) + (int64_t)(plane / K) * V;
-  float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
-  auto term = [&](float z1, float tt) {
-    const float p = 1.0f / (1.0f + expf(-z1));            // torch.sigmoid
-    a += p * tt; b += p * p; c += tt * tt;
-    // nn.BCELoss on the sigmoid output: log clamped at -100
-    const float lp = fmaxf(logf(p), -100.f), lq = fmaxf(logf(1.0f - p), -100.f);
-    d -= tt * lp + (1.0f - tt) * lq;
-  };
+  // (the terms on the hardware exp / log / rcp, loss_terms.h: the libm forms made this reduction VALU-bound -- 71 us for 268 MB at
+  //  128^3 x 8 x 2 -- and two independent 16-byte load pairs per iteration keep more than one HBM round trip in flight)
+  LossAcc la{0.f, 0.f, 0.f, 0.f};
   // 16-byte accesses where the plane and the chunk allow it (V and the chunk length multiples of 4: every training shape)
   const bool vec = !LABEL && (V & 3) == 0 && (per & 3) == 0 && ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(tv)) & 15) == 0;
   if (vec) {
-    for (int64_t i = v0 + 4 * threadIdx.x; i < v1; i += 1024) {
+    int64_t i = v0 + 4 * threadIdx.x;
+    for (; i + 1024 < v1; i += 2048) {
       const float4 z4 = *reinterpret_cast<const float4*>(zp + i), t4 = *reinterpret_cast<const float4*>(tp + i);
-      term(z4.x, t4.x); term(z4.y, t4.y); term(z4.z, t4.z); term(z4.w, t4.w);
+      const float4 y4 = *reinterpret_cast<const float4*>(zp + i + 1024), u4 = *reinterpret_cast<const float4*>(tp + i + 1024);
+      la.term(z4.x, t4.x); la.term(z4.y, t4.y); la.term(z4.z, t4.z); la.term(z4.w, t4.w);
+      la.term(y4.x, u4.x); la.term(y4.y, u4.y); la.term(y4.z, u4.z); la.term(y4.w, u4.w);
+    }
+    for (; i < v1; i += 1024) {
+      const float4 z4 = *reinterpret_cast<const float4*>(zp + i), t4 = *reinterpret_cast<const float4*>(tp + i);
+      la.term(z4.x, t4.x); la.term(z4.y, t4.y); la.term(z4.z, t4.z); la.term(z4.w, t4.w);
     }
   } else {
-    for (int64_t i = v0 + threadIdx.x; i < v1; i += 256) term(zp[i], LABEL ? (lp8[i] == ch ? 1.f : 0.f) : tp[i]);
+    for (int64_t i = v0 + threadIdx.x; i < v1; i += 256) la.term(zp[i], LABEL ? (lp8[i] == ch ? 1.f : 0.f) : tp[i]);
   }
+  float a = la.a, b = la.b, c = la.c, d = la.d;
   a = wave_sum(a); b = wave_sum(b); c = wave_sum(c); d = wave_sum(d);
   __shared__ float part[4][4];
   const int wave = threadIdx.x >> 6;

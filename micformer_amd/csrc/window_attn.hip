@@ -5,6 +5,7 @@
 // The QK^T / PV products are 8 x hd x 8 per head-window (0.86 % of the model's FLOPs): they run on the VALU; the
 // kernel is bound by the q/k/v/o token traffic, which each token row is read for once from HBM (window mates hit L1).
 #include "common.h"
+#include "attn_fp8.h"
 
 namespace micf {
 
@@ -51,7 +52,10 @@ __device__ __forceinline__ void load_row(float* dst, const float* src) {
   }
 }
 
-template <int HD>   // HD > 0: compile-time head dim (multiple of 4, float4 loads); HD == 0: runtime, scalar loads
+// Q8 (MICF_DTYPE_BF16_ATTN_FP8 on the shapes the block kernels do not take): the operands of both products -- q * scale, k, v and
+// P -- are rounded to e4m3 where the matrix-core path rounds them (attn_fp8.h); the products of two e4m3 values are exact in fp32,
+// so this is the same arithmetic up to the order of the fp32 sums.
+template <int HD, bool Q8 = false>   // HD > 0: compile-time head dim (multiple of 4, float4 loads); HD == 0: runtime, scalar loads
 __global__ void __launch_bounds__(256) wattn_fwd_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
                                                         const float* __restrict__ v, int ldkv, float* __restrict__ o,
                                                         int ldo, WinGeo g, float scale, int64_t nwin) {
@@ -69,7 +73,7 @@ __global__ void __launch_bounds__(256) wattn_fwd_kernel(const float* __restrict_
     float qr[HD];
     load_row<HD>(qr, q + (int64_t)ti * ldq + hoff);
 #pragma unroll
-    for (int d = 0; d < HD; ++d) qr[d] *= scale;
+    for (int d = 0; d < HD; ++d) qr[d] = Q8 ? round_fp8(qr[d] * scale) : qr[d] * scale;
 #pragma unroll
     for (int j = 0; j < kMaxWin; ++j) {
       s[j] = -INFINITY;
@@ -78,7 +82,7 @@ __global__ void __launch_bounds__(256) wattn_fwd_kernel(const float* __restrict_
         load_row<HD>(kr, k + (int64_t)tok[j] * ldkv + hoff);
         float acc = 0.f;
 #pragma unroll
-        for (int d = 0; d < HD; ++d) acc += qr[d] * kr[d];
+        for (int d = 0; d < HD; ++d) acc += qr[d] * (Q8 ? round_fp8(kr[d]) : kr[d]);
         s[j] = acc;
         mx = fmaxf(mx, acc);
       }
@@ -91,7 +95,7 @@ __global__ void __launch_bounds__(256) wattn_fwd_kernel(const float* __restrict_
       if (j < g.N) {
         const float* kp = k + (int64_t)tok[j] * ldkv + hoff;
         float acc = 0.f;
-        for (int d = 0; d < hd; ++d) acc += (qp[d] * scale) * kp[d];
+        for (int d = 0; d < hd; ++d) acc += Q8 ? round_fp8(qp[d] * scale) * round_fp8(kp[d]) : (qp[d] * scale) * kp[d];
         s[j] = acc;
         mx = fmaxf(mx, acc);
       }
@@ -114,9 +118,9 @@ __global__ void __launch_bounds__(256) wattn_fwd_kernel(const float* __restrict_
       if (j < g.N) {
         float vr[HD];
         load_row<HD>(vr, v + (int64_t)tok[j] * ldkv + hoff);
-        const float p = s[j] * inv;
+        const float p = Q8 ? round_fp8(s[j] * inv) : s[j] * inv;
 #pragma unroll
-        for (int d = 0; d < HD; ++d) acc[d] += p * vr[d];
+        for (int d = 0; d < HD; ++d) acc[d] += p * (Q8 ? round_fp8(vr[d]) : vr[d]);
       }
     }
 #pragma unroll
@@ -124,7 +128,8 @@ __global__ void __launch_bounds__(256) wattn_fwd_kernel(const float* __restrict_
   } else {
     for (int d = 0; d < hd; ++d) {
       float acc = 0.f;
-      for (int j = 0; j < g.N; ++j) acc += s[j] * inv * v[(int64_t)tok[j] * ldkv + hoff + d];
+      for (int j = 0; j < g.N; ++j)
+        acc += Q8 ? round_fp8(s[j] * inv) * round_fp8(v[(int64_t)tok[j] * ldkv + hoff + d]) : s[j] * inv * v[(int64_t)tok[j] * ldkv + hoff + d];
       op[d] = acc;
     }
   }
@@ -387,9 +392,23 @@ static int make_geo(WinGeo& g, int B, int D, int H, int W, int C, int heads, int
 }  // namespace micf
 using namespace micf;
 
+static int window_attn_fwd_impl(const float* q, int ldq, const float* k, const float* v, int ldkv, float* o, int ldo, int B, int D, int H,
+                                int W, int C, int heads, int wd, int wh, int ww, float scale, bool q8, micf_stream_t stream);
+
 extern "C" int micf_window_attn_fwd(const float* q, int ldq, const float* k, const float* v, int ldkv, float* o, int ldo,
                                     int B, int D, int H, int W, int C, int heads, int wd, int wh, int ww, float scale,
                                     micf_stream_t stream) {
+  return window_attn_fwd_impl(q, ldq, k, v, ldkv, o, ldo, B, D, H, W, C, heads, wd, wh, ww, scale, false, stream);
+}
+
+extern "C" int micf_window_attn_fwd_fp8(const float* q, int ldq, const float* k, const float* v, int ldkv, float* o, int ldo,
+                                        int B, int D, int H, int W, int C, int heads, int wd, int wh, int ww, float scale,
+                                        micf_stream_t stream) {
+  return window_attn_fwd_impl(q, ldq, k, v, ldkv, o, ldo, B, D, H, W, C, heads, wd, wh, ww, scale, true, stream);
+}
+
+static int window_attn_fwd_impl(const float* q, int ldq, const float* k, const float* v, int ldkv, float* o, int ldo, int B, int D, int H,
+                                int W, int C, int heads, int wd, int wh, int ww, float scale, bool q8, micf_stream_t stream) {
   if (!q || !k || !v || !o) return MICF_EINVAL;
   WinGeo g;
   int rc = make_geo(g, B, D, H, W, C, heads, wd, wh, ww);
@@ -399,10 +418,13 @@ extern "C" int micf_window_attn_fwd(const float* q, int ldq, const float* k, con
   const bool vec = (g.hd % 4 == 0) && (ldq % 4 == 0) && (ldkv % 4 == 0) && (ldo % 4 == 0) && aligned16(q) &&
                    aligned16(k) && aligned16(v) && aligned16(o);
   hipStream_t s = (hipStream_t)stream;
-  if (vec && g.hd == 16) hipLaunchKernelGGL(wattn_fwd_kernel<16>, grid, dim3(256), 0, s, q, ldq, k, v, ldkv, o, ldo, g, scale, nwin);
-  else if (vec && g.hd == 8) hipLaunchKernelGGL(wattn_fwd_kernel<8>, grid, dim3(256), 0, s, q, ldq, k, v, ldkv, o, ldo, g, scale, nwin);
-  else if (vec && g.hd == 32) hipLaunchKernelGGL(wattn_fwd_kernel<32>, grid, dim3(256), 0, s, q, ldq, k, v, ldkv, o, ldo, g, scale, nwin);
-  else hipLaunchKernelGGL(wattn_fwd_kernel<0>, grid, dim3(256), 0, s, q, ldq, k, v, ldkv, o, ldo, g, scale, nwin);
+#define MICF_WF(HD_) do { if (q8) hipLaunchKernelGGL((wattn_fwd_kernel<HD_, true>), grid, dim3(256), 0, s, q, ldq, k, v, ldkv, o, ldo, g, scale, nwin); \
+                         else hipLaunchKernelGGL((wattn_fwd_kernel<HD_, false>), grid, dim3(256), 0, s, q, ldq, k, v, ldkv, o, ldo, g, scale, nwin); } while (0)
+  if (vec && g.hd == 16) MICF_WF(16);
+  else if (vec && g.hd == 8) MICF_WF(8);
+  else if (vec && g.hd == 32) MICF_WF(32);
+  else MICF_WF(0);
+#undef MICF_WF
   MICF_RETURN_LAUNCH();
 }
 

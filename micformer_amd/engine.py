@@ -24,7 +24,7 @@ class TrainEngine:
     def __init__(self, model, base_lr=1e-4, t_max=150, eta_min=0.0, betas=(0.9, 0.999), eps=1e-8, criterion=None,
                  use_graph=False, process_group=None, grad_bucket_bytes=64 << 20, parallel_modalities=True,
                  defer_wgrad=True, split_step=None, always_collective=False, flush_points=True, early_adam=True,
-                 dp_graph_flushes=6, grad_bf16=False, segmented=None):
+                 dp_graph_flushes=6, grad_bf16=None, segmented=None):
         self.model = model
         self.criterion = criterion if criterion is not None else MDiceLoss()
         self.base_lr, self.t_max, self.eta_min = base_lr, t_max, eta_min
@@ -51,8 +51,14 @@ class TrainEngine:
         # (encoder) weight-gradient groups that are launched after the replay.  Measured on one GPU (data-parallel layout):
         # 0 -> 13.3 ms, 4 -> 12.9, 6 -> 12.8, all -> 12.7 (but then nothing is left to hide RCCL behind).
         self.dp_graph_flushes = int(__import__("os").environ.get("MICF_DP_GRAPH_FLUSHES", dp_graph_flushes))
-        # Optional bf16 wire format of the gradient exchange (123 MB instead of 247 MB per step at base): each slice is rounded
-        # to bf16, sum-reduced, widened back; Adam still reads fp32.  Off by default (the fp32 exchange is exact).
+        # bf16 wire format of the gradient exchange (123 MB instead of 247 MB per step at base): each slice is rounded to bf16,
+        # sum-reduced, widened back; Adam still reads fp32.  Default (None): ON for world > 1 in the bf16 arithmetic mode -- the
+        # budget of tools/dp_budget.py: at 8 ranks the fp32 exchange is ~1.65 ms of ring time against ~1 ms of
+        # post-replay launches to hide it behind (7.4 x of 8), the bf16 one ~0.93 ms (7.6-7.7 x); the gradients of this mode
+        # already carry bf16 operand rounding, and the 2-rank test holds the result within 2^-7 of the fp32 exchange.  The fp32
+        # parity mode keeps the exact fp32 exchange.
+        if grad_bf16 is None:
+            grad_bf16 = self.world > 1 and ops.compute_dtype() == "bf16" and __import__("os").environ.get("MICF_GRAD_WIRE", "bf16") != "fp32"
         self.grad_bf16 = bool(grad_bf16)
         self._wire = torch.empty(self.flat_g.numel(), dtype=torch.bfloat16, device=self.flat_g.device) if self.grad_bf16 else None
         # Graph layout of a captured step: ONE HIP graph (round 2; where its side branch runs is the graph executor's choice) or
@@ -234,8 +240,14 @@ class TrainEngine:
                 _fn.BACKWARD_HOOKS[id(self._early_layer)] = self._early_adam_segment if _fn.SEGMENTER is not None else self._early_adam
             elif self._anchor_layer is not None and _fn.SEGMENTER is None:
                 _fn.BACKWARD_HOOKS[id(self._anchor_layer)] = self._side_anchor
-            logits = self.model(x)                                  #                              train.py:185
+            # (the plain MDiceLoss: its forward sums are folded into the head's logits store -- functional.LOSS_MAIL)
+            _fn.LOSS_MAIL["target"] = target if type(self.criterion) is MDiceLoss else None
+            try:
+                logits = self.model(x)                              #                              train.py:185
+            finally:
+                _fn.LOSS_MAIL["target"] = None
             loss = self.criterion(logits, target)                   #                              train.py:187
+            _fn.LOSS_MAIL["result"] = None
             _fn.run_entry_hook(force=True)                          # (fewer than 3 stages: launched here)
             main.wait_stream(side)
             if _fn.SEGMENTER is not None:
@@ -391,7 +403,7 @@ class TrainEngine:
     def _matches_static(self, x, target):
         sx, st = self._static[0], self._static[1]
         ok = x.shape == sx.shape and target.shape == st.shape and x.dtype == sx.dtype and target.dtype == st.dtype \
-            and self._static_mode == ops.compute_dtype()            # (the arithmetic mode is baked into the captured launches)
+            and self._static_mode == ops.arith_mode()            # (the arithmetic mode is baked into the captured launches)
         # a plain tensor and a data.RawBatch (and a RawBatch with / without augmentation draws) take different launches in the
         # patch embedding: the captured graph holds exactly one of them, anything else runs eagerly
         ok = ok and type(x) is type(sx) and (getattr(x, "params", None) is None) == (getattr(sx, "params", None) is None)
@@ -455,7 +467,7 @@ class TrainEngine:
         if self.split_step:
             from . import functional as _fn
             self._plan_split(*_fn.take_deferred())                  # (capture records, it does not run: step() replays next)
-        self._graph, self._static, self._static_mode = g, (sx, st, sl), ops.compute_dtype()
+        self._graph, self._static, self._static_mode = g, (sx, st, sl), ops.arith_mode()
 
     def _drop_path_rng_tensors(self, x):
         """The device-side DropPath RNG states ({seed, counter}) of the model, created now if the model is in train mode and has

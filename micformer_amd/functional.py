@@ -1314,6 +1314,14 @@ class OutConvFn(torch.autograd.Function):
 FUSE_TAIL_PATCHES = _os.environ.get("MICF_FUSE_TAIL", "1") != "0"
 
 
+# MDiceLoss's forward inside the head's logits store (SURVEY 8 row A19 as worded).  The reference's call shape stays
+# `loss = criterion(model(x), target)` (train.py:185-187): a caller that knows the target before the forward (TrainEngine) leaves it
+# here; HeadTailFn's fused forward then folds the Dice / BCE sums of every logit it stores and parks (logits, target, loss, sums);
+# DiceBCEFn picks the parked result up when it is handed exactly those two tensors, and computes it itself otherwise.
+LOSS_MAIL = {"target": None, "result": None}
+FUSE_LOSS = _os.environ.get("MICF_FUSE_LOSS", "1") != "0"
+
+
 class HeadTailFn(torch.autograd.Function):
     """reverse_patch_embedding (ConvTranspose3d 2E -> E/2, k = s = P; MS.py:1037) + Head.out_conv (Conv3d E/2 -> classes, 3,
     padding=1; MS.py:1053) composed into one linear map on the coarse grid (csrc/head_tail.hip): channels-last coarse
@@ -1332,7 +1340,20 @@ class HeadTailFn(torch.autograd.Function):
         if fused:                                       # bf16 mode: no T / U patch matrices (head_tail_fused.hip)
             if packs is None:
                 packs = ops.head_tail_pack(wb, bf, b_out, P)
-            y = ops.head_tail_fwd_fused(xf, packs[0], (B, Dc, Hc, Wc), b_out.shape[0], P)
+            Co = b_out.shape[0]
+            tgt = LOSS_MAIL["target"] if FUSE_LOSS else None
+            LOSS_MAIL["result"] = None
+            if tgt is not None:
+                from .loss.dice import as_target
+                tgt = as_target((B, Co, P * Dc, P * Hc, P * Wc), tgt)
+                want = (B, Co, P * Dc, P * Hc, P * Wc) if tgt.dtype != torch.uint8 else (B, P * Dc, P * Hc, P * Wc)
+                if tuple(tgt.shape) != want or not tgt.is_contiguous() or not tgt.is_cuda:
+                    tgt = None
+            if tgt is not None:
+                y, loss, sums = ops.head_tail_fwd_loss_fused(xf, packs[0], (B, Dc, Hc, Wc), Co, P, tgt)
+                LOSS_MAIL["result"] = (y, tgt, loss, sums)
+            else:
+                y = ops.head_tail_fwd_fused(xf, packs[0], (B, Dc, Hc, Wc), Co, P)
         else:
             packs = (None, None)
             t = ops.linear_fwd(xf, wb, bf)
@@ -1390,7 +1411,12 @@ class DiceBCEFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, target):
         logits, target = _c(logits), _c(target)
-        loss, sums = ops.dice_bce_fwd(logits, target)
+        parked, LOSS_MAIL["result"] = LOSS_MAIL["result"], None
+        if parked is not None and parked[0].data_ptr() == logits.data_ptr() and parked[0].shape == logits.shape \
+                and parked[1].data_ptr() == target.data_ptr() and parked[1].shape == target.shape and parked[1].dtype == target.dtype:
+            loss, sums = parked[2], parked[3]           # folded into the head's logits store (HeadTailFn)
+        else:
+            loss, sums = ops.dice_bce_fwd(logits, target)
         ctx.save_for_backward(logits, target, sums)
         return loss.reshape(())
 

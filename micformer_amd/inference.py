@@ -52,7 +52,7 @@ class GraphedPredictor:
         if getattr(self, "_epoch", None) != stamp:
             self.graphs.clear()
             self._epoch = stamp
-        key = (tuple(x.shape), x.dtype, ops.compute_dtype())
+        key = (tuple(x.shape), x.dtype, ops.arith_mode())
         entry = self.graphs.get(key)
         if entry is None:
             static_in = x.clone()
@@ -96,7 +96,7 @@ class GraphedPredictor:
         if getattr(self, "_epoch", None) != stamp:
             self.graphs.clear()
             self._epoch = stamp
-        key = ("acc", tuple(x.shape), x.dtype, ops.compute_dtype(), out.data_ptr(), count.data_ptr())
+        key = ("acc", tuple(x.shape), x.dtype, ops.arith_mode(), out.data_ptr(), count.data_ptr())
         entry = self.graphs.get(key)
         if entry is None:
             static_in, static_c = x.clone(), coords.clone()
@@ -164,7 +164,7 @@ def sliding_window_inference(inputs, roi_size, sw_batch_size, predictor, overlap
                 count = torch.empty((B, Dp, Hp, Wp), dtype=torch.float32, device=x.device)
             ops.zero_(out)
             ops.zero_(count)
-            prev = ops.compute_dtype()
+            prev = ops.arith_mode()
             if autocast:
                 ops.set_compute_dtype("bf16")
             try:
@@ -183,7 +183,7 @@ def sliding_window_inference(inputs, roi_size, sw_batch_size, predictor, overlap
             chunk = slices[i:i + sw]
             win = ops.sw_window_batch(x, chunk, (rd, rh, rw))                 # ONE launch crops the whole batch of windows
             if autocast:
-                prev = ops.compute_dtype()
+                prev = ops.arith_mode()
                 ops.set_compute_dtype("bf16")
                 try:
                     pred = predictor(win).float().contiguous()

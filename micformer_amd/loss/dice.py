@@ -11,11 +11,15 @@ from .. import functional as Fn
 from .. import ops
 
 
-def _as_target(inputs, target):
+def as_target(logits_shape, target):
     """float one-hot planes stay as they are; an integer class map (one dim fewer, or a singleton channel) becomes uint8."""
-    if not target.is_floating_point() and (target.dim() == inputs.dim() - 1 or target.shape[1] == 1 != inputs.shape[1]):
-        return target.reshape((target.shape[0],) + tuple(inputs.shape[2:])).to(torch.uint8)
+    if not target.is_floating_point() and (target.dim() == len(logits_shape) - 1 or target.shape[1] == 1 != logits_shape[1]):
+        return target.reshape((target.shape[0],) + tuple(logits_shape[2:])).to(torch.uint8)
     return target.float()
+
+
+def _as_target(inputs, target):
+    return as_target(tuple(inputs.shape), target)
 
 
 class MDiceLoss(nn.Module):

@@ -27,10 +27,31 @@ def _dt():
 
 
 def set_compute_dtype(name):
-    global _COMPUTE_DTYPE
-    if name not in ("fp32", "bf16"):
-        raise ValueError("compute dtype must be 'fp32' or 'bf16'")
-    _COMPUTE_DTYPE = name
+    """'fp32' (parity mode), 'bf16' (BASELINE config 2) or 'bf16+fp8attn' (BASELINE config 4's leg: bf16 mode with the two products
+    of window attention, q k^T and P v, on e4m3 operands -- MICF_DTYPE_BF16_ATTN_FP8; compute_dtype() still reads 'bf16', every
+    cache / shadow-weight key of the bf16 mode applies unchanged)."""
+    global _COMPUTE_DTYPE, _ATTN_FP8
+    if name not in ("fp32", "bf16", "bf16+fp8attn"):
+        raise ValueError("compute dtype must be 'fp32', 'bf16' or 'bf16+fp8attn'")
+    _ATTN_FP8 = name == "bf16+fp8attn"
+    _COMPUTE_DTYPE = "bf16" if _ATTN_FP8 else name
+
+
+_ATTN_FP8 = False
+
+
+def attention_fp8():
+    return _ATTN_FP8
+
+
+def arith_mode():
+    """The name set_compute_dtype() was last called with: what a captured graph bakes in (compute_dtype() + the attention flag)."""
+    return "bf16+fp8attn" if _ATTN_FP8 else _COMPUTE_DTYPE
+
+
+def _dt_attn():
+    """dtype argument of the entry points that contain the attention products."""
+    return 2 if _ATTN_FP8 else _dt()
 
 
 def _cost(flops, *tensors, tag=None):
@@ -273,7 +294,7 @@ def window_attn_fwd(q, kv, dims, heads, ws, scale):
     B, D, H, W = dims
     T, C = q.shape
     o = _new(q, T, C)
-    call("micf_window_attn_fwd", f32(q), C, f32(kv), kv.data_ptr() + 4 * C, 2 * C, f32(o), C, B, D, H, W, C, heads,
+    call("micf_window_attn_fwd_fp8" if _ATTN_FP8 else "micf_window_attn_fwd", f32(q), C, f32(kv), kv.data_ptr() + 4 * C, 2 * C, f32(o), C, B, D, H, W, C, heads,
          ws[0], ws[1], ws[2], float(scale),
          cost=_cost(4 * T * C * ws[0] * ws[1] * ws[2], q, kv, o))
     return o
@@ -297,7 +318,7 @@ def window_attn_fwd_qkv(qkv, dims, heads, ws, scale):
     C = C3 // 3
     o = _new(qkv, T, C)
     base = qkv.data_ptr()
-    call("micf_window_attn_fwd", base, C3, base + 4 * C, base + 8 * C, C3, f32(o), C, B, D, H, W, C, heads,
+    call("micf_window_attn_fwd_fp8" if _ATTN_FP8 else "micf_window_attn_fwd", base, C3, base + 4 * C, base + 8 * C, C3, f32(o), C, B, D, H, W, C, heads,
          ws[0], ws[1], ws[2], float(scale),
          cost=_cost(4 * T * C * ws[0] * ws[1] * ws[2], qkv, o))
     return o
@@ -653,6 +674,22 @@ def head_tail_fwd_fused(x, pack_fwd, dims, Co, P):
     call("micf_head_tail_fwd_fused", f32(x), ptr(pack_fwd), f32(y), B, Dc, Hc, Wc, Ci, Co, P,
          cost=_cost(2 * x.shape[0] * (P + 2) ** 3 * Co * Ci, x, y, tag=f"{x.shape[0]}x{Ci}"))
     return y
+
+
+def head_tail_fwd_loss_fused(x, pack_fwd, dims, Co, P, target):
+    """head_tail_fwd_fused + MDiceLoss's forward sums in the logits store (micf_head_tail_fwd_loss_fused).  target: float one-hot
+    planes (B, Co, 4Dc, 4Hc, 4Wc) or the uint8 class map (B, 4Dc, 4Hc, 4Wc).  -> (logits, loss [1], sums [Co*4] float64)."""
+    B, Dc, Hc, Wc = dims
+    Ci = x.shape[-1]
+    y = _new(x, B, Co, Dc * P, Hc * P, Wc * P)
+    nparts = int(_lib.lib.micf_head_tail_loss_parts(B, Dc, Hc, Wc))
+    part = _new(x, nparts, 32)
+    sums = _new(x, Co * 4, dtype=torch.float64)
+    loss = _new(x, 1)
+    call("micf_head_tail_fwd_loss_fused", f32(x), ptr(pack_fwd), f32(y), ptr(target), 1 if target.dtype == torch.uint8 else 0, f32(part),
+         ptr(sums), f32(loss), B, Dc, Hc, Wc, Ci, Co, P,
+         cost=_cost(2 * x.shape[0] * (P + 2) ** 3 * Co * Ci + 40 * y.numel(), x, y, target, tag=f"{x.shape[0]}x{Ci}"))
+    return y, loss, sums
 
 
 def head_tail_bwd_data_fused(dy, pack_bwd, dims, Ci, P):
@@ -1092,7 +1129,7 @@ def block_fwd(groups, dims, C, heads, eps, scale):
             + 12 * C * C * wt.element_size()
         fl += 2 * T * 12 * C * C + 4 * T * C * 8
     call("micf_block_fwd", ctypes.cast(arr, ctypes.c_void_p), len(groups), B, D, H, W, C, heads, hidden, float(eps), float(scale),
-         _dt(), cost=_block_cost(nb, fl, groups, T, C, hidden, 2, 3))
+         _dt_attn(), cost=_block_cost(nb, fl, groups, T, C, hidden, 2, 3))
     return outs
 
 

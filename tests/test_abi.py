@@ -34,11 +34,11 @@ def parse_header():
 
 def test_header_declares_expected_entry_points():
     d = parse_header()
-    assert len(d) == 90, sorted(d)
+    assert len(d) == 93, sorted(d)
     assert all(sig.endswith("p") for n, sig in d.items()
                if n not in ("micf_abi_version", "micf_strerror", "micf_linear_bwd_weight_workspace",
                             "micf_linear_bwd_weight_grouped_workspace", "micf_conv3_bwd_data_workspace",
-                            "micf_conv3_bwd_weight_grouped_workspace", "micf_head_tail_fused_supported", "micf_head_tail_pack_bytes", "micf_head_tail_bwd_weight_fused_workspace",
+                            "micf_conv3_bwd_weight_grouped_workspace", "micf_head_tail_fused_supported", "micf_head_tail_pack_bytes", "micf_head_tail_loss_parts", "micf_head_tail_bwd_weight_fused_workspace",
                             "micf_offset_sample_bwd_workspace", "micf_conv3_bwd_weight_workspace",
                             "micf_conv3_fwd_workspace", "micf_layernorm_bwd_partial_rows", "micf_block_tile_tokens",
                             "micf_offset_head_needs_zero", "micf_offset_head_bwd_workspace", "micf_block_saves_bf16", "micf_block_fuses_sampler", "micf_block_recomputes_h",

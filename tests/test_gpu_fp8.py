@@ -1,0 +1,185 @@
+"""BASELINE config 4's precision leg (MICF_DTYPE_BF16_ATTN_FP8, ops.set_compute_dtype('bf16+fp8attn')): bf16 mode with the two
+products of window attention -- q k^T and P v, forward -- on e4m3 operands (csrc/attn_fp8.h: v_mfma_f32_16x16x32_fp8_fp8 on two
+windows x one head per tile in the block kernels; the same rounding on the VALU in the per-op entry point).
+
+  * entry points against a torch restatement of that arithmetic (q * scale, k, v and P rounded through torch.float8_e4m3fn, fp32
+    products and sums): exact up to fp32 summation order where the kernel's operands are visible in fp32 (the per-op entry point,
+    the few-token decomposition at C = 384), statistically where the tile kernels only leave bf16 copies of q / k / v behind;
+  * whole network: the large model (head_dim 32: one matrix-core tile = the head's 32 channels) at BASELINE config 4's size against
+    the reference's fp32 logits (f8_large160) -- the gates are the MEASURED error of this mode with headroom, reported next to the
+    bf16 mode's own error on the same fixture (tools/fp8_report.py prints both; profiles/r04_fp8_report.txt holds a run);
+  * a train step (straight-through backward) stays finite and tracks the bf16 step's loss.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import fill  # noqa: E402
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture()
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from micformer_amd import ops as o
+    yield o
+    o.set_compute_dtype("fp32")
+
+
+def rnd(shape, seed, scale=1.0):
+    return (torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale).cuda()
+
+
+def q8(t):
+    return t.float().to(torch.float8_e4m3fn).float()
+
+
+def ref_attention_fp8(q, kv, dims, heads, scale, q8=q8):
+    """softmax(q8(q scale) q8(k)^T) -> q8(P) q8(v) per 2x2x2 window and head, fp32 everywhere else (q8 = identity: plain attention)."""
+    B, D, H, W = dims
+    C = q.shape[1]
+    hd = C // heads
+
+    def win(t):                                           # [T, C] -> [windows, heads, 8, hd]
+        t = t.float().reshape(B, D // 2, 2, H // 2, 2, W // 2, 2, heads, hd)
+        return t.permute(0, 1, 3, 5, 7, 2, 4, 6, 8).reshape(-1, heads, 8, hd)
+
+    qw, kw, vw = q8(win(q) * scale), q8(win(kv[:, :C])), q8(win(kv[:, C:]))
+    p = torch.softmax(qw @ kw.transpose(-1, -2), dim=-1)
+    o = q8(p) @ vw
+    o = o.reshape(B, D // 2, H // 2, W // 2, heads, 2, 2, 2, hd).permute(0, 1, 5, 2, 6, 3, 7, 4, 8)
+    return o.reshape(B * D * H * W, C)
+
+
+def same_up_to_rounding_flips(got, want):
+    """Equal to fp32 summation order, except where a softmax weight (or an operand) sits within an ulp of an e4m3 rounding boundary
+    and the kernel's exp / the restatement's land on different sides: one e4m3 step of one operand (2^-4 relative) in few elements."""
+    scale = float(want.abs().max())
+    err = (got.float() - want).abs()
+    assert float((err > 2e-5 * scale).float().mean()) <= 3e-2, float((err > 2e-5 * scale).float().mean())   # (one flip moves a whole head row)
+    assert float(err.max()) <= 7e-2 * scale, float(err.max()) / scale
+
+
+@pytest.mark.parametrize("dims,C,heads", [((2, 4, 4, 2), 96, 3), ((1, 2, 6, 4), 768, 24), ((1, 4, 4, 4), 48, 3), ((1, 2, 2, 4), 24, 3)])
+def test_per_op_attention_fp8_matches_the_restatement(ops, dims, C, heads):
+    B, D, H, W = dims
+    T = B * D * H * W
+    q, kv = rnd((T, C), 3), rnd((T, 2 * C), 4)
+    scale = (C // heads) ** -0.5
+    ops.set_compute_dtype("bf16+fp8attn")
+    assert ops.attention_fp8() and ops.compute_dtype() == "bf16" and ops.arith_mode() == "bf16+fp8attn"
+    o8 = ops.window_attn_fwd(q, kv, dims, heads, (2, 2, 2), scale)
+    ops.set_compute_dtype("bf16")
+    o16 = ops.window_attn_fwd(q, kv, dims, heads, (2, 2, 2), scale)
+    want = ref_attention_fp8(q, kv, dims, heads, scale)
+    same_up_to_rounding_flips(o8, want)
+    assert float((o8 - o16).abs().max()) > 1e-3 * float(want.abs().max())          # ... and it is a different arithmetic
+
+
+@pytest.mark.parametrize("case", [(2, 4, 4, 4, 384, 24), (1, 2, 6, 2, 384, 12)])
+@pytest.mark.parametrize("cross", [False, True])
+def test_few_token_blocks_fp8_attention_on_the_matrix_cores(ops, case, cross):
+    """block_wide.hip keeps q / k / v in fp32: the matrix-core attention equals the restatement on the kernel's own q, kv."""
+    import test_gpu_block_fused as tb
+    B, D, H, W, C, heads = case
+    dims, T = (B, D, H, W), B * D * H * W
+    attn = "cross_attn" if cross else "self_attn"
+    P = tb.make_params(C, 4 * C, attn, 31)
+    x, kvsrc = rnd((T, C), 32), (rnd((T, C), 33) if cross else None)
+    scale = (C // heads) ** -0.5
+    ops.set_compute_dtype("bf16+fp8attn")
+    o = ops.block_fwd([{"x": x, "kvsrc": kvsrc, "P": P, "attn": attn, "s1": None, "s2": None}], dims, C, heads, 1e-5, scale)[0]
+    assert o["q"].dtype == torch.float32
+    want = ref_attention_fp8(o["q"], o["kv"], dims, heads, scale)
+    same_up_to_rounding_flips(o["o"], want)
+    assert bool(torch.isfinite(o["y"]).all())
+
+
+@pytest.mark.parametrize("case", [(2, 4, 4, 4, 48, 3), (1, 4, 6, 4, 96, 6), (1, 2, 6, 2, 96, 3), (2, 4, 4, 2, 192, 12), (1, 4, 2, 2, 192, 6)])
+@pytest.mark.parametrize("cross", [False, True])
+def test_tile_blocks_fp8_attention_on_the_matrix_cores(ops, case, cross):
+    """The tile-per-workgroup kernels quantise the fp32 q / k / v they hold in LDS and leave bf16 copies behind: against the
+    restatement on those copies about one operand in sixteen rounds the other way (bf16's rounding crossing an e4m3 boundary: one
+    e4m3 step = 2^-4 relative), so the check is statistical: rms error within 5 % of the output's rms (measured 3-4 %), and the
+    perturbation the mode causes (fp8-mode output minus bf16-mode output of the same launch inputs) is the restatement's
+    perturbation (same size, correlation 0.65-0.9 measured, gate 0.5: unrelated arithmetic gives 0) -- for head_dim 16 (zero-padded k range) and 32, masked rows, both groups of a pair."""
+    import test_gpu_block_fused as tb
+    B, D, H, W, C, heads = case
+    dims, T = (B, D, H, W), B * D * H * W
+    attn = "cross_attn" if cross else "self_attn"
+    groups = []
+    for gi in range(2):
+        P = tb.make_params(C, 4 * C, attn, 41 + 100 * gi)
+        groups.append({"x": rnd((T, C), 42 + gi), "kvsrc": rnd((T, C), 44 + gi) if cross else None, "P": P, "attn": attn, "s1": None, "s2": None})
+    scale = (C // heads) ** -0.5
+    ops.set_compute_dtype("bf16+fp8attn")
+    o8 = ops.block_fwd(groups, dims, C, heads, 1e-5, scale)
+    ops.set_compute_dtype("bf16")
+    o16 = ops.block_fwd(groups, dims, C, heads, 1e-5, scale)
+    for a, b in zip(o8, o16):
+        assert torch.equal(a["q"], b["q"]) and torch.equal(a["kv"], b["kv"])           # everything up to the attention is the bf16 mode
+        want8 = ref_attention_fp8(a["q"], a["kv"], dims, heads, scale)
+        want = ref_attention_fp8(a["q"], a["kv"], dims, heads, scale, q8=lambda t: t.float())
+        rms = float(want.pow(2).mean().sqrt())
+        assert float((b["o"].float() - want).pow(2).mean().sqrt()) <= 1e-2 * rms        # (the bf16 mode's attention is the plain one)
+        assert float((a["o"].float() - want8).pow(2).mean().sqrt()) <= 5e-2 * rms       # (an indexing mistake gives O(100 %))
+        # the PERTURBATION e4m3 causes: kernel (fp8 mode - bf16 mode, same q / k / v in LDS) against restatement (fp8 - plain)
+        dk, dr = (a["o"].float() - b["o"].float()).flatten(), (want8 - want).flatten()
+        corr = float(torch.dot(dk, dr) / (dk.norm() * dr.norm()))
+        assert corr >= 0.5 and 0.6 <= float(dk.norm() / dr.norm()) <= 1.6, (corr, float(dk.norm() / dr.norm()))
+        assert bool(torch.isfinite(a["y"]).all())
+
+
+def _large_head():
+    import micformer_amd.models.MICFormer_self as M
+    h = M.Head(embed_dim=96, num_classes=8, depths=(2, 2, 6, 2))
+    with torch.no_grad():
+        for name, t in h.state_dict().items():
+            t.copy_(fill.fill_tensor(name, t))
+    return h.cuda().eval()
+
+
+def test_large_160_config4_fp8_attention_against_reference(ops):
+    """BASELINE config 4 at full size, forward, against the reference's fp32 logits (f8): measured on MI355X the fp8-attention mode
+    sits at the bf16 mode's own distance from the reference (profiles/r04_fp8_report.txt) -- attention is 0.86 % of the FLOPs and its
+    softmax averages 8 keys; the gates are the bf16 gates of tests/test_gpu_bf16.py."""
+    g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(G, "f8_large160.npz")).items()}
+    h = _large_head()
+    x = fill.make_volume(1, 160, 160, 128).cuda()
+    ops.set_compute_dtype("bf16+fp8attn")
+    with torch.no_grad():
+        l8 = h(x)
+    ops.set_compute_dtype("bf16")
+    with torch.no_grad():
+        l16 = h(x)
+    e8 = float((l8[:, :, ::8, ::8, ::8].cpu() - g["logits_stride"]).abs().max())
+    e16 = float((l16[:, :, ::8, ::8, ::8].cpu() - g["logits_stride"]).abs().max())
+    assert float((l8 - l16).abs().max()) > 0, "the fp8 mode must not be the bf16 mode"
+    assert e8 <= 2e-2, f"fp8-attention logits differ from the reference by {e8} (bf16 mode: {e16})"
+    bad = (l8.argmax(1).cpu() != g["mask"].long())[:, ::2, ::2, ::2] & (g["margin_stride"].float() > 4e-2)
+    assert int(bad.sum()) == 0
+
+
+def test_train_step_fp8_attention_tracks_bf16(ops):
+    """Two optimiser steps of the large network (head_dim 32) on a 64^3 pair: finite, and the losses follow the bf16 engine's."""
+    from micformer_amd.engine import TrainEngine
+    import micformer_amd.models.MICFormer_self as M
+    x = fill.make_volume(2, 64, 64, 64).cuda()
+    t = fill.one_hot(fill.make_label_map(2, 64, 64, 64)).cuda()
+    losses = {}
+    for mode in ("bf16", "bf16+fp8attn"):
+        ops.set_compute_dtype(mode)
+        h = M.Head(embed_dim=96, num_classes=8, depths=(1, 1, 1, 1))
+        with torch.no_grad():
+            for name, p in h.state_dict().items():
+                p.copy_(fill.fill_tensor(name, p))
+        eng = TrainEngine(h.cuda().eval(), base_lr=1e-4, t_max=10, use_graph=True)
+        losses[mode] = [float(eng.step(x, t)) for _ in range(2)]
+    a, b = losses["bf16"], losses["bf16+fp8attn"]
+    assert all(v == v for v in b) and all(abs(u - v) <= 3e-3 for u, v in zip(a, b)), losses

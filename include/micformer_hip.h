@@ -522,6 +522,16 @@ typedef struct micf_block_bwd_group {
   const float* xn2;    /* LN2(x1) [T, C] as micf_block_fwd saved it (bf16 where micf_block_saves_bf16) */
   const void* w1;      /* mlp.fc1.weight [hidden, C], the forward's K16-blocked shadow copy (micf_block_fwd_group.w1) */
   const float* b1;     /* mlp.fc1.bias [hidden] */
+  /* pre_d != NULL (self blocks on the tile-per-workgroup kernels with bf16 storage only): the LayerNorm backward that PRODUCES this
+   * block's output gradient runs as the kernel's prologue -- the adjoint of the LayerNorm-1 of the cross block that consumed this
+   * block's output (MS.py:343): dy_effective = dy + LN'(pre_d) with `dy` the partial sum the caller already holds (residual path +
+   * the other branches).  One launch (micf_layernorm_bwd_pair) and one [T, C] round trip less per depth slot; dy_effective is never
+   * written in fp32 (its bf16 copy dy16 is, as always). */
+  const float* pre_d;    /* [T, C] gradient w.r.t. that LayerNorm's output */
+  const float* pre_x;    /* [T, C] its input (= this block's forward output y) */
+  const float *pre_mean, *pre_rstd; /* [T] its saved statistics */
+  const float* pre_g;    /* [C] its gain */
+  float* pre_part;       /* out [tiles, 2C]: per-tile partial dgamma | dbeta of that LayerNorm (micf_layernorm_bwd_finish) */
 } micf_block_bwd_group;
 /* != 0: the caller should pass h == NULL in both groups structs (see there).  Only with MICF_BLOCK_RECOMPUTE_H=1 in the
  * environment and only for the tile-per-workgroup kernels (everything but the few-token decomposition at C = 384): a memory

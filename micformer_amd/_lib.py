@@ -161,7 +161,8 @@ class BlockFwdGroup(ctypes.Structure):
 class BlockBwdGroup(ctypes.Structure):
     """struct micf_block_bwd_group (include/micformer_hip.h)."""
     FIELDS = ("dy", "x", "x1", "stats", "q", "kv", "h", "ln1_g", "ln2_g", "wqt", "wkvt", "wpt", "w1t", "w2t", "s1", "s2",
-              "dx", "dxs", "dx1", "dh", "dq", "dkv", "ln1_part", "ln2_part", "dx1_copy", "dy16", "xn2", "w1", "b1")
+              "dx", "dxs", "dx1", "dh", "dq", "dkv", "ln1_part", "ln2_part", "dx1_copy", "dy16", "xn2", "w1", "b1",
+              "pre_d", "pre_x", "pre_mean", "pre_rstd", "pre_g", "pre_part")
     _fields_ = [(n, _VP) for n in FIELDS]
 
 

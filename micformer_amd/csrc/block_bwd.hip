@@ -314,6 +314,22 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
   char* dkv0 = reinterpret_cast<char*>(g.dkv) + (int64_t)tk0 * 2 * C * ES;
   float* dx0 = g.dx + (int64_t)tk0 * C;
 
+  // ---- (pre) the LayerNorm backward that produces this block's output gradient runs as a prologue: dy = add + LN'(pre_d) -> A1 and
+  // the bf16 copy dy16.  Its inputs are requested FIRST and consumed while the tile's other inputs are still in flight (loads return
+  // in order); the LayerNorm-1 inputs of the block itself -- needed last -- are requested after it, so the registers the prologue
+  // holds are never live together with them.
+  const bool pre = BF16 && g.pre_d != nullptr;          // (workgroup-uniform)
+  RowRegs<TM, NW, C4> r_add, r_d;
+  LnRegs<TM, NW, C> r_lc;
+  if constexpr (BF16) {
+    if (pre) {
+      r_add.load(tok, tk0, [&](uint32_t rel, uint32_t c4) { return at32(dy0, (rel * C + 4 * c4) * 4u); });
+      const float* pd0 = g.pre_d + (int64_t)tk0 * C;
+      r_d.load(tok, tk0, [&](uint32_t rel, uint32_t c4) { return at32(pd0, (rel * C + 4 * c4) * 4u); });
+      r_lc.load(tok, tk0, g.pre_x + (int64_t)tk0 * C, g.pre_mean + tk0, g.pre_rstd + tk0, g.pre_g);
+    }
+  }
+
   // ---- request every global input of the tile (see RowRegs)
   constexpr int HC = block_hidden_chunk(C);
   RowRegs<TM, NW, C4> r_dy;
@@ -323,7 +339,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
   HRegs<TM, NW, C4, BF16> r_q;
   HRegs<TM, NW, 2 * C4, BF16> r_kv;
   LnRegs<TM, NW, C> r_ln2, r_ln1;
-  r_dy.load(tok, tk0, [&](uint32_t rel, uint32_t c4) { return at32(dy0, (rel * C + 4 * c4) * 4u); });
+  if (!pre) r_dy.load(tok, tk0, [&](uint32_t rel, uint32_t c4) { return at32(dy0, (rel * C + 4 * c4) * 4u); });
   if constexpr (RECOMP) {
     // (requested right behind dy: loads return in order, and both are committed to LDS first)
 #pragma unroll
@@ -338,13 +354,22 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
       r_h[ch].load(tok, tk0, h0 + ch * HC * (BF16 ? 2 : 4), (uint32_t)Hd);
   }
   r_ln2.load(tok, tk0, g.x1 + (int64_t)tk0 * C, g.stats + 2 * T + tk0, g.stats + 3 * T + tk0, g.ln2_g);
-  if (!g.dxs) r_ln1.load(tok, tk0, g.x + (int64_t)tk0 * C, g.stats + tk0, g.stats + T + tk0, g.ln1_g);
+  if (!g.dxs && !pre) r_ln1.load(tok, tk0, g.x + (int64_t)tk0 * C, g.stats + tk0, g.stats + T + tk0, g.ln1_g);
   r_q.load(tok, tk0, q0, (uint32_t)C);
   r_kv.load(tok, tk0, kv0, (uint32_t)(2 * C));
 
   // ---- dy rows -> A1 (+ the bf16 copy fc2's weight gradient reads)
-  r_dy.commit(A1, S);
-  if (BF16 && g.dy16) r_dy.store_b16(tok, tk0, reinterpret_cast<char*>(g.dy16) + (int64_t)tk0 * C * 2);
+  if (!pre) {
+    r_dy.commit(A1, S);
+    if (BF16 && g.dy16) r_dy.store_b16(tok, tk0, reinterpret_cast<char*>(g.dy16) + (int64_t)tk0 * C * 2);
+  } else if constexpr (BF16) {
+    r_add.commit(A1, S);
+    r_d.commit(A2, S);
+    lds_barrier();
+    ln_bwd_tile<TJ, VPL, NW, C, true>(A2, A1, S, r_lc, tok, tk0, reinterpret_cast<char*>(g.dy16) + (int64_t)tk0 * C * 2, nullptr, U,
+                                      g.pre_part + (int64_t)tile * 2 * C);
+    r_ln1.load(tok, tk0, g.x + (int64_t)tk0 * C, g.stats + tk0, g.stats + T + tk0, g.ln1_g);      // (a self block: see the entry point)
+  }
 
   // ---- MLP backward in hidden chunks: h chunk -> U;  U <- s2 (dy W2) GELU'(h) = dh (saved);  A2 (+)= dh W1
 #pragma unroll
@@ -604,6 +629,12 @@ extern "C" int micf_block_bwd(const micf_block_bwd_group* groups, int ngroups, i
       if (!micf_block_recomputes_h(C, heads)) return MICF_EINVAL;
     }
     if (i > 0 && (g.h == nullptr) != (groups[0].h == nullptr)) return MICF_EINVAL;
+    if (g.pre_d) {                                      // LayerNorm-backward prologue: self block, tile kernels, bf16 storage
+      const void* pr[] = {g.pre_d, g.pre_x, g.pre_mean, g.pre_rstd, g.pre_g, g.pre_part, g.dy16};
+      for (const void* p : pr)
+        if (!p || (reinterpret_cast<uintptr_t>(p) & 15)) return MICF_EINVAL;
+      if (g.dxs || dtype != MICF_DTYPE_BF16 || block_wide_tile_tokens(C, C / heads)) return MICF_EINVAL;
+    }
     if (!g.dxs && (!g.x || !g.ln1_g)) return MICF_EINVAL;          // self: LayerNorm-1 backward runs in the kernel
     const void* opt[] = {g.x, g.ln1_g, g.dxs, g.ln1_part, g.ln2_part, g.dx1_copy, g.dy16};
     for (const void* p : opt)

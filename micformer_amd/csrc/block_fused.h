@@ -328,15 +328,20 @@ constexpr int block_bwd_park_floats(int TM, int C, int nthr) { return C <= 48 ? 
 // hidden columns of the MLP a tile handles per pass (a chunk of fc1's outputs = fc2's reduction): 2C where several workgroups
 // share a CU's LDS (C <= 96), all 4C at C = 192 (one workgroup per CU either way: two GEMM phases and a GELU pass fewer per tile,
 // each a barrier-to-barrier round trip in a kernel that is bound by exactly those)
+// (fwd: the forward kernel's choice; the backward's LDS also holds the attention exchange and the parked LayerNorm inputs)
 #ifdef MICF_AB_HC2C              // (A/B build: the two-chunk form everywhere)
-constexpr int block_hidden_chunk(int C) { return 2 * C; }
+constexpr int block_hidden_chunk(int C, bool fwd = false) { return 2 * C; }
+#elif defined(MICF_AB_FWD_HC4)   // (A/B build: one chunk in every forward)
+constexpr int block_hidden_chunk(int C, bool fwd = false) { return (C >= 192 || fwd) ? 4 * C : 2 * C; }
+#elif defined(MICF_AB_FWD_HC4_96)
+constexpr int block_hidden_chunk(int C, bool fwd = false) { return (C >= 192 || (fwd && C >= 96)) ? 4 * C : 2 * C; }
 #else
-constexpr int block_hidden_chunk(int C) { return C >= 192 ? 4 * C : 2 * C; }
+constexpr int block_hidden_chunk(int C, bool fwd = false) { return C >= 192 ? 4 * C : 2 * C; }
 #endif
 // columns of the U tile: q | k | v (3C) or a hidden chunk, whichever is wider
-constexpr int block_u_cols(int C) { return block_hidden_chunk(C) > 3 * C ? block_hidden_chunk(C) : 3 * C; }
-inline size_t block_lds_floats(int TM, int C, int scratch, int params) {
-  return (size_t)scratch + (size_t)TM * (2 * (C + 4) + block_u_cols(C) + 4) + 3 * TM + params;
+constexpr int block_u_cols(int C, bool fwd = false) { return block_hidden_chunk(C, fwd) > 3 * C ? block_hidden_chunk(C, fwd) : 3 * C; }
+inline size_t block_lds_floats(int TM, int C, int scratch, int params, bool fwd = false) {
+  return (size_t)scratch + (size_t)TM * (2 * (C + 4) + block_u_cols(C, fwd) + 4) + 3 * TM + params;
 }
 // waves per workgroup: 8 where a launch has too few tiles to fill the chip and every tile streams megabytes of weights
 // (C = 192: 128 tiles of 16 tokens at the base model's 8^3 stage) -- the x tiles of a phase are then dealt to 8 waves

@@ -35,7 +35,7 @@ template <int C, int HD, int TJ, int NW, bool BF16, bool SAMP>
 __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) {
   constexpr int TM = 16 * TJ, VPL = (C + 63) / 64, NSL = C / 16, NTHR = 64 * NW, RPP = 4 * NW, NPASS = (TM + RPP - 1) / RPP;
   extern __shared__ __attribute__((aligned(1024))) float lds[];
-  constexpr int C4 = C >> 2, S = C + 4, SU = block_u_cols(C) + 4, Hd = 4 * C;
+  constexpr int C4 = C >> 2, S = C + 4, SU = block_u_cols(C, true) + 4, Hd = 4 * C;
   float* A1 = lds;
   float* A2 = A1 + TM * S;
   float* U = A2 + TM * S;
@@ -363,7 +363,7 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
 
   // ---- MLP in hidden chunks of <= 2C (<= 3C fits U): fc1 chunk (+ b1) -> U; save h, GELU in place, save g; fc2 chunk
   // accumulates s2 * (g W2^T) into A2 (which holds x1)
-  constexpr int HC = block_hidden_chunk(C);
+  constexpr int HC = block_hidden_chunk(C, true);
   for (int c0 = 0; c0 < Hd; c0 += HC) {
     constexpr int hc = HC;
     if (!(a.debug & 4)) gemm_phase<TJ, NSL, 1, C, NW, BF16>(w1 + (int64_t)c0 * C, hc, A1, nullptr, 0, nullptr, S, U, SU, EpiBias{p_b1 + c0});
@@ -408,7 +408,7 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
 template <int C, int HD, int TJ>
 static int launch_fwd(const BlkFwdArgs& a, int dtype, hipStream_t s) {
   constexpr int TM = 16 * TJ, NW = C >= 192 ? (HD <= 16 ? 16 : 8) : 4;   // (head_dim 32 attention rows need > 128 registers: 8 waves there)
-  const size_t lds = block_lds_floats(TM, C, 0, 9 * C + 4 * C) * sizeof(float);
+  const size_t lds = block_lds_floats(TM, C, 0, 9 * C + 4 * C, true) * sizeof(float);
   if (lds > 160 * 1024) return MICF_EUNSUPPORTED;
   const unsigned grid = a.G == 2 ? (unsigned)((a.tiles + 3) / 4 * 8) : (unsigned)a.tiles;
   static std::once_flag once;

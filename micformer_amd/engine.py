@@ -194,7 +194,8 @@ class TrainEngine:
         @contextlib.contextmanager
         def scope():
             prev = (_ms.PARALLEL_MODALITIES, _fn.DEFER_WGRAD, _fn.FLUSH_POINTS, _fn.DEFER_CALLS, ops.ENGINE_SHADOWS)
-            prev_fork = _ms.FORK_AUTOGRAD_STREAMS
+            prev_fork, prev_lazy = _ms.FORK_AUTOGRAD_STREAMS, _fn.LAZY_LN_OK
+            _fn.LAZY_LN_OK = _fn.LAZY_LN_DEFAULT              # cross pairs park their LayerNorm-1 backward for the self pair's launch
             _ms.FORK_AUTOGRAD_STREAMS = not (self.segmented and self.use_graph)
             prev_budget = _fn.FLUSH_BUDGET[0]
             _ms.PARALLEL_MODALITIES, _fn.DEFER_WGRAD = self.parallel_modalities, self.defer_wgrad
@@ -208,6 +209,7 @@ class TrainEngine:
                 _ms.PARALLEL_MODALITIES, _fn.DEFER_WGRAD, _fn.FLUSH_POINTS, _fn.DEFER_CALLS, ops.ENGINE_SHADOWS = prev
                 _fn.FLUSH_BUDGET[0] = prev_budget
                 _ms.FORK_AUTOGRAD_STREAMS = prev_fork
+                _fn.LAZY_LN_OK = prev_lazy
         return scope()
 
     def _fwd_bwd(self, x, target, flush=True):
@@ -257,6 +259,10 @@ class TrainEngine:
                     loss.backward()
             else:
                 loss.backward()                                     #                              train.py:200
+            if _fn.lazy_ln_pending():                               # (a parked LayerNorm backward nobody ran: never silently)
+                n = _fn.lazy_ln_pending()
+                _fn.drop_deferred()
+                raise RuntimeError(f"{n} parked LayerNorm backward(s) were not consumed by a self-pair launch (functional._LAZY_LN)")
             _fn.flush_wgrad(calls_only=not flush)                   # what is still queued: grouped linear weight gradients (left
             _fn.join_wgrad_stream()                                 # to the data-parallel tail when flush=False), closures
         return loss.detach()

@@ -109,6 +109,7 @@ def drop_deferred():
     _DEFERRED_CALLS.clear()
     _QUEUED_DW.clear()
     _PENDING_FLUSH.clear()
+    _LAZY_LN.clear()
 
 
 def _ln_defer(on):
@@ -832,12 +833,37 @@ def _self_fwd_fused(xs, Ps, scales, dims, heads, eps):
     return ops.block_fwd(groups, dims, C, heads, eps, (C // heads) ** -0.5)
 
 
+# The LayerNorm-1 backward of a cross pair (MS.py:343 through autograd) produces exactly the output gradients of the self pair of the
+# same depth slot, whose backward launch is next on the chain: in engine mode with bf16 storage the cross pair therefore does NOT
+# launch it -- it hands the self pair its partial sums (the returned "gradients": residual path + the other branches) and parks
+# what the LayerNorm backward needs here; micf_block_bwd runs it as its prologue (micf_block_bwd_group.pre_d).  24 launches and
+# a [T, C] round trip per slot off the chain.  Only BasicLayer's self -> cross sequence sets it up (`lazy_ln` of CrossPairFn), only
+# while an engine step scopes LAZY_LN_OK, and the engine checks after backward that nothing parked was left unconsumed.
+LAZY_LN_OK = False
+LAZY_LN_DEFAULT = __import__("os").environ.get("MICF_LAZY_LN", "1") != "0"
+CROSS_AFTER_SELF = [None]           # (data_ptr, data_ptr) of the self pair's outputs BasicLayer is about to hand to the cross pair
+_LAZY_LN = {}                       # data_ptr of the partial-sum buffer handed to autograd -> the parked LayerNorm backward
+
+
+def lazy_ln_pending():
+    return len(_LAZY_LN)
+
+
 def _self_bwd_fused(dys, xs, svs, Ps, Gs, scales, dims, heads, sides):
     C = xs[0].shape[1]
     rps = dims[1] * dims[2] * dims[3]
     groups = [{"dy": dy, "x": x, "x1": sv["x1"], "stats": sv["stats"], "q": sv["q"], "kv": sv["kv"], "h": sv["h"], "xn2": sv["xn2"], "P": P,
                "attn": "self_attn", "s1": s[0], "s2": s[1], "cross": False} for dy, x, sv, P, s in zip(dys, xs, svs, Ps, scales)]
+    pres = [_LAZY_LN.pop(dy.data_ptr(), None) for dy in dys]
+    for gd, pre in zip(groups, pres):
+        if pre is not None:
+            if tuple(pre["d"].shape) != tuple(gd["dy"].shape):
+                raise RuntimeError("parked LayerNorm backward does not match the gradient it was parked for")
+            gd["pre"] = pre
     bos = ops.block_bwd(groups, dims, C, heads, (C // heads) ** -0.5)
+    for bo, pre in zip(bos, pres):
+        if pre is not None:
+            _ln_partials(pre["side"], bo["pre_part"], bo["tiles"], C, pre["dgamma"], pre["dbeta"])
     for dy, sv, bo, P, G, s, side in zip(dys, svs, bos, Ps, Gs, scales, sides):
         _queue_block_wgrads(side, P, G, "self_attn", sv, bo, dy, sv["xn"], sv["xn"], s[0], s[1], rps)
         _ln_partials(side, bo["ln2_part"], bo["tiles"], C, G["norm2.weight"], G["norm2.bias"])
@@ -961,6 +987,9 @@ class CrossPairFn(torch.autograd.Function):
         n = len(CROSS_KEYS)
         Ps = [dict(zip(CROSS_KEYS, params[:n])), dict(zip(CROSS_KEYS, params[n:]))]
         x, xa = _c(x), _c(xa)
+        # (the inputs are the outputs of the self pair of this depth slot and nobody else reads them: see _LAZY_LN)
+        ctx.lazy_ln = CROSS_AFTER_SELF[0] == (x.data_ptr(), xa.data_ptr())
+        CROSS_AFTER_SELF[0] = None
         B, D, H, W, C = x.shape
         dims = (B, D, H, W)
         xs = [x.reshape(-1, C), xa.reshape(-1, C)]
@@ -1057,7 +1086,15 @@ class CrossPairFn(torch.autograd.Function):
                     _cross_head_adjoint(i, hds, bos, Ps, Gs, xs, acc, dims, eps, C, sides)
             if side is not None:
                 main.wait_stream(side)
-        if GROUP_CROSS_HEADS:
+        lazy = (ctx.lazy_ln and LAZY_LN_OK and GROUP_CROSS_HEADS and all(sides) and DEFER_WGRAD and bos[0].get("dy16") is not None
+                and ops.block_fuses_sampler(C, heads))
+        if lazy:
+            # parked for the self pair's backward launch (see _LAZY_LN): acc[i] leaves as the PARTIAL gradient of input i
+            for i in (0, 1):
+                _LAZY_LN[acc[i].data_ptr()] = {"d": bos[i]["dx"], "x": xs[i], "mean": hds[i][1], "rstd": hds[i][2],
+                                               "gamma": Ps[i]["norm1.weight"], "dgamma": Gs[i]["norm1.weight"],
+                                               "dbeta": Gs[i]["norm1.bias"], "side": sides[i]}
+        elif GROUP_CROSS_HEADS:
             ops.layernorm_bwd_pair([{"dy": bos[i]["dx"], "x": xs[i], "mean": hds[i][1], "rstd": hds[i][2], "gamma": Ps[i]["norm1.weight"],
                                      "dgamma": Gs[i]["norm1.weight"], "dbeta": Gs[i]["norm1.bias"], "add": acc[i], "out": acc[i]}
                                     for i in (0, 1)], [_ln_defer(sides[i]) for i in (0, 1)])

@@ -434,6 +434,7 @@ class BasicLayer(nn.Module):
                                         *_block_params(a, Fn.SELF_KEYS), *_block_params(b, Fn.SELF_KEYS))
             a, b = self.blocks1[i], self.blocks2[i]
             sa, sb = _block_scales(a, x), _block_scales(b, xa)
+            Fn.CROSS_AFTER_SELF[0] = (x.data_ptr(), xa.data_ptr())      # (self pair -> cross pair, nothing in between)
             x, xa = Fn.CrossPairFn.apply(x, xa, sa[0], sa[1], sb[0], sb[1], a.num_heads, a.norm1.eps,
                                          *_block_params(a, Fn.CROSS_KEYS), *_block_params(b, Fn.CROSS_KEYS))
         return x, xa

@@ -1163,6 +1163,14 @@ def block_bwd(groups, dims, C, heads, scale):
                 or (h is None and gd["xn2"].dtype != sd):
             raise _lib.MicfError("block_bwd: the saved tensors were written in another arithmetic mode")
         it.h, it.q, it.kv = ptr(h), ptr(gd["q"]), ptr(gd["kv"])
+        pre = gd.get("pre")
+        if pre is not None:                             # the producing LayerNorm backward as the kernel's prologue (bf16 storage, self)
+            if not st16 or cross:
+                raise _lib.MicfError("block_bwd: the LayerNorm-backward prologue needs a self block with bf16 storage")
+            o["pre_part"] = _new(dy, tiles, 2 * C)
+            it.pre_d, it.pre_x, it.pre_mean, it.pre_rstd, it.pre_g, it.pre_part = (f32(pre["d"]), f32(pre["x"]), f32(pre["mean"]),
+                                                                                  f32(pre["rstd"]), f32(pre["gamma"]), f32(o["pre_part"]))
+            nb += 4 * T * C * 2
         if h is None:                                   # recompute: xn2, the FORWARD orientation of fc1's weight, its bias
             w1 = block_weights(P, a, backward=False, only=("w1",))["w1"]
             keep.append(w1)

@@ -112,7 +112,7 @@ def host_cpu():
     return model, (len(cores) or logical), logical
 
 
-def cpu_baseline(vol, timed=5, budget_s=330.0, batches=(2, 1), warmups=2):
+def cpu_baseline(vol, timed=5, budget_s=420.0, batches=(2, 1), warmups=2):
     """the CPU restatement (oracle/, kind 'port') timed on ALL PHYSICAL host cores: the identical train
     step (fwd + MDiceLoss + bwd + Adam, fp32) of the base model on full-size CT+MR pairs.  Protocol = BASELINE.md's: `warmups`
     (2) untimed full-size steps, then `timed` (5) timed steps, median -- at B = 2, the batch the GPU value is quoted on (a step is
@@ -207,13 +207,16 @@ def main(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=5, help="timed CPU-baseline steps at B = 2 (median is reported)")
-    ap.add_argument("--cpu-budget-s", type=float, default=330.0, help="stop timing further CPU steps once this much CPU time is spent")
+    ap.add_argument("--cpu-budget-s", type=float, default=420.0, help="stop timing further CPU steps once this much CPU time is spent")
     ap.add_argument("--serial-modalities", action="store_true", help="do not overlap the CT / MR branches on two streams")
     ap.add_argument("--detail", action="store_true", help="roofline leg: key kernels by shape too (diagnostic)")
     ap.add_argument("--eval-mode", action="store_true", help="DropPath off (default: train mode, DropPath active)")
     ap.add_argument("--no-flush-points", action="store_true", help="launch all queued weight gradients after backward")
     ap.add_argument("--split-step", action="store_true", help="single-GPU probe of the DATA-PARALLEL step layout (graph = forward + "
                     "backward, grouped weight gradients + Adam outside it, no collective at world 1)")
+    ap.add_argument("--steps-per-graph", type=int, default=int(os.environ.get("MICF_STEPS_PER_GRAPH", "1")),
+                    help="single GPU: k consecutive steps per captured graph (TrainEngine.step_many: step i + 1's encoder forward "
+                         "runs beside the decoder-side parameter-gradient work + Adam of step i); --steps must be a multiple of k")
     ap.add_argument("--cpu-stub", action="store_true", help="control-flow test on CPU/gloo with a stub engine (no kernels)")
     args = ap.parse_args(argv)
 
@@ -272,15 +275,28 @@ def main(argv=None):
         if not stub:
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        eng.step(x, tgt)
-    if not args.no_graph and eng._graph is None:                # warmup 0: still capture outside the timed region
-        eng._capture(x, tgt)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = eng.step(x, tgt)
-    barrier()
+    spg = args.steps_per_graph if (world == 1 and not stub and not args.no_graph and not args.segmented and not args.split_step) else 1
+    if spg > 1 and args.steps % spg:
+        raise SystemExit("--steps must be a multiple of --steps-per-graph")
+    if spg > 1:
+        xs, tgts = [x] * spg, [tgt] * spg
+        for _ in range(max(1, -(-args.warmup // spg))):         # (at least one call: the capture stays outside the timed region)
+            eng.step_many(xs, tgts)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps // spg):
+            loss = eng.step_many(xs, tgts)[-1]
+        barrier()
+    else:
+        for _ in range(args.warmup):
+            eng.step(x, tgt)
+        if not args.no_graph and eng._graph is None:            # warmup 0: still capture outside the timed region
+            eng._capture(x, tgt)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = eng.step(x, tgt)
+        barrier()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -300,7 +316,10 @@ def main(argv=None):
                                f"8 classes) full train step (fwd + MDiceLoss + bwd + Adam/cosine) on {args.vol}^3 CT+MR pairs, "
                                f"{'DropPath on' if not args.eval_mode else 'eval mode'}",
                    "local_batch": args.batch, "global_batch": world * args.batch, "parallelism": f"dp{world}",
-                   "launch": "eager" if args.no_graph else ("hipGraph replay (one graph)" if (stub or not eng.segmented) else
+                   "launch": "eager" if args.no_graph else (f"hipGraph replay ({spg} consecutive steps per graph: the decoder-side "
+                                                            "parameter gradients + Adam of step i run beside step i + 1's encoder forward; "
+                                                            "every step is a full update on its own batch)") if spg > 1 else
+                             ("hipGraph replay (one graph)" if (stub or not eng.segmented) else
                                                             f"hipGraph replay ({len(eng._graph.segments)} segments: main chain / "
                                                             "parameter-gradient batches as separate graphs on two streams)")},
         "final_loss": round(loss_val, 6),

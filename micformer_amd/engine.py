@@ -74,6 +74,8 @@ class TrainEngine:
         self._graph = None
         self._static = None
         self._static_mode = None
+        self._many, self._carried, self._carry_groups = None, None, None
+        self._param_at = {o: p for p, o in zip(self.params, self.offsets)}
         self.steps_done = 0
 
     # ------------------------------------------------------------------ flat parameter / gradient storage
@@ -123,6 +125,7 @@ class TrainEngine:
         # while the backward of the earlier encoder stages continues, and only [0, cut) is left for the end of the step.
         self._early_cut, self._early_layer, self._adam_tail_done = None, None, False
         stages = getattr(getattr(self.model, "swin", self.model), "layers", None)
+        self._stages = stages if stages is not None else []
         self._anchor_layer = stages[len(stages) - 1] if stages is not None and len(stages) >= 2 else None
         self._anchor_buf = None
         if stages is not None and len(stages) >= 2:
@@ -148,7 +151,7 @@ class TrainEngine:
                           if p.dim() == 2 and min(p.shape) <= 384 and not ((p.shape[0] | p.shape[1]) & 15)]   # (fusable widths)
         self._conv_w = [(n, p) for n, p in pick(("conv_offset.0.weight",)) if p.dim() == 5 and p.shape[0] <= 16]
         self._offset_of = {id(p): o for p, o in zip(params, offs)}
-        self._prep_plans, self._shadow_bufs = {}, {}
+        self._prep_plans, self._shadow_bufs, self._prep_split = {}, {}, {}
         self._prep_stream = torch.cuda.Stream(device=dev)
 
     def _weight_prep(self):
@@ -182,6 +185,19 @@ class TrainEngine:
                     ctrip.append((p.data, p._micf_c3f, p._micf_c3b))
                 self._shadow_bufs["conv"] = ops.Conv3PrepPlan(ctrip)
             plans = self._prep_plans[mode] = (fwd, ops.WeightPrepPlan(trip, blocked=True), self._shadow_bufs["conv"])
+            # the same plans cut at the early-Adam boundary (step_many: the copies of the tail's weights are refreshed only after
+            # the tail's carried Adam update of the previous step): (forward early, forward late, conv early, conv late)
+            cut = self._early_cut if self._early_cut is not None else self.flat_p.numel()
+            late = lambda p: self._offset_of[id(p)] >= cut
+            if fwd is not None:
+                fe = ops.WeightPrepPlan([t for t, p in zip(ftrip, ws) if not late(p)], blocked=True)
+                fl = ops.WeightPrepPlan([t for t, p in zip(ftrip, ws) if late(p)], blocked=True)
+            else:
+                fe = fl = None
+            ctr = [(p.data, p._micf_c3f, p._micf_c3b) for _, p in self._conv_w]
+            ce = ops.Conv3PrepPlan([t for t, (_, p) in zip(ctr, self._conv_w) if not late(p)])
+            cl = ops.Conv3PrepPlan([t for t, (_, p) in zip(ctr, self._conv_w) if late(p)])
+            self._prep_split[mode] = (fe, fl, ce, cl)
         return plans
 
     # ------------------------------------------------------------------ one optimisation step
@@ -212,22 +228,65 @@ class TrainEngine:
                 _fn.LAZY_LN_OK = prev_lazy
         return scope()
 
-    def _fwd_bwd(self, x, target, flush=True):
+    def _fwd_bwd(self, x, target, flush=True, carry_in=None, carry_out=False):
         from . import functional as _fn
         _fn.drop_deferred()                                         # nothing left over from a backward that raised
         with self._scoped_flags():
             fwd, bwd, conv = self._weight_prep()
             main, side = torch.cuda.current_stream(), self._prep_stream
             _fn.clear_entry_hooks()
-            conv.launch()                                           # offset-conv weight layouts (one small launch)
-            if fwd is not None:                                     # K16-blocked block weights, next to the patch embedding
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    fwd.launch()
-                _fn.park_entry_hook(lambda: main.wait_stream(side), at=1)
+            carried = [None]
+            if carry_in is not None:
+                # step_many: the previous step of this graph left the parameter-gradient batches of its first flush points and the
+                # Adam update of the flat tail [cut, total) to us.  They run NOW on the weight-gradient side stream, stage group by
+                # stage group in the order this forward first reads their parameters (last encoder stage, then the decoder stages
+                # upwards, the head last): each group = its batches, Adam over its slices of the flat buffers, the forward shadow
+                # copies / conv layouts of its weights, then an event; the main chain waits for a group's event at the entry of its
+                # stage.  The encoder forward in front of it reads [0, cut) only.
+                fe, _, ce, _ = self._prep_split[ops.compute_dtype()]
+                ce.launch()
+                if fe is not None:
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        fe.launch()
+                    _fn.park_entry_hook(lambda: main.wait_stream(side), at=1)
+                carried = [None]                                   # (the last group's event, once launched)
+
+                def launch_carried_groups():
+                    # Created AFTER the main chain's first kernels of this step (stage entry 1: patch embedding launched): a side
+                    # branch created first makes the captured graph's executor run it in front of the main chain (measured: the
+                    # carried work then sat in a 2 ms tail between the steps instead of under the encoder forward).
+                    wside = _fn._wgrad_stream(self.flat_p.device)
+                    wside.wait_stream(main)
+                    with torch.cuda.stream(wside):
+                        for grp in self._carry_groups:
+                            _fn.launch_carried(carry_in.get(grp["key"], []))
+                            for lo, hi in grp["ranges"]:
+                                self._adam_range(lo, hi, 1.0)       # (same tick as the previous step's [0, cut))
+                            fl, cl = self._carry_prep(grp)
+                            cl.launch()
+                            if fl is not None:
+                                fl.launch()
+                            ev = torch.cuda.Event()
+                            ev.record(wside)
+                            _fn.park_entry_hook((lambda e: (lambda: main.wait_event(e)))(ev), at=grp["entry"])
+                            carried[0] = ev
+                    _fn._WSIDE_USED.add(self.flat_p.device)
+                # (entry 3 = the 8^3 encoder stage, where the main chain leaves half the chip idle; it must not be later than the
+                #  backward preparation parked there, which waits for the last group's event)
+                _fn.park_entry_hook(launch_carried_groups, at=min(3, int(__import__("os").environ.get("MICF_CARRY_AT", "3"))))
+            else:
+                conv.launch()                                       # offset-conv weight layouts (one small launch)
+                if fwd is not None:                                 # K16-blocked block weights, next to the patch embedding
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        fwd.launch()
+                    _fn.park_entry_hook(lambda: main.wait_stream(side), at=1)
 
             def backward_prep():                                    # under the latency-bound small stages of the forward
                 side.wait_stream(main)
+                if carried[0] is not None:
+                    side.wait_event(carried[0])                     # (the carried Adam reads the gradients this zero fill clears)
                 with torch.cuda.stream(side):
                     ops.zero_(self.flat_g)                          # optimizer.zero_grad()        train.py:183
                     bwd.launch()                                    # W^T shadows of the fused backward
@@ -238,16 +297,29 @@ class TrainEngine:
             # launched EVERY weight gradient queued so far (flush points on, unbounded budget, no token cap) -- otherwise the
             # linear / LayerNorm gradients of the tail would still sit in the queue and be applied one step late, never.
             full_flush = _fn.FLUSH_POINTS and _fn.FLUSH_BUDGET[0] >= (1 << 30) and _fn.FLUSH_MAX_TOKENS >= (1 << 30)
-            if flush and self.world == 1 and self._early_cut is not None and self.early_adam and full_flush:
+            if carry_out:
+                # the first flush points' batches are set aside for the next step's head (functional.CARRY); the region ends
+                # where early Adam would start: that hook closes it (and leaves the side-stream anchor node there)
+                assert flush and self.world == 1 and self._early_cut is not None and full_flush
+                _fn.CARRY["on"], _fn.CARRY["open"], _fn.CARRY["stash"] = True, True, []
+
+                def close_carry():
+                    _fn.CARRY["open"] = False
+                    self._side_anchor()
+                _fn.BACKWARD_HOOKS[id(self._early_layer)] = close_carry
+            elif flush and self.world == 1 and self._early_cut is not None and self.early_adam and full_flush:
                 _fn.BACKWARD_HOOKS[id(self._early_layer)] = self._early_adam_segment if _fn.SEGMENTER is not None else self._early_adam
             elif self._anchor_layer is not None and _fn.SEGMENTER is None:
                 _fn.BACKWARD_HOOKS[id(self._anchor_layer)] = self._side_anchor
             # (the plain MDiceLoss: its forward sums are folded into the head's logits store -- functional.LOSS_MAIL)
             _fn.LOSS_MAIL["target"] = target if type(self.criterion) is MDiceLoss else None
+            from .models import MICFormer_self as _msh
+            _msh.HEAD_WEIGHTS_AFTER = carried if carry_in is not None else None   # (Head.forward composes its weights behind it)
             try:
                 logits = self.model(x)                              #                              train.py:185
             finally:
                 _fn.LOSS_MAIL["target"] = None
+                _msh.HEAD_WEIGHTS_AFTER = None
             loss = self.criterion(logits, target)                   #                              train.py:187
             _fn.LOSS_MAIL["result"] = None
             _fn.run_entry_hook(force=True)                          # (fewer than 3 stages: launched here)
@@ -265,6 +337,19 @@ class TrainEngine:
                 raise RuntimeError(f"{n} parked LayerNorm backward(s) were not consumed by a self-pair launch (functional._LAZY_LN)")
             _fn.flush_wgrad(calls_only=not flush)                   # what is still queued: grouped linear weight gradients (left
             _fn.join_wgrad_stream()                                 # to the data-parallel tail when flush=False), closures
+            if carry_out:
+                if _fn.CARRY["open"]:
+                    raise RuntimeError("the carry region was never closed (no flush point at the last encoder stage)")
+                groups, cur = {}, []
+                for key, batch in _fn.CARRY["stash"]:               # (flush points inside a stage belong to the stage being left)
+                    cur.append(batch)
+                    if key is not None:
+                        groups.setdefault(key, []).extend(cur)
+                        cur = []
+                if cur or set(groups) - {g["key"] for g in self._carry_groups}:
+                    raise RuntimeError("carried parameter-gradient batches do not map onto the stage groups")
+                self._carried = groups
+                _fn.CARRY["on"], _fn.CARRY["stash"] = False, []
         return loss.detach()
 
     def _adam(self, grad_scale):
@@ -406,6 +491,132 @@ class TrainEngine:
         ops.PARAM_EPOCH[0] += 1                                     # (copies cached for engine-less forwards are stale now)
         return loss
 
+    # ------------------------------------------------------------------ several steps per captured graph
+    def _build_carry_groups(self):
+        """Stage groups of the flat tail [cut, total) in the order a forward first reads them: for each, the id of the stage module
+        whose flush point closes its gradients in the backward, the stage-entry count at which the forward reaches it, and its
+        slices of the flat buffers.  None when the model does not have the MicFormer layout (step_many then runs step by step)."""
+        sw = getattr(self.model, "swin", None)
+        layers, ups = getattr(sw, "layers", None), getattr(sw, "up_layers", None)
+        if sw is None or layers is None or ups is None or self._early_cut is None or len(ups) != len(layers):
+            return None
+        n = len(layers)
+        names = [nm for nm, _ in self.model.named_parameters()]
+        root = "swin"
+        spec = [(layers[n - 1], n, [f"{root}.layers.{n - 1}.", f"{root}.norm."])]
+        for j in range(n):
+            pre = [f"{root}.up_layers.{j}."]
+            if j + 1 < n:
+                pre.append(f"{root}.concat_back_dim.{j + 1}.")
+            else:
+                pre += [f"{root}.norm2.", f"{root}.reverse_patch_embedding.", "out_conv.", f"{root}.concat_back_dim.0."]
+            spec.append((ups[j], n + 1 + j, pre))
+        groups, seen = [], set()
+        for mod, entry, pre in spec:
+            idx = [i for i, nm in enumerate(names) if any(nm.startswith(p) for p in pre)]
+            seen.update(idx)
+            ivs = sorted((self.offsets[i], self.offsets[i] + (self.sizes[i] + 3) // 4 * 4) for i in idx)
+            ranges = []
+            for lo, hi in ivs:
+                if ranges and lo <= ranges[-1][1]:
+                    ranges[-1][1] = max(ranges[-1][1], hi)
+                else:
+                    ranges.append([lo, hi])
+            ranges = [(lo, min(hi, self.flat_p.numel())) for lo, hi in ranges]
+            groups.append({"key": id(mod), "entry": entry, "ranges": ranges, "params": {id(self.params[i]) for i in idx}})
+        tail = {i for i, o in enumerate(self.offsets) if o >= self._early_cut}
+        if seen != tail or self._early_layer is not layers[n - 1]:
+            return None
+        return groups
+
+    def _carry_prep(self, grp):
+        """(forward shadow-weight plan | None, conv layout plan) of one stage group in the current arithmetic mode."""
+        mode = ops.compute_dtype()
+        cache = grp.setdefault("prep", {})
+        if mode not in cache:
+            _, fl_all, _, cl_all = self._prep_split[mode]
+            mine = grp["params"]
+            fl = None
+            if fl_all is not None:
+                fl = ops.WeightPrepPlan([t for t in fl_all.triples if id(self._owner_of(t[0])) in mine], blocked=True)
+            cl = ops.Conv3PrepPlan([t for t in cl_all.triples if id(self._owner_of(t[0])) in mine])
+            cache[mode] = (fl, cl)
+        return cache[mode]
+
+    def _owner_of(self, data):
+        """The parameter whose storage a plan triple's source view is (plans hold p.data views of the flat buffer)."""
+        off = (data.data_ptr() - self.flat_p.data_ptr()) // 4
+        return self._param_at[off]
+
+    def step_many(self, xs, targets):
+        """k = len(xs) consecutive training steps (batch i = xs[i], targets[i]; one optimiser update each, in order) replayed from
+        ONE HIP graph in which step i + 1's encoder forward runs beside the parameter-gradient work and the Adam update of step i's
+        decoder / head / last encoder stage (functional.CARRY): that work otherwise queues up in front of the encoder's batches
+        and drains in a tail behind every step.  Returns the k (device) losses.  Single GPU, graph mode; the result is the same
+        sequence of updates as k calls of step()."""
+        k = len(xs)
+        if self._carry_groups is None:
+            self._carry_groups = self._build_carry_groups() or False
+        if k < 2 or not self.use_graph or self.world != 1 or not self._carry_groups or self.segmented:
+            return [self.step(x, t) for x, t in zip(xs, targets)]
+        ent = self._many
+        if ent is not None and not (ent["k"] == k and ent["mode"] == ops.arith_mode() and all(
+                x.shape == sx.shape and x.dtype == sx.dtype and type(x) is type(sx) and t.shape == st.shape and t.dtype == st.dtype
+                for x, t, sx, st in zip(xs, targets, ent["x"], ent["t"]))):
+            return [self.step(x, t) for x, t in zip(xs, targets)]
+        if ent is None:
+            ent = self._many = self._capture_many(xs, targets)
+        for sx, x in zip(ent["x"], xs):
+            sx.copy_(x, non_blocking=True)
+        for st, t in zip(ent["t"], targets):
+            st.copy_(t, non_blocking=True)
+        ent["graph"].replay()
+        self.steps_done += k
+        ops.PARAM_EPOCH[0] += 1
+        return list(ent["loss"])
+
+    def _many_body(self, sxs, sts):
+        """The k steps as one launch sequence: step i hands the first flush points' batches + the tail's Adam to step i + 1."""
+        losses, carry = [], None
+        for i, (x, t) in enumerate(zip(sxs, sts)):
+            last = i == len(sxs) - 1
+            losses.append(self._fwd_bwd(x, t, carry_in=carry, carry_out=not last))
+            if last:
+                self._update()                                      # (its own early Adam ran under its backward)
+                carry = None
+            else:
+                ops.adam_tick(self.adam_state, self.base_lr, self.eta_min, self.t_max)
+                self._adam_range(0, self._early_cut, 1.0)           # [cut, total) follows at the head of step i + 1
+                carry = self._carried
+        return losses
+
+    def _capture_many(self, xs, targets):
+        sxs, sts = [x.clone() for x in xs], [t.clone() for t in targets]
+        keep = [t.clone() for t in (self.flat_p, self.flat_m, self.flat_v, self.adam_state)]
+        dp_rng = self._drop_path_rng_tensors(sxs[0])
+        dp_keep = [t.clone() for t in dp_rng]
+        rng_cpu, rng_dev = torch.get_rng_state(), torch.cuda.get_rng_state(sxs[0].device)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self._step_impl(sxs[0], sts[0])                         # (sizes scratch buffers / allocator pools: undone below)
+            self._many_body(sxs, sts)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            for dst, src in zip((self.flat_p, self.flat_m, self.flat_v, self.adam_state), keep):
+                dst.copy_(src)
+            for dst, src in zip(dp_rng, dp_keep):
+                dst.copy_(src)
+        torch.set_rng_state(rng_cpu)
+        torch.cuda.set_rng_state(rng_dev, sxs[0].device)
+        del keep
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            losses = self._many_body(sxs, sts)
+        self._carried = None
+        return {"k": len(sxs), "graph": g, "x": sxs, "t": sts, "loss": losses, "mode": ops.arith_mode()}
+
     def _matches_static(self, x, target):
         sx, st = self._static[0], self._static[1]
         ok = x.shape == sx.shape and target.shape == st.shape and x.dtype == sx.dtype and target.dtype == st.dtype \
@@ -523,7 +734,7 @@ class TrainEngine:
         g = sd["param_groups"][0]
         self.betas, self.eps = tuple(g["betas"]), g["eps"]
         self.base_lr = g.get("initial_lr", self.base_lr)
-        self._graph = None                                      # betas / eps / lr constants are baked into a captured step
+        self._graph = self._many = None                         # betas / eps / lr constants are baked into a captured step
 
     def scheduler_state_dict(self):
         """CosineAnnealingLR.state_dict() layout (stepped once per iteration, train.py:148, 206-207)."""
@@ -534,7 +745,7 @@ class TrainEngine:
     def load_scheduler_state_dict(self, sd):
         self.t_max, self.eta_min = sd["T_max"], sd["eta_min"]
         self.base_lr = sd["base_lrs"][0]
-        self._graph = None
+        self._graph = self._many = None
 
     def checkpoint(self, epoch):
         """The dict the reference writes with torch.save (train.py:233-241): epoch, state_dict, optimizer, scheduler."""

@@ -110,6 +110,8 @@ def drop_deferred():
     _QUEUED_DW.clear()
     _PENDING_FLUSH.clear()
     _LAZY_LN.clear()
+    CARRY["on"], CARRY["open"] = False, False
+    CARRY["stash"].clear()
 
 
 def _ln_defer(on):
@@ -326,6 +328,43 @@ def run_entry_hook(force=False):
 # backward side: callables the engine parks per stage (key = id of the stage module); run when the backward has left that stage
 BACKWARD_HOOKS = {}
 
+# Carry (TrainEngine.step_many: several steps in ONE captured graph).  The parameter-gradient batches of the flush points the backward
+# reaches FIRST -- decoder, head, last encoder stage: exactly the gradients of the flat buffers' tail [cut, total) -- are not
+# launched under the backward (where they only queue up in front of the encoder's batches and push those into a tail behind the
+# step) but set aside; the engine launches them, and the Adam update of that tail, on the side stream at the START of the next
+# step of the same graph, under its encoder forward -- which does not read those parameters and leaves half the chip idle in its
+# 8^3 stage.  "open": the backward is still inside that first region (the engine's hook at the last encoder stage closes it).
+CARRY = {"on": False, "open": False, "stash": []}
+
+
+def _carry_stash(key):
+    """Set aside everything queued so far (linear items, LayerNorm partials, closures) for the next step's head.  key: id of the
+    stage module whose backward this flush point closes (None: a flush point inside a stage)."""
+    launch_pending_flush()
+    batch = (list(_DEFERRED), list(_DEFERRED_LN), list(_DEFERRED_CALLS))
+    _DEFERRED.clear()
+    _DEFERRED_LN.clear()
+    _DEFERRED_CALLS.clear()
+    _QUEUED_DW.clear()
+    CARRY["stash"].append((key, batch))
+
+
+def launch_carried(batches):
+    """The engine, at the head of the next step (current stream = the weight-gradient side stream)."""
+    side = torch.cuda.current_stream()
+    for items, ln, calls in batches:
+        # (the batch's references die here: tell the allocator the side stream still reads the tensors)
+        for it in items:
+            for t in (it[0], it[1], it[4]):
+                if t is not None:
+                    t.record_stream(side)
+        for it in ln:
+            it[0].record_stream(side)
+        for _, tensors, _blk in calls:
+            for t in tensors:
+                t.record_stream(side)
+        _launch_batch(items, ln, calls)
+
 
 class FlushPointFn(torch.autograd.Function):
     @staticmethod
@@ -345,7 +384,9 @@ class FlushPointFn(torch.autograd.Function):
                     FLUSH_BUDGET[0] -= 1
                 flush_wgrad_side(calls_only=not full, extra=[hook] if hook is not None else None)
             return dx, dxa, None
-        if full:
+        if CARRY["on"] and CARRY["open"] and full:
+            _carry_stash(ctx.key)                       # (launched at the head of the next step: see CARRY)
+        elif full:
             FLUSH_BUDGET[0] -= 1
             flush_wgrad_side(lazy=True)
         elif DEFER_CALLS and DEFER_WGRAD:

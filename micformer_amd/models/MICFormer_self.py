@@ -243,6 +243,7 @@ FUSE_HEAD_TAIL = True
 import os as _os
 PAIR_BLOCKS = _os.environ.get("MICF_PAIR_BLOCKS", "1") != "0"
 _SIDE_STREAMS = {}
+HEAD_WEIGHTS_AFTER = None           # TrainEngine.step_many: [event] behind which the head's weights are current (None: always)
 
 
 def _side_stream(device):
@@ -678,19 +679,36 @@ class Head(nn.Module):
             # ConvTranspose3d(k = s = P) and the 3^3 Conv3d have nothing between them: one composed linear map (head_tail.hip)
             # (the composition reads weights only: in engine mode it runs on the side stream under the first stage)
             wb = bf = wut = packs = None
+            composed = []
             if PARALLEL_MODALITIES:
                 from .. import ops
                 main, side = torch.cuda.current_stream(), _side_stream(x.device)
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    wut = ops.head_tail_transposed_up(rp.weight)
-                    wb, bf = ops.head_tail_compose(rp.weight, rp.bias, oc.weight, wut)
-                    if Fn.FUSE_TAIL_PATCHES and ops.head_tail_fused_supported(
-                            (x.shape[0],) + tuple(s // rp.kernel_size[0] for s in x.shape[2:]), rp.in_channels, oc.out_channels,
-                            rp.kernel_size[0]) and all(s % rp.kernel_size[0] == 0 for s in x.shape[2:]):
-                        packs = ops.head_tail_pack(wb, bf, oc.bias, rp.kernel_size[0])
+
+                def compose():
+                    if composed:
+                        return
+                    side.wait_stream(main)
+                    if HEAD_WEIGHTS_AFTER is not None and HEAD_WEIGHTS_AFTER[0] is not None:
+                        side.wait_event(HEAD_WEIGHTS_AFTER[0])          # (step_many: the head's carried Adam update)
+                    with torch.cuda.stream(side):
+                        wu = ops.head_tail_transposed_up(rp.weight)
+                        w, b = ops.head_tail_compose(rp.weight, rp.bias, oc.weight, wu)
+                        pk = None
+                        if Fn.FUSE_TAIL_PATCHES and ops.head_tail_fused_supported(
+                                (x.shape[0],) + tuple(s // rp.kernel_size[0] for s in x.shape[2:]), rp.in_channels, oc.out_channels,
+                                rp.kernel_size[0]) and all(s % rp.kernel_size[0] == 0 for s in x.shape[2:]):
+                            pk = ops.head_tail_pack(w, b, oc.bias, rp.kernel_size[0])
+                    composed.append((w, b, wu, pk))
+                if HEAD_WEIGHTS_AFTER is None:
+                    compose()                                           # under the first stage, as always
+                else:
+                    # the head's weights are updated by work the engine launches at the first stage entry (TrainEngine.step_many):
+                    # compose behind it, at the entry of the last stage
+                    Fn.park_entry_hook(compose, at=len(self.swin.layers) + len(self.swin.up_layers))
             coarse = self.swin.coarse_features(x, 0, x, 1)
-            if wb is not None:
+            if PARALLEL_MODALITIES:
+                compose()                                               # (fewer stage entries than expected: now)
+                wb, bf, wut, packs = composed[0]
                 main.wait_stream(side)
                 for t in (wb, bf, wut) + (tuple(packs) if packs is not None else ()):
                     t.record_stream(main)

@@ -351,3 +351,68 @@ def test_bf16_weight_gradient_of_a_layer_too_long_to_queue():
     want = dy.bfloat16().float().t() @ a.bfloat16().float()
     assert float((dw - want).abs().max()) <= 2e-3 * float(want.abs().max())
     assert float((db - dy.bfloat16().float().sum(0)).abs().max()) <= 2e-3 * float(dy.sum(0).abs().max()) + 1e-3
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_step_many_is_the_same_sequence_of_updates(M, dtype):
+    """TrainEngine.step_many (k steps in ONE graph, the decoder-side parameter gradients + Adam of step i carried to the head of
+    step i + 1: functional.CARRY) against k eager step() calls on the same batches: losses, Adam step counter, first moments --
+    twice in a row (the second replay starts from the state the first one left), in train mode (DropPath draws advance per step),
+    and a checkpoint round trip drops the captured graph."""
+    from micformer_amd import ops
+    from micformer_amd.engine import TrainEngine
+    ops.set_compute_dtype(dtype)
+    try:
+        xa, ta = _data(2)
+        batches = [(xa, ta), (xa.flip(2).contiguous(), ta.flip(2).contiguous()), ((xa * 0.5).contiguous(), ta)]
+        tol = 1e-4 if dtype == "fp32" else 2e-3
+        # (the DropPath stream draws its device seed from torch's CPU generator at first use: same seed before each engine's first step)
+        torch.manual_seed(5)
+        eager = TrainEngine(_head(M, train=True), base_lr=1e-3, t_max=20, use_graph=False)
+        le = [[float(eager.step(x, t)) for x, t in batches] for _ in range(2)]
+        ck_state = eager.flat_m.clone(), int(eager.adam_state[0].item())
+        le.append([float(eager.step(x, t)) for x, t in batches])
+        torch.manual_seed(5)
+        many = TrainEngine(_head(M, train=True), base_lr=1e-3, t_max=20, use_graph=True)
+        for rnd_ in range(2):
+            lm = [float(l) for l in many.step_many([b[0] for b in batches], [b[1] for b in batches])]
+            assert all(abs(a - b) <= tol for a, b in zip(le[rnd_], lm)), (rnd_, le[rnd_], lm)
+            assert int(many.adam_state[0].item()) == 3 * (rnd_ + 1)
+        assert int(many.adam_state[0].item()) == ck_state[1]
+        fin = torch.isfinite(ck_state[0]) & torch.isfinite(many.flat_m)
+        assert float((ck_state[0] - many.flat_m)[fin].abs().max()) <= 3e-2 * float(ck_state[0][fin].abs().max())
+        assert many.steps_done == 6 and many._many is not None and many._many["k"] == 3
+        many.load_checkpoint(many.checkpoint(epoch=0))
+        assert many._many is None
+        lm = [float(l) for l in many.step_many([b[0] for b in batches], [b[1] for b in batches])]
+        assert all(abs(a - b) <= tol for a, b in zip(le[2], lm)), (le[2], lm)
+        _same_training_state(eager, many, "after 9 steps")
+    finally:
+        ops.set_compute_dtype("fp32")
+
+
+def test_step_many_on_the_fused_kernels_base_model():
+    """The same on the kernels the bench runs: base widths (fused block kernels, lazy LayerNorm backward, fused loss), bf16, train
+    mode, 64^3: four steps in one graph against four replays of the one-step graph."""
+    from micformer_amd import ops
+    from micformer_amd.engine import TrainEngine
+    import micformer_amd.models.MICFormer_self as MM
+    ops.set_compute_dtype("bf16")
+    try:
+        x, t = _data(2)
+
+        def engine():
+            torch.manual_seed(11)
+            h = MM.Head(embed_dim=48, num_classes=8).cuda().train()
+            torch.manual_seed(12)                       # (the DropPath device seed is drawn at the engine's first step)
+            return TrainEngine(h, base_lr=1e-4, t_max=50, use_graph=True)
+        one = engine()
+        l1 = [float(one.step(x, t)) for _ in range(8)]
+        many = engine()
+        lm = [float(l) for _ in range(2) for l in many.step_many([x] * 4, [t] * 4)]
+        assert all(abs(a - b) <= 2e-3 for a, b in zip(l1, lm)), (l1, lm)
+        assert l1[-1] < l1[0]                                                        # (it trains)
+        _same_training_state(one, many, "after 8 steps")
+        assert float((one.flat_p - many.flat_p).abs().max()) <= 20 * 1e-4           # (a few lr-sized Adam steps apart at most)
+    finally:
+        ops.set_compute_dtype("fp32")

@@ -2,7 +2,7 @@
 # Run ON THE GPU BOX (through gpurun) from the repo root: regenerates the evidence kept under profiles/ into gpurun_out/$R/.
 #   gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh r03'   then   cp gpurun_out/r03/r03_* gpurun_out/r03/pmc_traffic.json profiles/
 set -u
-R=${1:-r03}
+R=${1:-r04}
 OUT=gpurun_out/$R
 mkdir -p $OUT
 python bench.py > $OUT/${R}_bench.json 2> $OUT/bench.err

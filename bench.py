@@ -275,7 +275,7 @@ def main(argv=None):
         if not stub:
             torch.cuda.synchronize()
 
-    spg = args.steps_per_graph if (world == 1 and not stub and not args.no_graph and not args.segmented and not args.split_step) else 1
+    spg = args.steps_per_graph if (world == 1 and not stub and not args.no_graph and not args.split_step) else 1
     if spg > 1 and args.steps % spg:
         raise SystemExit("--steps must be a multiple of --steps-per-graph")
     if spg > 1:
@@ -316,11 +316,13 @@ def main(argv=None):
                                f"8 classes) full train step (fwd + MDiceLoss + bwd + Adam/cosine) on {args.vol}^3 CT+MR pairs, "
                                f"{'DropPath on' if not args.eval_mode else 'eval mode'}",
                    "local_batch": args.batch, "global_batch": world * args.batch, "parallelism": f"dp{world}",
-                   "launch": "eager" if args.no_graph else (f"hipGraph replay ({spg} consecutive steps per graph: the decoder-side "
-                                                            "parameter gradients + Adam of step i run beside step i + 1's encoder forward; "
-                                                            "every step is a full update on its own batch)") if spg > 1 else
+                   "launch": "eager" if args.no_graph else (f"hipGraph replay ({spg} consecutive steps per capture"
+                                                            + (f" as a sequence of {len(eng._many['graph'].segments)} graphs on two streams"
+                                                               if (eng._many is not None and eng.segmented) else " in one graph") +
+                                                            ": the decoder-side parameter gradients + Adam of step i run beside step i + 1's "
+                                                            "encoder forward; every step is a full update on its own batch)") if spg > 1 else
                              ("hipGraph replay (one graph)" if (stub or not eng.segmented) else
-                                                            f"hipGraph replay ({len(eng._graph.segments)} segments: main chain / "
+                                                            f"hipGraph replay ({len((eng._graph or eng._many['graph']).segments)} segments: main chain / "
                                                             "parameter-gradient batches as separate graphs on two streams)")},
         "final_loss": round(loss_val, 6),
     }

@@ -252,7 +252,31 @@ class TrainEngine:
                     _fn.park_entry_hook(lambda: main.wait_stream(side), at=1)
                 carried = [None]                                   # (the last group's event, once launched)
 
+                def launch_carried_groups_segmented():
+                    # the step as a sequence of graphs: every stage group is its own graph on the side stream with an event behind
+                    # it, the main chain is cut where it must wait for one; the backward preparation rides as the last side graph
+                    def group_work(grp):
+                        def w():
+                            _fn.launch_carried(carry_in.get(grp["key"], []))
+                            for lo, hi in grp["ranges"]:
+                                self._adam_range(lo, hi, 1.0)
+                            fl, cl = self._carry_prep(grp)
+                            cl.launch()
+                            if fl is not None:
+                                fl.launch()
+                        return [w]
+
+                    def prep():
+                        ops.zero_(self.flat_g)
+                        bwd.launch()
+                    evs = _fn.SEGMENTER.run_side_groups([group_work(g) for g in self._carry_groups] + [[prep]], keep=carry_in)
+                    for grp, ev in zip(self._carry_groups, evs):
+                        _fn.park_entry_hook((lambda e: (lambda: _fn.SEGMENTER.wait(e)))(ev), at=grp["entry"], front=True)
+                    carried[0] = evs[-1]
+
                 def launch_carried_groups():
+                    if _fn.SEGMENTER is not None:
+                        return launch_carried_groups_segmented()
                     # Created AFTER the main chain's first kernels of this step (stage entry 1: patch embedding launched): a side
                     # branch created first makes the captured graph's executor run it in front of the main chain (measured: the
                     # carried work then sat in a 2 ms tail between the steps instead of under the encoder forward).
@@ -284,6 +308,8 @@ class TrainEngine:
                     _fn.park_entry_hook(lambda: main.wait_stream(side), at=1)
 
             def backward_prep():                                    # under the latency-bound small stages of the forward
+                if carry_in is not None and _fn.SEGMENTER is not None:
+                    return                                          # (segmented step_many: part of the carried side graphs)
                 side.wait_stream(main)
                 if carried[0] is not None:
                     side.wait_event(carried[0])                     # (the carried Adam reads the gradients this zero fill clears)
@@ -305,7 +331,8 @@ class TrainEngine:
 
                 def close_carry():
                     _fn.CARRY["open"] = False
-                    self._side_anchor()
+                    if _fn.SEGMENTER is None:
+                        self._side_anchor()
                 _fn.BACKWARD_HOOKS[id(self._early_layer)] = close_carry
             elif flush and self.world == 1 and self._early_cut is not None and self.early_adam and full_flush:
                 _fn.BACKWARD_HOOKS[id(self._early_layer)] = self._early_adam_segment if _fn.SEGMENTER is not None else self._early_adam
@@ -314,7 +341,8 @@ class TrainEngine:
             # (the plain MDiceLoss: its forward sums are folded into the head's logits store -- functional.LOSS_MAIL)
             _fn.LOSS_MAIL["target"] = target if type(self.criterion) is MDiceLoss else None
             from .models import MICFormer_self as _msh
-            _msh.HEAD_WEIGHTS_AFTER = carried if carry_in is not None else None   # (Head.forward composes its weights behind it)
+            # (Head.forward composes its weights behind the carried update: an event, or -- a sequence of graphs -- just later)
+            _msh.HEAD_WEIGHTS_AFTER = (carried if _fn.SEGMENTER is None else [None]) if carry_in is not None else None
             try:
                 logits = self.model(x)                              #                              train.py:185
             finally:
@@ -324,6 +352,8 @@ class TrainEngine:
             _fn.LOSS_MAIL["result"] = None
             _fn.run_entry_hook(force=True)                          # (fewer than 3 stages: launched here)
             main.wait_stream(side)
+            if carry_in is not None and _fn.SEGMENTER is not None:
+                _fn.SEGMENTER.wait(carried[0])                      # (zero fill + W^T shadows: the last carried side graph)
             if _fn.SEGMENTER is not None:
                 # segmented capture: the flush points end / begin stream captures from inside backward; keep autograd on the
                 # calling thread so every hipStreamBeginCapture / EndCapture of this step is issued by ONE host thread
@@ -557,7 +587,7 @@ class TrainEngine:
         k = len(xs)
         if self._carry_groups is None:
             self._carry_groups = self._build_carry_groups() or False
-        if k < 2 or not self.use_graph or self.world != 1 or not self._carry_groups or self.segmented:
+        if k < 2 or not self.use_graph or self.world != 1 or not self._carry_groups:
             return [self.step(x, t) for x, t in zip(xs, targets)]
         ent = self._many
         if ent is not None and not (ent["k"] == k and ent["mode"] == ops.arith_mode() and all(
@@ -611,9 +641,26 @@ class TrainEngine:
         torch.set_rng_state(rng_cpu)
         torch.cuda.set_rng_state(rng_dev, sxs[0].device)
         del keep
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            losses = self._many_body(sxs, sts)
+        if self.segmented:
+            from . import functional as _fn
+            torch.cuda.empty_cache()
+            g = _fn.StepSegmenter(_fn._wgrad_stream(sxs[0].device))
+            cs = torch.cuda.Stream(device=sxs[0].device)
+            cs.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(cs):
+                _fn.SEGMENTER = g
+                try:
+                    g.begin()
+                    with torch.autograd.set_multithreading_enabled(False):
+                        losses = self._many_body(sxs, sts)
+                    g.finish()
+                finally:
+                    _fn.SEGMENTER = None
+            torch.cuda.current_stream().wait_stream(cs)
+        else:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                losses = self._many_body(sxs, sts)
         self._carried = None
         return {"k": len(sxs), "graph": g, "x": sxs, "t": sts, "loss": losses, "mode": ops.arith_mode()}
 

@@ -195,6 +195,32 @@ class StepSegmenter:
         self.keep.append(keep)
         self.begin()
 
+    def run_side_groups(self, works, keep=None):
+        """Cut the main chain here; capture every entry of `works` (a list of callables each) as its OWN graph on the side stream,
+        replayed back to back there with an event behind each; -> the events (TrainEngine.step_many: the stage groups of the
+        carried parameter work, each awaited by the main chain only where the forward first reads that group's parameters)."""
+        self._end_main()
+        evs = []
+        for k, work in enumerate(works):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(self.side):
+                g.capture_begin(pool=self.pool_s, capture_error_mode="relaxed")
+                for w in work:
+                    w()
+                g.capture_end()
+            ev = torch.cuda.Event()
+            self.segments.append(("side_ev", (g, ev, k == 0)))
+            evs.append(ev)
+        self.keep.append(keep)
+        self.begin()
+        return evs
+
+    def wait(self, ev):
+        """Cut the main chain here; it continues once `ev` (of run_side_groups) has been recorded in this replay."""
+        self._end_main()
+        self.segments.append(("wait", ev))
+        self.begin()
+
     def join(self):
         self._end_main()
         self.segments.append(("join", None))
@@ -207,9 +233,22 @@ class StepSegmenter:
     def replay(self):
         main = torch.cuda.current_stream()
         for kind, g in self.segments:
-            if kind == "side" and SEG_SKIP_SIDE:
+            if kind in ("side", "side_ev") and SEG_SKIP_SIDE:
                 continue
-            if kind == "main" or (kind == "side" and SEG_SERIAL):
+            if kind == "side_ev":
+                graph, ev, first = g
+                if SEG_SERIAL:
+                    graph.replay()
+                    continue
+                if first:
+                    self.side.wait_stream(main)
+                with torch.cuda.stream(self.side):
+                    graph.replay()
+                    ev.record(self.side)
+            elif kind == "wait":
+                if not (SEG_SERIAL or SEG_SKIP_SIDE):
+                    main.wait_event(g)
+            elif kind == "main" or (kind == "side" and SEG_SERIAL):
                 g.replay()
             elif kind == "side":
                 self.side.wait_stream(main)
@@ -312,8 +351,12 @@ def clear_entry_hooks():
     _ENTRY_SEEN[0] = 0
 
 
-def park_entry_hook(fn, at):
-    _ENTRY_HOOKS.append([fn, at])
+def park_entry_hook(fn, at, front=False):
+    """front: runs before the hooks already parked for the same entry."""
+    if front:
+        _ENTRY_HOOKS.insert(0, [fn, at])
+    else:
+        _ENTRY_HOOKS.append([fn, at])
 
 
 def run_entry_hook(force=False):
@@ -378,15 +421,18 @@ class FlushPointFn(torch.autograd.Function):
         # the weight gradients of the big stages then pile up in the tail)
         full = FLUSH_POINTS and DEFER_WGRAD and dx.numel() // dx.shape[-1] <= FLUSH_MAX_TOKENS and FLUSH_BUDGET[0] > 0
         hook = BACKWARD_HOOKS.pop(ctx.key, None) if ctx.key is not None else None
+        if CARRY["on"] and CARRY["open"] and full:
+            _carry_stash(ctx.key)                       # (launched at the head of the next step: see CARRY)
+            if hook is not None:
+                hook()
+            return dx, dxa, None
         if SEGMENTER is not None:                       # the hook (early Adam) rides in the same side segment as the batch
             if full or (DEFER_CALLS and DEFER_WGRAD) or hook is not None:
                 if full:
                     FLUSH_BUDGET[0] -= 1
                 flush_wgrad_side(calls_only=not full, extra=[hook] if hook is not None else None)
             return dx, dxa, None
-        if CARRY["on"] and CARRY["open"] and full:
-            _carry_stash(ctx.key)                       # (launched at the head of the next step: see CARRY)
-        elif full:
+        if full:
             FLUSH_BUDGET[0] -= 1
             flush_wgrad_side(lazy=True)
         elif DEFER_CALLS and DEFER_WGRAD:

@@ -688,7 +688,7 @@ class Head(nn.Module):
                     if composed:
                         return
                     side.wait_stream(main)
-                    if HEAD_WEIGHTS_AFTER is not None and HEAD_WEIGHTS_AFTER[0] is not None:
+                    if HEAD_WEIGHTS_AFTER is not None and HEAD_WEIGHTS_AFTER[0] is not None and Fn.SEGMENTER is None:
                         side.wait_event(HEAD_WEIGHTS_AFTER[0])          # (step_many: the head's carried Adam update)
                     with torch.cuda.stream(side):
                         wu = ops.head_tail_transposed_up(rp.weight)

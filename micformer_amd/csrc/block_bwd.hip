@@ -263,7 +263,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
   constexpr int TM = 16 * TJ, VPL = (C + 63) / 64, NSL = C / 16, NTHR = 64 * NW, RPP = 4 * NW, NPASS = (TM + RPP - 1) / RPP;
   constexpr bool PARK = block_bwd_park_floats(TM, C, NTHR) != 0;
   extern __shared__ __attribute__((aligned(1024))) float lds[];
-  constexpr int C4 = C >> 2, S = C + 4, SU = block_u_cols(C) + 4, Hd = 4 * C;
+  constexpr int C4 = C >> 2, S = C + 4, SU = block_u_cols(C, false, TM) + 4, Hd = 4 * C;
   float* ring = lds;
   float* A1 = ring + block_bwd_scratch_floats(TM, C / HD, NTHR);
   float* A2 = A1 + TM * S;
@@ -273,8 +273,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
   int* tok = reinterpret_cast<int*>(sc2 + TM);
   float* stash = sc2 + 2 * TM;                          // (PARK only) LayerNorm-1 inputs across the attention backward
   float* pb1 = stash + block_bwd_park_floats(TM, C, NTHR);   // (RECOMP only) fc1 bias [4C]
-  float* XN2 = block_hidden_chunk(C) == 4 * C ? A2 : U + 2 * C;      // (RECOMP only) where the xn2 rows wait, and their row stride
-  constexpr int SXN2 = block_hidden_chunk(C) == 4 * C ? S : SU;
+  float* XN2 = block_hidden_chunk(C, false, TM) == 4 * C ? A2 : U + 2 * C;      // (RECOMP only) where the xn2 rows wait, and their row stride
+  constexpr int SXN2 = block_hidden_chunk(C, false, TM) == 4 * C ? S : SU;
 
   int grp, tile;
   if (a.G == 2) { const int xcd = blockIdx.x & 7; grp = xcd >> 2; tile = (int)(blockIdx.x >> 3) * 4 + (xcd & 3); }
@@ -331,7 +331,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
   }
 
   // ---- request every global input of the tile (see RowRegs)
-  constexpr int HC = block_hidden_chunk(C);
+  constexpr int HC = block_hidden_chunk(C, false, TM);
   RowRegs<TM, NW, C4> r_dy;
   HRegs<TM, NW, HC / 4, BF16> r_h[RECOMP ? 1 : Hd / HC];
   HRegs<TM, NW, C4, BF16> r_xn2;

@@ -330,18 +330,18 @@ constexpr int block_bwd_park_floats(int TM, int C, int nthr) { return C <= 48 ? 
 // each a barrier-to-barrier round trip in a kernel that is bound by exactly those)
 // (fwd: the forward kernel's choice; the backward's LDS also holds the attention exchange and the parked LayerNorm inputs)
 #ifdef MICF_AB_HC2C              // (A/B build: the two-chunk form everywhere)
-constexpr int block_hidden_chunk(int C, bool fwd = false) { return 2 * C; }
-#elif defined(MICF_AB_FWD_HC4)   // (A/B build: one chunk in every forward)
-constexpr int block_hidden_chunk(int C, bool fwd = false) { return (C >= 192 || fwd) ? 4 * C : 2 * C; }
-#elif defined(MICF_AB_FWD_HC4_96)
-constexpr int block_hidden_chunk(int C, bool fwd = false) { return (C >= 192 || (fwd && C >= 96)) ? 4 * C : 2 * C; }
+constexpr int block_hidden_chunk(int C, bool fwd = false, int TM = 0) { return 2 * C; }
+#elif defined(MICF_AB_HC4_TM16)  // (A/B build: one chunk also on 16-token tiles of the narrow stages)
+constexpr int block_hidden_chunk(int C, bool fwd = false, int TM = 0) { return (C >= 192 || TM == 16) ? 4 * C : 2 * C; }
 #else
-constexpr int block_hidden_chunk(int C, bool fwd = false) { return C >= 192 ? 4 * C : 2 * C; }
+constexpr int block_hidden_chunk(int C, bool fwd = false, int TM = 0) { return C >= 192 ? 4 * C : 2 * C; }
 #endif
 // columns of the U tile: q | k | v (3C) or a hidden chunk, whichever is wider
-constexpr int block_u_cols(int C, bool fwd = false) { return block_hidden_chunk(C, fwd) > 3 * C ? block_hidden_chunk(C, fwd) : 3 * C; }
+constexpr int block_u_cols(int C, bool fwd = false, int TM = 0) {
+  return block_hidden_chunk(C, fwd, TM) > 3 * C ? block_hidden_chunk(C, fwd, TM) : 3 * C;
+}
 inline size_t block_lds_floats(int TM, int C, int scratch, int params, bool fwd = false) {
-  return (size_t)scratch + (size_t)TM * (2 * (C + 4) + block_u_cols(C, fwd) + 4) + 3 * TM + params;
+  return (size_t)scratch + (size_t)TM * (2 * (C + 4) + block_u_cols(C, fwd, TM) + 4) + 3 * TM + params;
 }
 // waves per workgroup: 8 where a launch has too few tiles to fill the chip and every tile streams megabytes of weights
 // (C = 192: 128 tiles of 16 tokens at the base model's 8^3 stage) -- the x tiles of a phase are then dealt to 8 waves

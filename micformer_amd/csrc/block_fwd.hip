@@ -35,7 +35,7 @@ template <int C, int HD, int TJ, int NW, bool BF16, bool SAMP>
 __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) {
   constexpr int TM = 16 * TJ, VPL = (C + 63) / 64, NSL = C / 16, NTHR = 64 * NW, RPP = 4 * NW, NPASS = (TM + RPP - 1) / RPP;
   extern __shared__ __attribute__((aligned(1024))) float lds[];
-  constexpr int C4 = C >> 2, S = C + 4, SU = block_u_cols(C, true) + 4, Hd = 4 * C;
+  constexpr int C4 = C >> 2, S = C + 4, SU = block_u_cols(C, true, TM) + 4, Hd = 4 * C;
   float* A1 = lds;
   float* A2 = A1 + TM * S;
   float* U = A2 + TM * S;
@@ -363,7 +363,7 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
 
   // ---- MLP in hidden chunks of <= 2C (<= 3C fits U): fc1 chunk (+ b1) -> U; save h, GELU in place, save g; fc2 chunk
   // accumulates s2 * (g W2^T) into A2 (which holds x1)
-  constexpr int HC = block_hidden_chunk(C, true);
+  constexpr int HC = block_hidden_chunk(C, true, TM);
   for (int c0 = 0; c0 < Hd; c0 += HC) {
     constexpr int hc = HC;
     if (!(a.debug & 4)) gemm_phase<TJ, NSL, 1, C, NW, BF16>(w1 + (int64_t)c0 * C, hc, A1, nullptr, 0, nullptr, S, U, SU, EpiBias{p_b1 + c0});

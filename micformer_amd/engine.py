@@ -511,8 +511,10 @@ class TrainEngine:
         else:
             if self._graph is None:
                 self._capture(x, target)
-            self._static[0].copy_(x, non_blocking=True)
-            self._static[1].copy_(target, non_blocking=True)
+            if x is not self._static[0]:                            # (a loader that fills input_buffers() itself skips the copies)
+                self._static[0].copy_(x, non_blocking=True)
+            if target is not self._static[1]:
+                self._static[1].copy_(target, non_blocking=True)
             self._graph.replay()
             if self.split_step:                                     # weight-gradient groups, RCCL and Adam stay outside the graph
                 self._flush_and_reduce(then_update=True)
@@ -663,6 +665,12 @@ class TrainEngine:
                 losses = self._many_body(sxs, sts)
         self._carried = None
         return {"k": len(sxs), "graph": g, "x": sxs, "t": sts, "loss": losses, "mode": ops.arith_mode()}
+
+    def input_buffers(self):
+        """(x, target) device buffers the captured step reads, or None before the first graph step.  A data pipeline that writes its
+        batches straight into them (H2D copies, or the device-side input tail) and passes THESE objects to step() saves the
+        device-to-device staging copies of every step (201 MB at base / 128^3 / batch 2: ~0.1 ms)."""
+        return None if self._static is None else (self._static[0], self._static[1])
 
     def _matches_static(self, x, target):
         sx, st = self._static[0], self._static[1]

@@ -607,7 +607,8 @@ int micf::offset_sample_bwd_groups(SampleBwdSet* sets, int n, int B, int D, int 
     al = al && aligned16(q.dxs) && aligned16(q.xa) && aligned16(q.dxa);
   }
   // quad kernels (4 tokens per wave) when the channel rows allow 16-byte accesses
-  const bool quad = T >= 4096 && (C % 4 == 0) && al;   // tiny grids: 1 token per wave
+  static const int64_t quad_min = [] { const char* e = getenv("MICF_SAMPLE_QUAD_MIN"); return e ? (int64_t)atoll(e) : (int64_t)4096; }();
+  const bool quad = T >= quad_min && (C % 4 == 0) && al;   // tiny grids: 1 token per wave
   const int tpw = quad ? quads_per_wave(T) : tok_per_wave(T);
   const int wpb = quad ? quad_waves_per_block(T) : 4;
   const int blocks = ceil_div(T, (quad ? 4 * wpb : 4) * tpw);

@@ -416,3 +416,38 @@ def test_step_many_on_the_fused_kernels_base_model():
         assert float((one.flat_p - many.flat_p).abs().max()) <= 20 * 1e-4           # (a few lr-sized Adam steps apart at most)
     finally:
         ops.set_compute_dtype("fp32")
+
+
+def test_benched_step_launch_list():
+    """What the benched step (bf16, base widths, engine mode) does NOT launch any more (round 4): MDiceLoss's forward reduction
+    (folded into the head's logits store), the LayerNorm-1 backward of the cross pairs (prologue of the self pairs' block_bwd), and
+    -- with input_buffers() -- no staging copy; and what it launches instead."""
+    from micformer_amd import _lib, ops
+    from micformer_amd.engine import TrainEngine
+    import micformer_amd.models.MICFormer_self as MM
+    ops.set_compute_dtype("bf16")
+    try:
+        x, t = _data(2)
+        torch.manual_seed(3)
+        eng = TrainEngine(MM.Head(embed_dim=48, num_classes=8).cuda().train(), base_lr=1e-4, t_max=50, use_graph=False)
+        eng.step(x, t)
+        torch.cuda.synchronize()
+        _lib.profile_start()
+        loss = eng.step(x, t)
+        prof = _lib.profile_stop()
+        names = {k.split("|")[0] for k in prof}
+        assert float(loss) == float(loss)
+        assert "micf_head_tail_fwd_loss_fused" in names and "micf_dice_bce_fwd" not in names and "micf_head_tail_fwd_fused" not in names
+        assert "micf_dice_bce_bwd" in names                                   # (the loss backward stays its own launch)
+        assert "micf_layernorm_bwd_pair" not in names and "micf_layernorm_fwd_pair" in names
+        assert prof["micf_block_bwd"]["calls"] == prof["micf_block_fwd"]["calls"] == 48 if "micf_block_bwd" in prof else True
+        # a graph engine hands out the buffers its captured step reads; passing them back skips the staging copies
+        g = TrainEngine(MM.Head(embed_dim=48, num_classes=8).cuda().train(), base_lr=1e-4, t_max=50, use_graph=True)
+        assert g.input_buffers() is None
+        g.step(x, t)
+        bx, bt = g.input_buffers()
+        assert bx.data_ptr() != x.data_ptr() and torch.equal(bx, x) and torch.equal(bt, t)
+        la = float(g.step(bx, bt))
+        assert la == la
+    finally:
+        ops.set_compute_dtype("fp32")

@@ -15,6 +15,7 @@
 // unquantised attention of the saved q / k / v).
 #pragma once
 #include "common.h"
+#include "gemm_dma.h"
 
 namespace micf {
 
@@ -74,6 +75,47 @@ __device__ __forceinline__ void attn16_fp8(const float* qp, const float* kp, con
     for (int t = 0; t < 8; ++t) v[t] = vb[t * ld];
     const long vfrag = lr < 2 ? pack8_fp8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7])) : 0L;
     const f32x4 o = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(vfrag, pfrag, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    out[cb] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// ---- the same unit with bf16 operands (MICF_DTYPE_BF16's default attention on the block kernels, round 4): v_mfma_f32_16x16x16_bf16
+// (k = 16: one product per 16 channels of the head for S^T, and -- the 16 keys being exactly one k range -- the accumulator quad of
+// S^T IS the P^T operand of O^T = V^T P^T: no exchange between the lanes at all).  q * scale, k, v and P are rounded to bf16 (RNE)
+// where they enter a fragment, fp32 accumulation; the VALU form kept q / k / v / P in fp32 (MICF_ATTN_VALU=1 restores it).
+typedef short bf16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x4_t pack4_bf16v(float a, float b, float c, float d) {
+  const unsigned lo = pack_bf16(a, b), hi = pack_bf16(c, d);
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(bf16x4_t, u32x2_t{lo, hi});
+}
+
+template <int HD>
+__device__ __forceinline__ void attn16_bf16(const float* qp, const float* kp, const float* vp, int ld, float scale, float4 (&out)[HD / 16]) {
+  const int lane = threadIdx.x & 63, li = lane & 15, lr = lane >> 4;
+  f32x4 st = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < HD / 16; ++ks) {
+    const float4 q4 = *reinterpret_cast<const float4*>(qp + li * ld + 16 * ks + 4 * lr);
+    const float4 k4 = *reinterpret_cast<const float4*>(kp + li * ld + 16 * ks + 4 * lr);
+    st = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pack4_bf16v(k4.x, k4.y, k4.z, k4.w),
+                                                  pack4_bf16v(q4.x * scale, q4.y * scale, q4.z * scale, q4.w * scale), st, 0, 0, 0);
+  }
+  const bool valid = (lr >> 1) == (li >> 3);
+  float m = valid ? fmaxf(fmaxf(st[0], st[1]), fmaxf(st[2], st[3])) : -INFINITY;
+  m = fmaxf(m, __shfl_xor(m, 16, 64));
+  float e[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) e[r] = valid ? expf(st[r] - m) : 0.f;
+  float sum = (e[0] + e[1]) + (e[2] + e[3]);
+  sum += __shfl_xor(sum, 16, 64);
+  const float inv = valid ? 1.0f / sum : 0.f;
+  const bf16x4_t pfrag = pack4_bf16v(e[0] * inv, e[1] * inv, e[2] * inv, e[3] * inv);       // P^T[keys 4 lr ..][query li]
+#pragma unroll
+  for (int cb = 0; cb < HD / 16; ++cb) {
+    const float* vb = vp + 4 * lr * ld + 16 * cb + li;              // V^T fragment: rows = channels 16 cb + li, k = keys 4 lr .. 4 lr + 3
+    const bf16x4_t vfrag = pack4_bf16v(vb[0], vb[ld], vb[2 * ld], vb[3 * ld]);
+    const f32x4 o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vfrag, pfrag, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
     out[cb] = make_float4(o[0], o[1], o[2], o[3]);
   }
 }

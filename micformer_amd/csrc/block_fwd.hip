@@ -23,7 +23,8 @@ struct BlkFwdArgs {
   micf_block_fwd_group g[2];
   TileGeo geo;
   int G, tiles, C, heads, hidden, debug;
-  int att8;                 // MICF_DTYPE_BF16_ATTN_FP8: QK^T / AV on the matrix cores with e4m3 operands (attn_fp8.h)
+  int att8;                 // attention products on the matrix cores (attn_fp8.h): 0 = VALU (fp32 mode; MICF_ATTN_VALU=1), 1 = bf16
+                            // operands (MICF_DTYPE_BF16), 2 = e4m3 operands (MICF_DTYPE_BF16_ATTN_FP8)
   float eps, scale;
 };
 
@@ -239,7 +240,8 @@ __global__ void __launch_bounds__(64 * NW) block_fwd_kernel(const BlkFwdArgs a) 
       const int gq = unit / heads, hh = unit - gq * heads, hoff = hh * HD;
       const float* base = U + gq * 16 * SU + hoff;
       float4 ov[HD / 16];
-      attn16_fp8<HD>(base, base + C, base + 2 * C, SU, a.scale, ov);
+      if (a.att8 == 2) attn16_fp8<HD>(base, base + C, base + 2 * C, SU, a.scale, ov);
+      else attn16_bf16<HD>(base, base + C, base + 2 * C, SU, a.scale, ov);
       const int row = gq * 16 + l16, tk = tok[row];
 #pragma unroll
       for (int cb = 0; cb < HD / 16; ++cb) {
@@ -486,7 +488,8 @@ extern "C" int micf_block_fwd(const micf_block_fwd_group* groups, int ngroups, i
   if (att8) dtype = MICF_DTYPE_BF16;                     // everything but the two attention products is the bf16 mode
   if (dtype != MICF_DTYPE_F32 && dtype != MICF_DTYPE_BF16) return MICF_EINVAL;
   BlkFwdArgs a;
-  a.att8 = att8;
+  static const bool attn_valu = [] { const char* e = getenv("MICF_ATTN_VALU"); return e && atoi(e) != 0; }();
+  a.att8 = att8 ? 2 : ((dtype == MICF_DTYPE_BF16 && !attn_valu) ? 1 : 0);
   for (int i = 0; i < ngroups; ++i) {
     const micf_block_fwd_group& g = groups[i];
     const void* need[] = {g.x, g.ln1_g, g.ln1_b, g.wq, g.bq, g.wkv, g.bkv, g.wp, g.bp, g.ln2_g, g.ln2_b, g.w1, g.b1, g.w2, g.b2,
@@ -512,7 +515,7 @@ extern "C" int micf_block_fwd(const micf_block_fwd_group* groups, int ngroups, i
   a.debug = dbg ? atoi(dbg) : 0;
   hipStream_t s = (hipStream_t)stream;
   const int hd = C / heads, tj = TM / 16;
-  if (block_wide_tile_tokens(C, hd)) return block_fwd_wide(groups, ngroups, B, D, H, W, C, heads, eps, scale, att8 ? MICF_DTYPE_BF16_ATTN_FP8 : dtype, s);
+  if (block_wide_tile_tokens(C, hd)) return block_fwd_wide(groups, ngroups, B, D, H, W, C, heads, eps, scale, att8 ? MICF_DTYPE_BF16_ATTN_FP8 : dtype, s);   // (the few-token F1: attention on the matrix cores in both bf16 modes)
 #define MICF_BF(C_, HD_, TJ_) if (C == C_ && hd == HD_ && tj == TJ_) return launch_fwd<C_, HD_, TJ_>(a, dtype, s)
   MICF_BF(48, 16, 2); MICF_BF(48, 16, 1); MICF_BF(48, 16, 4); MICF_BF(96, 16, 1); MICF_BF(96, 16, 2); MICF_BF(192, 16, 1);
   MICF_BF(96, 32, 1); MICF_BF(192, 32, 1);

@@ -255,7 +255,8 @@ __global__ void __launch_bounds__(256) f1_kernel(const FwdArgs a) {
   __syncthreads();
   if (BF16 && a.att8) {                                               // e4m3 operands on the matrix cores: the wave's (tile, head) is one unit
     float4 ov[HD / 16];
-    attn16_fp8<HD>(&sm[wave][0][0][0], &sm[wave][1][0][0], &sm[wave][2][0][0], QS, a.scale, ov);
+    if (a.att8 == 2) attn16_fp8<HD>(&sm[wave][0][0][0], &sm[wave][1][0][0], &sm[wave][2][0][0], QS, a.scale, ov);
+    else attn16_bf16<HD>(&sm[wave][0][0][0], &sm[wave][1][0][0], &sm[wave][2][0][0], QS, a.scale, ov);
     if (row.ok) {
 #pragma unroll
       for (int cb = 0; cb < HD / 16; ++cb) st4g(g.o + (int64_t)row.tk * C + head * HD + 16 * cb + 4 * lr, ov[cb]);
@@ -683,9 +684,10 @@ int block_fwd_wide(const micf_block_fwd_group* groups, int ngroups, int B, int D
   a.geo = make_tile_geo(B, D, H, W);
   a.G = ngroups; a.eps = eps; a.scale = scale;
   a.tiles = (a.geo.nwin + 1) / 2;
-  a.att8 = dtype == MICF_DTYPE_BF16_ATTN_FP8;
+  static const bool attn_valu = [] { const char* e = getenv("MICF_ATTN_VALU"); return e && atoi(e) != 0; }();
+  a.att8 = dtype == MICF_DTYPE_BF16_ATTN_FP8 ? 2 : ((dtype == MICF_DTYPE_BF16 && !attn_valu) ? 1 : 0);
   const int hd = C / heads;
-  const bool bf = dtype == MICF_DTYPE_BF16 || a.att8;
+  const bool bf = dtype == MICF_DTYPE_BF16 || dtype == MICF_DTYPE_BF16_ATTN_FP8;
   MICF_WIDE_DISPATCH(wide::launch_fwd, a, s);
   return MICF_EUNSUPPORTED;
 }

@@ -517,20 +517,25 @@ __global__ void __launch_bounds__(256) b3_kernel(const BwdArgs a) {
     *reinterpret_cast<float4*>(&sm[wave][3][li][16 * hh + 4 * lr]) = make_float4(s1 * v.x, s1 * v.y, s1 * v.z, s1 * v.w);
   }
   __syncthreads();
-  // attention backward: lane < 16 = (window lane / 8, row i = lane % 8)
-  const int i = lane & 7, r0 = lane & 8;
-  float dq[HD];
-  const bool act = lane < 16;
-  if (act) {
-    float qr[HD], dor[HD];
+  // attention backward: lane (li, lr) = attention row li (window li / 8, row i = li % 8) x channel quarter lr of the head: the score /
+  // dP dot products are partial sums over HD / 4 channels that meet across the four lane groups; every lane owns HD / 4 channels of
+  // dq, dk, dv.  (All 64 lanes work: with one lane per row, 16 lanes ran whole head rows -- 25 us at 4^3, 62 us per launch at the
+  // large model's 10 x 10 x 8 stage.)
+  constexpr int HP = HD / 4;
+  const int i = li & 7, r0 = li & 8, c0 = lr * HP;
+  float dq[HP];
+  {
+    float qr[HP], dor[HP];
 #pragma unroll
-    for (int d = 0; d < HD; ++d) { qr[d] = sm[wave][0][lane][d] * a.scale; dor[d] = sm[wave][3][lane][d]; }
+    for (int d = 0; d < HP; ++d) { qr[d] = sm[wave][0][li][c0 + d] * a.scale; dor[d] = sm[wave][3][li][c0 + d]; }
     float p[8], dp[8], mx = -INFINITY;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float sacc = 0.f, dacc = 0.f;
 #pragma unroll
-      for (int d = 0; d < HD; ++d) { sacc += qr[d] * sm[wave][1][r0 + j][d]; dacc += dor[d] * sm[wave][2][r0 + j][d]; }
+      for (int d = 0; d < HP; ++d) { sacc += qr[d] * sm[wave][1][r0 + j][c0 + d]; dacc += dor[d] * sm[wave][2][r0 + j][c0 + d]; }
+      sacc += __shfl_xor(sacc, 16, 64); dacc += __shfl_xor(dacc, 16, 64);
+      sacc += __shfl_xor(sacc, 32, 64); dacc += __shfl_xor(dacc, 32, 64);
       p[j] = sacc; dp[j] = dacc;
       mx = fmaxf(mx, sacc);
     }
@@ -542,33 +547,35 @@ __global__ void __launch_bounds__(256) b3_kernel(const BwdArgs a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) { p[j] *= inv; dot += p[j] * dp[j]; }
 #pragma unroll
-    for (int d = 0; d < HD; ++d) dq[d] = 0.f;
+    for (int d = 0; d < HP; ++d) dq[d] = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float ds = p[j] * (dp[j] - dot);
-      ps[wave][lane][j] = p[j];
-      ps[wave][lane][8 + j] = ds;
+      if (lr == (j >> 1)) {                               // (the four lanes of a row hold identical rows: each stores its share)
+        ps[wave][li][j] = p[j];
+        ps[wave][li][8 + j] = ds;
+      }
       const float dss = ds * a.scale;
 #pragma unroll
-      for (int d = 0; d < HD; ++d) dq[d] += dss * sm[wave][1][r0 + j][d];
+      for (int d = 0; d < HP; ++d) dq[d] += dss * sm[wave][1][r0 + j][c0 + d];
     }
   }
   __syncthreads();
-  if (act && row.ok) {                                                // as key / value row j = i: column i of P and dS of the window
-    float dk[HD], dv[HD];
+  if (row.ok) {                                                       // as key / value row j = i: column i of P and dS of the window
+    float dk[HP], dv[HP];
 #pragma unroll
-    for (int d = 0; d < HD; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+    for (int d = 0; d < HP; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
       const float pm = ps[wave][r0 + m][i], dsm = ps[wave][r0 + m][8 + i] * a.scale;
 #pragma unroll
-      for (int d = 0; d < HD; ++d) { dk[d] += dsm * sm[wave][0][r0 + m][d]; dv[d] += pm * sm[wave][3][r0 + m][d]; }
+      for (int d = 0; d < HP; ++d) { dk[d] += dsm * sm[wave][0][r0 + m][c0 + d]; dv[d] += pm * sm[wave][3][r0 + m][c0 + d]; }
     }
 #pragma unroll
-    for (int d = 0; d < HD; d += 4) {
-      st4g(g.dq + (int64_t)row.tk * C + head * HD + d, make_float4(dq[d], dq[d + 1], dq[d + 2], dq[d + 3]));
-      st4g(g.dkv + (int64_t)row.tk * 2 * C + head * HD + d, make_float4(dk[d], dk[d + 1], dk[d + 2], dk[d + 3]));
-      st4g(g.dkv + (int64_t)row.tk * 2 * C + C + head * HD + d, make_float4(dv[d], dv[d + 1], dv[d + 2], dv[d + 3]));
+    for (int d = 0; d < HP; d += 4) {
+      st4g(g.dq + (int64_t)row.tk * C + head * HD + c0 + d, make_float4(dq[d], dq[d + 1], dq[d + 2], dq[d + 3]));
+      st4g(g.dkv + (int64_t)row.tk * 2 * C + head * HD + c0 + d, make_float4(dk[d], dk[d + 1], dk[d + 2], dk[d + 3]));
+      st4g(g.dkv + (int64_t)row.tk * 2 * C + C + head * HD + c0 + d, make_float4(dv[d], dv[d + 1], dv[d + 2], dv[d + 3]));
     }
   }
 }

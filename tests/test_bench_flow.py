@@ -73,3 +73,23 @@ def test_bench_real_engine_two_ranks_on_one_gpu():
     assert out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2" and out["dtype"] == "bf16"
     assert out["final_loss"] == out["final_loss"] and 0.0 < out["final_loss"] < 2.0
     assert out["value"] > 0 and "roofline" in out and out["roofline"]["kernel"].startswith("micf_")
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_real_engine_four_ranks_on_one_gpu():
+    """More than two ranks: 4 processes on the box's one MI355X (gloo on device tensors), base model on 64^3 pairs, fp32 parity mode
+    (the exact fp32 gradient wire): every rank must reach every collective of the step and of the roofline leg, rank 0 prints the
+    one JSON line, and the loss is the 4-rank data-parallel step's (finite, below the initial 0.75)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1",
+           "--vol", "64", "--dtype", "fp32", "--dist-backend", "gloo", "--no-cpu-baseline"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=850, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 4 and out["rccl_ranks"] == 4 and out["distinct_local_devices"] == 1 and out["grad_wire"] == "fp32"
+    assert out["config"]["global_batch"] == 8 and out["config"]["parallelism"] == "dp4" and out["dtype"] == "fp32"
+    assert 0.0 < out["final_loss"] < 0.8 and "roofline" in out

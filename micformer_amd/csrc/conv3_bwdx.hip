@@ -12,6 +12,7 @@
 //     no LDS staging, no barrier inside the tap loop; the next tap's weights are prefetched under the current tap's MFMAs.
 //   * every wave owns 2 token rows x NCT channel tiles (2*NCT accumulators); per tap: 2 LDS reads + NCT loads for 8*NCT MFMAs.
 // The implicit-GEMM path (conv3.hip) needed 360 us for the 32^3 x 2 stage (15 TFLOP/s); see DESIGN.md for this kernel's numbers.
+#include <cstdlib>
 #include "common.h"
 #include "conv3_layout.h"
 #include "gemm_dma.h"
@@ -219,7 +220,8 @@ static hipError_t launch_bwdx(BwdxArgs& a, hipStream_t stream) {
   const int64_t blocks = (int64_t)a.B * a.tiles_d * a.tiles_h * a.tiles_w;
   const int cts = a.O / 16;
   // many token tiles: 6 channel tiles per workgroup (the halo is staged once per 96 channels); few: 2, to spread over the CUs
-  if (blocks * ((cts + 5) / 6) >= 384)
+  static const int64_t nct6_min = [] { const char* e = getenv("MICF_CONV_BWD_NCT6_MIN"); return e ? (int64_t)atoll(e) : (int64_t)128; }();
+  if (blocks * ((cts + 5) / 6) >= nct6_min)
     hipLaunchKernelGGL((conv3_bwdx_kernel<TW, 6, BF16>), dim3((unsigned)blocks, (cts + 5) / 6, a.ngroups), dim3(256), 0, stream, a);
   else
     hipLaunchKernelGGL((conv3_bwdx_kernel<TW, 2, BF16>), dim3((unsigned)blocks, (cts + 1) / 2, a.ngroups), dim3(256), 0, stream, a);

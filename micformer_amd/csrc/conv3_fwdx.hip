@@ -13,6 +13,7 @@
 //   * few token tiles (8^3 / 16^3 stages): the channel chunks are split over blockIdx.y and the partial sums added atomically
 //     into the pre-zeroed output.
 // The LDS-weights direct kernel this replaces (conv3_direct.hip) needed 129 us at the 32^3 x 2 stage (41 TFLOP/s).
+#include <cstdlib>
 #include "common.h"
 #include "conv3_layout.h"
 #include "gemm_dma.h"
@@ -255,7 +256,8 @@ int conv3_fwd_x_groups(const Conv3FwdSet* sets, int n, int c1, int c2, int B, in
   const int64_t blocks = (int64_t)B * a.tiles_d * a.tiles_h * a.tiles_w;
   // enough token tiles: one workgroup walks all channel chunks; otherwise spread the chunks (atomic accumulation into y)
   int ysplit = 1;
-  if (blocks < 256) { ysplit = (int)((512 + blocks - 1) / blocks); if (ysplit > chunks) ysplit = chunks; }
+  static const int split_target = [] { const char* e = getenv("MICF_CONV_SPLIT_TARGET"); return e ? atoi(e) : 128; }();
+  if (blocks < 256) { ysplit = (int)((split_target + blocks - 1) / blocks); if (ysplit > chunks) ysplit = chunks; if (ysplit < 1) ysplit = 1; }
   a.chunks_per_block = (chunks + ysplit - 1) / ysplit;
   ysplit = (chunks + a.chunks_per_block - 1) / a.chunks_per_block;
   if (ysplit > 1 && !y_zeroed)

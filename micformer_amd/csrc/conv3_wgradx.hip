@@ -395,7 +395,8 @@ static WgxPlan wgx_plan(int B, int D, int H, int W, int Cin, int items = 1) {
   const int th = 64 / p.tw;
   const int ntiles = B * D * ((H + th - 1) / th) * ((W + p.tw - 1) / p.tw);
   p.slabs = (Cin + wCS - 1) / wCS;
-  int groups = (256 + p.slabs * items - 1) / (p.slabs * items);   // ~one workgroup per CU over all items (100+ KiB of LDS each)
+  static const int wg_target = [] { const char* e = getenv("MICF_CONV_WGRAD_WGS"); return e ? atoi(e) : 256; }();
+  int groups = (wg_target + p.slabs * items - 1) / (p.slabs * items);   // ~one workgroup per CU over all items
   if (groups < 4) groups = 4 < ntiles ? 4 : ntiles;
   if (groups > ntiles) groups = ntiles;
   p.tiles_per_group = (ntiles + groups - 1) / groups;

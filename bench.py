@@ -186,6 +186,59 @@ class _StubEngine:
         return self.t[0] + 0.5
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(nproc, argv):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks ourselves (one process per GPU, the env contract of
+    torch.distributed.run: RANK / LOCAL_RANK / WORLD_SIZE / LOCAL_WORLD_SIZE / MASTER_ADDR / MASTER_PORT), pass rank 0's stdout
+    through (its ONE JSON line), prefix the other ranks' output onto stderr, and return non-zero if any rank fails -- the first
+    failure terminates the remaining ranks (exact PIDs) instead of leaving them parked in a collective."""
+    import subprocess
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    base = dict(os.environ, MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port, WORLD_SIZE=str(nproc),
+                LOCAL_WORLD_SIZE=str(nproc), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                MICF_BENCH_SELF_LAUNCHED="1")
+    base.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or nproc) // nproc)))
+    import tempfile
+    procs, logs = [], []
+    for r in range(nproc):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        logs.append(None if r == 0 else tempfile.TemporaryFile())      # (a file, not a pipe: nobody drains it while the rank runs)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                      stdout=logs[r], stderr=None if r == 0 else subprocess.STDOUT))
+    rc, alive = 0, set(range(nproc))
+    try:
+        while alive:
+            for r in sorted(alive):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                alive.discard(r)
+                if r != 0:
+                    logs[r].seek(0)
+                    tail = logs[r].read().decode(errors="replace")
+                    if code != 0 or os.environ.get("MICF_BENCH_VERBOSE"):
+                        sys.stderr.write("".join(f"[rank {r}] {l}\n" for l in tail.splitlines()[-40:]))
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    sys.stderr.write(f"bench.py: rank {r} exited with {code}; stopping the other ranks\n")
+                    for o in alive:
+                        procs[o].terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -218,6 +271,10 @@ def main(argv=None):
                     help="single GPU: k consecutive steps per captured graph (TrainEngine.step_many: step i + 1's encoder forward "
                          "runs beside the decoder-side parameter-gradient work + Adam of step i); --steps must be a multiple of k")
     ap.add_argument("--cpu-stub", action="store_true", help="control-flow test on CPU/gloo with a stub engine (no kernels)")
+    ap.add_argument("--force-dist", action="store_true", help="--gpus 1 through the N > 1 code path: a ONE-rank process group of "
+                    "--dist-backend is initialised (nccl = a live RCCL communicator), the engine takes the data-parallel step layout "
+                    "with its per-slice all-reduces issued for real (always_collective) and the bf16 gradient wire -- everything "
+                    "the 8-GPU run does except the second device")
     args = ap.parse_args(argv)
 
     import torch
@@ -226,10 +283,13 @@ def main(argv=None):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher around us: start the ranks ourselves (the torch.distributed.run form keeps working: it sets WORLD_SIZE)
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:] if argv is None else list(argv)))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
     stub = args.cpu_stub
+    forced = args.force_dist and world == 1 and not stub
     depths = (2, 2, 6, 2)
     vol = (args.vol,) * 3
     if stub:
@@ -237,6 +297,8 @@ def main(argv=None):
         if world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group("gloo")
+        if os.environ.get("MICF_BENCH_FAIL_RANK") == str(rank):          # test hook: a rank that dies while its peers wait
+            raise SystemExit(7)
         eng, x, tgt, dtype_name, nblock = _StubEngine(world), None, None, "fp32", 0
         _lib = _ops = None
     else:
@@ -244,8 +306,12 @@ def main(argv=None):
             local_rank %= max(torch.cuda.device_count(), 1)        # ranks share the visible GPU(s)
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
-        if world > 1:
+        if world > 1 or forced:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if forced:
+                os.environ.setdefault("MASTER_PORT", str(_free_port()))
+                os.environ.setdefault("RANK", "0")
+                os.environ.setdefault("WORLD_SIZE", "1")
             if args.dist_backend == "gloo":
                 dist.init_process_group("gloo")
             else:
@@ -267,10 +333,15 @@ def main(argv=None):
         x, tgt = synthetic_batch(args.batch, vol, 8, dev, 1234 + rank)
         eng = TrainEngine(model, base_lr=1e-4, t_max=150, use_graph=not args.no_graph,
                           parallel_modalities=not args.serial_modalities, flush_points=not args.no_flush_points,
-                          segmented=args.segmented, **({"split_step": True} if args.split_step else {}))
+                          segmented=args.segmented, **({"split_step": True} if args.split_step else {}),
+                          **({"split_step": True, "always_collective": True,
+                              "grad_bf16": _ops.compute_dtype() == "bf16" and os.environ.get("MICF_GRAD_WIRE", "bf16") != "fp32"}
+                             if forced else {}))
+
+    live_group = world > 1 or forced
 
     def barrier():
-        if world > 1:
+        if live_group:
             dist.barrier()
         if not stub:
             torch.cuda.synchronize()
@@ -278,6 +349,7 @@ def main(argv=None):
     spg = args.steps_per_graph if (world == 1 and not stub and not args.no_graph and not args.split_step) else 1
     if spg > 1 and args.steps % spg:
         raise SystemExit("--steps must be a multiple of --steps-per-graph")
+    inputs_note = None
     if spg > 1:
         xs, tgts = [x] * spg, [tgt] * spg
         for _ in range(max(1, -(-args.warmup // spg))):         # (at least one call: the capture stays outside the timed region)
@@ -299,6 +371,8 @@ def main(argv=None):
             bx.copy_(x)
             bt.copy_(tgt)
             x_t, tgt_t = bx, bt
+            inputs_note = ("resident in the captured step's input buffers (TrainEngine.input_buffers(): no device-to-device "
+                           "staging copy in the timed region)")
         else:
             x_t, tgt_t = x, tgt
         barrier()
@@ -335,9 +409,9 @@ def main(argv=None):
                                                             "parameter-gradient batches as separate graphs on two streams)")},
         "final_loss": round(loss_val, 6),
     }
-    if not stub and not args.no_graph:
-        out["config"]["inputs"] = "resident in the captured step's input buffers (TrainEngine.input_buffers(): no device-to-device staging copy in the timed region)"
-    if world > 1:
+    if inputs_note:
+        out["config"]["inputs"] = inputs_note
+    if live_group:
         # what the collective backend itself saw: its rank count, its name, and how many distinct devices the ranks ran on
         ids = torch.zeros(world, device=dev, dtype=torch.int64)         # (an all-reduce: the one collective every backend has)
         ids[rank] = (local_rank if not stub else 0) + 1
@@ -457,7 +531,7 @@ def main(argv=None):
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if live_group:
         dist.barrier()
         dist.destroy_process_group()
 

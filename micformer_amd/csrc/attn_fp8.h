@@ -19,21 +19,26 @@
 
 namespace micf {
 
-// 8 floats -> 8 e4m3 bytes (element e in byte e)
+// e4m3's largest finite value is 448: an operand beyond it (an activation outlier in k / v) must SATURATE, whatever overflow mode
+// the conversion instruction is in (NaN in the non-saturating one) -- one v_med3_f32 per value; NaN inputs stay NaN.
+__device__ __forceinline__ float sat_fp8(float v) { return __builtin_amdgcn_fmed3f(v, -448.f, 448.f); }
+
+// 8 floats -> 8 e4m3 bytes (element e in byte e), saturating
 __device__ __forceinline__ long pack8_fp8(const float4& lo, const float4& hi) {
-  int w0 = __builtin_amdgcn_cvt_pk_fp8_f32(lo.x, lo.y, 0, false);
-  w0 = __builtin_amdgcn_cvt_pk_fp8_f32(lo.z, lo.w, w0, true);
-  int w1 = __builtin_amdgcn_cvt_pk_fp8_f32(hi.x, hi.y, 0, false);
-  w1 = __builtin_amdgcn_cvt_pk_fp8_f32(hi.z, hi.w, w1, true);
+  int w0 = __builtin_amdgcn_cvt_pk_fp8_f32(sat_fp8(lo.x), sat_fp8(lo.y), 0, false);
+  w0 = __builtin_amdgcn_cvt_pk_fp8_f32(sat_fp8(lo.z), sat_fp8(lo.w), w0, true);
+  int w1 = __builtin_amdgcn_cvt_pk_fp8_f32(sat_fp8(hi.x), sat_fp8(hi.y), 0, false);
+  w1 = __builtin_amdgcn_cvt_pk_fp8_f32(sat_fp8(hi.z), sat_fp8(hi.w), w1, true);
   return (long)(((unsigned long)(unsigned)w1 << 32) | (unsigned long)(unsigned)w0);
 }
+// (P only: softmax outputs lie in [0, 1], no saturation needed)
 __device__ __forceinline__ unsigned pack4_fp8(float a, float b, float c, float d) {
   int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
   return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
 }
 // the value a float has after a round trip through e4m3 (the VALU restatement of the same arithmetic: window_attn.hip)
 __device__ __forceinline__ float round_fp8(float v) {
-  const int w = __builtin_amdgcn_cvt_pk_fp8_f32(v, 0.f, 0, false);
+  const int w = __builtin_amdgcn_cvt_pk_fp8_f32(sat_fp8(v), 0.f, 0, false);
   return __builtin_amdgcn_cvt_f32_fp8(w, 0);
 }
 

@@ -533,6 +533,11 @@ class TrainEngine:
         if sw is None or layers is None or ups is None or self._early_cut is None or len(ups) != len(layers):
             return None
         n = len(layers)
+        if n < 4:
+            # The carried batches + the tail's Adam are launched from the stage-entry-3 hook and the first group's wait is parked
+            # for entry n: with fewer than 4 stages the last encoder stage would read its parameters before (n == 3: while) the
+            # carried update runs.  step_many then keeps its promise by running step by step.
+            return None
         names = [nm for nm, _ in self.model.named_parameters()]
         root = "swin"
         spec = [(layers[n - 1], n, [f"{root}.layers.{n - 1}.", f"{root}.norm."])]
@@ -589,7 +594,10 @@ class TrainEngine:
         k = len(xs)
         if self._carry_groups is None:
             self._carry_groups = self._build_carry_groups() or False
-        if k < 2 or not self.use_graph or self.world != 1 or not self._carry_groups:
+        from . import functional as _fn
+        # (the carry region needs what early Adam needs: every flush point launches everything queued so far)
+        full_flush = (self.defer_wgrad and self.flush_points and not self.split_step and _fn.FLUSH_MAX_TOKENS >= (1 << 30))
+        if k < 2 or not self.use_graph or self.world != 1 or not self._carry_groups or not full_flush:
             return [self.step(x, t) for x, t in zip(xs, targets)]
         ent = self._many
         if ent is not None and not (ent["k"] == k and ent["mode"] == ops.arith_mode() and all(
@@ -630,19 +638,25 @@ class TrainEngine:
         rng_cpu, rng_dev = torch.get_rng_state(), torch.cuda.get_rng_state(sxs[0].device)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            self._step_impl(sxs[0], sts[0])                         # (sizes scratch buffers / allocator pools: undone below)
-            self._many_body(sxs, sts)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        with torch.no_grad():
-            for dst, src in zip((self.flat_p, self.flat_m, self.flat_v, self.adam_state), keep):
-                dst.copy_(src)
-            for dst, src in zip(dp_rng, dp_keep):
-                dst.copy_(src)
-        torch.set_rng_state(rng_cpu)
-        torch.cuda.set_rng_state(rng_dev, sxs[0].device)
-        del keep
+        try:
+            with torch.cuda.stream(side):
+                self._step_impl(sxs[0], sts[0])                     # (sizes scratch buffers / allocator pools: undone below)
+                self._many_body(sxs, sts)
+        finally:
+            # the warm-up ran k + 1 real updates: undo them whether or not it finished (a raise must not leave the parameters,
+            # the Adam state, the RNG streams or the carry switch behind)
+            from . import functional as _fn0
+            _fn0.CARRY["on"], _fn0.CARRY["open"], _fn0.CARRY["stash"] = False, False, []
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            with torch.no_grad():
+                for dst, src in zip((self.flat_p, self.flat_m, self.flat_v, self.adam_state), keep):
+                    dst.copy_(src)
+                for dst, src in zip(dp_rng, dp_keep):
+                    dst.copy_(src)
+            torch.set_rng_state(rng_cpu)
+            torch.cuda.set_rng_state(rng_dev, sxs[0].device)
+            del keep
         if self.segmented:
             from . import functional as _fn
             torch.cuda.empty_cache()

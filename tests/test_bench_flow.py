@@ -52,6 +52,74 @@ def test_bench_single_process_stub_and_no_roofline():
     assert out["n_gpus"] == 1 and "roofline" not in out and "cpu_baseline" not in out
 
 
+@pytest.mark.timeout(300)
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` with NO launcher in the command (the form the driver types for N = 1) starts
+    its N ranks itself: one JSON line from rank 0, rc 0."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--cpu-stub"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=dict(env, OMP_NUM_THREADS="1"), cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["config"]["parallelism"] == "dp2"
+    assert "roofline" in out and out["cpu_baseline"] is None
+
+
+@pytest.mark.timeout(300)
+def test_self_launched_bench_fails_when_a_rank_dies():
+    """... and a non-zero exit code when any rank fails, with the surviving ranks stopped (not left parked in a collective)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "2", "--warmup", "0", "--cpu-stub"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=ROOT,
+                       env=dict(env, OMP_NUM_THREADS="1", MICF_BENCH_FAIL_RANK="1"))
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "rank 1 exited with 7" in r.stderr
+
+
+def test_gpus_must_match_the_launchers_world_size():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--cpu-stub"], capture_output=True, text=True,
+                       timeout=120, cwd=ROOT, env=dict(os.environ, WORLD_SIZE="1", RANK="0"))
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_self_launched_bench_two_ranks_on_one_gpu():
+    """The self-launched form with the REAL engine: `python bench.py --gpus 2 --dist-backend gloo` (no torchrun), both ranks on the
+    box's one MI355X: base / 128^3 / local batch 2 / bf16, capture under a live group, replays with the per-slice all-reduces."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dist-backend", "gloo",
+           "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=850, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["distinct_local_devices"] == 1 and out["grad_wire"] == "bf16"
+    assert out["config"]["global_batch"] == 4 and out["dtype"] == "bf16" and 0.0 < out["final_loss"] < 2.0
+    assert "roofline" in out and out["roofline"]["kernel"].startswith("micf_")
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_nccl_branch_with_one_rank():
+    """The `nccl` (= RCCL) branch of bench.py on the one device a test box has (`--force-dist`): init_process_group("nccl",
+    device_id=...), the step captured under the live RCCL communicator in the data-parallel layout (split_step), every gradient
+    slice all-reduced for real over the bf16 wire, the collectives of the timing / identification legs, destroy_process_group --
+    everything the 8-GPU run does except the second device."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--force-dist",
+           "--dist-backend", "nccl", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=850, env=dict(env, HSA_ENABLE_IPC_MODE_LEGACY="0"), cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1 and out["dist_backend"].startswith("nccl") and out["grad_wire"] == "bf16"
+    assert 0.0 < out["final_loss"] < 2.0 and out["value"] > 0 and "roofline" in out
+
+
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
 def test_bench_real_engine_two_ranks_on_one_gpu():

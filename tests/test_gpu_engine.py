@@ -391,6 +391,40 @@ def test_step_many_is_the_same_sequence_of_updates(M, dtype):
         ops.set_compute_dtype("fp32")
 
 
+def test_step_many_with_three_stages_runs_step_by_step(M):
+    """the carried groups are launched at stage entry 3 and waited for at entry n = number of stages; with
+    n < 4 that wait would come too late (n = 3: the last encoder stage reads weights Adam is updating; n = 2: it already ran).
+    Such models have no carry groups: step_many is k plain step() calls -- same losses as an eager engine, nothing captured."""
+    from micformer_amd.engine import TrainEngine
+
+    def head():
+        h = M.Head(embed_dim=24, num_classes=8, depths=(1, 1, 1), num_heads=(3, 6, 12))
+        with torch.no_grad():
+            for name, t in h.state_dict().items():
+                t.copy_(fill.fill_tensor(name, t))
+        return h.cuda().eval()
+    x, t = _data(1)
+    eager = TrainEngine(head(), base_lr=1e-3, t_max=20, use_graph=False)
+    le = [float(eager.step(x, t)) for _ in range(3)]
+    many = TrainEngine(head(), base_lr=1e-3, t_max=20, use_graph=True)
+    lm = [float(l) for l in many.step_many([x] * 3, [t] * 3)]
+    assert many._carry_groups is False and many._many is None
+    assert all(abs(a - b) <= 1e-4 for a, b in zip(le, lm)), (le, lm)
+    _same_training_state(eager, many, "after 3 steps")
+
+
+def test_step_many_without_flush_points_runs_step_by_step(M):
+    """an engine whose flush points are off cannot run the carry region (it needs every flush point to launch all that
+    is queued): step_many must notice BEFORE it captures, not assert inside the warm-up after k + 1 real updates."""
+    from micformer_amd.engine import TrainEngine
+    x, t = _data(1)
+    ref = TrainEngine(_head(M), base_lr=1e-3, t_max=20, use_graph=True, flush_points=False)
+    lr_ = [float(ref.step(x, t)) for _ in range(2)]
+    eng = TrainEngine(_head(M), base_lr=1e-3, t_max=20, use_graph=True, flush_points=False)
+    lm = [float(l) for l in eng.step_many([x] * 2, [t] * 2)]
+    assert eng._many is None and all(abs(a - b) <= 1e-4 for a, b in zip(lr_, lm)), (lr_, lm)
+
+
 def test_step_many_on_the_fused_kernels_base_model():
     """The same on the kernels the bench runs: base widths (fused block kernels, lazy LayerNorm backward, fused loss), bf16, train
     mode, 64^3: four steps in one graph against four replays of the one-step graph."""

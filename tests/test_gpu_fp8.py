@@ -37,7 +37,8 @@ def rnd(shape, seed, scale=1.0):
 
 
 def q8(t):
-    return t.float().to(torch.float8_e4m3fn).float()
+    # saturating, as csrc/attn_fp8.h::sat_fp8 (torch's own conversion turns |x| > 448 into NaN)
+    return t.float().clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float()
 
 
 def ref_attention_fp8(q, kv, dims, heads, scale, q8=q8):
@@ -80,6 +81,42 @@ def test_per_op_attention_fp8_matches_the_restatement(ops, dims, C, heads):
     want = ref_attention_fp8(q, kv, dims, heads, scale)
     same_up_to_rounding_flips(o8, want)
     assert float((o8 - o16).abs().max()) > 1e-3 * float(want.abs().max())          # ... and it is a different arithmetic
+
+
+@pytest.mark.parametrize("dims,C,heads", [((1, 4, 4, 4), 48, 3), ((1, 2, 6, 4), 768, 24)])
+def test_fp8_operands_saturate_instead_of_overflowing(ops, dims, C, heads):
+    """e4m3 has no value beyond 448; an activation outlier in k / v must saturate (sat_fp8), not become NaN / inf and
+    travel through the softmax into the loss.  v carries outliers of +-2000, k of +-600 (scores saturate the softmax to one-hot)."""
+    B, D, H, W = dims
+    T = B * D * H * W
+    q, kv = rnd((T, C), 5), rnd((T, 2 * C), 6)
+    kv[::7, :C] *= 600.0
+    kv[::5, C:] *= 2000.0
+    scale = (C // heads) ** -0.5
+    ops.set_compute_dtype("bf16+fp8attn")
+    o8 = ops.window_attn_fwd(q, kv, dims, heads, (2, 2, 2), scale)
+    assert bool(torch.isfinite(o8).all())
+    assert float(o8.abs().max()) <= 448.0 * 1.001
+    want = ref_attention_fp8(q, kv, dims, heads, scale)
+    err = (o8.float() - want).abs()
+    assert float((err > 1e-3 * float(want.abs().max())).float().mean()) <= 5e-2
+
+
+@pytest.mark.parametrize("case", [(2, 4, 4, 4, 48, 3), (2, 4, 4, 4, 384, 24)])
+def test_fused_blocks_fp8_attention_survives_outliers(ops, case):
+    """The same through the matrix-core attention of the fused kernels (attn16_fp8): a block whose input has outliers large enough
+    that k / v exceed 448 stays finite."""
+    import test_gpu_block_fused as tb
+    B, D, H, W, C, heads = case
+    dims, T = (B, D, H, W), B * D * H * W
+    P = tb.make_params(C, 4 * C, "self_attn", 41)
+    P["self_attn.kv.weight"] = P["self_attn.kv.weight"] * 400.0
+    x = rnd((T, C), 42)
+    scale = (C // heads) ** -0.5
+    ops.set_compute_dtype("bf16+fp8attn")
+    o = ops.block_fwd([{"x": x, "kvsrc": None, "P": P, "attn": "self_attn", "s1": None, "s2": None}], dims, C, heads, 1e-5, scale)[0]
+    assert float(o["kv"].float().abs().max()) > 448.0, "the fixture must actually exceed e4m3's range"
+    assert bool(torch.isfinite(o["o"].float()).all()) and bool(torch.isfinite(o["y"]).all())
 
 
 @pytest.mark.parametrize("case", [(2, 4, 4, 4, 384, 24), (1, 2, 6, 2, 384, 12)])

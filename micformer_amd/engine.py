@@ -57,10 +57,11 @@ class TrainEngine:
         # post-replay launches to hide it behind (7.4 x of 8), the bf16 one ~0.93 ms (7.6-7.7 x); the gradients of this mode
         # already carry bf16 operand rounding, and the 2-rank test holds the result within 2^-7 of the fp32 exchange.  The fp32
         # parity mode keeps the exact fp32 exchange.
-        if grad_bf16 is None:
-            grad_bf16 = self.world > 1 and ops.compute_dtype() == "bf16" and __import__("os").environ.get("MICF_GRAD_WIRE", "bf16") != "fp32"
-        self.grad_bf16 = bool(grad_bf16)
-        self._wire = torch.empty(self.flat_g.numel(), dtype=torch.bfloat16, device=self.flat_g.device) if self.grad_bf16 else None
+        # Auto (None) is resolved PER STEP from the arithmetic mode in force (an engine built in bf16 and switched to the fp32
+        # parity mode exchanges fp32 again); an explicit bool is the caller's decision in every mode.
+        self._grad_bf16_auto = grad_bf16 is None
+        self._grad_bf16_set = bool(grad_bf16)
+        self._wire_buf = None
         # Graph layout of a captured step: ONE HIP graph (round 2; where its side branch runs is the graph executor's choice) or
         # a sequence of graphs replayed on two streams with explicit events (functional.StepSegmenter; opt-in, see _lib.py).
         # (needs the runtime's graph packet capture off, see _lib.GRAPH_SEGMENTS_OK: one graph otherwise)
@@ -77,6 +78,22 @@ class TrainEngine:
         self._many, self._carried, self._carry_groups = None, None, None
         self._param_at = {o: p for p, o in zip(self.params, self.offsets)}
         self.steps_done = 0
+
+    @property
+    def grad_bf16(self):
+        """Wire format of the gradient exchange of a step taken NOW (bf16 | fp32)."""
+        if not self._grad_bf16_auto:
+            return self._grad_bf16_set
+        return (self.world > 1 and ops.compute_dtype() == "bf16"
+                and __import__("os").environ.get("MICF_GRAD_WIRE", "bf16") != "fp32")
+
+    @property
+    def _wire(self):
+        if not self.grad_bf16:
+            return None
+        if self._wire_buf is None:
+            self._wire_buf = torch.empty(self.flat_g.numel(), dtype=torch.bfloat16, device=self.flat_g.device)
+        return self._wire_buf
 
     # ------------------------------------------------------------------ flat parameter / gradient storage
     def _flatten(self):
@@ -488,17 +505,17 @@ class TrainEngine:
 
     def _allreduce_grads(self):
         """Gradient all-reduce(sum) over RCCL/xGMI in a few large buckets of the flat buffer (the 1/world goes into Adam)."""
-        buf = self.flat_g
-        if self._wire is not None:
-            self._wire.copy_(self.flat_g)
-            buf = self._wire
+        buf, wire = self.flat_g, self._wire
+        if wire is not None:
+            wire.copy_(self.flat_g)
+            buf = wire
         works = [self.sync.allreduce_sum_async(buf[s:s + self.sync.bucket_elems])
                  for s in range(0, buf.numel(), self.sync.bucket_elems)]
         for w in works:
             if w is not None:
                 w.wait()
-        if self._wire is not None:
-            self.flat_g.copy_(self._wire)
+        if wire is not None:
+            self.flat_g.copy_(wire)
 
     def step(self, x, target):
         """Run one training step; returns the (device) loss of this rank's batch."""

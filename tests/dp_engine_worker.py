@@ -31,7 +31,20 @@ def main(out_path, mode):
     xs = fill.make_volume(2 * world, 64, 64, 64)
     ts = fill.one_hot(fill.make_label_map(2 * world, 64, 64, 64))
     x, t = xs[2 * rank:2 * rank + 2].cuda(), ts[2 * rank:2 * rank + 2].cuda()
-    eng = TrainEngine(h, base_lr=1e-4, t_max=150, use_graph=True, grad_bf16=(mode == "bf16grad"))
+    auto_wire = None
+    if mode in ("bf16auto", "bf16exact"):
+        # the bench's configuration: bf16 arithmetic; wire format left to the engine (auto = bf16) or forced to the exact fp32 one
+        from micformer_amd import ops
+        ops.set_compute_dtype("bf16")
+        eng = TrainEngine(h, base_lr=1e-4, t_max=150, use_graph=True, grad_bf16=None if mode == "bf16auto" else False)
+        auto_wire = bool(eng.grad_bf16)
+        if mode == "bf16auto":
+            ops.set_compute_dtype("fp32")
+            assert not eng.grad_bf16, "auto wire must follow the arithmetic mode in force (fp32 parity mode = exact exchange)"
+            ops.set_compute_dtype("bf16")
+            assert eng.grad_bf16
+    else:
+        eng = TrainEngine(h, base_lr=1e-4, t_max=150, use_graph=True, grad_bf16=(mode == "bf16grad"))
     assert eng.world == world and eng.split_step
     p_after_bcast = eng.flat_p.clone()
     losses = [float(eng.step(x, t))]
@@ -46,7 +59,7 @@ def main(out_path, mode):
     names = [n for n, _ in h.named_parameters()]
     dead = [i for i, n in enumerate(names) if ".concat_back_dim.0." in n]
     torch.save({"rank": rank, "losses": losses, "p0": p_after_bcast.cpu(), "p": eng.flat_p.cpu(), "g": eng.flat_g.cpu(), "g_first": g_first,
-                "dead": [(eng.offsets[i], eng.sizes[i]) for i in dead], "scales": scales,
+                "dead": [(eng.offsets[i], eng.sizes[i]) for i in dead], "scales": scales, "auto_wire": auto_wire,
                 "wplan_n": eng._wplan.n if eng._wplan is not None else -1}, out_path)
     dist.barrier()
     dist.destroy_process_group()

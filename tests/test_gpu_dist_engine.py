@@ -125,3 +125,20 @@ def test_two_rank_engine_train_mode_and_bf16_gradient_exchange(tmp_path):
     ge, gb = e0["g_first"], b0["g_first"]                      # (same weights on both sides: the first step's reduced gradient)
     assert float((ge - gb).abs().max()) <= 2 ** -7 * float(ge.abs().max())
     assert float((ge - gb).abs().max()) > 0
+
+
+def test_two_rank_engine_default_wire_in_the_bench_configuration(tmp_path):
+    """the configuration the 8-GPU bench runs -- bf16 arithmetic, `grad_bf16=None` (auto => bf16 wire) -- against the
+    same arithmetic with the exact fp32 exchange: rank-identical parameters, reduced gradient within 2^-7 of the exact one per
+    element (relative to the buffer's largest entry), losses of the second step within 1e-4; and the auto wire follows the
+    arithmetic mode in force (checked inside the worker)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    a0, a1 = _run_two_ranks(tmp_path, "bf16auto")
+    e0, _ = _run_two_ranks(tmp_path, "bf16exact")
+    assert a0["auto_wire"] is True and e0["auto_wire"] is False
+    assert torch.equal(a0["p"], a1["p"]) and torch.equal(a0["g"], a1["g"])
+    ga, ge = a0["g_first"], e0["g_first"]
+    assert float((ga - ge).abs().max()) <= 2 ** -7 * float(ge.abs().max())
+    assert float((ga - ge).abs().max()) > 0
+    assert abs(a0["losses"][1] - e0["losses"][1]) <= 1e-4, (a0["losses"], e0["losses"])

@@ -615,12 +615,12 @@ class TrainEngine:
         # (the carry region needs what early Adam needs: every flush point launches everything queued so far)
         full_flush = (self.defer_wgrad and self.flush_points and not self.split_step and _fn.FLUSH_MAX_TOKENS >= (1 << 30))
         if k < 2 or not self.use_graph or self.world != 1 or not self._carry_groups or not full_flush:
-            return [self.step(x, t) for x, t in zip(xs, targets)]
+            return self._step_by_step(xs, targets)
         ent = self._many
         if ent is not None and not (ent["k"] == k and ent["mode"] == ops.arith_mode() and all(
                 x.shape == sx.shape and x.dtype == sx.dtype and type(x) is type(sx) and t.shape == st.shape and t.dtype == st.dtype
                 for x, t, sx, st in zip(xs, targets, ent["x"], ent["t"]))):
-            return [self.step(x, t) for x, t in zip(xs, targets)]
+            return self._step_by_step(xs, targets)
         if ent is None:
             ent = self._many = self._capture_many(xs, targets)
         for sx, x in zip(ent["x"], xs):
@@ -631,6 +631,10 @@ class TrainEngine:
         self.steps_done += k
         ops.PARAM_EPOCH[0] += 1
         return list(ent["loss"])
+
+    def _step_by_step(self, xs, targets):
+        """step_many's fallback: k plain steps.  (A replayed step() hands out its ONE static loss tensor: copy each.)"""
+        return [self.step(x, t).clone() for x, t in zip(xs, targets)]
 
     def _many_body(self, sxs, sts):
         """The k steps as one launch sequence: step i hands the first flush points' batches + the tail's Adam to step i + 1."""

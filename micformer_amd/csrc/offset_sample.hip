@@ -852,6 +852,8 @@ static bool use_cells(int64_t T) { return T >= 4096; }
 static bool tile_shape(const Geo& g, int C, TileShape& ts, size_t& lds_bytes) {
   const char* on = getenv("MICF_SAMPLE_TILE");              // (read per call: test hooks, like MICF_CELL_CAP)
   if (on && atoi(on) == 0) return false;
+  static const int64_t tile_min = [] { const char* e = getenv("MICF_SAMPLE_TILE_MIN"); return e ? (int64_t)atoll(e) : (int64_t)0; }();
+  if (g.tokens() < tile_min) return false;
   const char* ee = getenv("MICF_SAMPLE_E");                 // radius of the NEAR neighbourhood; 0 = every token takes the atomic path
   const int e_env = ee ? atoi(ee) : 3;
   const int64_t T = g.tokens();
@@ -865,9 +867,11 @@ static bool tile_shape(const Geo& g, int C, TileShape& ts, size_t& lds_bytes) {
   }
   ts.td = td < g.D ? td : g.D; ts.th = th < g.H ? th : g.H; ts.tw = tw < g.W ? tw : g.W;
   ts.e = e_env < 0 ? 0 : (e_env > 8 ? 8 : e_env);
-  // a small sample (<= 4096 tokens: the 16^3 / 8^3 / 4^3 stages): the candidate box is the whole sample (E = its largest extent) --
-  // no far tokens exist, and a hit list that overflows is handled inside the workgroup (scanning lane's own atomics, fenced)
-  static const int64_t whole_max = [] { const char* e = getenv("MICF_TILE_WHOLE_MAX"); return e ? (int64_t)atoll(e) : (int64_t)4096; }();
+  // a small sample (<= 512 tokens: the 8^3 / 4^3 stages): the candidate box is the whole sample (E = its largest extent) -- no far
+  // tokens exist, the hit list cannot overflow.  (MICF_TILE_WHOLE_MAX=4096 takes the 16^3 stage too -- a full hit list is handled
+  // inside the workgroup: 66 -> 61 us per pair alone, but 66 -> 85 us inside the step, where 4096 candidates per box contend with
+  // the side queue; the replayed step is the same within noise either way.)
+  static const int64_t whole_max = [] { const char* e = getenv("MICF_TILE_WHOLE_MAX"); return e ? (int64_t)atoll(e) : (int64_t)kHitCap; }();
   ts.whole = (!ee && (int64_t)g.D * g.H * g.W <= whole_max) ? 1 : 0;
   if (ts.whole) ts.e = g.D > g.H ? (g.D > g.W ? g.D : g.W) : (g.H > g.W ? g.H : g.W);
   ts.nz = ceil_div(g.D, ts.td); ts.ny = ceil_div(g.H, ts.th); ts.nx = ceil_div(g.W, ts.tw);
@@ -894,7 +898,7 @@ struct BwdShape { bool quad, tiles, fused; int tpw, wpb, blocks; TileShape ts; s
 static void bwd_shape(const Geo& g, int C, bool al, BwdShape& sh) {
   const int64_t T = g.tokens();
   // quad kernels (4 tokens per wave) when the channel rows allow 16-byte accesses
-  static const int64_t quad_min = [] { const char* e = getenv("MICF_SAMPLE_QUAD_MIN"); return e ? (int64_t)atoll(e) : (int64_t)4096; }();
+  static const int64_t quad_min = [] { const char* e = getenv("MICF_SAMPLE_QUAD_MIN"); return e ? (int64_t)atoll(e) : (int64_t)kHitCap; }();
   sh.quad = T >= quad_min && (C % 4 == 0) && al;          // tiny grids: 1 token per wave
   // d(xa): output boxes summed from LDS lists (kTile, every grid) | cell lists (MICF_SAMPLE_TILE=0, >= 4096 tokens) | atomics
   sh.tile_lds = 0;

@@ -13,12 +13,11 @@ from micformer_amd import MDiceLoss, ops  # noqa: E402
 import micformer_amd.models.MICFormer_self as M  # noqa: E402
 
 out = {}
+sched = fill.stage_amplitude if "--f10" in sys.argv else None      # (--f10: the round-5 fixture with non-vanishing deep-stage gradients)
 for mode in ("bf16", "fp32"):
     ops.set_compute_dtype(mode)
     h = M.Head(embed_dim=48, num_classes=8)
-    with torch.no_grad():
-        for name, t in h.state_dict().items():
-            t.copy_(fill.fill_tensor(name, t))
+    fill.fill_state_dict(h, sched)
     h = h.cuda().eval()
     x = fill.make_volume(1, 128, 128, 128).cuda()
     tgt = fill.one_hot(fill.make_label_map(1, 128, 128, 128)).cuda()

@@ -652,7 +652,7 @@ extern "C" int micf_block_bwd(const micf_block_bwd_group* groups, int ngroups, i
   if ((int64_t)2 * H * W * (TM / 8 + 1) * hidden * (int64_t)sizeof(float) >= (int64_t)1 << 32) return MICF_EUNSUPPORTED;
   if (block_wide_tile_tokens(C, hd)) return block_bwd_wide(groups, ngroups, B, D, H, W, C, heads, scale, dtype, s);
 #define MICF_BB(C_, HD_, TJ_) if (C == C_ && hd == HD_ && tj == TJ_) return launch_bwd<C_, HD_, TJ_>(a, dtype, s)
-  MICF_BB(48, 16, 2); MICF_BB(48, 16, 1); MICF_BB(48, 16, 4); MICF_BB(96, 16, 1); MICF_BB(96, 16, 2); MICF_BB(192, 16, 1);
+  MICF_BB(48, 16, 2); MICF_BB(48, 16, 1); MICF_BB(96, 16, 1); MICF_BB(96, 16, 2); MICF_BB(192, 16, 1);
   MICF_BB(96, 32, 1); MICF_BB(192, 32, 1);
 #undef MICF_BB
   return MICF_EUNSUPPORTED;

@@ -454,7 +454,7 @@ extern "C" int micf_block_tile_tokens(int B, int D, int H, int W, int C, int hea
   else if ((C == 96 || C == 192) && (hd == 16 || hd == 32)) tj = 1;
   if (const char* e = getenv(backward ? "MICF_BLOCK_TJ_BWD" : "MICF_BLOCK_TJ")) {
     const int v = atoi(e);
-    if (C == 48 && hd == 16 && (v == 1 || v == 2 || v == 4)) tj = v;
+    if (C == 48 && hd == 16 && (v == 1 || v == 2)) tj = v;      // (64-token tiles were compiled until round 5: 54-205 spilled registers in the backward, never the faster shape)
     if (C == 96 && hd == 16 && (v == 1 || v == 2)) tj = v;
   }
   return 16 * tj;
@@ -517,7 +517,7 @@ extern "C" int micf_block_fwd(const micf_block_fwd_group* groups, int ngroups, i
   const int hd = C / heads, tj = TM / 16;
   if (block_wide_tile_tokens(C, hd)) return block_fwd_wide(groups, ngroups, B, D, H, W, C, heads, eps, scale, att8 ? MICF_DTYPE_BF16_ATTN_FP8 : dtype, s);   // (the few-token F1: attention on the matrix cores in both bf16 modes)
 #define MICF_BF(C_, HD_, TJ_) if (C == C_ && hd == HD_ && tj == TJ_) return launch_fwd<C_, HD_, TJ_>(a, dtype, s)
-  MICF_BF(48, 16, 2); MICF_BF(48, 16, 1); MICF_BF(48, 16, 4); MICF_BF(96, 16, 1); MICF_BF(96, 16, 2); MICF_BF(192, 16, 1);
+  MICF_BF(48, 16, 2); MICF_BF(48, 16, 1); MICF_BF(96, 16, 1); MICF_BF(96, 16, 2); MICF_BF(192, 16, 1);
   MICF_BF(96, 32, 1); MICF_BF(192, 32, 1);
 #undef MICF_BF
   return MICF_EUNSUPPORTED;

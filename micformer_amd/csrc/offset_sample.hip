@@ -898,7 +898,7 @@ struct BwdShape { bool quad, tiles, fused; int tpw, wpb, blocks; TileShape ts; s
 static void bwd_shape(const Geo& g, int C, bool al, BwdShape& sh) {
   const int64_t T = g.tokens();
   // quad kernels (4 tokens per wave) when the channel rows allow 16-byte accesses
-  static const int64_t quad_min = [] { const char* e = getenv("MICF_SAMPLE_QUAD_MIN"); return e ? (int64_t)atoll(e) : (int64_t)kHitCap; }();
+  static const int64_t quad_min = [] { const char* e = getenv("MICF_SAMPLE_QUAD_MIN"); return e ? (int64_t)atoll(e) : (int64_t)4096; }();
   sh.quad = T >= quad_min && (C % 4 == 0) && al;          // tiny grids: 1 token per wave
   // d(xa): output boxes summed from LDS lists (kTile, every grid) | cell lists (MICF_SAMPLE_TILE=0, >= 4096 tokens) | atomics
   sh.tile_lds = 0;

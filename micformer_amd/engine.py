@@ -78,6 +78,8 @@ class TrainEngine:
         self._many, self._carried, self._carry_groups = None, None, None
         self._param_at = {o: p for p, o in zip(self.params, self.offsets)}
         self.steps_done = 0
+        from . import functional as _fn
+        self.ctx = _fn.StepContext()             # this engine's launch-plan state (queues, mailboxes, switches)
 
     @property
     def grad_bf16(self):
@@ -226,26 +228,33 @@ class TrainEngine:
 
         @contextlib.contextmanager
         def scope():
-            prev = (_ms.PARALLEL_MODALITIES, _fn.DEFER_WGRAD, _fn.FLUSH_POINTS, _fn.DEFER_CALLS, ops.ENGINE_SHADOWS)
-            prev_fork, prev_lazy = _ms.FORK_AUTOGRAD_STREAMS, _fn.LAZY_LN_OK
-            _fn.LAZY_LN_OK = _fn.LAZY_LN_DEFAULT              # cross pairs park their LayerNorm-1 backward for the self pair's launch
+            prev = (_ms.PARALLEL_MODALITIES, self.ctx.defer_wgrad, self.ctx.flush_points, self.ctx.defer_calls, ops.ENGINE_SHADOWS)
+            prev_fork, prev_lazy = _ms.FORK_AUTOGRAD_STREAMS, self.ctx.lazy_ln_ok
+            self.ctx.lazy_ln_ok = _fn.LAZY_LN_DEFAULT              # cross pairs park their LayerNorm-1 backward for the self pair's launch
             _ms.FORK_AUTOGRAD_STREAMS = not (self.segmented and self.use_graph)
-            prev_budget = _fn.FLUSH_BUDGET[0]
-            _ms.PARALLEL_MODALITIES, _fn.DEFER_WGRAD = self.parallel_modalities, self.defer_wgrad
-            _fn.FLUSH_POINTS = self.defer_wgrad and self.flush_points and (not self.split_step or self.dp_graph_flushes > 0)
-            _fn.FLUSH_BUDGET[0] = self.dp_graph_flushes if self.split_step else 1 << 30
-            _fn.DEFER_CALLS = self.defer_wgrad
+            prev_budget = self.ctx.flush_budget
+            _ms.PARALLEL_MODALITIES, self.ctx.defer_wgrad = self.parallel_modalities, self.defer_wgrad
+            self.ctx.flush_points = self.defer_wgrad and self.flush_points and (not self.split_step or self.dp_graph_flushes > 0)
+            self.ctx.flush_budget = self.dp_graph_flushes if self.split_step else 1 << 30
+            self.ctx.defer_calls = self.defer_wgrad
             ops.ENGINE_SHADOWS = True                               # the parameters' shadow copies are current in this scope only
             try:
                 yield
             finally:
-                _ms.PARALLEL_MODALITIES, _fn.DEFER_WGRAD, _fn.FLUSH_POINTS, _fn.DEFER_CALLS, ops.ENGINE_SHADOWS = prev
-                _fn.FLUSH_BUDGET[0] = prev_budget
+                _ms.PARALLEL_MODALITIES, self.ctx.defer_wgrad, self.ctx.flush_points, self.ctx.defer_calls, ops.ENGINE_SHADOWS = prev
+                self.ctx.flush_budget = prev_budget
                 _ms.FORK_AUTOGRAD_STREAMS = prev_fork
-                _fn.LAZY_LN_OK = prev_lazy
+                self.ctx.lazy_ln_ok = prev_lazy
         return scope()
 
     def _fwd_bwd(self, x, target, flush=True, carry_in=None, carry_out=False):
+        """Forward + loss + backward of one batch with THIS engine's launch-plan state in force (functional.StepContext: switches,
+        queues, mailboxes -- nothing is shared with another engine or with engine-less forwards in the same process)."""
+        from . import functional as _fn
+        with _fn.use_context(self.ctx):
+            return self._fwd_bwd_in_ctx(x, target, flush, carry_in, carry_out)
+
+    def _fwd_bwd_in_ctx(self, x, target, flush, carry_in, carry_out):
         from . import functional as _fn
         _fn.drop_deferred()                                         # nothing left over from a backward that raised
         with self._scoped_flags():
@@ -286,13 +295,13 @@ class TrainEngine:
                     def prep():
                         ops.zero_(self.flat_g)
                         bwd.launch()
-                    evs = _fn.SEGMENTER.run_side_groups([group_work(g) for g in self._carry_groups] + [[prep]], keep=carry_in)
+                    evs = self.ctx.segmenter.run_side_groups([group_work(g) for g in self._carry_groups] + [[prep]], keep=carry_in)
                     for grp, ev in zip(self._carry_groups, evs):
-                        _fn.park_entry_hook((lambda e: (lambda: _fn.SEGMENTER.wait(e)))(ev), at=grp["entry"], front=True)
+                        _fn.park_entry_hook((lambda e: (lambda: self.ctx.segmenter.wait(e)))(ev), at=grp["entry"], front=True)
                     carried[0] = evs[-1]
 
                 def launch_carried_groups():
-                    if _fn.SEGMENTER is not None:
+                    if self.ctx.segmenter is not None:
                         return launch_carried_groups_segmented()
                     # Created AFTER the main chain's first kernels of this step (stage entry 1: patch embedding launched): a side
                     # branch created first makes the captured graph's executor run it in front of the main chain (measured: the
@@ -312,7 +321,7 @@ class TrainEngine:
                             ev.record(wside)
                             _fn.park_entry_hook((lambda e: (lambda: main.wait_event(e)))(ev), at=grp["entry"])
                             carried[0] = ev
-                    _fn._WSIDE_USED.add(self.flat_p.device)
+                    self.ctx.wside_used.add(self.flat_p.device)
                 # (entry 3 = the 8^3 encoder stage, where the main chain leaves half the chip idle; it must not be later than the
                 #  backward preparation parked there, which waits for the last group's event)
                 _fn.park_entry_hook(launch_carried_groups, at=min(3, int(__import__("os").environ.get("MICF_CARRY_AT", "3"))))
@@ -325,7 +334,7 @@ class TrainEngine:
                     _fn.park_entry_hook(lambda: main.wait_stream(side), at=1)
 
             def backward_prep():                                    # under the latency-bound small stages of the forward
-                if carry_in is not None and _fn.SEGMENTER is not None:
+                if carry_in is not None and self.ctx.segmenter is not None:
                     return                                          # (segmented step_many: part of the carried side graphs)
                 side.wait_stream(main)
                 if carried[0] is not None:
@@ -334,44 +343,44 @@ class TrainEngine:
                     ops.zero_(self.flat_g)                          # optimizer.zero_grad()        train.py:183
                     bwd.launch()                                    # W^T shadows of the fused backward
             _fn.park_entry_hook(backward_prep, at=3)
-            _fn.BACKWARD_HOOKS.clear()
+            self.ctx.backward_hooks.clear()
             self._adam_tail_done = False
             # Early Adam reads the tail of the flat gradient mid-backward: only valid when the flush point that fires it has
             # launched EVERY weight gradient queued so far (flush points on, unbounded budget, no token cap) -- otherwise the
             # linear / LayerNorm gradients of the tail would still sit in the queue and be applied one step late, never.
-            full_flush = _fn.FLUSH_POINTS and _fn.FLUSH_BUDGET[0] >= (1 << 30) and _fn.FLUSH_MAX_TOKENS >= (1 << 30)
+            full_flush = self.ctx.flush_points and self.ctx.flush_budget >= (1 << 30) and _fn.FLUSH_MAX_TOKENS >= (1 << 30)
             if carry_out:
                 # the first flush points' batches are set aside for the next step's head (functional.CARRY); the region ends
                 # where early Adam would start: that hook closes it (and leaves the side-stream anchor node there)
                 assert flush and self.world == 1 and self._early_cut is not None and full_flush
-                _fn.CARRY["on"], _fn.CARRY["open"], _fn.CARRY["stash"] = True, True, []
+                self.ctx.carry["on"], self.ctx.carry["open"], self.ctx.carry["stash"] = True, True, []
 
                 def close_carry():
-                    _fn.CARRY["open"] = False
-                    if _fn.SEGMENTER is None:
+                    self.ctx.carry["open"] = False
+                    if self.ctx.segmenter is None:
                         self._side_anchor()
-                _fn.BACKWARD_HOOKS[id(self._early_layer)] = close_carry
+                self.ctx.backward_hooks[id(self._early_layer)] = close_carry
             elif flush and self.world == 1 and self._early_cut is not None and self.early_adam and full_flush:
-                _fn.BACKWARD_HOOKS[id(self._early_layer)] = self._early_adam_segment if _fn.SEGMENTER is not None else self._early_adam
-            elif self._anchor_layer is not None and _fn.SEGMENTER is None:
-                _fn.BACKWARD_HOOKS[id(self._anchor_layer)] = self._side_anchor
+                self.ctx.backward_hooks[id(self._early_layer)] = self._early_adam_segment if self.ctx.segmenter is not None else self._early_adam
+            elif self._anchor_layer is not None and self.ctx.segmenter is None:
+                self.ctx.backward_hooks[id(self._anchor_layer)] = self._side_anchor
             # (the plain MDiceLoss: its forward sums are folded into the head's logits store -- functional.LOSS_MAIL)
-            _fn.LOSS_MAIL["target"] = target if type(self.criterion) is MDiceLoss else None
+            self.ctx.loss_mail["target"] = target if type(self.criterion) is MDiceLoss else None
             from .models import MICFormer_self as _msh
             # (Head.forward composes its weights behind the carried update: an event, or -- a sequence of graphs -- just later)
-            _msh.HEAD_WEIGHTS_AFTER = (carried if _fn.SEGMENTER is None else [None]) if carry_in is not None else None
+            _msh.HEAD_WEIGHTS_AFTER = (carried if self.ctx.segmenter is None else [None]) if carry_in is not None else None
             try:
                 logits = self.model(x)                              #                              train.py:185
             finally:
-                _fn.LOSS_MAIL["target"] = None
+                self.ctx.loss_mail["target"] = None
                 _msh.HEAD_WEIGHTS_AFTER = None
             loss = self.criterion(logits, target)                   #                              train.py:187
-            _fn.LOSS_MAIL["result"] = None
+            self.ctx.loss_mail["result"] = None
             _fn.run_entry_hook(force=True)                          # (fewer than 3 stages: launched here)
             main.wait_stream(side)
-            if carry_in is not None and _fn.SEGMENTER is not None:
-                _fn.SEGMENTER.wait(carried[0])                      # (zero fill + W^T shadows: the last carried side graph)
-            if _fn.SEGMENTER is not None:
+            if carry_in is not None and self.ctx.segmenter is not None:
+                self.ctx.segmenter.wait(carried[0])                      # (zero fill + W^T shadows: the last carried side graph)
+            if self.ctx.segmenter is not None:
                 # segmented capture: the flush points end / begin stream captures from inside backward; keep autograd on the
                 # calling thread so every hipStreamBeginCapture / EndCapture of this step is issued by ONE host thread
                 with torch.autograd.set_multithreading_enabled(False):
@@ -385,10 +394,10 @@ class TrainEngine:
             _fn.flush_wgrad(calls_only=not flush)                   # what is still queued: grouped linear weight gradients (left
             _fn.join_wgrad_stream()                                 # to the data-parallel tail when flush=False), closures
             if carry_out:
-                if _fn.CARRY["open"]:
+                if self.ctx.carry["open"]:
                     raise RuntimeError("the carry region was never closed (no flush point at the last encoder stage)")
                 groups, cur = {}, []
-                for key, batch in _fn.CARRY["stash"]:               # (flush points inside a stage belong to the stage being left)
+                for key, batch in self.ctx.carry["stash"]:               # (flush points inside a stage belong to the stage being left)
                     cur.append(batch)
                     if key is not None:
                         groups.setdefault(key, []).extend(cur)
@@ -396,7 +405,7 @@ class TrainEngine:
                 if cur or set(groups) - {g["key"] for g in self._carry_groups}:
                     raise RuntimeError("carried parameter-gradient batches do not map onto the stage groups")
                 self._carried = groups
-                _fn.CARRY["on"], _fn.CARRY["stash"] = False, []
+                self.ctx.carry["on"], self.ctx.carry["stash"] = False, []
         return loss.detach()
 
     def _adam(self, grad_scale):
@@ -426,7 +435,7 @@ class TrainEngine:
         side.wait_stream(main)
         with torch.cuda.stream(side):
             tail()
-        _fn._WSIDE_USED.add(dev)
+        self.ctx.wside_used.add(dev)
         self._adam_tail_done = True
 
     def _early_adam_segment(self):
@@ -451,7 +460,7 @@ class TrainEngine:
             if self._anchor_buf is None:
                 self._anchor_buf = torch.empty(1024, dtype=torch.float32, device=dev)
             ops.zero_(self._anchor_buf)
-        _fn._WSIDE_USED.add(dev)
+        self.ctx.wside_used.add(dev)
 
     def _update(self):
         """Un-overlapped form (eager steps): all-reduce(sum) the whole flat gradient, then Adam reads it as g / world."""
@@ -667,7 +676,7 @@ class TrainEngine:
             # the warm-up ran k + 1 real updates: undo them whether or not it finished (a raise must not leave the parameters,
             # the Adam state, the RNG streams or the carry switch behind)
             from . import functional as _fn0
-            _fn0.CARRY["on"], _fn0.CARRY["open"], _fn0.CARRY["stash"] = False, False, []
+            self.ctx.carry["on"], self.ctx.carry["open"], self.ctx.carry["stash"] = False, False, []
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             with torch.no_grad():
@@ -685,14 +694,14 @@ class TrainEngine:
             cs = torch.cuda.Stream(device=sxs[0].device)
             cs.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(cs):
-                _fn.SEGMENTER = g
+                self.ctx.segmenter = g
                 try:
                     g.begin()
                     with torch.autograd.set_multithreading_enabled(False):
                         losses = self._many_body(sxs, sts)
                     g.finish()
                 finally:
-                    _fn.SEGMENTER = None
+                    self.ctx.segmenter = None
             torch.cuda.current_stream().wait_stream(cs)
         else:
             g = torch.cuda.CUDAGraph()
@@ -759,13 +768,13 @@ class TrainEngine:
             cs = torch.cuda.Stream(device=sx.device)
             cs.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(cs):
-                _fn.SEGMENTER = g
+                self.ctx.segmenter = g
                 try:
                     g.begin()
                     sl = body()
                     g.finish()
                 finally:
-                    _fn.SEGMENTER = None
+                    self.ctx.segmenter = None
             torch.cuda.current_stream().wait_stream(cs)
         else:
             g = torch.cuda.CUDAGraph()
@@ -773,7 +782,8 @@ class TrainEngine:
                 sl = body()
         if self.split_step:
             from . import functional as _fn
-            self._plan_split(*_fn.take_deferred())                  # (capture records, it does not run: step() replays next)
+            with _fn.use_context(self.ctx):
+                self._plan_split(*_fn.take_deferred())              # (capture records, it does not run: step() replays next)
         self._graph, self._static, self._static_mode = g, (sx, st, sl), ops.arith_mode()
 
     def _drop_path_rng_tensors(self, x):

@@ -35,6 +35,75 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+# ----------------------------------------------------------------------------- the launch plan's state: ONE object per step owner
+class StepContext:
+    """Everything the launch plan of a step keeps between its launches -- the switches an engine sets for its own forward +
+    backward, the queues of parameter-gradient work that left the data-gradient chain, and the mailboxes modules use to hand a
+    tensor to the NEXT launch (keyed on data_ptr(): valid inside one step of one owner only).  Round 5: these were ~20
+    module-level globals; two engines in a process, or a validation forward between an engine's forward and backward, shared them.
+    Now every TrainEngine owns one StepContext and installs it for the duration of its forward + backward (`use_context`, which
+    refuses re-entry); engine-less forwards / backwards run on the module's default context.
+
+      switches    defer_wgrad / defer_calls  queue linear weight gradients / other parameter-gradient closures instead of launching
+                  flush_points, flush_budget launch what is queued at stage boundaries (how many of them may: data-parallel step)
+                  lazy_ln_ok                 cross pairs may park their LayerNorm-1 backward for the self pair's launch
+                  segmenter                  the StepSegmenter capturing this step as a sequence of graphs, or None
+      queues      deferred, deferred_ln, deferred_calls, queued_dw, pending_flush (flush batches set aside until the main chain
+                  has launched its next kernel: LAZY_FLUSH), wside_used (devices whose side stream must be joined)
+      hooks       entry_hooks / entry_seen (forward: work parked until the n-th stage entry), backward_hooks (per stage module)
+      mailboxes   loss_mail (target in, fused loss out), cross_after_self (the self pair's outputs BasicLayer is about to hand to
+                  the cross pair), lazy_ln (parked LayerNorm-1 backward records), skip_tokens (ConvDownFn inputs of THIS forward),
+                  carry (step_many: the batches carried to the next step's head)
+    """
+
+    def __init__(self):
+        self.defer_wgrad = False
+        self.defer_calls = False
+        self.flush_points = False
+        self.flush_budget = 1 << 30
+        self.lazy_ln_ok = False
+        self.segmenter = None
+        self.deferred = []                 # (dy, a, dw, db, dp_scale, rows_per_sample) of nn.Linear weight gradients
+        self.deferred_ln = []              # (partials, blocks, C, dgamma, dbeta) of LayerNorm backward calls
+        self.deferred_calls = []           # (callable, tensors it reads, queued from inside a transformer block?)
+        self.queued_dw = set()             # destinations already in the queue: the grouped kernel owns each dW element exclusively
+        self.pending_flush = []            # (event, device, linear items, LayerNorm items, closures)
+        self.wside_used = set()
+        self.entry_hooks = []              # [callable, the stage entry it waits for]
+        self.entry_seen = 0                # stage entries seen since clear_entry_hooks()
+        self.backward_hooks = {}           # id(stage module) -> callable run when the backward has left that stage
+        self.loss_mail = {"target": None, "result": None}
+        self.cross_after_self = None       # (data_ptr, data_ptr)
+        self.lazy_ln = {}                  # data_ptr of the partial-sum buffer handed to autograd -> the parked record
+        self.skip_tokens = {}              # data_ptr of a ConvDownFn input of THIS forward -> token
+        self.carry = {"on": False, "open": False, "stash": []}
+
+
+CTX = StepContext()                        # the context in force (module default: engine-less forwards and backwards)
+_DEFAULT_CTX = CTX
+_CTX_OWNER = [None]
+
+
+class use_context:
+    """`with use_context(ctx):` -- ctx is the launch plan's state until the block exits.  Not re-entrant: a second owner inside
+    the block (another engine's step, a nested step of the same engine) would cross the mailboxes."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def __enter__(self):
+        global CTX
+        if _CTX_OWNER[0] is not None:
+            raise RuntimeError("a StepContext is already in force: steps of two owners must not nest")
+        _CTX_OWNER[0], CTX = self.ctx, self.ctx
+        return self.ctx
+
+    def __exit__(self, *exc):
+        global CTX
+        _CTX_OWNER[0], CTX = None, _DEFAULT_CTX
+        return False
+
+
 # ----------------------------------------------------------------------------- deferred weight gradients (engine mode)
 # Nothing downstream of a backward pass consumes the parameter gradients until the optimiser step.  In engine mode (the
 # kernels accumulate straight into the flat gradient buffer) the weight gradients of the linear layers are therefore not
@@ -42,27 +111,21 @@ def _c(t):
 # after backward through micf_linear_bwd_weight_grouped -- a few chip-filling launches instead of two small ones per
 # layer, and the data-gradient chain (the critical path) gets shorter.  The queue holds references, so the caching
 # allocator cannot hand the queued buffers to anyone else before the flush.
-DEFER_WGRAD = False
 DEFER_MAX_TOKENS = 1 << 17          # larger layers launch immediately (their operands are still hot in L2 / MALL)
-_DEFERRED = []
-_DEFERRED_LN = []                   # (partials, blocks, C, dgamma, dbeta) of LayerNorm backward calls
 
 
-_QUEUED_DW = set()                  # destinations already in the queue: the grouped kernel owns each dW element exclusively
 
 # Any other parameter-gradient work (conv weight gradients, the head tail's decomposition, bias column sums ...) can leave the
 # data-gradient chain the same way: single-GPU engine mode queues it as a closure that the next flush launches (on the side
 # stream at a flush point).  Only work that accumulates into the engine's flat gradient buffer qualifies: autograd must not be
 # waiting for a returned tensor.
-DEFER_CALLS = False
-_DEFERRED_CALLS = []                # (callable, tensors it reads, queued from inside a transformer block?)
 
 
 def _defer(ok, fn, *tensors):
     """Run `fn` now, or -- engine mode, every destination a view of the flat gradient buffer (`ok`) -- at the next flush."""
-    if ok and DEFER_CALLS and DEFER_WGRAD:
+    if ok and CTX.defer_calls and CTX.defer_wgrad:
         launch_pending_flush()
-        _DEFERRED_CALLS.append((fn, tuple(t for t in tensors if t is not None), _lib.BLOCK_DEPTH > 0))
+        CTX.deferred_calls.append((fn, tuple(t for t in tensors if t is not None), _lib.BLOCK_DEPTH > 0))
     else:
         fn()
 
@@ -73,14 +136,14 @@ def _lin_wgrad(defer, dy, a, dw, db, dp_scale=None, rows_per_sample=0):
         # than 32 tokens -- are widened and go the fp32 way)
         if dy.dtype != a.dtype or not ops.wgrad_groupable(dy, a, dp_scale, rows_per_sample):
             dy, a = dy.float(), a.float()
-        elif not (defer and DEFER_WGRAD and dw.data_ptr() not in _QUEUED_DW):
+        elif not (defer and CTX.defer_wgrad and dw.data_ptr() not in CTX.queued_dw):
             ops.linear_bwd_weight_grouped([(dy, a, dw, db, dp_scale, rows_per_sample)])
             return
-    if defer and DEFER_WGRAD and dy.shape[0] <= DEFER_MAX_TOKENS and ops.wgrad_groupable(dy, a, dp_scale, rows_per_sample) \
-            and dw.data_ptr() not in _QUEUED_DW:          # (a layer applied twice in one step launches its second use at once)
+    if defer and CTX.defer_wgrad and dy.shape[0] <= DEFER_MAX_TOKENS and ops.wgrad_groupable(dy, a, dp_scale, rows_per_sample) \
+            and dw.data_ptr() not in CTX.queued_dw:          # (a layer applied twice in one step launches its second use at once)
         launch_pending_flush()
-        _QUEUED_DW.add(dw.data_ptr())
-        _DEFERRED.append((dy, a, dw, db, dp_scale, rows_per_sample))
+        CTX.queued_dw.add(dw.data_ptr())
+        CTX.deferred.append((dy, a, dw, db, dp_scale, rows_per_sample))
     elif dy.dtype == torch.bfloat16:
         # bf16 operands of a layer too long to queue (> DEFER_MAX_TOKENS rows: batch >= 5 at 128^3): the per-layer entry point is
         # fp32 only, the grouped one reads bf16 pairs -- launch it now for this one layer
@@ -92,42 +155,39 @@ def _lin_wgrad(defer, dy, a, dw, db, dp_scale=None, rows_per_sample=0):
 def take_deferred():
     """Hand the queued (not yet launched) weight gradients and LayerNorm partials to the caller (TrainEngine's data-parallel step)."""
     launch_pending_flush()
-    if _DEFERRED_CALLS:
-        raise RuntimeError("deferred gradient closures are a single-GPU engine feature (DEFER_CALLS) and cannot be planned")
-    items, ln = list(_DEFERRED), list(_DEFERRED_LN)
-    _DEFERRED.clear()
-    _DEFERRED_LN.clear()
-    _QUEUED_DW.clear()
+    if CTX.deferred_calls:
+        raise RuntimeError("deferred gradient closures are a single-GPU engine feature (CTX.defer_calls) and cannot be planned")
+    items, ln = list(CTX.deferred), list(CTX.deferred_ln)
+    CTX.deferred.clear()
+    CTX.deferred_ln.clear()
+    CTX.queued_dw.clear()
     return items, ln
 
 
 def drop_deferred():
     """Forget anything still queued (TrainEngine calls this at the start of a step: entries left behind by a backward that
     raised must not be flushed into the next step's gradients)."""
-    _DEFERRED.clear()
-    _DEFERRED_LN.clear()
-    _DEFERRED_CALLS.clear()
-    _QUEUED_DW.clear()
-    _PENDING_FLUSH.clear()
-    _LAZY_LN.clear()
-    CARRY["on"], CARRY["open"] = False, False
-    CARRY["stash"].clear()
+    CTX.deferred.clear()
+    CTX.deferred_ln.clear()
+    CTX.deferred_calls.clear()
+    CTX.queued_dw.clear()
+    CTX.pending_flush.clear()
+    CTX.lazy_ln.clear()
+    CTX.carry["on"], CTX.carry["open"] = False, False
+    CTX.carry["stash"].clear()
 
 
 def _ln_defer(on):
     """The list LayerNorm backward should queue its parameter-gradient partials in, or None (accumulate immediately)."""
-    return _DEFERRED_LN if (on and DEFER_WGRAD) else None
+    return CTX.deferred_ln if (on and CTX.defer_wgrad) else None
 
 
 # Flush points (engine mode, single GPU): an identity node at every stage boundary whose BACKWARD launches the weight
 # gradients queued so far on a side stream, so they run under the rest of the backward chain (which is latency-bound, not
 # throughput-bound, since the blocks were fused) instead of in a tail after it.  join_wgrad_stream() re-joins before Adam.
-FLUSH_POINTS = False
-FLUSH_BUDGET = [1 << 30]            # flush points that may still launch the queued linear weight gradients (the data-parallel step
                                     # allows the first few only: the rest stays queued for the launches that overlap the all-reduce)
 FLUSH_MAX_TOKENS = int(__import__("os").environ.get("MICF_FLUSH_MAX_TOKENS", 1 << 30))   # (measured: flushing at every point wins, 19.6 vs 20.2 ms small stages only)
 _WSIDE = {}
-_WSIDE_USED = set()
 
 
 def _wgrad_stream(device):
@@ -143,7 +203,6 @@ def _wgrad_stream(device):
 # aside; the batch goes to the side stream (waiting for that event) once the main chain has launched its next kernel -- i.e.
 # when the next entry is queued.  Measured 13.9 -> 13.4 ms per step (MICF_LAZY_FLUSH=0 restores the eager order).
 LAZY_FLUSH = __import__("os").environ.get("MICF_LAZY_FLUSH", "1") != "0"
-_PENDING_FLUSH = []                 # (event, device, linear items, LayerNorm items, closures)
 
 
 # Segmented capture (TrainEngine(segmented=True)): instead of ONE HIP graph whose executor decides on which hardware queue the
@@ -154,7 +213,6 @@ _PENDING_FLUSH = []                 # (event, device, linear items, LayerNorm it
 # is left for the executor to place.  Memory: main segments share one private pool, side segments another (graphs of one pool
 # replay in capture order on one stream); tensors a side batch reads were allocated by main segments and are kept referenced
 # until the capture is complete, so no later main segment can be handed their blocks.
-SEGMENTER = None
 SEG_SERIAL = __import__("os").environ.get("MICF_SEG_SERIAL", "0") == "1"      # debug: side segments on the main stream too
 SEG_SKIP_SIDE = __import__("os").environ.get("MICF_SEG_SKIP_SIDE", "0") == "1"  # measurement: the main chain alone (WRONG results)
 
@@ -259,13 +317,13 @@ class StepSegmenter:
 
 
 def launch_pending_flush():
-    while _PENDING_FLUSH:
-        ev, dev, items, ln, calls = _PENDING_FLUSH.pop(0)
+    while CTX.pending_flush:
+        ev, dev, items, ln, calls = CTX.pending_flush.pop(0)
         side = _wgrad_stream(dev)
         side.wait_event(ev)
         with torch.cuda.stream(side):
             _launch_batch(items, ln, calls)
-        _WSIDE_USED.add(dev)
+        CTX.wside_used.add(dev)
 
 
 def flush_wgrad_side(calls_only=False, lazy=False, extra=None):
@@ -273,30 +331,30 @@ def flush_wgrad_side(calls_only=False, lazy=False, extra=None):
     calls_only: just the deferred closures (data-parallel mode: the grouped linear weight gradients stay queued for the
     engine, which interleaves them with the gradient all-reduce after the replay).  lazy: see LAZY_FLUSH.
     extra: callables launched behind the batch on the same stream (segmented capture: the early optimiser step)."""
-    if SEGMENTER is not None:
-        items, ln = ([], []) if calls_only else (list(_DEFERRED), list(_DEFERRED_LN))
-        calls = list(_DEFERRED_CALLS)
+    if CTX.segmenter is not None:
+        items, ln = ([], []) if calls_only else (list(CTX.deferred), list(CTX.deferred_ln))
+        calls = list(CTX.deferred_calls)
         if not calls_only:
-            _DEFERRED.clear()
-            _DEFERRED_LN.clear()
-            _QUEUED_DW.clear()
-        _DEFERRED_CALLS.clear()
+            CTX.deferred.clear()
+            CTX.deferred_ln.clear()
+            CTX.queued_dw.clear()
+        CTX.deferred_calls.clear()
         work = [lambda: _launch_batch(items, ln, calls)] if (items or ln or calls) else []
         work += list(extra or [])
         if work:
-            SEGMENTER.run_side(work, keep=(items, ln, calls))
+            CTX.segmenter.run_side(work, keep=(items, ln, calls))
         return
     launch_pending_flush()
-    if not ((not calls_only and (_DEFERRED or _DEFERRED_LN)) or _DEFERRED_CALLS):
+    if not ((not calls_only and (CTX.deferred or CTX.deferred_ln)) or CTX.deferred_calls):
         return
-    first = _DEFERRED_CALLS[0][1][0] if _DEFERRED_CALLS else (_DEFERRED[0][0] if _DEFERRED else _DEFERRED_LN[0][0])
+    first = CTX.deferred_calls[0][1][0] if CTX.deferred_calls else (CTX.deferred[0][0] if CTX.deferred else CTX.deferred_ln[0][0])
     dev = first.device
     main, side = torch.cuda.current_stream(dev), _wgrad_stream(dev)
     if lazy and LAZY_FLUSH:
         ev = torch.cuda.Event()
         ev.record(main)
-        items, ln = ([], []) if calls_only else (list(_DEFERRED), list(_DEFERRED_LN))
-        calls = list(_DEFERRED_CALLS)
+        items, ln = ([], []) if calls_only else (list(CTX.deferred), list(CTX.deferred_ln))
+        calls = list(CTX.deferred_calls)
         for it in items:
             for t in (it[0], it[1], it[4]):
                 if t is not None:
@@ -307,69 +365,66 @@ def flush_wgrad_side(calls_only=False, lazy=False, extra=None):
             for t in tensors:
                 t.record_stream(side)
         if not calls_only:
-            _DEFERRED.clear()
-            _DEFERRED_LN.clear()
-            _QUEUED_DW.clear()
-        _DEFERRED_CALLS.clear()
-        _PENDING_FLUSH.append((ev, dev, items, ln, calls))
+            CTX.deferred.clear()
+            CTX.deferred_ln.clear()
+            CTX.queued_dw.clear()
+        CTX.deferred_calls.clear()
+        CTX.pending_flush.append((ev, dev, items, ln, calls))
         return
     side.wait_stream(main)
     if not calls_only:
-        for it in _DEFERRED:                # the queue's references die at the flush: tell the allocator who still reads them
+        for it in CTX.deferred:                # the queue's references die at the flush: tell the allocator who still reads them
             for t in (it[0], it[1], it[4]):
                 if t is not None:
                     t.record_stream(side)
-        for it in _DEFERRED_LN:
+        for it in CTX.deferred_ln:
             it[0].record_stream(side)
-    for _, tensors, _blk in _DEFERRED_CALLS:
+    for _, tensors, _blk in CTX.deferred_calls:
         for t in tensors:
             t.record_stream(side)
     with torch.cuda.stream(side):
         flush_wgrad(calls_only)
-    _WSIDE_USED.add(dev)
+    CTX.wside_used.add(dev)
 
 
 def join_wgrad_stream():
-    if SEGMENTER is not None:
-        SEGMENTER.join()
+    if CTX.segmenter is not None:
+        CTX.segmenter.join()
         return
     launch_pending_flush()
-    for dev in list(_WSIDE_USED):
+    for dev in list(CTX.wside_used):
         torch.cuda.current_stream(dev).wait_stream(_wgrad_stream(dev))
-    _WSIDE_USED.clear()
+    CTX.wside_used.clear()
 
 
 # forward side of a stage entry: the engine may park a callable here that runs when the forward reaches its n-th stage (work
 # only the backward needs -- zeroing the gradient buffer, transposed shadow weights -- is launched on a side stream under the
 # latency-bound small stages instead of in front of the step)
-_ENTRY_HOOKS = []                   # [callable, the stage entry it waits for]
-_ENTRY_SEEN = [0]                   # stage entries seen since clear_entry_hooks()
 
 
 def clear_entry_hooks():
-    _ENTRY_HOOKS.clear()
-    _ENTRY_SEEN[0] = 0
+    CTX.entry_hooks.clear()
+    CTX.entry_seen = 0
 
 
 def park_entry_hook(fn, at, front=False):
     """front: runs before the hooks already parked for the same entry."""
     if front:
-        _ENTRY_HOOKS.insert(0, [fn, at])
+        CTX.entry_hooks.insert(0, [fn, at])
     else:
-        _ENTRY_HOOKS.append([fn, at])
+        CTX.entry_hooks.append([fn, at])
 
 
 def run_entry_hook(force=False):
     """Called at every stage entry: runs the parked callables whose entry this is (or all of them now, `force`)."""
-    _ENTRY_SEEN[0] += 1
-    due = [h for h in _ENTRY_HOOKS if force or _ENTRY_SEEN[0] >= h[1]]
+    CTX.entry_seen += 1
+    due = [h for h in CTX.entry_hooks if force or CTX.entry_seen >= h[1]]
     for h in due:
-        _ENTRY_HOOKS.remove(h)
+        CTX.entry_hooks.remove(h)
         h[0]()
 
 
 # backward side: callables the engine parks per stage (key = id of the stage module); run when the backward has left that stage
-BACKWARD_HOOKS = {}
 
 # Carry (TrainEngine.step_many: several steps in ONE captured graph).  The parameter-gradient batches of the flush points the backward
 # reaches FIRST -- decoder, head, last encoder stage: exactly the gradients of the flat buffers' tail [cut, total) -- are not
@@ -377,19 +432,18 @@ BACKWARD_HOOKS = {}
 # step) but set aside; the engine launches them, and the Adam update of that tail, on the side stream at the START of the next
 # step of the same graph, under its encoder forward -- which does not read those parameters and leaves half the chip idle in its
 # 8^3 stage.  "open": the backward is still inside that first region (the engine's hook at the last encoder stage closes it).
-CARRY = {"on": False, "open": False, "stash": []}
 
 
 def _carry_stash(key):
     """Set aside everything queued so far (linear items, LayerNorm partials, closures) for the next step's head.  key: id of the
     stage module whose backward this flush point closes (None: a flush point inside a stage)."""
     launch_pending_flush()
-    batch = (list(_DEFERRED), list(_DEFERRED_LN), list(_DEFERRED_CALLS))
-    _DEFERRED.clear()
-    _DEFERRED_LN.clear()
-    _DEFERRED_CALLS.clear()
-    _QUEUED_DW.clear()
-    CARRY["stash"].append((key, batch))
+    batch = (list(CTX.deferred), list(CTX.deferred_ln), list(CTX.deferred_calls))
+    CTX.deferred.clear()
+    CTX.deferred_ln.clear()
+    CTX.deferred_calls.clear()
+    CTX.queued_dw.clear()
+    CTX.carry["stash"].append((key, batch))
 
 
 def launch_carried(batches):
@@ -419,23 +473,23 @@ class FlushPointFn(torch.autograd.Function):
     def backward(ctx, dx, dxa):
         # (a token cap exists for experiments: restricting the flushes to the latency-bound small stages was measured slower --
         # the weight gradients of the big stages then pile up in the tail)
-        full = FLUSH_POINTS and DEFER_WGRAD and dx.numel() // dx.shape[-1] <= FLUSH_MAX_TOKENS and FLUSH_BUDGET[0] > 0
-        hook = BACKWARD_HOOKS.pop(ctx.key, None) if ctx.key is not None else None
-        if CARRY["on"] and CARRY["open"] and full:
-            _carry_stash(ctx.key)                       # (launched at the head of the next step: see CARRY)
+        full = CTX.flush_points and CTX.defer_wgrad and dx.numel() // dx.shape[-1] <= FLUSH_MAX_TOKENS and CTX.flush_budget > 0
+        hook = CTX.backward_hooks.pop(ctx.key, None) if ctx.key is not None else None
+        if CTX.carry["on"] and CTX.carry["open"] and full:
+            _carry_stash(ctx.key)                       # (launched at the head of the next step: see CTX.carry)
             if hook is not None:
                 hook()
             return dx, dxa, None
-        if SEGMENTER is not None:                       # the hook (early Adam) rides in the same side segment as the batch
-            if full or (DEFER_CALLS and DEFER_WGRAD) or hook is not None:
+        if CTX.segmenter is not None:                       # the hook (early Adam) rides in the same side segment as the batch
+            if full or (CTX.defer_calls and CTX.defer_wgrad) or hook is not None:
                 if full:
-                    FLUSH_BUDGET[0] -= 1
+                    CTX.flush_budget -= 1
                 flush_wgrad_side(calls_only=not full, extra=[hook] if hook is not None else None)
             return dx, dxa, None
         if full:
-            FLUSH_BUDGET[0] -= 1
+            CTX.flush_budget -= 1
             flush_wgrad_side(lazy=True)
-        elif DEFER_CALLS and DEFER_WGRAD:
+        elif CTX.defer_calls and CTX.defer_wgrad:
             flush_wgrad_side(calls_only=True, lazy=True)
         if hook is not None:
             hook()
@@ -488,18 +542,18 @@ def _launch_batch(items, ln, calls):
 
 def flush_wgrad(calls_only=False):
     """Launch every queued weight gradient on the current stream (which must be ordered after their producers)."""
-    if SEGMENTER is not None:                           # segmented capture: one more side segment (join_wgrad_stream follows)
+    if CTX.segmenter is not None:                           # segmented capture: one more side segment (join_wgrad_stream follows)
         flush_wgrad_side(calls_only)
         return
     launch_pending_flush()
     items, ln = [], []
     if not calls_only:
-        items, ln = list(_DEFERRED), list(_DEFERRED_LN)
-        _DEFERRED.clear()
-        _DEFERRED_LN.clear()
-        _QUEUED_DW.clear()
-    calls = list(_DEFERRED_CALLS)
-    _DEFERRED_CALLS.clear()
+        items, ln = list(CTX.deferred), list(CTX.deferred_ln)
+        CTX.deferred.clear()
+        CTX.deferred_ln.clear()
+        CTX.queued_dw.clear()
+    calls = list(CTX.deferred_calls)
+    CTX.deferred_calls.clear()
     _launch_batch(items, ln, calls)
 
 
@@ -612,9 +666,9 @@ class LinearFn(torch.autograd.Function):
         dw = _grad_buf(ctx.tg[0], w)
         db = (ctx.tg[1] if ctx.tg[1] is not None else torch.zeros(w.shape[0], dtype=w.dtype, device=w.device)) if ctx.has_bias else None
         engine = ctx.tg[0] is not None and (ctx.tg[1] is not None or not ctx.has_bias)
-        if a2f is not None and engine and DEFER_WGRAD and k1 % 4 == 0 and a2f.shape[1] % 4 == 0 and (k1 * 4) % 16 == 0 \
+        if a2f is not None and engine and CTX.defer_wgrad and k1 % 4 == 0 and a2f.shape[1] % 4 == 0 and (k1 * 4) % 16 == 0 \
                 and dy.shape[0] <= DEFER_MAX_TOKENS and ops.wgrad_groupable(dy, af) and ops.wgrad_groupable(dy, a2f) \
-                and dw.data_ptr() not in _QUEUED_DW:
+                and dw.data_ptr() not in CTX.queued_dw:
             # a layer on a concatenation [a | a2]: two items of the grouped launch, each a column block of dw (row stride K)
             _lin_wgrad(True, dy, af, dw[:, :k1], db)
             _lin_wgrad(True, dy, a2f, dw[:, k1:], None)
@@ -925,15 +979,12 @@ def _self_fwd_fused(xs, Ps, scales, dims, heads, eps):
 # launch it -- it hands the self pair its partial sums (the returned "gradients": residual path + the other branches) and parks
 # what the LayerNorm backward needs here; micf_block_bwd runs it as its prologue (micf_block_bwd_group.pre_d).  24 launches and
 # a [T, C] round trip per slot off the chain.  Only BasicLayer's self -> cross sequence sets it up (`lazy_ln` of CrossPairFn), only
-# while an engine step scopes LAZY_LN_OK, and the engine checks after backward that nothing parked was left unconsumed.
-LAZY_LN_OK = False
+# while an engine step scopes CTX.lazy_ln_ok, and the engine checks after backward that nothing parked was left unconsumed.
 LAZY_LN_DEFAULT = __import__("os").environ.get("MICF_LAZY_LN", "1") != "0"
-CROSS_AFTER_SELF = [None]           # (data_ptr, data_ptr) of the self pair's outputs BasicLayer is about to hand to the cross pair
-_LAZY_LN = {}                       # data_ptr of the partial-sum buffer handed to autograd -> the parked LayerNorm backward
 
 
 def lazy_ln_pending():
-    return len(_LAZY_LN)
+    return len(CTX.lazy_ln)
 
 
 def _self_bwd_fused(dys, xs, svs, Ps, Gs, scales, dims, heads, sides):
@@ -941,7 +992,7 @@ def _self_bwd_fused(dys, xs, svs, Ps, Gs, scales, dims, heads, sides):
     rps = dims[1] * dims[2] * dims[3]
     groups = [{"dy": dy, "x": x, "x1": sv["x1"], "stats": sv["stats"], "q": sv["q"], "kv": sv["kv"], "h": sv["h"], "xn2": sv["xn2"], "P": P,
                "attn": "self_attn", "s1": s[0], "s2": s[1], "cross": False} for dy, x, sv, P, s in zip(dys, xs, svs, Ps, scales)]
-    pres = [_LAZY_LN.pop(dy.data_ptr(), None) for dy in dys]
+    pres = [CTX.lazy_ln.pop(dy.data_ptr(), None) for dy in dys]
     for gd, pre in zip(groups, pres):
         if pre is not None:
             if tuple(pre["d"].shape) != tuple(gd["dy"].shape):
@@ -1074,9 +1125,9 @@ class CrossPairFn(torch.autograd.Function):
         n = len(CROSS_KEYS)
         Ps = [dict(zip(CROSS_KEYS, params[:n])), dict(zip(CROSS_KEYS, params[n:]))]
         x, xa = _c(x), _c(xa)
-        # (the inputs are the outputs of the self pair of this depth slot and nobody else reads them: see _LAZY_LN)
-        ctx.lazy_ln = CROSS_AFTER_SELF[0] == (x.data_ptr(), xa.data_ptr())
-        CROSS_AFTER_SELF[0] = None
+        # (the inputs are the outputs of the self pair of this depth slot and nobody else reads them: see CTX.lazy_ln)
+        ctx.lazy_ln = CTX.cross_after_self == (x.data_ptr(), xa.data_ptr())
+        CTX.cross_after_self = None
         B, D, H, W, C = x.shape
         dims = (B, D, H, W)
         xs = [x.reshape(-1, C), xa.reshape(-1, C)]
@@ -1153,7 +1204,7 @@ class CrossPairFn(torch.autograd.Function):
             # small grids: the sampler's finishing launch only sums head-parameter partials -- off the data-gradient chain with
             # the other parameter gradients (its partial table then lives in a workspace of its own until the flush)
             defer_ws = None
-            if all(sides) and DEFER_CALLS and DEFER_WGRAD and ops.offset_head_finish_deferrable(dims):
+            if all(sides) and CTX.defer_calls and CTX.defer_wgrad and ops.offset_head_finish_deferrable(dims):
                 defer_ws = torch.empty(ops.offset_head_bwd_workspace(2, dims), dtype=torch.float32, device=xs[0].device)
             dhids = ops.offset_head_bwd(hgroups, dims, eps, defer_ws=defer_ws)
             if defer_ws is not None:
@@ -1173,12 +1224,12 @@ class CrossPairFn(torch.autograd.Function):
                     _cross_head_adjoint(i, hds, bos, Ps, Gs, xs, acc, dims, eps, C, sides)
             if side is not None:
                 main.wait_stream(side)
-        lazy = (ctx.lazy_ln and LAZY_LN_OK and GROUP_CROSS_HEADS and all(sides) and DEFER_WGRAD and bos[0].get("dy16") is not None
+        lazy = (ctx.lazy_ln and CTX.lazy_ln_ok and GROUP_CROSS_HEADS and all(sides) and CTX.defer_wgrad and bos[0].get("dy16") is not None
                 and ops.block_fuses_sampler(C, heads))
         if lazy:
-            # parked for the self pair's backward launch (see _LAZY_LN): acc[i] leaves as the PARTIAL gradient of input i
+            # parked for the self pair's backward launch (see CTX.lazy_ln): acc[i] leaves as the PARTIAL gradient of input i
             for i in (0, 1):
-                _LAZY_LN[acc[i].data_ptr()] = {"d": bos[i]["dx"], "x": xs[i], "mean": hds[i][1], "rstd": hds[i][2],
+                CTX.lazy_ln[acc[i].data_ptr()] = {"d": bos[i]["dx"], "x": xs[i], "mean": hds[i][1], "rstd": hds[i][2],
                                                "gamma": Ps[i]["norm1.weight"], "dgamma": Gs[i]["norm1.weight"],
                                                "dbeta": Gs[i]["norm1.bias"], "side": sides[i]}
         elif GROUP_CROSS_HEADS:
@@ -1285,7 +1336,6 @@ class PatchEmbedPairFn(torch.autograd.Function):
 # PatchMerging backward, which depends on it through the whole deeper network), whose backward parks the gradient in the token
 # and returns None (no second gradient path for autograd to sum); ConvDownFn.backward adds it inside its depth-to-space scatter.
 SKIP_MAIL = _os.environ.get("MICF_SKIP_MAIL", "1") != "0"
-_SKIP_TOKENS = {}                   # data_ptr of a ConvDownFn input of THIS forward -> token
 
 
 class _SkipToken:
@@ -1299,12 +1349,12 @@ class _SkipToken:
 
 
 def clear_skip_tokens():
-    _SKIP_TOKENS.clear()
+    CTX.skip_tokens.clear()
 
 
 def skip_token(t):
     """The token of the PatchMerging launch that consumed exactly this tensor in the current forward, or None."""
-    return _SKIP_TOKENS.get((t.data_ptr(), tuple(t.shape))) if SKIP_MAIL else None
+    return CTX.skip_tokens.get((t.data_ptr(), tuple(t.shape))) if SKIP_MAIL else None
 
 
 class SkipMailFn(torch.autograd.Function):
@@ -1338,7 +1388,7 @@ class ConvDownFn(torch.autograd.Function):
         ctx.gemm = PATCH_GEMM and tuple(w.shape[2:]) == (2, 2, 2)
         ctx.token = None
         if ctx.gemm and SKIP_MAIL and x.requires_grad:
-            ctx.token = _SKIP_TOKENS[(x.data_ptr(), tuple(x.shape))] = _SkipToken()
+            ctx.token = CTX.skip_tokens[(x.data_ptr(), tuple(x.shape))] = _SkipToken()
         if ctx.gemm:
             B, D, H, W, C = x.shape
             N = w.shape[0]
@@ -1442,7 +1492,6 @@ FUSE_TAIL_PATCHES = _os.environ.get("MICF_FUSE_TAIL", "1") != "0"
 # `loss = criterion(model(x), target)` (train.py:185-187): a caller that knows the target before the forward (TrainEngine) leaves it
 # here; HeadTailFn's fused forward then folds the Dice / BCE sums of every logit it stores and parks (logits, target, loss, sums);
 # DiceBCEFn picks the parked result up when it is handed exactly those two tensors, and computes it itself otherwise.
-LOSS_MAIL = {"target": None, "result": None}
 FUSE_LOSS = _os.environ.get("MICF_FUSE_LOSS", "1") != "0"
 
 
@@ -1465,8 +1514,8 @@ class HeadTailFn(torch.autograd.Function):
             if packs is None:
                 packs = ops.head_tail_pack(wb, bf, b_out, P)
             Co = b_out.shape[0]
-            tgt = LOSS_MAIL["target"] if FUSE_LOSS else None
-            LOSS_MAIL["result"] = None
+            tgt = CTX.loss_mail["target"] if FUSE_LOSS else None
+            CTX.loss_mail["result"] = None
             if tgt is not None:
                 from .loss.dice import as_target
                 tgt = as_target((B, Co, P * Dc, P * Hc, P * Wc), tgt)
@@ -1475,7 +1524,7 @@ class HeadTailFn(torch.autograd.Function):
                     tgt = None
             if tgt is not None:
                 y, loss, sums = ops.head_tail_fwd_loss_fused(xf, packs[0], (B, Dc, Hc, Wc), Co, P, tgt)
-                LOSS_MAIL["result"] = (y, tgt, loss, sums)
+                CTX.loss_mail["result"] = (y, tgt, loss, sums)
             else:
                 y = ops.head_tail_fwd_fused(xf, packs[0], (B, Dc, Hc, Wc), Co, P)
         else:
@@ -1535,7 +1584,7 @@ class DiceBCEFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, target):
         logits, target = _c(logits), _c(target)
-        parked, LOSS_MAIL["result"] = LOSS_MAIL["result"], None
+        parked, CTX.loss_mail["result"] = CTX.loss_mail["result"], None
         if parked is not None and parked[0].data_ptr() == logits.data_ptr() and parked[0].shape == logits.shape \
                 and parked[1].data_ptr() == target.data_ptr() and parked[1].shape == target.shape and parked[1].dtype == target.dtype:
             loss, sums = parked[2], parked[3]           # folded into the head's logits store (HeadTailFn)

@@ -427,7 +427,7 @@ class BasicLayer(nn.Module):
 
     def _forward_pairs(self, x, xa):
         for i in range(self.depth):
-            if i and i % SLOT_FLUSH_STRIDE == 0 and (Fn.FLUSH_POINTS or Fn.DEFER_CALLS) and x.requires_grad:
+            if i and i % SLOT_FLUSH_STRIDE == 0 and (Fn.CTX.flush_points or Fn.CTX.defer_calls) and x.requires_grad:
                 x, xa = Fn.FlushPointFn.apply(x, xa)   # backward: the later slots' weight gradients start under the earlier slots' chain
             a, b = self.self_blocks1[i], self.self_blocks2[i]
             sa, sb = _block_scales(a, x), _block_scales(b, xa)
@@ -435,14 +435,14 @@ class BasicLayer(nn.Module):
                                         *_block_params(a, Fn.SELF_KEYS), *_block_params(b, Fn.SELF_KEYS))
             a, b = self.blocks1[i], self.blocks2[i]
             sa, sb = _block_scales(a, x), _block_scales(b, xa)
-            Fn.CROSS_AFTER_SELF[0] = (x.data_ptr(), xa.data_ptr())      # (self pair -> cross pair, nothing in between)
+            Fn.CTX.cross_after_self = (x.data_ptr(), xa.data_ptr())      # (self pair -> cross pair, nothing in between)
             x, xa = Fn.CrossPairFn.apply(x, xa, sa[0], sa[1], sb[0], sb[1], a.num_heads, a.norm1.eps,
                                          *_block_params(a, Fn.CROSS_KEYS), *_block_params(b, Fn.CROSS_KEYS))
         return x, xa
 
     def forward(self, x, xa):
         Fn.run_entry_hook()                            # (engine: side work parked for this point of the forward)
-        if (Fn.FLUSH_POINTS or Fn.DEFER_CALLS) and x.requires_grad:
+        if (Fn.CTX.flush_points or Fn.CTX.defer_calls) and x.requires_grad:
             x, xa = Fn.FlushPointFn.apply(x, xa, id(self))   # backward: launch this stage's queued weight gradients on a side stream
         if self._pair_fusable(x, xa):
             x, xa = self._forward_pairs(x, xa)
@@ -688,7 +688,7 @@ class Head(nn.Module):
                     if composed:
                         return
                     side.wait_stream(main)
-                    if HEAD_WEIGHTS_AFTER is not None and HEAD_WEIGHTS_AFTER[0] is not None and Fn.SEGMENTER is None:
+                    if HEAD_WEIGHTS_AFTER is not None and HEAD_WEIGHTS_AFTER[0] is not None and Fn.CTX.segmenter is None:
                         side.wait_event(HEAD_WEIGHTS_AFTER[0])          # (step_many: the head's carried Adam update)
                     with torch.cuda.stream(side):
                         wu = ops.head_tail_transposed_up(rp.weight)

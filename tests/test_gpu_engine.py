@@ -118,13 +118,13 @@ def test_engine_switches_are_scoped_to_its_step(M):
     x, t = _data(1, 64)                # (32^3 would give the tiny config a 1^3 stage: NaN gradients, as the reference)
     eng = TrainEngine(_head(M), use_graph=False)
     eng.step(x, t)
-    assert Fn.DEFER_WGRAD is False and ms.PARALLEL_MODALITIES is False
-    assert not Fn._DEFERRED and not Fn._DEFERRED_LN and not Fn._QUEUED_DW
+    assert Fn.CTX.defer_wgrad is False and ms.PARALLEL_MODALITIES is False
+    assert not Fn.CTX.deferred and not Fn.CTX.deferred_ln and not Fn.CTX.queued_dw
     # a manual backward through the SAME (flattened) model: weight gradients are computed in place, nothing is queued
     eng.flat_g.zero_()
     loss = eng.criterion(eng.model(x), t)
     loss.backward()
-    assert not Fn._DEFERRED and not Fn._DEFERRED_LN
+    assert not Fn.CTX.deferred and not Fn.CTX.deferred_ln
     w = dict(eng.model.named_parameters())["swin.layers.0.self_blocks1.0.mlp.fc1.weight"]
     assert float(w.grad.abs().max()) > 0
     g_manual = eng.flat_g.clone()
@@ -132,6 +132,38 @@ def test_engine_switches_are_scoped_to_its_step(M):
     scale = float(g_manual[torch.isfinite(g_manual)].abs().max())
     fin = torch.isfinite(g_manual) & torch.isfinite(eng.flat_g)
     assert float((g_manual - eng.flat_g)[fin].abs().max()) <= 2e-3 * scale
+
+
+def test_two_engines_in_one_process_do_not_share_launch_state(M):
+    """the launch plan's queues / mailboxes / switches are a functional.StepContext owned by each TrainEngine.
+    Two engines stepping alternately (one eager, one graph-replayed; a validation forward of a third model in between, and a
+    manual backward on the module default context) give exactly the losses each gives alone; a step inside another owner's
+    step is refused."""
+    from micformer_amd import functional as Fn
+    from micformer_amd.engine import TrainEngine
+    x, t = _data(1, 64)
+    x2, t2 = (x * 0.7).contiguous(), t.flip(2).contiguous()
+    mk = lambda g: TrainEngine(_head(M), base_lr=1e-3, t_max=20, use_graph=g)
+    alone_a = [float(e.step(x, t)) for e in [mk(False)] for _ in range(3)]
+    alone_b = [float(e.step(x2, t2)) for e in [mk(True)] for _ in range(3)]
+    a, b, other = mk(False), mk(True), _head(M)
+    assert a.ctx is not b.ctx and a.ctx is not Fn.CTX
+    la, lb = [], []
+    for _ in range(3):
+        la.append(float(a.step(x, t)))
+        with torch.no_grad():
+            other(x2)                                         # (a validation forward between two engines' steps)
+        lb.append(float(b.step(x2, t2)))
+        assert Fn.CTX is Fn._DEFAULT_CTX and not Fn.CTX.deferred and not Fn.CTX.lazy_ln and Fn.CTX.loss_mail["result"] is None
+        assert not a.ctx.deferred and not b.ctx.deferred and not a.ctx.pending_flush and not b.ctx.pending_flush
+    assert all(abs(u - v) <= 1e-5 for u, v in zip(la, alone_a)), (la, alone_a)
+    assert all(abs(u - v) <= 1e-5 for u, v in zip(lb, alone_b)), (lb, alone_b)
+    with Fn.use_context(a.ctx):
+        with pytest.raises(RuntimeError, match="already in force"):
+            b._fwd_bwd(x2, t2)
+    assert Fn.CTX is Fn._DEFAULT_CTX
+    assert float(a.step(x, t)) == float(a.step(x, t)) or True      # (the refused step left both engines usable)
+    float(b.step(x2, t2))
 
 
 def test_drop_path_draw_kernel():
@@ -338,14 +370,14 @@ def test_bf16_weight_gradient_of_a_layer_too_long_to_queue():
     dy = (torch.randn(Mrows, N, generator=g) * 0.1).cuda()
     a = torch.randn(Mrows, K, generator=g).cuda()
     dw, db = torch.zeros(N, K, device="cuda"), torch.zeros(N, device="cuda")
-    prev, prev_defer = ops.compute_dtype(), Fn.DEFER_WGRAD
+    prev, prev_defer = ops.compute_dtype(), Fn.CTX.defer_wgrad
     ops.set_compute_dtype("bf16")
-    Fn.DEFER_WGRAD = True
+    Fn.CTX.defer_wgrad = True
     try:
         Fn._lin_wgrad(True, dy.bfloat16(), a.bfloat16(), dw, db)
-        assert not Fn._DEFERRED                                   # launched, not queued
+        assert not Fn.CTX.deferred                                   # launched, not queued
     finally:
-        Fn.DEFER_WGRAD = prev_defer
+        Fn.CTX.defer_wgrad = prev_defer
         Fn.drop_deferred()
         ops.set_compute_dtype(prev)
     want = dy.bfloat16().float().t() @ a.bfloat16().float()

@@ -102,7 +102,7 @@ def test_fp8_operands_saturate_instead_of_overflowing(ops, dims, C, heads):
     ops.set_compute_dtype("bf16+fp8attn")
     o8 = ops.window_attn_fwd(q, kv, dims, heads, (2, 2, 2), scale)
     assert bool(torch.isfinite(o8).all())
-    assert float(o8.abs().max()) <= 448.0 * 1.001
+    assert float(o8.abs().max()) <= 448.0 * 1.07            # (the e4m3-rounded softmax weights of a row sum to 1 +- 2^-4)
     # (saturated scores make the softmax one-hot: an e4m3 rounding flip of one q / k element can move the arg-max, so the output is
     #  compared with the saturating restatement statistically, not element by element)
     want = ref_attention_fp8(q, kv, dims, heads, scale)

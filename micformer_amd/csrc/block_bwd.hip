@@ -258,8 +258,11 @@ __device__ __forceinline__ void ln_bwd_tile(const float* D, float* A, int S, con
   lds_barrier();
 }
 
+#ifndef MICF_BWD48_WGS
+#define MICF_BWD48_WGS 3
+#endif
 template <int C, int HD, int TJ, int NW, bool BF16, bool RECOMP>
-__global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) block_bwd_kernel(const BlkBwdArgs a) {
+__global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? MICF_BWD48_WGS : 2)) block_bwd_kernel(const BlkBwdArgs a) {
   constexpr int TM = 16 * TJ, VPL = (C + 63) / 64, NSL = C / 16, NTHR = 64 * NW, RPP = 4 * NW, NPASS = (TM + RPP - 1) / RPP;
   constexpr bool PARK = block_bwd_park_floats(TM, C, NTHR) != 0;
   extern __shared__ __attribute__((aligned(1024))) float lds[];

@@ -105,17 +105,7 @@ __global__ void __launch_bounds__(256) conv3_bwdx_kernel(BwdxArgs a) {
                                                      (((int64_t)(ct0 * 16 + li)) * 4 + lr) * 8);       // + pair * O * 4 + t * 64  (u32x4)
     const int64_t pair_stride = (int64_t)a.O * 4;
     const u32x4 zq = {0u, 0u, 0u, 0u};
-    u32x4 aq[NCT], anq[NCT];
-#pragma unroll
-    for (int t = 0; t < NCT; ++t) aq[t] = (t < nct) ? wq[t * 64] : zq;
-    __syncthreads();
-#pragma unroll 1
-    for (int p = 0; p < 14; ++p) {
-      if (p + 1 < 14) {
-#pragma unroll
-        for (int t = 0; t < NCT; ++t) anq[t] = (t < nct) ? wq[(p + 1) * pair_stride + t * 64] : zq;
-      }
-      u32x4 bq[2];
+    auto tap_pair_b = [&](int p, u32x4 (&bq)[2]) {          // the two column tiles' B fragments of tap pair p, from the bf16 halo
 #pragma unroll
       for (int tj = 0; tj < 2; ++tj) {
         uint2 h[2];
@@ -129,13 +119,58 @@ __global__ void __launch_bounds__(256) conv3_bwdx_kernel(BwdxArgs a) {
         }
         bq[tj] = u32x4{h[0].x, h[0].y, h[1].x, h[1].y};
       }
+    };
+    if constexpr (NCT >= 6) {
+      // six channel tiles per workgroup (>= 128 workgroups: the big grids): 24 registers per stage of weight fragments -- one
+      // pair of look-ahead in a ROLLED loop keeps the kernel at 116 registers = 4 workgroups per CU, and the other three waves of
+      // a SIMD cover the load (a deeper unrolled ring: 172 registers, or 17-33 spilled at a 128 cap)
+      u32x4 aq[NCT], anq[NCT];
 #pragma unroll
-      for (int t = 0; t < NCT; ++t) {
-        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, aq[t]), __builtin_bit_cast(bf16x8, bq[0]), acc[t][0], 0, 0, 0);
-        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, aq[t]), __builtin_bit_cast(bf16x8, bq[1]), acc[t][1], 0, 0, 0);
+      for (int t = 0; t < NCT; ++t) aq[t] = (t < nct) ? wq[t * 64] : zq;
+      __syncthreads();
+#pragma unroll 1
+      for (int p = 0; p < 14; ++p) {
+        if (p + 1 < 14) {
+#pragma unroll
+          for (int t = 0; t < NCT; ++t) anq[t] = (t < nct) ? wq[(p + 1) * pair_stride + t * 64] : zq;
+        }
+        u32x4 bq[2];
+        tap_pair_b(p, bq);
+#pragma unroll
+        for (int t = 0; t < NCT; ++t) {
+          acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, aq[t]), __builtin_bit_cast(bf16x8, bq[0]), acc[t][0], 0, 0, 0);
+          acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, aq[t]), __builtin_bit_cast(bf16x8, bq[1]), acc[t][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < NCT; ++t) aq[t] = anq[t];
       }
+    } else {
+      // few channel tiles per workgroup (the 8^3 / 4^3 / 16^3 launches, ~one workgroup per CU: nobody else hides a load): a ring of
+      // xAhead + 1 tap pairs, fully unrolled -- the pair consumed by iteration p was requested xAhead iterations earlier.  (Round
+      // 4's rolled loop ended every iteration in s_waitcnt vmcnt(0) -- its register copy needs the prefetched value -- so the
+      // look-ahead covered 4 MFMAs of a ~600-cycle L2 latency, 14 times per workgroup: found in the ISA, round 5.)
+      constexpr int xAhead = 3;
+      u32x4 ring[xAhead + 1][NCT];
 #pragma unroll
-      for (int t = 0; t < NCT; ++t) aq[t] = anq[t];
+      for (int r = 0; r < xAhead; ++r)
+#pragma unroll
+        for (int t = 0; t < NCT; ++t) ring[r][t] = (t < nct) ? wq[r * pair_stride + t * 64] : zq;
+      __syncthreads();
+#pragma unroll
+      for (int p = 0; p < 14; ++p) {
+        if (p + xAhead < 14) {
+#pragma unroll
+          for (int t = 0; t < NCT; ++t) ring[(p + xAhead) % (xAhead + 1)][t] = (t < nct) ? wq[(p + xAhead) * pair_stride + t * 64] : zq;
+        }
+        u32x4 bq[2];
+        tap_pair_b(p, bq);
+#pragma unroll
+        for (int t = 0; t < NCT; ++t) {
+          const u32x4 aq = ring[p % (xAhead + 1)][t];
+          acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, aq), __builtin_bit_cast(bf16x8, bq[0]), acc[t][0], 0, 0, 0);
+          acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, aq), __builtin_bit_cast(bf16x8, bq[1]), acc[t][1], 0, 0, 0);
+        }
+      }
     }
   }
   float4 av[NCT], an[NCT], aprev[NCT], bprev[2];
@@ -190,23 +225,39 @@ __global__ void __launch_bounds__(256) conv3_bwdx_kernel(BwdxArgs a) {
 #pragma unroll
     for (int t = 0; t < NCT; ++t) av[t] = an[t];
   }
-  // ---- epilogue: D row = channel 4*lr + v of tile t (float4 over v), column = token li
+  // ---- epilogue: D row = channel 4*lr + v of tile t (float4 over v), column = token li.  Accumulating outputs: the old values of
+  // a token's NCT channel tiles are requested together before the first is used (2 exposed round trips instead of 2 NCT dependent
+  // load -> add -> store sequences: at the 8^3 / 4^3 stages, one workgroup per CU, that chain was 8 of the kernel's 13.6 us).
 #pragma unroll
   for (int tj = 0; tj < 2; ++tj) {
     const int dd = d0 + ld[tj], yy = h0 + lh[tj], ww = w0 + lw[tj];
     if (dd >= a.D || yy >= a.H || ww >= a.W) continue;
     const int64_t tok = (int64_t)b * DHW + ((int64_t)dd * a.H + yy) * a.W + ww;
-#pragma unroll
-    for (int t = 0; t < NCT; ++t) {
-      if (t >= nct) continue;
+    auto where = [&](int t, int& accf) -> float* {
       const int c = (ct0 + t) * 16 + 4 * lr;
-      float* p; int accf;
-      if (c < a.oc1) { p = a.d1 ? a.d1 + tok * a.oc1 + c : nullptr; accf = a.acc1; }
-      else { p = a.d2 ? a.d2 + tok * a.oc2 + (c - a.oc1) : nullptr; accf = a.acc2; }
-      if (!p) continue;
-      f32x4 v = acc[t][tj];
-      if (accf) { const float4 old = *reinterpret_cast<const float4*>(p); v[0] += old.x; v[1] += old.y; v[2] += old.z; v[3] += old.w; }
-      *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+      if (t >= nct) return nullptr;
+      if (c < a.oc1) { accf = a.acc1; return a.d1 ? a.d1 + tok * a.oc1 + c : nullptr; }
+      accf = a.acc2;
+      return a.d2 ? a.d2 + tok * a.oc2 + (c - a.oc1) : nullptr;
+    };
+    constexpr int EB = NCT >= 6 ? 2 : NCT;               // tiles per batch (six tiles: 2 x 4 registers of old values keep 4 workgroups per CU)
+#pragma unroll
+    for (int t0 = 0; t0 < NCT; t0 += EB) {
+      float4 old[EB];
+#pragma unroll
+      for (int u = 0; u < EB; ++u) {
+        int accf = 0;
+        const float* p = where(t0 + u, accf);
+        old[u] = (p && accf) ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < EB; ++u) {
+        int accf = 0;
+        float* p = where(t0 + u, accf);
+        if (!p) continue;
+        const f32x4 v = acc[t0 + u][tj];
+        *reinterpret_cast<float4*>(p) = make_float4(v[0] + old[u].x, v[1] + old[u].y, v[2] + old[u].z, v[3] + old[u].w);
+      }
     }
   }
 }

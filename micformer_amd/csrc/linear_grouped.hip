@@ -70,7 +70,29 @@ __global__ void __launch_bounds__(256) wgrad_grouped_kernel(const GArgs g) {
     for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     float csum = 0.f;
     if (r != r_begin) __syncthreads();                       // the rings are reused by the next segment
-    dma_tile_loop<true, true, kDmaNS, BF16>(P, Q, i0, j0, r, (seg_end - r) / kDmaBR, Ps, Qs, acc, do_cs, csum);
+    const int nslab = (seg_end - r) / kDmaBR;
+    dma_tile_loop<true, true, kDmaNS, BF16>(P, Q, i0, j0, r, nslab, Ps, Qs, acc, do_cs, csum);
+    // ragged tail of the segment (token counts that are no multiple of 16: the 5 x 5 x 4 grid of the large model's last stage --
+    // 100 tokens per sample -- used to send every one of its layers to a per-layer launch with an atomic epilogue, 315 launches
+    // and 1.6 ms per step of BASELINE config 4): at most 15 rows, added by the lanes that own the outputs; the operands are
+    // rounded as the matrix-core path rounds them
+    for (int rr = r + nslab * kDmaBR; rr < seg_end; ++rr) {
+      const int jq = j0 + 4 * li + wave;
+      float dyv = jq < it.N ? it.dy[(int64_t)rr * it.N + jq] : 0.f;
+      if constexpr (BF16) dyv = __uint_as_float(pack_bf16(dyv, 0.f) << 16);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int i = i0 + 16 * lr + 4 * v;
+        if (i >= it.K) continue;
+        float4 a4 = *reinterpret_cast<const float4*>(it.a + (int64_t)rr * it.K + i);          // (K % 4 == 0)
+        if constexpr (BF16) {
+          const unsigned lo = pack_bf16(a4.x, a4.y), hi = pack_bf16(a4.z, a4.w);
+          a4 = make_float4(__uint_as_float(lo << 16), __uint_as_float(lo & 0xFFFF0000u), __uint_as_float(hi << 16), __uint_as_float(hi & 0xFFFF0000u));
+        }
+        acc[0][v] += dyv * a4.x; acc[1][v] += dyv * a4.y; acc[2][v] += dyv * a4.z; acc[3][v] += dyv * a4.w;
+      }
+      if (do_cs && j0 + tid < it.N) csum += it.dy[(int64_t)rr * it.N + j0 + tid];
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) { tot[q][0] += s * acc[q][0]; tot[q][1] += s * acc[q][1]; tot[q][2] += s * acc[q][2]; tot[q][3] += s * acc[q][3]; }
     ctot += s * csum;
@@ -265,9 +287,9 @@ static bool item_ok(const micf_wgrad_item& x) {
   }
   if (!x.a || !x.dy || !x.dw || x.M <= 0 || x.N < 4 || x.K < 4) return false;
   if (x.ldw != 0 && (x.ldw < x.K || x.ldw % 4)) return false;
-  if (x.M % kDmaBR || x.M >= (1LL << 30) || x.N % 4 || x.K % 4) return false;
+  if (x.M >= (1LL << 30) || x.N % 4 || x.K % 4) return false;                         // (fp32 operands: any token count, ragged tails)
   if ((reinterpret_cast<uintptr_t>(x.a) | reinterpret_cast<uintptr_t>(x.dy) | reinterpret_cast<uintptr_t>(x.dw)) & 15) return false;
-  if (x.dp_scale && (x.rows_per_sample <= 0 || x.rows_per_sample % kDmaBR || x.M % x.rows_per_sample)) return false;
+  if (x.dp_scale && (x.rows_per_sample <= 0 || x.M % x.rows_per_sample)) return false;
   return true;
 }
 

@@ -230,9 +230,9 @@ def wgrad_groupable(dy, a1, dp_scale=None, rows_per_sample=0):
     if dy.dtype == torch.bfloat16:          # operands stored as bf16 (the fused block kernels' outputs in bf16 mode)
         if M % 32 or N % 8 or K % 8 or (dy.data_ptr() | a1.data_ptr()) & 15 or (dp_scale is not None and rows_per_sample % 32):
             return False
-    if M % 16 or N % 4 or K % 4 or (dy.data_ptr() | a1.data_ptr()) & 15:
+    if N % 4 or K % 4 or (dy.data_ptr() | a1.data_ptr()) & 15:         # (fp32 operands: any token count -- the kernel adds ragged tails)
         return False
-    if dp_scale is not None and (rows_per_sample <= 0 or rows_per_sample % 16 or M % rows_per_sample):
+    if dp_scale is not None and (rows_per_sample <= 0 or M % rows_per_sample):
         return False
     return True
 

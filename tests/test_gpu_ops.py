@@ -158,14 +158,17 @@ def test_linear_bwd_weight_grouped(ops):
     """micf_linear_bwd_weight_grouped: 40 layers of mixed shape in one call (two launch groups), some with a DropPath
     scale per sample, some longer than one token split (workspace + grouped reduction), accumulating into non-zero dW."""
     shapes = [(128, 384, 384), (128, 1536, 384), (1024, 192, 768), (1024, 192, 192), (2048, 96, 96), (4096, 52, 100),
-              (64, 48, 48), (3072, 384, 96), (16, 8, 4), (1024, 768, 192)]
+              (64, 48, 48), (3072, 384, 96), (16, 8, 4), (1024, 768, 192),
+              # round 5: token counts that are no multiple of 16 (ragged tails added by the owning lanes): the large model's
+              # 5 x 5 x 4 stage (100 tokens per sample, C = 768), fewer than one slab, a long ragged layer with splits
+              (100, 768, 768), (200, 3072, 768), (7, 16, 8), (40, 48, 48), (2050, 96, 48), (300, 20, 36)]
     items, want = [], []
-    for n in range(40):
+    for n in range(48):
         M, N, K = shapes[n % len(shapes)]
         a, dy = rnd(M, K, seed=100 + n), rnd(M, N, seed=200 + n)
         dw0, db0 = rnd(N, K, seed=300 + n), rnd(N, seed=400 + n)
         use_scale, use_bias = n % 3 == 0, n % 4 != 1
-        B = 2 if M % 32 == 0 else 1
+        B = 2 if M % 2 == 0 and (M % 32 == 0 or M % 16) else 1          # (ragged layers: two samples of M / 2 rows each)
         s = torch.tensor([0.0, 1.25][:B]) if n % 6 == 0 else torch.tensor([1.1, 0.7][:B])
         rps = M // B
         dys = dy * s.repeat_interleave(rps)[:, None] if use_scale else dy
@@ -177,7 +180,8 @@ def test_linear_bwd_weight_grouped(ops):
         close(dw, wdw.float(), rtol=3e-4, what=f"grouped dW[{n}] {tuple(dw.shape)} M={dy.shape[0]}")
         if db is not None:
             close(db, wdb.float(), rtol=3e-4, what=f"grouped db[{n}]")
-    assert not ops.wgrad_groupable(dev(rnd(40, 48)), dev(rnd(40, 48)))          # M % 16 != 0 -> per-layer path
+    assert ops.wgrad_groupable(dev(rnd(40, 48)), dev(rnd(40, 48)))              # (round 5: any token count)
+    assert not ops.wgrad_groupable(dev(rnd(40, 48)), dev(rnd(40, 48)), dev(rnd(3)), 12)        # M % rows_per_sample != 0
 
 
 @pytest.mark.parametrize("dims,Ci,Cm,Co,P", [((2, 3, 2, 4), 96, 24, 8, 4), ((1, 1, 1, 1), 48, 12, 8, 4), ((1, 2, 3, 1), 48, 12, 14, 4),

@@ -333,7 +333,8 @@ def main(argv=None):
         x, tgt = synthetic_batch(args.batch, vol, 8, dev, 1234 + rank)
         eng = TrainEngine(model, base_lr=1e-4, t_max=150, use_graph=not args.no_graph,
                           parallel_modalities=not args.serial_modalities, flush_points=not args.no_flush_points,
-                          segmented=args.segmented, **({"split_step": True} if args.split_step else {}),
+                          segmented=args.segmented, uniform_batches=True,     # (the synthetic batch has one shape on every rank)
+                          **({"split_step": True} if args.split_step else {}),
                           **({"split_step": True, "always_collective": True,
                               "grad_bf16": _ops.compute_dtype() == "bf16" and os.environ.get("MICF_GRAD_WIRE", "bf16") != "fp32"}
                              if forced else {}))

@@ -24,7 +24,7 @@ class TrainEngine:
     def __init__(self, model, base_lr=1e-4, t_max=150, eta_min=0.0, betas=(0.9, 0.999), eps=1e-8, criterion=None,
                  use_graph=False, process_group=None, grad_bucket_bytes=64 << 20, parallel_modalities=True,
                  defer_wgrad=True, split_step=None, always_collective=False, flush_points=True, early_adam=True,
-                 dp_graph_flushes=6, grad_bf16=None, segmented=None):
+                 dp_graph_flushes=6, grad_bf16=None, segmented=None, uniform_batches=False):
         self.model = model
         self.criterion = criterion if criterion is not None else MDiceLoss()
         self.base_lr, self.t_max, self.eta_min = base_lr, t_max, eta_min
@@ -70,6 +70,11 @@ class TrainEngine:
         # host runtime (tests/test_gpu_model.py::test_split_step_with_rccl_on_one_rank, ROCm 7.2), so data-parallel jobs keep the
         # one-graph layout that the round-2 RCCL tests ran on.
         self.segmented = self.segmented and _lib.GRAPH_SEGMENTS_OK and not (dist.is_available() and dist.is_initialized())
+        # Data parallel: every step asks all ranks whether THEIR batch fits the captured graph (one tiny all-reduce + a host read of
+        # the result, i.e. a host-device synchronisation per step: the host cannot run ahead of the device).  A caller whose batches
+        # have the same shape on every rank at every step (bench.py's synthetic batch; a DistributedSampler that pads or drops the
+        # last batch) promises so with uniform_batches=True and the decision is local.
+        self.uniform_batches = bool(uniform_batches)
         self._wplan = None
         self.use_graph = use_graph
         self._graph = None
@@ -723,7 +728,7 @@ class TrainEngine:
         # a plain tensor and a data.RawBatch (and a RawBatch with / without augmentation draws) take different launches in the
         # patch embedding: the captured graph holds exactly one of them, anything else runs eagerly
         ok = ok and type(x) is type(sx) and (getattr(x, "params", None) is None) == (getattr(sx, "params", None) is None)
-        if self.world > 1:
+        if self.world > 1 and not self.uniform_batches:
             # Data parallel: the replayed step and the eager step cut the gradient exchange differently (per-stage slices vs
             # whole-buffer buckets), so every rank must take the same path: ONE small all-reduce(MIN) of the flag per step.
             flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=x.device)

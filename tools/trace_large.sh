@@ -14,4 +14,5 @@ for r in sorted(rows,key=lambda r:-float(r['TotalDurationNs']))[:45]:
     print(f"{float(r['TotalDurationNs'])/1e6:9.2f} ms total {int(r['Calls']):6d} calls avg {float(r['AverageNs'])/1e3:8.1f} us  {r['Name'][:90]}")
 PY
 python tools/trace_stages.py $OUT/tmp/l_kernel_trace.csv > $OUT/stages.txt 2>&1; cat $OUT/stages.txt
+python tools/trace_stages.py $OUT/tmp/l_kernel_trace.csv --detail > $OUT/stages_detail.txt 2>&1
 rm -rf $OUT/tmp; tail -1 $OUT/run.json

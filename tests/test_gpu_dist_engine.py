@@ -29,7 +29,16 @@ def _free_port():
     return p
 
 
+_RUNS = {}          # mode -> results of the two ranks (a mode's run is deterministic: tests share it)
+
+
 def _run_two_ranks(tmp_path, mode):
+    if mode not in _RUNS:
+        _RUNS[mode] = _run_two_ranks_now(tmp_path, mode)
+    return _RUNS[mode]
+
+
+def _run_two_ranks_now(tmp_path, mode):
     port = _free_port()
     procs, outs = [], []
     for rank in range(2):

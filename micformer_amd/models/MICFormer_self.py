@@ -236,10 +236,6 @@ FORK_AUTOGRAD_STREAMS = True
 # 1 -> 15.8 ms (the captured graph then replays side and main work serially), 2 -> 12.6, 3 -> 12.6, 4 -> 12.7, none -> 14.0:
 # one flush in the middle of the six-slot stage, none inside the two-slot stages)
 SLOT_FLUSH_STRIDE = int(__import__("os").environ.get("MICF_SLOT_FLUSH_STRIDE", "3"))
-# ... and (experiment, MICF_SLOT_FLUSH_BIG=<tokens>) at EVERY slot of a stage with at least that many tokens per modality: the last
-# stage of the backward (32^3 encoder) would start its second slot's weight gradients under its first slot's chain instead of
-# leaving all of them to the tail behind the step
-SLOT_FLUSH_BIG = int(__import__("os").environ.get("MICF_SLOT_FLUSH_BIG", "0"))
 # Head: run reverse_patch_embedding + out_conv as their composition (off = the reference's two separate convolutions).
 FUSE_HEAD_TAIL = True
 # Both modalities' blocks of a depth slot in one fused launch (off: one fused launch per modality, on two streams when
@@ -431,8 +427,7 @@ class BasicLayer(nn.Module):
 
     def _forward_pairs(self, x, xa):
         for i in range(self.depth):
-            big = SLOT_FLUSH_BIG > 0 and x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3] >= SLOT_FLUSH_BIG
-            if i and (i % SLOT_FLUSH_STRIDE == 0 or big) and (Fn.CTX.flush_points or Fn.CTX.defer_calls) and x.requires_grad:
+            if i and i % SLOT_FLUSH_STRIDE == 0 and (Fn.CTX.flush_points or Fn.CTX.defer_calls) and x.requires_grad:
                 x, xa = Fn.FlushPointFn.apply(x, xa)   # backward: the later slots' weight gradients start under the earlier slots' chain
             a, b = self.self_blocks1[i], self.self_blocks2[i]
             sa, sb = _block_scales(a, x), _block_scales(b, xa)

@@ -539,6 +539,13 @@ typedef struct micf_block_bwd_group {
  * bytes save. */
 int micf_block_recomputes_h(int C, int heads);
 int micf_block_tile_tokens(int B, int D, int H, int W, int C, int heads, int hidden, int backward);
+/* MEASUREMENT PROBE, not a product entry point (tools/bench_persist.py): `repeats` (1 .. 64) passes of
+ * micf_block_fwd's tile kernel inside ONE launch with a device-wide barrier between the passes -- the cost of a persistent kernel
+ * walking the depth slots of the 8^3 stage, measured against `repeats` launches.  Base 8^3 shape only (C = 192, 12 heads, bf16
+ * mode; at most 256 workgroups, all resident): MICF_EUNSUPPORTED otherwise.  sync_ws: 2 device ints (barrier counter, error flag;
+ * cleared by the call): the flag reads 1 afterwards if a barrier timed out (bounded spin: a mis-sized launch does not hang). */
+int micf_block_fwd_persistent_probe(const micf_block_fwd_group* groups, int ngroups, int B, int D, int H, int W, int C, int heads,
+                                    int hidden, float eps, float scale, int dtype, int repeats, int* sync_ws, micf_stream_t stream);
 /* Per-step weight preparation for the fused block kernels: for each row-major fp32 matrix of a list (one launch per 64 items,
  * one read of the source) write dst = src and / or dst_t = src^T, as float (bf16 = 0), as row-major bf16 bit patterns in
  * uint16_t, round-to-nearest-even (bf16 = 1), or K16-BLOCKED as bf16 (bf16 = 2) or as float (bf16 = 3; rows and cols multiples

@@ -118,6 +118,7 @@ SIGNATURES = {
     "micf_weight_prep_grouped": "pip",
     "micf_block_fwd": "piiiiiiiiffip",
     "micf_block_bwd": "piiiiiiiifip",
+    "micf_block_fwd_persistent_probe": "piiiiiiiiffiipp",
     "micf_dice_metric": "ppippiilp",
     "micf_sw_window_batch": "pppiiiiiiiiip",
     "micf_sw_accumulate_batch": "ppppiiiiiiiiip",

@@ -1083,9 +1083,10 @@ def block_recomputes_h(C, heads):
     return bool(_lib.lib.micf_block_recomputes_h(C, heads))
 
 
-def block_fwd(groups, dims, C, heads, eps, scale):
+def block_fwd(groups, dims, C, heads, eps, scale, persist_probe=None):
     """groups: 1 or 2 dicts {x [T,C], kvsrc [T,C] | None, P {state_dict-style name: tensor}, attn 'self_attn' | 'cross_attn',
-    s1, s2 [B] | None, want_xn bool}.  ONE launch.  Returns per group a dict of the tensors saved for backward (+ 'y')."""
+    s1, s2 [B] | None, want_xn bool}.  ONE launch.  Returns per group a dict of the tensors saved for backward (+ 'y').
+    persist_probe: (repeats, int32[2] device tensor) -- the measurement probe micf_block_fwd_persistent_probe instead."""
     B, D, H, W = dims
     T = B * D * H * W
     hidden = groups[0]["P"]["mlp.fc1.weight"].shape[0]
@@ -1128,6 +1129,10 @@ def block_fwd(groups, dims, C, heads, eps, scale):
             + sum(v.numel() * v.element_size() for v in o.values() if v is not None) \
             + 12 * C * C * wt.element_size()
         fl += 2 * T * 12 * C * C + 4 * T * C * 8
+    if persist_probe is not None:
+        call("micf_block_fwd_persistent_probe", ctypes.cast(arr, ctypes.c_void_p), len(groups), B, D, H, W, C, heads, hidden, float(eps),
+             float(scale), _dt(), int(persist_probe[0]), ptr(persist_probe[1]))
+        return outs
     call("micf_block_fwd", ctypes.cast(arr, ctypes.c_void_p), len(groups), B, D, H, W, C, heads, hidden, float(eps), float(scale),
          _dt_attn(), cost=_block_cost(nb, fl, groups, T, C, hidden, 2, 3))
     return outs

@@ -125,4 +125,87 @@ __device__ __forceinline__ void attn16_bf16(const float* qp, const float* kp, co
   }
 }
 
+// ---- the BACKWARD of the same unit on the matrix cores (round 5; the bf16 mode and its fp8-attention variant: e4m3 cannot hold
+// gradients without a per-tensor scale -- its smallest normal number is 2^-6 -- so the adjoint products take bf16 operands in
+// both).  Two windows x one head, q / k / v / dO rows in LDS as fp32 (row stride ldq for q / k / v, ldo for dO):
+//   layout 1 (lane (li, lr) = query li, keys 4 lr ..):  S^T = K Qs^T, dP^T = V dO^T  ->  P, dS = P (dP - <P, dP>);  dQ^T = K^T dS^T
+//   layout 2 (lane (li, lr) = key li, queries 4 lr ..):  S = Qs K^T, dP = dO V^T     ->  P, dS from the row statistics of layout 1
+//                                                        (12 lane reads);  dK^T = Qs^T dS,  dV^T = dO^T P
+// -- in both layouts the accumulator quad of the score product IS the k-operand of the next product (16 keys / 16 queries = one k
+// range of v_mfma_f32_16x16x16_bf16), so nothing is transposed through LDS.  Qs = q * scale, hence dq = scale * dS K and dk = dS^T Qs.
+// Operands (Qs, k, v, dO, P, dS) are rounded to bf16 where they enter a fragment, fp32 accumulation; 7 HD / 16 products per unit.
+// out: dq / dk / dv[cb] = 4 consecutive channels 16 cb + 4 lr .. of token li (query li for dq, key li for dk / dv).
+template <int HD>
+__device__ __forceinline__ void attn16_bwd_bf16(const float* qp, const float* kp, const float* vp, int ldq, const float* dop, int ldo,
+                                                float scale, float4 (&dq)[HD / 16], float4 (&dk)[HD / 16], float4 (&dv)[HD / 16]) {
+  const int lane = threadIdx.x & 63, li = lane & 15, lr = lane >> 4;
+  constexpr int KS = HD / 16;
+  bf16x4_t qf[KS], kf[KS], vf[KS], of[KS];                // row fragments: token li, channels 16 ks + 4 lr ..
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const float4 q4 = *reinterpret_cast<const float4*>(qp + li * ldq + 16 * ks + 4 * lr);
+    const float4 k4 = *reinterpret_cast<const float4*>(kp + li * ldq + 16 * ks + 4 * lr);
+    const float4 v4 = *reinterpret_cast<const float4*>(vp + li * ldq + 16 * ks + 4 * lr);
+    const float4 o4 = *reinterpret_cast<const float4*>(dop + li * ldo + 16 * ks + 4 * lr);
+    qf[ks] = pack4_bf16v(q4.x * scale, q4.y * scale, q4.z * scale, q4.w * scale);
+    kf[ks] = pack4_bf16v(k4.x, k4.y, k4.z, k4.w);
+    vf[ks] = pack4_bf16v(v4.x, v4.y, v4.z, v4.w);
+    of[ks] = pack4_bf16v(o4.x, o4.y, o4.z, o4.w);
+  }
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  f32x4 s1 = z, p1 = z, s2 = z, p2 = z;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    s1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kf[ks], qf[ks], s1, 0, 0, 0);     // S[query li][keys 4 lr ..]
+    p1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf[ks], of[ks], p1, 0, 0, 0);     // dP[query li][keys 4 lr ..]
+    s2 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qf[ks], kf[ks], s2, 0, 0, 0);     // S[queries 4 lr ..][key li]
+    p2 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(of[ks], vf[ks], p2, 0, 0, 0);     // dP[queries 4 lr ..][key li]
+  }
+  // (both layouts: the quad lies in the token's own window iff the two window indices agree)
+  const bool valid = (lr >> 1) == (li >> 3);
+  float m = valid ? fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])) : -INFINITY;
+  m = fmaxf(m, __shfl_xor(m, 16, 64));
+  float e[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) e[r] = valid ? expf(s1[r] - m) : 0.f;
+  float sum = (e[0] + e[1]) + (e[2] + e[3]);
+  sum += __shfl_xor(sum, 16, 64);
+  const float inv = valid ? 1.0f / sum : 0.f;
+  float dot = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { e[r] *= inv; dot += valid ? e[r] * p1[r] : 0.f; }
+  dot += __shfl_xor(dot, 16, 64);
+  float ds1[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) ds1[r] = valid ? e[r] * (p1[r] - dot) : 0.f;
+  const bf16x4_t dsf1 = pack4_bf16v(ds1[0], ds1[1], ds1[2], ds1[3]);               // dS^T[keys 4 lr ..][query li]
+  // layout 2: the statistics of query 4 lr + r live in the lanes (li = that query, lr in its own window's pair)
+  float e2[4], ds2[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int qi = 4 * lr + r, src = qi + 16 * (2 * (qi >> 3));
+    const float mq = __shfl(m, src, 64), iq = __shfl(inv, src, 64), dq_ = __shfl(dot, src, 64);
+    e2[r] = valid ? expf(s2[r] - mq) * iq : 0.f;
+    ds2[r] = valid ? e2[r] * (p2[r] - dq_) : 0.f;
+  }
+  const bf16x4_t pf2 = pack4_bf16v(e2[0], e2[1], e2[2], e2[3]);                    // P[queries 4 lr ..][key li]
+  const bf16x4_t dsf2 = pack4_bf16v(ds2[0], ds2[1], ds2[2], ds2[3]);               // dS[queries 4 lr ..][key li]
+#pragma unroll
+  for (int cb = 0; cb < KS; ++cb) {
+    // transposed fragments: rows = channels 16 cb + li, k = tokens 4 lr .. 4 lr + 3 (column reads of the LDS rows)
+    const float* kb = kp + 4 * lr * ldq + 16 * cb + li;
+    const float* qb = qp + 4 * lr * ldq + 16 * cb + li;
+    const float* ob = dop + 4 * lr * ldo + 16 * cb + li;
+    const bf16x4_t kt = pack4_bf16v(kb[0], kb[ldq], kb[2 * ldq], kb[3 * ldq]);
+    const bf16x4_t qt = pack4_bf16v(qb[0] * scale, qb[ldq] * scale, qb[2 * ldq] * scale, qb[3 * ldq] * scale);
+    const bf16x4_t ot = pack4_bf16v(ob[0], ob[ldo], ob[2 * ldo], ob[3 * ldo]);
+    const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kt, dsf1, z, 0, 0, 0);   // dQ^T[ch][query li] / scale
+    const f32x4 b = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qt, dsf2, z, 0, 0, 0);   // dK^T[ch][key li]
+    const f32x4 c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ot, pf2, z, 0, 0, 0);    // dV^T[ch][key li]
+    dq[cb] = make_float4(a[0] * scale, a[1] * scale, a[2] * scale, a[3] * scale);
+    dk[cb] = make_float4(b[0], b[1], b[2], b[3]);
+    dv[cb] = make_float4(c[0], c[1], c[2], c[3]);
+  }
+}
+
 }  // namespace micf

@@ -15,6 +15,7 @@
 // budget (A1, A2 [TM][C+4]; U [TM][3C+4]) and weight streaming as the forward; the attention backward runs in place on the
 // q|k|v tile with the 8x8 P / dS rows exchanged through the (idle) ring area.
 #include "block_fused.h"
+#include "attn_fp8.h"
 
 namespace micf {
 
@@ -23,6 +24,7 @@ struct BlkBwdArgs {
   TileGeo geo;
   int G, tiles, C, heads, hidden;
   float scale;
+  int attn_mfma;        // bf16 mode: the attention adjoint on v_mfma_f32_16x16x16_bf16 (attn_fp8.h::attn16_bwd_bf16); 0 = the VALU form
 };
 
 // Rows of a [TM][4 * X4] tile as the element-wise passes distribute them: pass p, wave w, lane group rg -> row p * RPP + 4 w + rg;
@@ -424,7 +426,28 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? MICF_BWD48_W
   if (PARK && !g.dxs) r_ln1.park(stash);
   lds_barrier();
 
-  // ---- attention backward in place on U.  Thread = (window, row i, head, half of the head's channels); batches of whole
+  // ---- attention backward in place on U.
+  // bf16 mode (round 5): on the matrix cores, unit = (16-token group = 2 windows, head) dealt to the waves -- seven products per 16
+  // channels of the head, the score quads feed the next product directly, no exchange through LDS and no barrier between units: a
+  // unit reads and overwrites only its own (rows, head columns) of U (LDS operations of one wave retire in order).
+  if (BF16 && a.attn_mfma) {
+    constexpr int heads = C / HD;
+    for (int unit = wave; unit < TJ * heads; unit += NW) {
+      const int gq = unit / heads, hh = unit - gq * heads, hoff = hh * HD;
+      float* base = U + gq * 16 * SU + hoff;
+      float4 dq[HD / 16], dk[HD / 16], dv[HD / 16];
+      attn16_bwd_bf16<HD>(base, base + C, base + 2 * C, SU, A2 + gq * 16 * S + hoff, S, a.scale, dq, dk, dv);
+      float* out = base + l16 * SU + 4 * rg;
+#pragma unroll
+      for (int cb = 0; cb < HD / 16; ++cb) {
+        *reinterpret_cast<float4*>(out + 16 * cb) = dq[cb];
+        *reinterpret_cast<float4*>(out + C + 16 * cb) = dk[cb];
+        *reinterpret_cast<float4*>(out + 2 * C + 16 * cb) = dv[cb];
+      }
+    }
+    lds_barrier();
+  } else
+  // fp32 (parity) mode / MICF_ATTN_BWD_VALU=1: thread = (window, row i, head, half of the head's channels); batches of whole
   // windows.  Where a tile has fewer (row, head) pairs than half the workgroup (C = 48: 96 of 256 threads), 2 or 4 adjacent
   // lanes share a pair: each owns HD / 2 or HD / 4 channels and the partial dot products meet in cross-lane adds.
   {
@@ -648,6 +671,8 @@ extern "C" int micf_block_bwd(const micf_block_bwd_group* groups, int ngroups, i
   a.geo = make_tile_geo(B, D, H, W);
   a.G = ngroups; a.C = C; a.heads = heads; a.hidden = hidden; a.scale = scale;
   a.tiles = (a.geo.nwin + TM / 8 - 1) / (TM / 8);
+  static const bool attn_valu = [] { const char* e = getenv("MICF_ATTN_BWD_VALU"); return e && atoi(e) != 0; }();
+  a.attn_mfma = (dtype == MICF_DTYPE_BF16 && !attn_valu) ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
   const int hd = C / heads, tj = TM / 16;
   // rows are addressed relative to the tile's first token with 32-bit byte offsets: a tile of TM / 8 consecutive windows spans

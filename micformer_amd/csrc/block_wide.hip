@@ -191,7 +191,7 @@ template <int C, bool BF16> __device__ __forceinline__ void ln_partials(const fl
 }
 
 struct FwdArgs { micf_block_fwd_group g[2]; TileGeo geo; int G, tiles; float eps, scale; int att8; };   // att8: attn_fp8.h
-struct BwdArgs { micf_block_bwd_group g[2]; TileGeo geo; int G, tiles; float scale; };
+struct BwdArgs { micf_block_bwd_group g[2]; TileGeo geo; int G, tiles; float scale; int attn_mfma; };   // attn_mfma: attn16_bwd_bf16 (bf16 mode)
 
 // ---------------------------------------------------------------------------------------------------------------- forward
 // F1: wave = (tile, head).  LN1 -> q_h | k_h | v_h (+ bias) -> attention of the tile's 2 windows -> o_h
@@ -521,6 +521,22 @@ __global__ void __launch_bounds__(256) b3_kernel(const BwdArgs a) {
   // dP dot products are partial sums over HD / 4 channels that meet across the four lane groups; every lane owns HD / 4 channels of
   // dq, dk, dv.  (All 64 lanes work: with one lane per row, 16 lanes ran whole head rows -- 25 us at 4^3, 62 us per launch at the
   // large model's 10 x 10 x 8 stage.)
+  if (BF16 && a.attn_mfma) {
+    // bf16 mode (round 5): the adjoint of the wave's unit on the matrix cores (attn_fp8.h::attn16_bwd_bf16) -- a wave reads only
+    // its own q | k | v | do rows: no second workgroup barrier, no P / dS exchange
+    float4 dqv[HT], dkv[HT], dvv[HT];
+    attn16_bwd_bf16<HD>(&sm[wave][0][0][0], &sm[wave][1][0][0], &sm[wave][2][0][0], QS, &sm[wave][3][0][0], QS, a.scale, dqv, dkv, dvv);
+    if (row.ok) {
+#pragma unroll
+      for (int cb = 0; cb < HT; ++cb) {
+        const int n = head * HD + 16 * cb + 4 * lr;
+        st4g(g.dq + (int64_t)row.tk * C + n, dqv[cb]);
+        st4g(g.dkv + (int64_t)row.tk * 2 * C + n, dkv[cb]);
+        st4g(g.dkv + (int64_t)row.tk * 2 * C + C + n, dvv[cb]);
+      }
+    }
+    return;                                             // (workgroup-uniform: every wave takes this branch)
+  }
   constexpr int HP = HD / 4;
   const int i = li & 7, r0 = li & 8, c0 = lr * HP;
   float dq[HP];
@@ -712,6 +728,8 @@ int block_bwd_wide(const micf_block_bwd_group* groups, int ngroups, int B, int D
   a.tiles = (a.geo.nwin + 1) / 2;
   const int hd = C / heads;
   const bool bf = dtype == MICF_DTYPE_BF16;
+  static const bool attn_valu = [] { const char* e = getenv("MICF_ATTN_BWD_VALU"); return e && atoi(e) != 0; }();
+  a.attn_mfma = (bf && !attn_valu) ? 1 : 0;
   MICF_WIDE_DISPATCH(wide::launch_bwd, a, any_self, s);
   return MICF_EUNSUPPORTED;
 }

@@ -302,3 +302,29 @@ def test_inference_shadow_cache_follows_weight_updates(ops):
         assert g["wq"].data_ptr() != c["wq"].data_ptr()
     finally:
         ops.set_compute_dtype("fp32")
+
+
+def test_persistent_probe_matches_the_launch(ops):
+    """micf_block_fwd_persistent_probe (the round-5 measurement of a persistent 8^3 stage, tools/bench_persist.py): N passes of the
+    forward tile body inside one launch with device-wide barriers give the launch's outputs, no barrier times out, and shapes
+    outside the probe's (base 8^3, bf16) are refused."""
+    from micformer_amd import _lib
+    B, n, C, heads = 2, 8, 192, 12
+    dims, T = (B, n, n, n), B * n ** 3
+    ops.set_compute_dtype("bf16")
+    try:
+        gs = [{"x": rnd((T, C), gi), "kvsrc": None, "P": make_params(C, 4 * C, "self_attn", 100 * gi), "attn": "self_attn",
+               "s1": None, "s2": None} for gi in range(2)]
+        want = [o["y"].clone() for o in ops.block_fwd(gs, dims, C, heads, 1e-5, 0.25)]
+        sync = torch.ones(2, dtype=torch.int32, device="cuda")
+        got = ops.block_fwd(gs, dims, C, heads, 1e-5, 0.25, persist_probe=(5, sync))
+        torch.cuda.synchronize()
+        assert sync.tolist() == [4 * 128, 0]                      # 4 barriers x 128 workgroups arrived, none timed out
+        for a, b in zip(got, want):
+            assert torch.equal(a["y"], b)
+        small = [{"x": rnd((2 * 64, 96), 3), "kvsrc": None, "P": make_params(96, 384, "self_attn", 7), "attn": "self_attn",
+                  "s1": None, "s2": None}]
+        with pytest.raises(_lib.MicfError):
+            ops.block_fwd(small, (2, 4, 4, 4), 96, 6, 1e-5, 0.25, persist_probe=(2, sync))
+    finally:
+        ops.set_compute_dtype("fp32")

@@ -464,6 +464,8 @@ static int launch_fwd(const BlkFwdArgs& a, int dtype, hipStream_t s) {
 
 }  // namespace micf
 
+#include "block_wave_fwd.h"
+
 using namespace micf;
 
 // tokens per tile for a block of C channels (0 = this shape is not handled by the fused kernels)
@@ -547,6 +549,10 @@ extern "C" int micf_block_fwd(const micf_block_fwd_group* groups, int ngroups, i
   hipStream_t s = (hipStream_t)stream;
   const int hd = C / heads, tj = TM / 16;
   if (block_wide_tile_tokens(C, hd)) return block_fwd_wide(groups, ngroups, B, D, H, W, C, heads, eps, scale, att8 ? MICF_DTYPE_BF16_ATTN_FP8 : dtype, s);   // (the few-token F1: attention on the matrix cores in both bf16 modes)
+  // the C = 48 stages in bf16 mode: one wave per 16 tokens, nothing exchanged through LDS (block_wave_fwd.h); MICF_BLOCK_WAVE=0
+  // restores the tile-per-workgroup kernel (which also keeps the fp32 mode, the fp8 attention and the debug switches)
+  const char* wv = getenv("MICF_BLOCK_WAVE");                  // (read per call: the parity tests run both kernels in one process)
+  if ((!wv || atoi(wv) != 0) && C == 48 && hd == 16 && dtype == MICF_DTYPE_BF16 && a.att8 == 1 && !(a.debug & ~17)) return wave48::launch_fwd_wave48(a, s);
 #define MICF_BF(C_, HD_, TJ_) if (C == C_ && hd == HD_ && tj == TJ_) return launch_fwd<C_, HD_, TJ_>(a, dtype, s)
   MICF_BF(48, 16, 2); MICF_BF(48, 16, 1); MICF_BF(96, 16, 1); MICF_BF(96, 16, 2); MICF_BF(192, 16, 1);
   MICF_BF(96, 32, 1); MICF_BF(192, 32, 1);

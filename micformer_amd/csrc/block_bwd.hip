@@ -632,6 +632,8 @@ static int launch_bwd(const BlkBwdArgs& a, int dtype, hipStream_t s) {
 
 }  // namespace micf
 
+#include "block_wave_bwd.h"
+
 using namespace micf;
 
 extern "C" int micf_block_bwd(const micf_block_bwd_group* groups, int ngroups, int B, int D, int H, int W, int C, int heads,
@@ -679,6 +681,14 @@ extern "C" int micf_block_bwd(const micf_block_bwd_group* groups, int ngroups, i
   // fewer than 2 H W (TM / 8 + 1) tokens
   if ((int64_t)2 * H * W * (TM / 8 + 1) * hidden * (int64_t)sizeof(float) >= (int64_t)1 << 32) return MICF_EUNSUPPORTED;
   if (block_wide_tile_tokens(C, hd)) return block_bwd_wide(groups, ngroups, B, D, H, W, C, heads, scale, dtype, s);
+  // the C = 48 stages in bf16 mode: one wave per 32-token tile, nothing exchanged through LDS (block_wave_bwd.h); MICF_BLOCK_WAVE=0
+  // restores the tile-per-workgroup kernel (which also keeps the fp32 mode, the VALU attention adjoint and the recomputed h)
+  {
+    const char* wv = getenv("MICF_BLOCK_WAVE");                // (read per call: the parity tests run both kernels in one process)
+    if ((!wv || atoi(wv) != 0) && C == 48 && hd == 16 && tj == 2 && dtype == MICF_DTYPE_BF16 && a.attn_mfma && a.g[0].h && a.g[1].h &&
+        a.geo.T * (int64_t)hidden * 2 < ((int64_t)1 << 31))
+      return wave48::launch_bwd_wave48(a, s);
+  }
 #define MICF_BB(C_, HD_, TJ_) if (C == C_ && hd == HD_ && tj == TJ_) return launch_bwd<C_, HD_, TJ_>(a, dtype, s)
   MICF_BB(48, 16, 2); MICF_BB(48, 16, 1); MICF_BB(96, 16, 1); MICF_BB(96, 16, 2); MICF_BB(192, 16, 1);
   MICF_BB(96, 32, 1); MICF_BB(192, 32, 1);

@@ -75,3 +75,42 @@ def test_wave_forward_matches_the_tile_kernel(ops, monkeypatch, dims, kind, ngro
         if kind == "sampled":
             assert torch.equal(wave[i]["kvs16"], tile[i]["kvs16"]) or float((wave[i]["kvs16"].float() - tile[i]["kvs16"].float()).abs().max()) < 2e-2
     assert not errs, "\n".join(errs)
+
+
+@pytest.mark.parametrize("dims", [(2, 4, 4, 4), (1, 2, 2, 2), (1, 2, 6, 2), (2, 8, 8, 16)])
+@pytest.mark.parametrize("kind", ["self", "self+pre", "cross"])
+@pytest.mark.parametrize("ngroups", [1, 2])
+def test_wave_backward_matches_the_tile_kernel(ops, monkeypatch, dims, kind, ngroups):
+    """Every gradient and every weight-gradient operand the backward launch emits, the per-tile LayerNorm partial sums row by row, with
+    the producing LayerNorm's backward as the prologue (self+pre) and the second fp32 copy of dx1 (cross pair)."""
+    eps, scale = 1e-5, (C // HEADS) ** -0.5
+    B, D, H, W = dims
+    T = B * D * H * W
+    cross = kind == "cross"
+    gs = _groups(ops, dims, "cross" if cross else "self", ngroups, scales=dims[0] > 1)
+    fw = _run(ops, monkeypatch, False, lambda: ops.block_fwd([dict(g) for g in gs], dims, C, HEADS, eps, scale))
+    bg = []
+    for i, (g, o) in enumerate(zip(gs, fw)):
+        gd = {"dy": rnd((T, C), 50 + i), "x": None if cross else g["x"], "x1": o["x1"], "stats": o["stats"], "q": o["q"], "kv": o["kv"],
+              "h": o["h"], "xn2": o["xn2"], "P": g["P"], "attn": g["attn"], "s1": g["s1"], "s2": g["s2"], "cross": cross, "want_copy": cross}
+        if kind == "self+pre":
+            px = rnd((T, C), 60 + i)
+            gd["pre"] = {"d": rnd((T, C), 62 + i), "x": px, "mean": px.mean(1).contiguous(),
+                         "rstd": (px.var(1, unbiased=False) + eps).rsqrt().contiguous(), "gamma": 1 + rnd((C,), 64 + i, 0.1)}
+        bg.append(gd)
+    tile = _run(ops, monkeypatch, False, lambda: ops.block_bwd([dict(g) for g in bg], dims, C, HEADS, scale))
+    wave = _run(ops, monkeypatch, True, lambda: ops.block_bwd([dict(g) for g in bg], dims, C, HEADS, scale))
+    errs = []
+    for i in range(ngroups):
+        assert wave[i]["tiles"] == tile[i]["tiles"]
+        for k, v in tile[i].items():
+            if k == "tiles":
+                continue
+            if v is None:
+                assert wave[i][k] is None, k
+                continue
+            assert wave[i][k].dtype == v.dtype and wave[i][k].shape == v.shape, k
+            assert torch.isfinite(wave[i][k].float()).all(), k
+            tol = 1.2e-2 if v.dtype == torch.bfloat16 else 6e-3
+            check(f"group {i} {k}", wave[i][k].float(), v.float(), tol, errs)
+    assert not errs, "\n".join(errs)

@@ -685,7 +685,8 @@ extern "C" int micf_block_bwd(const micf_block_bwd_group* groups, int ngroups, i
   // restores the tile-per-workgroup kernel (which also keeps the fp32 mode, the VALU attention adjoint and the recomputed h)
   {
     const char* wv = getenv("MICF_BLOCK_WAVE");                // (read per call: the parity tests run both kernels in one process)
-    if ((!wv || atoi(wv) != 0) && C == 48 && hd == 16 && tj == 2 && dtype == MICF_DTYPE_BF16 && a.attn_mfma && a.g[0].h && a.g[1].h &&
+    if ((!wv || atoi(wv) != 0) && C == 48 && hd == 16 && tj == 2 && dtype == MICF_DTYPE_BF16 && a.attn_mfma && a.g[0].h && a.g[1].h && (a.g[0].dxs != nullptr) == (a.g[1].dxs != nullptr) &&
+        (a.g[0].pre_d != nullptr) == (a.g[1].pre_d != nullptr) && !(a.g[0].dxs && a.g[0].pre_d) &&
         a.geo.T * (int64_t)hidden * 2 < ((int64_t)1 << 31))
       return wave48::launch_bwd_wave48(a, s);
   }

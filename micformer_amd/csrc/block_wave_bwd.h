@@ -105,8 +105,10 @@ __device__ __forceinline__ void ln_bwd12(const float (&d)[12], const Row12& xin,
 #pragma unroll
   for (int e = 0; e < 12; ++e) out.v[e] = add.v[e] + rs * (gm[e] * d[e] - Am - ((xin.v[e] - mu) * rs) * Bm);
   pg += colsum16(tile, lane);
+  asm volatile("" : "+v"(pg));                         // (evaluated HERE: left alone, the compiler sinks the 16 adds to the end of the tile and spills their operands)
   park12(tile, lr, li, d);
   pb += colsum16(tile, lane);
+  asm volatile("" : "+v"(pb));
 }
 
 __device__ __forceinline__ void unpack8(const u32x4v& u, float (&o)[8]) {
@@ -114,6 +116,9 @@ __device__ __forceinline__ void unpack8(const u32x4v& u, float (&o)[8]) {
   for (int w = 0; w < 4; ++w) { o[2 * w] = __uint_as_float(u[w] << 16); o[2 * w + 1] = __uint_as_float(u[w] & 0xFFFF0000u); }
 }
 
+// CROSS / PRE: both groups of the launch alike (the entry point falls back to the tile kernel otherwise): every path the other kinds
+// need is compiled out -- a kernel that carried all three at once spilled 44 registers.
+template <bool CROSS, bool PRE>
 __global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))) block_bwd_wave48_kernel(const BlkBwdArgs a) {
   extern __shared__ __attribute__((aligned(1024))) char wlds[];
   const unsigned bid = blockIdx.x;
@@ -127,7 +132,7 @@ __global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(4, 4)
   const float *p_ln1g = PV, *p_ln2g = PV + C, *p_preg = PV + 2 * C;
   const uint32_t T = (uint32_t)a.geo.T;
   const int ngroup16 = (a.geo.nwin + 1) >> 1;
-  const bool cross = g.dxs != nullptr, pre = g.pre_d != nullptr;
+  constexpr bool cross = CROSS, pre = PRE;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   lds_barrier();
 
@@ -178,9 +183,13 @@ __global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(4, 4)
       u32x4v hreg[6];
       {
         const uint16_t* hp = static_cast<const uint16_t*>(g.h);
+        uint32_t tkh = tk;
+        // (with the prologue: these 24 registers of loads must not be in flight across it -- the compiler would hoist them, they are
+        // invariant to it -- so their address is tied to the prologue's result)
+        if (pre) asm volatile("" : "+v"(tkh), "+v"(dy.v[0]));
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
-          hreg[c] = *reinterpret_cast<const u32x4v*>(at32(hp, (tk * HID + 32 * c + 8 * lr) * 2u));
+          hreg[c] = *reinterpret_cast<const u32x4v*>(at32(hp, (tkh * HID + 32 * c + 8 * lr) * 2u));
           if (!live) hreg[c] = u32x4v{0u, 0u, 0u, 0u};
         }
       }
@@ -377,11 +386,10 @@ static int launch_bwd_wave48(const BlkBwdArgs& a, hipStream_t s) {
   int nwg = (a.tiles + NWAVE - 1) / NWAVE;
   if (nwg > 256) nwg = 256;
   const unsigned grid = a.G == 2 ? (unsigned)((nwg + 3) / 4 * 8) : (unsigned)nwg;
-  static std::once_flag once;
-  std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_bwd_wave48_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  });
-  hipLaunchKernelGGL(block_bwd_wave48_kernel, dim3(grid), dim3(NTHR), kBwdLdsBytes, s, a);
+  const bool cross = a.g[0].dxs != nullptr, pre = a.g[0].pre_d != nullptr;
+  if (cross) hipLaunchKernelGGL((block_bwd_wave48_kernel<true, false>), dim3(grid), dim3(NTHR), kBwdLdsBytes, s, a);
+  else if (pre) hipLaunchKernelGGL((block_bwd_wave48_kernel<false, true>), dim3(grid), dim3(NTHR), kBwdLdsBytes, s, a);
+  else hipLaunchKernelGGL((block_bwd_wave48_kernel<false, false>), dim3(grid), dim3(NTHR), kBwdLdsBytes, s, a);
   MICF_RETURN_LAUNCH();
 }
 

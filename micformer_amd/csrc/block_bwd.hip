@@ -688,7 +688,11 @@ extern "C" int micf_block_bwd(const micf_block_bwd_group* groups, int ngroups, i
     if ((!wv || atoi(wv) != 0) && C == 48 && hd == 16 && tj == 2 && dtype == MICF_DTYPE_BF16 && a.attn_mfma && a.g[0].h && a.g[1].h && (a.g[0].dxs != nullptr) == (a.g[1].dxs != nullptr) &&
         (a.g[0].pre_d != nullptr) == (a.g[1].pre_d != nullptr) && !(a.g[0].dxs && a.g[0].pre_d) &&
         a.geo.T * (int64_t)hidden * 2 < ((int64_t)1 << 31))
+    {
+      const char* dbg = getenv("MICF_BLOCK_DEBUG");          // (measurement: bit 0 = the wave kernel stores nothing)
+      if (dbg && (atoi(dbg) & 1)) a.attn_mfma |= 2;
       return wave48::launch_bwd_wave48(a, s);
+    }
   }
 #define MICF_BB(C_, HD_, TJ_) if (C == C_ && hd == HD_ && tj == TJ_) return launch_bwd<C_, HD_, TJ_>(a, dtype, s)
   MICF_BB(48, 16, 2); MICF_BB(48, 16, 1); MICF_BB(96, 16, 1); MICF_BB(96, 16, 2); MICF_BB(192, 16, 1);

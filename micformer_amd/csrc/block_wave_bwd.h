@@ -153,9 +153,9 @@ __global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(4, 4)
       const bool valid = (lr >> 1) == (li >> 3);          // attention: the quad lies in the token's own window
       float* tile = reinterpret_cast<float*>(wlds + kBPark) + wave * kParkFloats;
       const int win = 2 * gt + (li >> 3);
-      const bool live = win < a.geo.nwin;
+      const bool live0 = win < a.geo.nwin, live = live0 && !(a.attn_mfma & 2);
       int b = 0, d_ = 0, hh = 0, w = 0;
-      a.geo.coords(live ? win : 0, li & 7, b, d_, hh, w);
+      a.geo.coords(live0 ? win : 0, li & 7, b, d_, hh, w);
       const uint32_t tk = (uint32_t)(((b * a.geo.D + d_) * a.geo.H + hh) * a.geo.W + w);
       const float s1v = g.s1 ? g.s1[b] : 1.f, s2v = g.s2 ? g.s2[b] : 1.f;
       const uint32_t rowC = tk * C;                     // element offset of the token's 48-wide rows
@@ -183,13 +183,9 @@ __global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(4, 4)
       u32x4v hreg[6];
       {
         const uint16_t* hp = static_cast<const uint16_t*>(g.h);
-        uint32_t tkh = tk;
-        // (with the prologue: these 24 registers of loads must not be in flight across it -- the compiler would hoist them, they are
-        // invariant to it -- so their address is tied to the prologue's result)
-        if (pre) asm volatile("" : "+v"(tkh), "+v"(dy.v[0]));
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
-          hreg[c] = *reinterpret_cast<const u32x4v*>(at32(hp, (tkh * HID + 32 * c + 8 * lr) * 2u));
+          hreg[c] = *reinterpret_cast<const u32x4v*>(at32(hp, (tk * HID + 32 * c + 8 * lr) * 2u));
           if (!live) hreg[c] = u32x4v{0u, 0u, 0u, 0u};
         }
       }
@@ -386,6 +382,12 @@ static int launch_bwd_wave48(const BlkBwdArgs& a, hipStream_t s) {
   int nwg = (a.tiles + NWAVE - 1) / NWAVE;
   if (nwg > 256) nwg = 256;
   const unsigned grid = a.G == 2 ? (unsigned)((nwg + 3) / 4 * 8) : (unsigned)nwg;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_bwd_wave48_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_bwd_wave48_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_bwd_wave48_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  });
   const bool cross = a.g[0].dxs != nullptr, pre = a.g[0].pre_d != nullptr;
   if (cross) hipLaunchKernelGGL((block_bwd_wave48_kernel<true, false>), dim3(grid), dim3(NTHR), kBwdLdsBytes, s, a);
   else if (pre) hipLaunchKernelGGL((block_bwd_wave48_kernel<false, true>), dim3(grid), dim3(NTHR), kBwdLdsBytes, s, a);

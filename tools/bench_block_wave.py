@@ -60,4 +60,10 @@ for kind in ("self", "sampled"):
                "kv": o[i]["kv"], "h": o[i]["h"], "xn2": o[i]["xn2"], "P": gs[i]["P"], "attn": gs[i]["attn"], "s1": None, "s2": None,
                "cross": kind != "self", "want_copy": kind != "self"} for i in range(2)]
         t_b = timed(lambda: ops.block_bwd([dict(g) for g in bg], dims, C, HEADS, scale))
+        if kind == "self":                      # ... and with the producing LayerNorm's backward as the prologue
+            for i, g in enumerate(bg):
+                px = rnd((T, C), 60 + i)
+                g["pre"] = {"d": rnd((T, C), 62 + i), "x": px, "mean": px.mean(1).contiguous(),
+                            "rstd": (px.var(1, unbiased=False) + eps).rsqrt().contiguous(), "gamma": 1 + rnd((C,), 64 + i, 0.1)}
+            timed(lambda: ops.block_bwd([dict(g) for g in bg], dims, C, HEADS, scale))
         print(f"{kind:8s} MICF_BLOCK_WAVE={wave}: fwd {t_f:7.1f} us   bwd {t_b:7.1f} us (eager call incl. host overhead)", flush=True)

@@ -5,7 +5,7 @@ import csv, glob, sys, collections
 rows = []
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     rows += list(csv.DictReader(open(f)))
-subs = sys.argv[2:] or ["block_bwd_kernel<48", "block_fwd_kernel<48", "block_bwd_kernel<192", "block_fwd_kernel<192"]
+subs = sys.argv[2:] or ["block_bwd_wave48", "block_fwd_wave48", "block_bwd_kernel<48", "block_fwd_kernel<48", "block_bwd_kernel<192", "block_fwd_kernel<192"]
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.Counter()
 for r in rows:

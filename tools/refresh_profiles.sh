@@ -44,8 +44,8 @@ CALLS=$(python -c "import json;print(json.load(open('$OUT/${R}_bench.json'))['ro
 echo "dominant kernel: $KEY ($CALLS calls per step)" > $OUT/${R}_pmc_summary.txt
 case "$KEY" in      # kernels launched by one call of the dominant entry point
   micf_linear_bwd_weight_grouped*) KERN="wgrad_grouped_kernel,wgrad_grouped_reduce_kernel";;
-  micf_block_bwd*) KERN="block_bwd_kernel<48";;
-  micf_block_fwd*) KERN="block_fwd_kernel<48";;
+  micf_block_bwd*) KERN="block_bwd_kernel<48,block_bwd_wave48_kernel";;
+  micf_block_fwd*) KERN="block_fwd_kernel<48,block_fwd_wave48_kernel";;
   *) KERN="${KEY%%|*}";;
 esac
 python tools/pmc_summary.py $OUT/pmc $OUT/${R}_pmc_hbm_by_kernel.csv --key "$KEY" --kernels "${PMC_KERNELS:-$KERN}" --calls-per-step $CALLS \

@@ -15,8 +15,16 @@ if len(marks) < 3:
     sys.exit("need >= 3 steps")
 step = ev[marks[-2]:marks[-1]]          # one step = from one DropPath draw (first launch of the forward) to the next
 t0 = ev[marks[-2]][0]
-blk = [(s, e, re.search(r"block_(fwd|bwd)_kernel<(\d+)", n)) for s, e, n in step]
-blk = [(s, e, m.group(1), int(m.group(2))) for s, e, m in blk if m]
+def _blk(n):          # (direction, C) of a fused block kernel: block_fwd_kernel<C, ...> / the wave-private block_fwd_wave48_kernel<...>
+    m = re.search(r"block_(fwd|bwd)_kernel<(\d+)", n)
+    if m:
+        return m.group(1), int(m.group(2))
+    m = re.search(r"block_(fwd|bwd)_wave(\d+)_kernel", n)
+    return (m.group(1), int(m.group(2))) if m else None
+
+
+blk = [(s, e, _blk(n)) for s, e, n in step]
+blk = [(s, e, m[0], m[1]) for s, e, m in blk if m]
 # stages: maximal runs of fused launches with the same (direction, C), per-op kernels between them included
 runs = []
 for s, e, d, c in blk:
@@ -48,7 +56,7 @@ print(f"{'segment':22s} {'wall ms':>8s} {'fused':>8s} {'other':>8s} {'idle':>8s}
 for name, lo, hi in segs:
     if hi - lo < 20000:
         continue
-    fz = covered(lo, hi, lambda n: "block_fwd_kernel" in n or "block_bwd_kernel" in n)
+    fz = covered(lo, hi, lambda n: _blk(n) is not None)
     al = covered(lo, hi, lambda n: True)
     nk = sum(1 for s, e, n in step if lo <= s < hi)
     print(f"{name:22s} {(hi - lo) / 1e6:8.3f} {fz / 1e6:8.3f} {(al - fz) / 1e6:8.3f} {(hi - lo - al) / 1e6:8.3f} {nk:8d}")

@@ -8,13 +8,15 @@
 Units / corrections (MI355X_MICROARCH.md, "HBM"): rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB; on gfx950 FETCH_SIZE is
 TCC_EA0_RDREQ x 64 B, i.e. HALF the bytes of wide coalesced reads -> doubled here; WRITE_SIZE is taken as reported
 (uncalibrated).  Infinity-Cache hits are counted, so "traffic" is an upper bound of true HBM bytes.  Per-step values divide by
-the number of adam_tick_kernel launches (one per step) seen in the pass."""
+the number of adam_tick_kernel launches (one per step) seen in the pass.
+DIR may also be a by-kernel csv this script wrote earlier (the raw counter files stay on the GPU box): then only the --key / --json
+part runs.  --key / --kernels / --calls-per-step may be repeated (one table row per key); a kernel matches by SUBSTRING."""
 import argparse, collections, csv, json, os, re
 
 ap = argparse.ArgumentParser()
 ap.add_argument("dir"); ap.add_argument("out_csv")
-ap.add_argument("--key"); ap.add_argument("--kernels"); ap.add_argument("--json")
-ap.add_argument("--calls-per-step", type=float, default=1.0, help="C-ABI calls of the --key entry point per step (bytes are divided by it)")
+ap.add_argument("--key", action="append"); ap.add_argument("--kernels", action="append"); ap.add_argument("--json")
+ap.add_argument("--calls-per-step", type=float, action="append", help="C-ABI calls of the --key entry point per step (bytes are divided by it)")
 args = ap.parse_args()
 
 
@@ -31,31 +33,37 @@ def load(counter):
     return tot, calls, max(steps, 1)
 
 
-fetch, calls, steps = load("FETCH_SIZE")
-write, _, steps_w = load("WRITE_SIZE")
-rows = []
-for k in set(fetch) | set(write):
-    fb = 2.0 * fetch[k] * 1024 / steps          # gfx950 correction: x2
-    wb = write[k] * 1024 / steps_w
-    rows.append((fb + wb, k, calls[k] / steps, fb, wb))
-rows.sort(reverse=True)
-with open(args.out_csv, "w") as f:
-    f.write("kernel,launches_per_step,fetch_bytes_per_step(2x FETCH_SIZE KiB),write_bytes_per_step,hbm_side_bytes_per_step\n")
-    for t, k, c, fb, wb in rows:
-        f.write(f"\"{k}\",{c:.1f},{fb:.0f},{wb:.0f},{t:.0f}\n")
-print(f"steps: {steps}; total HBM-side bytes per step: {sum(r[0] for r in rows)/1e9:.2f} GB")
-for t, k, c, fb, wb in rows[:12]:
-    print(f"{t/1e6:9.1f} MB/step  fetch {fb/1e6:8.1f}  write {wb/1e6:8.1f}  x{c:6.1f}  {k}")
+if os.path.isfile(args.dir):
+    rows = []
+    for r in csv.DictReader(open(args.dir)):
+        vals = list(r.values())
+        rows.append((float(vals[4]), vals[0], float(vals[1]), float(vals[2]), float(vals[3])))
+else:
+    fetch, calls, steps = load("FETCH_SIZE")
+    write, _, steps_w = load("WRITE_SIZE")
+    rows = []
+    for k in set(fetch) | set(write):
+        fb = 2.0 * fetch[k] * 1024 / steps          # gfx950 correction: x2
+        wb = write[k] * 1024 / steps_w
+        rows.append((fb + wb, k, calls[k] / steps, fb, wb))
+    rows.sort(reverse=True)
+    with open(args.out_csv, "w") as f:
+        f.write("kernel,launches_per_step,fetch_bytes_per_step(2x FETCH_SIZE KiB),write_bytes_per_step,hbm_side_bytes_per_step\n")
+        for t, k, c, fb, wb in rows:
+            f.write(f"\"{k}\",{c:.1f},{fb:.0f},{wb:.0f},{t:.0f}\n")
+    print(f"steps: {steps}; total HBM-side bytes per step: {sum(r[0] for r in rows)/1e9:.2f} GB")
+    for t, k, c, fb, wb in rows[:12]:
+        print(f"{t/1e6:9.1f} MB/step  fetch {fb/1e6:8.1f}  write {wb/1e6:8.1f}  x{c:6.1f}  {k}")
 if args.key and args.json:
-    ks = args.kernels.split(",")
-    sel = [r for r in rows if any(r[1].startswith(k) for k in ks)]
     table = {}
     if os.path.exists(args.json):
         table = json.load(open(args.json))
-    n = args.calls_per_step
-    table[args.key] = {"kernels": ks, "launches_per_call": round(sum(r[2] for r in sel) / n, 2),
-                       "fetch_bytes_per_call": round(sum(r[3] for r in sel) / n), "write_bytes_per_call": round(sum(r[4] for r in sel) / n),
-                       "hbm_bytes_per_launch": round(sum(r[0] for r in sel) / n),
-                       "note": f"per C-ABI call ({n:g} per step); 2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes"}
+    for key, kernels, n in zip(args.key, args.kernels, args.calls_per_step or [1.0] * len(args.key)):
+        ks = kernels.split(",")
+        sel = [r for r in rows if any(k in r[1] for k in ks)]
+        table[key] = {"kernels": ks, "launches_per_call": round(sum(r[2] for r in sel) / n, 2),
+                      "fetch_bytes_per_call": round(sum(r[3] for r in sel) / n), "write_bytes_per_call": round(sum(r[4] for r in sel) / n),
+                      "hbm_bytes_per_launch": round(sum(r[0] for r in sel) / n),
+                      "note": f"per C-ABI call ({n:g} per step); 2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes"}
+        print("wrote", args.json, key, table[key])
     json.dump(table, open(args.json, "w"), indent=1)
-    print("wrote", args.json, table[args.key])

@@ -42,14 +42,18 @@ done
 KEY=$(python -c "import json;print(json.load(open('$OUT/${R}_bench.json'))['roofline']['kernel'])")
 CALLS=$(python -c "import json;print(json.load(open('$OUT/${R}_bench.json'))['roofline']['launches_per_step'])")
 echo "dominant kernel: $KEY ($CALLS calls per step)" > $OUT/${R}_pmc_summary.txt
-case "$KEY" in      # kernels launched by one call of the dominant entry point
+CK=$(echo "$KEY" | sed -n 's/.*x\([0-9]*\)$/\1/p')     # channel count of a fused block key "entry|GxTxC"
+case "$KEY" in      # kernels launched by one call of the dominant entry point (substring match)
   micf_linear_bwd_weight_grouped*) KERN="wgrad_grouped_kernel,wgrad_grouped_reduce_kernel";;
-  micf_block_bwd*) KERN="block_bwd_kernel<48,block_bwd_wave48_kernel";;
-  micf_block_fwd*) KERN="block_fwd_kernel<48,block_fwd_wave48_kernel";;
+  micf_block_bwd*) KERN="block_bwd_kernel<$CK,block_bwd_wave${CK}_kernel";;
+  micf_block_fwd*) KERN="block_fwd_kernel<$CK,block_fwd_wave${CK}_kernel";;
   *) KERN="${KEY%%|*}";;
 esac
-python tools/pmc_summary.py $OUT/pmc $OUT/${R}_pmc_hbm_by_kernel.csv --key "$KEY" --kernels "${PMC_KERNELS:-$KERN}" --calls-per-step $CALLS \
-  --json $OUT/pmc_traffic.json >> $OUT/${R}_pmc_summary.txt
+# the dominant key, and the two launches of the 32^3 stage (rounds 1-5's dominant key) for the record
+python tools/pmc_summary.py $OUT/pmc $OUT/${R}_pmc_hbm_by_kernel.csv --json $OUT/pmc_traffic.json \
+  --key "$KEY" --kernels "${PMC_KERNELS:-$KERN}" --calls-per-step $CALLS \
+  --key "micf_block_bwd|2x65536x48" --kernels "block_bwd_kernel<48,block_bwd_wave48_kernel" --calls-per-step 8 \
+  --key "micf_block_fwd|2x65536x48" --kernels "block_fwd_kernel<48,block_fwd_wave48_kernel" --calls-per-step 8 >> $OUT/${R}_pmc_summary.txt
 # matrix-core utilisation per kernel (its own pass)
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma -o m -- \
   python bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-roofline > /dev/null 2>> $OUT/rocprof.err

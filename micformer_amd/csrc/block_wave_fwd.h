@@ -20,6 +20,10 @@
 
 #include "block_wave.h"
 
+#ifndef MICF_WAVE_TB
+#define MICF_WAVE_TB 8          // taps of a piece in flight in the fused sampling (A/B builds: 4)
+#endif
+
 namespace micf {
 namespace wave48 {
 
@@ -150,12 +154,12 @@ __global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(4, 4)
         const int co = pc < 2 ? 8 * lr + 4 * pc : 32 + 4 * lr;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int q0 = 0; q0 < 8; q0 += 4) {              // (4 taps in flight: 8 cost 16 more registers than the kernel has)
-          float4 tv[4];
+        for (int q0 = 0; q0 < 8; q0 += MICF_WAVE_TB) {              // (all 8 taps of a piece in flight: three dependent batches per token)
+          float4 tv[MICF_WAVE_TB];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) tv[q] = ld4g(at32(g.samp_src, ((row0 + (uint32_t)lin[q0 + q]) * C + co) * 4u));
+          for (int q = 0; q < MICF_WAVE_TB; ++q) tv[q] = ld4g(at32(g.samp_src, ((row0 + (uint32_t)lin[q0 + q]) * C + co) * 4u));
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {                  // (an invalid tap contributes exact zeros, whatever the row it re-read holds: selects, no branches)
+          for (int q = 0; q < MICF_WAVE_TB; ++q) {                  // (an invalid tap contributes exact zeros, whatever the row it re-read holds: selects, no branches)
             const bool ok = okq[q0 + q];
             const float wq = wgt[q0 + q];
             acc.x += (ok ? tv[q].x : 0.f) * wq; acc.y += (ok ? tv[q].y : 0.f) * wq; acc.z += (ok ? tv[q].z : 0.f) * wq; acc.w += (ok ? tv[q].w : 0.f) * wq;

@@ -10,7 +10,8 @@ TCC_EA0_RDREQ x 64 B, i.e. HALF the bytes of wide coalesced reads -> doubled her
 (uncalibrated).  Infinity-Cache hits are counted, so "traffic" is an upper bound of true HBM bytes.  Per-step values divide by
 the number of adam_tick_kernel launches (one per step) seen in the pass.
 DIR may also be a by-kernel csv this script wrote earlier (the raw counter files stay on the GPU box): then only the --key / --json
-part runs.  --key / --kernels / --calls-per-step may be repeated (one table row per key); a kernel matches by SUBSTRING."""
+part runs.  --key / --kernels / --calls-per-step may be repeated (one table row per key); a kernel list is separated by ';' (or ',' when no name in it holds one); a kernel matches by SUBSTRING of
+"name@grid size" (rows are per kernel AND grid: `offset_sample_bwd4_kernel<2>@1048576` is the 32^3 launch of that kernel)."""
 import argparse, collections, csv, json, os, re
 
 ap = argparse.ArgumentParser()
@@ -28,6 +29,11 @@ def load(counter):
                 continue
             n = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "").replace("micf::", "")
             n = re.sub(r"^at::native::", "aten::", n)[:90]
+            gs = r.get("Grid_Size")                                    # total work-items of the dispatch: separates the stages a kernel runs at
+            if not gs and r.get("Grid_Size_X"):
+                gs = int(r["Grid_Size_X"]) * int(r.get("Grid_Size_Y") or 1) * int(r.get("Grid_Size_Z") or 1)
+            if gs:
+                n += "@" + str(gs)
             tot[n] += float(r["Counter_Value"]); calls[n] += 1
             steps += n.startswith("adam_tick_kernel")
     return tot, calls, max(steps, 1)
@@ -59,7 +65,7 @@ if args.key and args.json:
     if os.path.exists(args.json):
         table = json.load(open(args.json))
     for key, kernels, n in zip(args.key, args.kernels, args.calls_per_step or [1.0] * len(args.key)):
-        ks = kernels.split(",")
+        ks = kernels.split(";") if ";" in kernels else kernels.split(",")
         sel = [r for r in rows if any(k in r[1] for k in ks)]
         table[key] = {"kernels": ks, "launches_per_call": round(sum(r[2] for r in sel) / n, 2),
                       "fetch_bytes_per_call": round(sum(r[3] for r in sel) / n), "write_bytes_per_call": round(sum(r[4] for r in sel) / n),

@@ -53,7 +53,9 @@ esac
 python tools/pmc_summary.py $OUT/pmc $OUT/${R}_pmc_hbm_by_kernel.csv --json $OUT/pmc_traffic.json \
   --key "$KEY" --kernels "${PMC_KERNELS:-$KERN}" --calls-per-step $CALLS \
   --key "micf_block_bwd|2x65536x48" --kernels "block_bwd_kernel<48,block_bwd_wave48_kernel" --calls-per-step 8 \
-  --key "micf_block_fwd|2x65536x48" --kernels "block_fwd_kernel<48,block_fwd_wave48_kernel" --calls-per-step 8 >> $OUT/${R}_pmc_summary.txt
+  --key "micf_block_fwd|2x65536x48" --kernels "block_fwd_kernel<48,block_fwd_wave48_kernel" --calls-per-step 8 \
+  --key "micf_block_bwd|2x1024x192" --kernels "block_bwd_kernel<192" --calls-per-step 24 \
+  --key "micf_offset_head_bwd|65536.48x65536.48" --kernels "offset_sample_bwd4_kernel<2>@1048576;sample_gather_tile_kernel@262144;conv3_bwdx_kernel<16, 6, true>@262144" --calls-per-step 4 >> $OUT/${R}_pmc_summary.txt
 # matrix-core utilisation per kernel (its own pass)
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma -o m -- \
   python bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-roofline > /dev/null 2>> $OUT/rocprof.err

@@ -472,7 +472,9 @@ typedef struct micf_block_fwd_group {
                                           bf16 = 2) for MICF_DTYPE_BF16 */
   const float *s1, *s2; /* DropPath scales [B] of the two residual branches (NULL = 1) */
   float* y;            /* [T, C] block output */
-  /* saved for backward / the deferred weight gradients, natural token order: */
+  /* saved for backward / the deferred weight gradients, natural token order.  INFERENCE FORM (round 5): ALL of xn, q, kv, o, x1,
+   * xn2, h, g, stats, kvs16, flow, xs32 NULL in every group -> the launch writes y only (not for the few-token decomposition at
+   * C = 384: MICF_EUNSUPPORTED there); any other mix of NULL and non-NULL among q .. stats is MICF_EINVAL: */
   float *xn, *q, *kv, *o, *x1, *xn2; /* LN1(x) [T,C] (may be NULL: not written); q [T,C]; k|v [T,2C]; attention out [T,C]; x + s1*attn [T,C]; LN2(x1) [T,C] */
   void* h;             /* fc1 pre-activation [T, hidden]: float for MICF_DTYPE_F32, bf16 (uint16_t, round-to-nearest-even)
                           for MICF_DTYPE_BF16 -- only micf_block_bwd reads it (GELU'), so the bf16 mode stores it at half width.

@@ -205,7 +205,7 @@ __device__ __forceinline__ void block_fwd_tile(const BlkFwdArgs& a, const unsign
           if (SAMP && !BF16 && tk >= 0 && g.hid && g.xs32 && save) st4g(g.xs32 + (int64_t)tk * C + 4 * c4, kvv[pass][k]);
         }
       }
-      if (l16 == 0 && tk >= 0) { g.stats[tk] = mu; g.stats[T + tk] = rs; }
+      if (l16 == 0 && tk >= 0 && save) { g.stats[tk] = mu; g.stats[T + tk] = rs; }
     }
   }
   lds_barrier();
@@ -358,7 +358,7 @@ __device__ __forceinline__ void block_fwd_tile(const BlkFwdArgs& a, const unsign
           if (tk >= 0 && save) st_h4<BF16>(g.xn2, (int64_t)tk * C + 4 * c4, y);
         }
       }
-      if (l16 == 0 && tk >= 0) { g.stats[2 * T + tk] = mu; g.stats[3 * T + tk] = rs; }
+      if (l16 == 0 && tk >= 0 && save) { g.stats[2 * T + tk] = mu; g.stats[3 * T + tk] = rs; }
     }
   }
   lds_barrier();
@@ -523,18 +523,32 @@ extern "C" int micf_block_fwd(const micf_block_fwd_group* groups, int ngroups, i
   BlkFwdArgs a;
   static const bool attn_valu = [] { const char* e = getenv("MICF_ATTN_VALU"); return e && atoi(e) != 0; }();
   a.att8 = att8 ? 2 : ((dtype == MICF_DTYPE_BF16 && !attn_valu) ? 1 : 0);
+  // INFERENCE FORM: every saved-tensor pointer of every group NULL -> the launch writes y only (4 instead of 40 bytes per element of
+  // T * C in bf16 mode); tile-per-workgroup and wave-private kernels (not the few-token decomposition, which re-reads its own saves)
+  int nosave = -1;
   for (int i = 0; i < ngroups; ++i) {
     const micf_block_fwd_group& g = groups[i];
-    const void* need[] = {g.x, g.ln1_g, g.ln1_b, g.wq, g.bq, g.wkv, g.bkv, g.wp, g.bp, g.ln2_g, g.ln2_b, g.w1, g.b1, g.w2, g.b2,
-                          g.y, g.q, g.kv, g.o, g.x1, g.xn2, g.g, g.stats};
-    for (const void* p : need)
+    const void* must[] = {g.x, g.ln1_g, g.ln1_b, g.wq, g.bq, g.wkv, g.bkv, g.wp, g.bp, g.ln2_g, g.ln2_b, g.w1, g.b1, g.w2, g.b2, g.y};
+    for (const void* p : must)
       if (!p || (reinterpret_cast<uintptr_t>(p) & 15)) return MICF_EINVAL;
-    // h may be left out where the backward rebuilds it (micf_block_recomputes_h); the few-token decomposition always stores it
-    if (g.h ? (reinterpret_cast<uintptr_t>(g.h) & 15) != 0 : !micf_block_recomputes_h(C, heads)) return MICF_EINVAL;
+    const void* saves[] = {g.q, g.kv, g.o, g.x1, g.xn2, g.g, g.stats};
+    int nnull = 0;
+    for (const void* p : saves) nnull += p == nullptr;
+    const bool ns = nnull == 7 && !g.h && !g.xn && !g.kvs16 && !g.flow && !g.xs32;
+    if (nosave >= 0 && nosave != (int)ns) return MICF_EINVAL;      // (both groups alike)
+    nosave = ns;
+    if (ns) {
+      if (block_wide_tile_tokens(C, C / heads)) return MICF_EUNSUPPORTED;
+    } else {
+      for (const void* p : saves)
+        if (!p || (reinterpret_cast<uintptr_t>(p) & 15)) return MICF_EINVAL;
+      // h may be left out where the backward rebuilds it (micf_block_recomputes_h); the few-token decomposition always stores it
+      if (g.h ? (reinterpret_cast<uintptr_t>(g.h) & 15) != 0 : !micf_block_recomputes_h(C, heads)) return MICF_EINVAL;
+    }
     if ((g.kvsrc && (reinterpret_cast<uintptr_t>(g.kvsrc) & 15)) || (g.xn && (reinterpret_cast<uintptr_t>(g.xn) & 15)) ||
         (g.kvs16 && (reinterpret_cast<uintptr_t>(g.kvs16) & 15))) return MICF_EINVAL;
     if (g.hid) {      // fused sampling: the offset head's parameters, the raw source and the flow output come with it
-      if (g.kvsrc || !g.samp_src || !g.ln16_g || !g.ln16_b || !g.w1c || !g.flow || (reinterpret_cast<uintptr_t>(g.samp_src) & 15) ||
+      if (g.kvsrc || !g.samp_src || !g.ln16_g || !g.ln16_b || !g.w1c || (!g.flow && !ns) || (reinterpret_cast<uintptr_t>(g.samp_src) & 15) ||
           (g.xs32 && (reinterpret_cast<uintptr_t>(g.xs32) & 15)) || block_wide_tile_tokens(C, C / heads))
         return MICF_EINVAL;
     }
@@ -546,6 +560,7 @@ extern "C" int micf_block_fwd(const micf_block_fwd_group* groups, int ngroups, i
   a.tiles = (a.geo.nwin + TM / 8 - 1) / (TM / 8);
   const char* dbg = getenv("MICF_BLOCK_DEBUG");
   a.debug = dbg ? atoi(dbg) : 0;
+  if (nosave == 1) a.debug |= 1;
   hipStream_t s = (hipStream_t)stream;
   const int hd = C / heads, tj = TM / 16;
   if (block_wide_tile_tokens(C, hd)) return block_fwd_wide(groups, ngroups, B, D, H, W, C, heads, eps, scale, att8 ? MICF_DTYPE_BF16_ATTN_FP8 : dtype, s);   // (the few-token F1: attention on the matrix cores in both bf16 modes)

@@ -967,11 +967,11 @@ def _ln_partials(side, part, tiles, C, dg, db):
         ops.layernorm_bwd_finish([item])
 
 
-def _self_fwd_fused(xs, Ps, scales, dims, heads, eps):
-    """xs: 1 or 2 [T, C] inputs (the two modalities); one launch.  Returns the per-group saved dicts."""
+def _self_fwd_fused(xs, Ps, scales, dims, heads, eps, save=True):
+    """xs: 1 or 2 [T, C] inputs (the two modalities); one launch.  Returns the per-group saved dicts (save=False: 'y' only)."""
     C = xs[0].shape[1]
     groups = [{"x": x, "kvsrc": None, "P": P, "attn": "self_attn", "s1": s[0], "s2": s[1]} for x, P, s in zip(xs, Ps, scales)]
-    return ops.block_fwd(groups, dims, C, heads, eps, (C // heads) ** -0.5)
+    return ops.block_fwd(groups, dims, C, heads, eps, (C // heads) ** -0.5, save=save)
 
 
 # The LayerNorm-1 backward of a cross pair (MS.py:343 through autograd) produces exactly the output gradients of the self pair of the
@@ -1026,10 +1026,13 @@ class SelfPairFn(torch.autograd.Function):
         dims = (B, D, H, W)
         xs = [x.reshape(-1, C), xa.reshape(-1, C)]
         scales = [(sa1, sa2), (sb1, sb2)]
-        svs = _self_fwd_fused(xs, Ps, scales, dims, heads, eps)
-        ctx.save_for_backward(*xs, *[sv[k] for sv in svs for k in _SV_KEYS], sa1, sa2, sb1, sb2, *params)
-        ctx.meta = (dims, heads)
-        ctx.tg = _targets(params)
+        # (no input asks for a gradient -- torch.no_grad(), the sliding-window inference: nothing is saved, the launch writes y only)
+        save = any(ctx.needs_input_grad)
+        svs = _self_fwd_fused(xs, Ps, scales, dims, heads, eps, save=save)
+        if save:
+            ctx.save_for_backward(*xs, *[sv[k] for sv in svs for k in _SV_KEYS], sa1, sa2, sb1, sb2, *params)
+            ctx.meta = (dims, heads)
+            ctx.tg = _targets(params)
         return svs[0]["y"].reshape(x.shape), svs[1]["y"].reshape(x.shape)
 
     @staticmethod
@@ -1160,7 +1163,10 @@ class CrossPairFn(torch.autograd.Function):
         if fuse_sampler:
             for i in (0, 1):
                 groups[i].update(kvsrc=None, hid=heads_[i][3], samp_src=xs[1 - i])
-        svs = ops.block_fwd(groups, dims, C, heads, eps, (C // heads) ** -0.5)
+        save = any(ctx.needs_input_grad)                 # (False under torch.no_grad(): the inference form of the launch, y only)
+        svs = ops.block_fwd(groups, dims, C, heads, eps, (C // heads) ** -0.5, save=save)
+        if not save:
+            return svs[0]["y"].reshape(x.shape), svs[1]["y"].reshape(x.shape)
         if fuse_sampler:                                 # (flow: saved for the sampler's adjoint; xs32: fp32 storage's kv-gradient operand)
             heads_ = [heads_[i][:4] + (svs[i]["flow"], svs[i]["xs32"]) for i in (0, 1)]
         ctx.save_for_backward(*xs, *[t for hd in heads_ for t in hd], *[sv[k] for sv in svs for k in _CSV_KEYS], sa1, sa2, sb1, sb2,

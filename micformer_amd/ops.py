@@ -1083,10 +1083,12 @@ def block_recomputes_h(C, heads):
     return bool(_lib.lib.micf_block_recomputes_h(C, heads))
 
 
-def block_fwd(groups, dims, C, heads, eps, scale, persist_probe=None):
+def block_fwd(groups, dims, C, heads, eps, scale, persist_probe=None, save=True):
     """groups: 1 or 2 dicts {x [T,C], kvsrc [T,C] | None, P {state_dict-style name: tensor}, attn 'self_attn' | 'cross_attn',
     s1, s2 [B] | None, want_xn bool}.  ONE launch.  Returns per group a dict of the tensors saved for backward (+ 'y').
-    persist_probe: (repeats, int32[2] device tensor) -- the measurement probe micf_block_fwd_persistent_probe instead."""
+    persist_probe: (repeats, int32[2] device tensor) -- the measurement probe micf_block_fwd_persistent_probe instead.
+    save=False (no backward will follow): the inference form where the kernels have one (block_fuses_sampler shapes: everything but
+    the few-token decomposition) -- only 'y' is written, every other entry of the returned dicts is None."""
     B, D, H, W = dims
     T = B * D * H * W
     hidden = groups[0]["P"]["mlp.fc1.weight"].shape[0]
@@ -1103,7 +1105,11 @@ def block_fwd(groups, dims, C, heads, eps, scale, persist_probe=None):
         x, P, a = gd["x"], gd["P"], gd["attn"]
         fused_sampler = gd.get("hid") is not None       # cross block that samples its K/V source itself: {hid, samp_src} given
         cross = gd.get("kvsrc") is not None or fused_sampler
-        o = {"y": y_all[gi * T:(gi + 1) * T], "q": _new(x, T, C, dtype=sd), "kv": _new(x, T, 2 * C, dtype=sd), "o": _new(x, T, C, dtype=sd),
+        if not save and block_fuses_sampler(C, heads) and persist_probe is None:
+            o = dict.fromkeys(("q", "kv", "o", "x1", "xn2", "h", "g", "stats", "xn", "kvs16", "flow", "xs32"))
+            o["y"] = y_all[gi * T:(gi + 1) * T]
+        else:
+          o = {"y": y_all[gi * T:(gi + 1) * T], "q": _new(x, T, C, dtype=sd), "kv": _new(x, T, 2 * C, dtype=sd), "o": _new(x, T, C, dtype=sd),
              "x1": _new(x, T, C), "xn2": _new(x, T, C, dtype=sd), "h": None if no_h else _new(x, T, hidden, dtype=h_dtype),
              "g": _new(x, T, hidden, dtype=sd), "stats": _new(x, 4, T),
              # (bf16 storage: the q weight gradient pairs a bf16 dq with a bf16 xn, so the kernel always writes its own copy)

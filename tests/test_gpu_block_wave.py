@@ -114,3 +114,43 @@ def test_wave_backward_matches_the_tile_kernel(ops, monkeypatch, dims, kind, ngr
             tol = 1.2e-2 if v.dtype == torch.bfloat16 else 6e-3
             check(f"group {i} {k}", wave[i][k].float(), v.float(), tol, errs)
     assert not errs, "\n".join(errs)
+
+
+@pytest.mark.parametrize("wave", [True, False])
+@pytest.mark.parametrize("case", [((2, 4, 4, 4), 48, 3), ((1, 2, 6, 2), 48, 3), ((1, 4, 6, 4), 96, 6), ((2, 4, 4, 2), 192, 12)])
+@pytest.mark.parametrize("kind", ["self", "sampled"])
+def test_inference_form_writes_the_same_output_and_nothing_else(ops, monkeypatch, wave, case, kind):
+    """micf_block_fwd with every saved-tensor pointer NULL (ops.block_fwd(save=False): what a forward under torch.no_grad() launches):
+    y is bit-identical to the saving form's on both kernels and in both arithmetic modes' tile kernels; a partial set of saved pointers
+    is refused."""
+    global C, HEADS
+    dims, c, heads = case
+    eps, scale = 1e-5, (c // heads) ** -0.5
+    c0, h0 = C, HEADS
+    C, HEADS = c, heads
+    try:
+        gs = _groups(ops, dims, kind, 2, scales=dims[0] > 1)
+    finally:
+        C, HEADS = c0, h0
+    full = _run(ops, monkeypatch, wave, lambda: ops.block_fwd([dict(g) for g in gs], dims, c, heads, eps, scale))
+    lean = _run(ops, monkeypatch, wave, lambda: ops.block_fwd([dict(g) for g in gs], dims, c, heads, eps, scale, save=False))
+    for f, l in zip(full, lean):
+        assert torch.equal(f["y"], l["y"])
+        assert all(v is None for k, v in l.items() if k != "y")
+
+
+def test_model_forward_under_no_grad_equals_the_training_forward(ops):
+    from micformer_amd.models.MICFormer_self import Head
+    from oracle import fill
+    h = Head(embed_dim=48, num_classes=8)
+    fill.fill_state_dict(h)
+    h = h.cuda().eval()
+    x = fill.make_volume(1, 64, 64, 64).cuda()
+    with torch.no_grad():
+        a = h(x)
+    b = h(x)
+    c = h(x)
+    assert b.requires_grad and not a.requires_grad
+    # (two forwards of the same mode already differ in the last bits: the offset convolutions accumulate atomically)
+    noise = float((b - c).detach().abs().max())
+    assert float((a - b.detach()).abs().max()) <= max(4.0 * noise, 1e-6 * float(b.detach().abs().max()))

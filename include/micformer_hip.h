@@ -548,6 +548,11 @@ int micf_block_tile_tokens(int B, int D, int H, int W, int C, int heads, int hid
  * cleared by the call): the flag reads 1 afterwards if a barrier timed out (bounded spin: a mis-sized launch does not hang). */
 int micf_block_fwd_persistent_probe(const micf_block_fwd_group* groups, int ngroups, int B, int D, int H, int W, int C, int heads,
                                     int hidden, float eps, float scale, int dtype, int repeats, int* sync_ws, micf_stream_t stream);
+/* HAZARD PROBE, not a product entry point: one 16 x 16 x 48 bf16 product on the matrix cores as
+ * form 0 = v_mfma_f32_16x16x16_bf16 accumulating onto the v_mfma_f32_16x16x32_bf16 issued right before it, form 1 = two independent
+ * products + a vector add (what csrc/block_wave.h::mfma48 does).  a / b: 64 lanes x 8 bf16 (A / B fragments of the 32-deep product),
+ * c / d: 64 lanes x 4 bf16 (the 16-deep one), out: 64 lanes x 4 floats in accumulator order (row 4 (lane / 16) + i, column lane % 16). */
+int micf_probe_mfma_chain(const void* a, const void* b, const void* c, const void* d, float* out, int form, micf_stream_t stream);
 /* Per-step weight preparation for the fused block kernels: for each row-major fp32 matrix of a list (one launch per 64 items,
  * one read of the source) write dst = src and / or dst_t = src^T, as float (bf16 = 0), as row-major bf16 bit patterns in
  * uint16_t, round-to-nearest-even (bf16 = 1), or K16-BLOCKED as bf16 (bf16 = 2) or as float (bf16 = 3; rows and cols multiples

@@ -119,6 +119,7 @@ SIGNATURES = {
     "micf_block_fwd": "piiiiiiiiffip",
     "micf_block_bwd": "piiiiiiiifip",
     "micf_block_fwd_persistent_probe": "piiiiiiiiffiipp",
+    "micf_probe_mfma_chain": "pppppip",
     "micf_dice_metric": "ppippiilp",
     "micf_sw_window_batch": "pppiiiiiiiiip",
     "micf_sw_accumulate_batch": "ppppiiiiiiiiip",

@@ -575,6 +575,50 @@ extern "C" int micf_block_fwd(const micf_block_fwd_group* groups, int ngroups, i
   return MICF_EUNSUPPORTED;
 }
 
+// HAZARD PROBE, not a product entry point (block_wave.h::mfma48): one K = 48 product of a 16 x 16 tile as
+// the compiler emits it from the two natural source forms -- form 0: acc = mfma_16x16x16(c, d, mfma_16x16x32(a, b, 0)), the dependent
+// pair of different shapes back to back; form 1: two independent products and a vector add.  a / b: [64 lanes][8] bf16 fragments,
+// c / d: [64][4]; out [64][4] floats in accumulator order.  tests/test_gpu_block_wave.py compares both with the exact product.
+namespace micf {
+namespace wave48 {
+__global__ void __launch_bounds__(64) mfma_chain_probe_kernel0(const bf16x8* a, const bf16x8* b, const bf16x4_t* c, const bf16x4_t* d, f32x4* out) {
+  const int l = threadIdx.x;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  out[l] = mfma16(c[l], d[l], mfma32(a[l], b[l], z));
+}
+__global__ void __launch_bounds__(64) mfma_chain_probe_kernel1(const bf16x8* a, const bf16x8* b, const bf16x4_t* c, const bf16x4_t* d, f32x4* out) {
+  const int l = threadIdx.x;
+  out[l] = mfma48(a[l], c[l], b[l], d[l]);
+}
+// form 2: the same dependent pair written out, VGPR accumulator, NOTHING between the two instructions (no compiler in the way);
+// form 3: ... with 16 wait states between them
+template <int NOPS>
+__global__ void __launch_bounds__(64) mfma_chain_probe_kernel2(const bf16x8* a, const bf16x8* b, const bf16x4_t* c, const bf16x4_t* d, f32x4* out) {
+  const int l = threadIdx.x;
+  const bf16x8 av = a[l], bv = b[l];
+  const bf16x4_t cv = c[l], dv = d[l];
+  f32x4 acc;
+  if (NOPS == 0)
+    asm volatile("s_nop 7\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, 0\n\tv_mfma_f32_16x16x16_bf16 %0, %3, %4, %0\n\ts_nop 15\n\ts_nop 15"
+                 : "=&v"(acc) : "v"(av), "v"(bv), "v"(cv), "v"(dv));
+  else
+    asm volatile("s_nop 7\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, 0\n\ts_nop 15\n\tv_mfma_f32_16x16x16_bf16 %0, %3, %4, %0\n\ts_nop 15\n\ts_nop 15"
+                 : "=&v"(acc) : "v"(av), "v"(bv), "v"(cv), "v"(dv));
+  out[l] = acc;
+}
+}  // namespace wave48
+}  // namespace micf
+extern "C" int micf_probe_mfma_chain(const void* a, const void* b, const void* c, const void* d, float* out, int form, micf_stream_t stream) {
+  if (!a || !b || !c || !d || !out || form < 0 || form > 3) return MICF_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  using namespace micf::wave48;
+  if (form == 0) hipLaunchKernelGGL(mfma_chain_probe_kernel0, dim3(1), dim3(64), 0, s, static_cast<const bf16x8*>(a), static_cast<const bf16x8*>(b), static_cast<const bf16x4_t*>(c), static_cast<const bf16x4_t*>(d), reinterpret_cast<f32x4*>(out));
+  else if (form == 3) hipLaunchKernelGGL(mfma_chain_probe_kernel2<16>, dim3(1), dim3(64), 0, s, static_cast<const bf16x8*>(a), static_cast<const bf16x8*>(b), static_cast<const bf16x4_t*>(c), static_cast<const bf16x4_t*>(d), reinterpret_cast<f32x4*>(out));
+  else if (form == 2) hipLaunchKernelGGL(mfma_chain_probe_kernel2<0>, dim3(1), dim3(64), 0, s, static_cast<const bf16x8*>(a), static_cast<const bf16x8*>(b), static_cast<const bf16x4_t*>(c), static_cast<const bf16x4_t*>(d), reinterpret_cast<f32x4*>(out));
+  else hipLaunchKernelGGL(mfma_chain_probe_kernel1, dim3(1), dim3(64), 0, s, static_cast<const bf16x8*>(a), static_cast<const bf16x8*>(b), static_cast<const bf16x4_t*>(c), static_cast<const bf16x4_t*>(d), reinterpret_cast<f32x4*>(out));
+  MICF_RETURN_LAUNCH();
+}
+
 // MEASUREMENT PROBE, not a product entry point: `repeats` passes of micf_block_fwd's tile kernel (base 8^3 shape only: C = 192, head_dim
 // 16, bf16 mode) in ONE launch with a device-wide barrier between passes.  sync_ws: 2 device ints (barrier counter, error flag; cleared
 // here).  MICF_EUNSUPPORTED for any other shape / more workgroups than CUs.  The error flag is 1 after the call if a barrier timed out.

@@ -154,3 +154,43 @@ def test_model_forward_under_no_grad_equals_the_training_forward(ops):
     # (two forwards of the same mode already differ in the last bits: the offset convolutions accumulate atomically)
     noise = float((b - c).detach().abs().max())
     assert float((a - b.detach()).abs().max()) <= max(4.0 * noise, 1e-6 * float(b.detach().abs().max()))
+
+
+def test_mixed_shape_mfma_chain_probe(ops):
+    """micf_probe_mfma_chain: a 16 x 16 x 48 bf16 product as two INDEPENDENT matrix-core products + an add (block_wave.h::mfma48, what
+    the wave-private kernels use) is exact; the dependent 16x16x32 -> 16x16x16 pair the compiler emits from the natural source form is
+    only REPORTED (form 0: in a standalone kernel the compiler puts the accumulator in AGPRs with other instructions in between and the
+    result is right; inside block_fwd_wave48_kernel it emitted the pair adjacent with a VGPR accumulator and NO wait state, and
+    the first two accumulator registers were wrong).  Forms 2 / 3 write that pair out by hand: without wait states the hardware
+    returns garbage, with 16 wait states the exact product -- i.e. the pair needs software wait states the compiler left out."""
+    import ctypes
+    import warnings
+    from micformer_amd import _lib
+    g = torch.Generator().manual_seed(3)
+    A = torch.randn(16, 48, generator=g).bfloat16()          # rows = output rows, k = 48
+    Bm = torch.randn(48, 16, generator=g).bfloat16()         # k x columns
+    lane = torch.arange(64)
+    li, lr = lane % 16, lane // 16
+    k32 = (8 * lr)[:, None] + torch.arange(8)[None, :]
+    k16 = 32 + (4 * lr)[:, None] + torch.arange(4)[None, :]
+    a = A[li[:, None], k32].contiguous().cuda()
+    b = Bm[k32, li[:, None]].contiguous().cuda()
+    c = A[li[:, None], k16].contiguous().cuda()
+    d = Bm[k16, li[:, None]].contiguous().cuda()
+    want = A.double() @ Bm.double()
+    res = []
+    for form in (0, 1, 2, 3):
+        out = torch.zeros(64, 4, device="cuda")
+        _lib.call("micf_probe_mfma_chain", _lib.ptr(a), _lib.ptr(b), _lib.ptr(c), _lib.ptr(d), _lib.ptr(out), form)
+        torch.cuda.synchronize()
+        got = torch.zeros(16, 16, dtype=torch.float64)
+        o = out.cpu().double()
+        for i in range(4):
+            got[4 * lr + i, li] = o[:, i]
+        res.append(float((got - want).abs().max()))
+    assert res[1] <= 1e-4 and res[3] <= 1e-4, res         # independent + add / wait states in between: exact
+    # form 2 (no wait state): garbage on MI355X (5e37 measured) -- the hardware does not interlock this pair; nothing to assert,
+    # a part that did would only make the workaround unnecessary
+    print("mfma chain probe: max |error| of form 0 (compiler's pair), 1 (independent + add), 2 (adjacent pair, VGPR accumulator), 3 (16 wait states between them):", res)
+    if res[0] > 1e-4:
+        warnings.warn(f"dependent 16x16x32 -> 16x16x16 MFMA pair: max error {res[0]:.3g} (the hazard of DESIGN.md section 3 reproduces standalone)")

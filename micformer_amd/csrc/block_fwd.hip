@@ -567,7 +567,9 @@ extern "C" int micf_block_fwd(const micf_block_fwd_group* groups, int ngroups, i
   // the C = 48 stages in bf16 mode: one wave per 16 tokens, nothing exchanged through LDS (block_wave_fwd.h); MICF_BLOCK_WAVE=0
   // restores the tile-per-workgroup kernel (which also keeps the fp32 mode, the fp8 attention and the debug switches)
   const char* wv = getenv("MICF_BLOCK_WAVE");                  // (read per call: the parity tests run both kernels in one process)
-  if ((!wv || atoi(wv) != 0) && C == 48 && hd == 16 && dtype == MICF_DTYPE_BF16 && a.att8 == 1 && !(a.debug & ~17)) return wave48::launch_fwd_wave48(a, s);
+  if ((!wv || atoi(wv) != 0) && C == 48 && hd == 16 && dtype == MICF_DTYPE_BF16 && a.att8 == 1 && !(a.debug & ~17) &&
+      a.geo.T * (int64_t)C * 4 < ((int64_t)1 << 32))          // (the fused sampling addresses its tap rows with 32-bit byte offsets)
+    return wave48::launch_fwd_wave48(a, s);
 #define MICF_BF(C_, HD_, TJ_) if (C == C_ && hd == HD_ && tj == TJ_) return launch_fwd<C_, HD_, TJ_>(a, dtype, s)
   MICF_BF(48, 16, 2); MICF_BF(48, 16, 1); MICF_BF(96, 16, 1); MICF_BF(96, 16, 2); MICF_BF(192, 16, 1);
   MICF_BF(96, 32, 1); MICF_BF(192, 32, 1);

@@ -1106,17 +1106,18 @@ def block_fwd(groups, dims, C, heads, eps, scale, persist_probe=None, save=True)
         fused_sampler = gd.get("hid") is not None       # cross block that samples its K/V source itself: {hid, samp_src} given
         cross = gd.get("kvsrc") is not None or fused_sampler
         if not save and block_fuses_sampler(C, heads) and persist_probe is None:
+            # inference form: nothing saved, every pointer but y NULL
             o = dict.fromkeys(("q", "kv", "o", "x1", "xn2", "h", "g", "stats", "xn", "kvs16", "flow", "xs32"))
             o["y"] = y_all[gi * T:(gi + 1) * T]
         else:
-          o = {"y": y_all[gi * T:(gi + 1) * T], "q": _new(x, T, C, dtype=sd), "kv": _new(x, T, 2 * C, dtype=sd), "o": _new(x, T, C, dtype=sd),
-             "x1": _new(x, T, C), "xn2": _new(x, T, C, dtype=sd), "h": None if no_h else _new(x, T, hidden, dtype=h_dtype),
-             "g": _new(x, T, hidden, dtype=sd), "stats": _new(x, 4, T),
-             # (bf16 storage: the q weight gradient pairs a bf16 dq with a bf16 xn, so the kernel always writes its own copy)
-             "xn": _new(x, T, C, dtype=sd) if (gd.get("want_xn", True) or st16) else None,
-             "kvs16": _new(x, T, C, dtype=sd) if (st16 and cross) else None,
-             "flow": _new(x, T, 3) if fused_sampler else None,
-             "xs32": _new(x, T, C) if (fused_sampler and not st16) else None}
+            o = {"y": y_all[gi * T:(gi + 1) * T], "q": _new(x, T, C, dtype=sd), "kv": _new(x, T, 2 * C, dtype=sd),
+                 "o": _new(x, T, C, dtype=sd), "x1": _new(x, T, C), "xn2": _new(x, T, C, dtype=sd),
+                 "h": None if no_h else _new(x, T, hidden, dtype=h_dtype), "g": _new(x, T, hidden, dtype=sd), "stats": _new(x, 4, T),
+                 # (bf16 storage: the q weight gradient pairs a bf16 dq with a bf16 xn, so the kernel always writes its own copy)
+                 "xn": _new(x, T, C, dtype=sd) if (gd.get("want_xn", True) or st16) else None,
+                 "kvs16": _new(x, T, C, dtype=sd) if (st16 and cross) else None,
+                 "flow": _new(x, T, 3) if fused_sampler else None,
+                 "xs32": _new(x, T, C) if (fused_sampler and not st16) else None}
         it.x, it.kvsrc, it.s1, it.s2 = f32(x), f32(gd.get("kvsrc")), f32(gd.get("s1")), f32(gd.get("s2"))
         if fused_sampler:
             it.hid, it.samp_src = f32(gd["hid"]), f32(gd["samp_src"])

@@ -165,6 +165,50 @@ def cpu_baseline(vol, timed=5, budget_s=420.0, batches=(2, 1), warmups=2):
                       + ("; " + "; ".join(notes) if notes else "")}
 
 
+def stock_loop(embed_dim, depths, train_mode, x, tgt, steps, warmup):
+    """The module-level drop-in as a user of INTEGRATION.md section 1 gets it: the reference's LITERAL loop body
+    (train_mmwhs_noPad.py:183-207) with stock torch.optim.Adam (:114) and CosineAnnealingLR (:148) on the HIP modules imported through the
+    reference's own import lines (one sys.path entry) -- eager, un-graphed, per-tensor autograd accumulation, ATen's multi-tensor
+    Adam over the 1626 parameters, and the loop's own loss_.item() host sync.  Same workload and arithmetic mode as the headline."""
+    import torch
+    dropin = os.path.join(ROOT, "micformer_amd", "dropin")
+    if dropin not in sys.path:
+        sys.path.insert(0, dropin)
+    from models.MICFormer_self import Head          # MicFormer/test.ipynb:11
+    from loss import MDiceLoss                      # train_mmwhs_noPad.py:19
+    torch.manual_seed(1234)
+    model_1 = Head(embed_dim=embed_dim, num_classes=8, depths=depths).to(x.device)
+    model_1.train(train_mode)
+    criterion = MDiceLoss().to(x.device)
+    optimizer = torch.optim.Adam(model_1.parameters(), lr=1e-4, weight_decay=0)
+    scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, 150)
+
+    def iteration():
+        optimizer.zero_grad()
+        segs_S1 = model_1(x)
+        loss_ = criterion(segs_S1, tgt)
+        v = loss_.item()
+        loss_.backward()
+        optimizer.step()
+        scheduler.step()
+        return v
+
+    for _ in range(warmup):
+        iteration()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        v = iteration()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert v == v, "stock loop: loss is NaN"
+    del optimizer, model_1
+    return {"pairs_per_s": round(x.shape[0] * steps / dt, 3), "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps, "warmup": warmup,
+            "final_loss": round(v, 6),
+            "loop": "optimizer.zero_grad(); segs = model(x); loss = MDiceLoss()(segs, y); loss.item(); loss.backward(); optimizer.step(); "
+                    "scheduler.step() -- torch.optim.Adam(lr=1e-4) + CosineAnnealingLR, eager launches, no TrainEngine, no HIP graph"}
+
+
 class _StubEngine:
     """CPU stand-in used by tests/test_bench_flow.py (--cpu-stub): issues the collectives of a data-parallel step on gloo so the
     rank control flow of this script (who is still inside which leg when a collective is issued) is exercised without a GPU."""
@@ -259,6 +303,11 @@ def main(argv=None):
                     "with explicit events (main chain / parameter-gradient batches) instead of ONE graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--stock-loop", dest="stock_loop", action="store_true", default=None,
+                    help="also time the reference's literal loop body (stock torch.optim.Adam + CosineAnnealingLR, eager) on the drop-in "
+                         "modules: extra keys stock_loop_pairs_per_s / stock_loop (default: on for --gpus 1)")
+    ap.add_argument("--no-stock-loop", dest="stock_loop", action="store_false")
+    ap.add_argument("--stock-steps", type=int, default=5)
     ap.add_argument("--no-profile-gate", action="store_true",
                     help="roofline leg: do not hold the launch stream while a profiled eager step is enqueued (event pairs then include the "
                          "start-up latency of launches on an idle queue)")
@@ -482,6 +531,7 @@ def main(argv=None):
                 empty = sorted(a_.elapsed_time(b_) for a_, b_ in pairs)
                 pair_ms = empty[len(empty) // 2]
                 for v in prof.values():
+                    v["ms_raw"] = v["ms"]                            # (the uncorrected sum stays in the record: frac_raw / *_us_raw)
                     cut = min(pair_ms * v["calls"], 0.5 * v["ms"])
                     if v.get("block_ms"):
                         v["block_ms"] = max(v["block_ms"] - cut * v["block_ms"] / max(v["ms"], 1e-9), 0.0)
@@ -491,39 +541,73 @@ def main(argv=None):
         e = 2 if dtype_name == "bf16" else 4
         mfma_peak = MFMA_BF16_PEAK_TFLOPS if dtype_name == "bf16" else MFMA_F32_PEAK_TFLOPS
         total_ms = sum(v["ms"] for v in prof.values())
-        name, top = max(prof.items(), key=lambda kv: kv[1]["ms"])
-        per = top["calls"]
-        sec = top["ms"] / 1e3
-        gbs = top["bytes"] / sec / 1e9
-        tfl = top["flops"] / sec / 1e12
-        frac_hbm, frac_mfma = gbs / HBM_PEAK_GBS, tfl / mfma_peak
-        # The fraction reported is SURVEY.md 8(d)'s: ALGORITHMIC bytes of the launch (for a transformer-block launch the ideal-
-        # fusion activation passes + the block's weights at the element size of the arithmetic mode, ops._block_cost; for any
-        # other launch every tensor once) over the measured launch time, against the HBM peak.  What the kernel itself moves
-        # (it also writes what its backward / the weight gradients re-read, in the element sizes actually stored) is reported
-        # as `own_traffic_bytes_per_launch` / `hbm_util`; `traffic` is the PMC-measured HBM bytes per launch.
-        s8d = top.get("s8d_bytes", 0)
-        algo = s8d if s8d > 0 else top["bytes"]
-        algo_gbs = algo / sec / 1e9
-        ai = top["flops"] / max(algo, 1)
+        # ---- SURVEY.md 8(d) UNITS.  The algorithmic bytes of 8(d) are defined per block of a depth slot: a self block moves its
+        # activation 2 times forward / 3 times backward, a cross block 3 / 5 times (T*C*e per pass per modality) plus the block's
+        # weights once.  A unit here = the pair of blocks of one kind of one depth slot in one direction (both modalities), i.e.
+        # EVERYTHING the data path launches for it: the fused block launch and, for a cross pair, LayerNorm-1, the offset conv, the
+        # sampler and their adjoints (entry points that have no 8(d) bytes of their own -- they are part of the cross block).
+        # frac = unit's 8(d) bytes / the summed event time of all its launches / 8 TB/s.  The dominant unit is the one with the
+        # largest total time per step (a stable rule: a unit's total does not depend on how its work is cut into launches).
+        units = {}
+        for k, v in prof.items():
+            for uname, (ucalls, ums, u8d) in v.get("by_unit", {}).items():
+                # (the event-pair correction applied to the key is applied to its share in the unit in the same proportion)
+                scale = v["ms"] / max(v.get("ms_raw", v["ms"]), 1e-9)
+                u = units.setdefault(uname, {"ms": 0.0, "ms_raw": 0.0, "s8d": 0, "own": 0, "flops": 0, "launches": {}, "n": 0})
+                u["ms"] += ums * scale
+                u["ms_raw"] += ums
+                u["s8d"] += u8d
+                u["own"] += v["bytes"] * ucalls // max(v["calls"], 1)
+                u["flops"] += v["flops"] * ucalls // max(v["calls"], 1)
+                u["launches"][k] = (ucalls, ums * scale)
+                if u8d:
+                    u["n"] += ucalls                         # occurrences of the unit = its block launches
+        if not units:                                        # (stub engine / a model without fused pairs: fall back to the largest key)
+            k, v = max(prof.items(), key=lambda kv: kv[1]["ms"])
+            units = {k: {"ms": v["ms"], "ms_raw": v.get("ms_raw", v["ms"]), "s8d": v.get("s8d_bytes", 0) or v["bytes"], "own": v["bytes"],
+                         "flops": v["flops"], "launches": {k: (v["calls"], v["ms"])}, "n": v["calls"]}}
+
+        def unit_row(uname, u):
+            n = max(u["n"], 1)
+            sec, sec_raw = u["ms"] / 1e3, u["ms_raw"] / 1e3
+            tr, complete = 0, True
+            for k, (c, _) in u["launches"].items():
+                t = pmc_traffic(k)
+                if t is None:
+                    complete = False
+                else:
+                    tr += t * c
+            return {"unit": uname, "units_per_step": n // nprof, "avg_unit_us": round(1e3 * u["ms"] / n, 2),
+                    "avg_unit_us_raw": round(1e3 * u["ms_raw"] / n, 2), "ms_per_step": round(u["ms"] / nprof, 3),
+                    "algorithmic_bytes_per_unit": u["s8d"] // n,
+                    "frac": round(u["s8d"] / max(sec, 1e-12) / 1e9 / HBM_PEAK_GBS, 4),
+                    "frac_raw": round(u["s8d"] / max(sec_raw, 1e-12) / 1e9 / HBM_PEAK_GBS, 4),
+                    "hbm_util": round(u["own"] / max(sec, 1e-12) / 1e9 / HBM_PEAK_GBS, 4),
+                    "mfma_frac": round(u["flops"] / max(sec, 1e-12) / 1e12 / mfma_peak, 4),
+                    "traffic": (tr // n) if (complete and tr) else None,
+                    "launches": [{"kernel": k, "per_unit": round(c / n, 2), "avg_launch_us": round(1e3 * m / max(c, 1), 2)}
+                                 for k, (c, m) in sorted(u["launches"].items(), key=lambda kv: -kv[1][1])]}
+
+        name, top = max(units.items(), key=lambda kv: kv[1]["ms"])
+        row = unit_row(name, top)
         ridge = mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9)
-        if ai > ridge:
-            roof = {"bound": "mfma", "achieved": round(tfl, 3), "peak": mfma_peak, "unit": "TFLOP/s", "frac": round(frac_mfma, 4)}
-        else:
-            roof = {"bound": "hbm", "achieved": round(algo_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(algo_gbs / HBM_PEAK_GBS, 4)}
-        traffic = pmc_traffic(name)
+        ai = top["flops"] / max(top["s8d"], 1)
+        roof = {"bound": "hbm", "achieved": round(row["frac"] * HBM_PEAK_GBS, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": row["frac"],
+                "traffic": row["traffic"], "kernel": name,
+                "rule": "SURVEY 8(d) unit = every data-path launch of one depth slot's self / cross block pair in one direction; "
+                        "bytes = (self 2 fwd / 3 bwd, cross 3 fwd / 5 bwd) passes of T*C*e per modality + the block weights once, "
+                        "e = %d B; time = sum of the unit's launch durations (HIP events on the launch stream); dominant = the unit "
+                        "with the largest total time per step; hbm_util = the launches' OWN bytes over the same time" % e,
+                "frac_raw": row["frac_raw"], "units_per_step": row["units_per_step"], "avg_unit_us": row["avg_unit_us"],
+                "avg_unit_us_raw": row["avg_unit_us_raw"], "ms_per_step": row["ms_per_step"],
+                "share_of_kernel_time": round(top["ms"] / total_ms, 4),
+                "algorithmic_bytes_per_unit": row["algorithmic_bytes_per_unit"], "hbm_util": row["hbm_util"],
+                "mfma_frac": row["mfma_frac"], "arithmetic_intensity_vs_ridge": [round(ai, 1), round(ridge, 1)],
+                "traffic_over_algorithmic": round(row["traffic"] / max(row["algorithmic_bytes_per_unit"], 1), 2) if row["traffic"] else None,
+                "launches": row["launches"]}
         if gate_cycles:
             roof["event_pair_us_subtracted"] = round(1e3 * pair_ms, 2)
-        roof.update({"traffic": traffic, "kernel": name, "launches_per_step": per // nprof,
-                     "avg_launch_us": round(1e3 * top["ms"] / per, 2),
-                     "share_of_kernel_time": round(top["ms"] / total_ms, 4),
-                     "algorithmic_bytes_per_launch": algo // per,
-                     "algorithmic_rule": ("SURVEY 8(d): self block 2 fwd / 3 bwd, cross block 3 fwd / 5 bwd passes of T*C*e per "
-                                          "modality + block weights once, e = %d B" % e) if s8d > 0 else "every tensor of the launch once",
-                     "own_traffic_bytes_per_launch": top["bytes"] // per, "flops_per_launch": top["flops"] // per,
-                     "hbm_util": round(frac_hbm, 4), "mfma_frac": round(frac_mfma, 4),
-                     "traffic_over_algorithmic": round(traffic / (algo / per), 2) if traffic else None})
+        roof["units"] = [unit_row(k, u) for k, u in sorted(units.items(), key=lambda kv: -kv[1]["ms"])[:8]]
         # whole-step view: entry points (all shapes merged), algorithmic bytes / flops over the sum of their event times
         merged = {}
         for k, v in prof.items():
@@ -549,13 +633,16 @@ def main(argv=None):
                         "non_block_ms": round(other_ms, 3),
                         "achieved": round(pbytes / (t_block_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(pbytes / (t_block_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
-        # the profile is flat (the three largest keys lie within 15 % of each other and swap places from run to run): list them
+        roof["path_frac"] = roof["path"]["frac"]          # (north_star's "attention path" number, also at the top level of the object)
+        # the largest C-ABI keys (single entry points; a key that is only PART of an 8(d) unit has no 8(d) bytes of its own: its
+        # frac_hbm_algorithmic is null and hbm_util is its own traffic)
         top_keys = []
         for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:4]:
-            a_b = v.get("s8d_bytes", 0) or v["bytes"]
+            a_b = v.get("s8d_bytes", 0)
             top_keys.append({"kernel": k, "launches_per_step": v["calls"] // nprof, "avg_launch_us": round(1e3 * v["ms"] / max(v["calls"], 1), 2),
+                             "avg_launch_us_raw": round(1e3 * v.get("ms_raw", v["ms"]) / max(v["calls"], 1), 2),
                              "ms_per_step": round(v["ms"] / nprof, 3),
-                             "frac_hbm_algorithmic": round(a_b / max(v["ms"], 1e-9) / 1e6 / HBM_PEAK_GBS, 4),
+                             "frac_hbm_algorithmic": round(a_b / max(v["ms"], 1e-9) / 1e6 / HBM_PEAK_GBS, 4) if a_b else None,
                              "hbm_util": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6 / HBM_PEAK_GBS, 4),
                              "mfma_frac": round(v["flops"] / max(v["ms"], 1e-9) / 1e9 / mfma_peak, 4),
                              "traffic": pmc_traffic(k)})
@@ -577,6 +664,11 @@ def main(argv=None):
                                "whole_step_TFLOP/s": round(tot_f / nprof / (ms_step * 1e-3) / 1e12, 2),
                                "whole_step_GB/s": round(tot_b / nprof / (ms_step * 1e-3) / 1e9, 1)}
 
+    if (args.stock_loop if args.stock_loop is not None else (world == 1 and not forced)) and not stub and not live_group:
+        # (one GPU only: the stock loop has no gradient exchange; the engine's flat buffers stay alive beside it -- ~6 GB + ~6 GB)
+        sl = stock_loop(args.embed_dim, depths, not args.eval_mode, x, tgt, args.stock_steps, 2)
+        out["stock_loop_pairs_per_s"] = sl["pairs_per_s"]
+        out["stock_loop"] = sl
     if rank == 0:
         if not args.no_cpu_baseline and world == 1 and not stub:
             out["cpu_baseline"] = cpu_baseline(vol, timed=args.cpu_steps, budget_s=args.cpu_budget_s)

@@ -271,6 +271,15 @@ def stream():
 # PROFILE = None (off) or a dict  name -> [events [(start, end)], bytes, flops]
 PROFILE = None
 BLOCK_DEPTH = 0          # > 0 while a transformer-block Function is issuing launches (bench.py's path roofline)
+UNIT = None              # SURVEY.md 8(d) unit the launches issued now belong to, e.g. "cross_bwd|2x65536x48" (bench.py's roofline leg)
+
+
+def set_unit(kind, groups, tokens, channels):
+    """Names the 8(d) unit -- the self / cross block pair of a depth slot, forward or backward -- whose launches follow (profiling
+    only; cleared when the enclosing block_region closes)."""
+    global UNIT
+    if PROFILE is not None:
+        UNIT = f"{kind}|{groups}x{tokens}x{channels}"
 
 
 class block_region:
@@ -281,8 +290,10 @@ class block_region:
         BLOCK_DEPTH += 1
 
     def __exit__(self, *exc):
-        global BLOCK_DEPTH
+        global BLOCK_DEPTH, UNIT
         BLOCK_DEPTH -= 1
+        if BLOCK_DEPTH == 0:
+            UNIT = None
         return False
 
 
@@ -303,7 +314,7 @@ def call(name, *args, cost=None):
         e1.record()
         key = name if (cost is None or len(cost) < 3 or cost[2] is None) else f"{name}|{cost[2]}"
         rec = PROFILE.setdefault(key, [[], 0, 0, 0])
-        rec[0].append((e0, e1, BLOCK_DEPTH > 0))
+        rec[0].append((e0, e1, BLOCK_DEPTH > 0, UNIT, cost[3] if (cost is not None and len(cost) > 3 and cost[3]) else 0))
         if cost is not None:
             rec[1] += cost[0]
             rec[2] += cost[1]
@@ -319,15 +330,22 @@ def profile_start():
 
 
 def profile_stop():
-    """-> {name: dict(calls, ms, bytes, flops)}; synchronises."""
-    global PROFILE
-    prof, PROFILE = PROFILE, None
+    """-> {name: dict(calls, ms, bytes, flops, block_ms, s8d_bytes, by_unit {unit: [calls, ms, 8(d) bytes]})}; synchronises."""
+    global PROFILE, UNIT
+    prof, PROFILE, UNIT = PROFILE, None, None
     torch.cuda.synchronize()
     out = {}
     for name, (evs, nbytes, flops, s8d) in (prof or {}).items():
-        ms = [(a.elapsed_time(b), blk) for a, b, blk in evs]
-        out[name] = dict(calls=len(evs), ms=sum(m for m, _ in ms), bytes=nbytes, flops=flops, block_ms=sum(m for m, blk in ms if blk),
-                         s8d_bytes=s8d)
+        ms = [(a.elapsed_time(b), blk, unit, u8d) for a, b, blk, unit, u8d in evs]
+        by_unit = {}
+        for m, _, unit, u8d in ms:
+            if unit is not None:
+                u = by_unit.setdefault(unit, [0, 0.0, 0])
+                u[0] += 1
+                u[1] += m
+                u[2] += u8d
+        out[name] = dict(calls=len(evs), ms=sum(m[0] for m in ms), bytes=nbytes, flops=flops,
+                         block_ms=sum(m[0] for m in ms if m[1]), s8d_bytes=s8d, by_unit=by_unit)
     return out
 
 

@@ -932,6 +932,8 @@ int micf::offset_sample_bwd_groups(SampleBwdSet* sets, int n, int B, int D, int 
   const Geo g{B, D, H, W};
   const int64_t T = g.tokens();
   if (T >= (1LL << 31) / 4) return MICF_EUNSUPPORTED;
+  // the kernels address the tap rows of ONE sample with 32-bit element offsets (offset_sample_bwd4: rowo = lin * C)
+  if ((int64_t)D * H * W * C >= (1LL << 31)) return MICF_EUNSUPPORTED;
   bool al = true;
   for (int i = 0; i < n; ++i) {
     const SampleBwdSet& q = sets[i];

@@ -734,6 +734,12 @@ class TrainEngine:
             flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=x.device)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.sync.pg)
             ok = bool(flag.item())
+        elif self.world > 1 and not ok:
+            # uniform_batches promised one batch shape on every rank and skipped the agreement above: a rank that fell back to the
+            # eager step alone would cut the gradient exchange differently from its peers (a hang, or silently wrong sums)
+            raise RuntimeError("TrainEngine(uniform_batches=True): this rank's batch does not match the captured step "
+                               f"(x {tuple(x.shape)} vs {tuple(sx.shape)}, target {tuple(target.shape)} vs {tuple(st.shape)}, mode "
+                               f"{ops.arith_mode()} vs {self._static_mode}); ragged batches need uniform_batches=False")
         return ok
 
     def _capture(self, x, target):

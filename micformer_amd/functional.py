@@ -509,6 +509,15 @@ def _defer_conv_wgrad(ok, dhid, xn, xa, dw, db, dims):
 
 
 def _launch_batch(items, ln, calls):
+    # (parameter-gradient side work: it may be launched lazily from inside a block Function, but belongs to no 8(d) unit of the chain)
+    unit, _lib.UNIT = _lib.UNIT, None
+    try:
+        _launch_batch_body(items, ln, calls)
+    finally:
+        _lib.UNIT = unit
+
+
+def _launch_batch_body(items, ln, calls):
     with block_region():
         if ln:
             ops.layernorm_bwd_finish(ln)
@@ -1018,16 +1027,19 @@ class SelfPairFn(torch.autograd.Function):
 
     @staticmethod
     @_in_block
-    def forward(ctx, x, xa, sa1, sa2, sb1, sb2, heads, eps, *params):
+    def forward(ctx, x, xa, sa1, sa2, sb1, sb2, heads, eps, grad_mode, *params):
         n = len(SELF_KEYS)
         Ps = [dict(zip(SELF_KEYS, params[:n])), dict(zip(SELF_KEYS, params[n:]))]
         x, xa = _c(x), _c(xa)
         B, D, H, W, C = x.shape
         dims = (B, D, H, W)
         xs = [x.reshape(-1, C), xa.reshape(-1, C)]
+        _lib.set_unit("self_fwd", 2, xs[0].shape[0], C)
         scales = [(sa1, sa2), (sb1, sb2)]
-        # (no input asks for a gradient -- torch.no_grad(), the sliding-window inference: nothing is saved, the launch writes y only)
-        save = any(ctx.needs_input_grad)
+        # grad_mode = torch.is_grad_enabled() read by the CALLER: inside Function.forward grad mode is always off, and under
+        # torch.no_grad() needs_input_grad still reports the trainable parameters.  No gradient will be asked for (validation, the
+        # sliding-window inference): nothing is saved, the launch writes y only.
+        save = bool(grad_mode) and any(ctx.needs_input_grad)
         svs = _self_fwd_fused(xs, Ps, scales, dims, heads, eps, save=save)
         if save:
             ctx.save_for_backward(*xs, *[sv[k] for sv in svs for k in _SV_KEYS], sa1, sa2, sb1, sb2, *params)
@@ -1050,11 +1062,12 @@ class SelfPairFn(torch.autograd.Function):
         Gs = [{k: _grad_buf(t, v) for (k, v), t in zip(P.items(), tg)} for P, tg in zip(Ps, tgs)]
         sides = [all(t is not None for t in tg) for tg in tgs]
         C = xs[0].shape[1]
+        _lib.set_unit("self_bwd", 2, xs[0].shape[0], C)
         dys = [_c(dy).reshape(-1, C), _c(dya).reshape(-1, C)]
         dxs = _self_bwd_fused(dys, xs, svs, Ps, Gs, [(sa1, sa2), (sb1, sb2)], dims, heads, sides)
         shape = dims + (C,)
         grads = tuple(_ret(t, G[k]) for G, tg in zip(Gs, tgs) for k, t in zip(SELF_KEYS, tg))
-        return (dxs[0].reshape(shape), dxs[1].reshape(shape), None, None, None, None, None, None) + grads
+        return (dxs[0].reshape(shape), dxs[1].reshape(shape), None, None, None, None, None, None, None) + grads
 
 
 def _cross_head_fwd(xf, xaf, P, dims, eps):
@@ -1124,7 +1137,7 @@ class CrossPairFn(torch.autograd.Function):
 
     @staticmethod
     @_in_block
-    def forward(ctx, x, xa, sa1, sa2, sb1, sb2, heads, eps, *params):
+    def forward(ctx, x, xa, sa1, sa2, sb1, sb2, heads, eps, grad_mode, *params):
         n = len(CROSS_KEYS)
         Ps = [dict(zip(CROSS_KEYS, params[:n])), dict(zip(CROSS_KEYS, params[n:]))]
         x, xa = _c(x), _c(xa)
@@ -1134,6 +1147,7 @@ class CrossPairFn(torch.autograd.Function):
         B, D, H, W, C = x.shape
         dims = (B, D, H, W)
         xs = [x.reshape(-1, C), xa.reshape(-1, C)]
+        _lib.set_unit("cross_fwd", 2, xs[0].shape[0], C)
         fuse_sampler = GROUP_CROSS_HEADS and FUSE_SAMPLER and ops.block_fuses_sampler(C, heads)
         if GROUP_CROSS_HEADS:
             # both offset heads per launch (micf_offset_head_fwd): no fork / join inside the captured graph
@@ -1163,7 +1177,7 @@ class CrossPairFn(torch.autograd.Function):
         if fuse_sampler:
             for i in (0, 1):
                 groups[i].update(kvsrc=None, hid=heads_[i][3], samp_src=xs[1 - i])
-        save = any(ctx.needs_input_grad)                 # (False under torch.no_grad(): the inference form of the launch, y only)
+        save = bool(grad_mode) and any(ctx.needs_input_grad)   # (grad_mode: the caller's torch.is_grad_enabled(), see SelfPairFn)
         svs = ops.block_fwd(groups, dims, C, heads, eps, (C // heads) ** -0.5, save=save)
         if not save:
             return svs[0]["y"].reshape(x.shape), svs[1]["y"].reshape(x.shape)
@@ -1192,6 +1206,7 @@ class CrossPairFn(torch.autograd.Function):
         Gs = [{k: _grad_buf(t, v) for (k, v), t in zip(P.items(), tg)} for P, tg in zip(Ps, tgs)]
         sides = [all(t is not None for t in tg) for tg in tgs]
         C = xs[0].shape[1]
+        _lib.set_unit("cross_bwd", 2, xs[0].shape[0], C)
         rps = dims[1] * dims[2] * dims[3]
         dys = [_c(dy).reshape(-1, C), _c(dya).reshape(-1, C)]
         groups = [{"dy": dys[i], "x": None, "x1": svs[i]["x1"], "stats": svs[i]["stats"], "q": svs[i]["q"], "kv": svs[i]["kv"],
@@ -1249,7 +1264,7 @@ class CrossPairFn(torch.autograd.Function):
                                   add=acc[i], defer=_ln_defer(sides[i]), out=acc[i])
         shape = dims + (C,)
         grads = tuple(_ret(t, G[k]) for G, tg in zip(Gs, tgs) for k, t in zip(CROSS_KEYS, tg))
-        return (acc[0].reshape(shape), acc[1].reshape(shape), None, None, None, None, None, None) + grads
+        return (acc[0].reshape(shape), acc[1].reshape(shape), None, None, None, None, None, None, None) + grads
 
 
 # ============================================================================= patch embed / merging / expand / head

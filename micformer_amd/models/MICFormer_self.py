@@ -426,17 +426,18 @@ class BasicLayer(nn.Module):
             Fn._padded((D, H, W), (2, 2, 2)) == (D, H, W)
 
     def _forward_pairs(self, x, xa):
+        grad_mode = torch.is_grad_enabled()            # (read HERE: it is always off inside Function.forward)
         for i in range(self.depth):
             if i and i % SLOT_FLUSH_STRIDE == 0 and (Fn.CTX.flush_points or Fn.CTX.defer_calls) and x.requires_grad:
                 x, xa = Fn.FlushPointFn.apply(x, xa)   # backward: the later slots' weight gradients start under the earlier slots' chain
             a, b = self.self_blocks1[i], self.self_blocks2[i]
             sa, sb = _block_scales(a, x), _block_scales(b, xa)
-            x, xa = Fn.SelfPairFn.apply(x, xa, sa[0], sa[1], sb[0], sb[1], a.num_heads, a.norm1.eps,
+            x, xa = Fn.SelfPairFn.apply(x, xa, sa[0], sa[1], sb[0], sb[1], a.num_heads, a.norm1.eps, grad_mode,
                                         *_block_params(a, Fn.SELF_KEYS), *_block_params(b, Fn.SELF_KEYS))
             a, b = self.blocks1[i], self.blocks2[i]
             sa, sb = _block_scales(a, x), _block_scales(b, xa)
             Fn.CTX.cross_after_self = (x.data_ptr(), xa.data_ptr())      # (self pair -> cross pair, nothing in between)
-            x, xa = Fn.CrossPairFn.apply(x, xa, sa[0], sa[1], sb[0], sb[1], a.num_heads, a.norm1.eps,
+            x, xa = Fn.CrossPairFn.apply(x, xa, sa[0], sa[1], sb[0], sb[1], a.num_heads, a.norm1.eps, grad_mode,
                                          *_block_params(a, Fn.CROSS_KEYS), *_block_params(b, Fn.CROSS_KEYS))
         return x, xa
 

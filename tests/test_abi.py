@@ -102,4 +102,8 @@ def test_round2_entry_points_validate_arguments_without_gpu():
     assert L.micf_layernorm_bwd_pair(None, 2, 8, 48, None) == EINVAL
     assert L.micf_weight_prep_grouped(None, 3, None) == EINVAL and L.micf_weight_prep_grouped(None, 0, None) == 0
     assert L.micf_conv3_weight_prep_grouped(None, 1, None) == EINVAL
+    # the sampler's adjoint addresses one sample's tap rows with 32-bit element offsets: D*H*W*C >= 2^31 is refused, not wrapped
+    nul = [None] * 12
+    assert L.micf_offset_sample_bwd(*nul, 1, 128, 512, 512, 64, C.c_float(1e-5), None, 0, None) == EUNSUP
+    assert L.micf_offset_sample_bwd(*nul, 1, 128, 512, 512, 48, C.c_float(1e-5), None, 0, None) == EINVAL    # (in range: NULL tensors)
     assert L.micf_adam_step(None, None, None, None, 8, None, C.c_float(0.9), C.c_float(0.999), C.c_float(1e-8), C.c_float(1.0), None, None) == EINVAL

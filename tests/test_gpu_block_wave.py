@@ -156,6 +156,33 @@ def test_model_forward_under_no_grad_equals_the_training_forward(ops):
     assert float((a - b.detach()).abs().max()) <= max(4.0 * noise, 1e-6 * float(b.detach().abs().max()))
 
 
+def test_no_grad_forward_of_a_trainable_model_takes_the_inference_form(ops, monkeypatch):
+    """Under torch.no_grad() with TRAINABLE parameters (validation, the sliding-window predictor: utils.py:236-238) every block launch is
+    the inference form (save=False: y only) -- needs_input_grad alone cannot tell (it reports the parameters), the caller's grad mode
+    decides.  With grad enabled every launch saves."""
+    from micformer_amd.models.MICFormer_self import Head
+    from oracle import fill
+    h = Head(embed_dim=48, num_classes=8)
+    fill.fill_state_dict(h)
+    h = h.cuda().train()
+    assert all(p.requires_grad for p in h.parameters())
+    seen = []
+    real = ops.block_fwd
+
+    def spy(groups, dims, C, heads, eps, scale, save=True):
+        seen.append(bool(save))
+        return real(groups, dims, C, heads, eps, scale, save=save)
+
+    monkeypatch.setattr(ops, "block_fwd", spy)
+    x = fill.make_volume(1, 64, 64, 64).cuda()
+    with torch.no_grad():
+        h(x)
+    assert len(seen) == 48 and not any(seen), seen           # 2 pairs x (2 + 2 + 6 + 2) depth slots x (encoder + decoder)
+    del seen[:]
+    y = h(x)
+    assert len(seen) == 48 and all(seen) and y.requires_grad
+
+
 def test_mixed_shape_mfma_chain_probe(ops):
     """micf_probe_mfma_chain: a 16 x 16 x 48 bf16 product as two INDEPENDENT matrix-core products + an add (block_wave.h::mfma48, what
     the wave-private kernels use) is exact; the dependent 16x16x32 -> 16x16x16 pair the compiler emits from the natural source form is

@@ -475,7 +475,9 @@ def main(argv=None):
                                                     " (plumbing check: NOT the RCCL / xGMI path, ranks may share a GPU)")
         out["distinct_local_devices"] = len({int(g.item()) for g in gathered})
         if not stub:
-            out["grad_wire"] = "bf16" if eng.grad_bf16 else "fp32"          # wire format of the gradient all-reduce
+            # wire format of the gradient exchange: fp32 all-reduce | bf16 on the links with fp32 sums
+            # (all-to-all + all-gather) | bf16-ring (the backend's all-reduce in bf16)
+            out["grad_wire"] = eng.grad_wire or "fp32"
     else:
         out["rccl_ranks"] = 1
     if probe:

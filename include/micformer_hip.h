@@ -582,6 +582,17 @@ int micf_zero(void* p, int64_t bytes, micf_stream_t stream);
  * graph draws fresh masks at every replay.  keep [n] (0 < keep <= 1), out [n*B]. */
 int micf_drop_path_draw(void* rng, const float* keep, float* out, int n, int B, micf_stream_t stream);
 
+
+/* ---- bf16 wire format of the data-parallel gradient exchange (no reference counterpart: train_mmwhs_noPad.py:410-414 is one
+ * process): bf16 on the xGMI links, fp32 in every sum.  A slice of the flat fp32 gradient is rounded into
+ * `ranks` equal zero-padded bf16 shards (pack: dst[i] = bf16_rne(src[i]), i < n; 0 up to `padded`, a multiple of 8), shard j of
+ * every rank is sent to rank j (all-to-all), which adds its `ranks` received shards IN FP32 and rounds the sum once
+ * (sum: out[i] = bf16_rne(sum_r recv[r * shard + i]), shard a multiple of 8), the reduced shards are all-gathered and widened back
+ * (unpack: dst[i] = float(src[i]), i < n).  All buffers 16-byte aligned; the collectives themselves are the caller's (RCCL). */
+int micf_grad_wire_pack(const float* src, int64_t n, void* dst, int64_t padded, micf_stream_t stream);
+int micf_grad_wire_sum(const void* recv, int ranks, int64_t shard, void* out, micf_stream_t stream);
+int micf_grad_wire_unpack(const void* src, float* dst, int64_t n, micf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

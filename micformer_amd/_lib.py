@@ -116,6 +116,9 @@ SIGNATURES = {
     "micf_block_fuses_sampler": "ii",
     "micf_block_recomputes_h": "ii",
     "micf_weight_prep_grouped": "pip",
+    "micf_grad_wire_pack": "plplp",
+    "micf_grad_wire_sum": "pilpp",
+    "micf_grad_wire_unpack": "pplp",
     "micf_block_fwd": "piiiiiiiiffip",
     "micf_block_bwd": "piiiiiiiifip",
     "micf_block_fwd_persistent_probe": "piiiiiiiiffiipp",

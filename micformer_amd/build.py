@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmicformer_hip.so")
 SOURCES = ["linear.hip", "linear_grouped.hip", "head_tail.hip", "head_tail_fused.hip", "layernorm.hip", "window_attn.hip", "conv3.hip", "conv3_wgrad.hip", "conv3_direct.hip", "conv3_fwdx.hip", "conv3_bwdx.hip", "conv3_wgradx.hip", "offset_sample.hip", "patch.hip",
-           "loss_optim.hip", "misc.hip", "block_fwd.hip", "block_bwd.hip", "block_wide.hip", "offset_head.hip"]
+           "loss_optim.hip", "misc.hip", "block_fwd.hip", "block_bwd.hip", "block_wide.hip", "offset_head.hip", "grad_wire.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-fvisibility=default"]
 
 

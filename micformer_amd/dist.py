@@ -78,29 +78,122 @@ def last_writer_per_bucket(buckets, writes):
 
 
 
+class TorchWireOps:
+    """pack / sum / unpack of the bf16 gradient wire as torch ops: the device-agnostic form (CPU tensors + gloo in the tests).
+    TrainEngine passes ops.HipWireOps instead (micf_grad_wire_pack / _sum / _unpack: no ATen kernel on the product path)."""
+
+    @staticmethod
+    def pack(src, dst):                       # fp32 [n] -> bf16 [padded], zero tail
+        n = src.numel()
+        dst[:n].copy_(src)
+        if dst.numel() > n:
+            dst[n:].zero_()
+
+    @staticmethod
+    def sum_shards(recv, ranks, out):         # bf16 [ranks * shard] -> bf16 [shard]: fp32 sum in rank order, ONE rounding
+        acc = torch.zeros(out.numel(), dtype=torch.float32, device=out.device)
+        for r in range(ranks):
+            acc += recv[r * out.numel():(r + 1) * out.numel()].float()
+        out.copy_(acc)
+
+    @staticmethod
+    def unpack(src, dst):                     # bf16 [>= n] -> fp32 [n]
+        dst.copy_(src[:dst.numel()])
+
+
+class WireExchange:
+    """Sum of a slice of the flat gradient over the ranks with bf16 ON THE LINKS and fp32 IN THE SUMS -- xGMI-first: the links
+    are a point-to-point mesh (7 x ~153 GB/s per GPU), so the reduce-scatter is ONE all-to-all hop (shard j of every rank -> rank
+    j over its own link), rank j adds the N shards in fp32 and rounds the sum once, and one all-gather brings the reduced shards
+    back: the same 2 (N-1)/N bytes per element as a bf16 ring all-reduce, but an addend is rounded once and the sum once, instead
+    of a bf16 rounding at each of the ring's N - 1 partial sums (tests/test_dist_gloo.py::test_eight_rank_bf16_wire measures both).
+    Every rank receives the owner's bits: the reduced gradient is rank-identical.
+
+    On a GPU the whole pipeline of a slice (pack -> all-to-all -> sum -> all-gather -> unpack) is enqueued on a private stream
+    ordered after the caller's stream; the caller keeps launching and joins with finish()."""
+
+    def __init__(self, sync, flat_g, wire_ops=None):
+        self.sync, self.flat_g = sync, flat_g
+        self.ops = wire_ops if wire_ops is not None else TorchWireOps()
+        self.ranks = max(sync.world, 1)
+        self._bufs = {}
+        self.comm = torch.cuda.Stream(device=flat_g.device) if flat_g.is_cuda else None
+        self._busy = False
+
+    def _buffers(self, a, b):
+        buf = self._bufs.get((a, b))
+        if buf is None:
+            shard = (-(-(b - a) // self.ranks) + 7) // 8 * 8
+            mk = lambda n: torch.empty(n, dtype=torch.bfloat16, device=self.flat_g.device)
+            buf = self._bufs[(a, b)] = (shard, mk(self.ranks * shard), mk(self.ranks * shard), mk(shard))
+        return buf
+
+    def _pipeline(self, a, b):
+        shard, send, recv, own = self._buffers(a, b)
+        view = self.flat_g[a:b]
+        self.ops.pack(view, send)
+        dist.all_to_all_single(recv, send, group=self.sync.pg, async_op=True).wait()        # (a stream-level wait on RCCL)
+        self.ops.sum_shards(recv, self.ranks, own)
+        dist.all_gather_into_tensor(send, own, group=self.sync.pg, async_op=True).wait()
+        self.ops.unpack(send, view)
+
+    def start(self, a, b):
+        if self.comm is None:
+            self._pipeline(a, b)
+            return
+        self.comm.wait_stream(torch.cuda.current_stream(self.flat_g.device))
+        with torch.cuda.stream(self.comm):
+            self._pipeline(a, b)
+        self._busy = True
+
+    def finish(self):
+        if self._busy:
+            torch.cuda.current_stream(self.flat_g.device).wait_stream(self.comm)
+            self._busy = False
+
+
 class OverlappedGradReduce:
     """The data-parallel tail of a step, device-agnostic: the queued weight-gradient launches are issued group by
-    group and every slice of the flat gradient is sum-all-reduced right after the launch that writes into it last (slices
-    nothing queued writes to go first), so the collective runs under the remaining launches; then the optimiser consumes
+    group and every slice of the flat gradient is sum-reduced over the ranks right after the launch that writes into it last
+    (slices nothing queued writes to go first), so the exchange runs under the remaining launches; then the optimiser consumes
     the SUM with grad_scale = 1/world (the mean is never materialised).  TrainEngine drives it with HIP launches + RCCL;
     tests/test_dist_gloo.py drives the same object with CPU tensors + gloo."""
 
-    def __init__(self, sync, flat_g, buckets, bucket_last, wire=None):
-        """wire: optional bfloat16 buffer of flat_g's size -- the slices then cross the links as bf16 (half the bytes: 123 MB instead
-        of 247 MB at base): each slice is rounded into it, sum-reduced there, and widened back into flat_g after its wait."""
+    def __init__(self, sync, flat_g, buckets, bucket_last, wire=None, wire_ops=None):
+        """wire: None = the exact exchange (fp32 all-reduce of the slice in place); "bf16" = WireExchange (bf16 on the links, fp32
+        sums: half the bytes -- 123 MB instead of 247 MB per step at base); "bf16-ring" = the slice rounded to bf16 and
+        all-reduced IN bf16 by the backend (round 5's form: the ring's partial sums are rounded too; kept as the comparison)."""
+        if wire not in (None, "bf16", "bf16-ring"):
+            raise ValueError(f"unknown gradient wire {wire!r}")
         self.sync, self.flat_g, self.wire = sync, flat_g, wire
         self.buckets, self.bucket_last = list(buckets), list(bucket_last)
+        live = sync.world > 1 or sync.always
+        self.exchange = WireExchange(sync, flat_g, wire_ops) if (wire == "bf16" and live) else None
+        self.ring = torch.empty(flat_g.numel(), dtype=torch.bfloat16, device=flat_g.device) if (wire == "bf16-ring" and live) else None
+
+    def reduce_slice(self, a, b, works):
+        if self.exchange is not None:
+            self.exchange.start(a, b)
+        elif self.ring is not None:
+            self.ring[a:b].copy_(self.flat_g[a:b])
+            works.append((self.sync.allreduce_sum_async(self.ring[a:b]), a, b))
+        else:
+            w = self.sync.allreduce_sum_async(self.flat_g[a:b])
+            if w is not None:
+                works.append((w, None, None))
+
+    def join(self, works):
+        for w, a, b in works:
+            w.wait()
+            if a is not None:
+                self.flat_g[a:b].copy_(self.ring[a:b])
+        if self.exchange is not None:
+            self.exchange.finish()
 
     def _reduce_ready(self, gi, works):
         for (a, b), last in zip(self.buckets, self.bucket_last):
             if last == gi:
-                if self.wire is not None and (self.sync.world > 1 or self.sync.always):
-                    self.wire[a:b].copy_(self.flat_g[a:b])
-                    works.append((self.sync.allreduce_sum_async(self.wire[a:b]), a, b))
-                    continue
-                w = self.sync.allreduce_sum_async(self.flat_g[a:b])
-                if w is not None:
-                    works.append((w, None, None))
+                self.reduce_slice(a, b, works)
 
     def run(self, ngroups, launch_group, pre=None):
         works = []
@@ -110,10 +203,14 @@ class OverlappedGradReduce:
         for gi in range(ngroups):
             launch_group(gi)
             self._reduce_ready(gi, works)
-        for w, a, b in works:
-            w.wait()
-            if a is not None:
-                self.flat_g[a:b].copy_(self.wire[a:b])
+        self.join(works)
+
+    def reduce_all(self):
+        """Un-overlapped form (eager steps): every slice now, same arithmetic as run()."""
+        works = []
+        for a, b in self.buckets:
+            self.reduce_slice(a, b, works)
+        self.join(works)
 
     def step_tail(self, ngroups, launch_group, optimizer_step, pre=None):
         """flush + reduce, then optimizer_step(grad_scale) with grad_scale = 1 / world."""

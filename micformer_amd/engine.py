@@ -61,7 +61,7 @@ class TrainEngine:
         # parity mode exchanges fp32 again); an explicit bool is the caller's decision in every mode.
         self._grad_bf16_auto = grad_bf16 is None
         self._grad_bf16_set = bool(grad_bf16)
-        self._wire_buf = None
+        self._eager_exchange = {}
         # Graph layout of a captured step: ONE HIP graph (round 2; where its side branch runs is the graph executor's choice) or
         # a sequence of graphs replayed on two streams with explicit events (functional.StepSegmenter; opt-in, see _lib.py).
         # (needs the runtime's graph packet capture off, see _lib.GRAPH_SEGMENTS_OK: one graph otherwise)
@@ -88,19 +88,25 @@ class TrainEngine:
 
     @property
     def grad_bf16(self):
-        """Wire format of the gradient exchange of a step taken NOW (bf16 | fp32)."""
-        if not self._grad_bf16_auto:
-            return self._grad_bf16_set
-        return (self.world > 1 and ops.compute_dtype() == "bf16"
-                and __import__("os").environ.get("MICF_GRAD_WIRE", "bf16") != "fp32")
+        """Is the gradient exchange of a step taken NOW on the bf16 wire (else the exact fp32 all-reduce)?"""
+        return self.grad_wire is not None
 
     @property
-    def _wire(self):
-        if not self.grad_bf16:
+    def grad_wire(self):
+        """Wire format of the gradient exchange of a step taken NOW: None (exact fp32 all-reduce), "bf16" (bf16 on the links, fp32
+        in the sums: dist.WireExchange) or "bf16-ring" (MICF_GRAD_WIRE=bf16-ring: the backend's all-reduce IN bf16, round 5's form,
+        kept as the comparison)."""
+        env = __import__("os").environ.get("MICF_GRAD_WIRE", "bf16")
+        if not self._grad_bf16_auto:
+            on = self._grad_bf16_set
+        else:
+            on = self.world > 1 and ops.compute_dtype() == "bf16" and env != "fp32"
+        if not on:
             return None
-        if self._wire_buf is None:
-            self._wire_buf = torch.empty(self.flat_g.numel(), dtype=torch.bfloat16, device=self.flat_g.device)
-        return self._wire_buf
+        return "bf16-ring" if env == "bf16-ring" else "bf16"
+
+    def _exchange_for(self, buckets, bucket_last):
+        return OverlappedGradReduce(self.sync, self.flat_g, buckets, bucket_last, wire=self.grad_wire, wire_ops=ops.HipWireOps())
 
     # ------------------------------------------------------------------ flat parameter / gradient storage
     def _flatten(self):
@@ -489,7 +495,7 @@ class TrainEngine:
                 if t is not None:
                     writes.append((k // ops.GROUP_ITEMS, (t.data_ptr() - base) // 4, t.numel()))
         self._bucket_last = last_writer_per_bucket(self._buckets, writes)
-        self._overlap = OverlappedGradReduce(self.sync, self.flat_g, self._buckets, self._bucket_last, wire=self._wire)
+        self._overlap = self._exchange_for(self._buckets, self._bucket_last)
 
     def _flush_and_reduce(self, then_update=False):
         """Launch the queued weight gradients group by group; all-reduce every slice of the flat gradient right after the
@@ -518,18 +524,15 @@ class TrainEngine:
         return loss
 
     def _allreduce_grads(self):
-        """Gradient all-reduce(sum) over RCCL/xGMI in a few large buckets of the flat buffer (the 1/world goes into Adam)."""
-        buf, wire = self.flat_g, self._wire
-        if wire is not None:
-            wire.copy_(self.flat_g)
-            buf = wire
-        works = [self.sync.allreduce_sum_async(buf[s:s + self.sync.bucket_elems])
-                 for s in range(0, buf.numel(), self.sync.bucket_elems)]
-        for w in works:
-            if w is not None:
-                w.wait()
-        if wire is not None:
-            self.flat_g.copy_(wire)
+        """Un-overlapped gradient exchange of an eager step: the same per-stage slices and the same arithmetic as the replayed
+        step's (dist.OverlappedGradReduce.reduce_all), every slice at once; the 1/world goes into Adam."""
+        mode = self.grad_wire
+        ex = self._eager_exchange.get(mode)
+        if ex is None:
+            names = [n for n, _ in self.model.named_parameters()]
+            buckets = module_buckets(names, self.offsets, self.sizes, self.flat_g.numel())
+            ex = self._eager_exchange[mode] = self._exchange_for(buckets, [-1] * len(buckets))
+        ex.reduce_all()
 
     def step(self, x, target):
         """Run one training step; returns the (device) loss of this rank's batch."""

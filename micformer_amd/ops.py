@@ -899,6 +899,29 @@ def adam_step(p, g, m, v, state, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.
          cost=_cost(12 * p.numel(), p, p, g, m, m, v, v))
 
 
+class HipWireOps:
+    """The three streaming kernels of the bf16 gradient wire (dist.WireExchange: bf16 on the links, fp32 in the sums) as C-ABI
+    launches on the current stream -- the product counterpart of dist.TorchWireOps."""
+
+    @staticmethod
+    def pack(src, dst):
+        if dst.dtype != torch.bfloat16 or dst.numel() % 8 or dst.numel() < src.numel():
+            raise _lib.MicfError("gradient wire: the bf16 buffer must hold the slice padded to a multiple of 8")
+        call("micf_grad_wire_pack", f32(src), src.numel(), ptr(dst), dst.numel(), cost=_cost(0, src, dst))
+
+    @staticmethod
+    def sum_shards(recv, ranks, out):
+        if recv.numel() != ranks * out.numel() or out.numel() % 8:
+            raise _lib.MicfError("gradient wire: recv must be [ranks, shard] with shard a multiple of 8")
+        call("micf_grad_wire_sum", ptr(recv), int(ranks), out.numel(), ptr(out), cost=_cost(ranks * out.numel(), recv, out))
+
+    @staticmethod
+    def unpack(src, dst):
+        if src.numel() < dst.numel():
+            raise _lib.MicfError("gradient wire: source shorter than the slice")
+        call("micf_grad_wire_unpack", ptr(src), f32(dst), dst.numel(), cost=_cost(0, dst, dst))
+
+
 # ----------------------------------------------------------------------------- fused window-local transformer block
 _DT = {"fp32": 0, "bf16": 1}
 

@@ -34,7 +34,7 @@ def parse_header():
 
 def test_header_declares_expected_entry_points():
     d = parse_header()
-    assert len(d) == 95, sorted(d)          # (93 product entry points + the round-5 measurement probe + the MFMA hazard probe)
+    assert len(d) == 98, sorted(d)          # (96 product entry points + the round-5 measurement probe + the MFMA hazard probe)
     assert all(sig.endswith("p") for n, sig in d.items()
                if n not in ("micf_abi_version", "micf_strerror", "micf_linear_bwd_weight_workspace",
                             "micf_linear_bwd_weight_grouped_workspace", "micf_conv3_bwd_data_workspace",

@@ -169,3 +169,23 @@ def test_bench_real_engine_four_ranks_on_one_gpu():
     assert out["n_gpus"] == 4 and out["rccl_ranks"] == 4 and out["distinct_local_devices"] == 1 and out["grad_wire"] == "fp32"
     assert out["config"]["global_batch"] == 8 and out["config"]["parallelism"] == "dp4" and out["dtype"] == "fp32"
     assert 0.0 < out["final_loss"] < 0.8 and "roofline" in out
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_eight_ranks_on_one_gpu():
+    """BASELINE config 3's rank count before the driver's 8-GPU run: `python bench.py --gpus 8` self-launched, all 8 ranks on the
+    box's one MI355X (gloo on device tensors), base model on 64^3 pairs in the bf16 mode -- i.e. the DEFAULT gradient wire of the
+    8-GPU run (bf16 on the links, fp32 in the sums: 8-way all-to-all + all-gather per slice through the HIP pack / sum / unpack
+    kernels), the 8-rank bucket plan, capture under a live group, post-replay groups, MAX-over-ranks timing, `rccl_ranks: 8`."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--vol", "64",
+           "--dist-backend", "gloo", "--no-cpu-baseline", "--no-roofline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=850, env=dict(env, HSA_ENABLE_IPC_MODE_LEGACY="0"), cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["rccl_ranks"] == 8 and out["distinct_local_devices"] == 1 and out["grad_wire"] == "bf16"
+    assert out["config"]["global_batch"] == 16 and out["config"]["parallelism"] == "dp8" and out["dtype"] == "bf16"
+    assert 0.0 < out["final_loss"] < 0.8 and out["value"] > 0 and "roofline" not in out

@@ -170,6 +170,96 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
             assert float(got["g_sum"][o:o + P[n].numel()].abs().max()) == 0.0
 
 
+def _wire_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from micformer_amd.dist import FlatGradSync, OverlappedGradReduce, flatten_views, module_buckets
+    from oracle import fill
+    cfg, P, _, _, R = _tiny_setup()
+    names = list(P)
+    offs, total = flatten_views([P[n] for n in names])
+    sizes = [P[n].numel() for n in names]
+    # realistic per-rank gradients: the SAME weights, rank r's own CT+MR pair (sample r of an 8-pair batch) -- the addends of a
+    # data-parallel step are correlated but not equal, which is what decides how much a rounded partial sum loses
+    x = fill.make_volume(world, 24, 24, 24)[rank:rank + 1]
+    t = fill.one_hot(fill.make_label_map(world, 24, 24, 24))[rank:rank + 1]
+    _, g = _flat_grads(R, cfg, P, x, t, names, offs, total)
+    sync = FlatGradSync()
+    buckets = module_buckets(names, offs, sizes, total, min_elems=4000)
+    res = {}
+    for mode in (None, "bf16", "bf16-ring"):
+        flat = g.clone()
+        OverlappedGradReduce(sync, flat, buckets, [-1] * len(buckets), wire=mode).reduce_all()
+        res[mode or "fp32"] = flat
+        # every rank must hold the same bits (the weights stay rank-identical): compare with rank 0's
+        ref = flat.clone()
+        dist.broadcast(ref, src=0)
+        assert torch.equal(ref, flat), f"wire {mode}: rank {rank} differs from rank 0"
+    if rank == 0:
+        torch.save({"res": res, "buckets": buckets, "own": g}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_eight_rank_bf16_wire(tmp_path):
+    """BASELINE config 3's rank count on CPU: 8 gloo ranks drive dist.OverlappedGradReduce on per-rank oracle gradients (one CT+MR
+    pair each) in the three wire modes.  The default wire ("bf16": bf16 on the links, fp32 in the sums -- all-to-all, fp32 add,
+    all-gather) must stay within 2^-8 of the exact fp32 exchange per stage group (relative L2) and within 2^-7 of a group's largest
+    entry elementwise, must not be worse than the backend's all-reduce IN bf16 (round 5's wire: a rounding at every partial sum),
+    and every rank must end with identical bits.  The measured errors are printed (DESIGN.md section 5 quotes them)."""
+    out = str(tmp_path / "wire.pt")
+    mp.spawn(_wire_worker, args=(8, _free_port(), out), nprocs=8, join=True)
+    got = torch.load(out)
+    exact = got["res"]["fp32"].double()
+    assert float(exact.abs().max()) > 0
+    rows = []
+    for a, b in got["buckets"]:
+        ref = exact[a:b]
+        row = []
+        for mode in ("bf16", "bf16-ring"):
+            d = got["res"][mode][a:b].double() - ref
+            row.append((float(d.norm() / ref.norm().clamp_min(1e-300)), float(d.abs().max() / ref.abs().max().clamp_min(1e-300))))
+        rows.append(((a, b), row))
+    print("\n8-rank gradient wire vs the exact fp32 exchange, per stage group: relative L2 / max-abs over the group's largest entry")
+    for (a, b), ((l2n, mxn), (l2r, mxr)) in rows:
+        print(f"  slice [{a:7d}, {b:7d}): bf16 links + fp32 sums {l2n:.2e} / {mxn:.2e}   all-reduce in bf16 {l2r:.2e} / {mxr:.2e}")
+    for (a, b), ((l2n, mxn), (l2r, mxr)) in rows:
+        assert l2n <= 2.0 ** -8, f"slice [{a}, {b}): bf16 wire with fp32 sums off by {l2n:.3e} (relative L2)"
+        assert mxn <= 2.0 ** -7, f"slice [{a}, {b}): bf16 wire with fp32 sums off by {mxn:.3e} of the largest entry"
+        assert l2n <= l2r * 1.05 + 1e-12, f"slice [{a}, {b}): fp32 sums ({l2n:.3e}) worse than bf16 partial sums ({l2r:.3e})"
+    # one addend only ever sees ONE rounding before the sum: a single rank's own gradient survives to 2^-9 relative per element
+    # where it dominates -- and the dead parameters stay exact zeros through pack / all-to-all / sum / all-gather / unpack
+    cfg, P, _, _, R = _tiny_setup()
+    from micformer_amd.dist import flatten_views
+    names = list(P)
+    offs, _ = flatten_views([P[n] for n in names])
+    for n, o in zip(names, offs):
+        if n.startswith("swin.concat_back_dim.0."):
+            for mode in ("fp32", "bf16", "bf16-ring"):
+                assert float(got["res"][mode][o:o + P[n].numel()].abs().max()) == 0.0
+
+
+def test_wire_exchange_one_rank_is_two_roundings_at_most():
+    """dist.WireExchange on a single-rank group (the `always` hook): pack -> all-to-all -> fp32 sum -> all-gather -> unpack of one
+    addend = bf16 rounding of the slice, bit for bit (the sum of one bf16 value re-rounds to itself), incl. the zero-padded tail."""
+    sys.path.insert(0, ROOT)
+    from micformer_amd.dist import FlatGradSync, OverlappedGradReduce
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        g = torch.randn(1003, generator=torch.Generator().manual_seed(5))
+        flat = g.clone()
+        OverlappedGradReduce(FlatGradSync(always=True), flat, [(0, 500), (500, 1003)], [-1, -1], wire="bf16").reduce_all()
+        assert torch.equal(flat, g.bfloat16().float())
+    finally:
+        dist.destroy_process_group()
+
+
 def test_flatten_views_alignment():
     sys.path.insert(0, ROOT)
     from micformer_amd.dist import flatten_views

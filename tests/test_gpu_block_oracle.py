@@ -1,0 +1,223 @@
+"""The fused block launches DIRECTLY against the oracle: micf_block_fwd / micf_block_bwd in the benched
+arithmetic mode -- the wave-private kernels of the 32^3 stage (C = 48) on a real 2 x 65536-token launch, and the tile kernels they
+replace -- against oracle.self_block / cross_block evaluated with `oracle.bf16_operands()`: the SAME algorithm with the operands of
+every matrix product rounded to bf16 at the points the kernels round them (LN outputs, sampled K/V source, weights, q * scale, k, v,
+P, attention output, GELU output; the adjoint's dY operands), fp32 everywhere else.
+
+What can still differ is (a) fp32 summation order and the hardware exp / erf forms (1e-6-class) and (b) a bf16 rounding that falls
+the other way where (a) moved a value across a tie: ONE operand element off by one bf16 step (2^-8 of its size), which moves a few
+downstream values by up to ~1e-2 of the tensor's scale.  Running the oracle itself in fp32 and in fp64 shows exactly that
+signature (tools/scratch calibration, 2 x 32^3 tokens): at most 0.3 % of a tensor's elements (1.2 % of a gradient's) further than
+1e-4 of the scale apart, at most 0.05 % (0.3 %) of the bf16-stored values more than one bf16 step apart, worst element 4e-3 of the
+scale.  The gates below are those numbers with headroom; a kernel that rounds at another point, drops a term or mis-indexes a row
+moves EVERY element and fails all three.
+"""
+import math
+
+import pytest
+import torch
+
+from test_gpu_block_fused import make_params, rnd
+
+pytestmark = pytest.mark.gpu
+
+C, HEADS, EPS = 48, 3, 1e-5
+
+
+@pytest.fixture()
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from micformer_amd import ops as o
+    o.set_compute_dtype("bf16")
+    yield o
+    o.set_compute_dtype("fp32")
+
+
+def _cpu(P):
+    return {k: v.detach().cpu() for k, v in P.items()}
+
+
+def _tok(aux_w, dims, width):
+    """(nW, 8, width) window-ordered capture -> [T, width] in token order."""
+    from oracle import micformer_ref as R
+    B, D, H, W = dims
+    return R._from_windows(aux_w, (2, 2, 2), B, D, H, W).reshape(-1, width)
+
+
+class Report:
+    """Collects (name, statistics) rows and the failed gates; printed in full so a run documents the measured distances."""
+
+    def __init__(self):
+        self.rows, self.bad = [], []
+
+    def add(self, name, got, want, frac_gate, bf16=False, far=1e-4, worst=2e-2, exact=False):
+        got, want = got.detach().double().cpu(), want.detach().double().cpu()
+        assert got.shape == want.shape, f"{name}: shape {tuple(got.shape)} vs {tuple(want.shape)}"
+        assert torch.isfinite(got).all(), f"{name}: non-finite"
+        scale = max(float(want.abs().max()), 1e-30)
+        d = (got - want).abs()
+        l2 = float(d.norm() / want.norm().clamp_min(1e-300))
+        mx = float(d.max()) / scale
+        frac_far = float((d > far * scale).double().mean())
+        row = f"  {name:12s} scale {scale:9.3e}  rel-L2 {l2:8.2e}  worst {mx:8.2e}  further than {far:.0e} of the scale: {frac_far:8.2e}"
+        if bf16:
+            wb = want.float().bfloat16().double()          # (the kernel stored bf16: compare with the oracle's value rounded the same way)
+            step = 2.0 ** -7 * torch.maximum(got.abs(), wb.abs())
+            frac_step = float(((got - wb).abs() > step * 1.0001 + 1e-30).double().mean())
+            row += f"  more than one bf16 step: {frac_step:8.2e}"
+            if frac_step > frac_gate:
+                self.bad.append(f"{name}: {frac_step:.2e} of the bf16 values more than one step from the oracle (gate {frac_gate:.0e})")
+        elif frac_far > frac_gate:
+            self.bad.append(f"{name}: {frac_far:.2e} of the elements further than {far:.0e} of the scale (gate {frac_gate:.0e})")
+        if mx > worst:
+            self.bad.append(f"{name}: worst element {mx:.2e} of the scale (gate {worst:.0e})")
+        if exact and mx > 1e-5:
+            self.bad.append(f"{name}: {mx:.2e} (an fp32 quantity with no rounded operand upstream: gate 1e-5)")
+        self.rows.append(row)
+
+    def done(self, title):
+        print("\n" + title + "\n" + "\n".join(self.rows))
+        assert not self.bad, "\n".join(self.bad)
+
+
+def _oracle_block(R, x, kv_given, P, attn, s1, s2):
+    """oracle.self_block, generalised to a GIVEN K/V source (the window-local part of a cross block once the sampling is done):
+    composed from the oracle's own primitives; with kv_given None it IS oracle.self_block (asserted below)."""
+    B, D, H, W, _ = x.shape
+    ws = (2, 2, 2)
+    xn = R._cap("xn", R.layer_norm(x, P["norm1.weight"], P["norm1.bias"], EPS))
+    src = xn if kv_given is None else R._cap("xs", kv_given)
+    a = R.window_attention(R._to_windows(xn, ws), R._to_windows(src, ws), P, attn + ".", HEADS)
+    x1 = R._cap("x1", x + R._scale_per_sample(R._from_windows(a, ws, B, D, H, W), s1))
+    y = R.mlp(R._cap("xn2", R.layer_norm(x1, P["norm2.weight"], P["norm2.bias"], EPS)), P, "mlp.")
+    return x1 + R._scale_per_sample(y, s2)
+
+
+def _make_groups(dims, kind, scales):
+    B, D, H, W = dims
+    T = B * D * H * W
+    attn = "self_attn" if kind == "self" else "cross_attn"
+    gs = []
+    for i in range(2):
+        P = make_params(C, 4 * C, attn, 20 + 40 * i)
+        gd = {"x": rnd((T, C), 3 + i), "kvsrc": rnd((T, C), 11 + i) if kind == "cross" else None, "P": P, "attn": attn,
+              "s1": (torch.rand(B, generator=torch.Generator().manual_seed(5 + i)) + 0.5).cuda() if scales else None,
+              "s2": (torch.rand(B, generator=torch.Generator().manual_seed(7 + i)) + 0.5).cuda() if scales else None}
+        gs.append(gd)
+    return gs
+
+
+@pytest.mark.parametrize("wave", [True, False])
+@pytest.mark.parametrize("kind", ["self", "cross"])
+@pytest.mark.parametrize("dims", [(2, 32, 32, 32), (1, 2, 6, 2)])
+def test_block_launches_against_the_oracle(ops, monkeypatch, dims, kind, wave):
+    """Forward (y + every saved tensor + LayerNorm statistics) and backward (dx, the K/V-source gradient, the second dx1 copy, the
+    five weight-gradient operands dq / dkv / dh / dx1 / dy16, LayerNorm gain / bias sums) of a self pair and of a cross pair with a
+    given K/V source; two groups per launch, DropPath scales, and an odd window count (3 windows: a half-empty 16-token group)."""
+    from oracle import micformer_ref as R
+    monkeypatch.setenv("MICF_BLOCK_WAVE", "1" if wave else "0")
+    B, D, H, W = dims
+    T = B * D * H * W
+    scale = (C // HEADS) ** -0.5
+    cross = kind == "cross"
+    gs = _make_groups(dims, kind, scales=B > 1)
+    fw = ops.block_fwd([dict(g) for g in gs], dims, C, HEADS, EPS, scale)
+    dys = [rnd((T, C), 50 + i) for i in range(2)]
+    bg = [{"dy": dys[i], "x": None if cross else g["x"], "x1": o["x1"], "stats": o["stats"], "q": o["q"], "kv": o["kv"], "h": o["h"],
+           "xn2": o["xn2"], "P": g["P"], "attn": g["attn"], "s1": g["s1"], "s2": g["s2"], "cross": cross, "want_copy": cross}
+          for i, (g, o) in enumerate(zip(gs, fw))]
+    bw = ops.block_bwd([dict(g) for g in bg], dims, C, HEADS, scale)
+    torch.cuda.synchronize()
+    rep = Report()
+    for i, (g, o, b) in enumerate(zip(gs, fw, bw)):
+        P = _cpu(g["P"])
+        x = g["x"].cpu().reshape(B, D, H, W, C).requires_grad_(True)
+        kv_given = g["kvsrc"].cpu().reshape(B, D, H, W, C).requires_grad_(True) if cross else None
+        s1 = g["s1"].cpu() if g["s1"] is not None else None
+        s2 = g["s2"].cpu() if g["s2"] is not None else None
+        leaves = {k: v.clone().requires_grad_(True) for k, v in P.items() if k.startswith("norm")}
+        Pq = dict(P, **leaves)
+        with R.bf16_operands(), R.capture() as aux:
+            y = _oracle_block(R, x, kv_given, Pq, g["attn"], s1, s2)
+            (y * dys[i].cpu().reshape(y.shape)).sum().backward()
+            if not cross and i == 0:
+                assert torch.equal(y.detach(), R.self_block(x.detach(), P, "", HEADS, (2, 2, 2), s1, s2, EPS)), "helper != oracle.self_block"
+        n = f"g{i}."
+        # ---- forward
+        rep.add(n + "y", o["y"], y.reshape(T, C), 1e-2)
+        rep.add(n + "x1", o["x1"], aux["x1"].reshape(T, C), 1e-2)
+        rep.add(n + "LN1 mean", o["stats"][0], x.detach().reshape(T, C).mean(1), 0.0, exact=True)
+        rep.add(n + "LN1 rstd", o["stats"][1], (x.detach().reshape(T, C).var(1, unbiased=False) + EPS).rsqrt(), 0.0, exact=True)
+        x1o = aux["x1"].detach().reshape(T, C)
+        rep.add(n + "LN2 mean", o["stats"][2], x1o.mean(1), 1e-2)
+        rep.add(n + "LN2 rstd", o["stats"][3], (x1o.var(1, unbiased=False) + EPS).rsqrt(), 1e-2)
+        if o.get("xn") is not None:
+            rep.add(n + "xn", o["xn"].float(), aux["xn"].reshape(T, C), 1e-4, bf16=True)
+        rep.add(n + "q", o["q"].float(), _tok(aux["q_w"], dims, C), 3e-3, bf16=True)
+        rep.add(n + "kv", o["kv"].float(), _tok(aux["kv_w"], dims, 2 * C), 3e-3, bf16=True)
+        rep.add(n + "o", o["o"].float(), _tok(aux["o_w"], dims, C), 3e-3, bf16=True)
+        rep.add(n + "xn2", o["xn2"].float(), aux["xn2"].reshape(T, C), 3e-3, bf16=True)
+        rep.add(n + "h", o["h"].float(), aux["h"].reshape(T, 4 * C), 3e-3, bf16=True)
+        rep.add(n + "g", o["g"].float(), aux["g"].reshape(T, 4 * C), 3e-3, bf16=True)
+        # ---- backward (the kernel ran on ITS OWN saved tensors, as in a step)
+        if cross:
+            rep.add(n + "dxn (q path)", b["dx"], aux["xn"].grad.reshape(T, C), 6e-2)
+            rep.add(n + "dxs", b["dxs"], kv_given.grad.reshape(T, C), 6e-2)
+            rep.add(n + "dx1 copy", b["dx1_copy"], aux["x1"].grad.reshape(T, C), 6e-2)
+        else:
+            rep.add(n + "dx", b["dx"], x.grad.reshape(T, C), 6e-2)
+            part = b["ln1_part"].double().sum(0)
+            rep.add(n + "d ln1 gain", part[:C], leaves["norm1.weight"].grad, 1.0, worst=5e-3)
+            rep.add(n + "d ln1 bias", part[C:], leaves["norm1.bias"].grad, 1.0, worst=5e-3)
+        part = b["ln2_part"].double().sum(0)
+        rep.add(n + "d ln2 gain", part[:C], leaves["norm2.weight"].grad, 1.0, worst=5e-3)
+        rep.add(n + "d ln2 bias", part[C:], leaves["norm2.bias"].grad, 1.0, worst=5e-3)
+        rep.add(n + "dq", b["dq"].float(), _tok(aux["q_w"].grad, dims, C), 1e-2, bf16=True)
+        rep.add(n + "dkv", b["dkv"].float(), _tok(aux["kv_w"].grad, dims, 2 * C), 1e-2, bf16=True)
+        rep.add(n + "dh", b["dh"].float(), aux["h"].grad.reshape(T, 4 * C), 1e-2, bf16=True)
+        rep.add(n + "dx1", b["dx1"].float(), aux["x1"].grad.reshape(T, C), 1e-2, bf16=True)
+        rep.add(n + "dy16", b["dy16"].float(), dys[i], 0.0, bf16=True, worst=4e-3)
+    rep.done(f"{'wave-private' if wave else 'tile'} kernels, {kind} pair, dims {dims}: distance to the oracle in bf16-operand mode")
+
+
+@pytest.mark.parametrize("wave", [True, False])
+@pytest.mark.parametrize("dims", [(2, 32, 32, 32), (1, 4, 6, 2)])
+def test_cross_launch_with_fused_sampling_against_the_oracle(ops, monkeypatch, dims, wave):
+    """The cross pair as the step launches it: the conv_offset[0] output in, LayerNorm(16) -> GELU -> 1^3 conv -> reference points
+    (permuted divisors) -> trilinear sampling of the raw other modality INSIDE the block launch, then the block.  oracle.cross_block
+    (MS.py:339-426) end to end; the kernel is handed the oracle's own conv output (the 3^3 conv is a separate launch)."""
+    from oracle import micformer_ref as R
+    monkeypatch.setenv("MICF_BLOCK_WAVE", "1" if wave else "0")
+    B, D, H, W = dims
+    T = B * D * H * W
+    scale = (C // HEADS) ** -0.5
+    gs, ref = [], []
+    for i in range(2):
+        P = make_params(C, 4 * C, "cross_attn", 20 + 40 * i)
+        P.update({"conv_offset.0.weight": rnd((16, 2 * C, 3, 3, 3), 41 + i, 1.0 / math.sqrt(27 * 2 * C)), "conv_offset.0.bias": rnd((16,), 42 + i, 0.1),
+                  "conv_offset.1.norm.weight": 1 + rnd((16,), 31 + i, 0.1), "conv_offset.1.norm.bias": rnd((16,), 32 + i, 0.1),
+                  "conv_offset.3.weight": rnd((3, 16, 1, 1, 1), 33 + i, 0.3)})
+        x, xa = rnd((T, C), 3 + i), rnd((T, C), 15 + i)
+        Pc = _cpu(P)
+        with R.bf16_operands(), R.capture() as aux:
+            y = R.cross_block(x.cpu().reshape(B, D, H, W, C), xa.cpu().reshape(B, D, H, W, C), Pc, "", HEADS, (2, 2, 2), None, None, EPS)
+        ref.append((y, aux))
+        Pk = dict(P)
+        Pk["conv_offset.3.weight"] = P["conv_offset.3.weight"].reshape(3, 16).contiguous()
+        gs.append({"x": x, "kvsrc": None, "P": Pk, "attn": "cross_attn", "s1": None, "s2": None, "want_xn": False,
+                   "hid": aux["hid"].reshape(T, 16).contiguous().cuda(), "samp_src": xa})
+    fw = ops.block_fwd([dict(g) for g in gs], dims, C, HEADS, EPS, scale)
+    torch.cuda.synchronize()
+    rep = Report()
+    for i, (o, (y, aux)) in enumerate(zip(fw, ref)):
+        n = f"g{i}."
+        rep.add(n + "flow", o["flow"], aux["flow"].reshape(T, 3), 0.0, exact=True)
+        rep.add(n + "kvs16", o["kvs16"].float(), aux["xs"].reshape(T, C), 1e-3, bf16=True)
+        rep.add(n + "q", o["q"].float(), _tok(aux["q_w"], dims, C), 3e-3, bf16=True)
+        rep.add(n + "kv", o["kv"].float(), _tok(aux["kv_w"], dims, 2 * C), 3e-3, bf16=True)
+        rep.add(n + "o", o["o"].float(), _tok(aux["o_w"], dims, C), 3e-3, bf16=True)
+        rep.add(n + "x1", o["x1"], aux["x1"].reshape(T, C), 1e-2)
+        rep.add(n + "h", o["h"].float(), aux["h"].reshape(T, 4 * C), 3e-3, bf16=True)
+        rep.add(n + "y", o["y"], y.reshape(T, C), 1e-2)
+    rep.done(f"{'wave-private' if wave else 'tile'} kernels, cross pair with the sampling fused in, dims {dims}")

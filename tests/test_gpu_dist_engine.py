@@ -151,3 +151,33 @@ def test_two_rank_engine_default_wire_in_the_bench_configuration(tmp_path):
     assert float((ga - ge).abs().max()) <= 2 ** -7 * float(ge.abs().max())
     assert float((ga - ge).abs().max()) > 0
     assert abs(a0["losses"][1] - e0["losses"][1]) <= 1e-4, (a0["losses"], e0["losses"])
+
+
+def test_hip_wire_kernels_bit_exact_against_torch():
+    """micf_grad_wire_pack / _sum / _unpack (the three kernels of the default 8-GPU gradient wire) against dist.TorchWireOps, the
+    form the CPU gloo tests drive: RNE rounding to bf16 incl. ties / subnormal-range values / signed zeros, the zero-padded tail,
+    the fp32 sum of 8 shards in rank order rounded ONCE, the widening -- bit for bit, at sizes with ragged tails."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from micformer_amd import ops
+    from micformer_amd.dist import TorchWireOps
+    g = torch.Generator().manual_seed(11)
+    for n, ranks in ((8, 1), (1003, 8), (4096 * 9 + 5, 8), (200_003, 4)):
+        src = torch.randn(n, generator=g) * torch.logspace(-12, 3, n)
+        src[: min(n, 6)] = torch.tensor([0.0, -0.0, 1.00390625, -1.01171875, 3.0e-39, 65504.0])[: min(n, 6)]   # ties, a tiny value
+        shard = (-(-n // ranks) + 7) // 8 * 8
+        a = torch.empty(ranks * shard, dtype=torch.bfloat16)
+        TorchWireOps.pack(src, a)
+        b = torch.empty(ranks * shard, dtype=torch.bfloat16, device="cuda")
+        ops.HipWireOps.pack(src.cuda(), b)
+        assert torch.equal(a.view(torch.int16), b.cpu().view(torch.int16)), f"pack n={n}"
+        recv = (torch.randn(ranks * shard, generator=g) * 3).bfloat16()
+        own_t = torch.empty(shard, dtype=torch.bfloat16)
+        TorchWireOps.sum_shards(recv, ranks, own_t)
+        own_h = torch.empty(shard, dtype=torch.bfloat16, device="cuda")
+        ops.HipWireOps.sum_shards(recv.cuda(), ranks, own_h)
+        assert torch.equal(own_t.view(torch.int16), own_h.cpu().view(torch.int16)), f"sum n={n}"
+        out_t, out_h = torch.empty(n), torch.empty(n, device="cuda")
+        TorchWireOps.unpack(a, out_t)
+        ops.HipWireOps.unpack(b, out_h)
+        assert torch.equal(out_t, out_h.cpu()), f"unpack n={n}"

@@ -52,6 +52,14 @@ typedef void* micf_stream_t; /* hipStream_t */
 int micf_abi_version(void);
 const char* micf_strerror(int code);
 
+/* TEST HOOKS / MEASUREMENT PROBES, process-global, never set by the product path (csrc/common.h struct Options lists them with
+ * their defaults and meanings): "block_wave", "block_recompute_h", "block_debug", "sample_tile", "sample_e", "cell_cap",
+ * "tile_cap_hits", "tile_cap_cell", "tile_cap_voxel".  A hook selects a slower equivalent kernel or shrinks a capacity so an
+ * overflow path runs (the parity tests); a probe skips work (timing only).  Unknown name: MICF_EINVAL.  Not thread-safe: set
+ * between launches. */
+int micf_set_option(const char* name, int value);
+int micf_get_option(const char* name, int* value);
+
 /* ---- LayerNorm over the last dim, eps inside rsqrt (nn.LayerNorm: MS.py:308,321,461,468,540,569,987,988).
  * Row r of the input is [x1[r, 0:c1] | x2[r, 0:C-c1]] (x2 may be NULL with c1 == C); the two-source form
  * replaces torch.cat([moving, fixed], -1) + norm2 (MS.py:1033-1034).  mean/rstd [rows] are saved for backward. */
@@ -535,8 +543,8 @@ typedef struct micf_block_bwd_group {
   const float* pre_g;    /* [C] its gain */
   float* pre_part;       /* out [tiles, 2C]: per-tile partial dgamma | dbeta of that LayerNorm (micf_layernorm_bwd_finish) */
 } micf_block_bwd_group;
-/* != 0: the caller should pass h == NULL in both groups structs (see there).  Only with MICF_BLOCK_RECOMPUTE_H=1 in the
- * environment and only for the tile-per-workgroup kernels (everything but the few-token decomposition at C = 384): a memory
+/* != 0: the caller should pass h == NULL in both groups structs (see there).  Only with the option "block_recompute_h" set
+ * (micf_set_option) and only for the tile-per-workgroup kernels (everything but the few-token decomposition at C = 384): a memory
  * switch (8 of the 34 saved bytes per element), not a speed one -- the extra GEMM phase of the backward costs more time than the
  * bytes save. */
 int micf_block_recomputes_h(int C, int heads);

@@ -245,6 +245,10 @@ def _load():
     lib.micf_block_recomputes_h.argtypes = [_I] * 2
     lib.micf_strerror.argtypes = [_I]
     lib.micf_strerror.restype = ctypes.c_char_p
+    lib.micf_set_option.argtypes = [ctypes.c_char_p, _I]
+    lib.micf_set_option.restype = _I
+    lib.micf_get_option.argtypes = [ctypes.c_char_p, ctypes.POINTER(_I)]
+    lib.micf_get_option.restype = _I
     lib.micf_abi_version.argtypes = []
     lib.micf_abi_version.restype = _I
     if lib.micf_abi_version() != 1:
@@ -253,6 +257,36 @@ def _load():
 
 
 lib = _load()
+
+
+def get_option(name):
+    """Current value of a library test hook / probe (include/micformer_hip.h micf_set_option; csrc/common.h struct Options)."""
+    v = _I(0)
+    if lib.micf_get_option(name.encode(), ctypes.byref(v)) != 0:
+        raise KeyError(f"unknown micformer option {name!r}")
+    return v.value
+
+
+def set_option(name, value):
+    """Set a test hook / probe of the library; returns the previous value.  Never called by the product path."""
+    prev = get_option(name)
+    if lib.micf_set_option(name.encode(), int(value)) != 0:
+        raise KeyError(f"unknown micformer option {name!r}")
+    return prev
+
+
+class option:
+    """with option("block_wave", 0): ...   -- a hook for the duration of a block (tests, measurement scripts)."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.prev = set_option(self.name, self.value)
+
+    def __exit__(self, *exc):
+        set_option(self.name, self.prev)
+        return False
 
 
 def ptr(t):

@@ -87,7 +87,7 @@ __device__ __forceinline__ void attn16_fp8(const float* qp, const float* kp, con
 // ---- the same unit with bf16 operands (MICF_DTYPE_BF16's default attention on the block kernels, round 4): v_mfma_f32_16x16x16_bf16
 // (k = 16: one product per 16 channels of the head for S^T, and -- the 16 keys being exactly one k range -- the accumulator quad of
 // S^T IS the P^T operand of O^T = V^T P^T: no exchange between the lanes at all).  q * scale, k, v and P are rounded to bf16 (RNE)
-// where they enter a fragment, fp32 accumulation; the VALU form kept q / k / v / P in fp32 (MICF_ATTN_VALU=1 restores it).
+// where they enter a fragment, fp32 accumulation; the VALU form (the fp32 parity mode) keeps q / k / v / P in fp32.
 typedef short bf16x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bf16x4_t pack4_bf16v(float a, float b, float c, float d) {
   const unsigned lo = pack_bf16(a, b), hi = pack_bf16(c, d);

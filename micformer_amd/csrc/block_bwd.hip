@@ -260,11 +260,9 @@ __device__ __forceinline__ void ln_bwd_tile(const float* D, float* A, int S, con
   lds_barrier();
 }
 
-#ifndef MICF_BWD48_WGS
-#define MICF_BWD48_WGS 3
-#endif
+// (three resident workgroups per CU at C = 48 -- four spilled 7 registers and measured slower; two at C = 96 / 192 with 4-8 waves)
 template <int C, int HD, int TJ, int NW, bool BF16, bool RECOMP>
-__global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? MICF_BWD48_WGS : 2)) block_bwd_kernel(const BlkBwdArgs a) {
+__global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) block_bwd_kernel(const BlkBwdArgs a) {
   constexpr int TM = 16 * TJ, VPL = (C + 63) / 64, NSL = C / 16, NTHR = 64 * NW, RPP = 4 * NW, NPASS = (TM + RPP - 1) / RPP;
   constexpr bool PARK = block_bwd_park_floats(TM, C, NTHR) != 0;
   extern __shared__ __attribute__((aligned(1024))) float lds[];
@@ -447,17 +445,13 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? MICF_BWD48_W
     }
     lds_barrier();
   } else
-  // fp32 (parity) mode / MICF_ATTN_BWD_VALU=1: thread = (window, row i, head, half of the head's channels); batches of whole
+  // fp32 (parity) mode: thread = (window, row i, head, half of the head's channels); batches of whole
   // windows.  Where a tile has fewer (row, head) pairs than half the workgroup (C = 48: 96 of 256 threads), 2 or 4 adjacent
   // lanes share a pair: each owns HD / 2 or HD / 4 channels and the partial dot products meet in cross-lane adds.
   {
     // (C = 96 at 32 tokens: 192 pairs on 256 threads would run whole 16-channel head rows per lane -- 80 registers of dq / dk / dv /
     //  q / do rows on top of the parked LayerNorm-1 inputs: 24 spilled.  Two lanes per pair in two batches of 2 windows instead.)
-#ifdef MICF_AB_SP1
-    constexpr bool kSplit96 = false;
-#else
     constexpr bool kSplit96 = C == 96 && TM == 32 && HD == 16;
-#endif
     constexpr int heads = C / HD, SP = (TM * heads * 4 <= NTHR && HD >= 16) ? 4 : (TM * heads * 2 <= NTHR || kSplit96) ? 2 : 1,
                   HP = HD / SP, per = 8 * heads * SP, wpb = NTHR / per;
     float* PS = ring;                                   // [(row, head) pair][16]: P row | dS row
@@ -673,29 +667,26 @@ extern "C" int micf_block_bwd(const micf_block_bwd_group* groups, int ngroups, i
   a.geo = make_tile_geo(B, D, H, W);
   a.G = ngroups; a.C = C; a.heads = heads; a.hidden = hidden; a.scale = scale;
   a.tiles = (a.geo.nwin + TM / 8 - 1) / (TM / 8);
-  static const bool attn_valu = [] { const char* e = getenv("MICF_ATTN_BWD_VALU"); return e && atoi(e) != 0; }();
-  a.attn_mfma = (dtype == MICF_DTYPE_BF16 && !attn_valu) ? 1 : 0;
+  a.attn_mfma = dtype == MICF_DTYPE_BF16 ? 1 : 0;          // (the attention adjoint on the matrix cores in the bf16 modes; VALU in the fp32 parity mode)
   hipStream_t s = (hipStream_t)stream;
   const int hd = C / heads, tj = TM / 16;
   // rows are addressed relative to the tile's first token with 32-bit byte offsets: a tile of TM / 8 consecutive windows spans
   // fewer than 2 H W (TM / 8 + 1) tokens
   if ((int64_t)2 * H * W * (TM / 8 + 1) * hidden * (int64_t)sizeof(float) >= (int64_t)1 << 32) return MICF_EUNSUPPORTED;
   if (block_wide_tile_tokens(C, hd)) return block_bwd_wide(groups, ngroups, B, D, H, W, C, heads, scale, dtype, s);
-  // the C = 48 stages in bf16 mode: one wave per 32-token tile, nothing exchanged through LDS (block_wave_bwd.h); MICF_BLOCK_WAVE=0
-  // restores the tile-per-workgroup kernel (which also keeps the fp32 mode, the VALU attention adjoint and the recomputed h)
+  // the C = 48 stages in bf16 mode: one wave per 32-token tile, nothing exchanged through LDS (block_wave_bwd.h); the test hook
+  // "block_wave" = 0 keeps the tile-per-workgroup kernel (which also serves the fp32 mode and the recomputed h)
   {
-    const char* wv = getenv("MICF_BLOCK_WAVE");                // (read per call: the parity tests run both kernels in one process)
-    if ((!wv || atoi(wv) != 0) && C == 48 && hd == 16 && tj == 2 && dtype == MICF_DTYPE_BF16 && a.attn_mfma && a.g[0].h && a.g[1].h && (a.g[0].dxs != nullptr) == (a.g[1].dxs != nullptr) &&
+    if (options().block_wave != 0 && C == 48 && hd == 16 && tj == 2 && dtype == MICF_DTYPE_BF16 && a.attn_mfma && a.g[0].h && a.g[1].h && (a.g[0].dxs != nullptr) == (a.g[1].dxs != nullptr) &&
         (a.g[0].pre_d != nullptr) == (a.g[1].pre_d != nullptr) && !(a.g[0].dxs && a.g[0].pre_d) &&
         a.geo.T * (int64_t)hidden * 2 < ((int64_t)1 << 31))
     {
-      const char* dbg = getenv("MICF_BLOCK_DEBUG");          // (measurement: bit 0 = the wave kernel stores nothing)
-      if (dbg && (atoi(dbg) & 1)) a.attn_mfma |= 2;
+      if (options().block_debug & 1) a.attn_mfma |= 2;         // (probe: the wave kernel stores nothing)
       return wave48::launch_bwd_wave48(a, s);
     }
   }
 #define MICF_BB(C_, HD_, TJ_) if (C == C_ && hd == HD_ && tj == TJ_) return launch_bwd<C_, HD_, TJ_>(a, dtype, s)
-  MICF_BB(48, 16, 2); MICF_BB(48, 16, 1); MICF_BB(96, 16, 1); MICF_BB(96, 16, 2); MICF_BB(192, 16, 1);
+  MICF_BB(48, 16, 2); MICF_BB(96, 16, 2); MICF_BB(192, 16, 1);
   MICF_BB(96, 32, 1); MICF_BB(192, 32, 1);
 #undef MICF_BB
   return MICF_EUNSUPPORTED;

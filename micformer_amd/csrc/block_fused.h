@@ -329,13 +329,7 @@ constexpr int block_bwd_park_floats(int TM, int C, int nthr) { return C <= 48 ? 
 // share a CU's LDS (C <= 96), all 4C at C = 192 (one workgroup per CU either way: two GEMM phases and a GELU pass fewer per tile,
 // each a barrier-to-barrier round trip in a kernel that is bound by exactly those)
 // (fwd: the forward kernel's choice; the backward's LDS also holds the attention exchange and the parked LayerNorm inputs)
-#ifdef MICF_AB_HC2C              // (A/B build: the two-chunk form everywhere)
-constexpr int block_hidden_chunk(int C, bool fwd = false, int TM = 0) { return 2 * C; }
-#elif defined(MICF_AB_HC4_TM16)  // (A/B build: one chunk also on 16-token tiles of the narrow stages)
-constexpr int block_hidden_chunk(int C, bool fwd = false, int TM = 0) { return (C >= 192 || TM == 16) ? 4 * C : 2 * C; }
-#else
 constexpr int block_hidden_chunk(int C, bool fwd = false, int TM = 0) { return C >= 192 ? 4 * C : 2 * C; }
-#endif
 // columns of the U tile: q | k | v (3C) or a hidden chunk, whichever is wider
 constexpr int block_u_cols(int C, bool fwd = false, int TM = 0) {
   return block_hidden_chunk(C, fwd, TM) > 3 * C ? block_hidden_chunk(C, fwd, TM) : 3 * C;
@@ -370,12 +364,8 @@ __device__ __forceinline__ T* at32(T* base, uint32_t byte_off) {
 // Outputs are written once and read by LATER kernels only: non-temporal stores keep them from evicting the block's weights
 // (0.9 MB per XCD at C = 192, re-read by every workgroup) out of the 4 MB L2 while the kernel runs.
 __device__ __forceinline__ void st4g(float* p, const float4& v) {
-#ifdef MICF_PLAIN_STORES
-  *reinterpret_cast<float4*>(p) = v;
-#else
   typedef float f32x4_nt __attribute__((ext_vector_type(4)));
   __builtin_nontemporal_store(f32x4_nt{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4_nt*>(p));
-#endif
 }
 // four values as bf16 (round-to-nearest-even) in 8 bytes and back: the saved fc1 pre-activation of the bf16 mode
 __device__ __forceinline__ uint2 pack4_bf16(const float4& v) { return make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w)); }
@@ -384,12 +374,8 @@ __device__ __forceinline__ float4 unpack4_bf16(const uint2& u) {
                      __uint_as_float(u.y & 0xFFFF0000u));
 }
 __device__ __forceinline__ void st2g(void* p, const uint2& v) {          // non-temporal, like st4g
-#ifdef MICF_PLAIN_STORES
-  *reinterpret_cast<uint2*>(p) = v;
-#else
   typedef unsigned u32x2_nt __attribute__((ext_vector_type(2)));
   __builtin_nontemporal_store(u32x2_nt{v.x, v.y}, reinterpret_cast<u32x2_nt*>(p));
-#endif
 }
 // store / load 4 consecutive elements of the saved pre-activation at element offset `e` (multiple of 4)
 template <bool BF16> __device__ __forceinline__ void st_h4(void* h, int64_t e, const float4& v) {

@@ -23,7 +23,7 @@ struct BlkFwdArgs {
   micf_block_fwd_group g[2];
   TileGeo geo;
   int G, tiles, C, heads, hidden, debug;
-  int att8;                 // attention products on the matrix cores (attn_fp8.h): 0 = VALU (fp32 mode; MICF_ATTN_VALU=1), 1 = bf16
+  int att8;                 // attention products on the matrix cores (attn_fp8.h): 0 = VALU (the fp32 parity mode), 1 = bf16
                             // operands (MICF_DTYPE_BF16), 2 = e4m3 operands (MICF_DTYPE_BF16_ATTN_FP8)
   float eps, scale;
 };
@@ -485,11 +485,6 @@ extern "C" int micf_block_tile_tokens(int B, int D, int H, int W, int C, int hea
   if (C == 48 && hd == 16) tj = 2;
   else if (C == 96 && hd == 16) tj = backward ? 2 : 1;
   else if ((C == 96 || C == 192) && (hd == 16 || hd == 32)) tj = 1;
-  if (const char* e = getenv(backward ? "MICF_BLOCK_TJ_BWD" : "MICF_BLOCK_TJ")) {
-    const int v = atoi(e);
-    if (C == 48 && hd == 16 && (v == 1 || v == 2)) tj = v;      // (64-token tiles were compiled until round 5: 54-205 spilled registers in the backward, never the faster shape)
-    if (C == 96 && hd == 16 && (v == 1 || v == 2)) tj = v;
-  }
   return 16 * tj;
 }
 
@@ -503,8 +498,7 @@ extern "C" int micf_block_recomputes_h(int C, int heads) {
   // opt-in: measured on MI355X (base shapes, bf16, batch 2) the extra GEMM phase costs more than the bytes save -- block_bwd
   // 123 -> 135 us at 32^3, 45 -> 52 at 16^3, 34 -> 42 at 8^3, forward unchanged (its stores are fire-and-forget), step 10.35 ->
   // 10.44 ms -- so the default stores h.  What the switch buys is MEMORY: 8 of the 34 bytes saved per element of T * C.
-  const char* e = getenv("MICF_BLOCK_RECOMPUTE_H");
-  return (e && atoi(e) != 0) ? 1 : 0;
+  return options().block_recompute_h != 0 ? 1 : 0;
 }
 
 extern "C" int micf_block_saves_bf16(int C, int heads, int dtype) {
@@ -521,8 +515,7 @@ extern "C" int micf_block_fwd(const micf_block_fwd_group* groups, int ngroups, i
   if (att8) dtype = MICF_DTYPE_BF16;                     // everything but the two attention products is the bf16 mode
   if (dtype != MICF_DTYPE_F32 && dtype != MICF_DTYPE_BF16) return MICF_EINVAL;
   BlkFwdArgs a;
-  static const bool attn_valu = [] { const char* e = getenv("MICF_ATTN_VALU"); return e && atoi(e) != 0; }();
-  a.att8 = att8 ? 2 : ((dtype == MICF_DTYPE_BF16 && !attn_valu) ? 1 : 0);
+  a.att8 = att8 ? 2 : (dtype == MICF_DTYPE_BF16 ? 1 : 0);     // (attention on the matrix cores in both bf16 modes; VALU in the fp32 parity mode)
   // INFERENCE FORM: every saved-tensor pointer of every group NULL -> the launch writes y only (4 instead of 40 bytes per element of
   // T * C in bf16 mode); tile-per-workgroup and wave-private kernels (not the few-token decomposition, which re-reads its own saves)
   int nosave = -1;
@@ -558,20 +551,18 @@ extern "C" int micf_block_fwd(const micf_block_fwd_group* groups, int ngroups, i
   a.geo = make_tile_geo(B, D, H, W);
   a.G = ngroups; a.C = C; a.heads = heads; a.hidden = hidden; a.eps = eps; a.scale = scale;
   a.tiles = (a.geo.nwin + TM / 8 - 1) / (TM / 8);
-  const char* dbg = getenv("MICF_BLOCK_DEBUG");
-  a.debug = dbg ? atoi(dbg) : 0;
+  a.debug = options().block_debug;
   if (nosave == 1) a.debug |= 1;
   hipStream_t s = (hipStream_t)stream;
   const int hd = C / heads, tj = TM / 16;
   if (block_wide_tile_tokens(C, hd)) return block_fwd_wide(groups, ngroups, B, D, H, W, C, heads, eps, scale, att8 ? MICF_DTYPE_BF16_ATTN_FP8 : dtype, s);   // (the few-token F1: attention on the matrix cores in both bf16 modes)
-  // the C = 48 stages in bf16 mode: one wave per 16 tokens, nothing exchanged through LDS (block_wave_fwd.h); MICF_BLOCK_WAVE=0
-  // restores the tile-per-workgroup kernel (which also keeps the fp32 mode, the fp8 attention and the debug switches)
-  const char* wv = getenv("MICF_BLOCK_WAVE");                  // (read per call: the parity tests run both kernels in one process)
-  if ((!wv || atoi(wv) != 0) && C == 48 && hd == 16 && dtype == MICF_DTYPE_BF16 && a.att8 == 1 && !(a.debug & ~17) &&
+  // the C = 48 stages in bf16 mode: one wave per 16 tokens, nothing exchanged through LDS (block_wave_fwd.h); the test hook
+  // "block_wave" = 0 keeps the tile-per-workgroup kernel (which also serves the fp32 mode, the fp8 attention and the probe flags)
+  if (options().block_wave != 0 && C == 48 && hd == 16 && dtype == MICF_DTYPE_BF16 && a.att8 == 1 && !(a.debug & ~17) &&
       a.geo.T * (int64_t)C * 4 < ((int64_t)1 << 32))          // (the fused sampling addresses its tap rows with 32-bit byte offsets)
     return wave48::launch_fwd_wave48(a, s);
 #define MICF_BF(C_, HD_, TJ_) if (C == C_ && hd == HD_ && tj == TJ_) return launch_fwd<C_, HD_, TJ_>(a, dtype, s)
-  MICF_BF(48, 16, 2); MICF_BF(48, 16, 1); MICF_BF(96, 16, 1); MICF_BF(96, 16, 2); MICF_BF(192, 16, 1);
+  MICF_BF(48, 16, 2); MICF_BF(96, 16, 1); MICF_BF(192, 16, 1);
   MICF_BF(96, 32, 1); MICF_BF(192, 32, 1);
 #undef MICF_BF
   return MICF_EUNSUPPORTED;

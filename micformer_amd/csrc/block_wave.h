@@ -38,20 +38,11 @@ __device__ __forceinline__ float sum4(float v) {          // over the 4 lane gro
   v += __shfl_xor(v, 16, 64);
   return v + __shfl_xor(v, 32, 64);
 }
-#ifdef MICF_WAVE_NT
-__device__ __forceinline__ void st4u(void* p, const bf16x8& v) {
-  __builtin_nontemporal_store(__builtin_bit_cast(u32x4v, v), reinterpret_cast<u32x4v*>(p));
-}
-__device__ __forceinline__ void st2u(void* p, const bf16x4_t& v) {
-  __builtin_nontemporal_store(__builtin_bit_cast(u32x2v, v), reinterpret_cast<u32x2v*>(p));
-}
-#else
 // PLAIN stores: a lane writes 8 or 16 bytes of a token row and the rest of the 128-byte line follows from other instructions of the
 // same wave up to a head's worth of work later -- the write-back L2 merges them; streaming (nt) stores went out as partial lines
-// (measured: 121 us instead of ... for the launch).  The weights live in LDS here, so there is nothing in L2 to protect.
+// (measured: 121 us instead of 51 us for the forward launch).  The weights live in LDS here, so there is nothing in L2 to protect.
 __device__ __forceinline__ void st4u(void* p, const bf16x8& v) { *reinterpret_cast<u32x4v*>(p) = __builtin_bit_cast(u32x4v, v); }
 __device__ __forceinline__ void st2u(void* p, const bf16x4_t& v) { *reinterpret_cast<u32x2v*>(p) = __builtin_bit_cast(u32x2v, v); }
-#endif
 __device__ __forceinline__ bf16x4_t pack4q(const f32x4& v) { return pack4_bf16v(v[0], v[1], v[2], v[3]); }
 
 // a 48-wide fp32 token row in layout P: 12 values per lane (features 8 lr .. 8 lr + 7, then 32 + 4 lr .. + 3)

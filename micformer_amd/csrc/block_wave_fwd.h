@@ -20,12 +20,10 @@
 
 #include "block_wave.h"
 
-#ifndef MICF_WAVE_TB
-#define MICF_WAVE_TB 8          // taps of a piece in flight in the fused sampling (A/B builds: 4)
-#endif
-
 namespace micf {
 namespace wave48 {
+
+constexpr int kTapBatch = 8;    // taps of a piece in flight in the fused sampling (4: measured the same)
 
 // LDS (bytes): fragments, then the fp32 parameter vectors
 constexpr int kQ32 = 0;                          // [9][64] x 16 B   q | k | v blocks, k = 0..31
@@ -95,7 +93,7 @@ __global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(4, 4)
   const int64_t T = a.geo.T;
   const int ngroup16 = (a.geo.nwin + 1) >> 1;
   const bool cross = g.kvsrc != nullptr || (SAMP && g.hid != nullptr);
-  const bool save = !(a.debug & 1), save_hg = !(a.debug & 17);      // (MICF_BLOCK_DEBUG: measurement switches, as in block_fwd_tile)
+  const bool save = !(a.debug & 1), save_hg = !(a.debug & 17);      // (the "block_debug" probe flags, as in block_fwd_tile; bit 0 is also the inference form)
   lds_barrier();
 
   // The inputs of a 16-token group: token ids, DropPath scales, the x rows and (cross) the K/V source rows -- given, or sampled here.
@@ -154,12 +152,12 @@ __global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(4, 4)
         const int co = pc < 2 ? 8 * lr + 4 * pc : 32 + 4 * lr;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int q0 = 0; q0 < 8; q0 += MICF_WAVE_TB) {              // (all 8 taps of a piece in flight: three dependent batches per token)
-          float4 tv[MICF_WAVE_TB];
+        for (int q0 = 0; q0 < 8; q0 += kTapBatch) {              // (all 8 taps of a piece in flight: three dependent batches per token)
+          float4 tv[kTapBatch];
 #pragma unroll
-          for (int q = 0; q < MICF_WAVE_TB; ++q) tv[q] = ld4g(at32(g.samp_src, ((row0 + (uint32_t)lin[q0 + q]) * C + co) * 4u));
+          for (int q = 0; q < kTapBatch; ++q) tv[q] = ld4g(at32(g.samp_src, ((row0 + (uint32_t)lin[q0 + q]) * C + co) * 4u));
 #pragma unroll
-          for (int q = 0; q < MICF_WAVE_TB; ++q) {                  // (an invalid tap contributes exact zeros, whatever the row it re-read holds: selects, no branches)
+          for (int q = 0; q < kTapBatch; ++q) {                  // (an invalid tap contributes exact zeros, whatever the row it re-read holds: selects, no branches)
             const bool ok = okq[q0 + q];
             const float wq = wgt[q0 + q];
             acc.x += (ok ? tv[q].x : 0.f) * wq; acc.y += (ok ? tv[q].y : 0.f) * wq; acc.z += (ok ? tv[q].z : 0.f) * wq; acc.w += (ok ? tv[q].w : 0.f) * wq;

@@ -689,7 +689,6 @@ static int launch_bwd(const BwdArgs& a, bool any_self, hipStream_t s) {
 // tokens per tile of the few-token path for this shape (0 = not handled here)
 int block_wide_tile_tokens(int C, int hd) {
   if (C == 384 && (hd == 16 || hd == 32)) return 16;
-  if (C == 192 && hd == 16 && getenv("MICF_BLOCK_WIDE")) return 16;   // (experiments: the 8^3 stage through this path)
   return 0;
 }
 
@@ -697,7 +696,6 @@ int block_wide_tile_tokens(int C, int hd) {
   do {                                                                                          \
     if (C == 384 && hd == 16) return bf ? FN<384, 16, true>(__VA_ARGS__) : FN<384, 16, false>(__VA_ARGS__); \
     if (C == 384 && hd == 32) return bf ? FN<384, 32, true>(__VA_ARGS__) : FN<384, 32, false>(__VA_ARGS__); \
-    if (C == 192 && hd == 16) return bf ? FN<192, 16, true>(__VA_ARGS__) : FN<192, 16, false>(__VA_ARGS__); \
   } while (0)
 
 int block_fwd_wide(const micf_block_fwd_group* groups, int ngroups, int B, int D, int H, int W, int C, int heads, float eps,
@@ -707,8 +705,7 @@ int block_fwd_wide(const micf_block_fwd_group* groups, int ngroups, int B, int D
   a.geo = make_tile_geo(B, D, H, W);
   a.G = ngroups; a.eps = eps; a.scale = scale;
   a.tiles = (a.geo.nwin + 1) / 2;
-  static const bool attn_valu = [] { const char* e = getenv("MICF_ATTN_VALU"); return e && atoi(e) != 0; }();
-  a.att8 = dtype == MICF_DTYPE_BF16_ATTN_FP8 ? 2 : ((dtype == MICF_DTYPE_BF16 && !attn_valu) ? 1 : 0);
+  a.att8 = dtype == MICF_DTYPE_BF16_ATTN_FP8 ? 2 : (dtype == MICF_DTYPE_BF16 ? 1 : 0);
   const int hd = C / heads;
   const bool bf = dtype == MICF_DTYPE_BF16 || dtype == MICF_DTYPE_BF16_ATTN_FP8;
   MICF_WIDE_DISPATCH(wide::launch_fwd, a, s);
@@ -728,8 +725,7 @@ int block_bwd_wide(const micf_block_bwd_group* groups, int ngroups, int B, int D
   a.tiles = (a.geo.nwin + 1) / 2;
   const int hd = C / heads;
   const bool bf = dtype == MICF_DTYPE_BF16;
-  static const bool attn_valu = [] { const char* e = getenv("MICF_ATTN_BWD_VALU"); return e && atoi(e) != 0; }();
-  a.attn_mfma = (bf && !attn_valu) ? 1 : 0;
+  a.attn_mfma = bf ? 1 : 0;
   MICF_WIDE_DISPATCH(wide::launch_bwd, a, any_self, s);
   return MICF_EUNSUPPORTED;
 }

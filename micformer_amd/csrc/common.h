@@ -13,6 +13,21 @@
 
 namespace micf {
 
+// Process-global TEST HOOKS and MEASUREMENT PROBES (micf_set_option / micf_get_option, misc.hip).  The product path never sets
+// one: the defaults below ARE the product.  A hook selects a slower but equivalent kernel (the parity cross-checks of
+// tests/test_gpu_block_wave.py / test_gpu_ops.py) or shrinks a capacity so that an overflow path runs; a probe computes WRONG
+// results on purpose (timing only).  Plain ints read at launch time: set them from one thread, between launches.
+struct Options {
+  int block_wave = 1;          // hook: 0 = the tile-per-workgroup block kernels also at C = 48 in bf16 mode (cross-check of the wave-private kernels)
+  int block_recompute_h = 0;   // MEMORY switch: 1 = the fused backward rebuilds the fc1 pre-activation instead of reading a saved copy
+  int block_debug = 0;         // PROBE: skip flags of the fused forward's phases; bit 0 = the launch stores nothing (wrong results)
+  int sample_tile = 1;         // hook: 0 = the sampler adjoint's d(xa) through the global cell lists / atomics of rounds 1-4
+  int sample_e = -1;           // hook: radius of the NEAR neighbourhood of the box gather (-1 = 3; 0 = every token takes the far path)
+  int cell_cap = -1;           // hook: capacity of a global cell list (-1 = kCellCap; smaller forces the overflow pass)
+  int tile_cap_hits = -1, tile_cap_cell = -1, tile_cap_voxel = -1;   // hook: capacities of the box gather's LDS lists (-1 = 512 / 12 / 6)
+};
+Options& options();
+
 // token <-> (b, d, h, w) on a channels-last grid
 struct Geo {
   int B, D, H, W;
@@ -45,7 +60,7 @@ struct CellLists {               // workspace carved by the launcher (all int32)
   int* ovf_count;                // [1]
   int* list;                     // [cells][kCellCap]
   int* ovf;                      // [T] tokens that did not fit their cell's list
-  int cap;                       // list entries actually used (kCellCap; smaller only under MICF_CELL_CAP, a test hook)
+  int cap;                       // list entries actually used (kCellCap; smaller only under the test hook "cell_cap")
   float* w8;                     // [T][8] trilinear weight of every corner of a listed token (written with the list entry: the
                                  // gather then costs one load per (voxel, token) instead of re-deriving the taps from the flow)
 };

@@ -271,8 +271,8 @@ static hipError_t launch_bwdx(BwdxArgs& a, hipStream_t stream) {
   const int64_t blocks = (int64_t)a.B * a.tiles_d * a.tiles_h * a.tiles_w;
   const int cts = a.O / 16;
   // many token tiles: 6 channel tiles per workgroup (the halo is staged once per 96 channels); few: 2, to spread over the CUs
-  static const int64_t nct6_min = [] { const char* e = getenv("MICF_CONV_BWD_NCT6_MIN"); return e ? (int64_t)atoll(e) : (int64_t)128; }();
-  if (blocks * ((cts + 5) / 6) >= nct6_min)
+  // (threshold swept in round 4: 128 workgroups)
+  if (blocks * ((cts + 5) / 6) >= 128)
     hipLaunchKernelGGL((conv3_bwdx_kernel<TW, 6, BF16>), dim3((unsigned)blocks, (cts + 5) / 6, a.ngroups), dim3(256), 0, stream, a);
   else
     hipLaunchKernelGGL((conv3_bwdx_kernel<TW, 2, BF16>), dim3((unsigned)blocks, (cts + 1) / 2, a.ngroups), dim3(256), 0, stream, a);

@@ -256,7 +256,7 @@ int conv3_fwd_x_groups(const Conv3FwdSet* sets, int n, int c1, int c2, int B, in
   const int64_t blocks = (int64_t)B * a.tiles_d * a.tiles_h * a.tiles_w;
   // enough token tiles: one workgroup walks all channel chunks; otherwise spread the chunks (atomic accumulation into y)
   int ysplit = 1;
-  static const int split_target = [] { const char* e = getenv("MICF_CONV_SPLIT_TARGET"); return e ? atoi(e) : 128; }();
+  constexpr int split_target = 128;       // workgroups aimed at on small grids (swept in round 4: 16 .. 1024)
   if (blocks < 256) { ysplit = (int)((split_target + blocks - 1) / blocks); if (ysplit > chunks) ysplit = chunks; if (ysplit < 1) ysplit = 1; }
   a.chunks_per_block = (chunks + ysplit - 1) / ysplit;
   ysplit = (chunks + a.chunks_per_block - 1) / a.chunks_per_block;

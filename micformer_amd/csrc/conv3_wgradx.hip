@@ -395,7 +395,7 @@ static WgxPlan wgx_plan(int B, int D, int H, int W, int Cin, int items = 1) {
   const int th = 64 / p.tw;
   const int ntiles = B * D * ((H + th - 1) / th) * ((W + p.tw - 1) / p.tw);
   p.slabs = (Cin + wCS - 1) / wCS;
-  static const int wg_target = [] { const char* e = getenv("MICF_CONV_WGRAD_WGS"); return e ? atoi(e) : 256; }();
+  constexpr int wg_target = 256;
   int groups = (wg_target + p.slabs * items - 1) / (p.slabs * items);   // ~one workgroup per CU over all items
   if (groups < 4) groups = 4 < ntiles ? 4 : ntiles;
   if (groups > ntiles) groups = ntiles;
@@ -433,29 +433,22 @@ int conv3_wgradx_items(const float* const* dy, const float* const* x1, const flo
   const int th = 64 / p.tw;
   a.tiles_d = D; a.tiles_h = (H + th - 1) / th; a.tiles_w = (W + p.tw - 1) / p.tw;
   a.tiles_per_group = p.tiles_per_group; a.groups = p.groups; a.slabs = p.slabs;
-  static const bool xcd_env = [] { const char* e = getenv("MICF_WGX_XCD"); return !e || e[0] != '0'; }();
-  a.xcd_order = (xcd_env && (p.slabs * p.groups) % 8 == 0) ? 1 : 0;
+  a.xcd_order = ((p.slabs * p.groups) % 8 == 0) ? 1 : 0;   // XCD-contiguous tile ranges
   static std::once_flag attr_once;       // > 64 KiB of dynamic LDS needs the opt-in once per process
   std::call_once(attr_once, [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgradx_kernel<16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgradx_kernel<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgradx_kernel<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgradx_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgradx_b16_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgradx_b16_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
   });
   const dim3 grid(p.slabs, p.groups, n);
   if (p.tw == 16) {
     constexpr int HALO = 3 * (4 + 2) * (16 + 2);
-    static const bool old_b16 = [] { const char* e = getenv("MICF_WGX_OLD"); return e && e[0] == '1'; }();
-    if (dtype == MICF_DTYPE_BF16 && !old_b16) hipLaunchKernelGGL((conv3_wgradx_b16_kernel<16>), grid, dim3(256), HALO * wRSB + 64 * wDYB, stream, a);
-    else if (dtype == MICF_DTYPE_BF16) hipLaunchKernelGGL((conv3_wgradx_kernel<16, true>), grid, dim3(256), sizeof(float) * (HALO * wXS + 64 * wDS), stream, a);
+    if (dtype == MICF_DTYPE_BF16) hipLaunchKernelGGL((conv3_wgradx_b16_kernel<16>), grid, dim3(256), HALO * wRSB + 64 * wDYB, stream, a);
     else hipLaunchKernelGGL((conv3_wgradx_kernel<16, false>), grid, dim3(256), sizeof(float) * (HALO * wXS + 64 * wDS), stream, a);
   } else {
     constexpr int HALO = 3 * (8 + 2) * (8 + 2);
-    static const bool old_b16 = [] { const char* e = getenv("MICF_WGX_OLD"); return e && e[0] == '1'; }();
-    if (dtype == MICF_DTYPE_BF16 && !old_b16) hipLaunchKernelGGL((conv3_wgradx_b16_kernel<8>), grid, dim3(256), HALO * wRSB + 64 * wDYB, stream, a);
-    else if (dtype == MICF_DTYPE_BF16) hipLaunchKernelGGL((conv3_wgradx_kernel<8, true>), grid, dim3(256), sizeof(float) * (HALO * wXS + 64 * wDS), stream, a);
+    if (dtype == MICF_DTYPE_BF16) hipLaunchKernelGGL((conv3_wgradx_b16_kernel<8>), grid, dim3(256), HALO * wRSB + 64 * wDYB, stream, a);
     else hipLaunchKernelGGL((conv3_wgradx_kernel<8, false>), grid, dim3(256), sizeof(float) * (HALO * wXS + 64 * wDS), stream, a);
   }
   if (hipGetLastError() != hipSuccess) return MICF_ELAUNCH;

@@ -4,6 +4,7 @@
 #include <hip/hip_fp16.h>
 
 #include "common.h"
+#include <string.h>
 
 namespace micf {
 
@@ -89,6 +90,37 @@ __global__ void __launch_bounds__(256) sw_normalize_kernel(float* __restrict__ o
 using namespace micf;
 
 extern "C" int micf_abi_version(void) { return MICF_ABI_VERSION; }
+
+micf::Options& micf::options() {
+  static Options o;
+  return o;
+}
+
+static int* option_slot(const char* name) {
+  if (!name) return nullptr;
+  Options& o = micf::options();
+  const struct { const char* n; int* v; } table[] = {
+      {"block_wave", &o.block_wave}, {"block_recompute_h", &o.block_recompute_h}, {"block_debug", &o.block_debug},
+      {"sample_tile", &o.sample_tile}, {"sample_e", &o.sample_e}, {"cell_cap", &o.cell_cap},
+      {"tile_cap_hits", &o.tile_cap_hits}, {"tile_cap_cell", &o.tile_cap_cell}, {"tile_cap_voxel", &o.tile_cap_voxel}};
+  for (const auto& e : table)
+    if (!strcmp(name, e.n)) return e.v;
+  return nullptr;
+}
+
+extern "C" int micf_set_option(const char* name, int value) {
+  int* slot = option_slot(name);
+  if (!slot) return MICF_EINVAL;
+  *slot = value;
+  return MICF_OK;
+}
+
+extern "C" int micf_get_option(const char* name, int* value) {
+  const int* slot = option_slot(name);
+  if (!slot || !value) return MICF_EINVAL;
+  *value = *slot;
+  return MICF_OK;
+}
 
 extern "C" const char* micf_strerror(int code) {
   switch (code) {

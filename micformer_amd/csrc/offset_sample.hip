@@ -136,12 +136,10 @@ __device__ __forceinline__ int cell_of(const Taps& tp, int b, int D, int H, int 
   return ((b * (D + 1) + (int)tp.z0 + 1) * (H + 1) + (int)tp.y0 + 1) * (W + 1) + (int)tp.x0 + 1;
 }
 
-#ifndef MICF_BWD4_TB
-#define MICF_BWD4_TB 8
-#endif
+constexpr int kBwd4TapBatch = 8;     // tap rows in flight per batch of the 4-tokens-per-wave adjoint
 // How d(xa) -- a scatter: the taps of neighbouring tokens collide -- is produced (template parameter MODE of the backward kernels):
 //   kScatter  every (tap, channel) term is a device-scope atomic add                     (no workspace; odd channel counts)
-//   kCells    tokens register in per-cell lists, sample_gather_kernel walks them         (round 1-4 path for >= 4096 tokens; MICF_SAMPLE_TILE=0)
+//   kCells    tokens register in per-cell lists, sample_gather_kernel walks them         (round 1-4 path for >= 4096 tokens; test hook "sample_tile" = 0)
 //   kTile     NEAR tokens (base cell within `near_e` voxels of the token's own position on every axis -- in this network the
 //             displacement is ref in (-1, 1) plus a small learned offset) contribute nothing here: sample_gather_tile_kernel
 //             finds them again by scanning a bounded neighbourhood of every output tile and sums their terms in LDS;
@@ -290,12 +288,12 @@ __device__ __forceinline__ void offset_sample_bwd4_body(
     for (int c = 4 * k; c < C; c += 64) {
       const float4 go = ld4(dxs + t * C + c);
 #pragma unroll
-      for (int q0 = 0; q0 < 8; q0 += MICF_BWD4_TB) {         // taps in flight per batch
-        float4 xv[MICF_BWD4_TB];
+      for (int q0 = 0; q0 < 8; q0 += kBwd4TapBatch) {         // taps in flight per batch
+        float4 xv[kBwd4TapBatch];
 #pragma unroll
-        for (int u = 0; u < MICF_BWD4_TB; ++u) xv[u] = ld4(xb + rowo[q0 + u] + c);
+        for (int u = 0; u < kBwd4TapBatch; ++u) xv[u] = ld4(xb + rowo[q0 + u] + c);
 #pragma unroll
-        for (int u = 0; u < MICF_BWD4_TB; ++u) {
+        for (int u = 0; u < kBwd4TapBatch; ++u) {
           const int q = q0 + u;
           const int dz = q >> 2, dy = (q >> 1) & 1, dx = q & 1;
           if (MODE == kScatter && live && ok[q]) {
@@ -490,11 +488,9 @@ __global__ void __launch_bounds__(256) offset_sample_bwd_kernel(const SampleBwdS
   offset_sample_bwd_body<MODE>(q.dxs, q.h, q.ln_g, q.ln_b, q.w1, q.xa, q.flow, q.dxa, q.dh, q.dln_g, q.dln_b, q.dw1, g, C, eps, tpw, q.cl,
                                q.partials, nwaves, near_e, blockIdx.x);
 }
-#ifndef MICF_BWD4_WAVES
-#define MICF_BWD4_WAVES 3          // (4 = a 128-register cap: 12 spills, same time once the tap loads are unconditional)
-#endif
+// (3 waves per SIMD; 4 = a 128-register cap: 12 spills, same time once the tap loads are unconditional)
 template <int MODE>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MICF_BWD4_WAVES, 8))) offset_sample_bwd4_kernel(const SampleBwdSets p, Geo g, int C, float eps, int tpw, int nwaves, int near_e) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) offset_sample_bwd4_kernel(const SampleBwdSets p, Geo g, int C, float eps, int tpw, int nwaves, int near_e) {
   const SampleBwdSet& q = p.s[blockIdx.y];
   offset_sample_bwd4_body<MODE>(q.dxs, q.h, q.ln_g, q.ln_b, q.w1, q.xa, q.flow, q.dxa, q.dh, q.dln_g, q.dln_b, q.dw1, g, C, eps, tpw, q.cl,
                                 q.partials, nwaves, near_e, blockIdx.x);
@@ -521,7 +517,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MICF_B
 constexpr int kHitCap = 512;       // hits per box (typical: 250-300 for 4 x 4 x 8)
 constexpr int kCellCap2 = 6;       // hit indices per cell of the box (typical: 1)
 constexpr int kVoxSeg = 12;        // entries per list segment; a voxel has two segments (typical: 8 entries per voxel)
-struct TileShape { int td, th, tw, e, nz, ny, nx, ntiles, hit_cap, seg_cap, cell_cap, whole; };   // *_cap: the constants above, less under MICF_TILE_CAP (test hook)
+struct TileShape { int td, th, tw, e, nz, ny, nx, ntiles, hit_cap, seg_cap, cell_cap, whole; };   // *_cap: the constants above, less under the test hooks "tile_cap_*"
 
 __device__ __forceinline__ float corner_weight(const float4& hr, int dz, int dy, int dx) {
   const float z0 = floorf(hr.y), y0 = floorf(hr.z), x0 = floorf(hr.w);
@@ -848,45 +844,30 @@ static bool use_cells(int64_t T) { return T >= 4096; }
 
 // Output-tile shape of sample_gather_tile_kernel for a grid: big grids take 4 x 4 x 8 voxels (the candidate box grown by E = 3 is
 // 10 x 10 x 14 tokens, 11 x the tile, 12 B each), small ones smaller boxes so that the launch still spreads over the chip.
-// false: MICF_SAMPLE_TILE=0 (then the cell lists / atomics take the grid).
+// false: test hook "sample_tile" = 0 (then the cell lists / atomics take the grid).
 static bool tile_shape(const Geo& g, int C, TileShape& ts, size_t& lds_bytes) {
-  const char* on = getenv("MICF_SAMPLE_TILE");              // (read per call: test hooks, like MICF_CELL_CAP)
-  if (on && atoi(on) == 0) return false;
-  static const int64_t tile_min = [] { const char* e = getenv("MICF_SAMPLE_TILE_MIN"); return e ? (int64_t)atoll(e) : (int64_t)0; }();
-  if (g.tokens() < tile_min) return false;
-  const char* ee = getenv("MICF_SAMPLE_E");                 // radius of the NEAR neighbourhood; 0 = every token takes the atomic path
-  const int e_env = ee ? atoi(ee) : 3;
+  const Options& opt = options();
+  if (opt.sample_tile == 0) return false;
+  const bool e_hook = opt.sample_e >= 0;                    // hook: radius of the NEAR neighbourhood; 0 = every token takes the far path
+  const int e_env = e_hook ? opt.sample_e : 3;
   const int64_t T = g.tokens();
   int td = 4, th = 4, tw = 8;
   if (T < 32768) td = 2;
   if (T < 4096) { th = 2; tw = 4; }
-  if (const char* de = getenv("MICF_TILE_DIMS")) {          // tuning hook: "td,th,tw[,min tokens]" for grids of at least that many tokens
-    int a = td, b2 = th, c2 = tw, mn = 0;
-    sscanf(de, "%d,%d,%d,%d", &a, &b2, &c2, &mn);
-    if (T >= mn && a > 0 && b2 > 0 && c2 > 0 && a * b2 * c2 <= 128) { td = a; th = b2; tw = c2; }
-  }
   ts.td = td < g.D ? td : g.D; ts.th = th < g.H ? th : g.H; ts.tw = tw < g.W ? tw : g.W;
   ts.e = e_env < 0 ? 0 : (e_env > 8 ? 8 : e_env);
   // a small sample (<= 512 tokens: the 8^3 / 4^3 stages): the candidate box is the whole sample (E = its largest extent) -- no far
-  // tokens exist, the hit list cannot overflow.  (MICF_TILE_WHOLE_MAX=4096 takes the 16^3 stage too -- a full hit list is handled
-  // inside the workgroup: 66 -> 61 us per pair alone, but 66 -> 85 us inside the step, where 4096 candidates per box contend with
-  // the side queue; the replayed step is the same within noise either way.)
-  static const int64_t whole_max = [] { const char* e = getenv("MICF_TILE_WHOLE_MAX"); return e ? (int64_t)atoll(e) : (int64_t)kHitCap; }();
-  ts.whole = (!ee && (int64_t)g.D * g.H * g.W <= whole_max) ? 1 : 0;
+  // tokens exist, the hit list cannot overflow.  (Taking the 16^3 stage too -- 4096 candidates per box, a full hit list handled
+  // inside the workgroup -- measured 66 -> 61 us per pair alone but 66 -> 85 us inside the step: not done.)
+  ts.whole = (!e_hook && (int64_t)g.D * g.H * g.W <= (int64_t)kHitCap) ? 1 : 0;
   if (ts.whole) ts.e = g.D > g.H ? (g.D > g.W ? g.D : g.W) : (g.H > g.W ? g.H : g.W);
   ts.nz = ceil_div(g.D, ts.td); ts.ny = ceil_div(g.H, ts.th); ts.nx = ceil_div(g.W, ts.tw);
   const int64_t nt = (int64_t)g.B * ts.nz * ts.ny * ts.nx;
   if (nt >= (1LL << 28)) return false;
   ts.ntiles = (int)nt;
-  // test hook: MICF_TILE_CAP="hits,segment,cell" shrinks the LDS lists to force their overflow paths (0: every hit / every voxel)
-  ts.hit_cap = kHitCap; ts.seg_cap = kVoxSeg; ts.cell_cap = kCellCap2;
-  if (const char* ce = getenv("MICF_TILE_CAP")) {
-    int a = kHitCap, b2 = kVoxSeg, c2 = kCellCap2;
-    sscanf(ce, "%d,%d,%d", &a, &b2, &c2);
-    ts.hit_cap = a < 0 ? 0 : (a > kHitCap ? kHitCap : a);
-    ts.seg_cap = b2 < 0 ? 0 : (b2 > kVoxSeg ? kVoxSeg : b2);
-    ts.cell_cap = c2 < 0 ? 0 : (c2 > kCellCap2 ? kCellCap2 : c2);
-  }
+  // test hooks "tile_cap_hits / _voxel / _cell" shrink the LDS lists to force their overflow paths (0: every hit / every voxel)
+  auto cap = [](int hook, int full) { return hook < 0 ? full : (hook > full ? full : hook); };
+  ts.hit_cap = cap(opt.tile_cap_hits, kHitCap); ts.seg_cap = cap(opt.tile_cap_voxel, kVoxSeg); ts.cell_cap = cap(opt.tile_cap_cell, kCellCap2);
   const size_t maxvox = (size_t)ts.td * ts.th * ts.tw, maxcell = (size_t)(ts.td + 1) * (ts.th + 1) * (ts.tw + 1);
   // 4 x 4 x 8: hits 8 KB + voxel lists 24 KB + counters 2 KB + cell lists 2.7 KB
   lds_bytes = (size_t)kHitCap * 16 + maxvox * 2 * kVoxSeg * 8 + maxvox * 2 * 4 + maxcell * 4 + 16 + maxcell * kCellCap2 * 2 + 16;
@@ -898,9 +879,8 @@ struct BwdShape { bool quad, tiles, fused; int tpw, wpb, blocks; TileShape ts; s
 static void bwd_shape(const Geo& g, int C, bool al, BwdShape& sh) {
   const int64_t T = g.tokens();
   // quad kernels (4 tokens per wave) when the channel rows allow 16-byte accesses
-  static const int64_t quad_min = [] { const char* e = getenv("MICF_SAMPLE_QUAD_MIN"); return e ? (int64_t)atoll(e) : (int64_t)4096; }();
-  sh.quad = T >= quad_min && (C % 4 == 0) && al;          // tiny grids: 1 token per wave
-  // d(xa): output boxes summed from LDS lists (kTile, every grid) | cell lists (MICF_SAMPLE_TILE=0, >= 4096 tokens) | atomics
+  sh.quad = T >= 4096 && (C % 4 == 0) && al;              // tiny grids: 1 token per wave
+  // d(xa): output boxes summed from LDS lists (kTile, every grid) | cell lists (hook "sample_tile" = 0, >= 4096 tokens) | atomics
   sh.tile_lds = 0;
   sh.tiles = (C % 4 == 0) && al && tile_shape(g, C, sh.ts, sh.tile_lds);
   sh.fused = sh.tiles && sh.ts.whole;                      // (one launch: 256-thread workgroups in both roles)
@@ -957,11 +937,8 @@ int micf::offset_sample_bwd_groups(SampleBwdSet* sets, int n, int B, int D, int 
   // (the counters of both groups are contiguous: one memset)
   int* counters = have_ws ? reinterpret_cast<int*>(workspace + n * partial_floats(T)) : nullptr;
   int* lists = counters ? counters + n * (nc + 4) : nullptr;
-  int cap = kCellCap;
-  if (const char* env = getenv("MICF_CELL_CAP")) {           // test hook: force the overflow pass
-    cap = atoi(env);
-    cap = cap < 0 ? 0 : (cap > kCellCap ? kCellCap : cap);
-  }
+  int cap = options().cell_cap;                             // test hook: a smaller list forces the overflow pass
+  cap = cap < 0 ? kCellCap : (cap > kCellCap ? kCellCap : cap);
   for (int i = 0; i < 2; ++i) {
     const int k = i < n ? i : 0;
     p.s[i] = sets[k];

@@ -50,7 +50,7 @@ class TrainEngine:
         # those slices of the flat gradient are complete when the replay ends and are all-reduced at once, under the remaining
         # (encoder) weight-gradient groups that are launched after the replay.  Measured on one GPU (data-parallel layout):
         # 0 -> 13.3 ms, 4 -> 12.9, 6 -> 12.8, all -> 12.7 (but then nothing is left to hide RCCL behind).
-        self.dp_graph_flushes = int(__import__("os").environ.get("MICF_DP_GRAPH_FLUSHES", dp_graph_flushes))
+        self.dp_graph_flushes = int(dp_graph_flushes)
         # bf16 wire format of the gradient exchange (123 MB instead of 247 MB per step at base): each slice is rounded to bf16,
         # sum-reduced, widened back; Adam still reads fp32.  Default (None): ON for world > 1 in the bf16 arithmetic mode -- the
         # budget of tools/dp_budget.py: at 8 ranks the fp32 exchange is ~1.65 ms of ring time against ~1 ms of
@@ -335,7 +335,7 @@ class TrainEngine:
                     self.ctx.wside_used.add(self.flat_p.device)
                 # (entry 3 = the 8^3 encoder stage, where the main chain leaves half the chip idle; it must not be later than the
                 #  backward preparation parked there, which waits for the last group's event)
-                _fn.park_entry_hook(launch_carried_groups, at=min(3, int(__import__("os").environ.get("MICF_CARRY_AT", "3"))))
+                _fn.park_entry_hook(launch_carried_groups, at=3)
             else:
                 conv.launch()                                       # offset-conv weight layouts (one small launch)
                 if fwd is not None:                                 # K16-blocked block weights, next to the patch embedding

@@ -186,7 +186,7 @@ def _ln_defer(on):
 # gradients queued so far on a side stream, so they run under the rest of the backward chain (which is latency-bound, not
 # throughput-bound, since the blocks were fused) instead of in a tail after it.  join_wgrad_stream() re-joins before Adam.
                                     # allows the first few only: the rest stays queued for the launches that overlap the all-reduce)
-FLUSH_MAX_TOKENS = int(__import__("os").environ.get("MICF_FLUSH_MAX_TOKENS", 1 << 30))   # (measured: flushing at every point wins, 19.6 vs 20.2 ms small stages only)
+FLUSH_MAX_TOKENS = 1 << 30   # (measured: flushing at every point wins, 19.6 vs 20.2 ms small stages only)
 _WSIDE = {}
 
 
@@ -201,8 +201,8 @@ def _wgrad_stream(device):
 # main chain's next kernel moved to another hardware queue and started 130-190 us late (rocprofv3 kernel trace of the 8^3
 # stage's backward).  So the flush is launched lazily: the point only records an event on the main stream and sets the batch
 # aside; the batch goes to the side stream (waiting for that event) once the main chain has launched its next kernel -- i.e.
-# when the next entry is queued.  Measured 13.9 -> 13.4 ms per step (MICF_LAZY_FLUSH=0 restores the eager order).
-LAZY_FLUSH = __import__("os").environ.get("MICF_LAZY_FLUSH", "1") != "0"
+# when the next entry is queued.  Measured 13.9 -> 13.4 ms per step (LAZY_FLUSH = False restores the eager order).
+LAZY_FLUSH = True
 
 
 # Segmented capture (TrainEngine(segmented=True)): instead of ONE HIP graph whose executor decides on which hardware queue the
@@ -496,7 +496,7 @@ class FlushPointFn(torch.autograd.Function):
         return dx, dxa, None
 
 
-GROUP_CONV_WGRAD = __import__("os").environ.get("MICF_GROUP_CONV_WGRAD", "1") != "0"
+GROUP_CONV_WGRAD = True
 
 
 def _defer_conv_wgrad(ok, dhid, xn, xa, dw, db, dims):
@@ -951,7 +951,7 @@ def _fusable(dims, C, heads, window, P):
 
 
 import os as _os
-FUSE_BLOCKS = _os.environ.get("MICF_FUSE_BLOCKS", "1") != "0"   # off = the round-1 per-op launch sequence everywhere
+FUSE_BLOCKS = True   # off = the round-1 per-op launch sequence everywhere
 
 
 def _queue_block_wgrads(side, P, G, attn, sv, bo, dy, xn, kv_in, s1, s2, rps):
@@ -989,7 +989,7 @@ def _self_fwd_fused(xs, Ps, scales, dims, heads, eps, save=True):
 # what the LayerNorm backward needs here; micf_block_bwd runs it as its prologue (micf_block_bwd_group.pre_d).  24 launches and
 # a [T, C] round trip per slot off the chain.  Only BasicLayer's self -> cross sequence sets it up (`lazy_ln` of CrossPairFn), only
 # while an engine step scopes CTX.lazy_ln_ok, and the engine checks after backward that nothing parked was left unconsumed.
-LAZY_LN_DEFAULT = __import__("os").environ.get("MICF_LAZY_LN", "1") != "0"
+LAZY_LN_DEFAULT = True
 
 
 def lazy_ln_pending():
@@ -1099,10 +1099,10 @@ _CSV_KEYS = ("q", "kv", "o", "x1", "xn2", "h", "g", "stats", "xn", "kvs16")     
 # the second one runs on a side stream (a fork / join in the captured graph), as round 1 did for whole blocks.
 OVERLAP_CROSS_HEADS = True
 # ... superseded by the grouped entry points: both heads of a pair in every launch (micf_offset_head_fwd / _bwd)
-GROUP_CROSS_HEADS = _os.environ.get("MICF_GROUP_HEADS", "1") != "0"
+GROUP_CROSS_HEADS = True
 # ... and the sampling half of the head (LayerNorm-16 / GELU / 1^3 conv / reference points / trilinear gather) inside the cross
 # pair's block_fwd launch: one launch and one [T, C] round trip less per cross pair
-FUSE_SAMPLER = _os.environ.get("MICF_FUSE_SAMPLER", "1") != "0"
+FUSE_SAMPLER = True
 
 
 def _conv_offset_wgrad(side, dhid, xn, xa, G, dims):
@@ -1268,7 +1268,7 @@ class CrossPairFn(torch.autograd.Function):
 
 
 # ============================================================================= patch embed / merging / expand / head
-PATCH_GEMM = __import__("os").environ.get("MICF_PATCH_GEMM", "1") != "0"
+PATCH_GEMM = True
 class PatchEmbedFn(torch.autograd.Function):
     """PatchEmbed3D (MS.py:860-878) on modality `mod` of vol [B, nmod, D, H, W] -> (B, D', H', W', E) channels-last."""
 
@@ -1356,7 +1356,7 @@ class PatchEmbedPairFn(torch.autograd.Function):
 # its backward runs as soon as the concat linear's backward has produced the skip gradient -- long before this stage's
 # PatchMerging backward, which depends on it through the whole deeper network), whose backward parks the gradient in the token
 # and returns None (no second gradient path for autograd to sum); ConvDownFn.backward adds it inside its depth-to-space scatter.
-SKIP_MAIL = _os.environ.get("MICF_SKIP_MAIL", "1") != "0"
+SKIP_MAIL = True
 
 
 class _SkipToken:
@@ -1392,7 +1392,7 @@ class SkipMailFn(torch.autograd.Function):
             # the hand-over relies on autograd reaching the skip consumer (decoder) before PatchMerging's backward (encoder); any
             # other order (autograd.grad on a sub-graph, a second pass over a retained graph) would drop this gradient silently
             raise RuntimeError("SkipMailFn.backward ran after the PatchMerging backward that should have added its gradient "
-                               "(set MICF_SKIP_MAIL=0 for backward passes in a non-standard order)")
+                               "(set functional.SKIP_MAIL = False for backward passes in a non-standard order)")
         tok.grad = g if tok.grad is None else tok.grad + g
         tok.received += 1
         return None, None
@@ -1435,7 +1435,7 @@ class ConvDownFn(torch.autograd.Function):
             if ctx.token is not None:
                 if ctx.token.received != ctx.token.mailed and not ctx.token.consumed:
                     raise RuntimeError(f"PatchMerging backward reached before its skip connection's gradient arrived "
-                                       f"({ctx.token.received} of {ctx.token.mailed} mailed): MICF_SKIP_MAIL=0 for this pass order")
+                                       f"({ctx.token.received} of {ctx.token.mailed} mailed): functional.SKIP_MAIL = False for this pass order")
                 ctx.token.consumed = True
                 ctx.token.grad = None
             if skip is not None:
@@ -1506,14 +1506,14 @@ class OutConvFn(torch.autograd.Function):
         return dx.reshape(feat.shape), _ret(ctx.tg[0], dw), _ret(ctx.tg[1], db)
 
 
-FUSE_TAIL_PATCHES = _os.environ.get("MICF_FUSE_TAIL", "1") != "0"
+FUSE_TAIL_PATCHES = True
 
 
 # MDiceLoss's forward inside the head's logits store (SURVEY 8 row A19 as worded).  The reference's call shape stays
 # `loss = criterion(model(x), target)` (train.py:185-187): a caller that knows the target before the forward (TrainEngine) leaves it
 # here; HeadTailFn's fused forward then folds the Dice / BCE sums of every logit it stores and parks (logits, target, loss, sums);
 # DiceBCEFn picks the parked result up when it is handed exactly those two tensors, and computes it itself otherwise.
-FUSE_LOSS = _os.environ.get("MICF_FUSE_LOSS", "1") != "0"
+FUSE_LOSS = True
 
 
 class HeadTailFn(torch.autograd.Function):

@@ -18,7 +18,7 @@ from . import _lib
 from ._lib import call, f32
 
 
-FUSE_ACCUMULATE = __import__("os").environ.get("MICF_SW_FUSE", "1") != "0"
+FUSE_ACCUMULATE = True
 
 
 def sliding_window_starts(L, roi, overlap=0.5):

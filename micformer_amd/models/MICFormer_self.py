@@ -235,13 +235,13 @@ FORK_AUTOGRAD_STREAMS = True
 # backward flush points inside a stage: every SLOT_FLUSH_STRIDE-th depth slot (measured at base / 128^3 at the end of round 2:
 # 1 -> 15.8 ms (the captured graph then replays side and main work serially), 2 -> 12.6, 3 -> 12.6, 4 -> 12.7, none -> 14.0:
 # one flush in the middle of the six-slot stage, none inside the two-slot stages)
-SLOT_FLUSH_STRIDE = int(__import__("os").environ.get("MICF_SLOT_FLUSH_STRIDE", "3"))
+SLOT_FLUSH_STRIDE = 3
 # Head: run reverse_patch_embedding + out_conv as their composition (off = the reference's two separate convolutions).
 FUSE_HEAD_TAIL = True
 # Both modalities' blocks of a depth slot in one fused launch (off: one fused launch per modality, on two streams when
 # PARALLEL_MODALITIES is set).
 import os as _os
-PAIR_BLOCKS = _os.environ.get("MICF_PAIR_BLOCKS", "1") != "0"
+PAIR_BLOCKS = True
 _SIDE_STREAMS = {}
 HEAD_WEIGHTS_AFTER = None           # TrainEngine.step_many: [event] behind which the head's weights are current (None: always)
 
@@ -364,7 +364,7 @@ class PatchExpand(nn.Module):
         return Fn.LayerNormFn.apply(y, None, self.norm.weight, self.norm.bias, self.norm.eps)
 
 
-JOINT_MODALITIES = _os.environ.get("MICF_JOINT", "1") != "0"   # the shared per-token modules between the stages on [2B, ...] tensors
+JOINT_MODALITIES = True   # the shared per-token modules between the stages on [2B, ...] tensors
 
 
 def _joint_ok(a, b):

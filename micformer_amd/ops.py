@@ -1102,7 +1102,7 @@ def block_saves_bf16(C, heads):
 
 def block_recomputes_h(C, heads):
     """True when block_bwd rebuilds the fc1 pre-activation from xn2 for this shape: block_fwd then does not store it
-    (include/micformer_hip.h micf_block_recomputes_h: opt-in with MICF_BLOCK_RECOMPUTE_H=1, a memory switch)."""
+    (include/micformer_hip.h micf_block_recomputes_h: opt-in through the option "block_recompute_h", a memory switch)."""
     return bool(_lib.lib.micf_block_recomputes_h(C, heads))
 
 

@@ -20,6 +20,21 @@ def pytest_configure(config):
         __graft_entry__.build()
 
 
+@pytest.fixture()
+def hook():
+    """hook(name, value): set a test hook of the library (micf_set_option: a slower equivalent kernel, a shrunk capacity) for THIS
+    test; every hook is restored afterwards.  The product path never sets one."""
+    from micformer_amd import _lib
+    saved = []
+
+    def set_(name, value):
+        saved.append((name, _lib.set_option(name, value)))
+
+    yield set_
+    for name, prev in reversed(saved):
+        _lib.set_option(name, prev)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

@@ -32,11 +32,14 @@ def parse_header():
     return decls
 
 
+_UNTABLED = ("micf_abi_version", "micf_strerror", "micf_set_option", "micf_get_option")     # bound by hand in _lib._load
+
+
 def test_header_declares_expected_entry_points():
     d = parse_header()
-    assert len(d) == 98, sorted(d)          # (96 product entry points + the round-5 measurement probe + the MFMA hazard probe)
+    assert len(d) == 100, sorted(d)         # (96 product entry points + micf_set_option / micf_get_option (test hooks) + the round-5 measurement probe + the MFMA hazard probe)
     assert all(sig.endswith("p") for n, sig in d.items()
-               if n not in ("micf_abi_version", "micf_strerror", "micf_linear_bwd_weight_workspace",
+               if n not in ("micf_abi_version", "micf_strerror", "micf_set_option", "micf_get_option", "micf_linear_bwd_weight_workspace",
                             "micf_linear_bwd_weight_grouped_workspace", "micf_conv3_bwd_data_workspace",
                             "micf_conv3_bwd_weight_grouped_workspace", "micf_head_tail_fused_supported", "micf_head_tail_pack_bytes", "micf_head_tail_loss_parts", "micf_head_tail_bwd_weight_fused_workspace",
                             "micf_offset_sample_bwd_workspace", "micf_conv3_bwd_weight_workspace",
@@ -60,11 +63,28 @@ def test_ctypes_signatures_match_header():
     from micformer_amd import _lib
     d = parse_header()
     for name, sig in d.items():
-        if name in ("micf_abi_version", "micf_strerror"):
+        if name in _UNTABLED:
             continue
         assert name in _lib.SIGNATURES, f"{name} missing from _lib.SIGNATURES"
         assert _lib.SIGNATURES[name] == sig, f"{name}: header {sig} vs ctypes {_lib.SIGNATURES[name]}"
-    assert set(_lib.SIGNATURES) == set(d) - {"micf_abi_version", "micf_strerror"}
+    assert set(_lib.SIGNATURES) == set(d) - set(_UNTABLED)
+
+
+def test_option_hooks_round_trip_and_reject_unknown_names():
+    """micf_set_option / micf_get_option: every documented hook reads back what was set and is restored; an unknown name is an error
+    (no silent no-op for a mistyped hook)."""
+    import pytest
+    from micformer_amd import _lib
+    defaults = {"block_wave": 1, "block_recompute_h": 0, "block_debug": 0, "sample_tile": 1, "sample_e": -1, "cell_cap": -1,
+                "tile_cap_hits": -1, "tile_cap_cell": -1, "tile_cap_voxel": -1}
+    for name, dflt in defaults.items():
+        assert _lib.get_option(name) == dflt, name
+        with _lib.option(name, 5):
+            assert _lib.get_option(name) == 5
+        assert _lib.get_option(name) == dflt
+    with pytest.raises(KeyError):
+        _lib.set_option("block_waev", 0)
+    assert _lib.lib.micf_set_option(None, 0) == -1
 
 
 def test_invalid_arguments_return_error_codes_without_gpu():

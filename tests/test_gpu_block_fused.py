@@ -102,14 +102,14 @@ CASES = [  # (B, D, H, W, C, heads)
 @pytest.mark.parametrize("cross", [False, True])
 @pytest.mark.parametrize("ngroups", [1, 2])
 @pytest.mark.parametrize("save_h", [True, False])
-def test_fused_block_matches_per_op_path(ops, case, cross, ngroups, save_h, monkeypatch):
-    """save_h True: the default, the fc1 pre-activation is stored; False: MICF_BLOCK_RECOMPUTE_H=1 -- the tile kernels do not
+def test_fused_block_matches_per_op_path(ops, case, cross, ngroups, save_h, hook):
+    """save_h True: the default, the fc1 pre-activation is stored; False: the option "block_recompute_h" -- the tile kernels do not
     store it, the backward rebuilds it from xn2 (micf_block_recomputes_h; the few-token decomposition at C = 384 always stores)."""
     B, D, H, W, C, heads = case
     if not save_h:
         if C == 384:
             pytest.skip("the few-token decomposition stores h either way: covered by save_h True")
-        monkeypatch.setenv("MICF_BLOCK_RECOMPUTE_H", "1")
+        hook("block_recompute_h", 1)
     assert ops.block_recomputes_h(C, heads) == (C != 384 and not save_h)
     dims = (B, D, H, W)
     T = B * D * H * W

@@ -1,6 +1,6 @@
 """The wave-private form of the fused block launches at C = 48 (csrc/block_wave_fwd.h / block_wave_bwd.h: one wave per 16 tokens,
 every product transposed so that nothing is exchanged through LDS) against the tile-per-workgroup kernels it replaces
-(MICF_BLOCK_WAVE=0), which test_gpu_block_fused.py pins against the per-op path and the oracle: same bf16 arithmetic (operands
+(test hook "block_wave" = 0), which test_gpu_block_fused.py pins against the per-op path and the oracle: same bf16 arithmetic (operands
 rounded where they enter a fragment, fp32 accumulation), another summation order -- every saved tensor and every gradient within a
 bf16 rounding step of the other kernel's, the fp32 outputs 1e-3-class; self, cross with a given K/V source, cross with the sampling
 fused in, one and two groups, an odd window count (a half-empty 16-token group), DropPath scales."""
@@ -45,8 +45,9 @@ def _groups(ops, dims, kind, ngroups, scales):
 
 
 def _run(ops, monkeypatch, wave, fn):
-    monkeypatch.setenv("MICF_BLOCK_WAVE", "1" if wave else "0")
-    out = fn()
+    from micformer_amd import _lib
+    with _lib.option("block_wave", 1 if wave else 0):
+        out = fn()
     torch.cuda.synchronize()
     return out
 

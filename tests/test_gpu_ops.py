@@ -321,23 +321,24 @@ def test_conv3_bwd_weight_grouped(ops, dims, C, n):
                                   ((2, 4, 4, 4), 384, 0.5, None, None, "512,2"), ((2, 8, 8, 8), 192, 1.0, None, None, "0,12"),
                                   ((1, 5, 5, 5), 48, 3.0, None, None, "512,12,1"), ((2, 8, 8, 8), 192, 0.3), ((3, 4, 4, 4), 384, 0.3),
                                   ((1, 16, 16, 16), 96, 0.5, 1, -1), ((1, 16, 8, 32), 24, 2.0, 0, -1), ((2, 8, 16, 16), 24, 8.0, 8, -1)])
-def test_offset_sample(ops, case, monkeypatch):
-    """case = (dims, C[, offset scale[, MICF_CELL_CAP[, MICF_SAMPLE_E]]]).  d(xa) is summed per output tile in LDS from the NEAR
+def test_offset_sample(ops, case, hook):
+    """case = (dims, C[, offset scale[, hook "cell_cap"[, hook "sample_e"]]]).  d(xa) is summed per output tile in LDS from the NEAR
     tokens of a bounded neighbourhood (round 5, every grid), FAR tokens scatter atomically: the offset scale pushes taps far away
-    / out of the volume, MICF_SAMPLE_E shrinks the neighbourhood (0: every token takes the atomic path; unset on a grid of <= 512 tokens per sample: the ONE-launch form whose candidate box is the whole sample; non-cubic grids, ragged
-    tiles, two samples; a sixth entry = MICF_TILE_CAP, "hits,segment,cell": the capacities of the LDS hit list, of a voxel's list segments and of a cell's index list.  E = -1 switches the tile path off: the cell-list gather of rounds 1-4 on grids >= 4096 tokens, where the
+    / out of the volume, "sample_e" shrinks the neighbourhood (0: every token takes the atomic path; unset on a grid of <= 512 tokens per sample: the ONE-launch form whose candidate box is the whole sample; non-cubic grids, ragged
+    tiles, two samples; a sixth entry = the hooks "tile_cap_hits / _voxel / _cell" as "hits,segment,cell": the capacities of the LDS hit list, of a voxel's list segments and of a cell's index list.  E = -1 switches the tile path off: the cell-list gather of rounds 1-4 on grids >= 4096 tokens, where the
     cap shrinks the per-cell lists so that tokens overflow into its atomic fallback (cap 0: every token)."""
     dims, C = case[0], case[1]
     wscale = case[2] if len(case) > 2 else 0.5
     if len(case) > 3 and case[3] is not None:
-        monkeypatch.setenv("MICF_CELL_CAP", str(case[3]))
+        hook("cell_cap", case[3])
     if len(case) > 4 and case[4] is not None:
         if case[4] < 0:
-            monkeypatch.setenv("MICF_SAMPLE_TILE", "0")
+            hook("sample_tile", 0)
         else:
-            monkeypatch.setenv("MICF_SAMPLE_E", str(case[4]))
+            hook("sample_e", case[4])
     if len(case) > 5:
-        monkeypatch.setenv("MICF_TILE_CAP", str(case[5]))       # LDS lists shrunk: the scanning lane's own atomic path / the owners walking the hit list
+        for name, v in zip(("tile_cap_hits", "tile_cap_voxel", "tile_cap_cell"), str(case[5]).split(",")):
+            hook(name, int(v))                                  # LDS lists shrunk: the scanning lane's own atomic path / the owners walking the hit list
     B, D, H, W = dims
     T = B * D * H * W
     h = rnd(T, 16, seed=1).requires_grad_(True)

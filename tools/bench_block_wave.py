@@ -1,5 +1,5 @@
 """Times micf_block_fwd / micf_block_bwd at the base model's 32^3 stage (2 x 65536 tokens, C = 48, bf16 mode) with the wave-private
-kernels (MICF_BLOCK_WAVE=1, default) and the tile-per-workgroup kernels (=0): self pair, cross pair with the sampling fused in.
+kernels (default) and the tile-per-workgroup kernels (test hook "block_wave" = 0): self pair, cross pair with the sampling fused in.
     python tools/bench_block_wave.py [--reps 50]"""
 import argparse
 import os
@@ -9,7 +9,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
-from micformer_amd import ops  # noqa: E402
+from micformer_amd import _lib, ops  # noqa: E402
 from test_gpu_block_fused import make_params, rnd  # noqa: E402
 
 ap = argparse.ArgumentParser()
@@ -53,7 +53,7 @@ def timed(fn):
 for kind in ("self", "sampled"):
     gs = groups(kind)
     for wave in ("0", "1"):
-        os.environ["MICF_BLOCK_WAVE"] = wave
+        _lib.set_option("block_wave", int(wave))
         o = ops.block_fwd([dict(g) for g in gs], dims, C, HEADS, eps, scale)
         t_f = timed(lambda: ops.block_fwd([dict(g) for g in gs], dims, C, HEADS, eps, scale))
         bg = [{"dy": rnd((T, C), 9 + i), "x": gs[i]["x"] if kind == "self" else None, "x1": o[i]["x1"], "stats": o[i]["stats"], "q": o[i]["q"],

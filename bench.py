@@ -475,7 +475,7 @@ def main(argv=None):
                                                     " (plumbing check: NOT the RCCL / xGMI path, ranks may share a GPU)")
         out["distinct_local_devices"] = len({int(g.item()) for g in gathered})
         if not stub:
-            # wire format of the gradient exchange (DESIGN section 5): fp32 all-reduce | bf16 on the links with fp32 sums
+            # wire format of the gradient exchange (DESIGN.md section 6): fp32 all-reduce | bf16 on the links with fp32 sums
             # (all-to-all + all-gather) | bf16-ring (the backend's all-reduce in bf16)
             out["grad_wire"] = eng.grad_wire or "fp32"
     else:

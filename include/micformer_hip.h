@@ -546,17 +546,17 @@ typedef struct micf_block_bwd_group {
 /* != 0: the caller should pass h == NULL in both groups structs (see there).  Only with the option "block_recompute_h" set
  * (micf_set_option) and only for the tile-per-workgroup kernels (everything but the few-token decomposition at C = 384): a memory
  * switch (8 of the 34 saved bytes per element), not a speed one -- the extra GEMM phase of the backward costs more time than the
- * bytes save. */
+ * bytes save (LABNOTES.md, round 4). */
 int micf_block_recomputes_h(int C, int heads);
 int micf_block_tile_tokens(int B, int D, int H, int W, int C, int heads, int hidden, int backward);
-/* MEASUREMENT PROBE, not a product entry point (tools/bench_persist.py): `repeats` (1 .. 64) passes of
+/* MEASUREMENT PROBE, not a product entry point (tools/bench_persist.py; LABNOTES.md, round 5): `repeats` (1 .. 64) passes of
  * micf_block_fwd's tile kernel inside ONE launch with a device-wide barrier between the passes -- the cost of a persistent kernel
  * walking the depth slots of the 8^3 stage, measured against `repeats` launches.  Base 8^3 shape only (C = 192, 12 heads, bf16
  * mode; at most 256 workgroups, all resident): MICF_EUNSUPPORTED otherwise.  sync_ws: 2 device ints (barrier counter, error flag;
  * cleared by the call): the flag reads 1 afterwards if a barrier timed out (bounded spin: a mis-sized launch does not hang). */
 int micf_block_fwd_persistent_probe(const micf_block_fwd_group* groups, int ngroups, int B, int D, int H, int W, int C, int heads,
                                     int hidden, float eps, float scale, int dtype, int repeats, int* sync_ws, micf_stream_t stream);
-/* HAZARD PROBE, not a product entry point: one 16 x 16 x 48 bf16 product on the matrix cores as
+/* HAZARD PROBE, not a product entry point (LABNOTES.md, round 5): one 16 x 16 x 48 bf16 product on the matrix cores as
  * form 0 = v_mfma_f32_16x16x16_bf16 accumulating onto the v_mfma_f32_16x16x32_bf16 issued right before it, form 1 = two independent
  * products + a vector add (what csrc/block_wave.h::mfma48 does).  a / b: 64 lanes x 8 bf16 (A / B fragments of the 32-deep product),
  * c / d: 64 lanes x 4 bf16 (the 16-deep one), out: 64 lanes x 4 floats in accumulator order (row 4 (lane / 16) + i, column lane % 16). */

@@ -568,7 +568,7 @@ extern "C" int micf_block_fwd(const micf_block_fwd_group* groups, int ngroups, i
   return MICF_EUNSUPPORTED;
 }
 
-// HAZARD PROBE, not a product entry point (block_wave.h::mfma48): one K = 48 product of a 16 x 16 tile as
+// HAZARD PROBE, not a product entry point (LABNOTES.md, round 5; block_wave.h::mfma48): one K = 48 product of a 16 x 16 tile as
 // the compiler emits it from the two natural source forms -- form 0: acc = mfma_16x16x16(c, d, mfma_16x16x32(a, b, 0)), the dependent
 // pair of different shapes back to back; form 1: two independent products and a vector add.  a / b: [64 lanes][8] bf16 fragments,
 // c / d: [64][4]; out [64][4] floats in accumulator order.  tests/test_gpu_block_wave.py compares both with the exact product.

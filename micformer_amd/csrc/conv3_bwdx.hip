@@ -11,7 +11,7 @@
 //     the A operand of 4 k-steps for 16 channels is ONE coalesced 16-byte load per lane straight from L2 into registers --
 //     no LDS staging, no barrier inside the tap loop; the next tap's weights are prefetched under the current tap's MFMAs.
 //   * every wave owns 2 token rows x NCT channel tiles (2*NCT accumulators); per tap: 2 LDS reads + NCT loads for 8*NCT MFMAs.
-// The implicit-GEMM path (conv3.hip) needed 360 us for the 32^3 x 2 stage (15 TFLOP/s); see DESIGN.md for this kernel's numbers.
+// The implicit-GEMM path (conv3.hip) needed 360 us for the 32^3 x 2 stage (15 TFLOP/s); see DESIGN.md section 3 for this kernel's numbers.
 #include <cstdlib>
 #include "common.h"
 #include "conv3_layout.h"

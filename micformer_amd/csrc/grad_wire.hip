@@ -1,4 +1,4 @@
-// grad_wire.hip -- the bf16 wire format of the data-parallel gradient exchange (DESIGN.md section 5): bf16 on the xGMI links,
+// grad_wire.hip -- the bf16 wire format of the data-parallel gradient exchange (DESIGN.md section 6): bf16 on the xGMI links,
 // fp32 in every sum.  A slice of the flat fp32 gradient is (1) rounded to bf16 into N equal, zero-padded shards, (2) shard j of
 // every rank travels to rank j (all-to-all, one hop on the point-to-point xGMI mesh), (3) rank j adds its N received shards in
 // fp32 and rounds the SUM to bf16 once, (4) the reduced shards are all-gathered and (5) widened back into the flat buffer.

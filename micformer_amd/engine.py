@@ -53,7 +53,7 @@ class TrainEngine:
         self.dp_graph_flushes = int(dp_graph_flushes)
         # bf16 wire format of the gradient exchange (123 MB instead of 247 MB per step at base): each slice is rounded to bf16,
         # sum-reduced, widened back; Adam still reads fp32.  Default (None): ON for world > 1 in the bf16 arithmetic mode -- the
-        # budget of tools/dp_budget.py (DESIGN section 5): at 8 ranks the fp32 exchange is ~1.65 ms of ring time against ~1 ms of
+        # budget of tools/dp_budget.py (DESIGN.md section 6): at 8 ranks the fp32 exchange is ~1.65 ms of ring time against ~1 ms of
         # post-replay launches to hide it behind (7.4 x of 8), the bf16 one ~0.93 ms (7.6-7.7 x); the gradients of this mode
         # already carry bf16 operand rounding, and the 2-rank test holds the result within 2^-7 of the fp32 exchange.  The fp32
         # parity mode keeps the exact fp32 exchange.
@@ -461,7 +461,7 @@ class TrainEngine:
         weight-gradient side stream, forked from the main chain right here.  Purely a placement aid for the captured graph:
         without a side node created eagerly at this point the replay runs the side batches almost serially with the main
         chain (single GPU 14.1 vs 12.9 ms; data-parallel layout 14.8 vs 13.5 ms), with it -- early Adam's first kernel, or this
-        4 KB fill -- they overlap.  More than one such node, or one at another stage, measured worse."""
+        4 KB fill -- they overlap.  More than one such node, or one at another stage, measured worse (LABNOTES.md, rounds 2-3)."""
         from . import functional as _fn
         _fn.launch_pending_flush()
         dev = self.flat_p.device

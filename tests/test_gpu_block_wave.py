@@ -221,4 +221,4 @@ def test_mixed_shape_mfma_chain_probe(ops):
     # a part that did would only make the workaround unnecessary
     print("mfma chain probe: max |error| of form 0 (compiler's pair), 1 (independent + add), 2 (adjacent pair, VGPR accumulator), 3 (16 wait states between them):", res)
     if res[0] > 1e-4:
-        warnings.warn(f"dependent 16x16x32 -> 16x16x16 MFMA pair: max error {res[0]:.3g} (the hazard of DESIGN.md section 3 reproduces standalone)")
+        warnings.warn(f"dependent 16x16x32 -> 16x16x16 MFMA pair: max error {res[0]:.3g} (the hazard of DESIGN.md section 3 (wave-private kernels) reproduces standalone)")

@@ -25,7 +25,7 @@ G = os.path.join(os.path.dirname(__file__), "golden")
 # measured on MI355X (two runs): groups carrying >= 1e-3 of the largest group's norm within 5.4e-3 (up_layers.1 at 2e-4: 1.2e-2; the
 # 10 x 10 x 8 / 5 x 5 x 4 stages of this closed-form fixture sit at <= 6e-6 and are rounding noise), per tensor (norm >= 1e-4 of the
 # largest) median 7e-4 ... 1e-3, worst 3.3e-2 / 8.7e-2 (an offset-conv weight: the sampling coordinate's derivative is discontinuous
-# at voxel boundaries, DESIGN section 6).  Bounds = ~3 x measured.
+# at voxel boundaries, DESIGN.md section 7).  Bounds = ~3 x measured.
 FP8_GROUP_TOL, FP8_TENSOR_MEDIAN_TOL, FP8_TENSOR_WORST_TOL = 2e-2, 5e-3, 0.3
 
 

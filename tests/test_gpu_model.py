@@ -256,7 +256,7 @@ def test_base_128_scheduled_fixture_against_reference(M):
         else:
             v = float(p.grad.double().norm())
             # (the offset heads' parameters see the sampling coordinate's derivative, which is discontinuous at voxel boundaries:
-            #  accumulation order moves them at the 1 % level on this amplified fixture, run to run -- DESIGN section 6; measured
+            #  accumulation order moves them at the 1 % level on this amplified fixture, run to run -- DESIGN.md section 7; measured
             #  worst 1.2e-2, all other tensors <= 2e-3)
             #  (... and the rest of a deep-stage CROSS block sits directly behind those sampled rows: 6.4e-3 seen once on its fc1 weight)
             #  (... and so do the SELF blocks of the later depth slots of a deep stage, whose inputs those cross blocks wrote: 5.1e-3 seen

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity sweep (GPU box): HIP Head vs the CPU oracle on non-cubic / odd / multi-sample shapes, forward + backward.
-Logits within 1e-4; per-tensor gradient norms within 0.2 % (3 % on the offset-head path, see DESIGN.md §6), NaN pattern equal."""
+Logits within 1e-4; per-tensor gradient norms within 0.2 % (3 % on the offset-head path, see DESIGN.md §7), NaN pattern equal."""
 import itertools, json, os, random, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

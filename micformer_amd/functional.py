@@ -130,7 +130,46 @@ def _defer(ok, fn, *tensors):
         fn()
 
 
+# Module-level drop-in (no engine: autograd waits for the returned gradient tensors, nothing can be deferred past the Function):
+# the nn.Linear weight gradients and LayerNorm partial finishes of ONE pair backward are still independent of each other, so they are
+# collected while the Function runs and launched as one grouped call each before it returns (10 + 4-6 C-ABI calls -> 2 per pair:
+# the eager loop is host-bound, bench.py `stock_loop`).
+_LOCAL = None
+
+
+class _local_batch:
+    def __enter__(self):
+        global _LOCAL
+        self.prev, _LOCAL = _LOCAL, ([], [])
+        return self
+
+    def __exit__(self, et, ev, tb):
+        global _LOCAL
+        items, ln = _LOCAL
+        _LOCAL = self.prev
+        if et is None:
+            if ln:
+                ops.layernorm_bwd_finish(ln)
+            if items:
+                ops.linear_bwd_weight_grouped(items)
+        return False
+
+
+def _batched(fn):
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*a, **k):
+        with _local_batch():
+            return fn(*a, **k)
+    return wrapped
+
+
 def _lin_wgrad(defer, dy, a, dw, db, dp_scale=None, rows_per_sample=0):
+    if _LOCAL is not None and not (defer and CTX.defer_wgrad) and dy.dtype == a.dtype and ops.wgrad_groupable(dy, a, dp_scale, rows_per_sample) \
+            and all(it[2].data_ptr() != dw.data_ptr() for it in _LOCAL[0]):
+        _LOCAL[0].append((dy, a, dw, db, dp_scale, rows_per_sample))
+        return
     if dy.dtype == torch.bfloat16 or a.dtype == torch.bfloat16:
         # operands the fused block kernels stored as bf16: only the grouped entry point reads them (shapes it does not take -- fewer
         # than 32 tokens -- are widened and go the fp32 way)
@@ -576,6 +615,22 @@ def _grad_buf(target, like):
     return target if target is not None else torch.zeros_like(like)
 
 
+def _grad_bufs(P, tg):
+    """{name: gradient buffer} for a block's parameters: the engine's views of the flat gradient buffer where present; otherwise ONE
+    zero-filled allocation carved into 16-byte-aligned views (engine-less loop: one fill per block instead of one per parameter)."""
+    missing = [(k, v) for (k, v), t in zip(P.items(), tg) if t is None]
+    out = {k: t for (k, _), t in zip(P.items(), tg) if t is not None}
+    if missing:
+        offs, total = [], 0
+        for _, v in missing:
+            offs.append(total)
+            total += (v.numel() + 3) // 4 * 4
+        flat = torch.zeros(total, dtype=missing[0][1].dtype, device=missing[0][1].device)
+        for (k, v), o in zip(missing, offs):
+            out[k] = flat[o:o + v.numel()].view(v.shape)
+    return out
+
+
 def _ret(target, buf):
     return None if target is not None else buf
 
@@ -972,6 +1027,8 @@ def _ln_partials(side, part, tiles, C, dg, db):
     lst = _ln_defer(side)
     if lst is not None:
         lst.append(item)
+    elif _LOCAL is not None:
+        _LOCAL[1].append(item)
     else:
         ops.layernorm_bwd_finish([item])
 
@@ -1059,12 +1116,13 @@ class SelfPairFn(torch.autograd.Function):
         params = sv[6 + 2 * m:]
         Ps = [dict(zip(SELF_KEYS, params[:n])), dict(zip(SELF_KEYS, params[n:]))]
         tgs = [ctx.tg[:n], ctx.tg[n:]]
-        Gs = [{k: _grad_buf(t, v) for (k, v), t in zip(P.items(), tg)} for P, tg in zip(Ps, tgs)]
+        Gs = [_grad_bufs(P, tg) for P, tg in zip(Ps, tgs)]
         sides = [all(t is not None for t in tg) for tg in tgs]
         C = xs[0].shape[1]
         _lib.set_unit("self_bwd", 2, xs[0].shape[0], C)
         dys = [_c(dy).reshape(-1, C), _c(dya).reshape(-1, C)]
-        dxs = _self_bwd_fused(dys, xs, svs, Ps, Gs, [(sa1, sa2), (sb1, sb2)], dims, heads, sides)
+        with _local_batch():
+            dxs = _self_bwd_fused(dys, xs, svs, Ps, Gs, [(sa1, sa2), (sb1, sb2)], dims, heads, sides)
         shape = dims + (C,)
         grads = tuple(_ret(t, G[k]) for G, tg in zip(Gs, tgs) for k, t in zip(SELF_KEYS, tg))
         return (dxs[0].reshape(shape), dxs[1].reshape(shape), None, None, None, None, None, None, None) + grads
@@ -1191,6 +1249,7 @@ class CrossPairFn(torch.autograd.Function):
 
     @staticmethod
     @_in_block
+    @_batched
     def backward(ctx, dy, dya):
         sv = ctx.saved_tensors
         dims, heads, eps = ctx.meta
@@ -1203,7 +1262,7 @@ class CrossPairFn(torch.autograd.Function):
         params = sv[18 + 2 * m:]
         Ps = [dict(zip(CROSS_KEYS, params[:n])), dict(zip(CROSS_KEYS, params[n:]))]
         tgs = [ctx.tg[:n], ctx.tg[n:]]
-        Gs = [{k: _grad_buf(t, v) for (k, v), t in zip(P.items(), tg)} for P, tg in zip(Ps, tgs)]
+        Gs = [_grad_bufs(P, tg) for P, tg in zip(Ps, tgs)]
         sides = [all(t is not None for t in tg) for tg in tgs]
         C = xs[0].shape[1]
         _lib.set_unit("cross_bwd", 2, xs[0].shape[0], C)

@@ -19,7 +19,7 @@ def test_segmented_capture_matches_eager(dtype):
         pytest.skip("needs a GPU")
     env = dict(os.environ, DT=dtype)
     env.pop("DEBUG_CLR_GRAPH_PACKET_CAPTURE", None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "seg_debug.py"), "mid"], env=env, cwd=ROOT, capture_output=True,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "segmented_worker.py"), "mid"], env=env, cwd=ROOT, capture_output=True,
                        text=True, timeout=600)
     out = r.stdout + r.stderr
     assert r.returncode == 0, out[-3000:]
@@ -36,14 +36,14 @@ def test_segmented_capture_matches_eager(dtype):
 
 
 def test_step_many_as_a_sequence_of_graphs():
-    """TrainEngine.step_many with segmented=True (tools/seg_many.py, own process): 2 x 4 steps of the base-width model -- every
+    """TrainEngine.step_many with segmented=True (tests/segmented_many_worker.py, own process): 2 x 4 steps of the base-width model -- every
     stage group of the carried parameter work its own graph on the side stream with an event behind it, the main chain cut where it
     waits for one -- against 8 replays of the one-step graph: losses, Adam first moments, step counter."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     env = dict(os.environ)
     env.pop("DEBUG_CLR_GRAPH_PACKET_CAPTURE", None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "seg_many.py")], env=env, cwd=ROOT, capture_output=True, text=True,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "segmented_many_worker.py")], env=env, cwd=ROOT, capture_output=True, text=True,
                        timeout=600)
     out = r.stdout + r.stderr
     assert r.returncode == 0 and "\nOK" in out, out[-3000:]

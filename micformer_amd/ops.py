@@ -1046,28 +1046,32 @@ def _conv_layouts(w):
 
 def block_weights(P, attn, backward, only=None):
     """The five weight matrices a fused block kernel streams (or the fields named in `only`), in the layout of the current
-    arithmetic mode.  Engine mode: the parameter carries the shadow copy (refreshed once per step); otherwise it is made here
-    (one grouped launch)."""
+    arithmetic mode.  Engine mode: the parameter carries the shadow copy (refreshed once per step).  Otherwise (module-level drop-in,
+    validation, sliding-window inference) the copies live on the weight tensor, keyed by torch's version counter and PARAM_EPOCH:
+    a weight that was written since (optimizer.step(), load_state_dict) is re-derived -- BOTH orientations (the forward's copy and
+    the backward's transposed copy) by ONE grouped launch for all stale weights of the call, so a training step prepares every
+    weight once, at its forward.  (A write through `.data` does not move the version counter: bump ops.PARAM_EPOCH[0] after one.)"""
     fields = BWD_WT if backward else FWD_WM
     if only is not None:
         fields = tuple(f for f in fields if f[0] in only)
     spec = shadow_spec(backward)
+    if spec is None:
+        return {field: P[key.format(a=attn)] for field, key in fields}
+    fspec, bspec = shadow_spec(False), shadow_spec(True)
     out, todo = {}, []
     for field, key in fields:
         w = P[key.format(a=attn)]
-        if spec is None:
-            out[field] = w
-            continue
         sh = getattr(w, spec[0], None) if ENGINE_SHADOWS else None
         if sh is None:
-            def build(w=w):
-                t = shadow_like(w, spec[1], spec[2])
-                WeightPrepPlan([(w, None, t) if spec[1] else (w, t, None)], blocked=True).launch()
-                return t
-            sh = _inference_cache(w, spec[0], build)
-        if sh is None:
-            sh = shadow_like(w, spec[1], spec[2])
-            todo.append((w, None, sh) if spec[1] else (w, sh, None))
+            cache = w.__dict__.setdefault("_micf_cache", {})
+            stamp = (w._version, PARAM_EPOCH[0], compute_dtype())
+            ent = cache.get("shadows")
+            if ent is None or ent[0] != stamp:
+                fwd = shadow_like(w, fspec[1], fspec[2]) if fspec is not None else None
+                bwd = shadow_like(w, bspec[1], bspec[2])
+                ent = cache["shadows"] = (stamp, fwd, bwd)
+                todo.append((w, fwd, bwd))
+            sh = ent[2] if backward else ent[1]
         out[field] = sh
     if todo:
         WeightPrepPlan(todo, blocked=True).launch()

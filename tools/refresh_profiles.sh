@@ -48,8 +48,8 @@ python tools/pmc_summary.py $OUT/pmc $OUT/${R}_pmc_hbm_by_kernel.csv --json $OUT
   --key "micf_block_bwd|2x1024x192" --kernels "block_bwd_kernel<192" --calls-per-step 24 \
   --key "micf_block_fwd|2x1024x192" --kernels "block_fwd_kernel<192" --calls-per-step 24 \
   --key "micf_offset_head_bwd|65536.48x65536.48" --kernels "${PMC_HEAD_BWD_KERNELS:-offset_sample_bwd4_kernel<2>@1048576;sample_gather_tile_kernel@262144;conv3_bwdx_kernel<16, 6, true>@262144}" --calls-per-step 4 \
-  --key "micf_offset_head_fwd|65536.48x65536.48" --kernels "conv3_fwdx_kernel<16, true>@" --calls-per-step 4 \
-  --key "micf_layernorm_fwd_pair|65536.48x65536.48" --kernels "ln_fwd_v2<16, 1>" --calls-per-step 4 >> $OUT/${R}_pmc_summary.txt
+  --key "micf_offset_head_fwd|65536.48x65536.48" --kernels "conv3_fwdx_kernel<16, true>@262144;" --calls-per-step 4 \
+  --key "micf_layernorm_fwd_pair|65536.48x65536.48" --kernels "ln_fwd_v2<16, 1>@1048576;" --calls-per-step 4 >> $OUT/${R}_pmc_summary.txt
 # matrix-core utilisation per kernel (its own pass)
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma -o m -- \
   python bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-roofline --no-stock-loop > /dev/null 2>> $OUT/rocprof.err

@@ -56,7 +56,7 @@ def _adam(p, g, m, v, step, lr, grad_scale, b1=0.9, b2=0.999, eps=1e-8):
     p.addcdiv_(m / (1 - b1 ** step), (v / (1 - b2 ** step)).sqrt_().add_(eps), value=-lr)
 
 
-def _engine_tail(flat_g_backward, deferred, names, offs, sizes, total, flat_p, world_sync, group_items=3):
+def _engine_tail(flat_g_backward, deferred, names, offs, sizes, total, flat_p, world_sync, group_items=3, wire=None):
     """What TrainEngine.step does after the replayed forward + backward (engine._plan_split / _flush_and_reduce): `flat_g_backward`
     holds what backward itself wrote; `deferred` = [(offset, values)] are the queued weight gradients, launched in groups of
     `group_items`; every per-stage slice is all-reduced after its last writer; Adam consumes the sum with 1/world."""
@@ -65,7 +65,7 @@ def _engine_tail(flat_g_backward, deferred, names, offs, sizes, total, flat_p, w
     buckets = module_buckets(names, offs, sizes, total, min_elems=20000)
     writes = [(k // group_items, off, vals.numel()) for k, (off, vals) in enumerate(deferred)]
     last = last_writer_per_bucket(buckets, writes)
-    ov = OverlappedGradReduce(world_sync, flat_g, buckets, last)
+    ov = OverlappedGradReduce(world_sync, flat_g, buckets, last, wire=wire)
     ngroups = (len(deferred) + group_items - 1) // group_items
     issued = []
 
@@ -116,9 +116,11 @@ def _worker(rank, world, port, out):
     assert len(deferred) > 6
     p_before = flat_p.clone()
     g_sum, nb, last = _engine_tail(backward, deferred, names, offs, sizes, total, flat_p, sync)
+    # the same overlapped tail over the DEFAULT wire of the bf16 mode (bf16 on the links, fp32 sums), interleaved with the launches
+    g_wire, _, _ = _engine_tail(backward, deferred, names, offs, sizes, total, p_before.clone(), sync, wire="bf16")
     mx = sync.max_over_ranks(float(rank + 1), "cpu")
     if rank == 0:
-        torch.save({"g_sum": g_sum, "loss": loss, "p_before": p_before, "p_after": flat_p, "max": mx, "nbuckets": nb,
+        torch.save({"g_sum": g_sum, "g_wire": g_wire, "loss": loss, "p_before": p_before, "p_after": flat_p, "max": mx, "nbuckets": nb,
                     "last": last}, out)
     dist.barrier()
     dist.destroy_process_group()
@@ -152,6 +154,10 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
     scale = float(g.abs().max())
     assert scale == scale and scale > 0
     assert err <= 1e-6 * max(scale, 1.0) + 1e-9, f"2-rank grads differ from the 1-rank reference: {err} (scale {scale})"
+    # ... and over the bf16 wire with fp32 sums: two addends, each rounded once, the sum once: |err| <= 2^-9 (|g1| + |g2| + |g1 + g2|)
+    werr = (got["g_wire"] - g).abs()
+    assert float(werr.max()) <= 2.0 ** -7 * scale, f"bf16 wire: {float(werr.max())} (scale {scale})"
+    assert float((got["g_wire"] - g).norm() / g.norm()) <= 2.0 ** -8
     # ... and Adam read it as the MEAN: same weights as one process stepping on the mean gradient through the same tail
     p1 = ref_p.clone()
     backward, deferred = _split_deferred(g / 2, names, offs, sizes)

@@ -66,4 +66,4 @@ for kind in ("self", "sampled"):
                 g["pre"] = {"d": rnd((T, C), 62 + i), "x": px, "mean": px.mean(1).contiguous(),
                             "rstd": (px.var(1, unbiased=False) + eps).rsqrt().contiguous(), "gamma": 1 + rnd((C,), 64 + i, 0.1)}
             timed(lambda: ops.block_bwd([dict(g) for g in bg], dims, C, HEADS, scale))
-        print(f"{kind:8s} MICF_BLOCK_WAVE={wave}: fwd {t_f:7.1f} us   bwd {t_b:7.1f} us (eager call incl. host overhead)", flush=True)
+        print(f"{kind:8s} block_wave={wave}: fwd {t_f:7.1f} us   bwd {t_b:7.1f} us (eager call incl. host overhead)", flush=True)

@@ -404,21 +404,24 @@ def test_step_many_is_the_same_sequence_of_updates(M, dtype):
         tol = 1e-4 if dtype == "fp32" else 2e-3
         # (the DropPath stream draws its device seed from torch's CPU generator at first use: same seed before each engine's first step)
         torch.manual_seed(5)
-        eager = TrainEngine(_head(M, train=True), base_lr=1e-3, t_max=20, use_graph=False)
+        # (bf16 at lr 1e-3: Adam's normalised updates amplify the rounding noise of the fixture's tiny deep-stage gradients into
+        # different trajectories -- two RUNS of the same layout then sit 4-44 % apart in the first moments after six steps, measured;
+        # at 1e-4 the layouts agree to 3e-3 and an extra / missing update still moves every moment by >= 14 %)
+        lr = 1e-3 if dtype == "fp32" else 1e-4
+        eager = TrainEngine(_head(M, train=True), base_lr=lr, t_max=20, use_graph=False)
         le = [[float(eager.step(x, t)) for x, t in batches] for _ in range(2)]
         ck_state = eager.flat_m.clone(), int(eager.adam_state[0].item())
         le.append([float(eager.step(x, t)) for x, t in batches])
         torch.manual_seed(5)
-        many = TrainEngine(_head(M, train=True), base_lr=1e-3, t_max=20, use_graph=True)
+        many = TrainEngine(_head(M, train=True), base_lr=lr, t_max=20, use_graph=True)
         for rnd_ in range(2):
             lm = [float(l) for l in many.step_many([b[0] for b in batches], [b[1] for b in batches])]
             assert all(abs(a - b) <= tol for a, b in zip(le[rnd_], lm)), (rnd_, le[rnd_], lm)
             assert int(many.adam_state[0].item()) == 3 * (rnd_ + 1)
         assert int(many.adam_state[0].item()) == ck_state[1]
         fin = torch.isfinite(ck_state[0]) & torch.isfinite(many.flat_m)
-        # (the gradient w.r.t. a sampling coordinate is discontinuous at voxel boundaries: a token an ulp from one moves the offset
-        # heads' gradients by O(1) between two runs whose sums were added in another order -- seen in ~1 run of 7 in the bf16 mode,
-        # on a handful of elements.  The sequence of updates is the same if the moments agree as a whole and almost everywhere.)
+        # (the sequence of updates is the same if the moments agree as a whole and almost everywhere: the sampling coordinate's
+        # derivative is discontinuous at voxel boundaries, a handful of offset-head elements may differ between two summation orders)
         dm, ref_m = (ck_state[0] - many.flat_m)[fin], ck_state[0][fin]
         assert float(dm.norm()) <= 3e-2 * float(ref_m.norm())
         assert float((dm.abs() > 3e-2 * float(ref_m.abs().max())).float().mean()) <= (0.0 if dtype == "fp32" else 1e-3)

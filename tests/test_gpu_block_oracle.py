@@ -11,8 +11,8 @@ signature (tools/scratch calibration, 2 x 32^3 tokens): at most 0.3 % of a tenso
 1e-4 of the scale apart, at most 0.05 % (0.3 %) of the bf16-stored values more than one bf16 step apart, worst element 4e-3 of the
 scale.  The FORWARD gates below are those numbers with headroom (measured on MI355X: y 5e-5 relative L2 / 0.1 % of the elements beyond
 1e-4 of the scale; at most 0.1 % of any saved bf16 tensor more than one bf16 step from the oracle; LayerNorm statistics and the
-sampling flow to 2e-7) -- a kernel that rounds at another point, drops a term or mis-indexes a row moves EVERY element.  The BACKWARD
-is gated by relative L2 distance (see there).
+sampling flow to 2e-7) -- a kernel that rounds at another point, drops a term or mis-indexes a row moves EVERY element.  The BACKWARD is
+held to the same kind of gates: the oracle's adjoint re-reads what the forward stored as bf16 and rounds where the kernels round.
 """
 import math
 
@@ -59,6 +59,10 @@ class Report:
         assert torch.isfinite(got).all(), f"{name}: non-finite"
         scale = max(float(want.abs().max()), 1e-30)
         d = (got - want).abs()
+        if frac_gate is not None and frac_gate > 0:
+            # (ONE rounding tie that fell the other way moves up to a window's worth of downstream values -- 8 tokens x 48 channels:
+            # on a launch of a few dozen tokens that alone is a third of a tensor)
+            frac_gate = max(frac_gate, 400.0 / got.numel())
         l2_ = float(d.norm() / want.norm().clamp_min(1e-300))
         mx = float(d.max()) / scale
         frac_far = float((d > far * scale).double().mean())
@@ -93,9 +97,9 @@ def _oracle_block(R, x, kv_given, P, attn, s1, s2):
     xn = R._cap("xn", R.layer_norm(x, P["norm1.weight"], P["norm1.bias"], EPS))
     src = xn if kv_given is None else R._cap("xs", kv_given)
     a = R.window_attention(R._to_windows(xn, ws), R._to_windows(src, ws), P, attn + ".", HEADS)
-    x1 = R._cap("x1", x + R._scale_per_sample(R._from_windows(a, ws, B, D, H, W), s1))
+    x1 = R._cap("x1", x + R._rg(R._scale_per_sample(R._from_windows(a, ws, B, D, H, W), s1)))
     y = R.mlp(R._cap("xn2", R.layer_norm(x1, P["norm2.weight"], P["norm2.bias"], EPS)), P, "mlp.")
-    return x1 + R._scale_per_sample(y, s2)
+    return x1 + R._rg(R._scale_per_sample(y, s2))
 
 
 def _make_groups(dims, kind, scales):
@@ -166,12 +170,14 @@ def test_block_launches_against_the_oracle(ops, hook, dims, kind, wave):
         rep.add(n + "xn2", o["xn2"].float(), aux["xn2"].reshape(T, C), 3e-3, bf16=True)
         rep.add(n + "h", o["h"].float(), aux["h"].reshape(T, 4 * C), 3e-3, bf16=True)
         rep.add(n + "g", o["g"].float(), aux["g"].reshape(T, 4 * C), 3e-3, bf16=True)
-        # ---- backward (the kernel ran on ITS OWN saved tensors, as in a step).  The adjoint re-reads what the forward STORED as bf16
-        # (q, kv, h: GELU' and the recomputed softmax see the rounded values, the forward saw them in fp32) and scales / rounds its dY
-        # operands in its own order, so a gradient is not the oracle's to one rounding step element by element: the gates are the
-        # tensor's relative L2 distance (measured 1.5e-3 .. 4.9e-3: the size of one more operand rounding, 2^-9 .. 2^-8) and the worst
-        # element -- an omitted term, a wrong row or a transposed operand is an O(1) distance.
-        G2 = dict(frac_gate=None, l2=1e-2, worst=2e-2)
+        # ---- backward (the kernel ran on ITS OWN saved tensors, as in a step).  The oracle's adjoint follows the kernels' (oracle
+        # _AttnCoreBF16 / _GeluSavedBF16 / _rg): q, k, v and h are re-read as the forward STORED them (bf16), S and P rebuilt from those,
+        # dY operands rounded where they enter a product, the DropPath scale applied after the product.  Measured on MI355X: input
+        # gradients 2e-4 relative L2 with 1 % of the elements beyond 1e-4 of the scale (the oracle against itself in fp64: 0.9-1.2 %),
+        # 0.03-0.23 % of the stored bf16 gradients more than one bf16 step off (fp64 self-check: 0.03-0.16 %), LayerNorm sums 1-4e-4.
+        G2 = dict(frac_gate=5e-2, l2=2e-3, worst=2e-2)
+        G16 = dict(frac_gate=1e-2, worst=2e-2, bf16=True)
+        GS = dict(frac_gate=None, l2=2e-3, worst=5e-3)
         if cross:
             rep.add(n + "dxn (q path)", b["dx"], aux["xn"].grad.reshape(T, C), **G2)
             rep.add(n + "dxs", b["dxs"], kv_given.grad.reshape(T, C), **G2)
@@ -179,15 +185,15 @@ def test_block_launches_against_the_oracle(ops, hook, dims, kind, wave):
         else:
             rep.add(n + "dx", b["dx"], x.grad.reshape(T, C), **G2)
             part = b["ln1_part"].double().sum(0)
-            rep.add(n + "d ln1 gain", part[:C], leaves["norm1.weight"].grad, **G2)
-            rep.add(n + "d ln1 bias", part[C:], leaves["norm1.bias"].grad, **G2)
+            rep.add(n + "d ln1 gain", part[:C], leaves["norm1.weight"].grad, **GS)
+            rep.add(n + "d ln1 bias", part[C:], leaves["norm1.bias"].grad, **GS)
         part = b["ln2_part"].double().sum(0)
-        rep.add(n + "d ln2 gain", part[:C], leaves["norm2.weight"].grad, **G2)
-        rep.add(n + "d ln2 bias", part[C:], leaves["norm2.bias"].grad, **G2)
-        rep.add(n + "dq", b["dq"].float(), _tok(aux["q_w"].grad, dims, C), bf16=True, **G2)
-        rep.add(n + "dkv", b["dkv"].float(), _tok(aux["kv_w"].grad, dims, 2 * C), bf16=True, **G2)
-        rep.add(n + "dh", b["dh"].float(), aux["h"].grad.reshape(T, 4 * C), bf16=True, **G2)
-        rep.add(n + "dx1", b["dx1"].float(), aux["x1"].grad.reshape(T, C), bf16=True, **G2)
+        rep.add(n + "d ln2 gain", part[:C], leaves["norm2.weight"].grad, **GS)
+        rep.add(n + "d ln2 bias", part[C:], leaves["norm2.bias"].grad, **GS)
+        rep.add(n + "dq", b["dq"].float(), _tok(aux["q_w"].grad, dims, C), **G16)
+        rep.add(n + "dkv", b["dkv"].float(), _tok(aux["kv_w"].grad, dims, 2 * C), **G16)
+        rep.add(n + "dh", b["dh"].float(), aux["h"].grad.reshape(T, 4 * C), **G16)
+        rep.add(n + "dx1", b["dx1"].float(), aux["x1"].grad.reshape(T, C), **G16)
         rep.add(n + "dy16", b["dy16"].float(), dys[i], 0.0, bf16=True, worst=4e-3)
     rep.done(f"{'wave-private' if wave else 'tile'} kernels, {kind} pair, dims {dims}: distance to the oracle in bf16-operand mode")
 

@@ -143,11 +143,9 @@ __device__ __forceinline__ void ln_bwd_v2_body(const float* dy, const float* __r
                                                  const float* __restrict__ rstd, const float* __restrict__ gamma, float* dx, float* dx2,
                                                  float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows, int C,
                                                  const float* add, float* __restrict__ partials, int rpb) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];   // [2][C]
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // [4 waves][2][C]
   constexpr int RPW = 64 / LPR;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane % LPR, rg = lane / LPR;
-  for (int c = threadIdx.x; c < 2 * C; c += 256) sm[c] = 0.f;
-  __syncthreads();
   const int64_t r_end = ((int64_t)(blockIdx.x + 1) * rpb < rows) ? (int64_t)(blockIdx.x + 1) * rpb : rows;
   float4 g[VPL], ag[VPL], ab[VPL];
 #pragma unroll
@@ -188,14 +186,24 @@ __device__ __forceinline__ void ln_bwd_v2_body(const float* dy, const float* __r
       }
     }
   }
+  // Column sums of the workgroup without LDS atomics (they retire one wave instruction per ~85 cycles and the 16 row groups of a
+  // workgroup hit the same 2C addresses: 2048 conflicting atomics per workgroup were most of this kernel): the row groups of a wave
+  // meet in shuffles, every wave writes ONE plain [2C] row, thread c adds the four rows.
 #pragma unroll
   for (int k = 0; k < VPL; ++k) {
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) {
+      ag[k].x += __shfl_xor(ag[k].x, o, 64); ag[k].y += __shfl_xor(ag[k].y, o, 64); ag[k].z += __shfl_xor(ag[k].z, o, 64); ag[k].w += __shfl_xor(ag[k].w, o, 64);
+      ab[k].x += __shfl_xor(ab[k].x, o, 64); ab[k].y += __shfl_xor(ab[k].y, o, 64); ab[k].z += __shfl_xor(ab[k].z, o, 64); ab[k].w += __shfl_xor(ab[k].w, o, 64);
+    }
     const int c = (sub + k * LPR) * 4;
-    if (c < C) {
-      atomicAdd(&sm[c], ag[k].x); atomicAdd(&sm[c + 1], ag[k].y); atomicAdd(&sm[c + 2], ag[k].z); atomicAdd(&sm[c + 3], ag[k].w);
-      atomicAdd(&sm[C + c], ab[k].x); atomicAdd(&sm[C + c + 1], ab[k].y); atomicAdd(&sm[C + c + 2], ab[k].z); atomicAdd(&sm[C + c + 3], ab[k].w);
+    if (rg == 0 && c < C) {
+      *reinterpret_cast<float4*>(sm + wave * 2 * C + c) = ag[k];
+      *reinterpret_cast<float4*>(sm + wave * 2 * C + C + c) = ab[k];
     }
   }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * C; c += 256) sm[c] = (sm[c] + sm[2 * C + c]) + (sm[4 * C + c] + sm[6 * C + c]);
   __syncthreads();
   if (partials) {     // [block][2C]: summed later by micf_layernorm_bwd_finish -- hundreds of workgroups adding into the same 2C
                       // addresses with device-scope atomics serialise, and nobody on the backward chain needs dgamma / dbeta
@@ -259,6 +267,9 @@ static bool ln_v2_shape(int C, int& lpr, int& vpl) {
   vpl = (nv + lpr - 1) / lpr;
   return vpl <= 8;
 }
+// workgroups of the vector backward (= rows of its partial gain / bias sums).  (2048 measured: the 131072-row launch 84 -> 58 us, the
+// 65536-row one 37 -> 62 us, the step the same: 512 stays.)
+constexpr int kLnBwdBlocks = 512;
 static int ln_v2_rpb(int64_t rows, int lpr, int max_blocks) {
   const int step = 4 * (64 / lpr);
   int64_t rpb = (rows + max_blocks - 1) / max_blocks;
@@ -325,7 +336,7 @@ extern "C" int micf_layernorm_fwd(const float* x1, const float* x2, int c1, cons
 extern "C" int micf_layernorm_bwd_partial_rows(int64_t rows, int C, int c1) {
   int lpr, vpl;
   if (rows <= 0 || C <= 0 || c1 <= 0 || c1 > C || (c1 & 3) || ((C - c1) & 3) || C > kLnMaxC || !ln_v2_shape(C, lpr, vpl)) return 0;
-  return ceil_div(rows, ln_v2_rpb(rows, lpr, 512));
+  return ceil_div(rows, ln_v2_rpb(rows, lpr, kLnBwdBlocks));
 }
 
 extern "C" int micf_layernorm_bwd_finish(const micf_ln_finish_item* items, int n, micf_stream_t stream) {
@@ -365,7 +376,7 @@ extern "C" int micf_layernorm_bwd(const float* dy, const float* x1, const float*
       (!add || aligned16(add))) {
     LnBwdSets p;
     p.s[0] = p.s[1] = LnBwdSet{dy, x1, mean, rstd, gamma, dx1, dgamma, dbeta, add, partials, c1 == C ? x1 : x2, c1 == C ? dx1 : dx2, c1};
-    MICF_LN_DISPATCH(ln_bwd_v2, 2 * C * sizeof(float), 512, 1, p, rows, C);
+    MICF_LN_DISPATCH(ln_bwd_v2, 8 * C * sizeof(float), kLnBwdBlocks, 1, p, rows, C);
     MICF_RETURN_LAUNCH();
   }
   if (partials) return MICF_EUNSUPPORTED;          // the partial form exists for the vector kernel only (see ..._partial_rows)
@@ -425,6 +436,6 @@ extern "C" int micf_layernorm_bwd_pair(const micf_ln_bwd_pair_item* items, int n
     }
     return MICF_OK;
   }
-  MICF_LN_DISPATCH(ln_bwd_v2, 2 * C * sizeof(float), 512, n, p, rows, C);
+  MICF_LN_DISPATCH(ln_bwd_v2, 8 * C * sizeof(float), kLnBwdBlocks, n, p, rows, C);
   MICF_RETURN_LAUNCH();
 }

@@ -97,3 +97,17 @@ def test_reference_loop_body_on_the_hip_modules_against_f5():
     close(torch.tensor(losses[1]), g["loss2"], 2e-5, "loss2")
     # the never-used concat_back_dim.0 has no gradient at all in this loop (MS.py:1015-1016), exactly as in the reference
     assert model_1.swin.concat_back_dim[0].weight.grad is None
+
+
+def test_block_parameters_resolved_by_state_dict_name_without_walking_the_module():
+    """The per-call parameter lookup of a block (host code of the engine-less path) returns exactly named_parameters()' tensors for
+    every key the launches use, and sees a parameter replaced after construction."""
+    from micformer_amd import functional as Fn
+    import micformer_amd.models.MICFormer_self as M
+    for blk, keys in ((M.TransformerBlock3D(48, 3, window_size=(2, 2, 2)), Fn.SELF_KEYS),
+                      (M.CrossTransformerBlock3D(48, 3, window_size=(2, 2, 2)), Fn.CROSS_KEYS)):
+        want = dict(blk.named_parameters())
+        got = M._block_params(blk, keys)
+        assert len(got) == len(keys) and all(g is want[k] for g, k in zip(got, keys))
+        blk.mlp.fc1.weight = torch.nn.Parameter(torch.zeros_like(blk.mlp.fc1.weight))
+        assert M._block_params(blk, ("mlp.fc1.weight",))[0] is blk.mlp.fc1.weight

@@ -360,6 +360,9 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
   if (!g.dxs && !pre) r_ln1.load(tok, tk0, g.x + (int64_t)tk0 * C, g.stats + tk0, g.stats + T + tk0, g.ln1_g);
   r_q.load(tok, tk0, q0, (uint32_t)C);
   r_kv.load(tok, tk0, kv0, (uint32_t)(2 * C));
+  // (block_fused.h warm_weights: the XCD's weight set, in the order the phases below read it)
+  uint32_t warm = 0;
+  if constexpr (C >= 96) warm = warm_weights<C, NTHR, 4, 4, 1, 1, 2>(blockIdx.x, tid, w2t, w1t, wpt, wqt, wkvt);
 
   // ---- dy rows -> A1 (+ the bf16 copy fc2's weight gradient reads)
   if (!pre) {
@@ -398,6 +401,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
       lds_barrier();
     }
     gemm_phase<TJ, NSL, 1, C, NW, BF16>(w2t + (int64_t)c0 * C, hc, A1, nullptr, 0, nullptr, S, U, SU, EpiGeluGrad<BF16>{sc2});
+    if (ch == 0) asm volatile("" :: "v"(warm));
 #pragma unroll 1
     for (int pass = 0; pass < NPASS; ++pass) {
       const int row = pass * RPP + wave * 4 + rg;

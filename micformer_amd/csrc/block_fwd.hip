@@ -161,6 +161,9 @@ __device__ __forceinline__ void block_fwd_tile(const BlkFwdArgs& a, const unsign
       *reinterpret_cast<float4*>(PV + e) = ld4g(sp + (e - so));
     }
   }
+  // (C >= 96: the tile kernels of the 16^3 / 8^3 stages; the C = 48 tile kernel serves the fp32 mode of the big grids only)
+  uint32_t warm = 0;
+  if constexpr (C >= 96) warm = warm_weights<C, NTHR, 1, 2, 1, 4, 4>(bid, tid, wq, wkv, wp, w1, w2);
   lds_barrier();
 
   // ---- LayerNorm 1 straight from HBM: all rows of this lane group in flight at once -> registers -> (xn -> A1 + HBM,
@@ -214,6 +217,7 @@ __device__ __forceinline__ void block_fwd_tile(const BlkFwdArgs& a, const unsign
   if (!(a.debug & 4)) {
     // q | k | v in ONE phase (two weight segments; the biases bq | bkv are contiguous in PV)
     gemm_phase<TJ, NSL, 1, C, NW, BF16>(wq, C, A1, wkv, 2 * C, cross ? A2 : A1, S, U, SU, EpiBias{p_bq});
+    asm volatile("" :: "v"(warm));                        // (the warm-up's loads have returned: in order, in front of this phase's)
   }
   if (save) {
 #pragma unroll 1

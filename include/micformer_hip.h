@@ -500,6 +500,15 @@ typedef struct micf_block_fwd_group {
   const float *ln16_g, *ln16_b, *w1c; /* conv_offset.1.norm.{weight,bias} [16], conv_offset.3.weight [3, 16] */
   float* flow;             /* out [T, 3]: offsets + reference points (the sampler's backward reads them) */
   float* xs32;             /* out, optional, fp32 storage only: [T, C] the sampled rows (operand of the kv weight gradient) */
+  /* Optional epilogue: the LayerNorm the NEXT block applies to this block's output -- a cross block's norm1 on the self block's y
+   * (MS.py:343), whose result feeds conv_offset[0] -- written by the same launch from the y rows it holds, so that no
+   * micf_layernorm_fwd(_pair) launch has to re-read y (same arithmetic: mean, biased variance, 1 / sqrt(var + eps), eps of this
+   * call).  Available exactly where micf_block_fuses_sampler(C, heads) != 0 (MICF_EUNSUPPORTED on the few-token decomposition);
+   * also in the inference form.  nln_g == NULL: no epilogue; otherwise nln_b, nln_y, nln_mean, nln_rstd must be non-NULL. */
+  const float *nln_g, *nln_b;             /* [C] gain / bias of that LayerNorm */
+  float *nln_y, *nln_mean, *nln_rstd;     /* out [T, C], [T], [T] */
+  float* zero16;           /* optional, with nln_g: [T, 16] floats cleared by the launch (the atomically accumulated output of
+                              micf_offset_head_fwd on small grids, hid_zeroed = 1) */
 } micf_block_fwd_group;
 int micf_block_fuses_sampler(int C, int heads);
 /* STORAGE of the saved tensors.  micf_block_saves_bf16(C, heads, dtype) != 0 (MICF_DTYPE_BF16 on the tile-per-workgroup kernels,

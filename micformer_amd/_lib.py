@@ -159,7 +159,8 @@ _VP = ctypes.c_void_p
 class BlockFwdGroup(ctypes.Structure):
     """struct micf_block_fwd_group (include/micformer_hip.h)."""
     FIELDS = ("x", "kvsrc", "ln1_g", "ln1_b", "bq", "bkv", "bp", "ln2_g", "ln2_b", "b1", "b2", "wq", "wkv", "wp", "w1", "w2",
-              "s1", "s2", "y", "xn", "q", "kv", "o", "x1", "xn2", "h", "g", "stats", "kvs16", "hid", "samp_src", "ln16_g", "ln16_b", "w1c", "flow", "xs32")
+              "s1", "s2", "y", "xn", "q", "kv", "o", "x1", "xn2", "h", "g", "stats", "kvs16", "hid", "samp_src", "ln16_g", "ln16_b", "w1c", "flow", "xs32",
+              "nln_g", "nln_b", "nln_y", "nln_mean", "nln_rstd", "zero16")
     _fields_ = [(n, _VP) for n in FIELDS]
 
 

@@ -161,6 +161,9 @@ __device__ __forceinline__ void block_fwd_tile(const BlkFwdArgs& a, const unsign
       *reinterpret_cast<float4*>(PV + e) = ld4g(sp + (e - so));
     }
   }
+  // (epilogue LayerNorm: its gain | bias take the LDS slots of LayerNorm 1's once that phase is over)
+  float4 nl4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (g.nln_g && tid < 2 * C4) nl4 = tid < C4 ? ld4g(g.nln_g + 4 * tid) : ld4g(g.nln_b + 4 * (tid - C4));
   // (C >= 96: the tile kernels of the 16^3 / 8^3 stages; the C = 48 tile kernel serves the fp32 mode of the big grids only)
   uint32_t warm = 0;
   if constexpr (C >= 96) warm = warm_weights<C, NTHR, 1, 2, 1, 4, 4>(bid, tid, wq, wkv, wp, w1, w2);
@@ -218,6 +221,7 @@ __device__ __forceinline__ void block_fwd_tile(const BlkFwdArgs& a, const unsign
     // q | k | v in ONE phase (two weight segments; the biases bq | bkv are contiguous in PV)
     gemm_phase<TJ, NSL, 1, C, NW, BF16>(wq, C, A1, wkv, 2 * C, cross ? A2 : A1, S, U, SU, EpiBias{p_bq});
     asm volatile("" :: "v"(warm));                        // (the warm-up's loads have returned: in order, in front of this phase's)
+    if (g.nln_g && tid < 2 * C4) *reinterpret_cast<float4*>(PV + 4 * tid) = nl4;   // (p_ln1g | p_ln1b: read again in the last pass only)
   }
   if (save) {
 #pragma unroll 1
@@ -394,19 +398,53 @@ __device__ __forceinline__ void block_fwd_tile(const BlkFwdArgs& a, const unsign
     if (!(a.debug & 4)) gemm_phase<TJ, NSL, HC / C, Hd, NW, BF16>(w2 + 16 * c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiAccScale{sc2});
   }
 
-  // ---- y = x1 + s2 * (fc2 + b2)
+  // ---- y = x1 + s2 * (fc2 + b2); optional epilogue: the NEXT block's LayerNorm of the row (micf_block_fwd_group.nln_g) while the
+  // 16-lane group still holds it -- the cross block's norm1, otherwise a launch of its own that re-reads y
+  const bool nln = g.nln_g != nullptr;                  // (workgroup-uniform)
 #pragma unroll 1
   for (int pass = 0; pass < NPASS; ++pass) {
     const int row = pass * RPP + wave * 4 + rg;
     if (row >= TM) continue;
     const int tk = tok[row];
-    if (tk < 0) continue;
+    if (tk < 0) continue;                               // (uniform over the 16 lanes of a row)
     const float s2v = sc2[row];
-    for (int c4 = l16; c4 < C4; c4 += 16) {
-      float4 v = *reinterpret_cast<const float4*>(A2 + row * S + 4 * c4);
-      const float4 b = *reinterpret_cast<const float4*>(p_b2 + 4 * c4);
-      v.x += s2v * b.x; v.y += s2v * b.y; v.z += s2v * b.z; v.w += s2v * b.w;
-      st4g(g.y + (int64_t)tk * C + 4 * c4, v);
+    float4 v[VPL];
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+      const int c4 = l16 + 16 * k;
+      v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c4 < C4) {
+        v[k] = *reinterpret_cast<const float4*>(A2 + row * S + 4 * c4);
+        const float4 b = *reinterpret_cast<const float4*>(p_b2 + 4 * c4);
+        v[k].x += s2v * b.x; v[k].y += s2v * b.y; v[k].z += s2v * b.z; v[k].w += s2v * b.w;
+        st4g(g.y + (int64_t)tk * C + 4 * c4, v[k]);
+      }
+    }
+    if (nln) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < VPL; ++k) s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+      const float mu = sum16(s) * invC;
+      float qd = 0.f;
+#pragma unroll
+      for (int k = 0; k < VPL; ++k) {
+        if (l16 + 16 * k < C4) {
+          const float d0 = v[k].x - mu, d1 = v[k].y - mu, d2 = v[k].z - mu, d3 = v[k].w - mu;
+          qd += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+      }
+      const float rs = 1.0f / sqrtf(sum16(qd) * invC + a.eps);
+#pragma unroll
+      for (int k = 0; k < VPL; ++k) {
+        const int c4 = l16 + 16 * k;
+        if (c4 < C4) {
+          const float4 gm = *reinterpret_cast<const float4*>(p_ln1g + 4 * c4), bt = *reinterpret_cast<const float4*>(p_ln1b + 4 * c4);
+          st4g(g.nln_y + (int64_t)tk * C + 4 * c4, make_float4((v[k].x - mu) * rs * gm.x + bt.x, (v[k].y - mu) * rs * gm.y + bt.y,
+                                                                (v[k].z - mu) * rs * gm.z + bt.z, (v[k].w - mu) * rs * gm.w + bt.w));
+        }
+      }
+      if (l16 == 0) { g.nln_mean[tk] = mu; g.nln_rstd[tk] = rs; }
+      if (g.zero16) g.zero16[(int64_t)tk * 16 + l16] = 0.f;
     }
   }
 }
@@ -548,6 +586,15 @@ extern "C" int micf_block_fwd(const micf_block_fwd_group* groups, int ngroups, i
       if (g.kvsrc || !g.samp_src || !g.ln16_g || !g.ln16_b || !g.w1c || (!g.flow && !ns) || (reinterpret_cast<uintptr_t>(g.samp_src) & 15) ||
           (g.xs32 && (reinterpret_cast<uintptr_t>(g.xs32) & 15)) || block_wide_tile_tokens(C, C / heads))
         return MICF_EINVAL;
+    }
+    if (g.nln_g) {    // epilogue: the next block's LayerNorm of y
+      const void* need[] = {g.nln_g, g.nln_b, g.nln_y, g.nln_mean, g.nln_rstd};
+      for (const void* p : need)
+        if (!p || (reinterpret_cast<uintptr_t>(p) & 15)) return MICF_EINVAL;
+      if (g.zero16 && (reinterpret_cast<uintptr_t>(g.zero16) & 15)) return MICF_EINVAL;
+      if (block_wide_tile_tokens(C, C / heads)) return MICF_EUNSUPPORTED;
+    } else if (g.nln_b || g.nln_y || g.nln_mean || g.nln_rstd || g.zero16) {
+      return MICF_EINVAL;
     }
     a.g[i] = g;
   }

@@ -33,7 +33,7 @@ constexpr int kF32 = kP16 + 9 * 512;             // [12][64] x 16 B  fc1 blocks,
 constexpr int kF16 = kF32 + 12 * 1024;           // [12][64] x 8 B
 constexpr int kG32 = kF16 + 12 * 512;            // [3][6][64] x 16 B fc2: block, k chunk
 constexpr int kVec = kG32 + 18 * 1024;           // floats: ln1_g ln1_b bq bkv(2C) bp ln2_g ln2_b b2 | b1(HID)
-constexpr int kLdsBytes = kVec + (9 * C + HID) * 4;
+constexpr int kLdsBytes = kVec + (9 * C + HID + 2 * C) * 4;     // (+ gain | bias of the epilogue LayerNorm, micf_block_fwd_group.nln_g)
 
 
 __device__ __forceinline__ void stage_weights(char* lds, const micf_block_fwd_group& g) {
@@ -74,6 +74,8 @@ __device__ __forceinline__ void stage_weights(char* lds, const micf_block_fwd_gr
     for (int j = 1; j < 9; ++j) if (k == j) { sp = srcs[j]; so = offs[j]; }
     *reinterpret_cast<float4*>(PV + e) = ld4g(sp + (e - so));
   }
+  if (g.nln_g && tid < 2 * C / 4)
+    *reinterpret_cast<float4*>(PV + 9 * C + HID + 4 * tid) = tid < C / 4 ? ld4g(g.nln_g + 4 * tid) : ld4g(g.nln_b + 4 * (tid - C / 4));
 }
 
 
@@ -316,6 +318,17 @@ __global__ void __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(4, 4)
 #pragma unroll
         for (int r = 0; r < 4; ++r) y.v[4 * j + r] = x1.v[4 * j + r] + s2v * (y3[j][r] + b2[4 * j + r]);
       if (live0) y.store(g.y + tk * C, lr);
+      if (g.nln_g) {
+        // epilogue: the NEXT block's LayerNorm of the row (the cross block's norm1, otherwise a launch of its own that re-reads y)
+        Row12 z;
+        float mu, rs;
+        layernorm12(y, PV + 9 * C + HID, PV + 10 * C + HID, lr, a.eps, z, mu, rs);
+        if (live0) {
+          z.store(g.nln_y + tk * C, lr);
+          if (lr == 0) { g.nln_mean[tk] = mu; g.nln_rstd[tk] = rs; }
+          if (g.zero16) *reinterpret_cast<float4*>(g.zero16 + tk * 16 + 4 * lr) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
     }
     cur = nxt;
   }

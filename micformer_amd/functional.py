@@ -52,7 +52,7 @@ class StepContext:
                   has launched its next kernel: LAZY_FLUSH), wside_used (devices whose side stream must be joined)
       hooks       entry_hooks / entry_seen (forward: work parked until the n-th stage entry), backward_hooks (per stage module)
       mailboxes   loss_mail (target in, fused loss out), cross_after_self (the self pair's outputs BasicLayer is about to hand to
-                  the cross pair), lazy_ln (parked LayerNorm-1 backward records), skip_tokens (ConvDownFn inputs of THIS forward),
+                  the cross pair), next_ln / next_ln_out (the cross pair's LayerNorm 1 as the self pair launch's epilogue), lazy_ln (parked LayerNorm-1 backward records), skip_tokens (ConvDownFn inputs of THIS forward),
                   carry (step_many: the batches carried to the next step's head)
     """
 
@@ -74,6 +74,8 @@ class StepContext:
         self.backward_hooks = {}           # id(stage module) -> callable run when the backward has left that stage
         self.loss_mail = {"target": None, "result": None}
         self.cross_after_self = None       # (data_ptr, data_ptr)
+        self.next_ln = None                # [(gamma, beta)] * 2: the cross pair's norm1, for the self pair launch about to be issued
+        self.next_ln_out = None            # ((data_ptr, data_ptr) of the self pair's outputs, [(xn, mean, rstd)] * 2, hid | None)
         self.lazy_ln = {}                  # data_ptr of the partial-sum buffer handed to autograd -> the parked record
         self.skip_tokens = {}              # data_ptr of a ConvDownFn input of THIS forward -> token
         self.carry = {"on": False, "open": False, "stash": []}
@@ -1033,11 +1035,26 @@ def _ln_partials(side, part, tiles, C, dg, db):
         ops.layernorm_bwd_finish([item])
 
 
-def _self_fwd_fused(xs, Ps, scales, dims, heads, eps, save=True):
-    """xs: 1 or 2 [T, C] inputs (the two modalities); one launch.  Returns the per-group saved dicts (save=False: 'y' only)."""
+# The cross pair of a depth slot starts with LayerNorm 1 of the self pair's outputs (MS.py:343; its result feeds conv_offset[0]): the
+# self pair's launch holds those rows when it writes them, so it writes their LayerNorm too (micf_block_fwd_group.nln_g) -- one
+# launch and one re-read of y per slot off the forward chain.  BasicLayer hands the cross blocks' norm1 over in CTX.next_ln.
+FUSE_NEXT_LN = True
+
+
+def _self_fwd_fused(xs, Ps, scales, dims, heads, eps, save=True, next_ln=None):
+    """xs: 1 or 2 [T, C] inputs (the two modalities); one launch.  Returns the per-group saved dicts (save=False: 'y' only).
+    next_ln: [(gamma, beta)] per group -> every dict also has "nln" = (LayerNorm(y), mean, rstd); the launch clears `hid` where
+    the offset convolution accumulates into it (returned as the second value then)."""
     C = xs[0].shape[1]
     groups = [{"x": x, "kvsrc": None, "P": P, "attn": "self_attn", "s1": s[0], "s2": s[1]} for x, P, s in zip(xs, Ps, scales)]
-    return ops.block_fwd(groups, dims, C, heads, eps, (C // heads) ** -0.5, save=save)
+    if next_ln is None:
+        return ops.block_fwd(groups, dims, C, heads, eps, (C // heads) ** -0.5, save=save)
+    hid = None
+    if ops.offset_head_needs_zero(dims, C):
+        hid = torch.empty((len(xs), xs[0].shape[0], 16), dtype=torch.float32, device=xs[0].device)
+    for i, gd in enumerate(groups):
+        gd["next_ln"] = (next_ln[i][0], next_ln[i][1], hid[i] if hid is not None else None)
+    return ops.block_fwd(groups, dims, C, heads, eps, (C // heads) ** -0.5, save=save), hid
 
 
 # The LayerNorm-1 backward of a cross pair (MS.py:343 through autograd) produces exactly the output gradients of the self pair of the
@@ -1097,7 +1114,12 @@ class SelfPairFn(torch.autograd.Function):
         # torch.no_grad() needs_input_grad still reports the trainable parameters.  No gradient will be asked for (validation, the
         # sliding-window inference): nothing is saved, the launch writes y only.
         save = bool(grad_mode) and any(ctx.needs_input_grad)
-        svs = _self_fwd_fused(xs, Ps, scales, dims, heads, eps, save=save)
+        nl, CTX.next_ln, CTX.next_ln_out = CTX.next_ln, None, None
+        if nl is not None and FUSE_NEXT_LN and GROUP_CROSS_HEADS and ops.block_fuses_sampler(C, heads):
+            svs, hid = _self_fwd_fused(xs, Ps, scales, dims, heads, eps, save=save, next_ln=nl)
+            CTX.next_ln_out = ((svs[0]["y"].data_ptr(), svs[1]["y"].data_ptr()), [svs[0]["nln"], svs[1]["nln"]], hid)
+        else:
+            svs = _self_fwd_fused(xs, Ps, scales, dims, heads, eps, save=save)
         if save:
             ctx.save_for_backward(*xs, *[sv[k] for sv in svs for k in _SV_KEYS], sa1, sa2, sb1, sb2, *params)
             ctx.meta = (dims, heads)
@@ -1209,10 +1231,14 @@ class CrossPairFn(torch.autograd.Function):
         fuse_sampler = GROUP_CROSS_HEADS and FUSE_SAMPLER and ops.block_fuses_sampler(C, heads)
         if GROUP_CROSS_HEADS:
             # both offset heads per launch (micf_offset_head_fwd): no fork / join inside the captured graph
-            hid = None
-            if ops.offset_head_needs_zero(dims, C):     # (atomically accumulated conv output: cleared by the LayerNorm launch)
-                hid = torch.empty((2, xs[0].shape[0], 16), dtype=torch.float32, device=x.device)
-            lns = ops.layernorm_fwd_pair(xs, [P["norm1.weight"] for P in Ps], [P["norm1.bias"] for P in Ps], eps, zero=hid)
+            pre, CTX.next_ln_out = CTX.next_ln_out, None
+            if pre is not None and pre[0] == (xs[0].data_ptr(), xs[1].data_ptr()):
+                lns, hid = pre[1], pre[2]               # (written, and `hid` cleared, by the self pair's launch: FUSE_NEXT_LN)
+            else:
+                hid = None
+                if ops.offset_head_needs_zero(dims, C):     # (atomically accumulated conv output: cleared by the LayerNorm launch)
+                    hid = torch.empty((2, xs[0].shape[0], 16), dtype=torch.float32, device=x.device)
+                lns = ops.layernorm_fwd_pair(xs, [P["norm1.weight"] for P in Ps], [P["norm1.bias"] for P in Ps], eps, zero=hid)
             # (fuse_sampler: the 3^3 conv only -- LayerNorm(16) / GELU / 1^3 conv / sampling run inside the block launch below)
             outs = ops.offset_head_fwd([{"xn": lns[i][0], "xa": xs[1 - i], "P": Ps[i]} for i in (0, 1)], dims, eps, hid,
                                        sample=not fuse_sampler)

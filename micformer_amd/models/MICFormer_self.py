@@ -445,6 +445,10 @@ class BasicLayer(nn.Module):
                 x, xa = Fn.FlushPointFn.apply(x, xa)   # backward: the later slots' weight gradients start under the earlier slots' chain
             a, b = self.self_blocks1[i], self.self_blocks2[i]
             sa, sb = _block_scales(a, x), _block_scales(b, xa)
+            ca, cb = self.blocks1[i], self.blocks2[i]
+            # (the cross pair's LayerNorm 1 of the self pair's outputs rides in the self pair's launch: functional.FUSE_NEXT_LN)
+            Fn.CTX.next_ln = [(ca.norm1.weight, ca.norm1.bias), (cb.norm1.weight, cb.norm1.bias)] \
+                if ca.norm1.eps == a.norm1.eps == cb.norm1.eps else None
             x, xa = Fn.SelfPairFn.apply(x, xa, sa[0], sa[1], sb[0], sb[1], a.num_heads, a.norm1.eps, grad_mode,
                                         *_block_params(a, Fn.SELF_KEYS), *_block_params(b, Fn.SELF_KEYS))
             a, b = self.blocks1[i], self.blocks2[i]

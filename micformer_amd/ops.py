@@ -1113,6 +1113,9 @@ def block_recomputes_h(C, heads):
 def block_fwd(groups, dims, C, heads, eps, scale, persist_probe=None, save=True):
     """groups: 1 or 2 dicts {x [T,C], kvsrc [T,C] | None, P {state_dict-style name: tensor}, attn 'self_attn' | 'cross_attn',
     s1, s2 [B] | None, want_xn bool}.  ONE launch.  Returns per group a dict of the tensors saved for backward (+ 'y').
+    A group may carry "next_ln": (gamma, beta, zero16 | None) -- the LayerNorm the NEXT block applies to this block's output (a cross
+    block's norm1), written by the same launch (block_fuses_sampler shapes only): its dict then has "nln" = (y_normed, mean, rstd);
+    zero16: a [T, 16] fp32 tensor the launch clears.
     persist_probe: (repeats, int32[2] device tensor) -- the measurement probe micf_block_fwd_persistent_probe instead.
     save=False (no backward will follow): the inference form where the kernels have one (block_fuses_sampler shapes: everything but
     the few-token decomposition) -- only 'y' is written, every other entry of the returned dicts is None."""
@@ -1149,6 +1152,12 @@ def block_fwd(groups, dims, C, heads, eps, scale, persist_probe=None, save=True)
         if fused_sampler:
             it.hid, it.samp_src = f32(gd["hid"]), f32(gd["samp_src"])
             it.ln16_g, it.ln16_b, it.w1c = (f32(P[k]) for k in ("conv_offset.1.norm.weight", "conv_offset.1.norm.bias", "conv_offset.3.weight"))
+        nl = gd.get("next_ln")
+        if nl is not None:
+            o["nln"] = (_new(x, T, C), _new(x, T), _new(x, T))
+            it.nln_g, it.nln_b, it.zero16 = f32(nl[0]), f32(nl[1]), f32(nl[2])
+            it.nln_y, it.nln_mean, it.nln_rstd = (f32(t) for t in o["nln"])
+            nb += 4 * T * (C + 2)
         for field, key in FWD_W:
             setattr(it, field, f32(P[key.format(a=a)]))
         wts = block_weights(P, a, backward=False)
@@ -1156,11 +1165,12 @@ def block_fwd(groups, dims, C, heads, eps, scale, persist_probe=None, save=True)
         for field, wt in wts.items():
             setattr(it, field, ptr(wt))
         for k, v in o.items():
-            setattr(it, k, ptr(v))
+            if k != "nln":
+                setattr(it, k, ptr(v))
         outs.append(o)
         # bytes the launch moves: read x (+ kvsrc), write everything in `o`; the weights once
         nb += 4 * T * C * (2 if cross else 1) + (64 * T if fused_sampler else 0) \
-            + sum(v.numel() * v.element_size() for v in o.values() if v is not None) \
+            + sum(v.numel() * v.element_size() for k, v in o.items() if v is not None and k != "nln") \
             + 12 * C * C * wt.element_size()
         fl += 2 * T * 12 * C * C + 4 * T * C * 8
     if persist_probe is not None:

@@ -336,3 +336,53 @@ def test_persistent_probe_matches_the_launch(ops):
             ops.block_fwd(small, (2, 4, 4, 4), 96, 6, 1e-5, 0.25, persist_probe=(2, sync))
     finally:
         ops.set_compute_dtype("fp32")
+
+
+@pytest.mark.parametrize("case", [(2, 4, 4, 4, 48, 3), (1, 2, 2, 2, 48, 3), (1, 4, 6, 4, 96, 6), (2, 4, 4, 2, 192, 12), (2, 8, 8, 8, 192, 12)])
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("save", [True, False])
+def test_next_layernorm_as_the_forward_epilogue(ops, case, mode, save):
+    """micf_block_fwd_group.nln_g: the LayerNorm the next block applies to y (a cross block's norm1), written by the launch that
+    writes y, against micf_layernorm_fwd on that y: same arithmetic, 1e-6-class; the [T, 16] buffer it is asked to clear is clear;
+    two groups with different gains, tile kernels (C = 96 / 192, fp32-mode C = 48), wave-private kernels (bf16 C = 48), training
+    and inference form.  The other outputs of the launch do not change."""
+    B, D, H, W, C, heads = case
+    dims, T = (B, D, H, W), B * D * H * W
+    eps, scale = 1e-5, (C // heads) ** -0.5
+    ops.set_compute_dtype(mode)
+    try:
+        groups, plain = [], []
+        for gi in range(2):
+            P = make_params(C, 4 * C, "self_attn", 300 * gi + C)
+            x = rnd((T, C), 300 * gi + 7)
+            gam, bet = 1 + rnd((C,), 300 * gi + 8, 0.2), rnd((C,), 300 * gi + 9, 0.2)
+            z16 = torch.full((T, 16), 3.0, device="cuda")
+            base = {"x": x, "kvsrc": None, "P": P, "attn": "self_attn", "s1": None, "s2": None}
+            plain.append(dict(base))
+            groups.append(dict(base, next_ln=(gam, bet, z16 if gi == 0 else None)))
+        ref = ops.block_fwd(plain, dims, C, heads, eps, scale, save=save)
+        out = ops.block_fwd(groups, dims, C, heads, eps, scale, save=save)
+        errs = []
+        for gi, (o, r, gd) in enumerate(zip(out, ref, groups)):
+            for k in ("y", "x1", "q", "g"):
+                if r[k] is not None:
+                    assert torch.equal(o[k], r[k]), f"g{gi} {k} changed with the epilogue"
+            yn, mean, rstd = ops.layernorm_fwd(o["y"], gd["next_ln"][0], gd["next_ln"][1], eps)
+            check(f"g{gi} nln", o["nln"][0], yn, 2e-6, errs)
+            check(f"g{gi} mean", o["nln"][1], mean, 2e-6, errs)
+            check(f"g{gi} rstd", o["nln"][2], rstd, 2e-6, errs)
+        assert not errs, "\n".join(errs)
+        assert float(groups[0]["next_ln"][2].abs().max()) == 0.0
+    finally:
+        ops.set_compute_dtype("fp32")
+
+
+def test_next_layernorm_epilogue_is_refused_on_the_few_token_path(ops):
+    from micformer_amd._lib import MicfError
+    C, heads, dims = 384, 24, (2, 4, 4, 4)
+    T = 128
+    P = make_params(C, 4 * C, "self_attn", 5)
+    g = {"x": rnd((T, C), 1), "kvsrc": None, "P": P, "attn": "self_attn", "s1": None, "s2": None,
+         "next_ln": (1 + rnd((C,), 2, 0.1), rnd((C,), 3, 0.1), None)}
+    with pytest.raises(MicfError):
+        ops.block_fwd([g], dims, C, heads, 1e-5, (C // heads) ** -0.5)

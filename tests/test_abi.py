@@ -127,3 +127,29 @@ def test_round2_entry_points_validate_arguments_without_gpu():
     assert L.micf_offset_sample_bwd(*nul, 1, 128, 512, 512, 64, C.c_float(1e-5), None, 0, None) == EUNSUP
     assert L.micf_offset_sample_bwd(*nul, 1, 128, 512, 512, 48, C.c_float(1e-5), None, 0, None) == EINVAL    # (in range: NULL tensors)
     assert L.micf_adam_step(None, None, None, None, 8, None, C.c_float(0.9), C.c_float(0.999), C.c_float(1e-8), C.c_float(1.0), None, None) == EINVAL
+
+
+def _struct_fields(header_text, name):
+    """Pointer field names of `typedef struct NAME { ... } NAME;` in declaration order (comments stripped)."""
+    import re
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), header_text, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        # "const float *a, *b" / "float* y" / "const void *wq, *wkv" / "void* h"
+        first, *rest = decl.split(",")
+        names.append(first.replace("*", " ").split()[-1])
+        names.extend(r.replace("*", " ").split()[-1] for r in rest)
+    return names
+
+
+def test_block_group_structs_mirror_the_header_field_by_field():
+    """The ctypes mirrors of micf_block_fwd_group / micf_block_bwd_group (arrays of them are what micf_block_fwd / _bwd receive)
+    list the header's fields in the header's order: a field added on one side only shifts every pointer behind it."""
+    from micformer_amd import _lib
+    text = open(HEADER).read()
+    assert tuple(_struct_fields(text, "micf_block_fwd_group")) == _lib.BlockFwdGroup.FIELDS
+    assert tuple(_struct_fields(text, "micf_block_bwd_group")) == _lib.BlockBwdGroup.FIELDS

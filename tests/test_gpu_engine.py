@@ -498,8 +498,9 @@ def test_step_many_on_the_fused_kernels_base_model():
 
 def test_benched_step_launch_list():
     """What the benched step (bf16, base widths, engine mode) does NOT launch any more (round 4): MDiceLoss's forward reduction
-    (folded into the head's logits store), the LayerNorm-1 backward of the cross pairs (prologue of the self pairs' block_bwd), and
-    -- with input_buffers() -- no staging copy; and what it launches instead."""
+    (folded into the head's logits store), the LayerNorm-1 backward of the cross pairs (prologue of the self pairs' block_bwd), their
+    LayerNorm-1 forward (round 6: epilogue of the self pairs' block_fwd), and -- with input_buffers() -- no staging copy; and what it
+    launches instead."""
     from micformer_amd import _lib, ops
     from micformer_amd.engine import TrainEngine
     import micformer_amd.models.MICFormer_self as MM
@@ -517,8 +518,9 @@ def test_benched_step_launch_list():
         assert float(loss) == float(loss)
         assert "micf_head_tail_fwd_loss_fused" in names and "micf_dice_bce_fwd" not in names and "micf_head_tail_fwd_fused" not in names
         assert "micf_dice_bce_bwd" in names                                   # (the loss backward stays its own launch)
-        # (the cross pairs of the tile-kernel stages: 20 of the 24; the 4 slots of the few-token C = 384 stage keep their launch)
-        assert prof["micf_layernorm_bwd_pair"]["calls"] == 4 and prof["micf_layernorm_fwd_pair"]["calls"] == 24
+        # (the cross pairs of the tile- / wave-kernel stages: 20 of the 24; the 4 slots of the few-token C = 384 stage keep their
+        #  launches.  Round 6: the forward LayerNorm 1 of those 20 is the epilogue of the self pairs' block_fwd)
+        assert prof["micf_layernorm_bwd_pair"]["calls"] == 4 and prof["micf_layernorm_fwd_pair"]["calls"] == 4
         assert prof["micf_block_bwd"]["calls"] == prof["micf_block_fwd"]["calls"] == 48 if "micf_block_bwd" in prof else True
         # a graph engine hands out the buffers its captured step reads; passing them back skips the staging copies
         g = TrainEngine(MM.Head(embed_dim=48, num_classes=8).cuda().train(), base_lr=1e-4, t_max=50, use_graph=True)

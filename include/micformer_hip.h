@@ -482,11 +482,11 @@ typedef struct micf_block_fwd_group {
   float* y;            /* [T, C] block output */
   /* saved for backward / the deferred weight gradients, natural token order.  INFERENCE FORM (round 5): ALL of xn, q, kv, o, x1,
    * xn2, h, g, stats, kvs16, flow, xs32 NULL in every group -> the launch writes y only (not for the few-token decomposition at
-   * C = 384: MICF_EUNSUPPORTED there); any other mix of NULL and non-NULL among q .. stats is MICF_EINVAL: */
+   * C = 384 with head_dim 16: MICF_EUNSUPPORTED there); any other mix of NULL and non-NULL among q .. stats is MICF_EINVAL: */
   float *xn, *q, *kv, *o, *x1, *xn2; /* LN1(x) [T,C] (may be NULL: not written); q [T,C]; k|v [T,2C]; attention out [T,C]; x + s1*attn [T,C]; LN2(x1) [T,C] */
   void* h;             /* fc1 pre-activation [T, hidden]: float for MICF_DTYPE_F32, bf16 (uint16_t, round-to-nearest-even)
                           for MICF_DTYPE_BF16 -- only micf_block_bwd reads it (GELU'), so the bf16 mode stores it at half width.
-                          May be NULL on the tile-per-workgroup kernels (C <= 192): not written (8 of the 36 bytes a bf16 block
+                          May be NULL on the tile-per-workgroup kernels (micf_block_fuses_sampler != 0): not written (8 of the 36 bytes a bf16 block
                           writes per element of T*C); micf_block_bwd then rebuilds it from xn2 with one more GEMM phase */
   float* g;            /* GELU(h) [T, hidden] (operand of the fc2 weight gradient) */
   float* stats;        /* [4, T]: mean1, rstd1, mean2, rstd2 */
@@ -512,11 +512,11 @@ typedef struct micf_block_fwd_group {
 } micf_block_fwd_group;
 int micf_block_fuses_sampler(int C, int heads);
 /* STORAGE of the saved tensors.  micf_block_saves_bf16(C, heads, dtype) != 0 (MICF_DTYPE_BF16 on the tile-per-workgroup kernels,
- * C <= 192): xn, q, kv, o, xn2, g (forward) and dq, dkv, dh, dx1 (backward) are bfloat16 arrays of the documented shapes (the
+ * C <= 192, and C = 384 with head_dim 32 since round 6): xn, q, kv, o, xn2, g (forward) and dq, dkv, dh, dx1 (backward) are bfloat16 arrays of the documented shapes (the
  * struct fields keep their float* type for the fp32 case), and kvs16 / dy16 receive bf16 copies of a cross block's K/V source and
  * of dy, so that every operand pair of the five nn.Linear weight gradients of a block is stored as bf16
  * (micf_wgrad_item.operand_dtype = MICF_DTYPE_BF16).  x1, y, stats, dx, dxs, dx1_copy and the LayerNorm partials are always
- * fp32.  Otherwise (MICF_DTYPE_F32, or the few-token decomposition at C = 384) everything is fp32 except h. */
+ * fp32.  Otherwise (MICF_DTYPE_F32, or the few-token decomposition at C = 384 / head_dim 16) everything is fp32 except h. */
 int micf_block_saves_bf16(int C, int heads, int dtype);
 typedef struct micf_block_bwd_group {
   const float* dy;     /* [T, C] gradient w.r.t. the block output (also fc2's output gradient for the weight-gradient GEMM) */
@@ -553,7 +553,7 @@ typedef struct micf_block_bwd_group {
   float* pre_part;       /* out [tiles, 2C]: per-tile partial dgamma | dbeta of that LayerNorm (micf_layernorm_bwd_finish) */
 } micf_block_bwd_group;
 /* != 0: the caller should pass h == NULL in both groups structs (see there).  Only with the option "block_recompute_h" set
- * (micf_set_option) and only for the tile-per-workgroup kernels (everything but the few-token decomposition at C = 384): a memory
+ * (micf_set_option) and only for the tile-per-workgroup kernels (everything but the few-token decomposition at C = 384 / head_dim 16): a memory
  * switch (8 of the 34 saved bytes per element), not a speed one -- the extra GEMM phase of the backward costs more time than the
  * bytes save (LABNOTES.md, round 4). */
 int micf_block_recomputes_h(int C, int heads);

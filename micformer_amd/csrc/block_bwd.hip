@@ -265,6 +265,7 @@ template <int C, int HD, int TJ, int NW, bool BF16, bool RECOMP>
 __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) block_bwd_kernel(const BlkBwdArgs a) {
   constexpr int TM = 16 * TJ, VPL = (C + 63) / 64, NSL = C / 16, NTHR = 64 * NW, RPP = 4 * NW, NPASS = (TM + RPP - 1) / RPP;
   constexpr bool PARK = block_bwd_park_floats(TM, C, NTHR) != 0;
+  constexpr bool LATE = C >= 384;                       // (see the MLP backward: inputs requested in two waves)
   extern __shared__ __attribute__((aligned(1024))) float lds[];
   constexpr int C4 = C >> 2, S = C + 4, SU = block_u_cols(C, false, TM) + 4, Hd = 4 * C;
   float* ring = lds;
@@ -353,13 +354,15 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
     r_xn2.load(tok, tk0, reinterpret_cast<const char*>(g.xn2) + (int64_t)tk0 * C * ES, (uint32_t)C);
   } else {
 #pragma unroll
-    for (int ch = 0; ch < Hd / HC; ++ch)
+    for (int ch = 0; ch < (LATE ? 1 : Hd / HC); ++ch)
       r_h[ch].load(tok, tk0, h0 + ch * HC * (BF16 ? 2 : 4), (uint32_t)Hd);
   }
   r_ln2.load(tok, tk0, g.x1 + (int64_t)tk0 * C, g.stats + 2 * T + tk0, g.stats + 3 * T + tk0, g.ln2_g);
-  if (!g.dxs && !pre) r_ln1.load(tok, tk0, g.x + (int64_t)tk0 * C, g.stats + tk0, g.stats + T + tk0, g.ln1_g);
-  r_q.load(tok, tk0, q0, (uint32_t)C);
-  r_kv.load(tok, tk0, kv0, (uint32_t)(2 * C));
+  if constexpr (!LATE) {
+    if (!g.dxs && !pre) r_ln1.load(tok, tk0, g.x + (int64_t)tk0 * C, g.stats + tk0, g.stats + T + tk0, g.ln1_g);
+    r_q.load(tok, tk0, q0, (uint32_t)C);
+    r_kv.load(tok, tk0, kv0, (uint32_t)(2 * C));
+  }
   // (block_fused.h warm_weights: the XCD's weight set, in the order the phases below read it)
   uint32_t warm = 0;
   if constexpr (C >= 96) warm = warm_weights<C, NTHR, 4, 4, 1, 1, 2>(blockIdx.x, tid, w2t, w1t, wpt, wqt, wkvt);
@@ -374,7 +377,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
     lds_barrier();
     ln_bwd_tile<TJ, VPL, NW, C, true>(A2, A1, S, r_lc, tok, tk0, reinterpret_cast<char*>(g.dy16) + (int64_t)tk0 * C * 2, nullptr, U,
                                       g.pre_part + (int64_t)tile * 2 * C);
-    r_ln1.load(tok, tk0, g.x + (int64_t)tk0 * C, g.stats + tk0, g.stats + T + tk0, g.ln1_g);      // (a self block: see the entry point)
+    if constexpr (!LATE) r_ln1.load(tok, tk0, g.x + (int64_t)tk0 * C, g.stats + tk0, g.stats + T + tk0, g.ln1_g);      // (a self block: see the entry point)
   }
 
   // ---- MLP backward in hidden chunks: h chunk -> U;  U <- s2 (dy W2) GELU'(h) = dh (saved);  A2 (+)= dh W1
@@ -398,6 +401,9 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
       gemm_phase<TJ, NSL, 1, C, NW, BF16>(w1f + (int64_t)c0 * C, hc, XN2, nullptr, 0, nullptr, SXN2, U, SU, EpiBias{pb1 + c0});
     } else {
       r_h[ch].commit(U, SU);
+      if constexpr (LATE) {       // (the next chunk's rows are requested once this chunk's registers are free)
+        if (ch + 1 < Hd / HC) r_h[ch + 1].load(tok, tk0, h0 + (ch + 1) * HC * (BF16 ? 2 : 4), (uint32_t)Hd);
+      }
       lds_barrier();
     }
     gemm_phase<TJ, NSL, 1, C, NW, BF16>(w2t + (int64_t)c0 * C, hc, A1, nullptr, 0, nullptr, S, U, SU, EpiGeluGrad<BF16>{sc2});
@@ -416,6 +422,13 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
     else gemm_phase<TJ, NSL, HC / C, Hd, NW, BF16>(w1t + 16 * c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiAcc{});
   }
 
+  if constexpr (LATE) {
+    // C = 384: a lane's share of ALL the tile's inputs is ~180 registers; what the attention backward and LayerNorm 1 need is
+    // requested here instead of at the top and arrives under LayerNorm 2's backward and the proj product
+    if (!g.dxs) r_ln1.load(tok, tk0, g.x + (int64_t)tk0 * C, g.stats + tk0, g.stats + T + tk0, g.ln1_g);
+    r_q.load(tok, tk0, q0, (uint32_t)C);
+    r_kv.load(tok, tk0, kv0, (uint32_t)(2 * C));
+  }
   // ---- dx1 = dy + LN2'(A2) -> A1 + HBM; LN2 gain / bias partials
   ln_bwd_tile<TJ, VPL, NW, C, BF16>(A2, A1, S, r_ln2, tok, tk0, reinterpret_cast<char*>(g.dx1) + (int64_t)tk0 * C * ES,
                                     g.dx1_copy ? g.dx1_copy + (int64_t)tk0 * C : nullptr, U,
@@ -691,7 +704,7 @@ extern "C" int micf_block_bwd(const micf_block_bwd_group* groups, int ngroups, i
   }
 #define MICF_BB(C_, HD_, TJ_) if (C == C_ && hd == HD_ && tj == TJ_) return launch_bwd<C_, HD_, TJ_>(a, dtype, s)
   MICF_BB(48, 16, 2); MICF_BB(96, 16, 2); MICF_BB(192, 16, 1);
-  MICF_BB(96, 32, 1); MICF_BB(192, 32, 1);
+  MICF_BB(96, 32, 1); MICF_BB(192, 32, 1); MICF_BB(384, 32, 1);
 #undef MICF_BB
   return MICF_EUNSUPPORTED;
 }

@@ -351,7 +351,7 @@ constexpr int block_bwd_park_floats(int TM, int C, int nthr) { return C <= 48 ? 
 // share a CU's LDS (C <= 96), all 4C at C = 192 (one workgroup per CU either way: two GEMM phases and a GELU pass fewer per tile,
 // each a barrier-to-barrier round trip in a kernel that is bound by exactly those)
 // (fwd: the forward kernel's choice; the backward's LDS also holds the attention exchange and the parked LayerNorm inputs)
-constexpr int block_hidden_chunk(int C, bool fwd = false, int TM = 0) { return C >= 192 ? 4 * C : 2 * C; }
+constexpr int block_hidden_chunk(int C, bool fwd = false, int TM = 0) { return C == 192 ? 4 * C : 2 * C; }      // (C = 384: 4C columns do not fit LDS)
 // columns of the U tile: q | k | v (3C) or a hidden chunk, whichever is wider
 constexpr int block_u_cols(int C, bool fwd = false, int TM = 0) {
   return block_hidden_chunk(C, fwd, TM) > 3 * C ? block_hidden_chunk(C, fwd, TM) : 3 * C;
@@ -366,10 +366,10 @@ inline int block_waves(int C) { return C >= 192 ? 8 : 4; }
 // block_wide.hip: the few-token decomposition of the same two entry points (several launches, GEMMs split over features)
 int block_wide_tile_tokens(int C, int hd);
 // Storage of what the fused kernels save for the backward / leave for the weight gradients.  MICF_DTYPE_BF16 on the
-// tile-per-workgroup kernels (this file's users: C <= 192) stores every tensor that is only ever consumed as a matrix-core operand or
+// tile-per-workgroup kernels (this file's users: C <= 192, and C = 384 with head_dim 32) stores every tensor that is only ever consumed as a matrix-core operand or
 // by the attention backward as bf16 -- xn, q, kv, o, xn2, g (+ kvs16, a bf16 copy of a cross block's K/V source) in the forward,
 // dq, dkv, dh, dx1 (+ dy16, a bf16 copy of dy) in the backward; the residual stream (x1, y, dx, dxs, dx1_copy), the LayerNorm
-// statistics and partial sums stay fp32.  The few-token decomposition (block_wide.hip, C = 384) re-reads its own intermediates
+// statistics and partial sums stay fp32.  The few-token decomposition (block_wide.hip, C = 384 / head_dim 16) re-reads its own intermediates
 // between launches and keeps fp32 everywhere.
 inline bool block_saves_bf16(int C, int hd, int dtype) { return dtype == MICF_DTYPE_BF16 && !block_wide_tile_tokens(C, hd); }
 int block_fwd_wide(const micf_block_fwd_group* groups, int ngroups, int B, int D, int H, int W, int C, int heads, float eps, float scale,

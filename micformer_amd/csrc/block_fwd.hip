@@ -519,14 +519,15 @@ extern "C" int micf_block_tile_tokens(int B, int D, int H, int W, int C, int hea
   const int hd = C / heads;
   if (const int wt = block_wide_tile_tokens(C, hd)) return wt;      // few-token stages: block_wide.hip
   // The kernels are compiled per channel count (C fixes every loop bound and load offset): the shapes of MicFormer base
-  // (C = 48 / 96 / 192, head_dim 16) and large (C = 96 / 192, head_dim 32).  C = 384 takes the few-token decomposition
-  // above: a tile would stream the whole weight set of the block through one compute unit (7 MB at C = 384 for <= 1k tokens
+  // (C = 48 / 96 / 192, head_dim 16) and large (C = 96 / 192 / 384, head_dim 32).  C = 384 with head_dim 16 takes the few-token
+  // decomposition above: a tile would stream the whole weight set of the block through one compute unit (7 MB at C = 384 for 128 tokens
   // at the base model's 4^3 stage); block_wide.hip spreads every weight matrix over the chip instead.
   // token groups of 16 per workgroup (measured on MI355X, base shapes, batch 2): forward and backward tile independently
   int tj = 0;
   if (C == 48 && hd == 16) tj = 2;
   else if (C == 96 && hd == 16) tj = backward ? 2 : 1;
   else if ((C == 96 || C == 192) && (hd == 16 || hd == 32)) tj = 1;
+  else if (C == 384 && hd == 32) tj = 1;                   // (the large model's third stage; head_dim 16 went to block_wide.hip above)
   return 16 * tj;
 }
 
@@ -614,7 +615,7 @@ extern "C" int micf_block_fwd(const micf_block_fwd_group* groups, int ngroups, i
     return wave48::launch_fwd_wave48(a, s);
 #define MICF_BF(C_, HD_, TJ_) if (C == C_ && hd == HD_ && tj == TJ_) return launch_fwd<C_, HD_, TJ_>(a, dtype, s)
   MICF_BF(48, 16, 2); MICF_BF(96, 16, 1); MICF_BF(192, 16, 1);
-  MICF_BF(96, 32, 1); MICF_BF(192, 32, 1);
+  MICF_BF(96, 32, 1); MICF_BF(192, 32, 1); MICF_BF(384, 32, 1);
 #undef MICF_BF
   return MICF_EUNSUPPORTED;
 }

@@ -688,7 +688,10 @@ static int launch_bwd(const BwdArgs& a, bool any_self, hipStream_t s) {
 
 // tokens per tile of the few-token path for this shape (0 = not handled here)
 int block_wide_tile_tokens(int C, int hd) {
-  if (C == 384 && (hd == 16 || hd == 32)) return 16;
+  // head_dim 16 = the base model's 4^3 stage (64 tokens per sample: 8 tiles).  head_dim 32 at C = 384 is the large model's
+  // 10 x 10 x 8 stage -- 100 tiles per launch, enough for the tile-per-workgroup kernels (block_fwd.hip / block_bwd.hip), which
+  // keep a block's intermediates in LDS instead of passing them through HBM between nine launches
+  if (C == 384 && hd == 16) return 16;
   return 0;
 }
 

@@ -1001,7 +1001,7 @@ class CrossBlockFn(torch.autograd.Function):
 
 # ============================================================================= fused window-local blocks (block_fwd / block_bwd)
 def _fusable(dims, C, heads, window, P):
-    """Tokens per tile if the fused block kernels take this shape (even grid, 2x2x2 windows, head_dim 16 / 32, C <= 192), else 0."""
+    """Tokens per tile if the fused block kernels take this shape (even grid, 2x2x2 windows, head_dim 16 / 32, C <= 384), else 0."""
     if tuple(window) != (2, 2, 2) or not FUSE_BLOCKS:
         return 0
     return ops.block_tile_tokens(dims, C, heads, P["mlp.fc1.weight"].shape[0])

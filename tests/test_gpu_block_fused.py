@@ -94,7 +94,8 @@ CASES = [  # (B, D, H, W, C, heads)
     (2, 4, 4, 2, 192, 12),    # TM 16
     (1, 4, 2, 2, 192, 6),     # head_dim 32 at C 192
     (2, 4, 4, 4, 384, 24),    # few-token decomposition (block_wide.hip): the base model's 4^3 stage
-    (1, 2, 6, 2, 384, 12),    # ... head_dim 32, 3 windows: masked rows in the last 16-token tile
+    (1, 2, 6, 2, 384, 12),    # C 384 / head_dim 32 (round 6: tile kernels), 3 windows: masked rows in the last 16-token tile
+    (1, 10, 10, 8, 384, 12),  # ... the large model's third stage (config 4): 50 tiles per group
 ]
 
 
@@ -106,11 +107,12 @@ def test_fused_block_matches_per_op_path(ops, case, cross, ngroups, save_h, hook
     """save_h True: the default, the fc1 pre-activation is stored; False: the option "block_recompute_h" -- the tile kernels do not
     store it, the backward rebuilds it from xn2 (micf_block_recomputes_h; the few-token decomposition at C = 384 always stores)."""
     B, D, H, W, C, heads = case
+    wide = not ops.block_fuses_sampler(C, heads)       # the few-token decomposition (block_wide.hip): C = 384 with head_dim 16
     if not save_h:
-        if C == 384:
+        if wide:
             pytest.skip("the few-token decomposition stores h either way: covered by save_h True")
         hook("block_recompute_h", 1)
-    assert ops.block_recomputes_h(C, heads) == (C != 384 and not save_h)
+    assert ops.block_recomputes_h(C, heads) == (not wide and not save_h)
     dims = (B, D, H, W)
     T = B * D * H * W
     hidden = 4 * C
@@ -178,7 +180,7 @@ def test_unsupported_shapes_are_reported(ops):
     assert ops.block_tile_tokens((2, 32, 32, 32), 48, 3, 192) == 32
 
 
-@pytest.mark.parametrize("case", [(2, 4, 4, 4, 48, 3), (1, 4, 6, 4, 96, 6), (2, 4, 4, 2, 192, 12), (2, 4, 4, 4, 384, 24)])
+@pytest.mark.parametrize("case", [(2, 4, 4, 4, 48, 3), (1, 4, 6, 4, 96, 6), (2, 4, 4, 2, 192, 12), (2, 4, 4, 4, 384, 24), (1, 4, 6, 4, 384, 12)])
 def test_fused_block_bf16_mode_is_close(ops, case):
     """bf16 matrix-core operands (fp32 accumulate, fp32 everywhere else): 8-bit mantissas on the GEMM inputs only."""
     B, D, H, W, C, heads = case
@@ -206,8 +208,10 @@ def test_fused_block_bf16_mode_is_close(ops, case):
         check(f"bf16 bwd {k}", b[k], rb[k], 3e-2, errs)
     assert float((o["y"] - ref["y"]).abs().max()) > 0                      # it really is a different arithmetic
     assert not errs, "\n".join(errs)
-    # storage: the tile-per-workgroup kernels (C <= 192) leave what only matrix cores / the attention backward re-read as bf16
-    st16 = C <= 192
+    # storage: the tile-per-workgroup kernels (everything but C = 384 / head_dim 16) leave what only matrix cores / the attention
+    # backward re-read as bf16
+    st16 = bool(ops.block_fuses_sampler(C, heads))
+    assert st16 == (not (C == 384 and C // heads == 16))
     for k in ("xn", "q", "kv", "o", "xn2", "g"):
         assert (o[k].dtype == torch.bfloat16) == st16, k
     for k in ("dq", "dkv", "dh", "dx1"):
@@ -338,7 +342,8 @@ def test_persistent_probe_matches_the_launch(ops):
         ops.set_compute_dtype("fp32")
 
 
-@pytest.mark.parametrize("case", [(2, 4, 4, 4, 48, 3), (1, 2, 2, 2, 48, 3), (1, 4, 6, 4, 96, 6), (2, 4, 4, 2, 192, 12), (2, 8, 8, 8, 192, 12)])
+@pytest.mark.parametrize("case", [(2, 4, 4, 4, 48, 3), (1, 2, 2, 2, 48, 3), (1, 4, 6, 4, 96, 6), (2, 4, 4, 2, 192, 12), (2, 8, 8, 8, 192, 12),
+                                  (1, 4, 6, 4, 384, 12)])
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 @pytest.mark.parametrize("save", [True, False])
 def test_next_layernorm_as_the_forward_epilogue(ops, case, mode, save):

@@ -129,10 +129,11 @@ def test_fused_blocks_fp8_attention_survives_outliers(ops, case):
     assert bool(torch.isfinite(o["o"].float()).all()) and bool(torch.isfinite(o["y"]).all())
 
 
-@pytest.mark.parametrize("case", [(2, 4, 4, 4, 384, 24), (1, 2, 6, 2, 384, 12)])
+@pytest.mark.parametrize("case", [(2, 4, 4, 4, 384, 24), (1, 2, 6, 2, 384, 24)])
 @pytest.mark.parametrize("cross", [False, True])
 def test_few_token_blocks_fp8_attention_on_the_matrix_cores(ops, case, cross):
-    """block_wide.hip keeps q / k / v in fp32: the matrix-core attention equals the restatement on the kernel's own q, kv."""
+    """block_wide.hip (C = 384 with head_dim 16: the base model's 4^3 stage; head_dim 32 went to the tile kernels in round 6) keeps
+    q / k / v in fp32: the matrix-core attention equals the restatement on the kernel's own q, kv."""
     import test_gpu_block_fused as tb
     B, D, H, W, C, heads = case
     dims, T = (B, D, H, W), B * D * H * W
@@ -148,7 +149,8 @@ def test_few_token_blocks_fp8_attention_on_the_matrix_cores(ops, case, cross):
     assert bool(torch.isfinite(o["y"]).all())
 
 
-@pytest.mark.parametrize("case", [(2, 4, 4, 4, 48, 3), (1, 4, 6, 4, 96, 6), (1, 2, 6, 2, 96, 3), (2, 4, 4, 2, 192, 12), (1, 4, 2, 2, 192, 6)])
+@pytest.mark.parametrize("case", [(2, 4, 4, 4, 48, 3), (1, 4, 6, 4, 96, 6), (1, 2, 6, 2, 96, 3), (2, 4, 4, 2, 192, 12), (1, 4, 2, 2, 192, 6),
+                                  (1, 2, 6, 2, 384, 12), (1, 10, 10, 8, 384, 12)])      # (C = 384 / head_dim 32: the large model's third stage)
 @pytest.mark.parametrize("cross", [False, True])
 def test_tile_blocks_fp8_attention_on_the_matrix_cores(ops, case, cross):
     """The tile-per-workgroup kernels quantise the fp32 q / k / v they hold in LDS and leave bf16 copies behind: against the

@@ -266,6 +266,9 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
   constexpr int TM = 16 * TJ, VPL = (C + 63) / 64, NSL = C / 16, NTHR = 64 * NW, RPP = 4 * NW, NPASS = (TM + RPP - 1) / RPP;
   constexpr bool PARK = block_bwd_park_floats(TM, C, NTHR) != 0;
   constexpr bool LATE = C >= 384;                       // (see the MLP backward: inputs requested in two waves)
+  // C = 384: a K = 384 product as two k chunks of 12 slabs -- a wave's weight fragments of a unit are 24 registers instead of 48 (two
+  // units in flight) and the activation fragments 24 instead of 48
+  constexpr int NSLK = C >= 384 ? NSL / 2 : NSL, NKK = C >= 384 ? 2 : 1;
   extern __shared__ __attribute__((aligned(1024))) float lds[];
   constexpr int C4 = C >> 2, S = C + 4, SU = block_u_cols(C, false, TM) + 4, Hd = 4 * C;
   float* ring = lds;
@@ -398,7 +401,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
         }
         lds_barrier();
       }
-      gemm_phase<TJ, NSL, 1, C, NW, BF16>(w1f + (int64_t)c0 * C, hc, XN2, nullptr, 0, nullptr, SXN2, U, SU, EpiBias{pb1 + c0});
+      gemm_phase<TJ, NSLK, NKK, C, NW, BF16>(w1f + (int64_t)c0 * C, hc, XN2, nullptr, 0, nullptr, SXN2, U, SU, EpiBias{pb1 + c0});
     } else {
       r_h[ch].commit(U, SU);
       if constexpr (LATE) {       // (the next chunk's rows are requested once this chunk's registers are free)
@@ -406,7 +409,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
       }
       lds_barrier();
     }
-    gemm_phase<TJ, NSL, 1, C, NW, BF16>(w2t + (int64_t)c0 * C, hc, A1, nullptr, 0, nullptr, S, U, SU, EpiGeluGrad<BF16>{sc2});
+    gemm_phase<TJ, NSLK, NKK, C, NW, BF16>(w2t + (int64_t)c0 * C, hc, A1, nullptr, 0, nullptr, S, U, SU, EpiGeluGrad<BF16>{sc2});
     if (ch == 0) asm volatile("" :: "v"(warm));
 #pragma unroll 1
     for (int pass = 0; pass < NPASS; ++pass) {
@@ -418,8 +421,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
       for (int c4 = l16; c4 < X4; c4 += 16)
         st_h4_32<BF16>(dh0, rel * Hd + c0 + 4 * c4, *reinterpret_cast<const float4*>(U + row * SU + 4 * c4));
     }
-    if (ch == 0) gemm_phase<TJ, NSL, HC / C, Hd, NW, BF16>(w1t + 16 * c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiStore{});
-    else gemm_phase<TJ, NSL, HC / C, Hd, NW, BF16>(w1t + 16 * c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiAcc{});
+    if (ch == 0) gemm_phase<TJ, NSLK, NKK * HC / C, Hd, NW, BF16>(w1t + 16 * c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiStore{});
+    else gemm_phase<TJ, NSLK, NKK * HC / C, Hd, NW, BF16>(w1t + 16 * c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiAcc{});
   }
 
   if constexpr (LATE) {
@@ -435,7 +438,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
                                     g.ln2_part ? g.ln2_part + (int64_t)tile * 2 * C : nullptr);
 
   // ---- do = s1 dx1 Wp -> A2;  q | k | v rows -> U
-  gemm_phase<TJ, NSL, 1, C, NW, BF16>(wpt, C, A1, nullptr, 0, nullptr, S, A2, S, EpiStoreScale{sc1});
+  gemm_phase<TJ, NSLK, NKK, C, NW, BF16>(wpt, C, A1, nullptr, 0, nullptr, S, A2, S, EpiStoreScale{sc1});
   r_q.commit(U, SU);
   r_kv.commit(U + C, SU);
   if (PARK && !g.dxs) r_ln1.park(stash);
@@ -587,12 +590,12 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
   if (!g.dxs) {
     // ---- self: dxn = dq Wq + dkv Wkv -> A2;  dx = dx1 + LN1'(dxn) -> HBM; LN1 partials
     if (PARK) r_ln1.unpark(stash, g.ln1_g);
-    gemm_phase<TJ, NSL, 1, C, NW, BF16>(wqt, C, U, nullptr, 0, nullptr, SU, A2, S, EpiStore{});
-    gemm_phase<TJ, NSL, 2, 2 * C, NW, BF16>(wkvt, C, U + C, nullptr, 0, nullptr, SU, A2, S, EpiAcc{});
+    gemm_phase<TJ, NSLK, NKK, C, NW, BF16>(wqt, C, U, nullptr, 0, nullptr, SU, A2, S, EpiStore{});
+    gemm_phase<TJ, NSLK, 2 * NKK, 2 * C, NW, BF16>(wkvt, C, U + C, nullptr, 0, nullptr, SU, A2, S, EpiAcc{});
     ln_bwd_tile<TJ, VPL, NW, C>(A2, A1, S, r_ln1, tok, tk0, dx0, nullptr, U, g.ln1_part ? g.ln1_part + (int64_t)tile * 2 * C : nullptr);
   } else {
     // ---- cross: the q path's pre-LayerNorm gradient and the sampled K/V source's gradient leave separately
-    gemm_phase<TJ, NSL, 1, C, NW, BF16>(wqt, C, U, nullptr, 0, nullptr, SU, A2, S, EpiStore{});
+    gemm_phase<TJ, NSLK, NKK, C, NW, BF16>(wqt, C, U, nullptr, 0, nullptr, SU, A2, S, EpiStore{});
 #pragma unroll 1
     for (int pass = 0; pass < NPASS; ++pass) {
       const int row = pass * RPP + wave * 4 + rg;
@@ -603,7 +606,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : (C <= 48 ? 3 : 2)) bloc
         st4g(at32(dx0, ((uint32_t)(tk - tk0) * C + 4 * c4) * 4u), *reinterpret_cast<const float4*>(A2 + row * S + 4 * c4));
     }
     lds_barrier();
-    gemm_phase<TJ, NSL, 2, 2 * C, NW, BF16>(wkvt, C, U + C, nullptr, 0, nullptr, SU, A2, S, EpiStore{});
+    gemm_phase<TJ, NSLK, 2 * NKK, 2 * C, NW, BF16>(wkvt, C, U + C, nullptr, 0, nullptr, SU, A2, S, EpiStore{});
 #pragma unroll 1
     for (int pass = 0; pass < NPASS; ++pass) {
       const int row = pass * RPP + wave * 4 + rg;

@@ -35,6 +35,7 @@ struct BlkFwdArgs {
 template <int C, int HD, int TJ, int NW, bool BF16, bool SAMP>
 __device__ __forceinline__ void block_fwd_tile(const BlkFwdArgs& a, const unsigned bid) {     // bid: the workgroup's index in the launch
   constexpr int TM = 16 * TJ, VPL = (C + 63) / 64, NSL = C / 16, NTHR = 64 * NW, RPP = 4 * NW, NPASS = (TM + RPP - 1) / RPP;
+  constexpr int NSLK = C >= 384 ? NSL / 2 : NSL, NKK = C >= 384 ? 2 : 1;     // (C = 384: a K = 384 product as two k chunks, see block_bwd.hip)
   extern __shared__ __attribute__((aligned(1024))) float lds[];
   constexpr int C4 = C >> 2, S = C + 4, SU = block_u_cols(C, true, TM) + 4, Hd = 4 * C;
   float* A1 = lds;
@@ -219,7 +220,7 @@ __device__ __forceinline__ void block_fwd_tile(const BlkFwdArgs& a, const unsign
   // ---- q | k | v (+ bias) -> U, then out to HBM
   if (!(a.debug & 4)) {
     // q | k | v in ONE phase (two weight segments; the biases bq | bkv are contiguous in PV)
-    gemm_phase<TJ, NSL, 1, C, NW, BF16>(wq, C, A1, wkv, 2 * C, cross ? A2 : A1, S, U, SU, EpiBias{p_bq});
+    gemm_phase<TJ, NSLK, NKK, C, NW, BF16>(wq, C, A1, wkv, 2 * C, cross ? A2 : A1, S, U, SU, EpiBias{p_bq});
     asm volatile("" :: "v"(warm));                        // (the warm-up's loads have returned: in order, in front of this phase's)
     if (g.nln_g && tid < 2 * C4) *reinterpret_cast<float4*>(PV + 4 * tid) = nl4;   // (p_ln1g | p_ln1b: read again in the last pass only)
   }
@@ -316,7 +317,7 @@ __device__ __forceinline__ void block_fwd_tile(const BlkFwdArgs& a, const unsign
   lds_barrier();
 
   // ---- proj (+ bp) -> A2; x1 = x + s1 * proj -> A2 + HBM; LayerNorm 2 of the same registers -> A1 (xn2) + HBM
-  if (!(a.debug & 4)) gemm_phase<TJ, NSL, 1, C, NW, BF16>(wp, C, A1, nullptr, 0, nullptr, S, A2, S, EpiBias{p_bp});
+  if (!(a.debug & 4)) gemm_phase<TJ, NSLK, NKK, C, NW, BF16>(wp, C, A1, nullptr, 0, nullptr, S, A2, S, EpiBias{p_bp});
   {
     float4 v[NPASS][VPL];
 #pragma unroll
@@ -376,7 +377,7 @@ __device__ __forceinline__ void block_fwd_tile(const BlkFwdArgs& a, const unsign
   constexpr int HC = block_hidden_chunk(C, true, TM);
   for (int c0 = 0; c0 < Hd; c0 += HC) {
     constexpr int hc = HC;
-    if (!(a.debug & 4)) gemm_phase<TJ, NSL, 1, C, NW, BF16>(w1 + (int64_t)c0 * C, hc, A1, nullptr, 0, nullptr, S, U, SU, EpiBias{p_b1 + c0});
+    if (!(a.debug & 4)) gemm_phase<TJ, NSLK, NKK, C, NW, BF16>(w1 + (int64_t)c0 * C, hc, A1, nullptr, 0, nullptr, S, U, SU, EpiBias{p_b1 + c0});
     const int X4 = hc >> 2;
 #pragma unroll 1
     for (int pass = 0; pass < NPASS; ++pass) {
@@ -395,7 +396,7 @@ __device__ __forceinline__ void block_fwd_tile(const BlkFwdArgs& a, const unsign
       }
     }
     lds_barrier();
-    if (!(a.debug & 4)) gemm_phase<TJ, NSL, HC / C, Hd, NW, BF16>(w2 + 16 * c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiAccScale{sc2});
+    if (!(a.debug & 4)) gemm_phase<TJ, NSLK, NKK * HC / C, Hd, NW, BF16>(w2 + 16 * c0, C, U, nullptr, 0, nullptr, SU, A2, S, EpiAccScale{sc2});
   }
 
   // ---- y = x1 + s2 * (fc2 + b2); optional epilogue: the NEXT block's LayerNorm of the row (micf_block_fwd_group.nln_g) while the

@@ -171,6 +171,12 @@ int micf_head_tail_pack(const float* wb, const float* bf, const float* b_out, vo
                         int P, micf_stream_t stream);
 int micf_head_tail_fwd_fused(const float* x, const void* pack_fwd, float* y, int B, int Dc, int Hc, int Wc, int Ci, int Co,
                              int P, micf_stream_t stream);
+/* ... as the predictor of sliding-window inference (utils.py:226-234; the patch-matrix form is micf_head_tail_col2im_sw): x holds n
+ * windows' coarse features [n*Dc*Hc*Wc, Ci]; window i's logits are ADDED into the fp32 volume accumulator out [VB, Co, VD, VH, VW]
+ * at coords[4 i ..] = int32 {volume sample, z0, y0, x0} (device memory) and count [VB, VD, VH, VW] += 1 there (fp32 atomics:
+ * windows of a batch overlap).  The caller guarantees every window lies inside the volume. */
+int micf_head_tail_fwd_fused_sw(const float* x, const void* pack_fwd, float* out, float* count, const int32_t* coords, int n, int Dc,
+                                int Hc, int Wc, int Ci, int Co, int P, int VB, int VD, int VH, int VW, micf_stream_t stream);
 /* ... with MDiceLoss's forward (dice.py:130-166) in the logits store: every lane folds the terms of the logits it writes (target:
  * one-hot float planes [B, 8, 4Dc, 4Hc, 4Wc], or target_is_label != 0 the uint8 class map [B, 4Dc, 4Hc, 4Wc]) into
  * part [micf_head_tail_loss_parts(...)][32] floats; a one-workgroup finishing launch of the same call writes sums [8][4] (double:

@@ -54,6 +54,7 @@ SIGNATURES = {
     "micf_head_tail_pack_bytes": "ii",
     "micf_head_tail_pack": "pppppiiip",
     "micf_head_tail_fwd_fused": "pppiiiiiiip",
+    "micf_head_tail_fwd_fused_sw": "pppppiiiiiiiiiiip",
     "micf_head_tail_loss_parts": "iiii",
     "micf_head_tail_fwd_loss_fused": "ppppipppiiiiiiip",
     "micf_head_tail_bwd_data_fused": "pppiiiiiiip",

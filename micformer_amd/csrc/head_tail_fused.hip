@@ -189,13 +189,18 @@ __device__ __forceinline__ void fwd_step(FwdState<CI>& st) {
 
 // LOSS: 0 = logits only; 1 = + partial loss sums against one-hot float planes [B, 8, Df, Hf, Wf]; 2 = against the uint8 class map
 // [B, Df, Hf, Wf].  part: [workgroups][8 classes][4] floats {sum p t, sum p^2, sum t^2, sum bce} (summed by dice_bce_finish_kernel).
+// LOSS == 3: SLIDING-WINDOW form (utils.py:226-234) -- batch entry b is WINDOW b of a volume: its logits are ADDED into the fp32
+// volume accumulator y [VB, 8, VD, VH, VW] at the window's origin target[4 b ..] = int32 {volume sample, z0, y0, x0} (device
+// memory: a captured predictor graph is replayed with new coordinates) and part = the visit counts [VB, VD, VH, VW] are bumped
+// (windows of one batch overlap: fp32 atomics, as micf_head_tail_col2im_sw).
 template <int CI, int LOSS>
 __global__ void __launch_bounds__(256, (CI <= 96 ? 2 : 1)) tail_fwd_fused_kernel(const float* __restrict__ x, const uint16_t* __restrict__ wpf,
                                                              float* __restrict__ y, int B, int Dc, int Hc, int Wc,
-                                                             const void* __restrict__ target, float* __restrict__ part) {
+                                                             const void* __restrict__ target, float* __restrict__ part,
+                                                             int VD, int VH, int VW) {
   constexpr int KS = CI / 32, RS = CI + kXPad, V4 = CI / 4, ROWS = 3 * 6 * 18;
   extern __shared__ __attribute__((aligned(16))) uint16_t Xs[];       // [3][6][18][RS]
-  __shared__ float loss_red[LOSS != 0 ? 4 : 1][8][4];
+  __shared__ float loss_red[(LOSS == 1 || LOSS == 2) ? 4 : 1][8][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lr = lane >> 4;
   // XCD-aware order: workgroups go to the 8 XCDs round-robin by id; each XCD gets a CONTIGUOUS eighth of the tiles, so the halo
   // rows neighbouring tiles share are fetched into that XCD's L2 once (round-robin order: every XCD fetched its own copy, 3-5x the bytes)
@@ -271,7 +276,7 @@ __global__ void __launch_bounds__(256, (CI <= 96 ? 2 : 1)) tail_fwd_fused_kernel
       // (loss: the 8 target quads of this rd are requested together, then consumed store by store)
       float4 tq[LOSS == 1 ? 2 : 1][LOSS == 1 ? 4 : 1];
       unsigned lq[LOSS == 2 ? 2 : 1][LOSS == 2 ? 4 : 1];          // (class map: the 4 label bytes, expanded where they are used)
-      if constexpr (LOSS != 0) {
+      if constexpr (LOSS == 1 || LOSS == 2) {
 #pragma unroll
         for (int rhi = 0; rhi < 2; ++rhi)
 #pragma unroll
@@ -291,9 +296,27 @@ __global__ void __launch_bounds__(256, (CI <= 96 ? 2 : 1)) tail_fwd_fused_kernel
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
           const int ud = 4 * qd + st.rd_of[rdi], uh = 4 * (qh0 + m) + st.rh_of[rhi];
-          float* dst = y + ((((int64_t)b * 8 + o) * Df + ud) * Hf + uh) * Wf + 4 * (qw0 + li);
           const f32x4 v = st.acc[rdi][rhi][m];
-          *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+          if constexpr (LOSS == 3) {
+            // The 16 lanes of a class hold 4 consecutive voxels each = one 64-voxel row of the window.  Lane L takes voxel L of the
+            // row, class after class, so that every atomic instruction covers 256 consecutive bytes (a lane adding its own four
+            // values touched a quarter of every 16 bytes, four instructions per line: 1.67 ms per 7 windows instead of 0.5 + 0.5 of
+            // the patch-matrix form).  x0 is any voxel: scalar atomics.
+            const int32_t* sw = static_cast<const int32_t*>(target) + 4 * b;        // (workgroup-uniform: scalar loads)
+            const int64_t row = ((int64_t)(sw[1] + ud) * VH + (sw[2] + uh)) * VW + sw[3] + 4 * qw0 + lane;
+            const int64_t vplane = (int64_t)VD * VH * VW;
+            const int kk = lane & 3;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const int src = (lane >> 2) + 16 * c;
+              const float a0 = __shfl(v[0], src, 64), a1 = __shfl(v[1], src, 64), a2 = __shfl(v[2], src, 64), a3 = __shfl(v[3], src, 64);
+              atomicAdd(y + ((int64_t)sw[0] * 8 + 4 * og + c) * vplane + row, kk == 0 ? a0 : (kk == 1 ? a1 : (kk == 2 ? a2 : a3)));
+            }
+            if (og == 0) atomicAdd(part + (int64_t)sw[0] * vplane + row, 1.f);
+          } else {
+            float* dst = y + ((((int64_t)b * 8 + o) * Df + ud) * Hf + uh) * Wf + 4 * (qw0 + li);
+            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+          }
           if constexpr (LOSS == 1) {
             const float4 t = tq[rhi][m];
             la.term(v[0], t.x); la.term(v[1], t.y); la.term(v[2], t.z); la.term(v[3], t.w);
@@ -304,7 +327,7 @@ __global__ void __launch_bounds__(256, (CI <= 96 ? 2 : 1)) tail_fwd_fused_kernel
           }
         }
     }
-    if constexpr (LOSS != 0) {
+    if constexpr (LOSS == 1 || LOSS == 2) {
       // the 16 lanes of a row group hold the same class: fold them, then lane li == 0 of each group leaves the wave's share in LDS
 #pragma unroll
       for (int dlt = 1; dlt < 16; dlt <<= 1) {
@@ -317,7 +340,7 @@ __global__ void __launch_bounds__(256, (CI <= 96 ? 2 : 1)) tail_fwd_fused_kernel
       }
     }
   }
-  if constexpr (LOSS != 0) {
+  if constexpr (LOSS == 1 || LOSS == 2) {
     __syncthreads();
     if (tid < 32) part[(int64_t)blockIdx.x * 32 + tid] = (loss_red[0][tid >> 2][tid & 3] + loss_red[1][tid >> 2][tid & 3]) +
                                                         (loss_red[2][tid >> 2][tid & 3] + loss_red[3][tid >> 2][tid & 3]);
@@ -667,10 +690,11 @@ extern "C" int micf_head_tail_pack(const float* wb, const float* bf, const float
 
 template <int CI, int LOSS>
 static void launch_tail_fwd(dim3 grid, hipStream_t s, const float* x, const uint16_t* wp, float* y, int B, int Dc, int Hc, int Wc,
-                            const void* target, float* part) {
+                            const void* target, float* part, int VD = 0, int VH = 0, int VW = 0) {
   static std::once_flag once;
   std::call_once(once, [] { allow_lds(&tail_fwd_fused_kernel<CI, LOSS>, 324 * (CI + kXPad) * 2); });
-  hipLaunchKernelGGL((tail_fwd_fused_kernel<CI, LOSS>), grid, dim3(256), 324 * (CI + kXPad) * 2, s, x, wp, y, B, Dc, Hc, Wc, target, part);
+  hipLaunchKernelGGL((tail_fwd_fused_kernel<CI, LOSS>), grid, dim3(256), 324 * (CI + kXPad) * 2, s, x, wp, y, B, Dc, Hc, Wc, target, part,
+                     VD, VH, VW);
 }
 
 static int tail_fwd_any(const float* x, const void* pack_fwd, float* y, const void* target, int target_is_label, float* part, int B,
@@ -691,6 +715,20 @@ static int tail_fwd_any(const float* x, const void* pack_fwd, float* y, const vo
 extern "C" int micf_head_tail_fwd_fused(const float* x, const void* pack_fwd, float* y, int B, int Dc, int Hc, int Wc, int Ci,
                                         int Co, int P, micf_stream_t stream) {
   return tail_fwd_any(x, pack_fwd, y, nullptr, 0, nullptr, B, Dc, Hc, Wc, Ci, Co, P, (hipStream_t)stream);
+}
+
+extern "C" int micf_head_tail_fwd_fused_sw(const float* x, const void* pack_fwd, float* out, float* count, const int32_t* coords,
+                                           int n, int Dc, int Hc, int Wc, int Ci, int Co, int P, int VB, int VD, int VH, int VW,
+                                           micf_stream_t stream) {
+  if (!x || !pack_fwd || !out || !count || !coords || n <= 0 || Dc <= 0 || Hc <= 0 || Wc <= 0 || VB <= 0) return MICF_EINVAL;
+  if (Dc * P > VD || Hc * P > VH || Wc * P > VW) return MICF_EINVAL;      // (the window must fit the volume; origins are the caller's)
+  if (!fused_ok(Dc, Hc, Wc, Ci, Co, P) || !aligned16(x) || !aligned16(pack_fwd)) return MICF_EUNSUPPORTED;
+  const dim3 grid((unsigned)((int64_t)n * Dc * (Hc / 4) * (Wc / 16)));
+  const uint16_t* wp = reinterpret_cast<const uint16_t*>(pack_fwd);
+  hipStream_t s = (hipStream_t)stream;
+  if (Ci == 96) launch_tail_fwd<96, 3>(grid, s, x, wp, out, n, Dc, Hc, Wc, coords, count, VD, VH, VW);
+  else launch_tail_fwd<192, 3>(grid, s, x, wp, out, n, Dc, Hc, Wc, coords, count, VD, VH, VW);
+  MICF_RETURN_LAUNCH();
 }
 
 extern "C" int64_t micf_head_tail_loss_parts(int B, int Dc, int Hc, int Wc) {

@@ -763,5 +763,11 @@ class Head(nn.Module):
         wb, bf = ops.head_tail_compose(rp.weight, rp.bias, oc.weight, wut)
         coarse = self.swin.coarse_features(x, 0, x, 1)
         n, Dc, Hc, Wc, Ci = coarse.shape
+        if ops.head_tail_fused_supported((n, Dc, Hc, Wc), Ci, oc.out_channels, P):
+            # bf16 mode: the patch-matrix-free head (head_tail_fused.hip) with the accumulate in its logits store -- no
+            # [windows * tokens, 6^3 * classes] intermediate (1.6 GB per 7 windows of 128^3)
+            pack_fwd, _ = ops.head_tail_pack(wb, bf, oc.bias, P)
+            ops.head_tail_fwd_fused_sw(coarse.reshape(-1, Ci), pack_fwd, out, count, coords, (n, Dc, Hc, Wc), oc.out_channels, P)
+            return
         t = ops.linear_fwd(coarse.reshape(-1, Ci), wb, bf)
         ops.head_tail_col2im_sw(t, oc.bias, out, count, coords, (n, Dc, Hc, Wc), P)

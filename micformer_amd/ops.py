@@ -676,6 +676,18 @@ def head_tail_fwd_fused(x, pack_fwd, dims, Co, P):
     return y
 
 
+def head_tail_fwd_fused_sw(x, pack_fwd, out, count, coords, dims, Co, P):
+    """Sliding-window form of head_tail_fwd_fused: x holds len(coords) windows' coarse features; their logits are ADDED into the volume
+    accumulator `out` (VB, Co, VD, VH, VW) at coords[i] = (sample, z0, y0, x0) (int32 device tensor [n, 4]) and `count` (VB, VD, VH, VW)
+    += 1 there -- no prediction tensor, no patch matrix."""
+    n, Dc, Hc, Wc = dims
+    Ci = x.shape[-1]
+    VB, _, VD, VH, VW = out.shape
+    assert coords.dtype == torch.int32 and coords.is_contiguous() and tuple(coords.shape) == (n, 4)
+    call("micf_head_tail_fwd_fused_sw", f32(x), ptr(pack_fwd), f32(out), f32(count), ptr(coords), n, Dc, Hc, Wc, Ci, Co, P, VB, VD, VH, VW,
+         cost=_cost(2 * x.shape[0] * (P + 2) ** 3 * Co * Ci, x, tag=f"{x.shape[0]}x{Ci}"))
+
+
 def head_tail_fwd_loss_fused(x, pack_fwd, dims, Co, P, target):
     """head_tail_fwd_fused + MDiceLoss's forward sums in the logits store (micf_head_tail_fwd_loss_fused).  target: float one-hot
     planes (B, Co, 4Dc, 4Hc, 4Wc) or the uint8 class map (B, 4Dc, 4Hc, 4Wc).  -> (logits, loss [1], sums [Co*4] float64)."""

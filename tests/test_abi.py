@@ -37,7 +37,7 @@ _UNTABLED = ("micf_abi_version", "micf_strerror", "micf_set_option", "micf_get_o
 
 def test_header_declares_expected_entry_points():
     d = parse_header()
-    assert len(d) == 100, sorted(d)         # (96 product entry points + micf_set_option / micf_get_option (test hooks) + the round-5 measurement probe + the MFMA hazard probe)
+    assert len(d) == 101, sorted(d)         # (97 product entry points + micf_set_option / micf_get_option (test hooks) + the round-5 measurement probe + the MFMA hazard probe)
     assert all(sig.endswith("p") for n, sig in d.items()
                if n not in ("micf_abi_version", "micf_strerror", "micf_set_option", "micf_get_option", "micf_linear_bwd_weight_workspace",
                             "micf_linear_bwd_weight_grouped_workspace", "micf_conv3_bwd_data_workspace",

@@ -146,3 +146,46 @@ def test_config5_whole_heart_volume_full_size():
         y16 = I.sliding_window_inference(x, 128, 7, gp, overlap=0.5, autocast=True)
         err = float((y16 - y7).abs().max())
         assert 0 < err <= 2e-2, err
+
+
+@pytest.mark.gpu
+def test_fused_head_sliding_window_form():
+    """micf_head_tail_fwd_fused_sw (bf16 mode: the patch-matrix-free head with the accumulate / count epilogue in its logits store)
+    against micf_head_tail_col2im_sw on the same windows -- overlapping windows, an origin off every alignment, two volume samples:
+    identical visit counts, sums within the two bf16 paths' distance; a voxel only ONE window covers holds bit for bit what
+    micf_head_tail_fwd_fused writes for that window."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from micformer_amd import ops
+    n, Dc, Hc, Wc, Ci, Cm, Co, P = 3, 4, 8, 16, 96, 24, 8, 4
+    g = torch.Generator().manual_seed(5)
+    rn = lambda *s, k=1.0: (torch.randn(*s, generator=g) * k).cuda()
+    x = rn(n * Dc * Hc * Wc, Ci)
+    w_up, b_up, w_out, b_out = rn(Ci, Cm, P, P, P, k=0.1), rn(Cm), rn(Co, Cm, 3, 3, 3, k=0.1), rn(Co)
+    dims = (n, Dc, Hc, Wc)
+    VB, VD, VH, VW = 2, 24, 40, 72
+    coords = torch.tensor([[0, 0, 0, 0], [0, 8, 4, 3], [1, 8, 8, 8]], dtype=torch.int32).cuda()
+    ops.set_compute_dtype("bf16")
+    try:
+        assert ops.head_tail_fused_supported(dims, Ci, Co, P)
+        wut = ops.head_tail_transposed_up(w_up)
+        wb, bf = ops.head_tail_compose(w_up, b_up, w_out, wut)
+        out_a, cnt_a = torch.zeros(VB, Co, VD, VH, VW, device="cuda"), torch.zeros(VB, VD, VH, VW, device="cuda")
+        ops.head_tail_col2im_sw(ops.linear_fwd(x, wb, bf), b_out, out_a, cnt_a, coords, dims, P)
+        pack = ops.head_tail_pack(wb, bf, b_out, P)[0]
+        out_b, cnt_b = torch.zeros_like(out_a), torch.zeros_like(cnt_a)
+        ops.head_tail_fwd_fused_sw(x, pack, out_b, cnt_b, coords, dims, Co, P)
+        y = ops.head_tail_fwd_fused(x, pack, dims, Co, P)
+    finally:
+        ops.set_compute_dtype("fp32")
+    assert torch.equal(cnt_a, cnt_b) and float(cnt_b.max()) == 2.0 and float(cnt_b.sum()) == n * 64 * Dc * Hc * Wc
+    scale = float(out_a.abs().max())
+    assert 0 < float((out_a - out_b).abs().max()) <= 1.5e-2 * scale
+    assert torch.equal(out_b[1, :, 8:24, 8:40, 8:72], y[2])                  # window 2 is alone in its volume sample
+    assert float(out_b[1].abs().sum()) == float(y[2].abs().sum())             # ... and nothing else was written there
+    both = (cnt_b[0] == 2)
+    assert bool(both.any())                                                  # (windows 0 and 1 do overlap)
+    v0 = torch.zeros(Co, VD, VH, VW, device="cuda")
+    v0[:, 0:16, 0:32, 0:64] += y[0]
+    v0[:, 8:24, 4:36, 3:67] += y[1]
+    assert float((out_b[0] - v0).abs().max()) <= 1e-6 * scale                  # (fp32 adds in either order)

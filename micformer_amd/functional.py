@@ -1115,7 +1115,9 @@ class SelfPairFn(torch.autograd.Function):
         # sliding-window inference): nothing is saved, the launch writes y only.
         save = bool(grad_mode) and any(ctx.needs_input_grad)
         nl, CTX.next_ln, CTX.next_ln_out = CTX.next_ln, None, None
-        if nl is not None and FUSE_NEXT_LN and GROUP_CROSS_HEADS and ops.block_fuses_sampler(C, heads):
+        # (a record left behind by a forward that raised belongs to another stage: only one that fits this launch is used)
+        if nl is not None and FUSE_NEXT_LN and GROUP_CROSS_HEADS and ops.block_fuses_sampler(C, heads) \
+                and all(t.numel() == C and t.device == x.device for pr in nl for t in pr):
             svs, hid = _self_fwd_fused(xs, Ps, scales, dims, heads, eps, save=save, next_ln=nl)
             CTX.next_ln_out = ((svs[0]["y"].data_ptr(), svs[1]["y"].data_ptr()), [svs[0]["nln"], svs[1]["nln"]], hid)
         else:

@@ -24,6 +24,12 @@ from test_gpu_block_fused import make_params, rnd
 pytestmark = pytest.mark.gpu
 
 C, HEADS, EPS = 48, 3, 1e-5
+# The "fraction of elements further than 1e-4 of the scale" gates are calibrated on C = 48 (sums over 48 ... 192 operands).  A value is
+# off by more than fp32 noise only downstream of a bf16 rounding TIE that fell the other way in the kernel's summation order; both the
+# chance of a tie (fp32 noise of a sum ~ sqrt(K) ulp against a fixed bf16 step) and the number of values downstream of one (K operands
+# per output) grow with the channel count, so the C = 384 run multiplies the FRACTION gates by 8 (the "more than one bf16 step" fractions too).  The rel-L2 (2e-3) and
+# worst-element gates are unchanged: measured there 1.4-1.7e-3 / 3e-3.
+FRAC_RELAX = 1.0
 
 
 @pytest.fixture()
@@ -60,9 +66,10 @@ class Report:
         scale = max(float(want.abs().max()), 1e-30)
         d = (got - want).abs()
         if frac_gate is not None and frac_gate > 0:
-            # (ONE rounding tie that fell the other way moves up to a window's worth of downstream values -- 8 tokens x 48 channels:
-            # on a launch of a few dozen tokens that alone is a third of a tensor)
-            frac_gate = max(frac_gate, 400.0 / got.numel())
+            # (ONE rounding tie that fell the other way moves up to a window's worth of downstream values -- 8 token rows of the
+            # tensor: on a launch of a few dozen tokens that alone is a third of it, whatever the channel count)
+            rows = got.numel() // got.shape[-1] if got.dim() > 1 else got.numel()
+            frac_gate = min(1.0, max(frac_gate * FRAC_RELAX, 8.4 * max(1.0, FRAC_RELAX / 4) / rows))
         l2_ = float(d.norm() / want.norm().clamp_min(1e-300))
         mx = float(d.max()) / scale
         frac_far = float((d > far * scale).double().mean())
@@ -238,3 +245,19 @@ def test_cross_launch_with_fused_sampling_against_the_oracle(ops, hook, dims, wa
         rep.add(n + "h", o["h"].float(), aux["h"].reshape(T, 4 * C), 3e-3, bf16=True)
         rep.add(n + "y", o["y"], y.reshape(T, C), 3e-2)        # (measured 7e-3: the gathered rows carry fp32 interpolation noise into more ties)
     rep.done(f"{'wave-private' if wave else 'tile'} kernels, cross pair with the sampling fused in, dims {dims}")
+
+
+@pytest.mark.parametrize("kind", ["self", "cross"])
+def test_c384_head_dim_32_tile_kernels_against_the_oracle(ops, hook, monkeypatch, kind):
+    """The instantiation round 6 added for the large model's third stage (C = 384, head_dim 32: `block_fwd_kernel<384, 32, 1, 8>`,
+    `block_bwd_kernel<384, 32, 1, 8>` -- hidden chunk 2C, K = 384 products in two k chunks, inputs requested in two waves): the same
+    forward and backward gates as the benched kernels, on a grid with a half-empty last tile (3 windows) and on 12 full tiles."""
+    import sys
+    mod = sys.modules[__name__]
+    monkeypatch.setattr(mod, "C", 384)
+    monkeypatch.setattr(mod, "HEADS", 12)
+    monkeypatch.setattr(mod, "FRAC_RELAX", 8.0)
+    assert ops.block_fuses_sampler(384, 12) and ops.block_tile_tokens((1, 4, 6, 8), 384, 12, 1536) == 16
+    for dims in ((1, 2, 6, 2), (1, 4, 6, 8)):
+        test_block_launches_against_the_oracle.__wrapped__(ops, hook, dims, kind, False) if hasattr(test_block_launches_against_the_oracle, "__wrapped__") \
+            else test_block_launches_against_the_oracle(ops, hook, dims, kind, False)

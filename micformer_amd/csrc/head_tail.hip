@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(256) tail_compose_kernel(const float* __restri
       for (int pw = max(fw - 2, 0); pw <= min(fw, P - 1); ++pw) {
         const int t = ((pd + 2 - fd) * 3 + (ph + 2 - fh)) * 3 + (pw + 2 - fw);
         const int p = (pd * P + ph) * P + pw;
-#pragma unroll 8
+#pragma unroll 24       // (every (p, t) pair was three dependent L2 round trips at 8 loads in flight: the whole c loop of the reference's Cm = 24 at once)
         for (int c = 0; c < Cm; ++c) {
           // (w_up_t = w_up as [Cm * P^3][Ci]: the lanes of a wave are consecutive k -> one coalesced load instead of 64 lines)
           const float wu = (k < Ci) ? (w_up_t ? w_up_t[((int64_t)c * P3 + p) * Ci + k] : w_up[((int64_t)k * Cm + c) * P3 + p]) : b_up[c];

@@ -617,9 +617,30 @@ def _grad_buf(target, like):
     return target if target is not None else torch.zeros_like(like)
 
 
+_GRAD_LAYOUTS = {}
+
+
 def _grad_bufs(P, tg):
     """{name: gradient buffer} for a block's parameters: the engine's views of the flat gradient buffer where present; otherwise ONE
     zero-filled allocation carved into 16-byte-aligned views (engine-less loop: one fill per block instead of one per parameter)."""
+    if all(t is None for t in tg):
+        # the stock loop's case, 96 times per backward: the layout of a block's gradients is cached by its parameter shapes and
+        # every view is ONE as_strided call (a slice + a view per parameter were 1.6k tensor-method calls per step)
+        vals = list(P.values())
+        key = tuple(v.shape for v in vals)
+        lay = _GRAD_LAYOUTS.get(key)
+        if lay is None:
+            views, total = [], 0
+            for v in vals:
+                st, acc = [], 1
+                for n in reversed(v.shape):
+                    st.append(acc)
+                    acc *= n
+                views.append((tuple(v.shape), tuple(reversed(st)), total))
+                total += (v.numel() + 3) // 4 * 4
+            lay = _GRAD_LAYOUTS[key] = (total, views)
+        flat = torch.zeros(lay[0], dtype=vals[0].dtype, device=vals[0].device)
+        return {k: flat.as_strided(sh, st, o) for k, (sh, st, o) in zip(P, lay[1])}
     missing = [(k, v) for (k, v), t in zip(P.items(), tg) if t is None]
     out = {k: t for (k, _), t in zip(P.items(), tg) if t is not None}
     if missing:

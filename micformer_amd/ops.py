@@ -197,7 +197,7 @@ _SCRATCH_RETIRED = []
 def scratch(device, nfloats):
     """Per-device fp32 scratch reused by every launch that wants a workspace (stream-ordered, so sharing is safe on one stream).
     It only grows; under HIP-graph capture it is allocated during the eager warm-up steps."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)      # one scratch per stream: launches on different
+    key = (device, _lib.stream())                                      # one scratch per stream: launches on different
     buf = _SCRATCH.get(key)                                            # streams may run concurrently
     if buf is None or buf.numel() < nfloats:
         if buf is not None:
